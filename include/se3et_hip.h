@@ -1,0 +1,65 @@
+/* se3et_hip.h -- C ABI of libse3et_hip.so: MI355X (gfx950) kernels for the SE3ET hot path.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes, no framework types; pointers are DEVICE pointers unless the name ends in _host;
+ *   - tensors are dense, row-major, float32 / int64 / int32 / uint8 as typed below;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); launches are asynchronous;
+ *   - outputs and workspaces are caller-allocated; the library never allocates or frees device memory
+ *     and keeps no global state (one stream per process is enough, several are safe);
+ *   - return value: 0 = ok, otherwise an SE3_ERR_* code (the Python host raises RuntimeError, mirroring the
+ *     TORCH_CHECK failures of the reference extension, geotransformer/extensions/common/torch_helper.h:6-35).
+ *
+ * Each entry point names the reference interface it replaces (paths under the reference repository).
+ */
+#ifndef SE3ET_HIP_H_
+#define SE3ET_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SE3_OK 0
+#define SE3_ERR_INVALID_ARG 1
+#define SE3_ERR_UNSUPPORTED 2
+#define SE3_ERR_LAUNCH 3
+#define SE3_ERR_WORKSPACE 4
+
+#define SE3_MAX_BATCH 16          /* clouds per stacked call (the reference always stacks 2: ref, src) */
+#define SE3_MAX_NEIGHBOR_LIMIT 64 /* radius search keeps at most this many nearest neighbours */
+
+/* Library / build identification. */
+const char* se3_version(void);
+const char* se3_last_error(void);   /* text of the last failure on the calling thread */
+
+/* ---- A2: stack-mode radius neighbour search ---------------------------------------------------------------
+ * Replaces geotransformer.ext.radius_neighbors (geotransformer/extensions/pybind.cpp:6-11,
+ * cpu/radius_neighbors/radius_neighbors.cpp:5-76, radius_neighbors_cpu.cpp:3-91) together with the column
+ * truncation of modules/ops/radius_search.py:25-27.
+ * For every query the support points of the same batch element with d2 = (dx*dx + dy*dy) + dz*dz < radius*radius
+ * (float32, unfused) are ranked by (d2, index); the first `limit` indices go to neighbors[q * limit + j], unused
+ * entries are filled with ns (the total support count).  *max_count receives max over queries of the number of
+ * in-radius points (the caller keeps min(limit, *max_count) columns).  q_lengths_host / s_lengths_host are HOST
+ * arrays of `batch` int64.  limit <= SE3_MAX_NEIGHBOR_LIMIT. */
+int se3_radius_neighbors(const float* q_points, int64_t nq, const float* s_points, int64_t ns,
+                         const int64_t* q_lengths_host, const int64_t* s_lengths_host, int batch, float radius,
+                         int limit, int64_t* neighbors, int32_t* max_count, void* stream);
+
+/* ---- A1: stack-mode grid subsampling ----------------------------------------------------------------------
+ * Replaces geotransformer.ext.grid_subsampling (pybind.cpp:13-17, cpu/grid_subsampling/grid_subsampling.cpp:5-83,
+ * grid_subsampling_cpu.cpp:3-109, grid_subsampling_cpu.h:24-74).  Per batch element: voxel hash, per voxel the
+ * input point closest to the voxel mean (float32 accumulation in input order, first minimum), emitted in the
+ * iteration order of libstdc++'s std::unordered_map<size_t,...> (emulated on the device).
+ * s_points / s_normals must hold n rows; s_lengths (DEVICE, `batch` int64) receives the per-cloud counts and the
+ * sampled clouds are written back to back.  `normals` may be NULL (then s_normals is not written). */
+size_t se3_grid_subsample_workspace_bytes(int64_t n, int batch);
+int se3_grid_subsample(const float* points, const float* normals, int64_t n, const int64_t* lengths_host, int batch,
+                       float voxel_size, float* s_points, float* s_normals, int64_t* s_lengths, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SE3ET_HIP_H_ */

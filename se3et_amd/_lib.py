@@ -1,0 +1,41 @@
+"""ctypes binding of libse3et_hip.so (C ABI declared in include/se3et_hip.h).
+
+There is deliberately no fallback: if the library is missing or a kernel reports an error the caller gets a
+RuntimeError -- the product never computes a hot-path op on the CPU or through eager PyTorch."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libse3et_hip.so')
+
+_vp, _i64, _i32, _f32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/se3et_hip.h declares (tests/test_cabi.py checks)
+SIGNATURES = {
+    'se3_version': (ctypes.c_char_p, []),
+    'se3_last_error': (ctypes.c_char_p, []),
+    'se3_radius_neighbors': (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _f32, _i32, _vp, _vp, _vp]),
+    'se3_grid_subsample_workspace_bytes': (_sz, [_i64, _i32]),
+    'se3_grid_subsample': (_i32, [_vp, _vp, _i64, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('%s is missing: build it with `python -m se3et_amd.build` '
+                               '(there is no CPU / eager fallback for the SE3ET hot path)' % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError('%s failed (code %d): %s' % (what, status, lib().se3_last_error().decode()))

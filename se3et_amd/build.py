@@ -1,0 +1,47 @@
+"""Builds se3et_amd/csrc/*.hip into the in-tree shared library libse3et_hip.so for gfx950 (hipcc cross-compiles
+without a GPU).  `python -m se3et_amd.build [--force]`."""
+import glob
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
+LIB = os.path.join(CSRC, 'libse3et_hip.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function']
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+    hdrs = sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [
+        os.path.join(os.path.dirname(os.path.dirname(CSRC)), 'include', 'se3et_hip.h')]
+    objs, jobs = [], []
+    os.makedirs(os.path.join(CSRC, 'build'), exist_ok=True)
+    for s in srcs:
+        o = os.path.join(CSRC, 'build', os.path.basename(s)[:-4] + '.o')
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            jobs.append([HIPCC] + FLAGS + ['-c', s, '-o', o])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _stale(LIB, objs):
+        run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

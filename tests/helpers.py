@@ -1,0 +1,66 @@
+"""Comparison helpers shared by the parity tests."""
+import numpy as np
+import torch
+
+
+def sq_dist_f32(q, s):
+    """(dx*dx + dy*dy) + dz*dz in float32, the metric both the reference and the kernels use."""
+    d = q[:, None, :] - s[None, :, :]
+    return (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+
+
+def assert_neighbors_equal(a, b, q_points, s_points, context=''):
+    """Bit-exact equality of two (Nq, W) neighbour tables, except that entries of one row whose float32 squared
+    distances are exactly equal may be permuted (the reference orders ties with an unstable std::sort)."""
+    a, b = torch.as_tensor(a).long().cpu(), torch.as_tensor(b).long().cpu()
+    assert a.shape == b.shape, '%s shape %s vs %s' % (context, tuple(a.shape), tuple(b.shape))
+    if torch.equal(a, b):
+        return 0
+    q, s = torch.as_tensor(q_points).float().cpu(), torch.as_tensor(s_points).float().cpu()
+    ns = s.shape[0]
+    s_pad = torch.cat((s, torch.full((1, 3), float('inf'))), 0)
+    rows = torch.nonzero((a != b).any(1))[:, 0]
+    for r in rows.tolist():
+        da = ((q[r] - s_pad[a[r]]) ** 2)
+        db = ((q[r] - s_pad[b[r]]) ** 2)
+        da = (da[:, 0] + da[:, 1]) + da[:, 2]
+        db = (db[:, 0] + db[:, 1]) + db[:, 2]
+        da[a[r] == ns] = float('inf')
+        db[b[r] == ns] = float('inf')
+        assert torch.equal(da, db), '%s row %d: distance sequences differ' % (context, r)
+        # a permutation inside a tie group can also push a tied entry across the last column, so compare as
+        # multisets except for the final tie group
+        last = da[-1]
+        keep = da != last
+        assert sorted(a[r][keep].tolist()) == sorted(b[r][keep].tolist()), '%s row %d: index sets differ' % (context, r)
+    return len(rows)
+
+
+def rel_err(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def assert_close(a, b, rel=1e-4, context=''):
+    """max |a-b| <= rel * max |b|  (the 1e-4 relative tolerance BASELINE.json states for fp32 outputs)."""
+    e = rel_err(a, b)
+    assert e <= rel, '%s: relative error %.3e > %.1e' % (context, e, rel)
+
+
+def assert_pairs_equal_up_to_ties(idx_a, scores_a, idx_b, scores_b, rtol=1e-5, context=''):
+    """Top-k (ref, src) correspondence lists: same pairs in the same order, except among near-equal scores."""
+    pa = list(zip(*[torch.as_tensor(x).cpu().tolist() for x in idx_a]))
+    pb = list(zip(*[torch.as_tensor(x).cpu().tolist() for x in idx_b]))
+    sa, sb = torch.as_tensor(scores_a).double().cpu(), torch.as_tensor(scores_b).double().cpu()
+    assert len(pa) == len(pb), context
+    np.testing.assert_allclose(sa.numpy(), sb.numpy(), rtol=1e-3, atol=0, err_msg=context)
+    i = 0
+    n = len(pa)
+    boundary = float(sb[-1])
+    while i < n:
+        j = i + 1
+        while j < n and abs(float(sb[j]) - float(sb[i])) <= rtol * abs(float(sb[i])):
+            j += 1
+        if abs(float(sb[i]) - boundary) > rtol * abs(boundary):       # the last tie group may be cut differently
+            assert sorted(pa[i:j]) == sorted(pb[i:j]), '%s: pairs %d..%d differ' % (context, i, j)
+        i = j
