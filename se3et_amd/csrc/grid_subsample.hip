@@ -148,8 +148,8 @@ __global__ __launch_bounds__(kBlock) void bounds_kernel(const float* __restrict_
     const float inv = (float)(1.0 / (double)voxel);
     for (int d = 0; d < 3; d++) m.org[d] = __fmul_rn(floorf(__fmul_rn(rmn[d], inv)), voxel);
     m.voxel = voxel;
-    m.nx = n > 0 ? (unsigned long long)__fadd_rn(floorf(__fdiv_rn(__fsub_rn(rmx[0], m.org[0]), voxel)), 1.0f) : 1ull;
-    m.ny = n > 0 ? (unsigned long long)__fadd_rn(floorf(__fdiv_rn(__fsub_rn(rmx[1], m.org[1]), voxel)), 1.0f) : 1ull;
+    m.nx = n > 0 ? (unsigned long long)__fadd_rn(floorf(se3_exact_div(__fsub_rn(rmx[0], m.org[0]), voxel)), 1.0f) : 1ull;
+    m.ny = n > 0 ? (unsigned long long)__fadd_rn(floorf(se3_exact_div(__fsub_rn(rmx[1], m.org[1]), voxel)), 1.0f) : 1ull;
     m.n_vox = 0;
     m.pad = 0;
     L.meta[b] = m;
@@ -162,9 +162,9 @@ __global__ void hash_kernel(const float* __restrict__ pts, BatchInfo bi, Layout 
   if (i >= bi.count[b]) return;
   const CloudMeta m = L.meta[b];
   const float* p = pts + 3 * (bi.start[b] + i);
-  const unsigned long long ix = (unsigned long long)floorf(__fdiv_rn(__fsub_rn(p[0], m.org[0]), m.voxel));
-  const unsigned long long iy = (unsigned long long)floorf(__fdiv_rn(__fsub_rn(p[1], m.org[1]), m.voxel));
-  const unsigned long long iz = (unsigned long long)floorf(__fdiv_rn(__fsub_rn(p[2], m.org[2]), m.voxel));
+  const unsigned long long ix = (unsigned long long)floorf(se3_exact_div(__fsub_rn(p[0], m.org[0]), m.voxel));
+  const unsigned long long iy = (unsigned long long)floorf(se3_exact_div(__fsub_rn(p[1], m.org[1]), m.voxel));
+  const unsigned long long iz = (unsigned long long)floorf(se3_exact_div(__fsub_rn(p[2], m.org[2]), m.voxel));
   const unsigned long long key = ix + m.nx * iy + m.nx * m.ny * iz;
   const unsigned long long mask = (unsigned long long)bi.cap[b] - 1ull;
   unsigned long long h = (key * 0x9E3779B97F4A7C15ull) >> 20 & mask;
@@ -254,7 +254,7 @@ __global__ void select_kernel(const float* __restrict__ pts, BatchInfo bi, Layou
   for (int i = 0; i < c; i++) {
     const float* p = P + 3 * (int64_t)mem[i];
     const float dx = __fsub_rn(p[0], ax), dy = __fsub_rn(p[1], ay), dz = __fsub_rn(p[2], az);
-    const float d = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    const float d = se3_exact_sqrt(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
     if (i == 0 || d < bestd) { bestd = d; best = mem[i]; }
   }
   L.sel[p0 + v] = best;
