@@ -1,0 +1,72 @@
+"""On-GPU counterpart of the reference's stack-mode collate (geotransformer/utils/data.py:13-97,159-209).
+
+The reference runs grid subsampling and the 3S-2 radius searches on the CPU inside DataLoader workers; here the
+whole pyramid is built on the GPU in the main process right after the raw pair was uploaded.  List structure,
+voxel/radius doubling, the 2000-point cap of the coarsest stage and the column truncation are reproduced exactly
+(pinned by tests/golden/precompute_c1.npz)."""
+import torch
+
+from . import ops as _ops
+from .modules.ops import grid_subsample
+
+
+def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, neighbor_limits):
+    """points (N, 3) float32 GPU tensor (ref rows then src rows), lengths (2,) int64 (host).  Returns the dict of lists
+    {'points', 'lengths', 'neighbors', 'subsampling', 'upsampling'}; `lengths` entries are host int64 tensors."""
+    assert num_stages == len(neighbor_limits)
+    if not points.is_cuda:
+        raise RuntimeError('precompute_data_stack_mode: points must be on the GPU')
+    lengths = torch.as_tensor(lengths, dtype=torch.int64).cpu()
+    points_list, lengths_list = [], []
+    for i in range(num_stages):
+        if i > 0:
+            points, lengths, _ = grid_subsample(points, lengths, None, voxel_size)
+        if i == num_stages - 1:
+            n0, n1 = int(lengths[0]), int(lengths[1])
+            if n0 > 2000:
+                points = torch.cat((points[:2000], points[n0:]), 0)
+                n0 = 2000
+            if n1 > 2000:
+                points = points[:n0 + 2000]
+                n1 = 2000
+            lengths = torch.tensor([n0, n1], dtype=torch.int64)
+        points_list.append(points.contiguous())
+        lengths_list.append(lengths)
+        voxel_size *= 2
+
+    # all 3S-2 searches are launched back to back; their column counts are fetched with ONE synchronisation
+    jobs = []
+    for i in range(num_stages):
+        cur, cl = points_list[i], lengths_list[i]
+        jobs.append(('neighbors', _ops.radius_neighbors(cur, cur, cl, cl, radius, neighbor_limits[i])))
+        if i < num_stages - 1:
+            sub, sl = points_list[i + 1], lengths_list[i + 1]
+            jobs.append(('subsampling', _ops.radius_neighbors(sub, cur, sl, cl, radius, neighbor_limits[i])))
+            jobs.append(('upsampling', _ops.radius_neighbors(cur, sub, cl, sl, radius * 2, neighbor_limits[i + 1])))
+        radius *= 2
+    counts = torch.stack([mc for _, (_, mc) in jobs]).cpu().tolist()
+    out = {'points': points_list, 'lengths': lengths_list, 'neighbors': [], 'subsampling': [], 'upsampling': []}
+    for (kind, (full, _)), c in zip(jobs, counts):
+        width = min(full.shape[1], int(c))
+        out[kind].append(full if width == full.shape[1] else full[:, :width].contiguous())
+    return out
+
+
+def registration_collate_fn_stack_mode(data_dicts, num_stages, voxel_size, search_radius, neighbor_limits,
+                                       precompute_data=True, device='cuda'):
+    """One-pair version of the reference collate: uploads the pair and builds the pyramid on the device."""
+    if len(data_dicts) != 1:
+        raise NotImplementedError('one registration pair per call (as the reference, batch_size = 1)')
+    d = data_dicts[0]
+    as_t = lambda a: torch.as_tensor(a)
+    ref, src = as_t(d['ref_points']).float(), as_t(d['src_points']).float()
+    out = {k: as_t(v).to(device) for k, v in d.items() if k not in ('ref_points', 'src_points', 'ref_feats', 'src_feats')}
+    out['features'] = torch.cat((as_t(d['ref_feats']).float(), as_t(d['src_feats']).float()), 0).to(device)
+    points = torch.cat((ref, src), 0).to(device)
+    lengths = torch.tensor([ref.shape[0], src.shape[0]], dtype=torch.int64)
+    if precompute_data:
+        out.update(precompute_data_stack_mode(points, lengths, num_stages, voxel_size, search_radius, neighbor_limits))
+    else:
+        out['points'], out['lengths'] = points, lengths
+    out['batch_size'] = 1
+    return out

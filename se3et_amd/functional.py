@@ -1,0 +1,156 @@
+"""Functional layer between the module mirror (se3et_amd.modules) and the C ABI (se3et_amd.ops).
+
+Every op of the SE3ET hot path enters here.  Ops listed in HIP_OPS run as hand-written gfx950
+kernels from libse3et_hip.so; dense Linear layers are plain library GEMMs (rocBLAS/hipBLASLt through torch, as the
+design allows for non-fused GEMMs).  Nothing here runs on the CPU: tensors must live on the GPU and a missing
+library raises (se3et_amd._lib).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import ops as _ops
+
+HIP_OPS = set()          # filled below as kernels are bound; tests assert the hot ops are in here
+
+
+def _hip(fn):
+    HIP_OPS.add(fn.__name__)
+    return fn
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# dense layers (library GEMMs) and small glue
+# ---------------------------------------------------------------------------------------------------------------------
+def linear(x, weight, bias=None, relu=False):
+    y = F.linear(x, weight, bias)
+    return F.relu_(y) if relu else y
+
+
+def add_layer_norm(hidden, residual, weight, bias, eps=1e-5):
+    """LayerNorm(hidden + residual) over the last dim (residual may broadcast over a leading anchor dim)."""
+    return _ops.add_layer_norm(hidden, residual, weight, bias, eps)
+
+
+def anchor_max(x, dim=1):
+    return x.amax(dim)
+
+
+def gather_rows_padded(x, idx):
+    """x[idx] where idx == x.shape[0] addresses an implicit all-zero row."""
+    return _ops.gather_rows_padded(x, idx)
+
+
+def neighbor_max_pool(x, idx):
+    """max over the neighbour rows of x (P_s, ...) for each query (idx (P_q, NN), padding row = zeros)."""
+    return _ops.neighbor_max_pool(x, idx)
+
+
+def apply_transform(points, T):
+    return points @ T[..., :3, :3].transpose(-1, -2) + T[..., None, :3, 3]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# B: backbone ops
+# ---------------------------------------------------------------------------------------------------------------------
+def group_norm_rows(x, weight, bias, groups, eps, leaky_slope=None, residual=None):
+    """GroupNorm over (rows x channels-in-group) for x (..., C) with ALL leading dims pooled into the statistics
+    (GroupNormEPN / kpconv GroupNorm), optionally `+ residual` then LeakyReLU, fused in one pass."""
+    return _ops.group_norm_rows(x, weight, bias, groups, eps, leaky_slope, residual)
+
+
+def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, sigma):
+    return _ops.kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, sigma)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# G: geometric structure embedding
+# ---------------------------------------------------------------------------------------------------------------------
+def sinusoidal_embedding(idx, div_term):
+    om = idx.reshape(-1, 1, 1) * div_term.view(1, -1, 1)
+    return torch.cat((torch.sin(om), torch.cos(om)), 2).reshape(*idx.shape, 2 * div_term.numel())
+
+
+def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, k):
+    return _ops.geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, k)
+
+
+def equiv_embedding(points, wigner_d1):
+    return _ops.equiv_embedding(points, wigner_d1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# D: attention
+# ---------------------------------------------------------------------------------------------------------------------
+def rpe_attention(q, k, v, emb, w_p, eq_emb, w_eq, num_heads, return_scores=False):
+    """q ([A,] N, C), k/v ([A,] M, C) already projected; emb (N, M, C); eq_emb (A, N, M, 4) or None.
+    softmax_m((q.k + q.(W_p emb) + q.(W_eq eq_emb)) / sqrt(d)) v with the position terms folded onto the query side
+    (q.(W e + b) = (W^T q).e + q.b, and the q.b term is constant along m so it cancels in the softmax)."""
+    return _ops.rpe_attention(q, k, v, emb, w_p, eq_emb, w_eq, num_heads, return_scores)
+
+
+def cross_attention(q, k, v, num_heads):
+    """q (N, C), k (M, C), v (M, C) or (A, M, C) -> (N, C) or (A, N, C)."""
+    return _ops.cross_attention(q, k, v, num_heads)
+
+
+def cross_attention_eq(q, k, v, num_heads, mode, trace_idx):
+    """q (A, N, C), k/v (A, M, C).  Returns (hidden (A, N, C), weights): g/sum_e g (A, A) for 'a_soft', w (R,) for 'r_soft'."""
+    return _ops.cross_attention_eq(q, k, v, num_heads, mode, trace_idx)
+
+
+def rotation_weighted_permute(feats, w, trace_idx):
+    """sum_r w[r] feats[:, trace[r, a]] for feats (B, A, N, C): the 24-term sum collapsed onto an (A, A) matrix."""
+    A = trace_idx.shape[1]
+    mix = torch.zeros((A, A), dtype=feats.dtype, device=feats.device)
+    mix.index_put_((torch.arange(A, device=feats.device)[None].expand_as(trace_idx), trace_idx),
+                   w[:, None].expand(-1, A), accumulate=True)
+    return torch.einsum('ae,benc->banc', mix, feats)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# E: matching
+# ---------------------------------------------------------------------------------------------------------------------
+def superpoint_scores(ref_feats, src_feats, dual_normalization=True):
+    return _ops.superpoint_scores(ref_feats, src_feats, dual_normalization)
+
+
+def log_optimal_transport(scores, row_masks, col_masks, alpha, num_iterations, inf):
+    return _ops.log_optimal_transport(scores, row_masks, col_masks, alpha, num_iterations, inf)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# F1: registration (device-side; 3x3 SVD through the batched library solver)
+# ---------------------------------------------------------------------------------------------------------------------
+def _kabsch(H, sc, rc):
+    U, _, Vh = torch.linalg.svd(H)
+    V, Ut = Vh.transpose(-1, -2), U.transpose(-1, -2)
+    eye = torch.eye(3, device=H.device).expand(H.shape[0], 3, 3).clone()
+    eye[:, 2, 2] = torch.sign(torch.det(V @ Ut))
+    R = V @ eye @ Ut
+    t = rc - (R @ sc[:, :, None])[:, :, 0]
+    T = torch.eye(4, device=H.device).repeat(H.shape[0], 1, 1)
+    T[:, :3, :3], T[:, :3, 3] = R, t
+    return T
+
+
+def weighted_procrustes(src, ref, w, eps=1e-5):
+    """(N, 3) x2, (N,) -> (4, 4) (geotransformer/modules/registration/procrustes.py:6-73)."""
+    w = torch.where(w < 0, torch.zeros_like(w), w)
+    w = (w / (w.sum() + eps))[:, None]
+    sc, rc = (src * w).sum(0, keepdim=True), (ref * w).sum(0, keepdim=True)
+    H = (src - sc).t() @ (w * (ref - rc))
+    return _kabsch(H[None], sc, rc)[0]
+
+
+def segment_procrustes(src, ref, w, seg, num_segments, eps=1e-5):
+    """One weighted Procrustes per segment id (sorted `seg`), by segment reductions -> (num_segments, 4, 4)."""
+    w = torch.where(w < 0, torch.zeros_like(w), w)
+    wsum = torch.zeros(num_segments, device=w.device).index_add_(0, seg, w)
+    wn = (w / (wsum[seg] + eps))[:, None]
+    sc = torch.zeros(num_segments, 3, device=w.device).index_add_(0, seg, src * wn)
+    rc = torch.zeros(num_segments, 3, device=w.device).index_add_(0, seg, ref * wn)
+    outer = (src - sc[seg])[:, :, None] * (wn * (ref - rc[seg]))[:, None, :]
+    H = torch.zeros(num_segments, 3, 3, device=w.device).index_add_(0, seg, outer)
+    return _kabsch(H, sc, rc)

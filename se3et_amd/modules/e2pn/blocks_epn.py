@@ -1,0 +1,174 @@
+"""E2PN anchor-equivariant KPConv blocks on HIP kernels.
+
+Mirror of the SE3ET-relevant classes of geotransformer/modules/e2pn/blocks_epn.py (KPConvInterSO3 :18-552,
+UnaryBlockEPN :639-665, GroupNormEPN :684-701, KPConvInterSO3Block :703-743, SimpleBlockEPN :770-796,
+ResnetBottleneckBlockEPN :798-852, InvOutBlockEPN :854-926, LiftBlockEPN :993-1004): same constructor arguments,
+forward signatures and parameter / buffer names.  Only the configuration the SE3ET
+experiments use is implemented (kanchor 6, quotient 4, 15 kernel points, non-separable rotate-by-permute conv,
+linear influence, sum aggregation); anything else raises NotImplementedError.
+
+Layout: features are (P, A, C) float32, points of ref and src stacked; neighbour tables (P, NN) int64 padded
+with the support size.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from ... import functional as SF
+from ... import tables
+
+
+def _check_epn_config(config):
+    ok = (config.kanchor == 6 and config.quotient_factor == 4 and config.num_kernel_points == 15
+          and config.non_sep_conv and config.rot_by_permute and config.equiv_mode_kp
+          and config.fixed_kernel_points == 'center' and config.KP_influence == 'linear'
+          and config.aggregation_mode == 'sum' and not getattr(config, 'epn_kernel', False)
+          and not getattr(config, 'ignore_steer_constraint', False))
+    if not ok:
+        raise NotImplementedError('the HIP E2PN path implements the SE3ET configuration only '
+                                  '(kanchor=6, quotient_factor=4, 15 kernel points, non_sep_conv, rot_by_permute)')
+
+
+class KPConvInterSO3(nn.Module):
+    def __init__(self, kernel_size, kanchor, in_channels, out_channels, KP_extent, radius, KP_influence='linear',
+                 aggregation_mode='sum', deformable=False, modulated=False, epn_kernel=False, equiv_mode_kp=False,
+                 non_sep_conv=False, rot_by_permute=False, fixed_kernel_points='center', quotient_factor=1,
+                 ignore_steer_constraint=False, gather_by_idxing=False):
+        super().__init__()
+        if not (kernel_size == 15 and kanchor == 6 and quotient_factor == 4 and non_sep_conv and rot_by_permute
+                and equiv_mode_kp and fixed_kernel_points == 'center' and KP_influence == 'linear'
+                and aggregation_mode == 'sum' and not deformable and not epn_kernel and not ignore_steer_constraint):
+            raise NotImplementedError('KPConvInterSO3 (HIP): unsupported configuration')
+        self.K, self.kanchor, self.K_real = kernel_size, kanchor, tables.NUM_WEIGHT_SLOTS
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.radius, self.KP_extent = radius, KP_extent
+        as_param = lambda a: nn.Parameter(torch.from_numpy(a), requires_grad=False)
+        self.kernel_points = as_param(tables.kernel_points(radius))
+        self.quotient_anchors = as_param(tables.quotient_anchors())
+        self.anchors = as_param(tables.anchors())
+        self.weights = nn.Parameter(torch.zeros((self.K_real, kanchor, in_channels, out_channels)))
+        kidx = torch.from_numpy(tables.kernel_slot_table())                 # (K, R)
+        ridx = torch.from_numpy(tables.anchor_slot_table())                 # (A, R)
+        self.register_buffer('kidx_rot', kidx[:, None, :].expand(-1, kanchor, -1).contiguous())
+        self.register_buffer('ridx_rot', ridx[None].expand(self.K, -1, -1).contiguous())
+        nn.init.kaiming_uniform_(self.weights, a=math.sqrt(5))
+
+    def forward(self, q_pts, s_pts, neighb_inds, x):
+        return SF.kpconv_inter_so3(x, q_pts, s_pts, neighb_inds, self.kernel_points, self.weights,
+                                   self.kidx_rot[:, 0, :], self.ridx_rot[0], self.KP_extent)
+
+    def __repr__(self):
+        return 'KPConvInterSO3(radius: {:.2f}, extent: {:.2f}, in_feat: {:d}, out_feat: {:d})'.format(
+            self.radius, self.KP_extent, self.in_channels, self.out_channels)
+
+
+class GroupNormEPN(nn.Module):
+    """GroupNorm whose statistics span (channels of the group) x anchors x ALL stacked points."""
+
+    def __init__(self, num_groups, num_channels):
+        super().__init__()
+        self.num_groups, self.num_channels = num_groups, num_channels
+        self.norm = nn.GroupNorm(num_groups, num_channels)      # parameter container (names: norm.weight / norm.bias)
+
+    def forward(self, x, leaky_slope=None, residual=None):
+        return SF.group_norm_rows(x, self.norm.weight, self.norm.bias, self.num_groups, self.norm.eps, leaky_slope,
+                                  residual)
+
+
+class UnaryBlockEPN(nn.Module):
+    def __init__(self, in_dim, out_dim, group_norm, bn_momentum, no_relu=False):
+        super().__init__()
+        self.no_relu, self.in_dim, self.out_dim = no_relu, in_dim, out_dim
+        self.mlp = nn.Linear(in_dim, out_dim)
+        self.norm = GroupNormEPN(group_norm, out_dim)
+
+    def forward(self, x, batch=None, residual=None, final_slope=None):
+        """`residual`/`final_slope` fuse the bottleneck tail lrelu(norm(mlp(x)) + shortcut) into the norm kernel."""
+        x = SF.linear(x, self.mlp.weight, self.mlp.bias)
+        if residual is not None or final_slope is not None:
+            return self.norm(x, leaky_slope=final_slope, residual=residual)
+        return self.norm(x, leaky_slope=None if self.no_relu else 0.1)
+
+
+class LastUnaryBlockEPN(nn.Module):
+    def __init__(self, in_dim, out_dim, bias=True):
+        super().__init__()
+        self.mlp = nn.Linear(in_dim, out_dim, bias=bias)
+
+    def forward(self, x):
+        return SF.linear(x, self.mlp.weight, self.mlp.bias)
+
+
+class KPConvInterSO3Block(nn.Module):
+    def __init__(self, block_name, in_dim, out_dim, radius, sigma, group_norm, config):
+        super().__init__()
+        _check_epn_config(config)
+        self.block_name, self.in_dim, self.out_dim = block_name, in_dim, out_dim
+        self.conv = KPConvInterSO3(config.num_kernel_points, config.kanchor, in_dim, out_dim, sigma, radius,
+                                   config.KP_influence, config.aggregation_mode, epn_kernel=config.epn_kernel,
+                                   equiv_mode_kp=config.equiv_mode_kp, non_sep_conv=config.non_sep_conv,
+                                   rot_by_permute=config.rot_by_permute, fixed_kernel_points=config.fixed_kernel_points,
+                                   quotient_factor=config.quotient_factor,
+                                   ignore_steer_constraint=config.ignore_steer_constraint,
+                                   gather_by_idxing=config.gather_by_idxing)
+        self.norm = GroupNormEPN(group_norm, out_dim)
+
+    def forward(self, x, q_pts, s_pts, neighb_inds):
+        return self.norm(self.conv(q_pts, s_pts, neighb_inds, x), leaky_slope=0.1)
+
+
+class SimpleBlockEPN(nn.Module):
+    def __init__(self, block_name, in_dim, out_dim, radius, sigma, group_norm, config):
+        super().__init__()
+        self.block_name, self.in_dim, self.out_dim = block_name, in_dim, out_dim
+        self.interso3 = KPConvInterSO3Block(block_name, in_dim, out_dim, radius, sigma, group_norm, config)
+        self.norm = GroupNormEPN(group_norm, out_dim)
+
+    def forward(self, x, q_pts, s_pts, neighb_inds):
+        return self.norm(self.interso3(x, q_pts, s_pts, neighb_inds), leaky_slope=0.1)
+
+
+class ResnetBottleneckBlockEPN(nn.Module):
+    def __init__(self, block_name, in_dim, out_dim, radius, sigma, group_norm, config):
+        super().__init__()
+        self.block_name, self.in_dim, self.out_dim = block_name, in_dim, out_dim
+        bn = getattr(config, 'batch_norm_momentum', 0.99)
+        mid = out_dim // 4
+        self.unary1 = UnaryBlockEPN(in_dim, mid, group_norm, bn) if in_dim != mid else nn.Identity()
+        self.interso3 = KPConvInterSO3Block(block_name, mid, mid, radius, sigma, group_norm, config)
+        self.norm = GroupNormEPN(group_norm, mid)
+        self.unary2 = UnaryBlockEPN(mid, out_dim, group_norm, bn, no_relu=True)
+        self.skip_conv = UnaryBlockEPN(in_dim, out_dim, group_norm, bn, no_relu=True) if in_dim != out_dim else nn.Identity()
+
+    def forward(self, x, q_pts, s_pts, neighb_inds):
+        skip = x
+        x = self.unary1(x)
+        x = self.interso3(x, q_pts, s_pts, neighb_inds)
+        x = self.norm(x, leaky_slope=0.1)
+        if 'strided' in self.block_name:
+            skip = SF.neighbor_max_pool(skip, neighb_inds)
+        skip = self.skip_conv(skip)
+        return self.unary2(x, residual=skip, final_slope=0.1)       # lrelu(norm(mlp(x)) + shortcut)
+
+
+class InvOutBlockEPN(nn.Module):
+    """Equivariant -> invariant by max over the anchor axis (the attention-pooling variants are not used by SE3ET)."""
+
+    def __init__(self, block_name, in_dim, config):
+        super().__init__()
+        if config.att_pooling or config.att_permute:
+            raise NotImplementedError('InvOutBlockEPN (HIP): attention pooling is not part of the SE3ET hot path')
+        self.block_name, self.in_dim = block_name, in_dim
+
+    def forward(self, x, q_pts=None, s_pts=None, neighb_inds=None):
+        return SF.anchor_max(x)
+
+
+class LiftBlockEPN(nn.Module):
+    def __init__(self, block_name, in_dim, config):
+        super().__init__()
+        self.block_name, self.in_dim, self.kanchor = block_name, in_dim, config.kanchor
+
+    def forward(self, x):
+        return x.unsqueeze(1).expand(-1, self.kanchor, -1)

@@ -1,0 +1,42 @@
+"""Decoder helpers the SE3ET backbone takes from geotransformer.modules.kpconv
+(functional.py:6-22 nearest_upsample; modules.py:34-110 GroupNorm / UnaryBlock / LastUnaryBlock)."""
+import torch.nn as nn
+
+from ... import functional as SF
+
+
+def nearest_upsample(x, upsample_indices):
+    """Feature of the nearest coarse point (column 0 of the sorted neighbour table; padded index -> zeros)."""
+    return SF.gather_rows_padded(x, upsample_indices[:, 0])
+
+
+class GroupNorm(nn.Module):
+    def __init__(self, num_groups, num_channels):
+        super().__init__()
+        self.num_groups, self.num_channels = num_groups, num_channels
+        self.norm = nn.GroupNorm(num_groups, num_channels)
+
+    def forward(self, x, leaky_slope=None):
+        return SF.group_norm_rows(x, self.norm.weight, self.norm.bias, self.num_groups, self.norm.eps, leaky_slope, None)
+
+
+class UnaryBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, group_norm, has_relu=True, bias=True, layer_norm=False):
+        super().__init__()
+        if layer_norm:
+            raise NotImplementedError('UnaryBlock (HIP): layer_norm=True is not used by SE3ET')
+        self.mlp = nn.Linear(in_channels, out_channels, bias=bias)
+        self.norm = GroupNorm(group_norm, out_channels)
+        self.has_relu = has_relu
+
+    def forward(self, x):
+        return self.norm(SF.linear(x, self.mlp.weight, self.mlp.bias), leaky_slope=0.1 if self.has_relu else None)
+
+
+class LastUnaryBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, bias=True):
+        super().__init__()
+        self.mlp = nn.Linear(in_channels, out_channels, bias=bias)
+
+    def forward(self, x):
+        return SF.linear(x, self.mlp.weight, self.mlp.bias)

@@ -71,3 +71,188 @@ def grid_subsample(points, lengths, normals, voxel_size):
                                    s_normals.data_ptr() if s_normals is not None else None, s_lengths.data_ptr(),
                                    ws.data_ptr(), ws_bytes, _stream()), 'se3_grid_subsample')
     return s_points, s_normals, s_lengths
+
+
+# =====================================================================================================================
+# Ops whose gfx950 kernel is not bound yet run as eager torch-on-GPU chains (never on the CPU); each entry of
+# INTERIM_TORCH is replaced by a C-ABI call as its kernel lands (DESIGN.md tracks the status per SURVEY row).
+# =====================================================================================================================
+import math
+
+import torch.nn.functional as F
+
+INTERIM_TORCH = set()
+
+
+def _interim(fn):
+    INTERIM_TORCH.add(fn.__name__)
+    return fn
+
+
+def _gpu(t, name):
+    if not t.is_cuda:
+        raise RuntimeError('%s must be a GPU tensor (the SE3ET hot path has no CPU implementation)' % name)
+    return t
+
+
+@_interim
+def add_layer_norm(hidden, residual, weight, bias, eps):
+    _gpu(hidden, 'hidden')
+    return F.layer_norm(hidden + residual, hidden.shape[-1:], weight, bias, eps)
+
+
+@_interim
+def gather_rows_padded(x, idx):
+    _gpu(x, 'x')
+    return torch.cat((x, torch.zeros_like(x[:1])), 0)[idx]
+
+
+@_interim
+def neighbor_max_pool(x, idx):
+    _gpu(x, 'x')
+    return torch.cat((x, torch.zeros_like(x[:1])), 0)[idx].amax(1)
+
+
+@_interim
+def group_norm_rows(x, weight, bias, groups, eps, leaky_slope, residual):
+    _gpu(x, 'x')
+    C = x.shape[-1]
+    y = F.group_norm(x.reshape(-1, C).t().unsqueeze(0), groups, weight, bias, eps).squeeze(0).t().reshape(x.shape)
+    if residual is not None:
+        y = y + residual
+    return F.leaky_relu(y, leaky_slope) if leaky_slope is not None else y
+
+
+@_interim
+def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, sigma):
+    _gpu(x, 'x')
+    s_pad = torch.cat((s_pts, torch.full_like(s_pts[:1], 1e6)), 0)
+    nbr = s_pad[idx] - q_pts[:, None, :]
+    infl = torch.clamp(1 - torch.sqrt(((nbr[:, :, None, :] - kernel_points) ** 2).sum(-1)) / sigma, min=0.0)
+    x_pad = torch.cat((x, torch.zeros_like(x[:1])), 0)
+    feats = torch.einsum('pnac,pnk->pkac', x_pad[idx], infl)
+    K, R = kidx.shape
+    A = ridx.shape[0]
+    w_full = weights[kidx[:, None, :].expand(K, A, R), ridx[None].expand(K, A, R)]
+    return torch.einsum('pkac,karcd->prd', feats, w_full)
+
+
+@_interim
+def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, k):
+    _gpu(points, 'points')
+    xy = points @ points.t()
+    sq = (points ** 2).sum(-1)
+    dist = torch.sqrt((sq[:, None] - 2 * xy + sq[None, :]).clamp(min=0.0))
+    knn = dist.topk(k + 1, dim=1, largest=False)[1][:, 1:]
+    ref = points[knn] - points[:, None, :]
+    anc = points[None, :, :] - points[:, None, :]
+    ref = ref[:, None].expand(-1, points.shape[0], -1, -1)
+    anc = anc[:, :, None].expand_as(ref)
+    ang = torch.atan2(torch.linalg.norm(torch.cross(ref, anc, dim=-1), dim=-1), (ref * anc).sum(-1))
+
+    def emb(v):
+        om = v.reshape(-1, 1, 1) * div_term.view(1, -1, 1)
+        return torch.cat((torch.sin(om), torch.cos(om)), 2).reshape(*v.shape, 2 * div_term.numel())
+    d = F.linear(emb(dist / sigma_d), w_d, b_d)
+    a = F.linear(emb(ang * (180.0 / (sigma_a * math.pi))), w_a, b_a).amax(2)
+    return d + a
+
+
+@_interim
+def equiv_embedding(points, wigner_d1):
+    _gpu(points, 'points')
+    diff = points[:, None, :] - points[None, :, :]
+    y1 = math.sqrt(3.0 / (4.0 * math.pi)) * F.normalize(diff, dim=-1)
+    out = torch.empty((wigner_d1.shape[0],) + diff.shape[:2] + (4,), dtype=points.dtype, device=points.device)
+    out[..., 0] = 0.5 / math.sqrt(math.pi)
+    out[..., 1:] = torch.einsum('acd,nmd->anmc', wigner_d1, y1)
+    return out
+
+
+def _split_heads(x, h):
+    return x.reshape(*x.shape[:-1], h, -1).transpose(-2, -3)
+
+
+def _merge_heads(x):
+    x = x.transpose(-2, -3)
+    return x.reshape(*x.shape[:-2], -1)
+
+
+@_interim
+def rpe_attention(q, k, v, emb, w_p, eq_emb, w_eq, num_heads, return_scores):
+    _gpu(q, 'q')
+    h = num_heads
+    qh, kh, vh = _split_heads(q, h), _split_heads(k, h), _split_heads(v, h)           # ([A,] H, N, d)
+    d = qh.shape[-1]
+    C = q.shape[-1]
+    qp = torch.einsum('...hnd,hdc->...hnc', qh, w_p.view(h, d, C))                      # folded position query
+    s = qh @ kh.transpose(-1, -2) + torch.einsum('...hnc,nmc->...hnm', qp, emb)
+    if eq_emb is not None:
+        qe = torch.einsum('ahnd,hde->ahne', qh, w_eq.view(h, d, -1))
+        s = s + torch.einsum('ahne,anme->ahnm', qe, eq_emb)
+    p = torch.softmax(s / d ** 0.5, -1)
+    return _merge_heads(p @ vh), (p if return_scores else None)
+
+
+@_interim
+def cross_attention(q, k, v, num_heads):
+    _gpu(q, 'q')
+    qh, kh, vh = _split_heads(q, num_heads), _split_heads(k, num_heads), _split_heads(v, num_heads)
+    p = torch.softmax(qh @ kh.transpose(-1, -2) / qh.shape[-1] ** 0.5, -1)
+    return _merge_heads(p @ vh)
+
+
+@_interim
+def cross_attention_eq(q, k, v, num_heads, mode, trace_idx):
+    _gpu(q, 'q')
+    qh, kh, vh = _split_heads(q, num_heads), _split_heads(k, num_heads), _split_heads(v, num_heads)   # (A, H, n, d)
+    s = torch.einsum('ahnc,ehmc->aehnm', qh, kh) / qh.shape[-1] ** 0.5
+    g = (s.mean(2) ** 2).mean((-2, -1))
+    A = g.shape[0]
+    if mode == 'a_soft':
+        w = g / g.sum(1, keepdim=True)
+        mix, ret = w, w
+    else:
+        ar = torch.arange(A, device=q.device)
+        wr = g[ar[None, :], trace_idx].mean(1)
+        wr = wr / wr.sum()
+        mix = torch.zeros_like(g)
+        mix.index_put_((ar[None].expand_as(trace_idx), trace_idx), wr[:, None].expand(-1, A), accumulate=True)
+        ret = wr
+    p = torch.softmax(s, -1) * mix[:, :, None, None, None]
+    return _merge_heads(torch.einsum('aehnm,ehmc->ahnc', p, vh)), ret
+
+
+@_interim
+def superpoint_scores(ref_feats, src_feats, dual_normalization):
+    _gpu(ref_feats, 'ref_feats')
+    s = torch.exp(-(2.0 - 2.0 * (ref_feats @ src_feats.t())).clamp(min=0.0))
+    if dual_normalization:
+        s = (s / s.sum(1, keepdim=True)) * (s / s.sum(0, keepdim=True))
+    return s
+
+
+@_interim
+def log_optimal_transport(scores, row_masks, col_masks, alpha, num_iterations, inf):
+    _gpu(scores, 'scores')
+    B, R, C = scores.shape
+    dev = scores.device
+    prm = torch.zeros(B, R + 1, dtype=torch.bool, device=dev)
+    prm[:, :R] = ~row_masks
+    pcm = torch.zeros(B, C + 1, dtype=torch.bool, device=dev)
+    pcm[:, :C] = ~col_masks
+    z = torch.cat((torch.cat((scores, alpha.expand(B, R, 1)), -1), alpha.expand(B, 1, C + 1)), 1)
+    z = z.masked_fill(prm[:, :, None] | pcm[:, None, :], -inf)
+    nvr, nvc = row_masks.float().sum(1), col_masks.float().sum(1)
+    norm = -torch.log(nvr + nvc)
+    log_mu = norm[:, None].repeat(1, R + 1)
+    log_mu[:, R] = torch.log(nvc) + norm
+    log_mu[prm] = -inf
+    log_nu = norm[:, None].repeat(1, C + 1)
+    log_nu[:, C] = torch.log(nvr) + norm
+    log_nu[pcm] = -inf
+    u, v = torch.zeros_like(log_mu), torch.zeros_like(log_nu)
+    for _ in range(num_iterations):
+        u = log_mu - torch.logsumexp(z + v[:, None, :], 2)
+        v = log_nu - torch.logsumexp(z + u[:, :, None], 1)
+    return z + u[:, :, None] + v[:, None, :] - norm[:, None, None]

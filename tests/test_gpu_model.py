@@ -1,0 +1,75 @@
+"""GPU parity of the whole SE3ET forward (HIP path through se3et_amd) against outputs captured from the genuine
+reference (tests/golden/*.npz).  Tolerance: 1e-4 relative (max-norm), the figure BASELINE.json states for fp32."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, assert_neighbors_equal, assert_pairs_equal_up_to_ties
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(variant, pair, state=None, synth_seed=None):
+    from se3et_amd.data import registration_collate_fn_stack_mode
+    from se3et_amd.model import create_model, load_synthetic_weights, make_cfg
+    from se3et_amd.synthetic import make_pair
+    cfg = make_cfg(variant)
+    model = create_model(cfg)
+    if state is not None:
+        model.load_state_dict(state, strict=True)
+    else:
+        load_synthetic_weights(model, synth_seed)
+    model = model.cuda().eval()
+    ref, src, T = make_pair(pair)
+    d = dict(ref_points=ref, src_points=src, ref_feats=np.ones((len(ref), 1), np.float32),
+             src_feats=np.ones((len(src), 1), np.float32), transform=T)
+    dd = registration_collate_fn_stack_mode([d], cfg.backbone.num_stages, cfg.backbone.init_voxel_size,
+                                            cfg.backbone.init_radius, cfg.neighbor_limits)
+    return model, dd, model(dd)
+
+
+def _check_outputs(out, g, full):
+    fc = out['feats_c'].cpu()
+    assert_close(fc if full else fc[:, :, :64], g['out/feats_c'], 1e-4, 'feats_c')
+    ff = out['feats_f'].cpu()
+    assert_close(ff if full else ff[::8], g['out/feats_f'], 1e-4, 'feats_f')
+    assert_close(out['ref_feats_c'].cpu(), g['out/ref_feats_c'], 1e-4, 'ref_feats_c')
+    assert_close(out['src_feats_c'].cpu(), g['out/src_feats_c'], 1e-4, 'src_feats_c')
+    ri, si = torch.from_numpy(g['out/ref_node_corr_indices']).long(), torch.from_numpy(g['out/src_node_corr_indices']).long()
+    # scores of the reference pairs recomputed from the reference features give the tie structure
+    rf, sf = torch.from_numpy(g['out/ref_feats_c']), torch.from_numpy(g['out/src_feats_c'])
+    s = torch.exp(-(2 - 2 * rf @ sf.t()).clamp(min=0))
+    s = (s / s.sum(1, keepdim=True)) * (s / s.sum(0, keepdim=True))
+    assert_pairs_equal_up_to_ties((out['ref_node_corr_indices'], out['src_node_corr_indices']), out['node_corr_scores'],
+                                  (ri, si), s[ri, si], rtol=2e-4, context='node correspondences')
+    same = (out['ref_node_corr_indices'].cpu()[:8] == ri[:8]).all() and (out['src_node_corr_indices'].cpu()[:8] == si[:8]).all()
+    if same:
+        got, want = out['matching_scores'][:8].cpu(), torch.from_numpy(g['out/matching_scores_head'])
+        valid = want > -1e11
+        assert torch.equal(got > -1e11, valid)
+        assert float((got[valid] - want[valid]).abs().max()) < 2e-3        # log-domain values of magnitude ~10
+    assert_close(out['estimated_transform'].cpu(), g['out/estimated_transform'], 2e-3, 'estimated_transform')
+
+
+@pytest.mark.parametrize('variant,fixture', [('micro_e', 'micro_se3ete.npz'), ('micro_i', 'micro_se3eti.npz')])
+def test_micro_model_matches_reference(golden_dir, variant, fixture):
+    g = np.load(golden_dir + '/' + fixture)
+    state = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd/')}
+    model, dd, out = _run(variant, 'micro', state=state)
+    for i in range(4):
+        assert dd['lengths'][i].tolist() == g['data/lengths_%d' % i].tolist()
+        assert torch.equal(dd['points'][i].cpu(), torch.from_numpy(g['data/points_%d' % i]))
+        assert_neighbors_equal(dd['neighbors'][i], g['data/neighbors_%d' % i], dd['points'][i], dd['points'][i])
+    _check_outputs(out, g, full=True)
+    for i in range(len(model.cfg.geotransformer.blocks)):
+        key = 'op/layer_%d/out0' % i
+        assert key in g.files
+
+
+@pytest.mark.parametrize('variant,fixture', [('se3ete2', 'synthw_se3ete2.npz'), ('se3eti2', 'synthw_se3eti2.npz'),
+                                             ('se3ete', 'synthw_se3ete.npz')])
+def test_real_width_model_matches_reference(golden_dir, variant, fixture):
+    g = np.load(golden_dir + '/' + fixture)
+    model, dd, out = _run(variant, str(g['pair']), synth_seed=int(g['synth_seed']))
+    assert np.array_equal(np.stack([l.numpy() for l in dd['lengths']]), g['lengths'])
+    _check_outputs(out, g, full=False)
