@@ -5,6 +5,7 @@ the SE3ET forward (experiments/se3ete.3dmatch/model.py:20-227) and the per-varia
 with load_state_dict(strict=True)."""
 from types import SimpleNamespace
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -183,6 +184,6 @@ def load_synthetic_weights(model, seed=7):
     for k, v in sd.items():
         leaf = k.rsplit('.', 1)[-1]
         if leaf in ('weight', 'bias', 'weights', 'alpha') and v.dtype == torch.float32 and 'anchors' not in k:
-            sd[k] = torch.from_numpy(synth_tensor(k, tuple(v.shape), seed).reshape(tuple(v.shape))).to(v.device)
+            sd[k] = torch.from_numpy(np.asarray(synth_tensor(k, tuple(v.shape), seed), dtype=np.float32).reshape(tuple(v.shape))).to(v.device)
     model.load_state_dict(sd)
     return model
