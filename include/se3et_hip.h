@@ -59,6 +59,40 @@ int se3_grid_subsample(const float* points, const float* normals, int64_t n, con
                        float voxel_size, float* s_points, float* s_normals, int64_t* s_lengths, void* workspace,
                        size_t workspace_bytes, void* stream);
 
+/* ---- E4: log-domain Sinkhorn with dustbin (LearnableLogOptimalTransport.forward) ---------------------------------
+ * Replaces geotransformer/modules/sinkhorn/learnable_sinkhorn.py:13-66.  scores (batch, rows, cols) float32,
+ * row_masks (batch, rows) / col_masks (batch, cols) uint8 (1 = valid point), alpha: device pointer to the learnable
+ * dustbin score, inf: the finite "minus infinity" (1e12 in the reference).  out (batch, rows+1, cols+1).
+ * rows, cols <= 143. */
+int se3_log_sinkhorn_fwd(const float* scores, const uint8_t* row_masks, const uint8_t* col_masks, const float* alpha,
+                         int batch, int rows, int cols, int iterations, float inf, float* out, void* stream);
+
+/* ---- B2: GroupNorm over stacked points, fused with "+ residual" and LeakyReLU ------------------------------------
+ * Replaces GroupNormEPN (geotransformer/modules/e2pn/blocks_epn.py:684-701) and kpconv GroupNorm
+ * (geotransformer/modules/kpconv/modules.py:34-51) plus the activation / shortcut add that follows them
+ * (blocks_epn.py:660-664, 741-742, 838-852).  x (rows, channels): every leading dim (points, anchors) is a row; the
+ * statistics of a group span all rows.  residual may be NULL.  out = act(norm(x) * weight + bias + residual). */
+size_t se3_group_norm_workspace_bytes(int64_t rows, int channels, int groups);
+int se3_group_norm_fwd(const float* x, const float* residual, const float* weight, const float* bias, int64_t rows,
+                       int channels, int groups, float eps, int apply_leaky_relu, float slope, float* out,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- D6: LayerNorm(hidden + residual) ---------------------------------------------------------------------------
+ * Replaces the residual + nn.LayerNorm tails of geotransformer/modules/transformer/rpe_transformer.py:163-164,
+ * vanilla_transformer.py:910-911 and output_layer.py:21,46.  hidden (rows, channels); residual (residual_rows,
+ * channels) is broadcast with row % residual_rows (anchor broadcast). */
+int se3_add_layer_norm_fwd(const float* hidden, const float* residual, const float* weight, const float* bias,
+                           int64_t rows, int64_t residual_rows, int channels, float eps, float* out, void* stream);
+
+/* ---- B2/B3: padded row gather and neighbour max pooling ------------------------------------------------------------
+ * Replace nearest_upsample (geotransformer/modules/kpconv/functional.py:6-22), the zero-padded patch gathers of
+ * experiments/se3ete.3dmatch/model.py:108-111,190-193 and max_pool (geotransformer/modules/e2pn/blocks.py:93-110).
+ * x (n, width); idx entries equal to n address an all-zero row. */
+int se3_gather_rows_padded(const float* x, const int64_t* idx, int64_t n, int64_t m, int64_t width, float* out,
+                           void* stream);
+int se3_neighbor_max_pool(const float* x, const int64_t* idx, int64_t n, int64_t m, int nn, int64_t width, float* out,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

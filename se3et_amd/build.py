@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libse3et_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
 
 def _stale(target, deps):
@@ -29,7 +29,9 @@ def build(force=False, verbose=True):
         o = os.path.join(CSRC, 'build', os.path.basename(s)[:-4] + '.o')
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([HIPCC] + FLAGS + ['-c', s, '-o', o])
+            # the bit-exact geometry kernels must not fuse a*b+c (they mirror unfused x86 float arithmetic)
+            extra = ['-ffp-contract=off'] if 'SE3_EXACT_FP' in open(s).read() else []
+            jobs.append([HIPCC] + FLAGS + extra + ['-c', s, '-o', o])
 
     def run(cmd):
         if verbose:

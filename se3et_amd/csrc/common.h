@@ -29,10 +29,10 @@ void se3_set_error(const char* fmt, ...);
 static inline int64_t se3_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Exactly-rounded float32 primitives for the bit-exact geometry kernels.  hipcc's __f*_rn intrinsics are plain
-// operators (and __fsqrt_rn is the approximate native sqrt), so: products/sums rely on -ffp-contract=off plus the
-// pragma below, division and square root go through float64 (53 >= 2*24+2 bits makes the double result round to the
-// correctly rounded float32 result).
-#pragma clang fp contract(off)
+// operators defined in a compiler header (and __fsqrt_rn is the approximate native sqrt), so: sources that define
+// SE3_EXACT_FP are compiled with -ffp-contract=off (se3et_amd/build.py) so that products and sums stay unfused, and
+// division and square root go through float64 (53 >= 2*24+2 bits makes the double result round to the correctly
+// rounded float32 result).
 __device__ __forceinline__ float se3_exact_div(float a, float b) { return (float)((double)a / (double)b); }
 __device__ __forceinline__ float se3_exact_sqrt(float a) { return (float)sqrt((double)a); }
 

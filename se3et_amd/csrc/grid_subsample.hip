@@ -22,6 +22,7 @@
 //                      members by DEscending position.  Each of the O(log V) growth stages is therefore evaluated in
 //                      parallel with atomics + one prefix sum instead of walking a list.
 //   gather_kernel      writes the selected rows in emission order, clouds back to back
+#define SE3_EXACT_FP 1
 #include "common.h"
 
 namespace {

@@ -11,6 +11,7 @@
 // unsigned order = (d2, index) order).  The support cloud is streamed through LDS in SoA tiles shared by the 4 waves of
 // a workgroup; every lane tests one support point per step, hits are inserted with a ballot + shuffle-shift.  The work
 // is LDS/VALU bound (each support point is read from HBM once per workgroup and sits in L2 for the others).
+#define SE3_EXACT_FP 1
 #include "common.h"
 
 namespace {

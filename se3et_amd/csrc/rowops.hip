@@ -1,0 +1,273 @@
+// B2 / D6 row-wise ops: GroupNorm over stacked points (+ residual + LeakyReLU), residual LayerNorm, padded row gather
+// and neighbour max pooling.  All are single-pass, HBM-streaming kernels over (rows, C) float32 tensors.
+//
+//   group norm    geotransformer/modules/e2pn/blocks_epn.py:684-701 (GroupNormEPN: statistics over channels-in-group x
+//                 anchors x ALL points of both clouds), kpconv/modules.py:34-51 (GroupNorm on (N, C)); the bottleneck tail
+//                 lrelu(norm(x) + shortcut) of blocks_epn.py:838-852 is fused in
+//   add+LN        rpe_transformer.py:163-164, vanilla_transformer.py:910-911, output_layer.py:21, 46
+//   gather / max  kpconv/functional.py:6-22 (nearest_upsample), e2pn/blocks.py:93-110 (max_pool)
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GroupNorm: per-(row chunk, channel) Welford partials -> per-group finalize (Chan merge) -> normalize.
+// Deterministic (no atomics) and cancellation-free (M2 form).
+// ---------------------------------------------------------------------------------------------------------------------
+struct WF {
+  float n, mean, m2;
+};
+__device__ __forceinline__ WF wf_merge(WF a, WF b) {
+  if (b.n == 0.f) return a;
+  if (a.n == 0.f) return b;
+  WF r;
+  r.n = a.n + b.n;
+  const float d = b.mean - a.mean;
+  const float f = b.n / r.n;
+  r.mean = a.mean + d * f;
+  r.m2 = a.m2 + b.m2 + d * d * a.n * f;
+  return r;
+}
+
+constexpr int kGNLanes = 64;   // channels per block
+constexpr int kGNRows = 4;     // row lanes per block
+
+__global__ __launch_bounds__(kGNLanes* kGNRows) void gn_partial_kernel(const float* __restrict__ x, int64_t rows, int C,
+                                                                       int nchunks, float* __restrict__ part) {
+  __shared__ WF sh[kGNRows][kGNLanes];
+  const int cl = threadIdx.x & (kGNLanes - 1), rl = threadIdx.x / kGNLanes;
+  const int c = blockIdx.y * kGNLanes + cl;
+  const int64_t per = (rows + nchunks - 1) / nchunks;
+  const int64_t r0 = (int64_t)blockIdx.x * per, r1 = min(rows, r0 + per);
+  WF w = {0.f, 0.f, 0.f};
+  if (c < C)
+    for (int64_t r = r0 + rl; r < r1; r += kGNRows) {
+      const float v = x[r * C + c];
+      w.n += 1.f;
+      const float d = v - w.mean;
+      w.mean += d / w.n;
+      w.m2 += d * (v - w.mean);
+    }
+  sh[rl][cl] = w;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    for (int k = 1; k < kGNRows; k++) w = wf_merge(w, sh[k][cl]);
+    float* p = part + ((int64_t)blockIdx.x * C + c) * 3;
+    p[0] = w.n; p[1] = w.mean; p[2] = w.m2;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, int C, int groups, int nchunks,
+                                                          float eps, float* __restrict__ stats) {
+  __shared__ WF sh[256];
+  const int g = blockIdx.x, cpg = C / groups;
+  const int total = nchunks * cpg;
+  WF w = {0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int chunk = i / cpg, c = g * cpg + (i - chunk * cpg);
+    const float* p = part + ((int64_t)chunk * C + c) * 3;
+    WF o = {p[0], p[1], p[2]};
+    w = wf_merge(w, o);
+  }
+  sh[threadIdx.x] = w;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sh[threadIdx.x] = wf_merge(sh[threadIdx.x], sh[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const WF r = sh[0];
+    stats[2 * g] = r.mean;
+    stats[2 * g + 1] = 1.0f / sqrtf(r.m2 / r.n + eps);
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                       const float* __restrict__ w, const float* __restrict__ b,
+                                                       const float* __restrict__ stats, int64_t rows, int C, int groups,
+                                                       int has_slope, float slope, float* __restrict__ y) {
+  const int cpg = C / groups;
+  const int64_t total = rows * C;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if ((C & 3) == 0) {
+    const int64_t total4 = total >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+      const int c0 = (int)((i << 2) % C);
+      const float4 v = reinterpret_cast<const float4*>(x)[i];
+      float o[4] = {v.x, v.y, v.z, v.w};
+      float rr[4] = {0.f, 0.f, 0.f, 0.f};
+      if (res) {
+        const float4 t = reinterpret_cast<const float4*>(res)[i];
+        rr[0] = t.x; rr[1] = t.y; rr[2] = t.z; rr[3] = t.w;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int c = c0 + k, g = c / cpg;
+        float t = (o[k] - stats[2 * g]) * stats[2 * g + 1] * w[c] + b[c] + rr[k];
+        if (has_slope) t = t > 0.f ? t : t * slope;
+        o[k] = t;
+      }
+      reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+      const int c = (int)(i % C), g = c / cpg;
+      float t = (x[i] - stats[2 * g]) * stats[2 * g + 1] * w[c] + b[c] + (res ? res[i] : 0.f);
+      if (has_slope) t = t > 0.f ? t : t * slope;
+      y[i] = t;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm(hidden + residual): one wavefront per row; residual row index = row % res_rows (broadcast over anchors)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int VPL>   // float4 vectors per lane: C <= 256 * VPL
+__global__ __launch_bounds__(256) void add_ln_kernel(const float* __restrict__ h, const float* __restrict__ res,
+                                                     const float* __restrict__ w, const float* __restrict__ b, int64_t rows,
+                                                     int64_t res_rows, int C, float eps, float* __restrict__ y) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const int C4 = C >> 2;
+  const float4* hp = reinterpret_cast<const float4*>(h + row * C);
+  const float4* rp = reinterpret_cast<const float4*>(res + (row % res_rows) * C);
+  float4 v[VPL];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPL; k++) {
+    const int i = lane + 64 * k;
+    if (i < C4) {
+      const float4 a = hp[i], r = rp[i];
+      v[k] = make_float4(a.x + r.x, a.y + r.y, a.z + r.z, a.w + r.w);
+      s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    } else {
+      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const float mean = se3_wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPL; k++) {
+    const int i = lane + 64 * k;
+    if (i < C4) {
+      const float dx = v[k].x - mean, dy = v[k].y - mean, dz = v[k].z - mean, dw = v[k].w - mean;
+      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(se3_wave_sum(q) / (float)C + eps);
+  float4* yp = reinterpret_cast<float4*>(y + row * C);
+#pragma unroll
+  for (int k = 0; k < VPL; k++) {
+    const int i = lane + 64 * k;
+    if (i < C4) {
+      const float4 ww = reinterpret_cast<const float4*>(w)[i], bb = reinterpret_cast<const float4*>(b)[i];
+      yp[i] = make_float4((v[k].x - mean) * rstd * ww.x + bb.x, (v[k].y - mean) * rstd * ww.y + bb.y,
+                          (v[k].z - mean) * rstd * ww.z + bb.z, (v[k].w - mean) * rstd * ww.w + bb.w);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// out[i, :] = x[idx[i], :] (zeros when idx[i] == n)   and   out[i, :] = max_j xpad[idx[i, j], :]
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void gather_rows_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx, int64_t n, int64_t m,
+                                   int64_t width, float* __restrict__ out) {
+  const int64_t total = m * width;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / width, c = i - r * width;
+    const int64_t s = idx[r];
+    out[i] = (s >= 0 && s < n) ? x[s * width + c] : 0.f;
+  }
+}
+
+__global__ void neighbor_max_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx, int64_t n, int64_t m,
+                                    int nn, int64_t width, float* __restrict__ out) {
+  const int64_t total = m * width;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / width, c = i - r * width;
+    float best = -INFINITY;
+    for (int j = 0; j < nn; j++) {
+      const int64_t s = idx[r * nn + j];
+      best = fmaxf(best, (s >= 0 && s < n) ? x[s * width + c] : 0.f);
+    }
+    out[i] = best;
+  }
+}
+
+inline unsigned grid_for(int64_t work, int tpb) {
+  int64_t g = se3_cdiv(work, tpb);
+  return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace
+
+extern "C" size_t se3_group_norm_workspace_bytes(int64_t rows, int channels, int groups) {
+  int64_t nchunks = rows / 64 + 1;
+  if (nchunks > 256) nchunks = 256;
+  return (size_t)(nchunks * channels * 3 + 2 * groups) * sizeof(float) + 256;
+}
+
+extern "C" int se3_group_norm_fwd(const float* x, const float* residual, const float* weight, const float* bias,
+                                  int64_t rows, int channels, int groups, float eps, int apply_leaky_relu, float slope,
+                                  float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  SE3_REQUIRE(x && weight && bias && out && workspace, SE3_ERR_INVALID_ARG, "group_norm: null pointer");
+  SE3_REQUIRE(rows >= 1 && channels >= 1 && groups >= 1 && channels % groups == 0, SE3_ERR_INVALID_ARG,
+              "group_norm: rows %lld channels %d groups %d", (long long)rows, channels, groups);
+  SE3_REQUIRE(workspace_bytes >= se3_group_norm_workspace_bytes(rows, channels, groups), SE3_ERR_WORKSPACE,
+              "group_norm: workspace too small");
+  int64_t nchunks = rows / 64 + 1;
+  if (nchunks > 256) nchunks = 256;
+  float* part = (float*)workspace;
+  float* stats = part + nchunks * channels * 3;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 g1((unsigned)nchunks, (unsigned)se3_cdiv(channels, kGNLanes));
+  gn_partial_kernel<<<g1, kGNLanes * kGNRows, 0, st>>>(x, rows, channels, (int)nchunks, part);
+  gn_finalize_kernel<<<groups, 256, 0, st>>>(part, channels, groups, (int)nchunks, eps, stats);
+  const int64_t work = (channels % 4 == 0) ? rows * channels / 4 : rows * channels;
+  gn_apply_kernel<<<grid_for(work, 256), 256, 0, st>>>(x, residual, weight, bias, stats, rows, channels, groups,
+                                                      apply_leaky_relu, slope, out);
+  SE3_CHECK_LAUNCH("group_norm");
+  return SE3_OK;
+}
+
+extern "C" int se3_add_layer_norm_fwd(const float* hidden, const float* residual, const float* weight, const float* bias,
+                                      int64_t rows, int64_t residual_rows, int channels, float eps, float* out,
+                                      void* stream) {
+  SE3_REQUIRE(hidden && residual && weight && bias && out, SE3_ERR_INVALID_ARG, "add_layer_norm: null pointer");
+  SE3_REQUIRE(channels % 4 == 0 && channels >= 4 && channels <= 2048, SE3_ERR_UNSUPPORTED,
+              "add_layer_norm: channels %d (need a multiple of 4 up to 2048)", channels);
+  SE3_REQUIRE(rows >= 0 && residual_rows >= 1 && rows % residual_rows == 0, SE3_ERR_INVALID_ARG,
+              "add_layer_norm: rows %lld not a multiple of residual rows %lld", (long long)rows, (long long)residual_rows);
+  if (rows == 0) return SE3_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)se3_cdiv(rows, 4);
+  if (channels <= 256)
+    add_ln_kernel<1><<<grid, 256, 0, st>>>(hidden, residual, weight, bias, rows, residual_rows, channels, eps, out);
+  else if (channels <= 512)
+    add_ln_kernel<2><<<grid, 256, 0, st>>>(hidden, residual, weight, bias, rows, residual_rows, channels, eps, out);
+  else if (channels <= 1024)
+    add_ln_kernel<4><<<grid, 256, 0, st>>>(hidden, residual, weight, bias, rows, residual_rows, channels, eps, out);
+  else
+    add_ln_kernel<8><<<grid, 256, 0, st>>>(hidden, residual, weight, bias, rows, residual_rows, channels, eps, out);
+  SE3_CHECK_LAUNCH("add_layer_norm");
+  return SE3_OK;
+}
+
+extern "C" int se3_gather_rows_padded(const float* x, const int64_t* idx, int64_t n, int64_t m, int64_t width, float* out,
+                                      void* stream) {
+  SE3_REQUIRE(x && idx && out, SE3_ERR_INVALID_ARG, "gather_rows_padded: null pointer");
+  if (m * width == 0) return SE3_OK;
+  gather_rows_kernel<<<grid_for(m * width, 256), 256, 0, (hipStream_t)stream>>>(x, idx, n, m, width, out);
+  SE3_CHECK_LAUNCH("gather_rows_padded");
+  return SE3_OK;
+}
+
+extern "C" int se3_neighbor_max_pool(const float* x, const int64_t* idx, int64_t n, int64_t m, int nn, int64_t width,
+                                     float* out, void* stream) {
+  SE3_REQUIRE(x && idx && out && nn >= 1, SE3_ERR_INVALID_ARG, "neighbor_max_pool: bad arguments");
+  if (m * width == 0) return SE3_OK;
+  neighbor_max_kernel<<<grid_for(m * width, 256), 256, 0, (hipStream_t)stream>>>(x, idx, n, m, nn, width, out);
+  SE3_CHECK_LAUNCH("neighbor_max_pool");
+  return SE3_OK;
+}

@@ -96,34 +96,6 @@ def _gpu(t, name):
 
 
 @_interim
-def add_layer_norm(hidden, residual, weight, bias, eps):
-    _gpu(hidden, 'hidden')
-    return F.layer_norm(hidden + residual, hidden.shape[-1:], weight, bias, eps)
-
-
-@_interim
-def gather_rows_padded(x, idx):
-    _gpu(x, 'x')
-    return torch.cat((x, torch.zeros_like(x[:1])), 0)[idx]
-
-
-@_interim
-def neighbor_max_pool(x, idx):
-    _gpu(x, 'x')
-    return torch.cat((x, torch.zeros_like(x[:1])), 0)[idx].amax(1)
-
-
-@_interim
-def group_norm_rows(x, weight, bias, groups, eps, leaky_slope, residual):
-    _gpu(x, 'x')
-    C = x.shape[-1]
-    y = F.group_norm(x.reshape(-1, C).t().unsqueeze(0), groups, weight, bias, eps).squeeze(0).t().reshape(x.shape)
-    if residual is not None:
-        y = y + residual
-    return F.leaky_relu(y, leaky_slope) if leaky_slope is not None else y
-
-
-@_interim
 def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, sigma):
     _gpu(x, 'x')
     s_pad = torch.cat((s_pts, torch.full_like(s_pts[:1], 1e6)), 0)
@@ -232,27 +204,73 @@ def superpoint_scores(ref_feats, src_feats, dual_normalization):
     return s
 
 
-@_interim
 def log_optimal_transport(scores, row_masks, col_masks, alpha, num_iterations, inf):
-    _gpu(scores, 'scores')
+    """HIP: one workgroup per patch pair, score matrix in registers for all iterations (csrc/sinkhorn.hip)."""
+    scores = _req(scores.contiguous(), torch.float32, 'scores', 3)
     B, R, C = scores.shape
-    dev = scores.device
-    prm = torch.zeros(B, R + 1, dtype=torch.bool, device=dev)
-    prm[:, :R] = ~row_masks
-    pcm = torch.zeros(B, C + 1, dtype=torch.bool, device=dev)
-    pcm[:, :C] = ~col_masks
-    z = torch.cat((torch.cat((scores, alpha.expand(B, R, 1)), -1), alpha.expand(B, 1, C + 1)), 1)
-    z = z.masked_fill(prm[:, :, None] | pcm[:, None, :], -inf)
-    nvr, nvc = row_masks.float().sum(1), col_masks.float().sum(1)
-    norm = -torch.log(nvr + nvc)
-    log_mu = norm[:, None].repeat(1, R + 1)
-    log_mu[:, R] = torch.log(nvc) + norm
-    log_mu[prm] = -inf
-    log_nu = norm[:, None].repeat(1, C + 1)
-    log_nu[:, C] = torch.log(nvr) + norm
-    log_nu[pcm] = -inf
-    u, v = torch.zeros_like(log_mu), torch.zeros_like(log_nu)
-    for _ in range(num_iterations):
-        u = log_mu - torch.logsumexp(z + v[:, None, :], 2)
-        v = log_nu - torch.logsumexp(z + u[:, :, None], 1)
-    return z + u[:, :, None] + v[:, None, :] - norm[:, None, None]
+    rm = _req(row_masks.to(torch.uint8).contiguous(), torch.uint8, 'row_masks', 2)
+    cm = _req(col_masks.to(torch.uint8).contiguous(), torch.uint8, 'col_masks', 2)
+    al = _req(alpha.detach().reshape(1).contiguous(), torch.float32, 'alpha')
+    out = torch.empty((B, R + 1, C + 1), dtype=torch.float32, device=scores.device)
+    check(lib().se3_log_sinkhorn_fwd(scores.data_ptr(), rm.data_ptr(), cm.data_ptr(), al.data_ptr(), B, R, C,
+                                     int(num_iterations), float(inf), out.data_ptr(), _stream()), 'se3_log_sinkhorn_fwd')
+    return out
+
+
+def add_layer_norm(hidden, residual, weight, bias, eps):
+    """HIP (csrc/rowops.hip): LayerNorm(hidden + residual); residual may lack leading (anchor) dims of hidden."""
+    hidden = _req(hidden.contiguous(), torch.float32, 'hidden')
+    C = hidden.shape[-1]
+    if residual.shape != hidden.shape:
+        # supported broadcast: one (N, C) residual block shared by all leading (anchor) slices of hidden
+        if tuple(residual.shape[-2:]) != tuple(hidden.shape[-2:]) or residual.numel() != hidden.shape[-2] * C:
+            raise RuntimeError('add_layer_norm: unsupported residual broadcast %s vs %s'
+                               % (tuple(residual.shape), tuple(hidden.shape)))
+    residual = _req(residual.contiguous(), torch.float32, 'residual')
+    rows, res_rows = hidden.numel() // C, residual.numel() // C
+    out = torch.empty_like(hidden)
+    check(lib().se3_add_layer_norm_fwd(hidden.data_ptr(), residual.data_ptr(), weight.data_ptr(), bias.data_ptr(), rows,
+                                       res_rows, C, float(eps), out.data_ptr(), _stream()), 'se3_add_layer_norm_fwd')
+    return out
+
+
+def gather_rows_padded(x, idx):
+    """HIP: x[idx] with idx == x.shape[0] addressing an all-zero row; idx of any shape."""
+    x = _req(x.contiguous(), torch.float32, 'x')
+    idx = _req(idx.contiguous(), torch.int64, 'idx')
+    n = x.shape[0]
+    width = x.numel() // max(n, 1)
+    out = torch.empty(tuple(idx.shape) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+    check(lib().se3_gather_rows_padded(x.data_ptr(), idx.data_ptr(), n, idx.numel(), width, out.data_ptr(), _stream()),
+          'se3_gather_rows_padded')
+    return out
+
+
+def neighbor_max_pool(x, idx):
+    x = _req(x.contiguous(), torch.float32, 'x')
+    idx = _req(idx.contiguous(), torch.int64, 'idx', 2)
+    n = x.shape[0]
+    width = x.numel() // max(n, 1)
+    out = torch.empty((idx.shape[0],) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+    check(lib().se3_neighbor_max_pool(x.data_ptr(), idx.data_ptr(), n, idx.shape[0], idx.shape[1], width, out.data_ptr(),
+                                      _stream()), 'se3_neighbor_max_pool')
+    return out
+
+
+def group_norm_rows(x, weight, bias, groups, eps, leaky_slope, residual):
+    """HIP (csrc/rowops.hip): GroupNorm with statistics over all leading dims, fused residual add + LeakyReLU."""
+    x = _req(x.contiguous(), torch.float32, 'x')
+    C = x.shape[-1]
+    rows = x.numel() // C
+    if residual is not None:
+        residual = _req(residual.contiguous(), torch.float32, 'residual')
+        if residual.shape != x.shape:
+            raise RuntimeError('group_norm_rows: residual shape mismatch')
+    ws_bytes = lib().se3_group_norm_workspace_bytes(rows, C, groups)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+    out = torch.empty_like(x)
+    check(lib().se3_group_norm_fwd(x.data_ptr(), residual.data_ptr() if residual is not None else None, weight.data_ptr(),
+                                   bias.data_ptr(), rows, C, int(groups), float(eps), 1 if leaky_slope is not None else 0,
+                                   float(leaky_slope or 0.0), out.data_ptr(), ws.data_ptr(), ws_bytes, _stream()),
+          'se3_group_norm_fwd')
+    return out
