@@ -93,6 +93,44 @@ int se3_gather_rows_padded(const float* x, const int64_t* idx, int64_t n, int64_
 int se3_neighbor_max_pool(const float* x, const int64_t* idx, int64_t n, int64_t m, int nn, int64_t width, float* out,
                           void* stream);
 
+/* ---- B1: E2PN anchor-group KPConv (KPConvInterSO3), neighbour-gather stage ---------------------------------------
+ * Replaces feat_gather_by_perm + the (k, a) part of the weight contraction of
+ * geotransformer/modules/e2pn/blocks_epn.py:334-390,454-546.  x (num_support, 6, Cin), idx (num_queries, NN) int64
+ * padded with num_support; kernel_points_host (15, 3) float32, kidx_host (15, 6) int64 [k][r] -> weight slot,
+ * ridx_host (6, 6) int64 [a][r] -> anchor slot: HOST arrays (tiny constant tables).  Writes
+ * G (num_queries, 6[r], 6[s], 6[t], Cin) so that out[(p, r), :] = G[(p, r), (s, t, c)] @ weights[(s, t, c), :]. */
+int se3_kpconv_so3_gather(const float* q_pts, const float* s_pts, const int64_t* idx, const float* x,
+                          const float* kernel_points_host, const int64_t* kidx_host, const int64_t* ridx_host, float sigma,
+                          int64_t num_queries, int64_t num_support, int num_neighbors, int in_channels, float* G,
+                          void* stream);
+
+/* ---- D1/D2: RPE self attention (RPEMultiHeadAttention.forward) ------------------------------------------------------
+ * Replaces geotransformer/modules/transformer/rpe_transformer.py:39-131 in two launches.
+ * (1) se3_rpe_bias_fwd streams the (N, M, C) geometric embedding once and writes the relative-position logits
+ *     bias[ah, n, m] = qp[n, ah, :] . emb[n, m, :] (+ qe[n, ah, :] . eq_emb[a, n, m, :]), where qp = W_p^T q (N, AH, C) and
+ *     qe = W_eq^T q (N, AH, 4) are the position projections folded onto the query (AH = anchors * heads <= 32, ah = a*H+h).
+ *     eq_emb (A, N, M, 4) and qe are NULL for non-equivariant layers.  bias has row stride bias_row_stride >= M.
+ * (2) se3_attention_fwd: out[a, n, h*d:(h+1)*d] = softmax_m((q_a[n,h] . k_a[m,h] + bias[a*H+h, n, m]) * scale) v_a[m, h].
+ *     q/k/v/out are (anchors, rows, C) with explicit anchor strides in floats (0 = the same tensor for every anchor, which
+ *     is how plain cross attention vanilla_transformer.py:39-85 with per-anchor values is expressed); bias may be NULL,
+ *     otherwise its row stride must be a multiple of 32 that covers M.  C / H in {8, 16, 32, 64}; C in {32,64,128,256} for (1). */
+int se3_rpe_bias_fwd(const float* qp, const float* qe, const float* emb, const float* eq_emb, int N, int M, int C, int AH,
+                     int H, int bias_row_stride, float* bias, void* stream);
+int se3_attention_fwd(const float* q, const float* k, const float* v, const float* bias, int num_anchors, int N, int M, int C,
+                      int H, int64_t q_anchor_stride, int64_t k_anchor_stride, int64_t v_anchor_stride,
+                      int64_t out_anchor_stride, int bias_row_stride, float scale, float* out, void* stream);
+
+/* ---- D4/D5: anchor-equivariant cross attention (MultiHeadAttentionEQ, 'a_soft' / 'r_soft') ----------------------------
+ * Replaces geotransformer/modules/transformer/vanilla_transformer.py:247-476,506-577,751-870.  q (A, N, C), k/v (A, M, C).
+ * se3_cross_eq_stats writes partial[(a*A+e) * P + i] whose sum over i is sum_{n,m} (mean_h q_a.k_e * scale)^2
+ * (*num_partials_per_pair = P = ceil(N/32)); the caller turns g = sum / (N M) into the (A, A) mixing weights `mix`
+ * (a_soft: g / sum_e g; r_soft: the 24 rotation weights collapsed onto anchor pairs) and se3_cross_eq_apply computes
+ * out[a] = sum_e mix[a, e] softmax_m(q_a.k_e * scale) v_e. */
+int se3_cross_eq_stats(const float* q, const float* k, int A, int N, int M, int C, int H, float scale, float* partial,
+                       int* num_partials_per_pair, void* stream);
+int se3_cross_eq_apply(const float* q, const float* k, const float* v, const float* mix, int A, int N, int M, int C, int H,
+                       float scale, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

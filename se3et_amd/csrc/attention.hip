@@ -1,0 +1,462 @@
+// D1-D5: attention kernels of the SE3ET coarse transformer on gfx950 (fp32 in, fp32 accumulate, f32 MFMA).
+//
+//   rpe_bias_kernel    the HBM-streaming half of RPE self attention (rpe_transformer.py:39-131): for every query row n the
+//                      relative-position term of the logits, bias[ah, n, m] = qp[n, ah, :] . E[n, m, :] (+ qe . Eeq), where
+//                      qp = W_p^T q is the position projection folded onto the query side.  The (N, M, C) embedding is read
+//                      exactly once, in 16-row tiles of fully used 64 B segments, straight into the B operand of
+//                      v_mfma_f32_16x16x4_f32; the 24 (anchor, head) folded queries of the row sit in LDS in MFMA-fragment
+//                      order (ds_read_b128, conflict free).  Never materialises p = W_p E (N, M, C) or eq = W_eq Eeq.
+//   attention_kernel   softmax((q k^T [+ bias]) * scale) v per (anchor, head, 32-query tile), flash style: S^T = K Q^T with
+//                      v_mfma_f32_32x32x2_f32 so that a lane owns ONE query column (row max / row sum are lane-local plus one
+//                      cross-half exchange), and the P^T accumulator registers are directly the B operand of O^T += V^T P^T.
+//                      The 4 waves of a workgroup split the key tiles and merge (m, l, O) through LDS.  Serves RPE self
+//                      attention (with bias), plain cross attention (vanilla_transformer.py:39-85, optionally per-anchor
+//                      values) and, looped over key anchors, the equivariant cross attention.
+//   cross_eq_stats     g[a, e] = sum_{n,m} (mean_h q_a.k_e / sqrt(d))^2 (vanilla_transformer.py:380-389,425-426), partial
+//                      sums per workgroup (deterministic two-stage reduction).
+//   cross_eq_apply     out[a] = sum_e W[a, e] softmax_m(S[a, e]) v_e (vanilla_transformer.py:812-818; r_soft collapsed from
+//                      24 rotations to the (A, A) anchor pairs, :506-577,839-845).
+#include <type_traits>
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float f4get(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+
+// =====================================================================================================================
+// rpe_bias_kernel
+// =====================================================================================================================
+template <int CT, int RT>   // CT = C / 16 ; RT = row tiles of 16 folded queries (1: AH <= 16, 2: AH <= 32)
+__global__ __launch_bounds__(256) void rpe_bias_kernel(const float* __restrict__ qp, const float* __restrict__ qe,
+                                                       const float* __restrict__ emb, const float* __restrict__ eq_emb,
+                                                       int N, int M, int AH, int H, int Mp, float* __restrict__ bias) {
+  constexpr int C = CT * 16;
+  __shared__ float4 afrag[RT][CT][64];
+  __shared__ float4 qe_s[32];
+  const int n = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  // folded queries of row n -> LDS in fragment order: afrag[rt][t][kq*16 + r] = qp[n, 16 rt + r, 16 t + 4 kq .. +3]
+  for (int i = threadIdx.x; i < RT * 16 * (C / 4); i += 256) {
+    const int row = i / (C / 4), c4 = i - row * (C / 4);
+    const int t = c4 >> 2, kq = c4 & 3;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < AH) v = ld4(qp + ((size_t)n * AH + row) * C + 4 * c4);
+    afrag[row >> 4][t][kq * 16 + (row & 15)] = v;
+  }
+  if (threadIdx.x < 32) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (qe != nullptr && threadIdx.x < AH) v = ld4(qe + ((size_t)n * AH + threadIdx.x) * 4);
+    qe_s[threadIdx.x] = v;
+  }
+  __syncthreads();
+
+  const int tiles = (M + 15) >> 4;
+  const int per = (tiles + gridDim.y - 1) / gridDim.y;
+  const int t_begin = blockIdx.y * per, t_end = min(tiles, t_begin + per);
+  const int col = lane & 15, kq = lane >> 4;
+  const float* Erow0 = emb + (size_t)n * M * C;
+  for (int tile = t_begin + wave; tile < t_end; tile += 4) {
+    const int m0 = tile << 4;
+    const int mrow = min(m0 + col, M - 1);
+    const float* Er = Erow0 + (size_t)mrow * C + 4 * kq;
+    float4 b[CT];
+#pragma unroll
+    for (int t = 0; t < CT; t++) b[t] = ld4(Er + 16 * t);
+    f32x4 acc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < CT; t++) {
+      float4 a[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++) a[rt] = afrag[rt][t][lane];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+          acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(a[rt], i), f4get(b[t], i), acc[rt], 0, 0, 0);
+      }
+    }
+    const int m = m0 + col;
+    if (m < M) {
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int row = 16 * rt + 4 * kq + j;
+          if (row < AH) {
+            float val = acc[rt][j];
+            if (eq_emb != nullptr) {
+              const int a = row / H;
+              const float4 e = ld4(eq_emb + (((size_t)a * N + n) * M + m) * 4);
+              const float4 w = qe_s[row];
+              val += (w.x * e.x + w.y * e.y) + (w.z * e.z + w.w * e.w);
+            }
+            bias[((size_t)row * N + n) * Mp + m] = val;
+          }
+        }
+      }
+    }
+  }
+}
+
+// =====================================================================================================================
+// flash-style core: one wave, one 32-query tile, a strided set of 32-key tiles
+// =====================================================================================================================
+template <int D>
+struct FlashState {
+  static constexpr int DT = (D + 31) / 32;
+  static constexpr int KU = D / 8;
+  float m, l;
+  f32x16 o[DT];
+};
+
+// q/k/v point at the (anchor, head) slice: row stride = C floats.  bias (may be null) points at the (ah) slice, row stride Mp.
+template <int D>
+__device__ __forceinline__ void flash_tiles(FlashState<D>& st, const float* __restrict__ q, const float* __restrict__ k,
+                                            const float* __restrict__ v, const float* __restrict__ bias, int n0, int N, int M,
+                                            int C, int Mp, float scale, int tile_begin, int tile_step) {
+  constexpr int DT = FlashState<D>::DT, KU = FlashState<D>::KU;
+  const int lane = threadIdx.x & 63, half = lane >> 5, c32 = lane & 31;
+  const int nq = min(n0 + c32, N - 1);
+  float4 qf[KU];
+#pragma unroll
+  for (int u = 0; u < KU; u++) qf[u] = ld4(q + (size_t)nq * C + 8 * u + 4 * half);
+  const int tiles = (M + 31) >> 5;
+  for (int tile = tile_begin; tile < tiles; tile += tile_step) {
+    const int m0 = tile << 5;
+    const int kr = min(m0 + c32, M - 1);
+    float4 kf[KU];
+#pragma unroll
+    for (int u = 0; u < KU; u++) kf[u] = ld4(k + (size_t)kr * C + 8 * u + 4 * half);
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; r++) s[r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < KU; u++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) s = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(kf[u], i), f4get(qf[u], i), s, 0, 0, 0);
+    // s[r] = S^T[key = (r&3) + 8 (r>>2) + 4 half][query = c32]
+    float mx = -INFINITY;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bias != nullptr) b4 = ld4(bias + (size_t)nq * Mp + m0 + 8 * g + 4 * half);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int key = m0 + 8 * g + 4 * half + j;
+        float val = (s[4 * g + j] + f4get(b4, j)) * scale;
+        val = key < M ? val : -INFINITY;
+        s[4 * g + j] = val;
+        mx = fmaxf(mx, val);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(st.m, mx);
+    const float alpha = __expf(st.m - m_new);        // st.m = -inf on the first tile -> 0
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      s[r] = __expf(s[r] - m_new);
+      ps += s[r];
+    }
+    ps += __shfl_xor(ps, 32);
+    st.l = st.l * alpha + ps;
+    st.m = m_new;
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) st.o[dt][r] *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int key = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int vr = min(m0 + key, M - 1);
+        const int dd = 32 * dt + c32;
+        const float a = dd < D ? v[(size_t)vr * C + dd] : 0.f;
+        st.o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[r], st.o[dt], 0, 0, 0);
+      }
+    }
+  }
+}
+
+template <int D>
+__device__ __forceinline__ void flash_init(FlashState<D>& st) {
+  st.m = -INFINITY;
+  st.l = 0.f;
+#pragma unroll
+  for (int dt = 0; dt < FlashState<D>::DT; dt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) st.o[dt][r] = 0.f;
+}
+
+// merge the states of the 4 waves of a workgroup into wave 0 (through LDS); returns normalised output in st (wave 0 only)
+template <int D>
+__device__ __forceinline__ void flash_merge4(FlashState<D>& st, float* sm, float* sl, float* so) {
+  constexpr int DT = FlashState<D>::DT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  sm[wave * 64 + lane] = st.m;
+  sl[wave * 64 + lane] = st.l;
+#pragma unroll
+  for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) so[((wave * DT + dt) * 16 + r) * 64 + lane] = st.o[dt][r];
+  __syncthreads();
+  if (wave == 0) {
+    float mt = fmaxf(fmaxf(sm[lane], sm[64 + lane]), fmaxf(sm[128 + lane], sm[192 + lane]));
+    float lt = 0.f;
+    float f[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      f[w] = __expf(sm[w * 64 + lane] - mt);
+      lt += sl[w * 64 + lane] * f[w];
+    }
+    const float inv = 1.f / lt;
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; w++) acc += so[((w * DT + dt) * 16 + r) * 64 + lane] * f[w];
+        st.o[dt][r] = acc * inv;
+      }
+    st.m = mt;
+    st.l = lt;
+  }
+}
+
+template <int D>
+__device__ __forceinline__ void flash_store(const FlashState<D>& st, float* __restrict__ out, int n0, int N, int C,
+                                            float weight, bool accumulate) {
+  constexpr int DT = FlashState<D>::DT;
+  const int lane = threadIdx.x & 63, half = lane >> 5, c32 = lane & 31;
+  const int nq = n0 + c32;
+  if (nq >= N) return;
+#pragma unroll
+  for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const int dd = 32 * dt + 8 * g + 4 * half;
+      if (dd < D) {
+        float4* p = reinterpret_cast<float4*>(out + (size_t)nq * C + dd);
+        float4 val = make_float4(st.o[dt][4 * g] * weight, st.o[dt][4 * g + 1] * weight, st.o[dt][4 * g + 2] * weight,
+                                 st.o[dt][4 * g + 3] * weight);
+        if (accumulate) {
+          const float4 old = *p;
+          val = make_float4(val.x + old.x, val.y + old.y, val.z + old.z, val.w + old.w);
+        }
+        *p = val;
+      }
+    }
+}
+
+struct AttnArgs {
+  const float *q, *k, *v, *bias;
+  float* out;
+  int N, M, C, H, Mp;
+  long long q_sa, k_sa, v_sa, o_sa;   // anchor strides in floats (0 = shared by all anchors)
+  float scale;
+};
+
+// grid (ceil(N/32), H, A_out)
+template <int D>
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
+  __shared__ float sm[256], sl[256];
+  __shared__ float so[4 * FlashState<D>::DT * 16 * 64];
+  const int n0 = blockIdx.x * 32, h = blockIdx.y, a = blockIdx.z;
+  const int wave = threadIdx.x >> 6;
+  FlashState<D> st;
+  flash_init(st);
+  const float* bias = p.bias ? p.bias + ((size_t)(a * p.H + h) * p.N) * p.Mp : nullptr;
+  flash_tiles<D>(st, p.q + a * p.q_sa + h * D, p.k + a * p.k_sa + h * D, p.v + a * p.v_sa + h * D, bias, n0, p.N, p.M, p.C,
+                 p.Mp, p.scale, wave, 4);
+  flash_merge4<D>(st, sm, sl, so);
+  if (wave == 0) flash_store<D>(st, p.out + a * p.o_sa + h * D, n0, p.N, p.C, 1.f, false);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// equivariant cross attention
+// ---------------------------------------------------------------------------------------------------------------------
+// grid (ceil(N/32), A*A): partial[blockIdx] = sum over the tile's (n, m) of (mean_h S[a,e,h,n,m])^2
+template <int D>
+__global__ __launch_bounds__(256) void cross_eq_stats_kernel(const float* __restrict__ q, const float* __restrict__ k, int A,
+                                                             int N, int M, int C, int H, float scale,
+                                                             float* __restrict__ partial) {
+  constexpr int KU = D / 8;
+  __shared__ float red[4];
+  const int n0 = blockIdx.x * 32, ae = blockIdx.y, a = ae / A, e = ae - a * A;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, c32 = lane & 31;
+  const int nq = min(n0 + c32, N - 1);
+  const int tiles = (M + 31) >> 5;
+  float total = 0.f;
+  for (int tile = wave; tile < tiles; tile += 4) {
+    const int m0 = tile << 5;
+    const int kr = min(m0 + c32, M - 1);
+    f32x16 mean;
+#pragma unroll
+    for (int r = 0; r < 16; r++) mean[r] = 0.f;
+    for (int h = 0; h < H; h++) {
+      const float* qh = q + ((size_t)a * N + nq) * C + h * D;
+      const float* kh = k + ((size_t)e * M + kr) * C + h * D;
+#pragma unroll
+      for (int u = 0; u < KU; u++) {
+        const float4 kf = ld4(kh + 8 * u + 4 * half), qf = ld4(qh + 8 * u + 4 * half);
+#pragma unroll
+        for (int i = 0; i < 4; i++) mean = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(kf, i), f4get(qf, i), mean, 0, 0, 0);
+      }
+    }
+    const float f = scale / (float)H;
+    const bool qok = n0 + c32 < N;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int key = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float val = mean[r] * f;
+      total += (qok && key < M) ? val * val : 0.f;
+    }
+  }
+  total = se3_wave_sum(total);
+  if (lane == 0) red[wave] = total;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// grid (ceil(N/32), H, A): out[a, n, h] = sum_e mix[a, e] softmax_m(q_a.k_e * scale) v_e ; waves split the key anchors e
+template <int D>
+__global__ __launch_bounds__(256) void cross_eq_apply_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                             const float* __restrict__ v, const float* __restrict__ mix,
+                                                             int A, int N, int M, int C, float scale, float* __restrict__ out) {
+  constexpr int DT = FlashState<D>::DT;
+  __shared__ float so[4 * DT * 16 * 64];
+  const int n0 = blockIdx.x * 32, h = blockIdx.y, a = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  FlashState<D> tot;
+  flash_init(tot);
+  for (int e = wave; e < A; e += 4) {
+    FlashState<D> st;
+    flash_init(st);
+    flash_tiles<D>(st, q + (size_t)a * N * C + h * D, k + (size_t)e * M * C + h * D, v + (size_t)e * M * C + h * D, nullptr,
+                   n0, N, M, C, 0, scale, 0, 1);
+    const float w = mix[a * A + e] / st.l;
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) tot.o[dt][r] += st.o[dt][r] * w;
+  }
+#pragma unroll
+  for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) so[((wave * DT + dt) * 16 + r) * 64 + lane] = tot.o[dt][r];
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; w++) acc += so[((w * DT + dt) * 16 + r) * 64 + lane];
+        tot.o[dt][r] = acc;
+      }
+    flash_store<D>(tot, out + (size_t)a * N * C + h * D, n0, N, C, 1.f, false);
+  }
+}
+
+template <typename F>
+int dispatch_head_dim(int D, F&& f, const char* what) {
+  switch (D) {
+    case 8: f(std::integral_constant<int, 8>()); return SE3_OK;
+    case 16: f(std::integral_constant<int, 16>()); return SE3_OK;
+    case 32: f(std::integral_constant<int, 32>()); return SE3_OK;
+    case 64: f(std::integral_constant<int, 64>()); return SE3_OK;
+    default:
+      se3_set_error("%s: head dim %d not in {8, 16, 32, 64}", what, D);
+      return SE3_ERR_UNSUPPORTED;
+  }
+}
+
+}  // namespace
+
+extern "C" int se3_rpe_bias_fwd(const float* qp, const float* qe, const float* emb, const float* eq_emb, int N, int M, int C,
+                                int AH, int H, int bias_row_stride, float* bias, void* stream) {
+  SE3_REQUIRE(qp && emb && bias, SE3_ERR_INVALID_ARG, "rpe_bias: null pointer");
+  SE3_REQUIRE((qe == nullptr) == (eq_emb == nullptr), SE3_ERR_INVALID_ARG, "rpe_bias: qe and eq_emb go together");
+  SE3_REQUIRE(N >= 1 && M >= 1 && AH >= 1 && AH <= 32 && H >= 1 && AH % H == 0, SE3_ERR_UNSUPPORTED,
+              "rpe_bias: N %d M %d AH %d H %d", N, M, AH, H);
+  SE3_REQUIRE(bias_row_stride >= M, SE3_ERR_INVALID_ARG, "rpe_bias: bias row stride < M");
+  hipStream_t st = (hipStream_t)stream;
+  int split = (768 + N - 1) / N;
+  const int tiles = (M + 15) / 16;
+  if (split > (tiles + 3) / 4) split = (tiles + 3) / 4;
+  if (split < 1) split = 1;
+  dim3 grid((unsigned)N, (unsigned)split);
+#define SE3_BIAS_LAUNCH(CT)                                                                                          \
+  if (AH <= 16)                                                                                                      \
+    rpe_bias_kernel<CT, 1><<<grid, 256, 0, st>>>(qp, qe, emb, eq_emb, N, M, AH, H, bias_row_stride, bias);           \
+  else                                                                                                               \
+    rpe_bias_kernel<CT, 2><<<grid, 256, 0, st>>>(qp, qe, emb, eq_emb, N, M, AH, H, bias_row_stride, bias);
+  switch (C) {
+    case 32: SE3_BIAS_LAUNCH(2) break;
+    case 64: SE3_BIAS_LAUNCH(4) break;
+    case 128: SE3_BIAS_LAUNCH(8) break;
+    case 256: SE3_BIAS_LAUNCH(16) break;
+    default:
+      se3_set_error("rpe_bias: channels %d not in {32, 64, 128, 256}", C);
+      return SE3_ERR_UNSUPPORTED;
+  }
+#undef SE3_BIAS_LAUNCH
+  SE3_CHECK_LAUNCH("rpe_bias");
+  return SE3_OK;
+}
+
+extern "C" int se3_attention_fwd(const float* q, const float* k, const float* v, const float* bias, int num_anchors, int N,
+                                 int M, int C, int H, int64_t q_anchor_stride, int64_t k_anchor_stride,
+                                 int64_t v_anchor_stride, int64_t out_anchor_stride, int bias_row_stride, float scale,
+                                 float* out, void* stream) {
+  SE3_REQUIRE(q && k && v && out, SE3_ERR_INVALID_ARG, "attention: null pointer");
+  SE3_REQUIRE(num_anchors >= 1 && N >= 1 && M >= 1 && H >= 1 && C % H == 0, SE3_ERR_INVALID_ARG, "attention: bad sizes");
+  SE3_REQUIRE(bias == nullptr || (bias_row_stride >= ((M + 31) / 32) * 32 && bias_row_stride % 4 == 0), SE3_ERR_INVALID_ARG,
+              "attention: bias rows must be padded to a multiple of 32 keys");
+  AttnArgs p{q, k, v, bias, out, N, M, C, H, bias_row_stride, q_anchor_stride, k_anchor_stride, v_anchor_stride,
+             out_anchor_stride, scale};
+  dim3 grid((unsigned)((N + 31) / 32), (unsigned)H, (unsigned)num_anchors);
+  hipStream_t st = (hipStream_t)stream;
+  int rc = dispatch_head_dim(C / H, [&](auto d) { attention_kernel<decltype(d)::value><<<grid, 256, 0, st>>>(p); },
+                             "attention");
+  if (rc != SE3_OK) return rc;
+  SE3_CHECK_LAUNCH("attention");
+  return SE3_OK;
+}
+
+extern "C" int se3_cross_eq_stats(const float* q, const float* k, int A, int N, int M, int C, int H, float scale,
+                                  float* partial, int* num_partials_per_pair, void* stream) {
+  SE3_REQUIRE(q && k && partial && num_partials_per_pair, SE3_ERR_INVALID_ARG, "cross_eq_stats: null pointer");
+  SE3_REQUIRE(A >= 1 && N >= 1 && M >= 1 && H >= 1 && C % H == 0, SE3_ERR_INVALID_ARG, "cross_eq_stats: bad sizes");
+  dim3 grid((unsigned)((N + 31) / 32), (unsigned)(A * A));
+  *num_partials_per_pair = (int)grid.x;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = dispatch_head_dim(C / H, [&](auto d) {
+    cross_eq_stats_kernel<decltype(d)::value><<<grid, 256, 0, st>>>(q, k, A, N, M, C, H, scale, partial);
+  }, "cross_eq_stats");
+  if (rc != SE3_OK) return rc;
+  SE3_CHECK_LAUNCH("cross_eq_stats");
+  return SE3_OK;
+}
+
+extern "C" int se3_cross_eq_apply(const float* q, const float* k, const float* v, const float* mix, int A, int N, int M, int C,
+                                  int H, float scale, float* out, void* stream) {
+  SE3_REQUIRE(q && k && v && mix && out, SE3_ERR_INVALID_ARG, "cross_eq_apply: null pointer");
+  SE3_REQUIRE(A >= 1 && N >= 1 && M >= 1 && H >= 1 && C % H == 0, SE3_ERR_INVALID_ARG, "cross_eq_apply: bad sizes");
+  dim3 grid((unsigned)((N + 31) / 32), (unsigned)H, (unsigned)A);
+  hipStream_t st = (hipStream_t)stream;
+  int rc = dispatch_head_dim(C / H, [&](auto d) {
+    cross_eq_apply_kernel<decltype(d)::value><<<grid, 256, 0, st>>>(q, k, v, mix, A, N, M, C, scale, out);
+  }, "cross_eq_apply");
+  if (rc != SE3_OK) return rc;
+  SE3_CHECK_LAUNCH("cross_eq_apply");
+  return SE3_OK;
+}

@@ -8,6 +8,26 @@ import torch
 from ._lib import check, lib
 
 
+# ---- optional per-kernel timing with HIP events on the launch stream (enabled by bench.py) -----------------------------
+KERNEL_TIMINGS = None          # dict name -> list of (start_event, end_event, algorithmic_bytes) while enabled
+
+
+class _timed:
+    def __init__(self, name, nbytes):
+        self.name, self.nbytes = name, nbytes
+
+    def __enter__(self):
+        if KERNEL_TIMINGS is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream())
+
+    def __exit__(self, *exc):
+        if KERNEL_TIMINGS is not None:
+            self.e1.record(torch.cuda.current_stream())
+            KERNEL_TIMINGS.setdefault(self.name, []).append((self.e0, self.e1, self.nbytes))
+        return False
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -96,20 +116,6 @@ def _gpu(t, name):
 
 
 @_interim
-def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, sigma):
-    _gpu(x, 'x')
-    s_pad = torch.cat((s_pts, torch.full_like(s_pts[:1], 1e6)), 0)
-    nbr = s_pad[idx] - q_pts[:, None, :]
-    infl = torch.clamp(1 - torch.sqrt(((nbr[:, :, None, :] - kernel_points) ** 2).sum(-1)) / sigma, min=0.0)
-    x_pad = torch.cat((x, torch.zeros_like(x[:1])), 0)
-    feats = torch.einsum('pnac,pnk->pkac', x_pad[idx], infl)
-    K, R = kidx.shape
-    A = ridx.shape[0]
-    w_full = weights[kidx[:, None, :].expand(K, A, R), ridx[None].expand(K, A, R)]
-    return torch.einsum('pkac,karcd->prd', feats, w_full)
-
-
-@_interim
 def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, k):
     _gpu(points, 'points')
     xy = points @ points.t()
@@ -148,51 +154,6 @@ def _split_heads(x, h):
 def _merge_heads(x):
     x = x.transpose(-2, -3)
     return x.reshape(*x.shape[:-2], -1)
-
-
-@_interim
-def rpe_attention(q, k, v, emb, w_p, eq_emb, w_eq, num_heads, return_scores):
-    _gpu(q, 'q')
-    h = num_heads
-    qh, kh, vh = _split_heads(q, h), _split_heads(k, h), _split_heads(v, h)           # ([A,] H, N, d)
-    d = qh.shape[-1]
-    C = q.shape[-1]
-    qp = torch.einsum('...hnd,hdc->...hnc', qh, w_p.view(h, d, C))                      # folded position query
-    s = qh @ kh.transpose(-1, -2) + torch.einsum('...hnc,nmc->...hnm', qp, emb)
-    if eq_emb is not None:
-        qe = torch.einsum('ahnd,hde->ahne', qh, w_eq.view(h, d, -1))
-        s = s + torch.einsum('ahne,anme->ahnm', qe, eq_emb)
-    p = torch.softmax(s / d ** 0.5, -1)
-    return _merge_heads(p @ vh), (p if return_scores else None)
-
-
-@_interim
-def cross_attention(q, k, v, num_heads):
-    _gpu(q, 'q')
-    qh, kh, vh = _split_heads(q, num_heads), _split_heads(k, num_heads), _split_heads(v, num_heads)
-    p = torch.softmax(qh @ kh.transpose(-1, -2) / qh.shape[-1] ** 0.5, -1)
-    return _merge_heads(p @ vh)
-
-
-@_interim
-def cross_attention_eq(q, k, v, num_heads, mode, trace_idx):
-    _gpu(q, 'q')
-    qh, kh, vh = _split_heads(q, num_heads), _split_heads(k, num_heads), _split_heads(v, num_heads)   # (A, H, n, d)
-    s = torch.einsum('ahnc,ehmc->aehnm', qh, kh) / qh.shape[-1] ** 0.5
-    g = (s.mean(2) ** 2).mean((-2, -1))
-    A = g.shape[0]
-    if mode == 'a_soft':
-        w = g / g.sum(1, keepdim=True)
-        mix, ret = w, w
-    else:
-        ar = torch.arange(A, device=q.device)
-        wr = g[ar[None, :], trace_idx].mean(1)
-        wr = wr / wr.sum()
-        mix = torch.zeros_like(g)
-        mix.index_put_((ar[None].expand_as(trace_idx), trace_idx), wr[:, None].expand(-1, A), accumulate=True)
-        ret = wr
-    p = torch.softmax(s, -1) * mix[:, :, None, None, None]
-    return _merge_heads(torch.einsum('aehnm,ehmc->ahnc', p, vh)), ret
 
 
 @_interim
@@ -274,3 +235,126 @@ def group_norm_rows(x, weight, bias, groups, eps, leaky_slope, residual):
                                    float(leaky_slope or 0.0), out.data_ptr(), ws.data_ptr(), ws_bytes, _stream()),
           'se3_group_norm_fwd')
     return out
+
+
+_host_table_cache = {}
+
+
+def _host_table(t, dtype):
+    """Constant module tables (kernel points, permutation indices) as host arrays; cached per tensor version."""
+    key = (t.data_ptr(), t._version, tuple(t.shape))
+    hit = _host_table_cache.get(key)
+    if hit is None:
+        hit = t.detach().to('cpu', dtype).contiguous()
+        if len(_host_table_cache) > 256:
+            _host_table_cache.clear()
+        _host_table_cache[key] = hit
+    return hit
+
+
+def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, sigma):
+    """HIP gather of the slot-summed neighbourhood features (csrc/kpconv_so3.hip) + one library GEMM with the
+    (36 Cin, Cout) weight matrix."""
+    x = _req(x.contiguous(), torch.float32, 'x', 3)
+    q_pts, s_pts = _req(q_pts.contiguous(), torch.float32, 'q_pts', 2), _req(s_pts.contiguous(), torch.float32, 's_pts', 2)
+    idx = _req(idx.contiguous(), torch.int64, 'neighb_inds', 2)
+    P, NN = idx.shape
+    Ns, A, Cin = x.shape
+    Cout = weights.shape[-1]
+    if A != 6 or tuple(weights.shape[:3]) != (6, 6, Cin) or Ns != s_pts.shape[0]:
+        raise RuntimeError('kpconv_inter_so3: inconsistent shapes')
+    kp, kt, rt = _host_table(kernel_points, torch.float32), _host_table(kidx, torch.int64), _host_table(ridx, torch.int64)
+    G = torch.empty((P * 6, 36 * Cin), dtype=torch.float32, device=x.device)
+    check(lib().se3_kpconv_so3_gather(q_pts.data_ptr(), s_pts.data_ptr(), idx.data_ptr(), x.data_ptr(), kp.data_ptr(),
+                                      kt.data_ptr(), rt.data_ptr(), float(sigma), P, Ns, NN, Cin, G.data_ptr(), _stream()),
+          'se3_kpconv_so3_gather')
+    return torch.mm(G, weights.reshape(36 * Cin, Cout)).view(P, 6, Cout)
+
+
+def _attention(q, k, v, bias, A, N, M, C, H, q_sa, k_sa, v_sa, bias_stride):
+    out = torch.empty((A, N, C), dtype=torch.float32, device=q.device)
+    check(lib().se3_attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), bias.data_ptr() if bias is not None else None, A,
+                                  N, M, C, H, q_sa, k_sa, v_sa, N * C, bias_stride, 1.0 / math.sqrt(C // H), out.data_ptr(),
+                                  _stream()), 'se3_attention_fwd')
+    return out
+
+
+def rpe_attention(q, k, v, emb, w_p, eq_emb, w_eq, num_heads, return_scores):
+    """HIP (csrc/attention.hip): position logits streamed from the embedding once (se3_rpe_bias_fwd), then the
+    flash-style softmax/PV kernel (se3_attention_fwd).  The two fold GEMMs W_p^T q / W_eq^T q are library GEMMs."""
+    anchored = q.dim() == 3
+    q3 = _req((q if anchored else q.unsqueeze(0)).contiguous(), torch.float32, 'q', 3)
+    k3 = _req((k if anchored else k.unsqueeze(0)).contiguous(), torch.float32, 'k', 3)
+    v3 = _req((v if anchored else v.unsqueeze(0)).contiguous(), torch.float32, 'v', 3)
+    emb = _req(emb.contiguous(), torch.float32, 'embed_qk', 3)
+    A, N, C = q3.shape
+    M, H = k3.shape[1], num_heads
+    d = C // H
+    if tuple(emb.shape) != (N, M, C):
+        raise RuntimeError('rpe_attention: embedding shape %s != %s' % (tuple(emb.shape), (N, M, C)))
+    qh = q3.view(A, N, H, d)
+    qp = torch.einsum('anhd,hdc->nahc', qh, w_p.view(H, d, C)).contiguous()            # (N, A*H, C)
+    qe = None
+    if eq_emb is not None:
+        eq_emb = _req(eq_emb.contiguous(), torch.float32, 'embed_eq', 4)
+        if tuple(eq_emb.shape) != (A, N, M, 4):
+            raise RuntimeError('rpe_attention: equivariant embedding shape %s' % (tuple(eq_emb.shape),))
+        qe = torch.einsum('anhd,hde->nahe', qh, w_eq.view(H, d, 4)).contiguous()       # (N, A*H, 4)
+    Mp = (M + 31) // 32 * 32
+    bias = torch.empty((A * H, N, Mp), dtype=torch.float32, device=q.device)
+    with _timed('rpe_bias', 4 * (N * M * C + (A * N * M * 4 if qe is not None else 0) + A * H * N * (C + M))):
+        check(lib().se3_rpe_bias_fwd(qp.data_ptr(), qe.data_ptr() if qe is not None else None, emb.data_ptr(),
+                                     eq_emb.data_ptr() if qe is not None else None, N, M, C, A * H, H, Mp, bias.data_ptr(),
+                                     _stream()), 'se3_rpe_bias_fwd')
+    with _timed('attention', 4 * (4 * A * N * C + A * H * N * M)):
+        out = _attention(q3, k3, v3, bias, A, N, M, C, H, N * C, M * C, M * C, Mp)
+    scores = None
+    if return_scores:        # diagnostic path: the product never needs the (A, H, N, M) tensor
+        s = torch.einsum('anhd,amhd->ahnm', qh, k3.view(A, M, H, d)) + bias.view(A, H, N, Mp)[..., :M]
+        scores = torch.softmax(s / math.sqrt(d), -1)
+        scores = scores if anchored else scores[0]
+    return (out if anchored else out[0]), scores
+
+
+def cross_attention(q, k, v, num_heads):
+    """HIP: plain cross attention; v (A, M, C) applies the invariant scores to per-anchor values."""
+    q = _req(q.contiguous(), torch.float32, 'q', 2)
+    k = _req(k.contiguous(), torch.float32, 'k', 2)
+    v = _req(v.contiguous(), torch.float32, 'v')
+    N, C = q.shape
+    M = k.shape[0]
+    if v.dim() == 2:
+        return _attention(q, k, v, None, 1, N, M, C, num_heads, 0, 0, 0, 0)[0]
+    return _attention(q, k, v, None, v.shape[0], N, M, C, num_heads, 0, 0, M * C, 0)
+
+
+def cross_attention_eq(q, k, v, num_heads, mode, trace_idx):
+    """HIP: global anchor-pair statistics (se3_cross_eq_stats) + weighted per-pair softmax.V (se3_cross_eq_apply)."""
+    q = _req(q.contiguous(), torch.float32, 'q', 3)
+    k = _req(k.contiguous(), torch.float32, 'k', 3)
+    v = _req(v.contiguous(), torch.float32, 'v', 3)
+    A, N, C = q.shape
+    M, H = k.shape[1], num_heads
+    scale = 1.0 / math.sqrt(C // H)
+    P = (N + 31) // 32
+    partial = torch.empty((A * A, P), dtype=torch.float32, device=q.device)
+    nparts = ctypes.c_int(0)
+    check(lib().se3_cross_eq_stats(q.data_ptr(), k.data_ptr(), A, N, M, C, H, scale, partial.data_ptr(),
+                                   ctypes.byref(nparts), _stream()), 'se3_cross_eq_stats')
+    g = partial.sum(1).view(A, A) / float(N * M)
+    if mode == 'a_soft':
+        mix = g / g.sum(1, keepdim=True)
+        ret = mix
+    elif mode == 'r_soft':
+        ar = torch.arange(A, device=q.device)
+        wr = g[ar[None, :], trace_idx].mean(1)
+        wr = wr / wr.sum()
+        mix = torch.zeros_like(g)
+        mix.index_put_((ar[None].expand_as(trace_idx), trace_idx), wr[:, None].expand(-1, A), accumulate=True)
+        ret = wr
+    else:
+        raise RuntimeError('cross_attention_eq: mode %r' % (mode,))
+    out = torch.empty((A, N, C), dtype=torch.float32, device=q.device)
+    check(lib().se3_cross_eq_apply(q.data_ptr(), k.data_ptr(), v.data_ptr(), mix.contiguous().data_ptr(), A, N, M, C, H,
+                                   scale, out.data_ptr(), _stream()), 'se3_cross_eq_apply')
+    return out, ret

@@ -92,3 +92,139 @@ def test_gather_and_max_pool_match_oracle():
     assert torch.equal(SF.gather_rows_padded(x.cuda(), idx[:, 0].contiguous().cuda()).cpu(), want)
     want2 = torch.cat((x, torch.zeros_like(x[:1])), 0)[idx]
     assert torch.equal(SF.gather_rows_padded(x.cuda(), idx.cuda()).cpu(), want2)
+
+
+def _conv_state(Cin, Cout, radius, seed=0):
+    from se3et_amd import tables
+    g = torch.Generator().manual_seed(seed)
+    return {'kernel_points': torch.from_numpy(tables.kernel_points(radius)),
+            'weights': torch.randn(6, 6, Cin, Cout, generator=g) / (36 * Cin) ** 0.5,
+            'kidx_rot': torch.from_numpy(tables.kernel_slot_table())[:, None, :].expand(-1, 6, -1).contiguous(),
+            'ridx_rot': torch.from_numpy(tables.anchor_slot_table())[None].expand(15, -1, -1).contiguous()}
+
+
+@pytest.mark.parametrize('P,Ns,NN,Cin,Cout', [(700, 900, 19, 1, 16), (500, 500, 35, 32, 32), (300, 800, 36, 64, 64),
+                                              (120, 120, 38, 256, 256), (257, 300, 13, 8, 8)])
+def test_kpconv_matches_oracle(P, Ns, NN, Cin, Cout):
+    from oracle import se3et_oracle as O
+    from se3et_amd import functional as SF
+    g = torch.Generator().manual_seed(4)
+    radius, sigma = 0.0625, 0.05
+    s_pts = torch.rand(Ns, 3, generator=g) * 0.3
+    q_pts = s_pts[torch.randperm(Ns, generator=g)[:P]].contiguous() if P <= Ns else torch.rand(P, 3, generator=g) * 0.3
+    d = ((q_pts[:, None] - s_pts[None]) ** 2).sum(-1)
+    idx = d.topk(NN, dim=1, largest=False)[1]
+    idx[d.gather(1, idx) > radius ** 2] = Ns                      # shadow neighbours
+    x = torch.randn(Ns, 6, Cin, generator=g)
+    st = _conv_state(Cin, Cout, radius)
+    want = O.kpconv_inter_so3({'c.' + k: v for k, v in st.items()}, 'c.', q_pts, s_pts, idx, x, sigma)
+    got = SF.kpconv_inter_so3(x.cuda(), q_pts.cuda(), s_pts.cuda(), idx.cuda(), st['kernel_points'].cuda(),
+                              st['weights'].cuda(), st['kidx_rot'][:, 0, :].cuda(), st['ridx_rot'][0].cuda(), sigma).cpu()
+    assert_close(got, want, 1e-4, 'kpconv')
+
+
+def test_kpconv_matches_reference_fixture(golden_dir):
+    from se3et_amd import functional as SF
+    g = _golden(golden_dir)
+    sd = _state(g)
+    for name, blk, sigma in (('kpconv_2_2', 'encoder2_2', 0.1), ('kpconv_2_1', 'encoder2_1', 0.05)):
+        q, s, idx, x = [torch.from_numpy(g['op/%s/in%d' % (name, i)]) for i in range(4)]
+        pre = 'backbone.%s.interso3.conv.' % blk
+        got = SF.kpconv_inter_so3(x.cuda(), q.cuda(), s.cuda(), idx.long().cuda(), sd[pre + 'kernel_points'].cuda(),
+                                  sd[pre + 'weights'].cuda(), sd[pre + 'kidx_rot'][:, 0, :].cuda(),
+                                  sd[pre + 'ridx_rot'][0].cuda(), sigma).cpu()
+        assert_close(got, g['op/%s/out0' % name], 1e-4, name)
+
+
+def _attn_state(C, eq, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    st = {}
+    for n in ('q', 'k', 'v', 'p'):
+        st['l.proj_%s.weight' % n] = torch.randn(C, C, generator=g) / C ** 0.5
+        st['l.proj_%s.bias' % n] = torch.randn(C, generator=g) * 0.1
+    if eq:
+        st['l.proj_eq.weight'] = torch.randn(C, 4, generator=g) * 0.5
+        st['l.proj_eq.bias'] = torch.randn(C, generator=g) * 0.1
+    return st
+
+
+@pytest.mark.parametrize('A,N,C,H,eq', [(6, 59, 32, 4, True), (6, 382, 256, 4, True), (1, 304, 256, 4, False),
+                                        (6, 100, 128, 4, True), (1, 33, 128, 4, False), (6, 17, 64, 4, True)])
+def test_rpe_attention_matches_oracle(A, N, C, H, eq):
+    from oracle import se3et_oracle as O
+    from se3et_amd import functional as SF
+    g = torch.Generator().manual_seed(5)
+    st = _attn_state(C, eq)
+    x = torch.randn((A, N, C) if A > 1 else (N, C), generator=g)
+    emb = torch.randn(N, N, C, generator=g)
+    eq_emb = torch.randn(A, N, N, 4, generator=g) if eq else None
+    want, want_scores = O.rpe_attention(st, 'l.', x, x, emb, eq_emb, H)
+    lin = lambda n: torch.nn.functional.linear(x, st['l.proj_%s.weight' % n], st['l.proj_%s.bias' % n]).cuda()
+    got, scores = SF.rpe_attention(lin('q'), lin('k'), lin('v'), emb.cuda(), st['l.proj_p.weight'].cuda(),
+                                   eq_emb.cuda() if eq else None, st['l.proj_eq.weight'].cuda() if eq else None, H,
+                                   return_scores=True)
+    assert_close(got.cpu(), want, 1e-4, 'rpe attention hidden')
+    assert_close(scores.cpu(), want_scores, 1e-4, 'rpe attention scores')
+
+
+def test_rpe_attention_matches_reference_fixture(golden_dir):
+    from se3et_amd import functional as SF
+    g = _golden(golden_dir)
+    sd = _state(g)
+    emb, eq_emb = torch.from_numpy(g['op/embedding/out0'])[0], torch.from_numpy(g['op/embedding/out1'])[0]
+    for layer, eq in ((0, True), (4, False)):
+        pre = 'transformer.transformer.layers.%d.attention.attention.' % layer
+        x = torch.from_numpy(g['op/attn_%d/in0' % layer])[0]
+        lin = lambda n: torch.nn.functional.linear(x, sd[pre + 'proj_%s.weight' % n], sd[pre + 'proj_%s.bias' % n]).cuda()
+        got, scores = SF.rpe_attention(lin('q'), lin('k'), lin('v'), emb.cuda(), sd[pre + 'proj_p.weight'].cuda(),
+                                       eq_emb.cuda() if eq else None, sd[pre + 'proj_eq.weight'].cuda() if eq else None, 4,
+                                       return_scores=True)
+        assert_close(got.cpu(), g['op/attn_%d/out0' % layer][0], 1e-4, 'layer %d hidden' % layer)
+        assert_close(scores.cpu(), g['op/attn_%d/out1' % layer][0], 1e-4, 'layer %d scores' % layer)
+
+
+@pytest.mark.parametrize('A,N,M,C,H', [(1, 59, 53, 32, 4), (6, 382, 304, 256, 4), (6, 304, 382, 256, 4), (1, 40, 700, 128, 4)])
+def test_cross_attention_matches_oracle(A, N, M, C, H):
+    from se3et_amd import functional as SF
+    g = torch.Generator().manual_seed(6)
+    q, k = torch.randn(N, C, generator=g), torch.randn(M, C, generator=g)
+    v = torch.randn((A, M, C) if A > 1 else (M, C), generator=g)
+    hs = lambda t: t.reshape(*t.shape[:-1], H, -1).transpose(-2, -3)
+    p = torch.softmax(hs(q) @ hs(k).transpose(-1, -2) / (C // H) ** 0.5, -1)
+    want = (p @ hs(v)).transpose(-2, -3)
+    want = want.reshape(*want.shape[:-2], -1)
+    got = SF.cross_attention(q.cuda(), k.cuda(), v.cuda(), H).cpu()
+    assert_close(got, want, 1e-4, 'cross attention')
+
+
+@pytest.mark.parametrize('N,M,C,mode', [(59, 53, 32, 'a_soft'), (59, 53, 32, 'r_soft'), (382, 304, 256, 'a_soft'),
+                                        (304, 382, 256, 'r_soft'), (100, 37, 128, 'r_soft')])
+def test_cross_attention_eq_matches_oracle(N, M, C, mode):
+    from oracle import se3et_oracle as O
+    from se3et_amd import functional as SF
+    from se3et_amd import tables
+    g = torch.Generator().manual_seed(7)
+    H = 4
+    trace = torch.from_numpy(tables.trace_indices()[0])
+    q, k, v = torch.randn(6, N, C, generator=g), torch.randn(6, M, C, generator=g), torch.randn(6, M, C, generator=g)
+    hs = lambda t: t.reshape(*t.shape[:-1], H, -1).transpose(-2, -3)
+    qh, kh, vh = hs(q), hs(k), hs(v)
+    s = torch.einsum('ahnc,ehmc->aehnm', qh, kh) / (C // H) ** 0.5
+    gg = (s.mean(2) ** 2).mean((-2, -1))
+    p = torch.softmax(s, -1)
+    if mode == 'a_soft':
+        w = gg / gg.sum(1, keepdim=True)
+        hidden = torch.einsum('aehnm,ehmc->ahnc', p * w[:, :, None, None, None], vh)
+        want_w = w
+    else:
+        ar = torch.arange(6)
+        w = gg[ar[None, :], trace].mean(1)
+        w = w / w.sum()
+        hidden = torch.zeros_like(qh)
+        for r in range(24):
+            hidden = hidden + w[r] * torch.einsum('ahnm,ahmc->ahnc', p[ar, trace[r]], vh[trace[r]])
+        want_w = w
+    want = hidden.transpose(-2, -3).reshape(6, N, C)
+    got, got_w = SF.cross_attention_eq(q.cuda(), k.cuda(), v.cuda(), H, mode, trace.cuda())
+    assert_close(got_w.cpu(), want_w, 1e-4, 'global weights')
+    assert_close(got.cpu(), want, 1e-4, 'eq cross attention')
