@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""Benchmark of the SE3ET hot path on MI355X:  python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): SE3ET-E forward on synthetic 5k+5k point-cloud pairs (3DMatch-sized), fp32,
+name-keyed synthetic weights.  A step = one registration pair per rank: on-GPU stage pyramid (grid subsampling + 10
+radius searches) -> E2PN backbone -> geometric transformer -> superpoint matching -> Sinkhorn -> local-to-global
+registration.  The raw pairs are resident in HBM before the timed region.  Pairs are sharded round-robin over ranks with
+no collective on the data path (weak scaling); the job time is the MAX over ranks.
+
+Prints ONE JSON line: pairs/s plus a `roofline` object for the RPE self-attention kernels (HIP events on the launch
+stream, live over the timed region) and a `cpu_baseline` object (the CPU oracle timed on this box's host cores)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s is achievable
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--variant', default='se3ete')
+    ap.add_argument('--pair', default='c2_5k')
+    ap.add_argument('--cpu-baseline-pairs', type=int, default=2)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from se3et_amd import ops as se3_ops
+    from se3et_amd import sharding
+    from se3et_amd.data import precompute_data_stack_mode
+    from se3et_amd.model import create_model, load_synthetic_weights, make_cfg
+    from se3et_amd.synthetic import PAIR_PRESETS, make_pair
+
+    rank, world, local = sharding.init_distributed('nccl')
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    cfg = make_cfg(args.variant)
+    model = load_synthetic_weights(create_model(cfg)).to(dev).eval()
+    total_steps = args.steps + args.warmup
+    # this rank's pairs, uploaded before the timed region (global pair index = step * world + rank)
+    pairs = []
+    for s in range(total_steps):
+        ref, src, _ = make_pair(args.pair, index=s * world + rank)
+        pts = torch.from_numpy(np.concatenate([ref, src], 0)).to(dev)
+        pairs.append((pts, torch.tensor([len(ref), len(src)], dtype=torch.int64)))
+    feats = torch.ones((pairs[0][0].shape[0], 1), dtype=torch.float32, device=dev)
+    b = cfg.backbone
+
+    def step(i):
+        pts, lens = pairs[i]
+        data = precompute_data_stack_mode(pts, lens, b.num_stages, b.init_voxel_size, b.init_radius, cfg.neighbor_limits)
+        data['features'] = feats
+        return model(data)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    sharding.barrier(dev)
+    se3_ops.KERNEL_TIMINGS = {}
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total_steps):
+        out = step(i)
+    torch.cuda.synchronize()
+    sharding.barrier(dev)
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
+    timings, se3_ops.KERNEL_TIMINGS = se3_ops.KERNEL_TIMINGS, None
+
+    def agg(name):
+        recs = timings.get(name, [])
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
+        nbytes = sum(nb for _, _, nb in recs)
+        return len(recs), ms, nbytes
+
+    n_att, ms_att, bytes_att = agg('rpe_self_attention')
+    n_bias, ms_bias, bytes_bias = agg('rpe_bias_kernel')
+    achieved = bytes_att / (ms_att * 1e-3) / 1e9 if ms_att > 0 else 0.0
+    roofline = {
+        'kernel': 'rpe_self_attention = rpe_bias_kernel + attention_kernel (one launch pair per RPE self-attention call)',
+        'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+        'launches': n_att, 'avg_us': round(ms_att * 1e3 / max(n_att, 1), 2),
+        'algorithmic_bytes_per_launch': int(bytes_att / max(n_att, 1)),
+        'rpe_bias_kernel': {'avg_us': round(ms_bias * 1e3 / max(n_bias, 1), 2),
+                            'achieved_GBs': round(bytes_bias / (ms_bias * 1e-3) / 1e9, 1) if ms_bias > 0 else 0.0,
+                            'embedding_bytes_per_launch': int(bytes_bias / max(n_bias, 1))},
+    }
+
+    cpu_baseline = None
+    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(model, cfg, args)
+
+    if rank == 0:
+        n, dims, _ = PAIR_PRESETS[args.pair]
+        line = {
+            'metric': 'point-cloud pairs/sec (fwd), SE3ET-E 5k-pt pairs', 'value': round(world * args.steps / elapsed, 3),
+            'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'SE3ET-E forward (pyramid + backbone + transformer + matching + Sinkhorn + LGR) on '
+                                   'synthetic %d+%d-point pairs, one pair per rank per step' % (n, n),
+                       'variant': args.variant, 'pair_preset': args.pair, 'sharding': 'pairs round-robin over ranks, no collective'},
+            'roofline': roofline, 'cpu_baseline': cpu_baseline,
+        }
+        print(json.dumps(line), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+def run_cpu_baseline(model, cfg, args):
+    """The CPU oracle (a restatement of the reference algorithm, kind 'port') on a bounded sample of the same workload."""
+    from oracle import se3et_oracle as O
+    from se3et_amd.synthetic import make_pair
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))          # the small CPU ops of this path stop scaling (and thrash) beyond ~16 threads
+    torch.set_num_threads(cores)
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    g, b = cfg.geotransformer, cfg.backbone
+    oc = O.OracleConfig(num_stages=b.num_stages, init_voxel_size=b.init_voxel_size, base_radius=b.base_radius,
+                        group_norm=b.group_norm, init_dim=b.init_dim, output_dim=b.output_dim,
+                        neighbor_limits=list(cfg.neighbor_limits), num_points_in_patch=cfg.model.num_points_in_patch,
+                        gt_hidden_dim=g.hidden_dim, gt_num_heads=g.num_heads, blocks=list(g.blocks), sigma_d=g.sigma_d,
+                        sigma_a=g.sigma_a, angle_k=g.angle_k, n_level_equiv=g.n_level_equiv,
+                        lgr_topk=cfg.fine_matching.topk, lgr_acceptance_radius=cfg.fine_matching.acceptance_radius)
+
+    def one(i):
+        ref, src, _ = make_pair(args.pair, index=i)
+        pts = torch.from_numpy(np.concatenate([ref, src], 0))
+        data = O.precompute(pts, torch.tensor([len(ref), len(src)]), oc.num_stages, oc.init_voxel_size, oc.init_radius,
+                            oc.neighbor_limits)
+        data['features'] = torch.ones((pts.shape[0], 1))
+        with torch.no_grad():
+            return O.forward(state, oc, data)
+
+    t0 = time.perf_counter()
+    one(0)
+    warm = time.perf_counter() - t0
+    n_timed = args.cpu_baseline_pairs if warm < 15.0 else 0      # keep the default run within minutes on slow hosts
+    if n_timed:
+        t0 = time.perf_counter()
+        for i in range(n_timed):
+            one(i + 1)
+        dt = time.perf_counter() - t0
+    else:
+        n_timed, dt = 1, warm
+    args.cpu_baseline_pairs = n_timed
+    return {'value': round(args.cpu_baseline_pairs / dt, 4), 'unit': 'pairs/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d pair(s) of the same workload (oracle/se3et_oracle.py on PyTorch-CPU fp32, '
+                      '%d threads); the genuine reference measured 0.19 pairs/s on 8 cores (BASELINE.md)' %
+                      (args.cpu_baseline_pairs, cores)}
+
+
+if __name__ == '__main__':
+    main()

@@ -302,11 +302,13 @@ def rpe_attention(q, k, v, emb, w_p, eq_emb, w_eq, num_heads, return_scores):
         qe = torch.einsum('anhd,hde->nahe', qh, w_eq.view(H, d, 4)).contiguous()       # (N, A*H, 4)
     Mp = (M + 31) // 32 * 32
     bias = torch.empty((A * H, N, Mp), dtype=torch.float32, device=q.device)
-    with _timed('rpe_bias', 4 * (N * M * C + (A * N * M * 4 if qe is not None else 0) + A * H * N * (C + M))):
-        check(lib().se3_rpe_bias_fwd(qp.data_ptr(), qe.data_ptr() if qe is not None else None, emb.data_ptr(),
-                                     eq_emb.data_ptr() if qe is not None else None, N, M, C, A * H, H, Mp, bias.data_ptr(),
-                                     _stream()), 'se3_rpe_bias_fwd')
-    with _timed('attention', 4 * (4 * A * N * C + A * H * N * M)):
+    # algorithmic bytes of one self-attention call: q, k, v in + out, the embedding, the eq-embedding
+    survey_bytes = 4 * (4 * A * N * C + N * M * C + (A * N * M * 4 if qe is not None else 0))
+    with _timed('rpe_self_attention', survey_bytes):
+        with _timed('rpe_bias_kernel', 4 * (N * M * C + (A * N * M * 4 if qe is not None else 0))):
+            check(lib().se3_rpe_bias_fwd(qp.data_ptr(), qe.data_ptr() if qe is not None else None, emb.data_ptr(),
+                                         eq_emb.data_ptr() if qe is not None else None, N, M, C, A * H, H, Mp,
+                                         bias.data_ptr(), _stream()), 'se3_rpe_bias_fwd')
         out = _attention(q3, k3, v3, bias, A, N, M, C, H, N * C, M * C, M * C, Mp)
     scores = None
     if return_scores:        # diagnostic path: the product never needs the (A, H, N, M) tensor
