@@ -33,6 +33,7 @@ extern "C" {
 /* Library / build identification. */
 const char* se3_version(void);
 const char* se3_last_error(void);   /* text of the last failure on the calling thread */
+void se3_debug_set_bias_variant(int variant, int split);   /* benchmark tuning hook of se3_rpe_bias_fwd; (0, 0) = default */
 
 /* ---- A2: stack-mode radius neighbour search ---------------------------------------------------------------
  * Replaces geotransformer.ext.radius_neighbors (geotransformer/extensions/pybind.cpp:6-11,
@@ -109,14 +110,18 @@ int se3_kpconv_so3_gather(const float* q_pts, const float* s_pts, const int64_t*
  * (1) se3_rpe_bias_fwd streams the (N, M, C) geometric embedding once and writes the relative-position logits
  *     bias[ah, n, m] = qp[n, ah, :] . emb[n, m, :] (+ qe[n, ah, :] . eq_emb[a, n, m, :]), where qp = W_p^T q (N, AH, C) and
  *     qe = W_eq^T q (N, AH, 4) are the position projections folded onto the query (AH = anchors * heads <= 32, ah = a*H+h).
+ *     qp is passed in MFMA-fragment order qp_frag[n][rt][t][kq][r][4] = qp[n, 16 rt + r, 16 t + 4 kq .. +3] with the rows
+ *     zero-padded to 16 * RT (RT = 1 if AH <= 16 else 2): a (N, 16 RT, C) tensor viewed (N, RT, 16, C/16, 4, 4) and
+ *     permuted to (N, RT, C/16, 4, 16, 4).
  *     eq_emb (A, N, M, 4) and qe are NULL for non-equivariant layers.  bias has row stride bias_row_stride >= M.
  * (2) se3_attention_fwd: out[a, n, h*d:(h+1)*d] = softmax_m((q_a[n,h] . k_a[m,h] + bias[a*H+h, n, m]) * scale) v_a[m, h].
- *     q/k/v/out are (anchors, rows, C) with explicit anchor strides in floats (0 = the same tensor for every anchor, which
- *     is how plain cross attention vanilla_transformer.py:39-85 with per-anchor values is expressed); bias may be NULL,
- *     otherwise its row stride must be a multiple of 32 that covers M.  C / H in {8, 16, 32, 64}; C in {32,64,128,256} for (1). */
-int se3_rpe_bias_fwd(const float* qp, const float* qe, const float* emb, const float* eq_emb, int N, int M, int C, int AH,
+ *     q/k/out are (anchors, rows, C); the values are passed TRANSPOSED and key-padded, vt (anchors, C, key_stride) with
+ *     key_stride = bias_row_stride a multiple of 4 >= ceil32(M) (zero padding), so that the P.V operand loads are
+ *     contiguous.  Anchor strides are in floats (0 = the same tensor for every anchor, which is how plain cross attention
+ *     vanilla_transformer.py:39-85 with per-anchor values is expressed); bias may be NULL.  C / H in {8, 16, 32, 64}; C in {32,64,128,256} for (1). */
+int se3_rpe_bias_fwd(const float* qp_frag, const float* qe, const float* emb, const float* eq_emb, int N, int M, int C, int AH,
                      int H, int bias_row_stride, float* bias, void* stream);
-int se3_attention_fwd(const float* q, const float* k, const float* v, const float* bias, int num_anchors, int N, int M, int C,
+int se3_attention_fwd(const float* q, const float* k, const float* vt, const float* bias, int num_anchors, int N, int M, int C,
                       int H, int64_t q_anchor_stride, int64_t k_anchor_stride, int64_t v_anchor_stride,
                       int64_t out_anchor_stride, int bias_row_stride, float scale, float* out, void* stream);
 
@@ -125,11 +130,11 @@ int se3_attention_fwd(const float* q, const float* k, const float* v, const floa
  * se3_cross_eq_stats writes partial[(a*A+e) * P + i] whose sum over i is sum_{n,m} (mean_h q_a.k_e * scale)^2
  * (*num_partials_per_pair = P = ceil(N/32)); the caller turns g = sum / (N M) into the (A, A) mixing weights `mix`
  * (a_soft: g / sum_e g; r_soft: the 24 rotation weights collapsed onto anchor pairs) and se3_cross_eq_apply computes
- * out[a] = sum_e mix[a, e] softmax_m(q_a.k_e * scale) v_e. */
+ * out[a] = sum_e mix[a, e] softmax_m(q_a.k_e * scale) v_e (vt: transposed key-padded values (A, C, key_stride)). */
 int se3_cross_eq_stats(const float* q, const float* k, int A, int N, int M, int C, int H, float scale, float* partial,
                        int* num_partials_per_pair, void* stream);
-int se3_cross_eq_apply(const float* q, const float* k, const float* v, const float* mix, int A, int N, int M, int C, int H,
-                       float scale, float* out, void* stream);
+int se3_cross_eq_apply(const float* q, const float* k, const float* vt, const float* mix, int A, int N, int M, int C, int H,
+                       int key_stride, float scale, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,7 @@ _vp, _i64, _i32, _f32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctyp
 SIGNATURES = {
     'se3_version': (ctypes.c_char_p, []),
     'se3_last_error': (ctypes.c_char_p, []),
+    'se3_debug_set_bias_variant': (None, [_i32, _i32]),
     'se3_radius_neighbors': (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _f32, _i32, _vp, _vp, _vp]),
     'se3_grid_subsample_workspace_bytes': (_sz, [_i64, _i32]),
     'se3_grid_subsample': (_i32, [_vp, _vp, _i64, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -26,7 +27,7 @@ SIGNATURES = {
     'se3_rpe_bias_fwd': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     'se3_attention_fwd': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _f32, _vp, _vp]),
     'se3_cross_eq_stats': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
-    'se3_cross_eq_apply': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
+    'se3_cross_eq_apply': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     'se3_log_sinkhorn_fwd': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
 }
 

@@ -30,24 +30,20 @@ __device__ __forceinline__ float f4get(const float4& v, int i) { return i == 0 ?
 // =====================================================================================================================
 // rpe_bias_kernel
 // =====================================================================================================================
-template <int CT, int RT>   // CT = C / 16 ; RT = row tiles of 16 folded queries (1: AH <= 16, 2: AH <= 32)
-__global__ __launch_bounds__(256) void rpe_bias_kernel(const float* __restrict__ qp, const float* __restrict__ qe,
+template <int CT, int RT, bool PREFETCH, int MINW>   // CT = C / 16 ; RT = row tiles of 16 folded queries (AH <= 16 RT)
+__global__ __launch_bounds__(256, MINW) void rpe_bias_kernel(const float* __restrict__ qp_frag, const float* __restrict__ qe,
                                                        const float* __restrict__ emb, const float* __restrict__ eq_emb,
                                                        int N, int M, int AH, int H, int Mp, float* __restrict__ bias) {
   constexpr int C = CT * 16;
-  __shared__ float4 afrag[RT][CT][64];
+  __shared__ float4 afrag[RT * CT * 64];
   __shared__ float4 qe_s[32];
   const int n = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-  // folded queries of row n -> LDS in fragment order: afrag[rt][t][kq*16 + r] = qp[n, 16 rt + r, 16 t + 4 kq .. +3]
-  for (int i = threadIdx.x; i < RT * 16 * (C / 4); i += 256) {
-    const int row = i / (C / 4), c4 = i - row * (C / 4);
-    const int t = c4 >> 2, kq = c4 & 3;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < AH) v = ld4(qp + ((size_t)n * AH + row) * C + 4 * c4);
-    afrag[row >> 4][t][kq * 16 + (row & 15)] = v;
-  }
+  // folded queries of row n, already in MFMA-fragment order [rt][t][kq*16 + r] (float4 = channels 16 t + 4 kq .. +3):
+  // a straight, conflict-free copy into LDS
+  const float4* src = reinterpret_cast<const float4*>(qp_frag) + (size_t)n * (RT * CT * 64);
+  for (int i = threadIdx.x; i < RT * CT * 64; i += 256) afrag[i] = src[i];
   if (threadIdx.x < 32) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (qe != nullptr && threadIdx.x < AH) v = ld4(qe + ((size_t)n * AH + threadIdx.x) * 4);
@@ -59,14 +55,42 @@ __global__ __launch_bounds__(256) void rpe_bias_kernel(const float* __restrict__
   const int per = (tiles + gridDim.y - 1) / gridDim.y;
   const int t_begin = blockIdx.y * per, t_end = min(tiles, t_begin + per);
   const int col = lane & 15, kq = lane >> 4;
-  const float* Erow0 = emb + (size_t)n * M * C;
-  for (int tile = t_begin + wave; tile < t_end; tile += 4) {
-    const int m0 = tile << 4;
-    const int mrow = min(m0 + col, M - 1);
-    const float* Er = Erow0 + (size_t)mrow * C + 4 * kq;
-    float4 b[CT];
+  const float* Erow0 = emb + (size_t)n * M * C + 4 * kq;
+  const bool uniform_anchor = (H % 4) == 0;      // the 4 rows a lane owns in a row tile then share one anchor
+
+  int tile = t_begin + wave;
+  float4 b[CT], bn[PREFETCH ? CT : 1];
+  if (PREFETCH && tile < t_end) {
+    const float* Er = Erow0 + (size_t)min((tile << 4) + col, M - 1) * C;
 #pragma unroll
     for (int t = 0; t < CT; t++) b[t] = ld4(Er + 16 * t);
+  }
+  for (; tile < t_end; tile += 4) {
+    // compiler fence: without it the loop-invariant LDS fragment reads are hoisted out of the tile loop (128 VGPRs) and
+    // spilled to scratch -- the reads must stay inside the loop, next to their MFMAs
+    asm volatile("" ::: "memory");
+    const int m0 = tile << 4;
+    const bool more = PREFETCH && tile + 4 < t_end;
+    if (PREFETCH) {
+      if (more) {                                  // software prefetch of the next tile (second register set)
+        const float* Er = Erow0 + (size_t)min(((tile + 4) << 4) + col, M - 1) * C;
+#pragma unroll
+        for (int t = 0; t < CT; t++) bn[t] = ld4(Er + 16 * t);
+      }
+    } else {
+      const float* Er = Erow0 + (size_t)min(m0 + col, M - 1) * C;
+#pragma unroll
+      for (int t = 0; t < CT; t++) b[t] = ld4(Er + 16 * t);
+    }
+    const int m = m0 + col;
+    float4 e4[RT];
+    if (eq_emb != nullptr && uniform_anchor) {
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++) {
+        const int a = min((16 * rt + 4 * kq) / H, AH / H - 1);
+        e4[rt] = ld4(eq_emb + (((size_t)a * N + n) * M + min(m, M - 1)) * 4);
+      }
+    }
     f32x4 acc[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; rt++) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -74,7 +98,7 @@ __global__ __launch_bounds__(256) void rpe_bias_kernel(const float* __restrict__
     for (int t = 0; t < CT; t++) {
       float4 a[RT];
 #pragma unroll
-      for (int rt = 0; rt < RT; rt++) a[rt] = afrag[rt][t][lane];
+      for (int rt = 0; rt < RT; rt++) a[rt] = afrag[(rt * CT + t) * 64 + lane];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
 #pragma unroll
@@ -82,7 +106,6 @@ __global__ __launch_bounds__(256) void rpe_bias_kernel(const float* __restrict__
           acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(a[rt], i), f4get(b[t], i), acc[rt], 0, 0, 0);
       }
     }
-    const int m = m0 + col;
     if (m < M) {
 #pragma unroll
       for (int rt = 0; rt < RT; rt++) {
@@ -92,8 +115,7 @@ __global__ __launch_bounds__(256) void rpe_bias_kernel(const float* __restrict__
           if (row < AH) {
             float val = acc[rt][j];
             if (eq_emb != nullptr) {
-              const int a = row / H;
-              const float4 e = ld4(eq_emb + (((size_t)a * N + n) * M + m) * 4);
+              const float4 e = uniform_anchor ? e4[rt] : ld4(eq_emb + (((size_t)(row / H) * N + n) * M + m) * 4);
               const float4 w = qe_s[row];
               val += (w.x * e.x + w.y * e.y) + (w.z * e.z + w.w * e.w);
             }
@@ -101,6 +123,10 @@ __global__ __launch_bounds__(256) void rpe_bias_kernel(const float* __restrict__
           }
         }
       }
+    }
+    if (PREFETCH && more) {
+#pragma unroll
+      for (int t = 0; t < CT; t++) b[t] = bn[t];
     }
   }
 }
@@ -116,7 +142,41 @@ struct FlashState {
   f32x16 o[DT];
 };
 
-// q/k/v point at the (anchor, head) slice: row stride = C floats.  bias (may be null) points at the (ah) slice, row stride Mp.
+template <int D>
+struct TileRegs {
+  float4 kf[FlashState<D>::KU];
+  float4 b4[4];
+  float vv[FlashState<D>::DT * 16];
+};
+
+template <int D>
+__device__ __forceinline__ void flash_load(TileRegs<D>& r, const float* __restrict__ k, const float* __restrict__ v,
+                                           const float* __restrict__ bias_row, int m0, int M, int C, int Mp) {
+  constexpr int DT = FlashState<D>::DT, KU = FlashState<D>::KU;
+  const int lane = threadIdx.x & 63, half = lane >> 5, c32 = lane & 31;
+  const float* kr = k + (size_t)min(m0 + c32, M - 1) * C + 4 * half;
+#pragma unroll
+  for (int u = 0; u < KU; u++) r.kf[u] = ld4(kr + 8 * u);
+#pragma unroll
+  for (int g = 0; g < 4; g++)
+    r.b4[g] = bias_row ? ld4(bias_row + m0 + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int dt = 0; dt < DT; dt++) {
+    const int dd = 32 * dt + c32;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {          // keys m0 + 8 g + 4 half .. +3 are contiguous in the transposed values
+      const float4 t = dd < D ? ld4(v + (size_t)dd * Mp + m0 + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+      r.vv[dt * 16 + 4 * g + 0] = t.x;
+      r.vv[dt * 16 + 4 * g + 1] = t.y;
+      r.vv[dt * 16 + 4 * g + 2] = t.z;
+      r.vv[dt * 16 + 4 * g + 3] = t.w;
+    }
+  }
+}
+
+// q/k point at the (anchor, head) slice (row stride C floats); v points at the TRANSPOSED values of the slice, vt[dd * Mp + key]
+// (keys zero-padded to Mp, a multiple of 32).  bias (may be null) points at the (ah) slice, row stride Mp.
+// The loads of tile t+step are issued before the MFMAs of tile t (two register sets).
 template <int D>
 __device__ __forceinline__ void flash_tiles(FlashState<D>& st, const float* __restrict__ q, const float* __restrict__ k,
                                             const float* __restrict__ v, const float* __restrict__ bias, int n0, int N, int M,
@@ -127,30 +187,31 @@ __device__ __forceinline__ void flash_tiles(FlashState<D>& st, const float* __re
   float4 qf[KU];
 #pragma unroll
   for (int u = 0; u < KU; u++) qf[u] = ld4(q + (size_t)nq * C + 8 * u + 4 * half);
+  const float* bias_row = bias ? bias + (size_t)nq * Mp : nullptr;
   const int tiles = (M + 31) >> 5;
-  for (int tile = tile_begin; tile < tiles; tile += tile_step) {
+  TileRegs<D> cur, nxt;
+  int tile = tile_begin;
+  if (tile < tiles) flash_load<D>(cur, k, v, bias_row, tile << 5, M, C, Mp);
+  for (; tile < tiles; tile += tile_step) {
     const int m0 = tile << 5;
-    const int kr = min(m0 + c32, M - 1);
-    float4 kf[KU];
-#pragma unroll
-    for (int u = 0; u < KU; u++) kf[u] = ld4(k + (size_t)kr * C + 8 * u + 4 * half);
+    const bool more = tile + tile_step < tiles;
+    if (more) flash_load<D>(nxt, k, v, bias_row, (tile + tile_step) << 5, M, C, Mp);
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; r++) s[r] = 0.f;
 #pragma unroll
     for (int u = 0; u < KU; u++)
 #pragma unroll
-      for (int i = 0; i < 4; i++) s = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(kf[u], i), f4get(qf[u], i), s, 0, 0, 0);
+      for (int i = 0; i < 4; i++)
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(cur.kf[u], i), f4get(qf[u], i), s, 0, 0, 0);
     // s[r] = S^T[key = (r&3) + 8 (r>>2) + 4 half][query = c32]
     float mx = -INFINITY;
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (bias != nullptr) b4 = ld4(bias + (size_t)nq * Mp + m0 + 8 * g + 4 * half);
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int key = m0 + 8 * g + 4 * half + j;
-        float val = (s[4 * g + j] + f4get(b4, j)) * scale;
+        float val = (s[4 * g + j] + f4get(cur.b4[g], j)) * scale;
         val = key < M ? val : -INFINITY;
         s[4 * g + j] = val;
         mx = fmaxf(mx, val);
@@ -173,14 +234,9 @@ __device__ __forceinline__ void flash_tiles(FlashState<D>& st, const float* __re
 #pragma unroll
       for (int r = 0; r < 16; r++) st.o[dt][r] *= alpha;
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int key = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int vr = min(m0 + key, M - 1);
-        const int dd = 32 * dt + c32;
-        const float a = dd < D ? v[(size_t)vr * C + dd] : 0.f;
-        st.o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[r], st.o[dt], 0, 0, 0);
-      }
+      for (int r = 0; r < 16; r++) st.o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.vv[dt * 16 + r], s[r], st.o[dt], 0, 0, 0);
     }
+    if (more) cur = nxt;
   }
 }
 
@@ -194,9 +250,9 @@ __device__ __forceinline__ void flash_init(FlashState<D>& st) {
     for (int r = 0; r < 16; r++) st.o[dt][r] = 0.f;
 }
 
-// merge the states of the 4 waves of a workgroup into wave 0 (through LDS); returns normalised output in st (wave 0 only)
-template <int D>
-__device__ __forceinline__ void flash_merge4(FlashState<D>& st, float* sm, float* sl, float* so) {
+// merge the states of the NW waves of a workgroup into wave 0 (through LDS); returns normalised output in st (wave 0 only)
+template <int D, int NW>
+__device__ __forceinline__ void flash_merge(FlashState<D>& st, float* sm, float* sl, float* so) {
   constexpr int DT = FlashState<D>::DT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   sm[wave * 64 + lane] = st.m;
@@ -207,11 +263,13 @@ __device__ __forceinline__ void flash_merge4(FlashState<D>& st, float* sm, float
     for (int r = 0; r < 16; r++) so[((wave * DT + dt) * 16 + r) * 64 + lane] = st.o[dt][r];
   __syncthreads();
   if (wave == 0) {
-    float mt = fmaxf(fmaxf(sm[lane], sm[64 + lane]), fmaxf(sm[128 + lane], sm[192 + lane]));
-    float lt = 0.f;
-    float f[4];
+    float mt = -INFINITY;
 #pragma unroll
-    for (int w = 0; w < 4; w++) {
+    for (int w = 0; w < NW; w++) mt = fmaxf(mt, sm[w * 64 + lane]);
+    float lt = 0.f;
+    float f[NW];
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
       f[w] = __expf(sm[w * 64 + lane] - mt);
       lt += sl[w * 64 + lane] * f[w];
     }
@@ -222,7 +280,7 @@ __device__ __forceinline__ void flash_merge4(FlashState<D>& st, float* sm, float
       for (int r = 0; r < 16; r++) {
         float acc = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; w++) acc += so[((w * DT + dt) * 16 + r) * 64 + lane] * f[w];
+        for (int w = 0; w < NW; w++) acc += so[((w * DT + dt) * 16 + r) * 64 + lane] * f[w];
         st.o[dt][r] = acc * inv;
       }
     st.m = mt;
@@ -263,19 +321,19 @@ struct AttnArgs {
   float scale;
 };
 
-// grid (ceil(N/32), H, A_out)
-template <int D>
-__global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
-  __shared__ float sm[256], sl[256];
-  __shared__ float so[4 * FlashState<D>::DT * 16 * 64];
+// grid (ceil(N/32), H, A_out); NW waves split the key tiles of one (anchor, head, 32-query tile)
+template <int D, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attention_kernel(AttnArgs p) {
+  __shared__ float sm[64 * NW], sl[64 * NW];
+  __shared__ float so[NW * FlashState<D>::DT * 16 * 64];
   const int n0 = blockIdx.x * 32, h = blockIdx.y, a = blockIdx.z;
   const int wave = threadIdx.x >> 6;
   FlashState<D> st;
   flash_init(st);
   const float* bias = p.bias ? p.bias + ((size_t)(a * p.H + h) * p.N) * p.Mp : nullptr;
-  flash_tiles<D>(st, p.q + a * p.q_sa + h * D, p.k + a * p.k_sa + h * D, p.v + a * p.v_sa + h * D, bias, n0, p.N, p.M, p.C,
-                 p.Mp, p.scale, wave, 4);
-  flash_merge4<D>(st, sm, sl, so);
+  flash_tiles<D>(st, p.q + a * p.q_sa + h * D, p.k + a * p.k_sa + h * D, p.v + a * p.v_sa + (size_t)h * D * p.Mp, bias, n0, p.N, p.M, p.C,
+                 p.Mp, p.scale, wave, NW);
+  flash_merge<D, NW>(st, sm, sl, so);
   if (wave == 0) flash_store<D>(st, p.out + a * p.o_sa + h * D, n0, p.N, p.C, 1.f, false);
 }
 
@@ -328,8 +386,8 @@ __global__ __launch_bounds__(256) void cross_eq_stats_kernel(const float* __rest
 // grid (ceil(N/32), H, A): out[a, n, h] = sum_e mix[a, e] softmax_m(q_a.k_e * scale) v_e ; waves split the key anchors e
 template <int D>
 __global__ __launch_bounds__(256) void cross_eq_apply_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                             const float* __restrict__ v, const float* __restrict__ mix,
-                                                             int A, int N, int M, int C, float scale, float* __restrict__ out) {
+                                                             const float* __restrict__ vt, const float* __restrict__ mix,
+                                                             int A, int N, int M, int C, int Mp, float scale, float* __restrict__ out) {
   constexpr int DT = FlashState<D>::DT;
   __shared__ float so[4 * DT * 16 * 64];
   const int n0 = blockIdx.x * 32, h = blockIdx.y, a = blockIdx.z;
@@ -339,8 +397,8 @@ __global__ __launch_bounds__(256) void cross_eq_apply_kernel(const float* __rest
   for (int e = wave; e < A; e += 4) {
     FlashState<D> st;
     flash_init(st);
-    flash_tiles<D>(st, q + (size_t)a * N * C + h * D, k + (size_t)e * M * C + h * D, v + (size_t)e * M * C + h * D, nullptr,
-                   n0, N, M, C, 0, scale, 0, 1);
+    flash_tiles<D>(st, q + (size_t)a * N * C + h * D, k + (size_t)e * M * C + h * D, vt + ((size_t)e * C + h * D) * Mp, nullptr,
+                   n0, N, M, C, Mp, scale, 0, 1);
     const float w = mix[a * A + e] / st.l;
 #pragma unroll
     for (int dt = 0; dt < DT; dt++)
@@ -381,9 +439,14 @@ int dispatch_head_dim(int D, F&& f, const char* what) {
 
 }  // namespace
 
-extern "C" int se3_rpe_bias_fwd(const float* qp, const float* qe, const float* emb, const float* eq_emb, int N, int M, int C,
+static int g_bias_variant = 0;
+static int g_bias_split = 0;
+// tuning hooks (benchmarks only): kernel variant / m-split override; 0 = default
+extern "C" void se3_debug_set_bias_variant(int variant, int split) { g_bias_variant = variant; g_bias_split = split; }
+
+extern "C" int se3_rpe_bias_fwd(const float* qp_frag, const float* qe, const float* emb, const float* eq_emb, int N, int M, int C,
                                 int AH, int H, int bias_row_stride, float* bias, void* stream) {
-  SE3_REQUIRE(qp && emb && bias, SE3_ERR_INVALID_ARG, "rpe_bias: null pointer");
+  SE3_REQUIRE(qp_frag && emb && bias, SE3_ERR_INVALID_ARG, "rpe_bias: null pointer");
   SE3_REQUIRE((qe == nullptr) == (eq_emb == nullptr), SE3_ERR_INVALID_ARG, "rpe_bias: qe and eq_emb go together");
   SE3_REQUIRE(N >= 1 && M >= 1 && AH >= 1 && AH <= 32 && H >= 1 && AH % H == 0, SE3_ERR_UNSUPPORTED,
               "rpe_bias: N %d M %d AH %d H %d", N, M, AH, H);
@@ -393,12 +456,27 @@ extern "C" int se3_rpe_bias_fwd(const float* qp, const float* qe, const float* e
   const int tiles = (M + 15) / 16;
   if (split > (tiles + 3) / 4) split = (tiles + 3) / 4;
   if (split < 1) split = 1;
+  if (g_bias_split > 0) split = g_bias_split;
   dim3 grid((unsigned)N, (unsigned)split);
+#define SE3_BIAS_ARGS qp_frag, qe, emb, eq_emb, N, M, AH, H, bias_row_stride, bias
 #define SE3_BIAS_LAUNCH(CT)                                                                                          \
-  if (AH <= 16)                                                                                                      \
-    rpe_bias_kernel<CT, 1><<<grid, 256, 0, st>>>(qp, qe, emb, eq_emb, N, M, AH, H, bias_row_stride, bias);           \
-  else                                                                                                               \
-    rpe_bias_kernel<CT, 2><<<grid, 256, 0, st>>>(qp, qe, emb, eq_emb, N, M, AH, H, bias_row_stride, bias);
+  if (AH <= 16) {                                                                                                    \
+    switch (g_bias_variant) {                                                                                        \
+      case 1: rpe_bias_kernel<CT, 1, true, 2><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS); break;                           \
+      case 2: rpe_bias_kernel<CT, 1, true, 3><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS); break;                           \
+      case 3: rpe_bias_kernel<CT, 1, false, 3><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS); break;                          \
+      case 4: rpe_bias_kernel<CT, 1, false, 5><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS); break;                          \
+      default: rpe_bias_kernel<CT, 1, false, 4><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS); break;                         \
+    }                                                                                                                \
+  } else {                                                                                                           \
+    switch (g_bias_variant) {                                                                                        \
+      case 1: rpe_bias_kernel<CT, 2, true, 2><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS); break;                           \
+      case 2: rpe_bias_kernel<CT, 2, true, 3><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS); break;                           \
+      case 3: rpe_bias_kernel<CT, 2, false, 3><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS); break;                          \
+      case 4: rpe_bias_kernel<CT, 2, false, 5><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS); break;                          \
+      default: rpe_bias_kernel<CT, 2, false, 4><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS); break;                         \
+    }                                                                                                                \
+  }
   switch (C) {
     case 32: SE3_BIAS_LAUNCH(2) break;
     case 64: SE3_BIAS_LAUNCH(4) break;
@@ -419,14 +497,18 @@ extern "C" int se3_attention_fwd(const float* q, const float* k, const float* v,
                                  float* out, void* stream) {
   SE3_REQUIRE(q && k && v && out, SE3_ERR_INVALID_ARG, "attention: null pointer");
   SE3_REQUIRE(num_anchors >= 1 && N >= 1 && M >= 1 && H >= 1 && C % H == 0, SE3_ERR_INVALID_ARG, "attention: bad sizes");
-  SE3_REQUIRE(bias == nullptr || (bias_row_stride >= ((M + 31) / 32) * 32 && bias_row_stride % 4 == 0), SE3_ERR_INVALID_ARG,
-              "attention: bias rows must be padded to a multiple of 32 keys");
+  SE3_REQUIRE(bias_row_stride >= ((M + 31) / 32) * 32 && bias_row_stride % 4 == 0, SE3_ERR_INVALID_ARG,
+              "attention: the key stride (bias rows, transposed values) must be a multiple of 4 covering ceil32(M)");
   AttnArgs p{q, k, v, bias, out, N, M, C, H, bias_row_stride, q_anchor_stride, k_anchor_stride, v_anchor_stride,
              out_anchor_stride, scale};
   dim3 grid((unsigned)((N + 31) / 32), (unsigned)H, (unsigned)num_anchors);
   hipStream_t st = (hipStream_t)stream;
-  int rc = dispatch_head_dim(C / H, [&](auto d) { attention_kernel<decltype(d)::value><<<grid, 256, 0, st>>>(p); },
-                             "attention");
+  const bool wide = (M + 31) / 32 >= 6;      // enough key tiles to feed 8 waves per (anchor, head, query tile)
+  int rc = dispatch_head_dim(C / H, [&](auto d) {
+    constexpr int D = decltype(d)::value;
+    (void)wide;
+    attention_kernel<D, 4><<<grid, 256, 0, st>>>(p);
+  }, "attention");
   if (rc != SE3_OK) return rc;
   SE3_CHECK_LAUNCH("attention");
   return SE3_OK;
@@ -447,14 +529,15 @@ extern "C" int se3_cross_eq_stats(const float* q, const float* k, int A, int N, 
   return SE3_OK;
 }
 
-extern "C" int se3_cross_eq_apply(const float* q, const float* k, const float* v, const float* mix, int A, int N, int M, int C,
-                                  int H, float scale, float* out, void* stream) {
-  SE3_REQUIRE(q && k && v && mix && out, SE3_ERR_INVALID_ARG, "cross_eq_apply: null pointer");
+extern "C" int se3_cross_eq_apply(const float* q, const float* k, const float* vt, const float* mix, int A, int N, int M, int C,
+                                  int H, int key_stride, float scale, float* out, void* stream) {
+  SE3_REQUIRE(key_stride >= ((M + 31) / 32) * 32 && key_stride % 4 == 0, SE3_ERR_INVALID_ARG, "cross_eq_apply: key stride");
+  SE3_REQUIRE(q && k && vt && mix && out, SE3_ERR_INVALID_ARG, "cross_eq_apply: null pointer");
   SE3_REQUIRE(A >= 1 && N >= 1 && M >= 1 && H >= 1 && C % H == 0, SE3_ERR_INVALID_ARG, "cross_eq_apply: bad sizes");
   dim3 grid((unsigned)((N + 31) / 32), (unsigned)H, (unsigned)A);
   hipStream_t st = (hipStream_t)stream;
   int rc = dispatch_head_dim(C / H, [&](auto d) {
-    cross_eq_apply_kernel<decltype(d)::value><<<grid, 256, 0, st>>>(q, k, v, mix, A, N, M, C, scale, out);
+    cross_eq_apply_kernel<decltype(d)::value><<<grid, 256, 0, st>>>(q, k, vt, mix, A, N, M, C, key_stride, scale, out);
   }, "cross_eq_apply");
   if (rc != SE3_OK) return rc;
   SE3_CHECK_LAUNCH("cross_eq_apply");

@@ -9,6 +9,7 @@ from ._lib import check, lib
 
 
 # ---- optional per-kernel timing with HIP events on the launch stream (enabled by bench.py) -----------------------------
+TIMING_TAG = None             # optional tag (e.g. 'self') set by callers that want a separate bucket
 KERNEL_TIMINGS = None          # dict name -> list of (start_event, end_event, algorithmic_bytes) while enabled
 
 
@@ -25,6 +26,8 @@ class _timed:
         if KERNEL_TIMINGS is not None:
             self.e1.record(torch.cuda.current_stream())
             KERNEL_TIMINGS.setdefault(self.name, []).append((self.e0, self.e1, self.nbytes))
+            if TIMING_TAG is not None:
+                KERNEL_TIMINGS.setdefault(self.name + '@' + TIMING_TAG, []).append((self.e0, self.e1, self.nbytes))
         return False
 
 
@@ -271,11 +274,22 @@ def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, s
     return torch.mm(G, weights.reshape(36 * Cin, Cout)).view(P, 6, Cout)
 
 
-def _attention(q, k, v, bias, A, N, M, C, H, q_sa, k_sa, v_sa, bias_stride):
+def _transposed_values(v, Mp):
+    """(..., M, C) -> (..., C, Mp) zero-padded along the keys (operand layout of the P.V MFMAs)."""
+    M = v.shape[-2]
+    vt = torch.zeros(v.shape[:-2] + (v.shape[-1], Mp), dtype=torch.float32, device=v.device)
+    vt[..., :M] = v.transpose(-1, -2)
+    return vt
+
+
+def _attention(q, k, v, bias, A, N, M, C, H, q_sa, k_sa, v_per_anchor, Mp, timed_bytes=None):
     out = torch.empty((A, N, C), dtype=torch.float32, device=q.device)
-    check(lib().se3_attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), bias.data_ptr() if bias is not None else None, A,
-                                  N, M, C, H, q_sa, k_sa, v_sa, N * C, bias_stride, 1.0 / math.sqrt(C // H), out.data_ptr(),
-                                  _stream()), 'se3_attention_fwd')
+    vt = _transposed_values(v, Mp)
+    with _timed('attention_kernel', timed_bytes or 0):
+        check(lib().se3_attention_fwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(),
+                                      bias.data_ptr() if bias is not None else None, A, N, M, C, H, q_sa, k_sa,
+                                      C * Mp if v_per_anchor else 0, N * C, Mp, 1.0 / math.sqrt(C // H), out.data_ptr(),
+                                      _stream()), 'se3_attention_fwd')
     return out
 
 
@@ -293,7 +307,14 @@ def rpe_attention(q, k, v, emb, w_p, eq_emb, w_eq, num_heads, return_scores):
     if tuple(emb.shape) != (N, M, C):
         raise RuntimeError('rpe_attention: embedding shape %s != %s' % (tuple(emb.shape), (N, M, C)))
     qh = q3.view(A, N, H, d)
-    qp = torch.einsum('anhd,hdc->nahc', qh, w_p.view(H, d, C)).contiguous()            # (N, A*H, C)
+    AH = A * H
+    RT = 1 if AH <= 16 else 2
+    if AH > 32 or C % 16 != 0:
+        raise RuntimeError('rpe_attention: anchors*heads must be <= 32 and C a multiple of 16')
+    qp = torch.zeros((N, RT * 16, C), dtype=torch.float32, device=q.device)
+    qp[:, :AH] = torch.einsum('anhd,hdc->nahc', qh, w_p.view(H, d, C)).reshape(N, AH, C)
+    # MFMA-fragment order for the bias kernel: [n][rt][t][kq][r][4]
+    qp = qp.view(N, RT, 16, C // 16, 4, 4).permute(0, 1, 3, 4, 2, 5).contiguous()
     qe = None
     if eq_emb is not None:
         eq_emb = _req(eq_emb.contiguous(), torch.float32, 'embed_eq', 4)
@@ -302,14 +323,19 @@ def rpe_attention(q, k, v, emb, w_p, eq_emb, w_eq, num_heads, return_scores):
         qe = torch.einsum('anhd,hde->nahe', qh, w_eq.view(H, d, 4)).contiguous()       # (N, A*H, 4)
     Mp = (M + 31) // 32 * 32
     bias = torch.empty((A * H, N, Mp), dtype=torch.float32, device=q.device)
-    # algorithmic bytes of one self-attention call: q, k, v in + out, the embedding, the eq-embedding
+    # algorithmic bytes of one self-attention call: q, k, v in + out, the embedding, the eq-embedding;
+    # booked on the embedding-streaming kernel, the attention kernel is booked with 0 extra bytes (same call)
     survey_bytes = 4 * (4 * A * N * C + N * M * C + (A * N * M * 4 if qe is not None else 0))
-    with _timed('rpe_self_attention', survey_bytes):
-        with _timed('rpe_bias_kernel', 4 * (N * M * C + (A * N * M * 4 if qe is not None else 0))):
-            check(lib().se3_rpe_bias_fwd(qp.data_ptr(), qe.data_ptr() if qe is not None else None, emb.data_ptr(),
-                                         eq_emb.data_ptr() if qe is not None else None, N, M, C, A * H, H, Mp,
-                                         bias.data_ptr(), _stream()), 'se3_rpe_bias_fwd')
-        out = _attention(q3, k3, v3, bias, A, N, M, C, H, N * C, M * C, M * C, Mp)
+    with _timed('rpe_bias_kernel', survey_bytes):
+        check(lib().se3_rpe_bias_fwd(qp.data_ptr(), qe.data_ptr() if qe is not None else None, emb.data_ptr(),
+                                     eq_emb.data_ptr() if qe is not None else None, N, M, C, A * H, H, Mp,
+                                     bias.data_ptr(), _stream()), 'se3_rpe_bias_fwd')
+    global TIMING_TAG
+    TIMING_TAG = 'rpe'
+    try:
+        out = _attention(q3, k3, v3, bias, A, N, M, C, H, N * C, M * C, True, Mp, timed_bytes=0)
+    finally:
+        TIMING_TAG = None
     scores = None
     if return_scores:        # diagnostic path: the product never needs the (A, H, N, M) tensor
         s = torch.einsum('anhd,amhd->ahnm', qh, k3.view(A, M, H, d)) + bias.view(A, H, N, Mp)[..., :M]
@@ -325,9 +351,10 @@ def cross_attention(q, k, v, num_heads):
     v = _req(v.contiguous(), torch.float32, 'v')
     N, C = q.shape
     M = k.shape[0]
+    Mp = (M + 31) // 32 * 32
     if v.dim() == 2:
-        return _attention(q, k, v, None, 1, N, M, C, num_heads, 0, 0, 0, 0)[0]
-    return _attention(q, k, v, None, v.shape[0], N, M, C, num_heads, 0, 0, M * C, 0)
+        return _attention(q, k, v, None, 1, N, M, C, num_heads, 0, 0, False, Mp)[0]
+    return _attention(q, k, v, None, v.shape[0], N, M, C, num_heads, 0, 0, True, Mp)
 
 
 def cross_attention_eq(q, k, v, num_heads, mode, trace_idx):
@@ -357,6 +384,8 @@ def cross_attention_eq(q, k, v, num_heads, mode, trace_idx):
     else:
         raise RuntimeError('cross_attention_eq: mode %r' % (mode,))
     out = torch.empty((A, N, C), dtype=torch.float32, device=q.device)
-    check(lib().se3_cross_eq_apply(q.data_ptr(), k.data_ptr(), v.data_ptr(), mix.contiguous().data_ptr(), A, N, M, C, H,
-                                   scale, out.data_ptr(), _stream()), 'se3_cross_eq_apply')
+    Mp = (M + 31) // 32 * 32
+    vt = _transposed_values(v, Mp)
+    check(lib().se3_cross_eq_apply(q.data_ptr(), k.data_ptr(), vt.data_ptr(), mix.contiguous().data_ptr(), A, N, M, C, H,
+                                   Mp, scale, out.data_ptr(), _stream()), 'se3_cross_eq_apply')
     return out, ret
