@@ -136,6 +136,18 @@ int se3_cross_eq_stats(const float* q, const float* k, int A, int N, int M, int 
 int se3_cross_eq_apply(const float* q, const float* k, const float* vt, const float* mix, int A, int N, int M, int C, int H,
                        int key_stride, float scale, float* out, void* stream);
 
+/* ---- G1/G2: geometric structure embedding --------------------------------------------------------------------------
+ * Replaces GeometricStructureEmbedding.forward (geotransformer/modules/geotransformer/geotransformer.py:57-121 with
+ * transformer/positional_embedding.py:8-34).  points (N, 3); knn (N, 3) int64: the 3 nearest other points of each point.
+ * table_d / table_a: (entries, C, 2) float32 = (f, df/dx) of f(x) = W emb(x) + b sampled at x = j / entries_per_unit
+ * (built by the caller with two small GEMMs); indices beyond a table fall back to the exact sinusoid sum with
+ * w_* (C, C), b_* (C,), div_term (C/2,).  emb (N, N, C); eq_emb (num_anchors, N, N, 4) or NULL, wigner_d1 (num_anchors, 3, 3). */
+int se3_geo_embedding_fwd(const float* points, const int64_t* knn, int N, int C, const float* table_d, int d_entries,
+                          float d_entries_per_unit, const float* table_a, int a_entries, float a_entries_per_unit,
+                          float sigma_d, float sigma_a, const float* w_d, const float* b_d, const float* w_a, const float* b_a,
+                          const float* div_term, const float* wigner_d1, int num_anchors, float* emb, float* eq_emb,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

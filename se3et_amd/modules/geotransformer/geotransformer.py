@@ -32,11 +32,12 @@ class GeometricStructureEmbedding(nn.Module):
     def forward(self, points):
         if points.shape[0] != 1:
             raise NotImplementedError('batch size must be 1')
-        emb = SF.geometric_embedding(points[0], self.embedding.div_term, self.proj_d.weight, self.proj_d.bias,
-                                     self.proj_a.weight, self.proj_a.bias, self.sigma_d, self.sigma_a, self.angle_k)
+        args = (points[0], self.embedding.div_term, self.proj_d.weight, self.proj_d.bias, self.proj_a.weight,
+                self.proj_a.bias, self.sigma_d, self.sigma_a, self.angle_k)
         if self.n_level_equiv > 0:
-            return emb.unsqueeze(0), SF.equiv_embedding(points[0], self.anchors_wignerD[1]).unsqueeze(0)
-        return emb.unsqueeze(0)
+            emb, eq = SF.geometric_embedding(*args, wigner_d1=self.anchors_wignerD[1])
+            return emb.unsqueeze(0), eq.unsqueeze(0)
+        return SF.geometric_embedding(*args).unsqueeze(0)
 
 
 class GeometricTransformer(nn.Module):

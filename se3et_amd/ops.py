@@ -2,6 +2,7 @@
 (device / dtype / contiguity -> RuntimeError), allocates outputs with torch (device memory stays owned by
 PyTorch) and launches the HIP kernels on the current torch stream."""
 import ctypes
+import weakref
 
 import torch
 
@@ -116,38 +117,6 @@ def _gpu(t, name):
     if not t.is_cuda:
         raise RuntimeError('%s must be a GPU tensor (the SE3ET hot path has no CPU implementation)' % name)
     return t
-
-
-@_interim
-def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, k):
-    _gpu(points, 'points')
-    xy = points @ points.t()
-    sq = (points ** 2).sum(-1)
-    dist = torch.sqrt((sq[:, None] - 2 * xy + sq[None, :]).clamp(min=0.0))
-    knn = dist.topk(k + 1, dim=1, largest=False)[1][:, 1:]
-    ref = points[knn] - points[:, None, :]
-    anc = points[None, :, :] - points[:, None, :]
-    ref = ref[:, None].expand(-1, points.shape[0], -1, -1)
-    anc = anc[:, :, None].expand_as(ref)
-    ang = torch.atan2(torch.linalg.norm(torch.cross(ref, anc, dim=-1), dim=-1), (ref * anc).sum(-1))
-
-    def emb(v):
-        om = v.reshape(-1, 1, 1) * div_term.view(1, -1, 1)
-        return torch.cat((torch.sin(om), torch.cos(om)), 2).reshape(*v.shape, 2 * div_term.numel())
-    d = F.linear(emb(dist / sigma_d), w_d, b_d)
-    a = F.linear(emb(ang * (180.0 / (sigma_a * math.pi))), w_a, b_a).amax(2)
-    return d + a
-
-
-@_interim
-def equiv_embedding(points, wigner_d1):
-    _gpu(points, 'points')
-    diff = points[:, None, :] - points[None, :, :]
-    y1 = math.sqrt(3.0 / (4.0 * math.pi)) * F.normalize(diff, dim=-1)
-    out = torch.empty((wigner_d1.shape[0],) + diff.shape[:2] + (4,), dtype=points.dtype, device=points.device)
-    out[..., 0] = 0.5 / math.sqrt(math.pi)
-    out[..., 1:] = torch.einsum('acd,nmd->anmc', wigner_d1, y1)
-    return out
 
 
 def _split_heads(x, h):
@@ -389,3 +358,59 @@ def cross_attention_eq(q, k, v, num_heads, mode, trace_idx):
     check(lib().se3_cross_eq_apply(q.data_ptr(), k.data_ptr(), vt.data_ptr(), mix.contiguous().data_ptr(), A, N, M, C, H,
                                    Mp, scale, out.data_ptr(), _stream()), 'se3_cross_eq_apply')
     return out, ret
+
+
+_EMB_D_RANGE, _EMB_D_PER_UNIT = 64.0, 64.0        # distance-index table: [0, 64) index units, 64 entries per unit
+_EMB_A_PER_UNIT = 64.0
+_emb_table_cache = {}
+
+
+def _embedding_table(weight, bias, div_term, x_max, per_unit):
+    """(entries, C, 2): f(x) = W emb(x) + b and f'(x) at x = j / per_unit, j = 0 .. x_max * per_unit (two library GEMMs,
+    cached per weight version -- rebuilt automatically after an optimizer step)."""
+    key = (id(weight), weight._version, id(bias), bias._version, float(x_max), float(per_unit))
+    hit = _emb_table_cache.get(key)
+    tab = hit[0] if hit is not None and hit[1]() is weight and hit[2]() is bias else None     # ids can be recycled
+    if tab is None:
+        n = int(math.ceil(x_max * per_unit)) + 2
+        x = torch.arange(n, device=weight.device, dtype=torch.float64) / per_unit
+        om = x[:, None] * div_term.double()[None, :]                                   # (n, C/2)
+        s, c = torch.sin(om), torch.cos(om)
+        emb = torch.stack((s, c), 2).reshape(n, -1)                                    # sin/cos interleaved
+        demb = torch.stack((c, -s), 2).reshape(n, -1) * div_term.double().repeat_interleave(2)[None, :]
+        w = weight.detach().double()
+        f = emb @ w.t() + bias.detach().double()
+        df = demb @ w.t()
+        tab = torch.stack((f, df), 2).float().contiguous()
+        if len(_emb_table_cache) > 16:
+            _emb_table_cache.clear()
+        _emb_table_cache[key] = (tab, weakref.ref(weight), weakref.ref(bias))
+    return tab
+
+
+def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, k, wigner_d1=None):
+    """HIP (csrc/geo_embedding.hip).  Returns emb (N, N, C), or (emb, eq_emb (A, N, N, 4)) when wigner_d1 is given."""
+    points = _req(points.contiguous(), torch.float32, 'points', 2)
+    if k != 3:
+        raise RuntimeError('geometric_embedding: angle_k must be 3 on the HIP path')
+    N, C = points.shape[0], w_d.shape[0]
+    # 3 nearest other points (the reference takes top-(k+1) of the distance map and drops the first column)
+    sq = (points * points).sum(-1)
+    dist = (sq[:, None] - 2 * (points @ points.t()) + sq[None, :]).clamp_(min=0.0)
+    knn = dist.topk(k + 1, dim=1, largest=False)[1][:, 1:].contiguous()
+    tab_d = _embedding_table(w_d, b_d, div_term, _EMB_D_RANGE, _EMB_D_PER_UNIT)
+    tab_a = _embedding_table(w_a, b_a, div_term, 180.0 / sigma_a + 1.0, _EMB_A_PER_UNIT)
+    emb = torch.empty((N, N, C), dtype=torch.float32, device=points.device)
+    eq = None
+    A = 0
+    if wigner_d1 is not None:
+        A = wigner_d1.shape[0]
+        eq = torch.empty((A, N, N, 4), dtype=torch.float32, device=points.device)
+        wigner_d1 = wigner_d1.detach().contiguous()
+    check(lib().se3_geo_embedding_fwd(points.data_ptr(), knn.data_ptr(), N, C, tab_d.data_ptr(), tab_d.shape[0],
+                                      _EMB_D_PER_UNIT, tab_a.data_ptr(), tab_a.shape[0], _EMB_A_PER_UNIT, float(sigma_d),
+                                      float(sigma_a), w_d.data_ptr(), b_d.data_ptr(), w_a.data_ptr(), b_a.data_ptr(),
+                                      div_term.data_ptr(), wigner_d1.data_ptr() if eq is not None else None, A,
+                                      emb.data_ptr(), eq.data_ptr() if eq is not None else None, _stream()),
+          'se3_geo_embedding_fwd')
+    return emb if eq is None else (emb, eq)

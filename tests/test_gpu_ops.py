@@ -228,3 +228,70 @@ def test_cross_attention_eq_matches_oracle(N, M, C, mode):
     got, got_w = SF.cross_attention_eq(q.cuda(), k.cuda(), v.cuda(), H, mode, trace.cuda())
     assert_close(got_w.cpu(), want_w, 1e-4, 'global weights')
     assert_close(got.cpu(), want, 1e-4, 'eq cross attention')
+
+
+@pytest.mark.parametrize('N,C,eq', [(59, 32, True), (382, 256, True), (304, 256, False), (100, 128, True)])
+def test_geometric_embedding_matches_oracle(N, C, eq):
+    from oracle import se3et_oracle as O
+    from se3et_amd import functional as SF
+    from se3et_amd import tables
+    g = torch.Generator().manual_seed(8)
+    pts = torch.rand(N, 3, generator=g) * torch.tensor([1.5, 1.2, 1.0])
+    div = torch.exp(torch.arange(0, C, 2).float() * (-np.log(10000.0) / C))
+    st = {'e.embedding.div_term': div}
+    for n in ('d', 'a'):
+        st['e.proj_%s.weight' % n] = torch.randn(C, C, generator=g) / C ** 0.5
+        st['e.proj_%s.bias' % n] = torch.randn(C, generator=g) * 0.1
+    w0, w1 = [torch.from_numpy(t) for t in tables.wigner_tables()]
+    st['e.anchors_wignerD.0'], st['e.anchors_wignerD.1'] = w0, w1
+    cfg = O.OracleConfig()
+    want = O.geometric_embedding(st, 'e.', pts, cfg)
+    c = lambda k: st[k].cuda()
+    out = SF.geometric_embedding(pts.cuda(), c('e.embedding.div_term'), c('e.proj_d.weight'), c('e.proj_d.bias'),
+                                 c('e.proj_a.weight'), c('e.proj_a.bias'), cfg.sigma_d, cfg.sigma_a, 3,
+                                 wigner_d1=w1.cuda() if eq else None)
+    emb = (out[0] if eq else out).cpu()
+    # the n == m diagonal of the distance index is sqrt of the rounding residue of |x|^2 - 2 x.y + |y|^2 in the reference
+    # (pure noise, ~1e-3 index units, BLAS dependent); everything else must agree to 1e-4
+    off = ~torch.eye(N, dtype=torch.bool)
+    assert_close(emb[off], want[off], 1e-4, 'geometric embedding (off-diagonal)')
+    assert_close(emb, want, 2e-3, 'geometric embedding (diagonal noise)')
+    if eq:
+        assert_close(out[1].cpu(), O.equiv_embedding(st, 'e.', pts), 1e-5, 'equivariant embedding')
+
+
+def test_geometric_embedding_out_of_table_range():
+    """Distance indices beyond the tabulated range (here sigma_d = 0.002 -> indices up to ~800) take the exact-sum path."""
+    from oracle import se3et_oracle as O
+    from se3et_amd import functional as SF
+    g = torch.Generator().manual_seed(9)
+    N, C = 40, 32
+    pts = torch.rand(N, 3, generator=g)
+    div = torch.exp(torch.arange(0, C, 2).float() * (-np.log(10000.0) / C))
+    st = {'e.embedding.div_term': div}
+    for n in ('d', 'a'):
+        st['e.proj_%s.weight' % n] = torch.randn(C, C, generator=g) / C ** 0.5
+        st['e.proj_%s.bias' % n] = torch.randn(C, generator=g) * 0.1
+    cfg = O.OracleConfig(sigma_d=0.002)
+    want = O.geometric_embedding(st, 'e.', pts.double(), cfg) if False else O.geometric_embedding(st, 'e.', pts, cfg)
+    c = lambda k: st[k].cuda()
+    got = SF.geometric_embedding(pts.cuda(), c('e.embedding.div_term'), c('e.proj_d.weight'), c('e.proj_d.bias'),
+                                 c('e.proj_a.weight'), c('e.proj_a.bias'), cfg.sigma_d, cfg.sigma_a, 3).cpu()
+    off = ~torch.eye(N, dtype=torch.bool)
+    # the index x = d / sigma_d amplifies the fp32 rounding of d (both sides) by 1 / sigma_d: 1e-3 is the noise floor here
+    assert_close(got[off], want[off], 2e-3, 'embedding, exact path')
+
+
+def test_geometric_embedding_matches_reference_fixture(golden_dir):
+    from se3et_amd import functional as SF
+    g = _golden(golden_dir)
+    sd = _state(g)
+    pts = torch.from_numpy(g['op/embedding/in0'])[0]
+    p = 'transformer.embedding.'
+    c = lambda k: sd[p + k].cuda()
+    emb, eq = SF.geometric_embedding(pts.cuda(), c('embedding.div_term'), c('proj_d.weight'), c('proj_d.bias'),
+                                     c('proj_a.weight'), c('proj_a.bias'), 0.2, 15, 3, wigner_d1=c('anchors_wignerD.1'))
+    off = ~torch.eye(pts.shape[0], dtype=torch.bool)
+    assert_close(emb.cpu()[off], torch.from_numpy(g['op/embedding/out0'][0])[off], 1e-4, 'embedding vs reference')
+    assert_close(emb.cpu(), g['op/embedding/out0'][0], 2e-3, 'embedding vs reference (diagonal noise)')
+    assert_close(eq.cpu(), g['op/embedding/out1'][0], 1e-5, 'eq embedding vs reference')
