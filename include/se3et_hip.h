@@ -148,6 +148,13 @@ int se3_geo_embedding_fwd(const float* points, const int64_t* knn, int N, int C,
                           const float* div_term, const float* wigner_d1, int num_anchors, float* emb, float* eq_emb,
                           void* stream);
 
+/* ---- E2: superpoint matching scores --------------------------------------------------------------------------------
+ * Replaces the score part of SuperPointMatching.forward (geotransformer/modules/geotransformer/superpoint_matching.py:31-39):
+ * scores[n, m] = exp(-clamp(2 - 2 ref[n].src[m], 0)), optionally dual-normalised (S / rowsum * S / colsum).
+ * ref (N, C), src (M, C) L2-normalised; workspace: N + M floats. */
+int se3_superpoint_scores(const float* ref_feats, const float* src_feats, int N, int M, int C, int dual_normalization,
+                          float* scores, float* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -128,15 +128,6 @@ def _merge_heads(x):
     return x.reshape(*x.shape[:-2], -1)
 
 
-@_interim
-def superpoint_scores(ref_feats, src_feats, dual_normalization):
-    _gpu(ref_feats, 'ref_feats')
-    s = torch.exp(-(2.0 - 2.0 * (ref_feats @ src_feats.t())).clamp(min=0.0))
-    if dual_normalization:
-        s = (s / s.sum(1, keepdim=True)) * (s / s.sum(0, keepdim=True))
-    return s
-
-
 def log_optimal_transport(scores, row_masks, col_masks, alpha, num_iterations, inf):
     """HIP: one workgroup per patch pair, score matrix in registers for all iterations (csrc/sinkhorn.hip)."""
     scores = _req(scores.contiguous(), torch.float32, 'scores', 3)
@@ -414,3 +405,16 @@ def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, 
                                       emb.data_ptr(), eq.data_ptr() if eq is not None else None, _stream()),
           'se3_geo_embedding_fwd')
     return emb if eq is None else (emb, eq)
+
+
+def superpoint_scores(ref_feats, src_feats, dual_normalization):
+    """HIP (csrc/matching.hip): exp(-||f_r - f_s||^2) on unit features with dual normalisation."""
+    ref_feats = _req(ref_feats.contiguous(), torch.float32, 'ref_feats', 2)
+    src_feats = _req(src_feats.contiguous(), torch.float32, 'src_feats', 2)
+    N, C = ref_feats.shape
+    M = src_feats.shape[0]
+    scores = torch.empty((N, M), dtype=torch.float32, device=ref_feats.device)
+    ws = torch.empty((N + M,), dtype=torch.float32, device=ref_feats.device)
+    check(lib().se3_superpoint_scores(ref_feats.data_ptr(), src_feats.data_ptr(), N, M, C, 1 if dual_normalization else 0,
+                                      scores.data_ptr(), ws.data_ptr(), _stream()), 'se3_superpoint_scores')
+    return scores

@@ -295,3 +295,17 @@ def test_geometric_embedding_matches_reference_fixture(golden_dir):
     assert_close(emb.cpu()[off], torch.from_numpy(g['op/embedding/out0'][0])[off], 1e-4, 'embedding vs reference')
     assert_close(emb.cpu(), g['op/embedding/out0'][0], 2e-3, 'embedding vs reference (diagonal noise)')
     assert_close(eq.cpu(), g['op/embedding/out1'][0], 1e-5, 'eq embedding vs reference')
+
+
+@pytest.mark.parametrize('N,M,C', [(382, 304, 256), (59, 53, 32), (1, 700, 128)])
+def test_superpoint_scores_match_oracle(N, M, C):
+    from oracle import se3et_oracle as O
+    from se3et_amd import functional as SF
+    g = torch.Generator().manual_seed(10)
+    r = torch.nn.functional.normalize(torch.randn(N, C, generator=g), dim=1)
+    s = torch.nn.functional.normalize(torch.randn(M, C, generator=g) + 0.5 * r[torch.randint(0, N, (M,), generator=g)], dim=1)
+    want = torch.exp(-O.pairwise_distance(r, s, normalized=True))
+    want = (want / want.sum(1, keepdim=True)) * (want / want.sum(0, keepdim=True))
+    got = SF.superpoint_scores(r.cuda(), s.cuda(), True).cpu()
+    assert_close(got, want, 1e-4, 'superpoint scores')
+    assert float((got / want - 1).abs().max()) < 1e-3
