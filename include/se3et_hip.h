@@ -155,6 +155,19 @@ int se3_geo_embedding_fwd(const float* points, const int64_t* knn, int N, int C,
 int se3_superpoint_scores(const float* ref_feats, const float* src_feats, int N, int M, int C, int dual_normalization,
                           float* scores, float* workspace, void* stream);
 
+/* ---- F1: weighted Procrustes / inlier voting for local-to-global registration -------------------------------------------
+ * Replace weighted_procrustes (geotransformer/modules/registration/procrustes.py:6-73, SVD on the CPU in the reference) and
+ * the hypothesis voting of LocalGlobalRegistration (geotransformer/modules/geotransformer/local_global_registration.py:139-194).
+ * Correspondences are stacked: src/ref (total, 3), scores (total,); problem s uses rows [segment_offsets[s],
+ * segment_offsets[s+1]) (int64, DEVICE, num_segments + 1 entries).  If gate_transform (4x4 row-major, DEVICE) is not NULL the
+ * weight of a correspondence is score * [ |ref - T src| < gate_radius ] (the refinement re-weighting).  Weights are
+ * normalised by (sum + eps).  transforms: (num_segments, 4, 4).  se3_count_inliers: votes[b] = #{i : |ref_i - T_b src_i| < radius}. */
+int se3_weighted_procrustes(const float* src_points, const float* ref_points, const float* scores,
+                            const int64_t* segment_offsets, int num_segments, const float* gate_transform, float gate_radius,
+                            float eps, float* transforms, void* stream);
+int se3_count_inliers(const float* src_points, const float* ref_points, int64_t num_points, const float* transforms,
+                      int num_transforms, float radius, int32_t* votes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -118,36 +118,11 @@ def log_optimal_transport(scores, row_masks, col_masks, alpha, num_iterations, i
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# F1: registration (device-side; 3x3 SVD through the batched library solver)
+# F1: registration (device-side Kabsch, csrc/registration.hip)
 # ---------------------------------------------------------------------------------------------------------------------
-def _kabsch(H, sc, rc):
-    U, _, Vh = torch.linalg.svd(H)
-    V, Ut = Vh.transpose(-1, -2), U.transpose(-1, -2)
-    eye = torch.eye(3, device=H.device).expand(H.shape[0], 3, 3).clone()
-    eye[:, 2, 2] = torch.sign(torch.det(V @ Ut))
-    R = V @ eye @ Ut
-    t = rc - (R @ sc[:, :, None])[:, :, 0]
-    T = torch.eye(4, device=H.device).repeat(H.shape[0], 1, 1)
-    T[:, :3, :3], T[:, :3, 3] = R, t
-    return T
+def weighted_procrustes(src, ref, scores, offsets, gate_transform=None, gate_radius=0.0, eps=1e-5):
+    return _ops.weighted_procrustes(src, ref, scores, offsets, gate_transform, gate_radius, eps)
 
 
-def weighted_procrustes(src, ref, w, eps=1e-5):
-    """(N, 3) x2, (N,) -> (4, 4) (geotransformer/modules/registration/procrustes.py:6-73)."""
-    w = torch.where(w < 0, torch.zeros_like(w), w)
-    w = (w / (w.sum() + eps))[:, None]
-    sc, rc = (src * w).sum(0, keepdim=True), (ref * w).sum(0, keepdim=True)
-    H = (src - sc).t() @ (w * (ref - rc))
-    return _kabsch(H[None], sc, rc)[0]
-
-
-def segment_procrustes(src, ref, w, seg, num_segments, eps=1e-5):
-    """One weighted Procrustes per segment id (sorted `seg`), by segment reductions -> (num_segments, 4, 4)."""
-    w = torch.where(w < 0, torch.zeros_like(w), w)
-    wsum = torch.zeros(num_segments, device=w.device).index_add_(0, seg, w)
-    wn = (w / (wsum[seg] + eps))[:, None]
-    sc = torch.zeros(num_segments, 3, device=w.device).index_add_(0, seg, src * wn)
-    rc = torch.zeros(num_segments, 3, device=w.device).index_add_(0, seg, ref * wn)
-    outer = (src - sc[seg])[:, :, None] * (wn * (ref - rc[seg]))[:, None, :]
-    H = torch.zeros(num_segments, 3, 3, device=w.device).index_add_(0, seg, outer)
-    return _kabsch(H, sc, rc)
+def count_inliers(src, ref, transforms, radius):
+    return _ops.count_inliers(src, ref, transforms, radius)

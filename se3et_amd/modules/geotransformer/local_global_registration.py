@@ -22,10 +22,6 @@ class LocalGlobalRegistration(nn.Module):
         self.confidence_threshold, self.correspondence_threshold = confidence_threshold, correspondence_threshold
         self.num_refinement_steps = num_refinement_steps
 
-    def _rescore(self, ref_pts, src_pts, scores, T):
-        res = torch.linalg.norm(ref_pts - SF.apply_transform(src_pts, T), dim=-1)
-        return scores * (res < self.acceptance_radius).float()
-
     @torch.no_grad()
     def forward(self, ref_knn_points, src_knn_points, ref_knn_masks, src_knn_masks, score_mat, global_scores):
         score_mat = torch.exp(score_mat)
@@ -36,23 +32,26 @@ class LocalGlobalRegistration(nn.Module):
                (torch.zeros_like(score_mat).scatter_(1, si, ss) > self.confidence_threshold) & \
                (ref_knn_masks[:, :, None] & src_knn_masks[:, None, :])
         b_idx, r_idx, c_idx = torch.nonzero(corr, as_tuple=True)           # one host sync (row-major, as the reference)
-        ref_c, src_c = ref_knn_points[b_idx, r_idx], src_knn_points[b_idx, c_idx]
-        sc = score_mat[b_idx, r_idx, c_idx]
+        ref_c, src_c = ref_knn_points[b_idx, r_idx].contiguous(), src_knn_points[b_idx, c_idx].contiguous()
+        sc = score_mat[b_idx, r_idx, c_idx].contiguous()
+        total = sc.shape[0]
+        dev = sc.device
         counts = torch.bincount(b_idx, minlength=B)
-        valid = counts >= self.correspondence_threshold
-        if bool(valid.any()):
-            Ts = SF.segment_procrustes(src_c, ref_c, sc, b_idx, B)          # (B, 4, 4); rows of invalid patches unused
-            res = torch.linalg.norm(ref_c[None] - SF.apply_transform(src_c[None], Ts), dim=2)      # (B, total)
-            inl = (res < self.acceptance_radius)
-            votes = inl.sum(1).masked_fill(~valid, -1)
-            # first maximum among the valid patches in patch order (reference: argmax over the kept chunks)
-            best = int(torch.nonzero(votes == votes.max())[0, 0])
-            cur = sc * inl[best].float()
-        else:
-            T = SF.weighted_procrustes(src_c, ref_c, sc)
-            cur = self._rescore(ref_c, src_c, sc, T)
-        T = SF.weighted_procrustes(src_c, ref_c, cur)
+        offsets = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+        offsets[1:] = torch.cumsum(counts, 0)
+        whole = torch.tensor([0, total], dtype=torch.int64, device=dev)
+        # local hypotheses: one weighted Procrustes per patch pair (patches below the threshold never win the vote)
+        Ts = SF.weighted_procrustes(src_c, ref_c, sc, offsets)
+        votes = SF.count_inliers(src_c, ref_c, Ts, self.acceptance_radius)
+        votes = torch.where(counts >= self.correspondence_threshold, votes, torch.full_like(votes, -1))
+        best = torch.argmax(votes)                       # first maximum in patch order, stays on the device
+        any_valid = votes.max() >= 0
+        T0 = Ts[best]
+        # degenerate case (no patch pair with enough correspondences): start from all correspondences instead
+        T_all = SF.weighted_procrustes(src_c, ref_c, sc, whole)[0]
+        T_init = torch.where(any_valid, T0, T_all)
+        # global refinement: weights = score * [residual under the previous estimate < radius], one launch per step
+        T = SF.weighted_procrustes(src_c, ref_c, sc, whole, gate_transform=T_init, gate_radius=self.acceptance_radius)[0]
         for _ in range(self.num_refinement_steps - 1):
-            cur = self._rescore(ref_c, src_c, sc, T)
-            T = SF.weighted_procrustes(src_c, ref_c, cur)
+            T = SF.weighted_procrustes(src_c, ref_c, sc, whole, gate_transform=T, gate_radius=self.acceptance_radius)[0]
         return ref_c, src_c, sc, T

@@ -418,3 +418,28 @@ def superpoint_scores(ref_feats, src_feats, dual_normalization):
     check(lib().se3_superpoint_scores(ref_feats.data_ptr(), src_feats.data_ptr(), N, M, C, 1 if dual_normalization else 0,
                                       scores.data_ptr(), ws.data_ptr(), _stream()), 'se3_superpoint_scores')
     return scores
+
+
+def weighted_procrustes(src, ref, scores, offsets, gate_transform=None, gate_radius=0.0, eps=1e-5):
+    """HIP (csrc/registration.hip): one weighted Kabsch solve per segment of the stacked correspondences -> (S, 4, 4)."""
+    src = _req(src.contiguous(), torch.float32, 'src', 2)
+    ref = _req(ref.contiguous(), torch.float32, 'ref', 2)
+    scores = _req(scores.contiguous(), torch.float32, 'scores', 1)
+    offsets = _req(offsets.contiguous(), torch.int64, 'offsets', 1)
+    S = offsets.shape[0] - 1
+    T = torch.empty((S, 4, 4), dtype=torch.float32, device=src.device)
+    gt = _req(gate_transform.contiguous(), torch.float32, 'gate_transform') if gate_transform is not None else None
+    check(lib().se3_weighted_procrustes(src.data_ptr(), ref.data_ptr(), scores.data_ptr(), offsets.data_ptr(), S,
+                                        gt.data_ptr() if gt is not None else None, float(gate_radius), float(eps),
+                                        T.data_ptr(), _stream()), 'se3_weighted_procrustes')
+    return T
+
+
+def count_inliers(src, ref, transforms, radius):
+    src = _req(src.contiguous(), torch.float32, 'src', 2)
+    ref = _req(ref.contiguous(), torch.float32, 'ref', 2)
+    transforms = _req(transforms.contiguous(), torch.float32, 'transforms', 3)
+    votes = torch.empty((transforms.shape[0],), dtype=torch.int32, device=src.device)
+    check(lib().se3_count_inliers(src.data_ptr(), ref.data_ptr(), src.shape[0], transforms.data_ptr(), transforms.shape[0],
+                                  float(radius), votes.data_ptr(), _stream()), 'se3_count_inliers')
+    return votes

@@ -309,3 +309,43 @@ def test_superpoint_scores_match_oracle(N, M, C):
     got = SF.superpoint_scores(r.cuda(), s.cuda(), True).cpu()
     assert_close(got, want, 1e-4, 'superpoint scores')
     assert float((got / want - 1).abs().max()) < 1e-3
+
+
+def test_weighted_procrustes_matches_oracle():
+    from oracle import se3et_oracle as O
+    from se3et_amd import functional as SF
+    g = torch.Generator().manual_seed(11)
+    segs = [0, 5, 5, 40, 43, 300, 1000]                        # includes an empty and a 3-point segment
+    total = segs[-1]
+    src = torch.randn(total, 3, generator=g)
+    ang = torch.tensor(0.7)
+    R = torch.tensor([[torch.cos(ang), -torch.sin(ang), 0.], [torch.sin(ang), torch.cos(ang), 0.], [0., 0., 1.]])
+    ref = src @ R.t() + torch.tensor([0.3, -0.2, 0.1]) + 0.01 * torch.randn(total, 3, generator=g)
+    w = torch.rand(total, generator=g)
+    offsets = torch.tensor(segs, dtype=torch.int64)
+    got = SF.weighted_procrustes(src.cuda(), ref.cuda(), w.cuda(), offsets.cuda()).cpu()
+    for s in range(len(segs) - 1):
+        a, b = segs[s], segs[s + 1]
+        if b - a >= 3:
+            want = O.weighted_procrustes(src[None, a:b], ref[None, a:b], w[None, a:b])[0]
+            assert_close(got[s], want, 1e-4, 'segment %d' % s)
+            assert abs(float(torch.det(got[s][:3, :3])) - 1) < 1e-4
+    # gated refinement step = the reference's re-scoring followed by a solve
+    T0 = got[-1]
+    res = torch.linalg.norm(ref - (src @ T0[:3, :3].t() + T0[:3, 3]), dim=1)
+    want = O.weighted_procrustes(src[None], ref[None], (w * (res < 0.02).float())[None])[0]
+    whole = torch.tensor([0, total], dtype=torch.int64)
+    got2 = SF.weighted_procrustes(src.cuda(), ref.cuda(), w.cuda(), whole.cuda(), gate_transform=T0.cuda(), gate_radius=0.02)[0]
+    assert_close(got2.cpu(), want, 1e-4, 'gated solve')
+    votes = SF.count_inliers(src.cuda(), ref.cuda(), got.cuda(), 0.02).cpu()
+    for s in (2, 4, 5):
+        Ts = got[s]
+        r = torch.linalg.norm(ref - (src @ Ts[:3, :3].t() + Ts[:3, 3]), dim=1)
+        assert abs(int(votes[s]) - int((r < 0.02).sum())) <= 2          # boundary residuals may flip in fp32
+    # reflection case: planar, mirrored correspondences must still give a proper rotation
+    p = torch.randn(50, 3, generator=g); p[:, 2] = 0
+    q = p.clone(); q[:, 0] = -q[:, 0]
+    T = SF.weighted_procrustes(p.cuda(), q.cuda(), torch.ones(50).cuda(), torch.tensor([0, 50]).cuda())[0].cpu()
+    assert abs(float(torch.det(T[:3, :3])) - 1) < 1e-4
+    want = O.weighted_procrustes(p[None], q[None], torch.ones(1, 50))[0]
+    assert_close(T, want, 1e-3, 'reflection case')
