@@ -28,6 +28,22 @@ def linear(x, weight, bias=None, relu=False):
     return F.relu_(y) if relu else y
 
 
+def project_qk(x, w_q, b_q, w_k, b_k):
+    """q and k projections of the same tensor as ONE library GEMM with stacked weights -> (q, k)."""
+    qk = F.linear(x, torch.cat((w_q, w_k), 0), torch.cat((b_q, b_k), 0))
+    C = w_q.shape[0]
+    return qk[..., :C].contiguous(), qk[..., C:].contiguous()
+
+
+def project_values_transposed(x, w_v, b_v):
+    """Value projection emitted directly in the operand layout of the P.V MFMAs: (..., C, Mp) = W_v x^T + b with the keys
+    zero-padded to the key stride (padded keys carry probability 0, their values never matter)."""
+    M = x.shape[-2]
+    Mp = _ops.key_stride(M)
+    xp = F.pad(x, (0, 0, 0, Mp - M)) if Mp != M else x
+    return torch.matmul(w_v, xp.transpose(-1, -2)) + b_v[:, None]
+
+
 def add_layer_norm(hidden, residual, weight, bias, eps=1e-5):
     """LayerNorm(hidden + residual) over the last dim (residual may broadcast over a leading anchor dim)."""
     return _ops.add_layer_norm(hidden, residual, weight, bias, eps)
@@ -80,21 +96,21 @@ def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, 
 # ---------------------------------------------------------------------------------------------------------------------
 # D: attention
 # ---------------------------------------------------------------------------------------------------------------------
-def rpe_attention(q, k, v, emb, w_p, eq_emb, w_eq, num_heads, return_scores=False):
-    """q ([A,] N, C), k/v ([A,] M, C) already projected; emb (N, M, C); eq_emb (A, N, M, 4) or None.
+def rpe_attention(q, k, vt, emb, w_p, eq_emb, w_eq, num_heads, return_scores=False):
+    """q ([A,] N, C), k ([A,] M, C) already projected, vt ([A,] C, Mp) = project_values_transposed; emb (N, M, C); eq_emb (A, N, M, 4) or None.
     softmax_m((q.k + q.(W_p emb) + q.(W_eq eq_emb)) / sqrt(d)) v with the position terms folded onto the query side
     (q.(W e + b) = (W^T q).e + q.b, and the q.b term is constant along m so it cancels in the softmax)."""
-    return _ops.rpe_attention(q, k, v, emb, w_p, eq_emb, w_eq, num_heads, return_scores)
+    return _ops.rpe_attention(q, k, vt, emb, w_p, eq_emb, w_eq, num_heads, return_scores)
 
 
-def cross_attention(q, k, v, num_heads):
-    """q (N, C), k (M, C), v (M, C) or (A, M, C) -> (N, C) or (A, N, C)."""
-    return _ops.cross_attention(q, k, v, num_heads)
+def cross_attention(q, k, vt, num_heads):
+    """q (N, C), k (M, C), vt (C, Mp) or (A, C, Mp) -> (N, C) or (A, N, C)."""
+    return _ops.cross_attention(q, k, vt, num_heads)
 
 
-def cross_attention_eq(q, k, v, num_heads, mode, trace_idx):
-    """q (A, N, C), k/v (A, M, C).  Returns (hidden (A, N, C), weights): g/sum_e g (A, A) for 'a_soft', w (R,) for 'r_soft'."""
-    return _ops.cross_attention_eq(q, k, v, num_heads, mode, trace_idx)
+def cross_attention_eq(q, k, vt, num_heads, mode, trace_idx):
+    """q (A, N, C), k (A, M, C), vt (A, C, Mp).  Returns (hidden (A, N, C), weights): g/sum_e g (A, A) for 'a_soft', w (R,) for 'r_soft'."""
+    return _ops.cross_attention_eq(q, k, vt, num_heads, mode, trace_idx)
 
 
 def rotation_weighted_permute(feats, w, trace_idx):

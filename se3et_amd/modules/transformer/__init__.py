@@ -106,9 +106,13 @@ class RPEMultiHeadAttention(nn.Module):
     def forward(self, input_q, input_k, input_v, embed_qk, key_weights=None, key_masks=None, attention_factors=None,
                 embed_eq=None):
         _no(key_weights, 'key_weights'), _no(key_masks, 'key_masks'), _no(attention_factors, 'attention_factors')
-        q = SF.linear(_one(input_q, 'input_q'), self.proj_q.weight, self.proj_q.bias)
-        k = SF.linear(_one(input_k, 'input_k'), self.proj_k.weight, self.proj_k.bias)
-        v = SF.linear(_one(input_v, 'input_v'), self.proj_v.weight, self.proj_v.bias)
+        xq, xk, xv = _one(input_q, 'input_q'), _one(input_k, 'input_k'), _one(input_v, 'input_v')
+        if xq is xk or (xq.data_ptr() == xk.data_ptr() and xq.shape == xk.shape):      # self attention: one stacked GEMM
+            q, k = SF.project_qk(xq, self.proj_q.weight, self.proj_q.bias, self.proj_k.weight, self.proj_k.bias)
+        else:
+            q = SF.linear(xq, self.proj_q.weight, self.proj_q.bias)
+            k = SF.linear(xk, self.proj_k.weight, self.proj_k.bias)
+        v = SF.project_values_transposed(xv, self.proj_v.weight, self.proj_v.bias)
         use_eq = self.equivariant and self.d_equiv_embed > 0
         if use_eq and embed_eq is None:
             raise RuntimeError('Equivariant embedding required here.')
@@ -166,9 +170,13 @@ class MultiHeadAttention(nn.Module):
                 attention_masks=None, gt_indices=None, gt_overlap=None):
         _no(key_weights, 'key_weights'), _no(key_masks, 'key_masks'), _no(attention_factors, 'attention_factors')
         _no(attention_masks, 'attention_masks')
-        q = SF.linear(_one(input_q, 'input_q'), self.proj_q.weight, self.proj_q.bias)
-        k = SF.linear(_one(input_k, 'input_k'), self.proj_k.weight, self.proj_k.bias)
-        v = SF.linear(_one(input_v, 'input_v'), self.proj_v.weight, self.proj_v.bias)
+        xq, xk, xv = _one(input_q, 'input_q'), _one(input_k, 'input_k'), _one(input_v, 'input_v')
+        if xq is xk or (xq.data_ptr() == xk.data_ptr() and xq.shape == xk.shape):      # self attention: one stacked GEMM
+            q, k = SF.project_qk(xq, self.proj_q.weight, self.proj_q.bias, self.proj_k.weight, self.proj_k.bias)
+        else:
+            q = SF.linear(xq, self.proj_q.weight, self.proj_q.bias)
+            k = SF.linear(xk, self.proj_k.weight, self.proj_k.bias)
+        v = SF.project_values_transposed(xv, self.proj_v.weight, self.proj_v.bias)
         hidden = SF.cross_attention(q, k, v, self.num_heads)
         return hidden.unsqueeze(0), None
 
@@ -204,9 +212,13 @@ class MultiHeadAttentionEQ(nn.Module):
                 attention_masks=None, gt_indices=None, gt_overlap=None):
         _no(key_weights, 'key_weights'), _no(key_masks, 'key_masks'), _no(attention_factors, 'attention_factors')
         _no(attention_masks, 'attention_masks')
-        q = SF.linear(_one(input_q, 'input_q'), self.proj_q.weight, self.proj_q.bias)
-        k = SF.linear(_one(input_k, 'input_k'), self.proj_k.weight, self.proj_k.bias)
-        v = SF.linear(_one(input_v, 'input_v'), self.proj_v.weight, self.proj_v.bias)
+        xq, xk, xv = _one(input_q, 'input_q'), _one(input_k, 'input_k'), _one(input_v, 'input_v')
+        if xq is xk or (xq.data_ptr() == xk.data_ptr() and xq.shape == xk.shape):      # self attention: one stacked GEMM
+            q, k = SF.project_qk(xq, self.proj_q.weight, self.proj_q.bias, self.proj_k.weight, self.proj_k.bias)
+        else:
+            q = SF.linear(xq, self.proj_q.weight, self.proj_q.bias)
+            k = SF.linear(xk, self.proj_k.weight, self.proj_k.bias)
+        v = SF.project_values_transposed(xv, self.proj_v.weight, self.proj_v.bias)
         hidden, w = SF.cross_attention_eq(q, k, v, self.num_heads, self.attn_mode, self.trace_idx_ori)
         if self.attn_mode == 'a_soft':
             return hidden.unsqueeze(0), [None, w.reshape(1, self.na, self.na, 1, 1, 1)]

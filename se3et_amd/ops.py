@@ -234,17 +234,16 @@ def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, s
     return torch.mm(G, weights.reshape(36 * Cin, Cout)).view(P, 6, Cout)
 
 
-def _transposed_values(v, Mp):
-    """(..., M, C) -> (..., C, Mp) zero-padded along the keys (operand layout of the P.V MFMAs)."""
-    M = v.shape[-2]
-    vt = torch.zeros(v.shape[:-2] + (v.shape[-1], Mp), dtype=torch.float32, device=v.device)
-    vt[..., :M] = v.transpose(-1, -2)
-    return vt
+def key_stride(M):
+    """Row stride of key-major operands (relative-position logits, transposed values): keys padded to a multiple of 32."""
+    return (M + 31) // 32 * 32
 
 
-def _attention(q, k, v, bias, A, N, M, C, H, q_sa, k_sa, v_per_anchor, Mp, timed_bytes=None):
+def _attention(q, k, vt, bias, A, N, M, C, H, q_sa, k_sa, v_per_anchor, Mp, timed_bytes=None):
+    """vt: transposed, key-padded values ([A,] C, Mp) (see functional.project_values_transposed)."""
     out = torch.empty((A, N, C), dtype=torch.float32, device=q.device)
-    vt = _transposed_values(v, Mp)
+    if vt.shape[-1] != Mp or vt.shape[-2] != C:
+        raise RuntimeError('attention: transposed values must be (.., C, %d), got %s' % (Mp, tuple(vt.shape)))
     with _timed('attention_kernel', timed_bytes or 0):
         check(lib().se3_attention_fwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(),
                                       bias.data_ptr() if bias is not None else None, A, N, M, C, H, q_sa, k_sa,
@@ -253,13 +252,13 @@ def _attention(q, k, v, bias, A, N, M, C, H, q_sa, k_sa, v_per_anchor, Mp, timed
     return out
 
 
-def rpe_attention(q, k, v, emb, w_p, eq_emb, w_eq, num_heads, return_scores):
+def rpe_attention(q, k, vt, emb, w_p, eq_emb, w_eq, num_heads, return_scores):
     """HIP (csrc/attention.hip): position logits streamed from the embedding once (se3_rpe_bias_fwd), then the
     flash-style softmax/PV kernel (se3_attention_fwd).  The two fold GEMMs W_p^T q / W_eq^T q are library GEMMs."""
     anchored = q.dim() == 3
     q3 = _req((q if anchored else q.unsqueeze(0)).contiguous(), torch.float32, 'q', 3)
     k3 = _req((k if anchored else k.unsqueeze(0)).contiguous(), torch.float32, 'k', 3)
-    v3 = _req((v if anchored else v.unsqueeze(0)).contiguous(), torch.float32, 'v', 3)
+    vt3 = _req((vt if anchored else vt.unsqueeze(0)).contiguous(), torch.float32, 'vt', 3)
     emb = _req(emb.contiguous(), torch.float32, 'embed_qk', 3)
     A, N, C = q3.shape
     M, H = k3.shape[1], num_heads
@@ -293,7 +292,7 @@ def rpe_attention(q, k, v, emb, w_p, eq_emb, w_eq, num_heads, return_scores):
     global TIMING_TAG
     TIMING_TAG = 'rpe'
     try:
-        out = _attention(q3, k3, v3, bias, A, N, M, C, H, N * C, M * C, True, Mp, timed_bytes=0)
+        out = _attention(q3, k3, vt3, bias, A, N, M, C, H, N * C, M * C, True, Mp, timed_bytes=0)
     finally:
         TIMING_TAG = None
     scores = None
@@ -304,24 +303,24 @@ def rpe_attention(q, k, v, emb, w_p, eq_emb, w_eq, num_heads, return_scores):
     return (out if anchored else out[0]), scores
 
 
-def cross_attention(q, k, v, num_heads):
-    """HIP: plain cross attention; v (A, M, C) applies the invariant scores to per-anchor values."""
+def cross_attention(q, k, vt, num_heads):
+    """HIP: plain cross attention; vt (C, Mp) or (A, C, Mp) transposed key-padded values (per-anchor values share the scores)."""
     q = _req(q.contiguous(), torch.float32, 'q', 2)
     k = _req(k.contiguous(), torch.float32, 'k', 2)
-    v = _req(v.contiguous(), torch.float32, 'v')
+    vt = _req(vt.contiguous(), torch.float32, 'vt')
     N, C = q.shape
     M = k.shape[0]
-    Mp = (M + 31) // 32 * 32
-    if v.dim() == 2:
-        return _attention(q, k, v, None, 1, N, M, C, num_heads, 0, 0, False, Mp)[0]
-    return _attention(q, k, v, None, v.shape[0], N, M, C, num_heads, 0, 0, True, Mp)
+    Mp = key_stride(M)
+    if vt.dim() == 2:
+        return _attention(q, k, vt, None, 1, N, M, C, num_heads, 0, 0, False, Mp)[0]
+    return _attention(q, k, vt, None, vt.shape[0], N, M, C, num_heads, 0, 0, True, Mp)
 
 
-def cross_attention_eq(q, k, v, num_heads, mode, trace_idx):
+def cross_attention_eq(q, k, vt, num_heads, mode, trace_idx):
     """HIP: global anchor-pair statistics (se3_cross_eq_stats) + weighted per-pair softmax.V (se3_cross_eq_apply)."""
     q = _req(q.contiguous(), torch.float32, 'q', 3)
     k = _req(k.contiguous(), torch.float32, 'k', 3)
-    v = _req(v.contiguous(), torch.float32, 'v', 3)
+    vt = _req(vt.contiguous(), torch.float32, 'vt', 3)
     A, N, C = q.shape
     M, H = k.shape[1], num_heads
     scale = 1.0 / math.sqrt(C // H)
@@ -344,8 +343,9 @@ def cross_attention_eq(q, k, v, num_heads, mode, trace_idx):
     else:
         raise RuntimeError('cross_attention_eq: mode %r' % (mode,))
     out = torch.empty((A, N, C), dtype=torch.float32, device=q.device)
-    Mp = (M + 31) // 32 * 32
-    vt = _transposed_values(v, Mp)
+    Mp = key_stride(M)
+    if tuple(vt.shape) != (A, C, Mp):
+        raise RuntimeError('cross_attention_eq: transposed values must be (A, C, %d)' % Mp)
     check(lib().se3_cross_eq_apply(q.data_ptr(), k.data_ptr(), vt.data_ptr(), mix.contiguous().data_ptr(), A, N, M, C, H,
                                    Mp, scale, out.data_ptr(), _stream()), 'se3_cross_eq_apply')
     return out, ret

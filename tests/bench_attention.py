@@ -12,6 +12,8 @@ def run(A, N, C, H, eq, variant, split, iters=30):
     wp, weq = r(C, C) / 16, (r(C, 4) if eq else None)
     lib().se3_debug_set_bias_variant(variant, split)
     if A == 1: q, k, v = q[0], k[0], v[0]
+    from se3et_amd import functional as SF
+    v = SF.project_values_transposed(v, torch.eye(C, device='cuda'), torch.zeros(C, device='cuda'))
     for _ in range(3): ops.rpe_attention(q, k, v, emb, wp, eqe, weq, H, False)
     ops.KERNEL_TIMINGS = {}
     for _ in range(iters): ops.rpe_attention(q, k, v, emb, wp, eqe, weq, H, False)

@@ -160,7 +160,8 @@ def test_rpe_attention_matches_oracle(A, N, C, H, eq):
     eq_emb = torch.randn(A, N, N, 4, generator=g) if eq else None
     want, want_scores = O.rpe_attention(st, 'l.', x, x, emb, eq_emb, H)
     lin = lambda n: torch.nn.functional.linear(x, st['l.proj_%s.weight' % n], st['l.proj_%s.bias' % n]).cuda()
-    got, scores = SF.rpe_attention(lin('q'), lin('k'), lin('v'), emb.cuda(), st['l.proj_p.weight'].cuda(),
+    vt = SF.project_values_transposed(x.cuda(), st['l.proj_v.weight'].cuda(), st['l.proj_v.bias'].cuda())
+    got, scores = SF.rpe_attention(lin('q'), lin('k'), vt, emb.cuda(), st['l.proj_p.weight'].cuda(),
                                    eq_emb.cuda() if eq else None, st['l.proj_eq.weight'].cuda() if eq else None, H,
                                    return_scores=True)
     assert_close(got.cpu(), want, 1e-4, 'rpe attention hidden')
@@ -176,7 +177,8 @@ def test_rpe_attention_matches_reference_fixture(golden_dir):
         pre = 'transformer.transformer.layers.%d.attention.attention.' % layer
         x = torch.from_numpy(g['op/attn_%d/in0' % layer])[0]
         lin = lambda n: torch.nn.functional.linear(x, sd[pre + 'proj_%s.weight' % n], sd[pre + 'proj_%s.bias' % n]).cuda()
-        got, scores = SF.rpe_attention(lin('q'), lin('k'), lin('v'), emb.cuda(), sd[pre + 'proj_p.weight'].cuda(),
+        vt = SF.project_values_transposed(x.cuda(), sd[pre + 'proj_v.weight'].cuda(), sd[pre + 'proj_v.bias'].cuda())
+        got, scores = SF.rpe_attention(lin('q'), lin('k'), vt, emb.cuda(), sd[pre + 'proj_p.weight'].cuda(),
                                        eq_emb.cuda() if eq else None, sd[pre + 'proj_eq.weight'].cuda() if eq else None, 4,
                                        return_scores=True)
         assert_close(got.cpu(), g['op/attn_%d/out0' % layer][0], 1e-4, 'layer %d hidden' % layer)
@@ -193,7 +195,8 @@ def test_cross_attention_matches_oracle(A, N, M, C, H):
     p = torch.softmax(hs(q) @ hs(k).transpose(-1, -2) / (C // H) ** 0.5, -1)
     want = (p @ hs(v)).transpose(-2, -3)
     want = want.reshape(*want.shape[:-2], -1)
-    got = SF.cross_attention(q.cuda(), k.cuda(), v.cuda(), H).cpu()
+    eye, zero = torch.eye(C).cuda(), torch.zeros(C).cuda()
+    got = SF.cross_attention(q.cuda(), k.cuda(), SF.project_values_transposed(v.cuda(), eye, zero), H).cpu()
     assert_close(got, want, 1e-4, 'cross attention')
 
 
@@ -225,7 +228,9 @@ def test_cross_attention_eq_matches_oracle(N, M, C, mode):
             hidden = hidden + w[r] * torch.einsum('ahnm,ahmc->ahnc', p[ar, trace[r]], vh[trace[r]])
         want_w = w
     want = hidden.transpose(-2, -3).reshape(6, N, C)
-    got, got_w = SF.cross_attention_eq(q.cuda(), k.cuda(), v.cuda(), H, mode, trace.cuda())
+    eye, zero = torch.eye(C).cuda(), torch.zeros(C).cuda()
+    got, got_w = SF.cross_attention_eq(q.cuda(), k.cuda(), SF.project_values_transposed(v.cuda(), eye, zero), H, mode,
+                                       trace.cuda())
     assert_close(got_w.cpu(), want_w, 1e-4, 'global weights')
     assert_close(got.cpu(), want, 1e-4, 'eq cross attention')
 

@@ -18,4 +18,4 @@ torch.cuda.synchronize(); print('ms/pair', (time.time() - t0) * 100)
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     step(); torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=25, max_name_column_width=60))
+print(prof.key_averages().table(sort_by='self_cpu_time_total', row_limit=28, max_name_column_width=50))
