@@ -108,22 +108,23 @@ int se3_kpconv_so3_gather(const float* q_pts, const float* s_pts, const int64_t*
 /* ---- D1/D2: RPE self attention (RPEMultiHeadAttention.forward) ------------------------------------------------------
  * Replaces geotransformer/modules/transformer/rpe_transformer.py:39-131 in two launches.
  * (1) se3_rpe_bias_fwd streams the (N, M, C) geometric embedding once and writes the relative-position logits
- *     bias[ah, n, m] = qp[n, ah, :] . emb[n, m, :] (+ qe[n, ah, :] . eq_emb[a, n, m, :]), where qp = W_p^T q (N, AH, C) and
- *     qe = W_eq^T q (N, AH, 4) are the position projections folded onto the query (AH = anchors * heads <= 32, ah = a*H+h).
- *     qp is passed in MFMA-fragment order qp_frag[n][rt][t][kq][r][4] = qp[n, 16 rt + r, 16 t + 4 kq .. +3] with the rows
- *     zero-padded to 16 * RT (RT = 1 if AH <= 16 else 2): a (N, 16 RT, C) tensor viewed (N, RT, 16, C/16, 4, 4) and
- *     permuted to (N, RT, C/16, 4, 16, 4).
+ *     bias[a*H+h, n, m] = qp[a, n, h, :] . emb[n, m, :] (+ qe[a, n, h, :] . eq_emb[a, n, m, :]), where qp = W_p^T q (C values
+ *     per head) and qe = W_eq^T q (4 values per head) are the position projections folded onto the query side
+ *     (anchors * heads <= 32).  qp and qe are column blocks of one projection output: element (a, n, h, c) of qp lives at
+ *     qp[a * anchor_stride + n * row_stride + h * C + c], element (a, n, h, e) of qe at qe[a * anchor_stride + n * row_stride
+ *     + 4 h + e] (strides in floats, multiples of 4).
  *     eq_emb (A, N, M, 4) and qe are NULL for non-equivariant layers.  bias has row stride bias_row_stride >= M.
  * (2) se3_attention_fwd: out[a, n, h*d:(h+1)*d] = softmax_m((q_a[n,h] . k_a[m,h] + bias[a*H+h, n, m]) * scale) v_a[m, h].
- *     q/k/out are (anchors, rows, C); the values are passed TRANSPOSED and key-padded, vt (anchors, C, key_stride) with
- *     key_stride = bias_row_stride a multiple of 4 >= ceil32(M) (zero padding), so that the P.V operand loads are
- *     contiguous.  Anchor strides are in floats (0 = the same tensor for every anchor, which is how plain cross attention
+ *     q/k are (anchors, rows, row_stride >= C) -- column blocks of a wider projection are fine --, out (anchors, N, C);
+ *     the values are passed TRANSPOSED, vt (anchors, C, v_row_stride) with v_row_stride a multiple of 4 >= ceil32(M)
+ *     (entries beyond M must be finite), so that the P.V operand loads are contiguous; bias_row_stride likewise.  Anchor strides are in floats (0 = the same tensor for every anchor, which is how plain cross attention
  *     vanilla_transformer.py:39-85 with per-anchor values is expressed); bias may be NULL.  C / H in {8, 16, 32, 64}; C in {32,64,128,256} for (1). */
-int se3_rpe_bias_fwd(const float* qp_frag, const float* qe, const float* emb, const float* eq_emb, int N, int M, int C, int AH,
-                     int H, int bias_row_stride, float* bias, void* stream);
+int se3_rpe_bias_fwd(const float* qp, const float* qe, int row_stride, int64_t anchor_stride, const float* emb,
+                     const float* eq_emb, int N, int M, int C, int AH, int H, int bias_row_stride, float* bias, void* stream);
 int se3_attention_fwd(const float* q, const float* k, const float* vt, const float* bias, int num_anchors, int N, int M, int C,
-                      int H, int64_t q_anchor_stride, int64_t k_anchor_stride, int64_t v_anchor_stride,
-                      int64_t out_anchor_stride, int bias_row_stride, float scale, float* out, void* stream);
+                      int H, int q_row_stride, int k_row_stride, int v_row_stride, int64_t q_anchor_stride,
+                      int64_t k_anchor_stride, int64_t v_anchor_stride, int64_t out_anchor_stride, int bias_row_stride,
+                      float scale, float* out, void* stream);
 
 /* ---- D4/D5: anchor-equivariant cross attention (MultiHeadAttentionEQ, 'a_soft' / 'r_soft') ----------------------------
  * Replaces geotransformer/modules/transformer/vanilla_transformer.py:247-476,506-577,751-870.  q (A, N, C), k/v (A, M, C).

@@ -31,22 +31,35 @@ __device__ __forceinline__ float f4get(const float4& v, int i) { return i == 0 ?
 // rpe_bias_kernel
 // =====================================================================================================================
 template <int CT, int RT, bool PREFETCH, int MINW>   // CT = C / 16 ; RT = row tiles of 16 folded queries (AH <= 16 RT)
-__global__ __launch_bounds__(256, MINW) void rpe_bias_kernel(const float* __restrict__ qp_frag, const float* __restrict__ qe,
-                                                       const float* __restrict__ emb, const float* __restrict__ eq_emb,
-                                                       int N, int M, int AH, int H, int Mp, float* __restrict__ bias) {
+__global__ __launch_bounds__(256, MINW) void rpe_bias_kernel(const float* __restrict__ qp, const float* __restrict__ qe,
+                                                       int qp_rs, long long qp_sa, const float* __restrict__ emb,
+                                                       const float* __restrict__ eq_emb, int N, int M, int AH, int H, int Mp,
+                                                       float* __restrict__ bias) {
   constexpr int C = CT * 16;
   __shared__ float4 afrag[RT * CT * 64];
   __shared__ float4 qe_s[32];
   const int n = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-  // folded queries of row n, already in MFMA-fragment order [rt][t][kq*16 + r] (float4 = channels 16 t + 4 kq .. +3):
-  // a straight, conflict-free copy into LDS
-  const float4* src = reinterpret_cast<const float4*>(qp_frag) + (size_t)n * (RT * CT * 64);
-  for (int i = threadIdx.x; i < RT * CT * 64; i += 256) afrag[i] = src[i];
+  // folded queries of row n: qp[a][n][h*C + c] (row stride qp_rs, anchor stride qp_sa) -> LDS in MFMA-fragment order
+  // afrag[(rt*CT + t)*64 + kq*16 + r] = float4 of channels 16 t + 4 kq .. +3 of folded query row 16 rt + r (r = a*H + h).
+  // Thread i takes row (i % (16 RT)) and chunk i / (16 RT): consecutive lanes write consecutive float4 (conflict free).
+  for (int i = threadIdx.x; i < RT * 16 * (C / 4); i += 256) {
+    const int row = i % (RT * 16), c4 = i / (RT * 16);
+    const int t = c4 >> 2, kq = c4 & 3;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < AH) {
+      const int a = row / H, h = row - a * H;
+      v = ld4(qp + (size_t)a * qp_sa + (size_t)n * qp_rs + h * C + 4 * c4);
+    }
+    afrag[((row >> 4) * CT + t) * 64 + kq * 16 + (row & 15)] = v;
+  }
   if (threadIdx.x < 32) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (qe != nullptr && threadIdx.x < AH) v = ld4(qe + ((size_t)n * AH + threadIdx.x) * 4);
+    if (qe != nullptr && threadIdx.x < AH) {
+      const int a = threadIdx.x / H, h = threadIdx.x - a * H;
+      v = ld4(qe + (size_t)a * qp_sa + (size_t)n * qp_rs + 4 * h);
+    }
     qe_s[threadIdx.x] = v;
   }
   __syncthreads();
@@ -151,10 +164,10 @@ struct TileRegs {
 
 template <int D>
 __device__ __forceinline__ void flash_load(TileRegs<D>& r, const float* __restrict__ k, const float* __restrict__ v,
-                                           const float* __restrict__ bias_row, int m0, int M, int C, int Mp) {
+                                           const float* __restrict__ bias_row, int m0, int M, int k_rs, int v_rs) {
   constexpr int DT = FlashState<D>::DT, KU = FlashState<D>::KU;
   const int lane = threadIdx.x & 63, half = lane >> 5, c32 = lane & 31;
-  const float* kr = k + (size_t)min(m0 + c32, M - 1) * C + 4 * half;
+  const float* kr = k + (size_t)min(m0 + c32, M - 1) * k_rs + 4 * half;
 #pragma unroll
   for (int u = 0; u < KU; u++) r.kf[u] = ld4(kr + 8 * u);
 #pragma unroll
@@ -165,7 +178,7 @@ __device__ __forceinline__ void flash_load(TileRegs<D>& r, const float* __restri
     const int dd = 32 * dt + c32;
 #pragma unroll
     for (int g = 0; g < 4; g++) {          // keys m0 + 8 g + 4 half .. +3 are contiguous in the transposed values
-      const float4 t = dd < D ? ld4(v + (size_t)dd * Mp + m0 + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 t = dd < D ? ld4(v + (size_t)dd * v_rs + m0 + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
       r.vv[dt * 16 + 4 * g + 0] = t.x;
       r.vv[dt * 16 + 4 * g + 1] = t.y;
       r.vv[dt * 16 + 4 * g + 2] = t.z;
@@ -174,28 +187,28 @@ __device__ __forceinline__ void flash_load(TileRegs<D>& r, const float* __restri
   }
 }
 
-// q/k point at the (anchor, head) slice (row stride C floats); v points at the TRANSPOSED values of the slice, vt[dd * Mp + key]
+// q/k point at the (anchor, head) slice (row strides q_rs / k_rs floats: they may be column blocks of a wider projection); v points at the TRANSPOSED values of the slice, vt[dd * Mp + key]
 // (keys zero-padded to Mp, a multiple of 32).  bias (may be null) points at the (ah) slice, row stride Mp.
 // The loads of tile t+step are issued before the MFMAs of tile t (two register sets).
 template <int D>
 __device__ __forceinline__ void flash_tiles(FlashState<D>& st, const float* __restrict__ q, const float* __restrict__ k,
                                             const float* __restrict__ v, const float* __restrict__ bias, int n0, int N, int M,
-                                            int C, int Mp, float scale, int tile_begin, int tile_step) {
+                                            int q_rs, int k_rs, int v_rs, int Mp, float scale, int tile_begin, int tile_step) {
   constexpr int DT = FlashState<D>::DT, KU = FlashState<D>::KU;
   const int lane = threadIdx.x & 63, half = lane >> 5, c32 = lane & 31;
   const int nq = min(n0 + c32, N - 1);
   float4 qf[KU];
 #pragma unroll
-  for (int u = 0; u < KU; u++) qf[u] = ld4(q + (size_t)nq * C + 8 * u + 4 * half);
+  for (int u = 0; u < KU; u++) qf[u] = ld4(q + (size_t)nq * q_rs + 8 * u + 4 * half);
   const float* bias_row = bias ? bias + (size_t)nq * Mp : nullptr;
   const int tiles = (M + 31) >> 5;
   TileRegs<D> cur, nxt;
   int tile = tile_begin;
-  if (tile < tiles) flash_load<D>(cur, k, v, bias_row, tile << 5, M, C, Mp);
+  if (tile < tiles) flash_load<D>(cur, k, v, bias_row, tile << 5, M, k_rs, v_rs);
   for (; tile < tiles; tile += tile_step) {
     const int m0 = tile << 5;
     const bool more = tile + tile_step < tiles;
-    if (more) flash_load<D>(nxt, k, v, bias_row, (tile + tile_step) << 5, M, C, Mp);
+    if (more) flash_load<D>(nxt, k, v, bias_row, (tile + tile_step) << 5, M, k_rs, v_rs);
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; r++) s[r] = 0.f;
@@ -317,6 +330,7 @@ struct AttnArgs {
   const float *q, *k, *v, *bias;
   float* out;
   int N, M, C, H, Mp;
+  int q_rs, k_rs, v_rs;               // row strides of q, k (>= C) and of the transposed values (>= ceil32(M)) in floats
   long long q_sa, k_sa, v_sa, o_sa;   // anchor strides in floats (0 = shared by all anchors)
   float scale;
 };
@@ -331,8 +345,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_kernel(AttnArgs p) {
   FlashState<D> st;
   flash_init(st);
   const float* bias = p.bias ? p.bias + ((size_t)(a * p.H + h) * p.N) * p.Mp : nullptr;
-  flash_tiles<D>(st, p.q + a * p.q_sa + h * D, p.k + a * p.k_sa + h * D, p.v + a * p.v_sa + (size_t)h * D * p.Mp, bias, n0, p.N, p.M, p.C,
-                 p.Mp, p.scale, wave, NW);
+  flash_tiles<D>(st, p.q + a * p.q_sa + h * D, p.k + a * p.k_sa + h * D, p.v + a * p.v_sa + (size_t)h * D * p.v_rs, bias, n0, p.N, p.M, p.q_rs,
+                 p.k_rs, p.v_rs, p.Mp, p.scale, wave, NW);
   flash_merge<D, NW>(st, sm, sl, so);
   if (wave == 0) flash_store<D>(st, p.out + a * p.o_sa + h * D, n0, p.N, p.C, 1.f, false);
 }
@@ -398,7 +412,7 @@ __global__ __launch_bounds__(256) void cross_eq_apply_kernel(const float* __rest
     FlashState<D> st;
     flash_init(st);
     flash_tiles<D>(st, q + (size_t)a * N * C + h * D, k + (size_t)e * M * C + h * D, vt + ((size_t)e * C + h * D) * Mp, nullptr,
-                   n0, N, M, C, Mp, scale, 0, 1);
+                   n0, N, M, C, C, Mp, Mp, scale, 0, 1);
     const float w = mix[a * A + e] / st.l;
 #pragma unroll
     for (int dt = 0; dt < DT; dt++)
@@ -444,9 +458,11 @@ static int g_bias_split = 0;
 // tuning hooks (benchmarks only): kernel variant / m-split override; 0 = default
 extern "C" void se3_debug_set_bias_variant(int variant, int split) { g_bias_variant = variant; g_bias_split = split; }
 
-extern "C" int se3_rpe_bias_fwd(const float* qp_frag, const float* qe, const float* emb, const float* eq_emb, int N, int M, int C,
-                                int AH, int H, int bias_row_stride, float* bias, void* stream) {
-  SE3_REQUIRE(qp_frag && emb && bias, SE3_ERR_INVALID_ARG, "rpe_bias: null pointer");
+extern "C" int se3_rpe_bias_fwd(const float* qp, const float* qe, int row_stride, int64_t anchor_stride, const float* emb,
+                                const float* eq_emb, int N, int M, int C, int AH, int H, int bias_row_stride, float* bias,
+                                void* stream) {
+  SE3_REQUIRE(qp && emb && bias, SE3_ERR_INVALID_ARG, "rpe_bias: null pointer");
+  SE3_REQUIRE(row_stride % 4 == 0 && row_stride >= H * C, SE3_ERR_INVALID_ARG, "rpe_bias: folded-query row stride");
   SE3_REQUIRE((qe == nullptr) == (eq_emb == nullptr), SE3_ERR_INVALID_ARG, "rpe_bias: qe and eq_emb go together");
   SE3_REQUIRE(N >= 1 && M >= 1 && AH >= 1 && AH <= 32 && H >= 1 && AH % H == 0, SE3_ERR_UNSUPPORTED,
               "rpe_bias: N %d M %d AH %d H %d", N, M, AH, H);
@@ -458,7 +474,7 @@ extern "C" int se3_rpe_bias_fwd(const float* qp_frag, const float* qe, const flo
   if (split < 1) split = 1;
   if (g_bias_split > 0) split = g_bias_split;
   dim3 grid((unsigned)N, (unsigned)split);
-#define SE3_BIAS_ARGS qp_frag, qe, emb, eq_emb, N, M, AH, H, bias_row_stride, bias
+#define SE3_BIAS_ARGS qp, qe, row_stride, anchor_stride, emb, eq_emb, N, M, AH, H, bias_row_stride, bias
 #define SE3_BIAS_LAUNCH(CT)                                                                                          \
   if (AH <= 16) {                                                                                                    \
     switch (g_bias_variant) {                                                                                        \
@@ -492,15 +508,19 @@ extern "C" int se3_rpe_bias_fwd(const float* qp_frag, const float* qe, const flo
 }
 
 extern "C" int se3_attention_fwd(const float* q, const float* k, const float* v, const float* bias, int num_anchors, int N,
-                                 int M, int C, int H, int64_t q_anchor_stride, int64_t k_anchor_stride,
-                                 int64_t v_anchor_stride, int64_t out_anchor_stride, int bias_row_stride, float scale,
-                                 float* out, void* stream) {
+                                 int M, int C, int H, int q_row_stride, int k_row_stride, int v_row_stride,
+                                 int64_t q_anchor_stride, int64_t k_anchor_stride, int64_t v_anchor_stride,
+                                 int64_t out_anchor_stride, int bias_row_stride, float scale, float* out, void* stream) {
+  SE3_REQUIRE(v_row_stride >= ((M + 31) / 32) * 32 && v_row_stride % 4 == 0, SE3_ERR_INVALID_ARG,
+              "attention: transposed-value row stride must be a multiple of 4 covering ceil32(M)");
+  SE3_REQUIRE(q_row_stride >= C && k_row_stride >= C && q_row_stride % 4 == 0 && k_row_stride % 4 == 0, SE3_ERR_INVALID_ARG,
+              "attention: q/k row strides must be multiples of 4 and >= C");
   SE3_REQUIRE(q && k && v && out, SE3_ERR_INVALID_ARG, "attention: null pointer");
   SE3_REQUIRE(num_anchors >= 1 && N >= 1 && M >= 1 && H >= 1 && C % H == 0, SE3_ERR_INVALID_ARG, "attention: bad sizes");
-  SE3_REQUIRE(bias_row_stride >= ((M + 31) / 32) * 32 && bias_row_stride % 4 == 0, SE3_ERR_INVALID_ARG,
-              "attention: the key stride (bias rows, transposed values) must be a multiple of 4 covering ceil32(M)");
-  AttnArgs p{q, k, v, bias, out, N, M, C, H, bias_row_stride, q_anchor_stride, k_anchor_stride, v_anchor_stride,
-             out_anchor_stride, scale};
+  SE3_REQUIRE(bias == nullptr || (bias_row_stride >= ((M + 31) / 32) * 32 && bias_row_stride % 4 == 0), SE3_ERR_INVALID_ARG,
+              "attention: bias rows must be padded to a multiple of 4 covering ceil32(M)");
+  AttnArgs p{q, k, v, bias, out, N, M, C, H, bias_row_stride, q_row_stride, k_row_stride, v_row_stride, q_anchor_stride, k_anchor_stride,
+             v_anchor_stride, out_anchor_stride, scale};
   dim3 grid((unsigned)((N + 31) / 32), (unsigned)H, (unsigned)num_anchors);
   hipStream_t st = (hipStream_t)stream;
   const bool wide = (M + 31) / 32 >= 6;      // enough key tiles to feed 8 waves per (anchor, head, query tile)

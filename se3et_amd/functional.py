@@ -97,10 +97,82 @@ def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, 
 # D: attention
 # ---------------------------------------------------------------------------------------------------------------------
 def rpe_attention(q, k, vt, emb, w_p, eq_emb, w_eq, num_heads, return_scores=False):
-    """q ([A,] N, C), k ([A,] M, C) already projected, vt ([A,] C, Mp) = project_values_transposed; emb (N, M, C); eq_emb (A, N, M, 4) or None.
-    softmax_m((q.k + q.(W_p emb) + q.(W_eq eq_emb)) / sqrt(d)) v with the position terms folded onto the query side
-    (q.(W e + b) = (W^T q).e + q.b, and the q.b term is constant along m so it cancels in the softmax)."""
-    return _ops.rpe_attention(q, k, vt, emb, w_p, eq_emb, w_eq, num_heads, return_scores)
+    """q ([A,] N, C), k ([A,] M, C) already projected, vt ([A,] C, Mp) = project_values_transposed; emb (N, M, C); eq_emb
+    (A, N, M, 4) or None.  softmax_m((q.k + q.(W_p emb) + q.(W_eq eq_emb)) / sqrt(d)) v with the position terms folded onto
+    the query side (q.(W e + b) = (W^T q).e + q.b; the q.b term is constant along m and cancels in the softmax).
+    Convenience form (the layers use `rpe_self_attention_packed`, which gets q, k and the folded queries from ONE GEMM)."""
+    anchored = q.dim() == 3
+    q3 = q if anchored else q.unsqueeze(0)
+    A, N, C = q3.shape
+    H = num_heads
+    d = C // H
+    qh = q3.reshape(A, N, H, d)
+    qp = torch.einsum('anhd,hdc->anhc', qh, w_p.view(H, d, C)).reshape(A, N, H * C)
+    qe = None
+    if eq_emb is not None:      # qp and qe must be column blocks of one tensor (shared strides)
+        both = torch.cat((qp, torch.einsum('anhd,hde->anhe', qh, w_eq.view(H, d, 4)).reshape(A, N, 4 * H)), -1)
+        qp, qe = both[..., :H * C], both[..., H * C:]
+    bias = _ops.rpe_bias(qp, qe, emb, eq_emb, H)
+    out = _ops.attention(q3, k if anchored else k.unsqueeze(0), vt if anchored else vt.unsqueeze(0), bias, H, tag='rpe')
+    scores = None
+    if return_scores:        # diagnostic path: the product never needs the (A, H, N, M) tensor
+        M = emb.shape[1]
+        k3 = k if anchored else k.unsqueeze(0)
+        sc = torch.einsum('anhd,amhd->ahnm', qh, k3.reshape(A, M, H, d)) + bias.view(A, H, N, -1)[..., :M]
+        scores = torch.softmax(sc / math.sqrt(d), -1)
+        scores = scores if anchored else scores[0]
+    return (out if anchored else out[0]), scores
+
+
+def compose_self_attention_weights(w_q, b_q, w_k, b_k, w_p, w_eq, num_heads):
+    """Stacked projection [q | k | qp | qe] of RPE self attention as ONE linear layer.  qp = W_p^T q and qe = W_eq^T q are
+    linear in x, so their weights compose with W_q: W_qp[(h, c), i] = sum_j W_q[h d + j, i] W_p[h d + j, c] (float64
+    composition, cached by the caller per weight version).  Returns (weight (2C + HC [+ 4H], C), bias, column offsets)."""
+    C = w_q.shape[0]
+    H = num_heads
+    d = C // H
+    wq, bq, wp = w_q.detach().double(), b_q.detach().double(), w_p.detach().double()
+    w_qp = torch.einsum('hji,hjc->hci', wq.view(H, d, C), wp.view(H, d, C)).reshape(H * C, C)
+    b_qp = torch.einsum('hj,hjc->hc', bq.view(H, d), wp.view(H, d, C)).reshape(H * C)
+    ws, bs = [wq, w_k.detach().double(), w_qp], [bq, b_k.detach().double(), b_qp]
+    offs = {'q': 0, 'k': C, 'qp': 2 * C, 'qe': None}
+    if w_eq is not None:
+        we = w_eq.detach().double()
+        ws.append(torch.einsum('hji,hje->hei', wq.view(H, d, C), we.view(H, d, 4)).reshape(4 * H, C))
+        bs.append(torch.einsum('hj,hje->he', bq.view(H, d), we.view(H, d, 4)).reshape(4 * H))
+        offs['qe'] = 2 * C + H * C
+    return torch.cat(ws, 0).float().contiguous(), torch.cat(bs, 0).float().contiguous(), offs
+
+
+def pack_rows(xs, multiple=32):
+    """([A,] N_i, C) tensors -> one zero-padded ([A,] sum ceil_mult(N_i), C) tensor + the row offset of every segment."""
+    starts, total = [], 0
+    for x in xs:
+        starts.append(total)
+        total += (x.shape[-2] + multiple - 1) // multiple * multiple
+    packed = torch.zeros(xs[0].shape[:-2] + (total, xs[0].shape[-1]), dtype=xs[0].dtype, device=xs[0].device)
+    for x, s0 in zip(xs, starts):
+        packed[..., s0:s0 + x.shape[-2], :] = x
+    return packed, starts
+
+
+def rpe_self_attention_packed(x, starts, lengths, embs, eq_embs, w_stack, b_stack, offs, w_v, b_v, num_heads):
+    """RPE self attention of several clouds at once.  x ([A,] R, C): the clouds' rows packed at `starts` (multiples of 32) with
+    `lengths`; ONE stacked GEMM yields q, k and the folded queries of all clouds, ONE GEMM the transposed values; the two
+    attention kernels run per cloud on strided views.  Returns hidden ([A,] R, C) (padding rows are zero)."""
+    H = num_heads
+    C = x.shape[-1]
+    x3 = x if x.dim() == 3 else x.unsqueeze(0)
+    proj = F.linear(x3, w_stack, b_stack)                                  # (A, R, 2C + HC [+ 4H])
+    vt = torch.matmul(w_v, x3.transpose(-1, -2)) + b_v[:, None]            # (A, C, R): transposed values of every cloud
+    hidden = torch.zeros_like(x3)
+    for s0, n, emb, eq in zip(starts, lengths, embs, eq_embs):
+        rows = proj[:, s0:s0 + n]
+        qe = rows[..., offs['qe']:offs['qe'] + 4 * H] if eq is not None else None
+        bias = _ops.rpe_bias(rows[..., offs['qp']:offs['qp'] + H * C], qe, emb, eq, H)
+        _ops.attention(rows[..., offs['q']:offs['q'] + C], rows[..., offs['k']:offs['k'] + C],
+                       vt[:, :, s0:s0 + _ops.key_stride(n)], bias, H, out=hidden[:, s0:s0 + n], tag='rpe')
+    return hidden if x.dim() == 3 else hidden[0]
 
 
 def cross_attention(q, k, vt, num_heads):

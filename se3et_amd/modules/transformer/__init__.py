@@ -103,15 +103,37 @@ class RPEMultiHeadAttention(nn.Module):
         if equivariant and d_equiv_embed > 0:
             self.proj_eq = nn.Linear(d_equiv_embed, d_model)
 
+    def stacked_projection(self):
+        """(weight, bias, column offsets) of the fused [q | k | W_p^T q | W_eq^T q] projection, cached per weight version."""
+        params = [self.proj_q.weight, self.proj_q.bias, self.proj_k.weight, self.proj_k.bias, self.proj_p.weight]
+        use_eq = self.equivariant and self.d_equiv_embed > 0
+        if use_eq:
+            params.append(self.proj_eq.weight)
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        cache = getattr(self, '_stack_cache', None)
+        if cache is None or cache[0] != key:
+            w, b, offs = SF.compose_self_attention_weights(self.proj_q.weight, self.proj_q.bias, self.proj_k.weight,
+                                                           self.proj_k.bias, self.proj_p.weight,
+                                                           self.proj_eq.weight if use_eq else None, self.num_heads)
+            cache = (key, w, b, offs)
+            self._stack_cache = cache
+        return cache[1], cache[2], cache[3]
+
+    def forward_packed(self, x, starts, lengths, embs, eq_embs):
+        """Self attention of several clouds packed row-wise in x ([A,] R, C) (see functional.pack_rows)."""
+        use_eq = self.equivariant and self.d_equiv_embed > 0
+        if use_eq and any(e is None for e in eq_embs):
+            raise RuntimeError('Equivariant embedding required here.')
+        w, b, offs = self.stacked_projection()
+        return SF.rpe_self_attention_packed(x, starts, lengths, embs, eq_embs if use_eq else [None] * len(embs), w, b, offs,
+                                            self.proj_v.weight, self.proj_v.bias, self.num_heads)
+
     def forward(self, input_q, input_k, input_v, embed_qk, key_weights=None, key_masks=None, attention_factors=None,
                 embed_eq=None):
         _no(key_weights, 'key_weights'), _no(key_masks, 'key_masks'), _no(attention_factors, 'attention_factors')
         xq, xk, xv = _one(input_q, 'input_q'), _one(input_k, 'input_k'), _one(input_v, 'input_v')
-        if xq is xk or (xq.data_ptr() == xk.data_ptr() and xq.shape == xk.shape):      # self attention: one stacked GEMM
-            q, k = SF.project_qk(xq, self.proj_q.weight, self.proj_q.bias, self.proj_k.weight, self.proj_k.bias)
-        else:
-            q = SF.linear(xq, self.proj_q.weight, self.proj_q.bias)
-            k = SF.linear(xk, self.proj_k.weight, self.proj_k.bias)
+        q = SF.linear(xq, self.proj_q.weight, self.proj_q.bias)
+        k = SF.linear(xk, self.proj_k.weight, self.proj_k.bias)
         v = SF.project_values_transposed(xv, self.proj_v.weight, self.proj_v.bias)
         use_eq = self.equivariant and self.d_equiv_embed > 0
         if use_eq and embed_eq is None:
@@ -139,6 +161,11 @@ class RPEAttentionLayer(nn.Module):
         hidden = SF.linear(hidden, self.linear.weight, self.linear.bias)
         return SF.add_layer_norm(hidden, input_states, self.norm.weight, self.norm.bias, self.norm.eps), scores
 
+    def forward_packed(self, x, starts, lengths, embs, eq_embs):
+        hidden = self.attention.forward_packed(x, starts, lengths, embs, eq_embs)
+        hidden = SF.linear(hidden, self.linear.weight, self.linear.bias)
+        return SF.add_layer_norm(hidden, x, self.norm.weight, self.norm.bias, self.norm.eps)
+
 
 class RPETransformerLayer(nn.Module):
     def __init__(self, d_model, num_heads, dropout=None, activation_fn='ReLU', equivariant=False, d_equiv_embed=0):
@@ -151,6 +178,18 @@ class RPETransformerLayer(nn.Module):
         hidden, scores = self.attention(input_states, memory_states, position_states, memory_weights, memory_masks,
                                         attention_factors, equiv_states)
         return self.output(hidden), scores
+
+    def forward_pair(self, feats0, feats1, embeddings0, embeddings1, equiv0=None, equiv1=None):
+        """Self attention of both clouds in one pass: rows packed into one tensor so that every dense layer (stacked
+        q/k/folded-query projection, value projection, output linear, FFN, both LayerNorms) runs ONCE for the pair."""
+        x0, x1 = _one(feats0, 'feats0'), _one(feats1, 'feats1')
+        x, starts = SF.pack_rows([x0, x1])
+        lengths = [x0.shape[-2], x1.shape[-2]]
+        eqs = [_one(equiv0, 'equiv0') if equiv0 is not None else None, _one(equiv1, 'equiv1') if equiv1 is not None else None]
+        y = self.attention.forward_packed(x, starts, lengths, [_one(embeddings0, 'emb0'), _one(embeddings1, 'emb1')], eqs)
+        y = self.output(y)
+        return (y[..., starts[0]:starts[0] + lengths[0], :].unsqueeze(0),
+                y[..., starts[1]:starts[1] + lengths[1], :].unsqueeze(0))
 
 
 class MultiHeadAttention(nn.Module):
@@ -322,8 +361,8 @@ class RPEConditionalTransformer(nn.Module):
             if 'self' in block:
                 src0, src1 = (feats0_eq, feats1_eq) if feats0_eq is not None and feats1_eq is not None else (feats0, feats1)
                 eq = block == 'self_eq'
-                feats0, _ = layer(src0, src0, embeddings0, equiv_states=equiv_embed0 if eq else None)
-                feats1, _ = layer(src1, src1, embeddings1, equiv_states=equiv_embed1 if eq else None)
+                feats0, feats1 = layer.forward_pair(src0, src1, embeddings0, embeddings1, equiv_embed0 if eq else None,
+                                                    equiv_embed1 if eq else None)
                 if eq and nxt == 'cross':
                     feats0_eq, feats1_eq = feats0, feats1
                     feats0, feats1 = SF.anchor_max(feats0_eq, dim=1), SF.anchor_max(feats1_eq, dim=1)

@@ -239,81 +239,87 @@ def key_stride(M):
     return (M + 31) // 32 * 32
 
 
-def _attention(q, k, vt, bias, A, N, M, C, H, q_sa, k_sa, v_per_anchor, Mp, timed_bytes=None):
-    """vt: transposed, key-padded values ([A,] C, Mp) (see functional.project_values_transposed)."""
-    out = torch.empty((A, N, C), dtype=torch.float32, device=q.device)
-    if vt.shape[-1] != Mp or vt.shape[-2] != C:
-        raise RuntimeError('attention: transposed values must be (.., C, %d), got %s' % (Mp, tuple(vt.shape)))
-    with _timed('attention_kernel', timed_bytes or 0):
-        check(lib().se3_attention_fwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(),
-                                      bias.data_ptr() if bias is not None else None, A, N, M, C, H, q_sa, k_sa,
-                                      C * Mp if v_per_anchor else 0, N * C, Mp, 1.0 / math.sqrt(C // H), out.data_ptr(),
-                                      _stream()), 'se3_attention_fwd')
+def _rows_view(t, name, C=None):
+    """([A,] rows, C') float32 GPU view with unit last stride and 16-byte aligned rows -> (tensor3, anchors, rows, row_stride,
+    anchor_stride); column blocks / row ranges of a wider tensor are accepted as they are (no copy)."""
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise RuntimeError('%s must be a float32 GPU tensor' % name)
+    if t.dim() == 2:
+        t = t.unsqueeze(0)
+    if t.dim() != 3 or t.stride(-1) != 1 or t.stride(-2) % 4 or (t.shape[0] > 1 and t.stride(0) % 4) or t.data_ptr() % 16:
+        t = t.contiguous()
+    if C is not None and t.shape[-1] != C:
+        raise RuntimeError('%s: last dim %d != %d' % (name, t.shape[-1], C))
+    return t, t.shape[0], t.shape[1], t.stride(1), (t.stride(0) if t.shape[0] > 1 else 0)
+
+
+def attention(q, k, vt, bias, num_heads, out=None, v_shared=False, tag=None):
+    """softmax_m((q.k [+ bias]) / sqrt(d)) v through se3_attention_fwd.  q ([A,] N, C), k ([A,] M, C): strided views are
+    fine; vt ([A,] C, >= ceil32(M)) transposed values; bias (A*H, N, Mp) or None; out: optional ([A,] N, C) view with
+    contiguous rows.  A = number of output anchors = anchors of vt (q/k with one anchor are broadcast)."""
+    H = num_heads
+    q3, Aq, N, q_rs, q_sa = _rows_view(q, 'q')
+    C = q3.shape[-1]
+    k3, Ak, M, k_rs, k_sa = _rows_view(k, 'k', C)
+    v3 = vt if vt.dim() == 3 else vt.unsqueeze(0)
+    if not v3.is_cuda or v3.dtype != torch.float32 or v3.stride(-1) != 1 or v3.stride(-2) % 4 or v3.data_ptr() % 16:
+        v3 = v3.contiguous()
+    Av, v_rs = v3.shape[0], v3.stride(1)
+    if v3.shape[1] != C or v3.shape[2] < M:
+        raise RuntimeError('attention: transposed values %s do not match C=%d, M=%d' % (tuple(v3.shape), C, M))
+    A = max(Aq, Ak, Av)
+    Mp = key_stride(M)
+    if bias is not None and (tuple(bias.shape) != (A * H, N, Mp) or not bias.is_contiguous()):
+        raise RuntimeError('attention: bias must be a contiguous (A*H, N, %d) tensor' % Mp)
+    if out is None:
+        out = torch.empty((A, N, C), dtype=torch.float32, device=q3.device)
+    o3 = out if out.dim() == 3 else out.unsqueeze(0)
+    if tuple(o3.shape) != (A, N, C) or o3.stride(-1) != 1 or o3.stride(-2) != C:
+        raise RuntimeError('attention: out must be (A, N, C) with contiguous rows')
+    with _timed('attention_kernel' if tag is None else 'attention_kernel@' + tag, 0):
+        check(lib().se3_attention_fwd(q3.data_ptr(), k3.data_ptr(), v3.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                      A, N, M, C, H, q_rs, k_rs, v_rs, q_sa if Aq > 1 else 0, k_sa if Ak > 1 else 0,
+                                      v3.stride(0) if Av > 1 else 0, o3.stride(0) if A > 1 else 0, Mp,
+                                      1.0 / math.sqrt(C // H), o3.data_ptr(), _stream()), 'se3_attention_fwd')
     return out
 
 
-def rpe_attention(q, k, vt, emb, w_p, eq_emb, w_eq, num_heads, return_scores):
-    """HIP (csrc/attention.hip): position logits streamed from the embedding once (se3_rpe_bias_fwd), then the
-    flash-style softmax/PV kernel (se3_attention_fwd).  The two fold GEMMs W_p^T q / W_eq^T q are library GEMMs."""
-    anchored = q.dim() == 3
-    q3 = _req((q if anchored else q.unsqueeze(0)).contiguous(), torch.float32, 'q', 3)
-    k3 = _req((k if anchored else k.unsqueeze(0)).contiguous(), torch.float32, 'k', 3)
-    vt3 = _req((vt if anchored else vt.unsqueeze(0)).contiguous(), torch.float32, 'vt', 3)
-    emb = _req(emb.contiguous(), torch.float32, 'embed_qk', 3)
-    A, N, C = q3.shape
-    M, H = k3.shape[1], num_heads
-    d = C // H
-    if tuple(emb.shape) != (N, M, C):
-        raise RuntimeError('rpe_attention: embedding shape %s != %s' % (tuple(emb.shape), (N, M, C)))
-    qh = q3.view(A, N, H, d)
-    AH = A * H
-    RT = 1 if AH <= 16 else 2
-    if AH > 32 or C % 16 != 0:
-        raise RuntimeError('rpe_attention: anchors*heads must be <= 32 and C a multiple of 16')
-    qp = torch.zeros((N, RT * 16, C), dtype=torch.float32, device=q.device)
-    qp[:, :AH] = torch.einsum('anhd,hdc->nahc', qh, w_p.view(H, d, C)).reshape(N, AH, C)
-    # MFMA-fragment order for the bias kernel: [n][rt][t][kq][r][4]
-    qp = qp.view(N, RT, 16, C // 16, 4, 4).permute(0, 1, 3, 4, 2, 5).contiguous()
-    qe = None
-    if eq_emb is not None:
-        eq_emb = _req(eq_emb.contiguous(), torch.float32, 'embed_eq', 4)
+def rpe_bias(qp, qe, emb, eq_emb, num_heads):
+    """Relative-position logits (A*H, N, Mp) from the folded queries qp ([A,] N, H*C) [and qe ([A,] N, 4*H)] (strided views
+    of one projection are fine: qp and qe must share row / anchor strides) and the embeddings emb (N, M, C), eq_emb (A, N, M, 4)."""
+    H = num_heads
+    emb = _req(emb, torch.float32, 'embed_qk', 3)
+    N, M, C = emb.shape
+    qp3, A, Nq, rs, sa = _rows_view(qp, 'qp', H * C)
+    if Nq != N:
+        raise RuntimeError('rpe_bias: %d folded query rows for an (N=%d, M, C) embedding' % (Nq, N))
+    qe_ptr = None
+    eq_ptr = None
+    if qe is not None:
+        qe3, Ae, Ne, rs_e, sa_e = _rows_view(qe, 'qe', 4 * H)
+        if (Ae, Ne, rs_e, sa_e) != (A, N, rs, sa):
+            raise RuntimeError('rpe_bias: qe must be a column block of the same projection as qp')
+        eq_emb = _req(eq_emb, torch.float32, 'embed_eq', 4)
         if tuple(eq_emb.shape) != (A, N, M, 4):
-            raise RuntimeError('rpe_attention: equivariant embedding shape %s' % (tuple(eq_emb.shape),))
-        qe = torch.einsum('anhd,hde->nahe', qh, w_eq.view(H, d, 4)).contiguous()       # (N, A*H, 4)
-    Mp = (M + 31) // 32 * 32
-    bias = torch.empty((A * H, N, Mp), dtype=torch.float32, device=q.device)
+            raise RuntimeError('rpe_bias: equivariant embedding shape %s' % (tuple(eq_emb.shape),))
+        qe_ptr, eq_ptr = qe3.data_ptr(), eq_emb.data_ptr()
+    if A * H > 32 or C % 16:
+        raise RuntimeError('rpe_bias: anchors*heads must be <= 32 and C a multiple of 16')
+    Mp = key_stride(M)
+    bias = torch.empty((A * H, N, Mp), dtype=torch.float32, device=emb.device)
     # algorithmic bytes of one self-attention call (SURVEY.md section 8d): q, k, v in + out, the embedding, the eq-embedding;
-    # booked on the embedding-streaming kernel, the attention kernel is booked with 0 extra bytes (same call)
+    # booked on this (embedding-streaming) launch, the attention launch of the same call is booked with 0 bytes
     survey_bytes = 4 * (4 * A * N * C + N * M * C + (A * N * M * 4 if qe is not None else 0))
     with _timed('rpe_bias_kernel', survey_bytes):
-        check(lib().se3_rpe_bias_fwd(qp.data_ptr(), qe.data_ptr() if qe is not None else None, emb.data_ptr(),
-                                     eq_emb.data_ptr() if qe is not None else None, N, M, C, A * H, H, Mp,
+        check(lib().se3_rpe_bias_fwd(qp3.data_ptr(), qe_ptr, rs, sa, emb.data_ptr(), eq_ptr, N, M, C, A * H, H, Mp,
                                      bias.data_ptr(), _stream()), 'se3_rpe_bias_fwd')
-    global TIMING_TAG
-    TIMING_TAG = 'rpe'
-    try:
-        out = _attention(q3, k3, vt3, bias, A, N, M, C, H, N * C, M * C, True, Mp, timed_bytes=0)
-    finally:
-        TIMING_TAG = None
-    scores = None
-    if return_scores:        # diagnostic path: the product never needs the (A, H, N, M) tensor
-        s = torch.einsum('anhd,amhd->ahnm', qh, k3.view(A, M, H, d)) + bias.view(A, H, N, Mp)[..., :M]
-        scores = torch.softmax(s / math.sqrt(d), -1)
-        scores = scores if anchored else scores[0]
-    return (out if anchored else out[0]), scores
+    return bias
 
 
 def cross_attention(q, k, vt, num_heads):
-    """HIP: plain cross attention; vt (C, Mp) or (A, C, Mp) transposed key-padded values (per-anchor values share the scores)."""
-    q = _req(q.contiguous(), torch.float32, 'q', 2)
-    k = _req(k.contiguous(), torch.float32, 'k', 2)
-    vt = _req(vt.contiguous(), torch.float32, 'vt')
-    N, C = q.shape
-    M = k.shape[0]
-    Mp = key_stride(M)
-    if vt.dim() == 2:
-        return _attention(q, k, vt, None, 1, N, M, C, num_heads, 0, 0, False, Mp)[0]
-    return _attention(q, k, vt, None, vt.shape[0], N, M, C, num_heads, 0, 0, True, Mp)
+    """HIP: plain cross attention; vt (C, Mp) or (A, C, Mp) transposed values (per-anchor values share the scores)."""
+    out = attention(q, k, vt, None, num_heads)
+    return out[0] if vt.dim() == 2 else out
 
 
 def cross_attention_eq(q, k, vt, num_heads, mode, trace_idx):

@@ -14,14 +14,14 @@ def run(A, N, C, H, eq, variant, split, iters=30):
     if A == 1: q, k, v = q[0], k[0], v[0]
     from se3et_amd import functional as SF
     v = SF.project_values_transposed(v, torch.eye(C, device='cuda'), torch.zeros(C, device='cuda'))
-    for _ in range(3): ops.rpe_attention(q, k, v, emb, wp, eqe, weq, H, False)
+    for _ in range(3): SF.rpe_attention(q, k, v, emb, wp, eqe, weq, H, False)
     ops.KERNEL_TIMINGS = {}
-    for _ in range(iters): ops.rpe_attention(q, k, v, emb, wp, eqe, weq, H, False)
+    for _ in range(iters): SF.rpe_attention(q, k, v, emb, wp, eqe, weq, H, False)
     torch.cuda.synchronize()
     t = ops.KERNEL_TIMINGS; ops.KERNEL_TIMINGS = None
     f = lambda n: sum(a.elapsed_time(b) for a, b, _ in t[n]) / len(t[n]) * 1e3
     nb = t['rpe_bias_kernel'][0][2]
-    return f('rpe_bias_kernel'), f('rpe_bias_kernel') + f('attention_kernel'), nb, f('attention_kernel')
+    return f('rpe_bias_kernel'), f('rpe_bias_kernel') + f('attention_kernel@rpe'), nb, f('attention_kernel@rpe')
 
 import random, time
 x = torch.randn(4096, 4096, device='cuda')

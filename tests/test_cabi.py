@@ -33,7 +33,7 @@ def test_argument_validation_without_gpu():
     assert b'radius_neighbors' in L.se3_last_error()
     assert L.se3_grid_subsample_workspace_bytes(10000, 2) > 0
     assert L.se3_group_norm_workspace_bytes(1000, 64, 32) > 0
-    assert L.se3_attention_fwd(None, None, None, None, 1, 1, 1, 32, 4, 0, 0, 0, 0, 0, 1.0, None, None) != 0
+    assert L.se3_attention_fwd(None, None, None, None, 1, 1, 1, 32, 4, 32, 32, 32, 0, 0, 0, 0, 0, 1.0, None, None) != 0
 
 
 def test_product_refuses_cpu_tensors():
