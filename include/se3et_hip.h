@@ -134,6 +134,9 @@ int se3_attention_fwd(const float* q, const float* k, const float* vt, const flo
  * out[a] = sum_e mix[a, e] softmax_m(q_a.k_e * scale) v_e (vt: transposed key-padded values (A, C, key_stride)). */
 int se3_cross_eq_stats(const float* q, const float* k, int A, int N, int M, int C, int H, float scale, float* partial,
                        int* num_partials_per_pair, void* stream);
+/* mode 0 = a_soft (weights: A*A values = mix), mode 1 = r_soft (weights: num_rotations values; trace_idx (R, A) int64) */
+int se3_cross_eq_mix(const float* partial, int num_partials_per_pair, int A, int N, int M, int mode, const int64_t* trace_idx,
+                     int num_rotations, float* mix, float* weights, void* stream);
 int se3_cross_eq_apply(const float* q, const float* k, const float* vt, const float* mix, int A, int N, int M, int C, int H,
                        int key_stride, float scale, float* out, void* stream);
 

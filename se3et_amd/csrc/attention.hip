@@ -438,6 +438,56 @@ __global__ __launch_bounds__(256) void cross_eq_apply_kernel(const float* __rest
   }
 }
 
+// one workgroup: g[a,e] = sum_i partial[(a*A+e)*P + i] / (N M) -> mixing weights.
+//   mode 0 (a_soft): mix[a,e] = g[a,e] / sum_e g[a,e];  weights = mix (A*A values)
+//   mode 1 (r_soft): w[r] = mean_a g[a, trace[r,a]] normalised over r; mix[a,e] = sum_{r: trace[r,a]=e} w[r]; weights = w (R values)
+__global__ __launch_bounds__(64) void cross_eq_mix_kernel(const float* __restrict__ partial, int P, float inv_nm, int A, int R,
+                                                          const int64_t* __restrict__ trace, int mode, float* __restrict__ mix,
+                                                          float* __restrict__ weights) {
+  __shared__ float g[64], w[64], tot;
+  const int t = threadIdx.x;
+  if (t < A * A) {
+    float acc = 0.f;
+    for (int i = 0; i < P; i++) acc += partial[(size_t)t * P + i];
+    g[t] = acc * inv_nm;
+  }
+  __syncthreads();
+  if (mode == 0) {
+    if (t < A * A) {
+      const int a = t / A;
+      float rs = 0.f;
+      for (int e = 0; e < A; e++) rs += g[a * A + e];
+      const float v = g[t] / rs;
+      mix[t] = v;
+      weights[t] = v;
+    }
+    return;
+  }
+  if (t < R) {
+    float acc = 0.f;
+    for (int a = 0; a < A; a++) acc += g[a * A + (int)trace[t * A + a]];
+    w[t] = acc / (float)A;
+  }
+  __syncthreads();
+  if (t == 0) {
+    float s = 0.f;
+    for (int r = 0; r < R; r++) s += w[r];
+    tot = s;
+  }
+  __syncthreads();
+  if (t < R) {
+    w[t] = w[t] / tot;
+    weights[t] = w[t];
+  }
+  __syncthreads();
+  if (t < A * A) {
+    const int a = t / A, e = t - a * A;
+    float acc = 0.f;
+    for (int r = 0; r < R; r++) acc += ((int)trace[r * A + a] == e) ? w[r] : 0.f;
+    mix[t] = acc;
+  }
+}
+
 template <typename F>
 int dispatch_head_dim(int D, F&& f, const char* what) {
   switch (D) {
@@ -546,6 +596,17 @@ extern "C" int se3_cross_eq_stats(const float* q, const float* k, int A, int N, 
   }, "cross_eq_stats");
   if (rc != SE3_OK) return rc;
   SE3_CHECK_LAUNCH("cross_eq_stats");
+  return SE3_OK;
+}
+
+extern "C" int se3_cross_eq_mix(const float* partial, int num_partials_per_pair, int A, int N, int M, int mode,
+                                const int64_t* trace_idx, int num_rotations, float* mix, float* weights, void* stream) {
+  SE3_REQUIRE(partial && mix && weights, SE3_ERR_INVALID_ARG, "cross_eq_mix: null pointer");
+  SE3_REQUIRE(A >= 1 && A * A <= 64 && (mode == 0 || (mode == 1 && trace_idx && num_rotations >= 1 && num_rotations <= 64)),
+              SE3_ERR_UNSUPPORTED, "cross_eq_mix: A %d mode %d rotations %d", A, mode, num_rotations);
+  cross_eq_mix_kernel<<<1, 64, 0, (hipStream_t)stream>>>(partial, num_partials_per_pair, 1.0f / ((float)N * (float)M), A,
+                                                       num_rotations, trace_idx, mode, mix, weights);
+  SE3_CHECK_LAUNCH("cross_eq_mix");
   return SE3_OK;
 }
 

@@ -181,16 +181,14 @@ def cross_attention(q, k, vt, num_heads):
 
 
 def cross_attention_eq(q, k, vt, num_heads, mode, trace_idx):
-    """q (A, N, C), k (A, M, C), vt (A, C, Mp).  Returns (hidden (A, N, C), weights): g/sum_e g (A, A) for 'a_soft', w (R,) for 'r_soft'."""
+    """q (A, N, C), k (A, M, C), vt (A, C, Mp).  Returns (hidden (A, N, C), weights, mix): weights = g/sum_e g (A, A) for
+    'a_soft', w (R,) for 'r_soft'; mix (A, A) = the anchor-pair weights actually applied (for r_soft the 24 rotation weights
+    collapsed onto anchor pairs, mix[a, e] = sum_{r: trace[r, a] = e} w[r])."""
     return _ops.cross_attention_eq(q, k, vt, num_heads, mode, trace_idx)
 
 
-def rotation_weighted_permute(feats, w, trace_idx):
-    """sum_r w[r] feats[:, trace[r, a]] for feats (B, A, N, C): the 24-term sum collapsed onto an (A, A) matrix."""
-    A = trace_idx.shape[1]
-    mix = torch.zeros((A, A), dtype=feats.dtype, device=feats.device)
-    mix.index_put_((torch.arange(A, device=feats.device)[None].expand_as(trace_idx), trace_idx),
-                   w[:, None].expand(-1, A), accumulate=True)
+def rotation_weighted_permute(feats, mix):
+    """sum_r w[r] feats[:, trace[r, a]] for feats (B, A, N, C) with the rotation sum collapsed onto mix (A, A)."""
     return torch.einsum('ae,benc->banc', mix, feats)
 
 

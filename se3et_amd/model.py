@@ -127,6 +127,7 @@ class SE3ET(nn.Module):
                                                      correspondence_limit=f.correspondence_limit,
                                                      num_refinement_steps=f.num_refinement_steps)
         self.optimal_transport = LearnableLogOptimalTransport(cfg.model.num_sinkhorn_iterations)
+        self._valid_host = None
 
     @torch.no_grad()
     def forward(self, data_dict, with_registration=True):
@@ -142,6 +143,12 @@ class SE3ET(nn.Module):
         _, src_nm, src_knn, src_km = point_to_node_partition(src_f, src_c, self.num_points_in_patch)
         ref_knn_pts = SF.gather_rows_padded(ref_f, ref_knn)
         src_knn_pts = SF.gather_rows_padded(src_f, src_knn)
+        # number of non-empty nodes, fetched asynchronously (read only after the transformer, when it has long arrived)
+        if self._valid_host is None:
+            self._valid_host = torch.empty(2, dtype=torch.int64).pin_memory()
+        self._valid_host.copy_(torch.stack((ref_nm.sum(), src_nm.sum())), non_blocking=True)
+        valid_event = torch.cuda.Event()
+        valid_event.record()
 
         feats_list = self.backbone(feats, data_dict)
         feats_c, feats_f = feats_list[-1], feats_list[0]
@@ -153,7 +160,9 @@ class SE3ET(nn.Module):
         out['ref_feats_c'], out['src_feats_c'] = r, s
         out['ref_feats_f'], out['src_feats_f'] = feats_f[:n_f], feats_f[n_f:]
 
-        ri, si, node_scores = self.coarse_matching(r, s, ref_nm, src_nm)
+        valid_event.synchronize()
+        all_valid = self._valid_host.tolist() == [ref_c.shape[0], src_c.shape[0]]
+        ri, si, node_scores = self.coarse_matching(r, s, ref_nm, src_nm, all_valid=all_valid)
         out['ref_node_corr_indices'], out['src_node_corr_indices'], out['node_corr_scores'] = ri, si, node_scores
 
         ref_ck, src_ck = ref_knn[ri], src_knn[si]

@@ -258,11 +258,12 @@ class MultiHeadAttentionEQ(nn.Module):
             q = SF.linear(xq, self.proj_q.weight, self.proj_q.bias)
             k = SF.linear(xk, self.proj_k.weight, self.proj_k.bias)
         v = SF.project_values_transposed(xv, self.proj_v.weight, self.proj_v.bias)
-        hidden, w = SF.cross_attention_eq(q, k, v, self.num_heads, self.attn_mode, self.trace_idx_ori)
+        hidden, w, mix = SF.cross_attention_eq(q, k, v, self.num_heads, self.attn_mode, self.trace_idx_ori)
         if self.attn_mode == 'a_soft':
             return hidden.unsqueeze(0), [None, w.reshape(1, self.na, self.na, 1, 1, 1)]
-        # reference returns [scores, attn_r (b,r,1,1,1,1), attn_matrix, q_inv]; the last two only feed rotation supervision
-        return hidden.unsqueeze(0), [None, w.reshape(1, self.nr, 1, 1, 1, 1), None, None]
+        # reference returns [scores, attn_r (b,r,1,1,1,1), attn_matrix, q_inv] (the last two only feed rotation supervision);
+        # a fifth entry carries the rotation weights collapsed onto anchor pairs for eq2inv_soft
+        return hidden.unsqueeze(0), [None, w.reshape(1, self.nr, 1, 1, 1, 1), None, None, mix]
 
 
 class AttentionLayer(nn.Module):
@@ -344,11 +345,10 @@ class RPEConditionalTransformer(nn.Module):
         if 'cross_r_soft' in self.blocks:
             self.rotcompress = RotCompressOutput(d_model, dropout, activation_fn, na=na)
 
-    def eq2inv_soft(self, feats0, feats1, attn_w0, layer):
-        """feats1 re-expressed in the frame that the ref<-src rotation weights prefer, then both compressed over anchors."""
-        trace = layer.attention.attention.trace_idx_ori
-        feats1_inv = SF.rotation_weighted_permute(feats1, attn_w0.reshape(-1), trace)
-        return self.rotcompress(feats0), self.rotcompress(feats1_inv)
+    def eq2inv_soft(self, feats0, feats1, mix0):
+        """feats1 re-expressed in the frame that the ref<-src rotation weights prefer (sum_r w0[r] feats1[trace[r, a]] =
+        sum_e mix0[a, e] feats1[e]), then both compressed over anchors."""
+        return self.rotcompress(feats0), self.rotcompress(SF.rotation_weighted_permute(feats1, mix0))
 
     def forward(self, feats0, feats1, embeddings0, embeddings1, masks0=None, masks1=None, gt_indices=None,
                 gt_overlap=None, equiv_embed0=None, equiv_embed1=None, ref_normal=None, src_normal=None):
@@ -380,5 +380,5 @@ class RPEConditionalTransformer(nn.Module):
                 feats1, s1 = layer(feats1, feats0)
                 if block == 'cross_r_soft' and nxt is not None and not _block_is_eq(nxt):
                     feats0_eq = feats1_eq = None
-                    feats0, feats1 = self.eq2inv_soft(feats0, feats1, s0[1], layer)
+                    feats0, feats1 = self.eq2inv_soft(feats0, feats1, s0[4])
         return feats0, feats1

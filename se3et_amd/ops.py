@@ -335,26 +335,21 @@ def cross_attention_eq(q, k, vt, num_heads, mode, trace_idx):
     nparts = ctypes.c_int(0)
     check(lib().se3_cross_eq_stats(q.data_ptr(), k.data_ptr(), A, N, M, C, H, scale, partial.data_ptr(),
                                    ctypes.byref(nparts), _stream()), 'se3_cross_eq_stats')
-    g = partial.sum(1).view(A, A) / float(N * M)
-    if mode == 'a_soft':
-        mix = g / g.sum(1, keepdim=True)
-        ret = mix
-    elif mode == 'r_soft':
-        ar = torch.arange(A, device=q.device)
-        wr = g[ar[None, :], trace_idx].mean(1)
-        wr = wr / wr.sum()
-        mix = torch.zeros_like(g)
-        mix.index_put_((ar[None].expand_as(trace_idx), trace_idx), wr[:, None].expand(-1, A), accumulate=True)
-        ret = wr
-    else:
+    if mode not in ('a_soft', 'r_soft'):
         raise RuntimeError('cross_attention_eq: mode %r' % (mode,))
+    R = trace_idx.shape[0]
+    mix = torch.empty((A, A), dtype=torch.float32, device=q.device)
+    ret = torch.empty((A, A) if mode == 'a_soft' else (R,), dtype=torch.float32, device=q.device)
+    trace_idx = _req(trace_idx.contiguous(), torch.int64, 'trace_idx', 2)
+    check(lib().se3_cross_eq_mix(partial.data_ptr(), P, A, N, M, 0 if mode == 'a_soft' else 1, trace_idx.data_ptr(), R,
+                                 mix.data_ptr(), ret.data_ptr(), _stream()), 'se3_cross_eq_mix')
     out = torch.empty((A, N, C), dtype=torch.float32, device=q.device)
     Mp = key_stride(M)
     if tuple(vt.shape) != (A, C, Mp):
         raise RuntimeError('cross_attention_eq: transposed values must be (A, C, %d)' % Mp)
-    check(lib().se3_cross_eq_apply(q.data_ptr(), k.data_ptr(), vt.data_ptr(), mix.contiguous().data_ptr(), A, N, M, C, H,
+    check(lib().se3_cross_eq_apply(q.data_ptr(), k.data_ptr(), vt.data_ptr(), mix.data_ptr(), A, N, M, C, H,
                                    Mp, scale, out.data_ptr(), _stream()), 'se3_cross_eq_apply')
-    return out, ret
+    return out, ret, mix
 
 
 _EMB_D_RANGE, _EMB_D_PER_UNIT = 64.0, 64.0        # distance-index table: [0, 64) index units, 64 entries per unit

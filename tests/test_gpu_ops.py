@@ -229,7 +229,7 @@ def test_cross_attention_eq_matches_oracle(N, M, C, mode):
         want_w = w
     want = hidden.transpose(-2, -3).reshape(6, N, C)
     eye, zero = torch.eye(C).cuda(), torch.zeros(C).cuda()
-    got, got_w = SF.cross_attention_eq(q.cuda(), k.cuda(), SF.project_values_transposed(v.cuda(), eye, zero), H, mode,
+    got, got_w, got_mix = SF.cross_attention_eq(q.cuda(), k.cuda(), SF.project_values_transposed(v.cuda(), eye, zero), H, mode,
                                        trace.cuda())
     assert_close(got_w.cpu(), want_w, 1e-4, 'global weights')
     assert_close(got.cpu(), want, 1e-4, 'eq cross attention')
