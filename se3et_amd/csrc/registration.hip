@@ -131,29 +131,36 @@ __global__ __launch_bounds__(256) void procrustes_kernel(const float* __restrict
     }
     return w;
   };
-  double ws = 0;
-  for (int64_t i = b0 + threadIdx.x; i < b1; i += blockDim.x) ws += (double)weight(i);
-  ws = block_sum(ws, sh);
-  const double inv = 1.0 / (ws + (double)eps);
-  double acc[6] = {0, 0, 0, 0, 0, 0};
+  // one pass: raw weighted moments in float64 (sum w, sum w s, sum w r, sum w s r^T), centred afterwards -- in double the
+  // cancellation of the centring is harmless (coordinates ~1e0..1e2, 53-bit sums)
+  double m[16];
+  for (int k = 0; k < 16; k++) m[k] = 0;
   for (int64_t i = b0 + threadIdx.x; i < b1; i += blockDim.x) {
-    const double w = (double)weight(i) * inv;
-    for (int d = 0; d < 3; d++) { acc[d] += w * src[3 * i + d]; acc[3 + d] += w * ref[3 * i + d]; }
-  }
-  double sc[3], rc[3];
-  for (int d = 0; d < 3; d++) { sc[d] = block_sum(acc[d], sh); rc[d] = block_sum(acc[3 + d], sh); }
-  double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int64_t i = b0 + threadIdx.x; i < b1; i += blockDim.x) {
-    const double w = (double)weight(i) * inv;
-    double s[3], r[3];
-    for (int d = 0; d < 3; d++) { s[d] = src[3 * i + d] - sc[d]; r[d] = w * (ref[3 * i + d] - rc[d]); }
+    const double w = (double)weight(i);
+    const double s3[3] = {src[3 * i], src[3 * i + 1], src[3 * i + 2]}, r3[3] = {ref[3 * i], ref[3 * i + 1], ref[3 * i + 2]};
+    m[0] += w;
+    for (int d = 0; d < 3; d++) { m[1 + d] += w * s3[d]; m[4 + d] += w * r3[d]; }
     for (int a = 0; a < 3; a++)
-      for (int c = 0; c < 3; c++) h[3 * a + c] += s[a] * r[c];
+      for (int c = 0; c < 3; c++) m[7 + 3 * a + c] += w * s3[a] * r3[c];
   }
-  double H[3][3];
+  __shared__ double red[4][16];
+  for (int k = 0; k < 16; k++) {
+    double v = m[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  (void)sh;
+  if (threadIdx.x != 0) return;
+  for (int k = 0; k < 16; k++) m[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+  const double inv = 1.0 / (m[0] + (double)eps);       // weights are normalised by (sum + eps) as in the reference
+  const double W1 = m[0] * inv;                        // sum of the normalised weights (slightly below 1)
+  double sc[3], rc[3], H[3][3];
+  for (int d = 0; d < 3; d++) { sc[d] = m[1 + d] * inv; rc[d] = m[4 + d] * inv; }
+  // H = sum w' (s - sc)(r - rc)^T = sum w' s r^T - sc (sum w' r)^T - (sum w' s) rc^T + W1 sc rc^T = M - (2 - W1) sc rc^T
   for (int a = 0; a < 3; a++)
-    for (int c = 0; c < 3; c++) H[a][c] = block_sum(h[3 * a + c], sh);
-  if (threadIdx.x == 0) kabsch(H, sc, rc, T_out + 16 * blockIdx.x);
+    for (int c = 0; c < 3; c++) H[a][c] = m[7 + 3 * a + c] * inv - (2.0 - W1) * sc[a] * rc[c];
+  kabsch(H, sc, rc, T_out + 16 * blockIdx.x);
 }
 
 // votes[b] = number of correspondences with |ref - T_b src| < radius ; inlier mask optional (for the chosen hypothesis)
