@@ -336,8 +336,8 @@ struct AttnArgs {
 };
 
 // grid (ceil(N/32), H, A_out); NW waves split the key tiles of one (anchor, head, 32-query tile)
-template <int D, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void attention_kernel(AttnArgs p) {
+template <int D, int NW, int MINW>
+__global__ __launch_bounds__(64 * NW, MINW) void attention_kernel(AttnArgs p) {
   __shared__ float sm[64 * NW], sl[64 * NW];
   __shared__ float so[NW * FlashState<D>::DT * 16 * 64];
   const int n0 = blockIdx.x * 32, h = blockIdx.y, a = blockIdx.z;
@@ -503,6 +503,8 @@ int dispatch_head_dim(int D, F&& f, const char* what) {
 
 }  // namespace
 
+static int g_attn_variant = 0;
+extern "C" void se3_debug_set_attention_variant(int variant) { g_attn_variant = variant; }
 static int g_bias_variant = 0;
 static int g_bias_split = 0;
 // tuning hooks (benchmarks only): kernel variant / m-split override; 0 = default
@@ -577,7 +579,13 @@ extern "C" int se3_attention_fwd(const float* q, const float* k, const float* v,
   int rc = dispatch_head_dim(C / H, [&](auto d) {
     constexpr int D = decltype(d)::value;
     (void)wide;
-    attention_kernel<D, 4><<<grid, 256, 0, st>>>(p);
+    switch (g_attn_variant) {
+      case 1: attention_kernel<D, 3, 1><<<grid, 192, 0, st>>>(p); break;
+      case 2: attention_kernel<D, 4, 1><<<grid, 256, 0, st>>>(p); break;
+      case 3: attention_kernel<D, 2, 1><<<grid, 128, 0, st>>>(p); break;
+      case 4: attention_kernel<D, 6, 1><<<grid, 384, 0, st>>>(p); break;
+      default: attention_kernel<D, 4, 2><<<grid, 256, 0, st>>>(p); break;
+    }
   }, "attention");
   if (rc != SE3_OK) return rc;
   SE3_CHECK_LAUNCH("attention");

@@ -24,6 +24,10 @@ def _hip(fn):
 # dense layers (library GEMMs) and small glue
 # ---------------------------------------------------------------------------------------------------------------------
 def linear(x, weight, bias=None, relu=False):
+    """Library GEMM x W^T + b; with relu=True the activation rides in the GEMM epilogue (one launch)."""
+    if relu and bias is not None and x.dim() >= 2:
+        x2 = x.reshape(-1, x.shape[-1])
+        return torch._addmm_activation(bias, x2, weight.t(), use_gelu=False).reshape(x.shape[:-1] + (weight.shape[0],))
     y = F.linear(x, weight, bias)
     return F.relu_(y) if relu else y
 
@@ -41,7 +45,11 @@ def project_values_transposed(x, w_v, b_v):
     M = x.shape[-2]
     Mp = _ops.key_stride(M)
     xp = F.pad(x, (0, 0, 0, Mp - M)) if Mp != M else x
-    return torch.matmul(w_v, xp.transpose(-1, -2)) + b_v[:, None]
+    C = w_v.shape[0]
+    if xp.dim() == 2:
+        return torch.addmm(b_v[:, None].expand(C, Mp), w_v, xp.t())
+    A = xp.shape[0]
+    return torch.baddbmm(b_v[None, :, None].expand(A, C, Mp), w_v[None].expand(A, C, C), xp.transpose(1, 2))
 
 
 def add_layer_norm(hidden, residual, weight, bias, eps=1e-5):
@@ -164,7 +172,8 @@ def rpe_self_attention_packed(x, starts, lengths, embs, eq_embs, w_stack, b_stac
     C = x.shape[-1]
     x3 = x if x.dim() == 3 else x.unsqueeze(0)
     proj = F.linear(x3, w_stack, b_stack)                                  # (A, R, 2C + HC [+ 4H])
-    vt = torch.matmul(w_v, x3.transpose(-1, -2)) + b_v[:, None]            # (A, C, R): transposed values of every cloud
+    A_, R_ = x3.shape[0], x3.shape[1]
+    vt = torch.baddbmm(b_v[None, :, None].expand(A_, C, R_), w_v[None].expand(A_, C, C), x3.transpose(1, 2))   # (A, C, R)
     hidden = torch.zeros_like(x3)
     for s0, n, emb, eq in zip(starts, lengths, embs, eq_embs):
         rows = proj[:, s0:s0 + n]

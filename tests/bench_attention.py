@@ -28,15 +28,15 @@ x = torch.randn(4096, 4096, device='cuda')
 t0 = time.time()
 while time.time() - t0 < 1.5: y = x @ x          # ramp the clocks
 torch.cuda.synchronize()
-configs = [(A, N, eq, v, sp) for (A, N, eq) in ((6, 382, True), (6, 304, True), (1, 382, False)) for v in (0,) for sp in (2,)]
+configs = [(A, N, eq, v, sp) for (A, N, eq) in ((6, 382, True), (6, 304, True), (1, 382, False)) for v in (0, 1, 2, 3, 4) for sp in (2,)]
 res = {}
 for rep in range(3):
     random.shuffle(configs)
     for c in configs:
         A, N, eq, v, sp = c
-        res.setdefault(c, []).append(run(A, N, 256, 4, eq, v, sp, iters=60))
+        lib().se3_debug_set_attention_variant(v)
+        res.setdefault(c, []).append(run(A, N, 256, 4, eq, 0, sp, iters=60))
 for c in sorted(res):
-    tb = min(r[0] for r in res[c]); ta = min(r[1] for r in res[c]); nb = res[c][0][2]
-    tk = min(r[3] for r in res[c])
-    print('A=%d N=%d eq=%d variant=%d split=%d  bias %.1f us  attn %.1f us  total %.1f us  -> %.0f GB/s (%.1f%% of 8TB/s)' % (*c, tb, tk, ta, nb / ta / 1e3, nb / ta / 1e3 / 80))
-lib().se3_debug_set_bias_variant(0, 0)
+    tb = min(r[0] for r in res[c]); ta = min(r[1] for r in res[c]); nb = res[c][0][2]; tk = min(r[3] for r in res[c])
+    print('A=%d N=%d eq=%d attn_variant=%d  bias %.1f us  attn %.1f us  total %.1f us  -> %.0f GB/s (%.1f%% of 8TB/s)' % (c[0], c[1], c[2], c[3], tb, tk, ta, nb / ta / 1e3, nb / ta / 1e3 / 80))
+lib().se3_debug_set_bias_variant(0, 0); lib().se3_debug_set_attention_variant(0)
