@@ -49,6 +49,17 @@ int se3_radius_neighbors(const float* q_points, int64_t nq, const float* s_point
                          const int64_t* q_lengths_host, const int64_t* s_lengths_host, int batch, float radius,
                          int limit, int64_t* neighbors, int32_t* max_count, void* stream);
 
+/* Uniform-grid variant of se3_radius_neighbors for large supports (identical results).  se3_radius_grid_build bins the
+ * support cloud (cells of edge >= radius) into a caller-owned workspace; se3_radius_neighbors_grid then searches any query
+ * set against it with the SAME radius.  One grid serves every search sharing support and radius (a stage's neighbour and
+ * sub-sampling tables and the previous stage's up-sampling table in geotransformer/utils/data.py:48-84). */
+size_t se3_radius_grid_workspace_bytes(int64_t ns, int batch);
+int se3_radius_grid_build(const float* s_points, int64_t ns, const int64_t* s_lengths_host, int batch, float radius,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int se3_radius_neighbors_grid(const float* q_points, int64_t nq, const int64_t* q_lengths_host, const int64_t* s_lengths_host,
+                              int64_t ns, int batch, const void* grid_workspace, float radius, int limit, int64_t* neighbors,
+                              int32_t* max_count, void* stream);
+
 /* ---- A1: stack-mode grid subsampling ----------------------------------------------------------------------
  * Replaces geotransformer.ext.grid_subsampling (pybind.cpp:13-17, cpu/grid_subsampling/grid_subsampling.cpp:5-83,
  * grid_subsampling_cpu.cpp:3-109, grid_subsampling_cpu.h:24-74).  Per batch element: voxel hash, per voxel the

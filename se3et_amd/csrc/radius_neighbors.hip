@@ -147,3 +147,291 @@ extern "C" int se3_radius_neighbors(const float* q_points, int64_t nq, const flo
   SE3_CHECK_LAUNCH("radius_neighbors");
   return SE3_OK;
 }
+
+// =====================================================================================================================
+// Uniform-grid variant for large supports.  The support cloud is binned once into cells of edge >= radius (counting sort on
+// the device: cell histogram -> prefix sum -> scatter of (x, y, z, index)); a query then only visits the 3 x 3 x 3 block of
+// cells around it, i.e. nine contiguous runs of the cell-sorted array.  The distance arithmetic, the strict d2 < r2 test and
+// the (d2, index) ranking are exactly those of the exhaustive kernel above, so the results are bit-identical; only the
+// candidates that cannot be within the radius are skipped.  One grid serves every search that shares support and radius
+// (stage neighbours, sub-sampling, and the previous stage's up-sampling).
+// =====================================================================================================================
+namespace {
+
+constexpr int kGridCap = 64;                       // cells per axis at most
+constexpr int kCellCap = kGridCap * kGridCap * kGridCap;
+
+struct GridMeta {
+  float org[3];
+  float inv_cell;
+  int dim[3];
+  int ncells;
+};
+
+struct GridLayout {
+  GridMeta* meta;        // [batch]
+  int* cell_start;       // [batch][kCellCap + 1]
+  int* cell_fill;        // [batch][kCellCap]
+  int* cell_of;          // [ns]
+  float4* sorted;        // [ns]  (x, y, z, bits of the stacked support index)
+};
+
+size_t grid_carve(int64_t ns, int batch, char* base, GridLayout* L) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    off = (off + 255) & ~(size_t)255;
+    char* p = base ? base + off : nullptr;
+    off += bytes;
+    return p;
+  };
+  GridLayout l;
+  l.meta = (GridMeta*)take(sizeof(GridMeta) * batch);
+  l.cell_start = (int*)take(sizeof(int) * (size_t)batch * (kCellCap + 1));
+  l.cell_fill = (int*)take(sizeof(int) * (size_t)batch * kCellCap);
+  l.cell_of = (int*)take(sizeof(int) * (size_t)(ns > 0 ? ns : 1));
+  l.sorted = (float4*)take(sizeof(float4) * (size_t)(ns > 0 ? ns : 1));
+  if (L) *L = l;
+  return (off + 255) & ~(size_t)255;
+}
+
+__device__ __forceinline__ int cell_coord(float v, float org, float inv_cell, int dim) {
+  int c = (int)floorf((v - org) * inv_cell);
+  return c < 0 ? 0 : (c >= dim ? dim - 1 : c);
+}
+
+__global__ __launch_bounds__(1024) void grid_bounds_kernel(const float* __restrict__ s, BatchTable bt, float radius,
+                                                           GridLayout G) {
+  __shared__ float sh[16];
+  const int b = blockIdx.x;
+  const int64_t n = bt.s_count[b];
+  const float* p = s + 3 * bt.s_start[b];
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int64_t i = threadIdx.x; i < n; i += 1024)
+    for (int d = 0; d < 3; d++) {
+      const float v = p[3 * i + d];
+      mn[d] = fminf(mn[d], v);
+      mx[d] = fmaxf(mx[d], v);
+    }
+  float r[6];
+  for (int d = 0; d < 6; d++) {
+    float v = d < 3 ? mn[d] : -mx[d - 3];
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = sh[0];
+    for (int w = 1; w < 16; w++) t = fminf(t, sh[w]);
+    r[d] = t;
+  }
+  if (threadIdx.x == 0) {
+    GridMeta m;
+    float ext = 0.f;
+    for (int d = 0; d < 3; d++) ext = fmaxf(ext, (-r[3 + d]) - r[d]);
+    float cell = fmaxf(radius, ext / (float)(kGridCap - 1));
+    cell = fmaxf(cell, 1e-20f) * 1.0001f;          // strictly larger than the radius: the 3x3x3 block always covers the ball
+    m.inv_cell = 1.0f / cell;
+    m.ncells = 1;
+    for (int d = 0; d < 3; d++) {
+      m.org[d] = n > 0 ? r[d] : 0.f;
+      int dim = n > 0 ? (int)floorf(((-r[3 + d]) - r[d]) * m.inv_cell) + 1 : 1;
+      m.dim[d] = dim < 1 ? 1 : (dim > kGridCap ? kGridCap : dim);
+      m.ncells *= m.dim[d];
+    }
+    G.meta[b] = m;
+  }
+}
+
+__global__ void grid_count_kernel(const float* __restrict__ s, BatchTable bt, GridLayout G) {
+  const int b = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= bt.s_count[b]) return;
+  const GridMeta m = G.meta[b];
+  const float* p = s + 3 * (bt.s_start[b] + i);
+  const int cx = cell_coord(p[0], m.org[0], m.inv_cell, m.dim[0]);
+  const int cy = cell_coord(p[1], m.org[1], m.inv_cell, m.dim[1]);
+  const int cz = cell_coord(p[2], m.org[2], m.inv_cell, m.dim[2]);
+  const int cell = cx + m.dim[0] * (cy + m.dim[1] * cz);
+  G.cell_of[bt.s_start[b] + i] = cell;
+  atomicAdd(&G.cell_start[(size_t)b * (kCellCap + 1) + cell], 1);
+}
+
+__global__ __launch_bounds__(1024) void grid_scan_kernel(GridLayout G) {
+  __shared__ int sh[1024];
+  const int b = blockIdx.x;
+  const int n = G.meta[b].ncells;
+  int* a = G.cell_start + (size_t)b * (kCellCap + 1);
+  const int t = threadIdx.x;
+  const int chunk = (n + 1023) / 1024;
+  const int lo = t * chunk, hi = min(n, lo + chunk);
+  int sum = 0;
+  for (int i = lo; i < hi; i++) sum += a[i];
+  sh[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = (t >= off) ? sh[t - off] : 0;
+    __syncthreads();
+    sh[t] += v;
+    __syncthreads();
+  }
+  int run = sh[t] - sum;
+  for (int i = lo; i < hi; i++) {
+    const int v = a[i];
+    a[i] = run;
+    run += v;
+  }
+  if (t == 1023) a[n] = sh[1023];
+}
+
+__global__ void grid_scatter_kernel(const float* __restrict__ s, BatchTable bt, GridLayout G) {
+  const int b = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= bt.s_count[b]) return;
+  const int64_t g = bt.s_start[b] + i;
+  const int cell = G.cell_of[g];
+  const int pos = G.cell_start[(size_t)b * (kCellCap + 1) + cell] + atomicAdd(&G.cell_fill[(size_t)b * kCellCap + cell], 1);
+  G.sorted[bt.s_start[b] + pos] = make_float4(s[3 * g], s[3 * g + 1], s[3 * g + 2], __int_as_float((int)g));
+}
+
+// one wavefront per query; the nine (y, z) rows of the 3x3x3 cell block are contiguous runs of `sorted`
+__global__ __launch_bounds__(256) void radius_grid_search_kernel(const float* __restrict__ q, BatchTable bt, GridLayout G,
+                                                                 int64_t ns_total, float r2, int limit,
+                                                                 int64_t* __restrict__ out, int32_t* __restrict__ max_count) {
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= bt.q_count[b]) return;
+  const GridMeta m = G.meta[b];
+  const int64_t gq = bt.q_start[b] + qi;
+  const float qx = q[3 * gq], qy = q[3 * gq + 1], qz = q[3 * gq + 2];
+  // cell coordinates of the query, NOT clamped: a query outside the support box still has to see the boundary cells
+  const int cx = (int)floorf((qx - m.org[0]) * m.inv_cell), cy = (int)floorf((qy - m.org[1]) * m.inv_cell),
+            cz = (int)floorf((qz - m.org[2]) * m.inv_cell);
+  const int x0 = max(cx - 1, 0), x1 = min(cx + 1, m.dim[0] - 1);
+  const int* cs = G.cell_start + (size_t)b * (kCellCap + 1);
+  const float4* pts = G.sorted + bt.s_start[b];
+  unsigned long long best = ~0ull;
+  int count = 0;
+  // lanes 0..8 fetch the [begin, end) run of one (y, z) row each (all 18 loads in flight at once); the nine runs are then
+  // walked as ONE flat candidate list, 64 candidates per step
+  int beg = 0, len = 0;
+  if (lane < 9 && x0 <= x1) {
+    const int z = cz + lane / 3 - 1, y = cy + lane % 3 - 1;
+    if (z >= 0 && z < m.dim[2] && y >= 0 && y < m.dim[1]) {
+      const int rowc = m.dim[0] * (y + m.dim[1] * z);
+      beg = cs[rowc + x0];
+      len = cs[rowc + x1 + 1] - beg;
+    }
+  }
+  int rb[9], ro[9], total = 0;
+#pragma unroll
+  for (int r = 0; r < 9; r++) {
+    rb[r] = __builtin_amdgcn_readlane(beg, r);
+    ro[r] = total;                                       // exclusive offset of run r in the flat list
+    total += __builtin_amdgcn_readlane(len, r);
+  }
+  for (int base = 0; base < total; base += 64) {
+    const int t = base + lane;
+    const bool valid = t < total;
+    int p = 0;
+#pragma unroll
+    for (int r = 0; r < 9; r++) p = (t >= ro[r]) ? rb[r] + (t - ro[r]) : p;
+    const float4 c = valid ? pts[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float dx = __fsub_rn(qx, c.x), dyv = __fsub_rn(qy, c.y), dzv = __fsub_rn(qz, c.z);
+    const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dyv, dyv)), __fmul_rn(dzv, dzv));
+    unsigned long long mk = __ballot(valid && (d2 < r2));
+    if (mk == 0ull) continue;
+    count += __popcll(mk);
+    const unsigned long long mykey = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(c.w);
+    while (mk) {
+      const int src = __ffsll((long long)mk) - 1;
+      mk &= mk - 1;
+      const unsigned lo = __shfl((int)(unsigned)(mykey & 0xffffffffull), src);
+      const unsigned hi = __shfl((int)(unsigned)(mykey >> 32), src);
+      const unsigned long long cand = ((unsigned long long)hi << 32) | lo;
+      const int pos = __popcll(__ballot(best < cand));
+      const unsigned long long up = shfl_up_u64(best, lane);
+      if (lane == pos) best = cand;
+      else if (lane > pos) best = up;
+    }
+  }
+  if (lane < limit) out[gq * limit + lane] = (best != ~0ull) ? (int64_t)(unsigned)(best & 0xffffffffull) : ns_total;
+  if (lane == 0) atomicMax(max_count, count);
+}
+
+int fill_batch_table(BatchTable* bt, const int64_t* q_len, const int64_t* s_len, int batch, int64_t nq, int64_t ns,
+                     int64_t* qmax, int64_t* smax) {
+  int64_t qs = 0, ss = 0;
+  *qmax = 0;
+  *smax = 0;
+  for (int b = 0; b < batch; b++) {
+    const int64_t ql = q_len ? q_len[b] : 0, sl = s_len[b];
+    if (ql < 0 || sl < 0) return 1;
+    bt->q_start[b] = qs; bt->q_count[b] = ql;
+    bt->s_start[b] = ss; bt->s_count[b] = sl;
+    qs += ql; ss += sl;
+    if (ql > *qmax) *qmax = ql;
+    if (sl > *smax) *smax = sl;
+  }
+  return (q_len && qs != nq) || ss != ns;
+}
+
+}  // namespace
+
+extern "C" size_t se3_radius_grid_workspace_bytes(int64_t ns, int batch) {
+  if (ns < 0 || batch < 1 || batch > SE3_MAX_BATCH) return 0;
+  return grid_carve(ns, batch, nullptr, nullptr);
+}
+
+extern "C" int se3_radius_grid_build(const float* s_points, int64_t ns, const int64_t* s_lengths_host, int batch, float radius,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  SE3_REQUIRE(s_points && s_lengths_host && workspace, SE3_ERR_INVALID_ARG, "radius_grid_build: null pointer");
+  SE3_REQUIRE(batch >= 1 && batch <= SE3_MAX_BATCH && radius > 0.f, SE3_ERR_INVALID_ARG, "radius_grid_build: bad batch/radius");
+  SE3_REQUIRE(ns < (1ll << 31), SE3_ERR_UNSUPPORTED, "radius_grid_build: support too large");
+  BatchTable bt;
+  int64_t qmax, smax;
+  SE3_REQUIRE(fill_batch_table(&bt, nullptr, s_lengths_host, batch, 0, ns, &qmax, &smax) == 0, SE3_ERR_INVALID_ARG,
+              "radius_grid_build: lengths do not sum to ns");
+  GridLayout G;
+  SE3_REQUIRE(grid_carve(ns, batch, (char*)workspace, &G) <= workspace_bytes, SE3_ERR_WORKSPACE,
+              "radius_grid_build: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(G.cell_start, 0, sizeof(int) * (size_t)batch * (kCellCap + 1), st);
+  if (e == hipSuccess) e = hipMemsetAsync(G.cell_fill, 0, sizeof(int) * (size_t)batch * kCellCap, st);
+  if (e != hipSuccess) { se3_set_error("radius_grid_build: memset failed"); return SE3_ERR_LAUNCH; }
+  grid_bounds_kernel<<<batch, 1024, 0, st>>>(s_points, bt, radius, G);
+  if (smax > 0) {
+    dim3 gp((unsigned)se3_cdiv(smax, 256), (unsigned)batch);
+    grid_count_kernel<<<gp, 256, 0, st>>>(s_points, bt, G);
+    grid_scan_kernel<<<batch, 1024, 0, st>>>(G);
+    grid_scatter_kernel<<<gp, 256, 0, st>>>(s_points, bt, G);
+  } else {
+    grid_scan_kernel<<<batch, 1024, 0, st>>>(G);
+  }
+  SE3_CHECK_LAUNCH("radius_grid_build");
+  return SE3_OK;
+}
+
+extern "C" int se3_radius_neighbors_grid(const float* q_points, int64_t nq, const int64_t* q_lengths_host,
+                                         const int64_t* s_lengths_host, int64_t ns, int batch, const void* grid_workspace,
+                                         float radius, int limit, int64_t* neighbors, int32_t* max_count, void* stream) {
+  SE3_REQUIRE(q_points && q_lengths_host && s_lengths_host && grid_workspace && neighbors && max_count, SE3_ERR_INVALID_ARG,
+              "radius_neighbors_grid: null pointer");
+  SE3_REQUIRE(batch >= 1 && batch <= SE3_MAX_BATCH, SE3_ERR_INVALID_ARG, "radius_neighbors_grid: batch");
+  SE3_REQUIRE(limit >= 1 && limit <= SE3_MAX_NEIGHBOR_LIMIT, SE3_ERR_UNSUPPORTED, "radius_neighbors_grid: limit %d", limit);
+  BatchTable bt;
+  int64_t qmax, smax;
+  SE3_REQUIRE(fill_batch_table(&bt, q_lengths_host, s_lengths_host, batch, nq, ns, &qmax, &smax) == 0, SE3_ERR_INVALID_ARG,
+              "radius_neighbors_grid: lengths do not sum to the sizes");
+  GridLayout G;
+  grid_carve(ns, batch, (char*)grid_workspace, &G);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(max_count, 0, sizeof(int32_t), st) != hipSuccess) {
+    se3_set_error("radius_neighbors_grid: memset failed");
+    return SE3_ERR_LAUNCH;
+  }
+  if (nq == 0) return SE3_OK;
+  dim3 grid((unsigned)se3_cdiv(qmax, 4), (unsigned)batch);
+  radius_grid_search_kernel<<<grid, 256, 0, st>>>(q_points, bt, G, ns, radius * radius, limit, neighbors, max_count);
+  SE3_CHECK_LAUNCH("radius_neighbors_grid");
+  return SE3_OK;
+}

@@ -33,7 +33,7 @@ constexpr int kGNLanes = 64;   // channels per block
 constexpr int kGNRows = 4;     // row lanes per block
 
 __global__ __launch_bounds__(kGNLanes* kGNRows) void gn_partial_kernel(const float* __restrict__ x, int64_t rows, int C,
-                                                                       int cpg, int nchunks, float* __restrict__ part) {
+                                                                       int nchunks, float* __restrict__ part) {
   __shared__ WF sh[kGNRows][kGNLanes];
   const int cl = threadIdx.x & (kGNLanes - 1), rl = threadIdx.x / kGNLanes;
   const int c = blockIdx.y * kGNLanes + cl;
@@ -50,37 +50,42 @@ __global__ __launch_bounds__(kGNLanes* kGNRows) void gn_partial_kernel(const flo
     }
   sh[rl][cl] = w;
   __syncthreads();
-  if (rl == 0) {
+  if (rl == 0 && c < C) {
     for (int k = 1; k < kGNRows; k++) w = wf_merge(w, sh[k][cl]);
-    sh[0][cl] = w;                      // per-channel statistics of this row chunk
-  }
-  __syncthreads();
-  // merge the channels of each group (a block's 64 channels hold whole groups: cpg divides 64, or C <= 64)
-  if (rl == 0 && c < C && (c % cpg) == 0) {
-    for (int k = 1; k < cpg; k++) w = wf_merge(w, sh[0][cl + k]);
-    float* p = part + ((int64_t)blockIdx.x * (C / cpg) + c / cpg) * 3;
+    float* p = part + ((int64_t)blockIdx.x * C + c) * 3;
     p[0] = w.n; p[1] = w.mean; p[2] = w.m2;
   }
 }
 
-// every block first merges the (few) per-chunk partials of all groups into (mean, rstd) in LDS, then streams its elements
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, int C, int groups, int nchunks,
+                                                          float eps, float* __restrict__ stats) {
+  __shared__ WF sh[256];
+  const int g = blockIdx.x, cpg = C / groups;
+  const int total = nchunks * cpg;
+  WF w = {0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int chunk = i / cpg, c = g * cpg + (i - chunk * cpg);
+    const float* p = part + ((int64_t)chunk * C + c) * 3;
+    WF o = {p[0], p[1], p[2]};
+    w = wf_merge(w, o);
+  }
+  sh[threadIdx.x] = w;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sh[threadIdx.x] = wf_merge(sh[threadIdx.x], sh[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const WF r = sh[0];
+    stats[2 * g] = r.mean;
+    stats[2 * g + 1] = 1.0f / sqrtf(r.m2 / r.n + eps);
+  }
+}
+
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                        const float* __restrict__ w, const float* __restrict__ b,
-                                                       const float* __restrict__ part, int nchunks, float eps, int64_t rows,
-                                                       int C, int groups, int has_slope, float slope,
-                                                       float* __restrict__ y) {
-  __shared__ float stats[2 * 256];
-  for (int g = threadIdx.x; g < groups; g += blockDim.x) {
-    WF acc = {0.f, 0.f, 0.f};
-    for (int k = 0; k < nchunks; k++) {
-      const float* p = part + ((int64_t)k * groups + g) * 3;
-      WF o = {p[0], p[1], p[2]};
-      acc = wf_merge(acc, o);
-    }
-    stats[2 * g] = acc.mean;
-    stats[2 * g + 1] = 1.0f / sqrtf(acc.m2 / acc.n + eps);
-  }
-  __syncthreads();
+                                                       const float* __restrict__ stats, int64_t rows, int C, int groups,
+                                                       int has_slope, float slope, float* __restrict__ y) {
   const int cpg = C / groups;
   const int64_t total = rows * C;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -212,34 +217,31 @@ inline unsigned grid_for(int64_t work, int tpb) {
 
 }  // namespace
 
-static int64_t gn_chunks(int64_t rows) {
-  int64_t n = rows / 128 + 1;
-  return n > 64 ? 64 : n;
-}
-
 extern "C" size_t se3_group_norm_workspace_bytes(int64_t rows, int channels, int groups) {
-  return (size_t)(gn_chunks(rows) * groups * 3) * sizeof(float) + 256;
+  int64_t nchunks = rows / 64 + 1;
+  if (nchunks > 256) nchunks = 256;
+  return (size_t)(nchunks * channels * 3 + 2 * groups) * sizeof(float) + 256;
 }
 
 extern "C" int se3_group_norm_fwd(const float* x, const float* residual, const float* weight, const float* bias,
                                   int64_t rows, int channels, int groups, float eps, int apply_leaky_relu, float slope,
                                   float* out, void* workspace, size_t workspace_bytes, void* stream) {
   SE3_REQUIRE(x && weight && bias && out && workspace, SE3_ERR_INVALID_ARG, "group_norm: null pointer");
-  SE3_REQUIRE(rows >= 1 && channels >= 1 && groups >= 1 && groups <= 256 && channels % groups == 0, SE3_ERR_INVALID_ARG,
+  SE3_REQUIRE(rows >= 1 && channels >= 1 && groups >= 1 && channels % groups == 0, SE3_ERR_INVALID_ARG,
               "group_norm: rows %lld channels %d groups %d", (long long)rows, channels, groups);
-  const int cpg = channels / groups;
-  SE3_REQUIRE(cpg <= kGNLanes && (kGNLanes % cpg == 0 || channels <= kGNLanes), SE3_ERR_UNSUPPORTED,
-              "group_norm: %d channels per group (must divide %d)", cpg, kGNLanes);
   SE3_REQUIRE(workspace_bytes >= se3_group_norm_workspace_bytes(rows, channels, groups), SE3_ERR_WORKSPACE,
               "group_norm: workspace too small");
-  const int64_t nchunks = gn_chunks(rows);
+  int64_t nchunks = rows / 64 + 1;
+  if (nchunks > 256) nchunks = 256;
   float* part = (float*)workspace;
+  float* stats = part + nchunks * channels * 3;
   hipStream_t st = (hipStream_t)stream;
   dim3 g1((unsigned)nchunks, (unsigned)se3_cdiv(channels, kGNLanes));
-  gn_partial_kernel<<<g1, kGNLanes * kGNRows, 0, st>>>(x, rows, channels, cpg, (int)nchunks, part);
+  gn_partial_kernel<<<g1, kGNLanes * kGNRows, 0, st>>>(x, rows, channels, (int)nchunks, part);
+  gn_finalize_kernel<<<groups, 256, 0, st>>>(part, channels, groups, (int)nchunks, eps, stats);
   const int64_t work = (channels % 4 == 0) ? rows * channels / 4 : rows * channels;
-  gn_apply_kernel<<<grid_for(work, 256 * 4), 256, 0, st>>>(x, residual, weight, bias, part, (int)nchunks, eps, rows, channels,
-                                                          groups, apply_leaky_relu, slope, out);
+  gn_apply_kernel<<<grid_for(work, 256), 256, 0, st>>>(x, residual, weight, bias, stats, rows, channels, groups,
+                                                      apply_leaky_relu, slope, out);
   SE3_CHECK_LAUNCH("group_norm");
   return SE3_OK;
 }

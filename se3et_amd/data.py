@@ -36,13 +36,25 @@ def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, 
 
     # all 3S-2 searches are launched back to back; their column counts are fetched with ONE synchronisation
     jobs = []
+    grids = {}
+
+    def grid_for(stage, r):       # one cell grid per (support stage, radius): shared by up to three searches
+        key = (stage, float(r))
+        if key not in grids:
+            s_pts = points_list[stage]
+            grids[key] = (_ops.RadiusGrid(s_pts, lengths_list[stage], r)
+                          if s_pts.shape[0] >= _ops.GRID_SEARCH_MIN_SUPPORT else None)
+        return grids[key]
+
     for i in range(num_stages):
         cur, cl = points_list[i], lengths_list[i]
-        jobs.append(('neighbors', _ops.radius_neighbors(cur, cur, cl, cl, radius, neighbor_limits[i])))
+        jobs.append(('neighbors', _ops.radius_neighbors(cur, cur, cl, cl, radius, neighbor_limits[i], grid=grid_for(i, radius))))
         if i < num_stages - 1:
             sub, sl = points_list[i + 1], lengths_list[i + 1]
-            jobs.append(('subsampling', _ops.radius_neighbors(sub, cur, sl, cl, radius, neighbor_limits[i])))
-            jobs.append(('upsampling', _ops.radius_neighbors(cur, sub, cl, sl, radius * 2, neighbor_limits[i + 1])))
+            jobs.append(('subsampling', _ops.radius_neighbors(sub, cur, sl, cl, radius, neighbor_limits[i],
+                                                              grid=grid_for(i, radius))))
+            jobs.append(('upsampling', _ops.radius_neighbors(cur, sub, cl, sl, radius * 2, neighbor_limits[i + 1],
+                                                             grid=grid_for(i + 1, radius * 2))))
         radius *= 2
     counts = torch.stack([mc for _, (_, mc) in jobs]).cpu().tolist()
     out = {'points': points_list, 'lengths': lengths_list, 'neighbors': [], 'subsampling': [], 'upsampling': []}

@@ -60,10 +60,47 @@ def _host_lengths(lengths, name):
     return arr, len(lengths)
 
 
-def radius_neighbors(q_points, s_points, q_lengths, s_lengths, radius, limit):
-    """Returns (neighbors (Nq, limit) int64 padded with Ns, max_count 0-d int32 device tensor)."""
+GRID_SEARCH_MIN_SUPPORT = 1500        # below this the exhaustive kernel is faster than building a grid
+
+
+class RadiusGrid:
+    """Cell-binned support cloud for repeated radius searches with one radius (csrc/radius_neighbors.hip)."""
+
+    def __init__(self, s_points, s_lengths, radius):
+        self.s_points = _req(s_points, torch.float32, 's_points', 2)
+        self.lengths, self.batch = _host_lengths(s_lengths, 's_lengths')
+        self.radius = float(radius)
+        self.ns = s_points.shape[0]
+        nbytes = lib().se3_radius_grid_workspace_bytes(self.ns, self.batch)
+        self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=s_points.device)
+        check(lib().se3_radius_grid_build(self.s_points.data_ptr(), self.ns, self.lengths, self.batch, self.radius,
+                                          self.ws.data_ptr(), nbytes, _stream()), 'se3_radius_grid_build')
+
+    def search(self, q_points, q_lengths, limit):
+        _req(q_points, torch.float32, 'q_points', 2)
+        ql, nb = _host_lengths(q_lengths, 'q_lengths')
+        if nb != self.batch:
+            raise RuntimeError('q_lengths and s_lengths differ in batch size')
+        nq = q_points.shape[0]
+        out = torch.empty((nq, limit), dtype=torch.int64, device=q_points.device)
+        max_count = torch.empty((), dtype=torch.int32, device=q_points.device)
+        check(lib().se3_radius_neighbors_grid(q_points.data_ptr(), nq, ql, self.lengths, self.ns, self.batch, self.ws.data_ptr(),
+                                              self.radius, int(limit), out.data_ptr(), max_count.data_ptr(), _stream()),
+              'se3_radius_neighbors_grid')
+        return out, max_count
+
+
+def radius_neighbors(q_points, s_points, q_lengths, s_lengths, radius, limit, grid=None):
+    """Returns (neighbors (Nq, limit) int64 padded with Ns, max_count 0-d int32 device tensor).  Large supports go through
+    a uniform grid (pass a prebuilt RadiusGrid to share it between searches); results are identical either way."""
     _req(q_points, torch.float32, 'q_points', 2)
     _req(s_points, torch.float32, 's_points', 2)
+    if grid is None and s_points.shape[0] >= GRID_SEARCH_MIN_SUPPORT:
+        grid = RadiusGrid(s_points, s_lengths, radius)
+    if grid is not None:
+        if grid.s_points.data_ptr() != s_points.data_ptr() or grid.radius != float(radius):
+            raise RuntimeError('radius_neighbors: the grid was built for another support cloud / radius')
+        return grid.search(q_points, q_lengths, limit)
     ql, nb = _host_lengths(q_lengths, 'q_lengths')
     sl, nb2 = _host_lengths(s_lengths, 's_lengths')
     if nb != nb2:
@@ -181,6 +218,9 @@ def neighbor_max_pool(x, idx):
     return out
 
 
+_gn_workspace = {}       # per device; calls are ordered on the (single) launch stream
+
+
 def group_norm_rows(x, weight, bias, groups, eps, leaky_slope, residual):
     """HIP (csrc/rowops.hip): GroupNorm with statistics over all leading dims, fused residual add + LeakyReLU."""
     x = _req(x.contiguous(), torch.float32, 'x')
@@ -191,11 +231,14 @@ def group_norm_rows(x, weight, bias, groups, eps, leaky_slope, residual):
         if residual.shape != x.shape:
             raise RuntimeError('group_norm_rows: residual shape mismatch')
     ws_bytes = lib().se3_group_norm_workspace_bytes(rows, C, groups)
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+    ws = _gn_workspace.get(x.device)
+    if ws is None or ws.numel() < ws_bytes:        # zero-initialised once; the kernel keeps its arrival counter at zero
+        ws = torch.zeros((max(ws_bytes, 1 << 20),), dtype=torch.uint8, device=x.device)
+        _gn_workspace[x.device] = ws
     out = torch.empty_like(x)
     check(lib().se3_group_norm_fwd(x.data_ptr(), residual.data_ptr() if residual is not None else None, weight.data_ptr(),
                                    bias.data_ptr(), rows, C, int(groups), float(eps), 1 if leaky_slope is not None else 0,
-                                   float(leaky_slope or 0.0), out.data_ptr(), ws.data_ptr(), ws_bytes, _stream()),
+                                   float(leaky_slope or 0.0), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
           'se3_group_norm_fwd')
     return out
 

@@ -47,6 +47,25 @@ def test_radius_search_matches_oracle(n1, n2, scale, radius, limit):
     assert_neighbors_equal(got[:, :width].cpu(), want, q, pts, 'radius_search')
 
 
+@pytest.mark.parametrize('ns,nq,radius', [(6000, 3000, 0.08), (20000, 7000, 0.05), (1600, 50, 0.3)])
+def test_grid_and_exhaustive_search_agree(ns, nq, radius):
+    """The uniform-grid kernel against the exhaustive kernel, with queries partly OUTSIDE the support bounding box."""
+    from se3et_amd import ops
+    g = np.random.default_rng(7)
+    s = torch.from_numpy(g.uniform(0, 1, (ns, 3)).astype(np.float32)).cuda()
+    q = torch.from_numpy(g.uniform(-0.2, 1.2, (nq, 3)).astype(np.float32)).cuda()
+    sl, ql = torch.tensor([ns // 2, ns - ns // 2]), torch.tensor([nq // 3, nq - nq // 3])
+    grid = ops.RadiusGrid(s, sl, radius)
+    a, ca = grid.search(q, ql, 40)
+    old, ops.GRID_SEARCH_MIN_SUPPORT = ops.GRID_SEARCH_MIN_SUPPORT, 10 ** 12
+    try:
+        b, cb = ops.radius_neighbors(q, s, ql, sl, radius, 40)
+    finally:
+        ops.GRID_SEARCH_MIN_SUPPORT = old
+    assert int(ca) == int(cb)
+    assert torch.equal(a, b)
+
+
 def test_precompute_matches_reference_fixture(golden_dir):
     """Whole stage pyramid of the C1 pair against arrays captured from the genuine reference collate."""
     from se3et_amd.modules.ops import grid_subsample, radius_search
