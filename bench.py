@@ -21,6 +21,12 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# HBM traffic of one RPE self-attention call relative to its algorithmic bytes, from the rocprofv3 PMC passes committed as
+# profiles/r01_pmc_attention.csv (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of tests/pmc_attention.py at N=M=382,
+# gfx950 correction: FETCH_SIZE x2 for the 16-B/lane streaming reads of rpe_bias_kernel; attention_kernel counters raw):
+#   eq  call: (2*94707.4 + 27506.2 + 23539.2 + 4308.0) KiB = 250.6 MB  vs 172.8 MB algorithmic
+#   inv call: (2*75382.9 +  4622.0 +  2451.9 +  718.0) KiB = 162.4 MB  vs 151.0 MB algorithmic
+PMC_TRAFFIC_RATIO = {'eq': 250.6 / 172.8, 'inv': 162.4 / 151.0}
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s is achievable
 
 
@@ -89,11 +95,14 @@ def main():
     n_bias, ms_bias, bytes_call = agg('rpe_bias_kernel')
     n_attn, ms_attn, _ = agg('attention_kernel@rpe')
     ms_call = ms_bias + ms_attn
+    traffic = sum(PMC_TRAFFIC_RATIO[k] * agg('rpe_bias_kernel/' + k)[2] for k in PMC_TRAFFIC_RATIO) / max(n_bias, 1)
     achieved = bytes_call / (ms_call * 1e-3) / 1e9 if ms_call > 0 else 0.0
     roofline = {
         'kernel': 'RPE self-attention call = rpe_bias_kernel + attention_kernel',
         'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-        'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+        'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': int(traffic),
+        'traffic_source': 'bytes per call; PMC FETCH_SIZE(x2 on the streaming kernel)+WRITE_SIZE per algorithmic byte from '
+                          'profiles/r01_pmc_attention.csv, applied to the calls of this run',
         'launches': n_bias, 'avg_us': round(ms_call * 1e3 / max(n_bias, 1), 2),
         'algorithmic_bytes_per_launch': int(bytes_call / max(n_bias, 1)),
         'rpe_bias_kernel_avg_us': round(ms_bias * 1e3 / max(n_bias, 1), 2),

@@ -15,8 +15,8 @@ KERNEL_TIMINGS = None          # dict name -> list of (start_event, end_event, a
 
 
 class _timed:
-    def __init__(self, name, nbytes):
-        self.name, self.nbytes = name, nbytes
+    def __init__(self, name, nbytes, kind=None):
+        self.name, self.nbytes, self.kind = name, nbytes, kind
 
     def __enter__(self):
         if KERNEL_TIMINGS is not None:
@@ -27,6 +27,8 @@ class _timed:
         if KERNEL_TIMINGS is not None:
             self.e1.record(torch.cuda.current_stream())
             KERNEL_TIMINGS.setdefault(self.name, []).append((self.e0, self.e1, self.nbytes))
+            if self.kind is not None:
+                KERNEL_TIMINGS.setdefault(self.name + '/' + self.kind, []).append((self.e0, self.e1, self.nbytes))
             if TIMING_TAG is not None:
                 KERNEL_TIMINGS.setdefault(self.name + '@' + TIMING_TAG, []).append((self.e0, self.e1, self.nbytes))
         return False
@@ -353,7 +355,7 @@ def rpe_bias(qp, qe, emb, eq_emb, num_heads):
     # algorithmic bytes of one self-attention call: q, k, v in + out, the embedding, the eq-embedding;
     # booked on this (embedding-streaming) launch, the attention launch of the same call is booked with 0 bytes
     survey_bytes = 4 * (4 * A * N * C + N * M * C + (A * N * M * 4 if qe is not None else 0))
-    with _timed('rpe_bias_kernel', survey_bytes):
+    with _timed('rpe_bias_kernel', survey_bytes, 'eq' if qe is not None else 'inv'):
         check(lib().se3_rpe_bias_fwd(qp3.data_ptr(), qe_ptr, rs, sa, emb.data_ptr(), eq_ptr, N, M, C, A * H, H, Mp,
                                      bias.data_ptr(), _stream()), 'se3_rpe_bias_fwd')
     return bias
