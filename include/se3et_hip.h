@@ -138,6 +138,23 @@ int se3_attention_fwd(const float* q, const float* k, const float* vt, const flo
                       int64_t k_anchor_stride, int64_t v_anchor_stride, int64_t out_anchor_stride, int bias_row_stride,
                       float scale, float* out, void* stream);
 
+/* Stack mode of the two calls above (the reference runs the same RPETransformerLayer on the ref and the src cloud one after
+ * the other, rpe_conditional_transformer.py:49-53; here the clouds of a pair share ONE launch per kernel).  The clouds' rows
+ * are packed in one (anchors, rows, row_stride) projection: cloud c owns the query rows q_starts[c] .. + q_lengths[c] and the
+ * key rows k_starts[c] .. + k_lengths[c] (self attention: the same rows; k_starts multiples of 32 because the transposed
+ * values vt (anchors, C, v_row_stride) are addressed by key column).  emb_ptrs[c] -> (N_c, M_c, C), eq_ptrs[c] -> (A, N_c, M_c, 4)
+ * or NULL (all clouds alike).  The logits of cloud c are the block bias + bias_offsets[c] of shape (A*H, N_c, ceil32(M_c)).
+ * All arrays are HOST arrays of num_clouds (<= 4) entries.  out is (anchors, rows, C) in the packed row order. */
+int se3_rpe_bias_stack_fwd(const float* qp, const float* qe, int row_stride, int64_t anchor_stride,
+                           const float* const* emb_ptrs, const float* const* eq_ptrs, const int64_t* q_starts,
+                           const int64_t* q_lengths, const int64_t* k_lengths, const int64_t* bias_offsets, int num_clouds,
+                           int C, int AH, int H, float* bias, void* stream);
+int se3_attention_stack_fwd(const float* q, const float* k, const float* vt, const float* bias, const int64_t* q_starts,
+                            const int64_t* q_lengths, const int64_t* k_starts, const int64_t* k_lengths,
+                            const int64_t* bias_offsets, int num_clouds, int num_anchors, int C, int H, int q_row_stride,
+                            int k_row_stride, int v_row_stride, int64_t q_anchor_stride, int64_t k_anchor_stride,
+                            int64_t v_anchor_stride, int64_t out_anchor_stride, float scale, float* out, void* stream);
+
 /* ---- D4/D5: anchor-equivariant cross attention (MultiHeadAttentionEQ, 'a_soft' / 'r_soft') ----------------------------
  * Replaces geotransformer/modules/transformer/vanilla_transformer.py:247-476,506-577,751-870.  q (A, N, C), k/v (A, M, C).
  * se3_cross_eq_stats writes partial[(a*A+e) * P + i] whose sum over i is sum_{n,m} (mean_h q_a.k_e * scale)^2

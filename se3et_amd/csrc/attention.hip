@@ -27,119 +27,207 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float f4get(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// stack mode: the clouds of a pair (ref, src) share one launch
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kMaxClouds = 4;
+struct StackCloud {
+  const float* emb;     // (N, M, C) geometric embedding (bias kernel only)
+  const float* eq;      // (A, N, M, 4) equivariant embedding or null
+  int q_start, k_start; // first packed row of the cloud's queries / keys
+  int N, M, Mp;         // queries, keys, logits row stride (multiple of 32 >= M)
+  int unit_begin;       // bias kernel: flat index of the cloud's first (row, 32-key unit)
+  long long bias_off;   // float offset of the cloud's (A*H, N, Mp) logits block
+};
+struct Stack {
+  StackCloud c[kMaxClouds];
+  int n;
+  int total_units;
+};
+
+__device__ __forceinline__ StackCloud stack_pick(const Stack& S, int idx) {
+  StackCloud r = S.c[0];
+#pragma unroll
+  for (int i = 1; i < kMaxClouds; i++) {      // field-wise scalar selects (an indexed copy would go through scratch)
+    const bool hit = idx == i;
+    r.emb = hit ? S.c[i].emb : r.emb;
+    r.eq = hit ? S.c[i].eq : r.eq;
+    r.q_start = hit ? S.c[i].q_start : r.q_start;
+    r.k_start = hit ? S.c[i].k_start : r.k_start;
+    r.N = hit ? S.c[i].N : r.N;
+    r.M = hit ? S.c[i].M : r.M;
+    r.Mp = hit ? S.c[i].Mp : r.Mp;
+    r.unit_begin = hit ? S.c[i].unit_begin : r.unit_begin;
+    r.bias_off = hit ? S.c[i].bias_off : r.bias_off;
+  }
+  return r;
+}
+
 // =====================================================================================================================
 // rpe_bias_kernel
 // =====================================================================================================================
-template <int CT, int RT, bool PREFETCH, int MINW>   // CT = C / 16 ; RT = row tiles of 16 folded queries (AH <= 16 RT)
+constexpr int kStageStride = 36;     // floats per staged logits row (32 keys + 4: the 4 lane groups of a store hit disjoint banks)
+
+// One 16-key tile of the relative-position logits: 4 RT MFMAs per 16-channel chunk against the LDS-resident folded queries;
+// the tile's (16 RT rows, 16 keys) result (+ the equivariant term) goes to the wave's LDS staging block, columns col0 .. +15.
+// NEXT: as soon as the MFMAs of chunk t are issued, b[t] is re-loaded with the same chunk of the wave's next tile (rotating
+// prefetch: about one tile of loads stays in flight per wave at all times, so the embedding stream never drains).
+// Erow / eq_row are wave-uniform bases; EQ / UA are compile-time because a run-time branch around the e4 loads would put
+// their s_waitcnt vmcnt(0) at the top of every tile and drain the prefetched loads.  UA (H % 4 == 0): the 4 rows a lane owns
+// in a row tile share one anchor.
+template <int CT, int RT, bool NEXT, bool EQ, bool UA>
+__device__ __forceinline__ void bias_tile(float4 (&b)[CT], const float4* afrag, const float4* qe_s, float* stage, int col0,
+                                          const float* Erow, const float* eq_row, unsigned eq_anchor_stride, int tile,
+                                          int next_tile, int M, int AH, int H) {
+  constexpr int C = CT * 16;
+  const int lane = threadIdx.x & 63, col = lane & 15, kq = lane >> 4;
+  asm volatile("" ::: "memory");        // keeps the LDS fragment reads inside the tile loop (otherwise hoisted and spilled)
+  const int m = (tile << 4) + col;
+  const float* Enext = Erow + ((unsigned)min((next_tile << 4) + col, M - 1) * C + 4 * kq);     // chunk t at +16 t (immediate)
+  float4 e4[RT];
+  if (EQ && UA) {
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+      const int a = min((16 * rt + 4 * kq) / H, AH / H - 1);
+      e4[rt] = ld4(eq_row + ((unsigned)a * eq_anchor_stride + (unsigned)min(m, M - 1) * 4));
+    }
+  }
+  f32x4 acc[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 a[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++) a[rt] = afrag[(rt * CT) * 64 + lane];
+#pragma unroll
+  for (int t = 0; t < CT; t++) {
+    // one scheduling group per channel chunk: [LDS fragments of chunk t+1] [4 RT MFMAs of chunk t] [reload of b[t]]; the
+    // barrier keeps the machine scheduler from sinking the 16 reloads behind the last MFMA (which would undo the prefetch)
+    float4 an[RT];
+    if (t + 1 < CT) {
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++) an[rt] = afrag[(rt * CT + t + 1) * 64 + lane];
+    }
+    const float4 bt = b[t];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++)
+        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(a[rt], i), f4get(bt, i), acc[rt], 0, 0, 0);
+    }
+    if (NEXT) b[t] = ld4(Enext + 16 * t);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < CT) {
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++) a[rt] = an[rt];
+    }
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int row = 16 * rt + 4 * kq + j;      // rows >= AH: zero queries, never written out
+      float val = acc[rt][j];
+      if (EQ) {
+        const float4 e = UA ? e4[rt]
+                            : ld4(eq_row + ((unsigned)min(row / H, AH / H - 1) * eq_anchor_stride + (unsigned)min(m, M - 1) * 4));
+        const float4 w = qe_s[row];
+        val += (w.x * e.x + w.y * e.y) + (w.z * e.z + w.w * e.w);
+      }
+      stage[row * kStageStride + col0 + col] = m < M ? val : 0.f;
+    }
+  }
+}
+
+// Flat, balanced decomposition: the (row n, 32-key unit) pairs of all clouds form one list; workgroup w owns the contiguous
+// range [w U / G, (w+1) U / G) and walks it row segment by row segment (the folded queries of the segment's row are staged
+// in LDS in MFMA-fragment order); inside a segment the 4 waves stride over the units.  A unit = two 16-key tiles whose
+// logits are collected in a wave-private LDS block and written out as full 128-byte row segments (float4 per lane).
+template <int CT, int RT, int MINW, bool EQ, bool UA>
 __global__ __launch_bounds__(256, MINW) void rpe_bias_kernel(const float* __restrict__ qp, const float* __restrict__ qe,
-                                                       int qp_rs, long long qp_sa, const float* __restrict__ emb,
-                                                       const float* __restrict__ eq_emb, int N, int M, int AH, int H, int Mp,
-                                                       float* __restrict__ bias) {
+                                                             int qp_rs, long long qp_sa, Stack S, int AH, int H,
+                                                             float* __restrict__ bias) {
   constexpr int C = CT * 16;
   __shared__ float4 afrag[RT * CT * 64];
   __shared__ float4 qe_s[32];
-  const int n = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ __attribute__((aligned(16))) float stage_s[4 * RT * 16 * kStageStride];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, kq = lane >> 4;
+  float* stage = stage_s + wave * (RT * 16 * kStageStride);
+  int f = (int)((long long)blockIdx.x * S.total_units / gridDim.x);
+  const int f_end = (int)((long long)(blockIdx.x + 1) * S.total_units / gridDim.x);
+  while (f < f_end) {
+    int ci = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxClouds; i++)
+      if (i < S.n && f >= S.c[i].unit_begin) ci = i;
+    const StackCloud cl = stack_pick(S, ci);
+    const int units = cl.Mp >> 5;
+    const int rel = f - cl.unit_begin;
+    const int n = rel / units, u_lo = rel - n * units;
+    const int u_hi = min(units, u_lo + (f_end - f));
+    f += u_hi - u_lo;
 
-  // folded queries of row n: qp[a][n][h*C + c] (row stride qp_rs, anchor stride qp_sa) -> LDS in MFMA-fragment order
-  // afrag[(rt*CT + t)*64 + kq*16 + r] = float4 of channels 16 t + 4 kq .. +3 of folded query row 16 rt + r (r = a*H + h).
-  // Thread i takes row (i % (16 RT)) and chunk i / (16 RT): consecutive lanes write consecutive float4 (conflict free).
-  for (int i = threadIdx.x; i < RT * 16 * (C / 4); i += 256) {
-    const int row = i % (RT * 16), c4 = i / (RT * 16);
-    const int t = c4 >> 2, kq = c4 & 3;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < AH) {
-      const int a = row / H, h = row - a * H;
-      v = ld4(qp + (size_t)a * qp_sa + (size_t)n * qp_rs + h * C + 4 * c4);
+    const float* Erow = cl.emb + (size_t)n * cl.M * C;           // wave-uniform base of the embedding row block
+    int unit = u_lo + wave;
+    // Issue order (the VMEM counter is in-order): folded queries of packed row q_start + n first, then the wave's first
+    // embedding tile; the queries are waited for and written to LDS while the tile is still in flight.
+    // afrag[(rt*CT + t)*64 + kq*16 + r] = float4 of channels 16 t + 4 kq .. +3 of folded query row 16 rt + r (r = a*H + h);
+    // thread i takes row i % (16 RT) and chunk i / (16 RT): consecutive lanes write consecutive float4 (conflict free).
+    constexpr int QTOT = RT * 16 * (C / 4), QI = (QTOT + 255) / 256;
+    const size_t qrow = (size_t)(cl.q_start + n) * qp_rs;
+    float4 qv[QI];
+#pragma unroll
+    for (int u = 0; u < QI; u++) {
+      const int i = threadIdx.x + 256 * u;
+      const int row = i % (RT * 16), c4 = i / (RT * 16);
+      qv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < QTOT && row < AH) {
+        const int a = row / H, h = row - a * H;
+        qv[u] = ld4(qp + (size_t)a * qp_sa + qrow + h * C + 4 * c4);
+      }
     }
-    afrag[((row >> 4) * CT + t) * 64 + kq * 16 + (row & 15)] = v;
-  }
-  if (threadIdx.x < 32) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (qe != nullptr && threadIdx.x < AH) {
+    float4 qev = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EQ && threadIdx.x < AH) {
       const int a = threadIdx.x / H, h = threadIdx.x - a * H;
-      v = ld4(qe + (size_t)a * qp_sa + (size_t)n * qp_rs + 4 * h);
+      qev = ld4(qe + (size_t)a * qp_sa + qrow + 4 * h);
     }
-    qe_s[threadIdx.x] = v;
-  }
-  __syncthreads();
+    float4 b[CT];
+    if (unit < u_hi) {
+      const float* E0 = Erow + ((unsigned)min((unit << 5) + col, cl.M - 1) * C + 4 * kq);
+#pragma unroll
+      for (int t = 0; t < CT; t++) b[t] = ld4(E0 + 16 * t);
+    }
+    __syncthreads();                      // the previous segment's fragment reads are done
+#pragma unroll
+    for (int u = 0; u < QI; u++) {
+      const int i = threadIdx.x + 256 * u;
+      const int row = i % (RT * 16), c4 = i / (RT * 16);
+      const int t = c4 >> 2, kk = c4 & 3;
+      if (i < QTOT) afrag[((row >> 4) * CT + t) * 64 + kk * 16 + (row & 15)] = qv[u];
+    }
+    if (threadIdx.x < 32) qe_s[threadIdx.x] = qev;
+    __syncthreads();
 
-  const int tiles = (M + 15) >> 4;
-  const int per = (tiles + gridDim.y - 1) / gridDim.y;
-  const int t_begin = blockIdx.y * per, t_end = min(tiles, t_begin + per);
-  const int col = lane & 15, kq = lane >> 4;
-  const float* Erow0 = emb + (size_t)n * M * C + 4 * kq;
-  const bool uniform_anchor = (H % 4) == 0;      // the 4 rows a lane owns in a row tile then share one anchor
-
-  int tile = t_begin + wave;
-  float4 b[CT], bn[PREFETCH ? CT : 1];
-  if (PREFETCH && tile < t_end) {
-    const float* Er = Erow0 + (size_t)min((tile << 4) + col, M - 1) * C;
+    const unsigned eq_sa = (unsigned)cl.N * cl.M * 4;
+    const float* eq_row = EQ ? cl.eq + (size_t)n * cl.M * 4 : nullptr;
+    float* bias_row = bias + cl.bias_off + (size_t)n * cl.Mp;
+    const unsigned bias_ah = (unsigned)cl.N * cl.Mp;
+    for (; unit < u_hi; unit += 4) {
+      const int t0 = unit << 1;
+      bias_tile<CT, RT, true, EQ, UA>(b, afrag, qe_s, stage, 0, Erow, eq_row, eq_sa, t0, t0 + 1, cl.M, AH, H);
+      if (unit + 4 < u_hi)
+        bias_tile<CT, RT, true, EQ, UA>(b, afrag, qe_s, stage, 16, Erow, eq_row, eq_sa, t0 + 1, t0 + 8, cl.M, AH, H);
+      else
+        bias_tile<CT, RT, false, EQ, UA>(b, afrag, qe_s, stage, 16, Erow, eq_row, eq_sa, t0 + 1, t0 + 1, cl.M, AH, H);
+      // the unit's (rows, 32 keys) block: 8 lanes cover one row's 128 bytes
+      const int r8 = lane >> 3, m4 = (lane & 7) * 4;
 #pragma unroll
-    for (int t = 0; t < CT; t++) b[t] = ld4(Er + 16 * t);
-  }
-  for (; tile < t_end; tile += 4) {
-    // compiler fence: without it the loop-invariant LDS fragment reads are hoisted out of the tile loop (128 VGPRs) and
-    // spilled to scratch -- the reads must stay inside the loop, next to their MFMAs
-    asm volatile("" ::: "memory");
-    const int m0 = tile << 4;
-    const bool more = PREFETCH && tile + 4 < t_end;
-    if (PREFETCH) {
-      if (more) {                                  // software prefetch of the next tile (second register set)
-        const float* Er = Erow0 + (size_t)min(((tile + 4) << 4) + col, M - 1) * C;
-#pragma unroll
-        for (int t = 0; t < CT; t++) bn[t] = ld4(Er + 16 * t);
-      }
-    } else {
-      const float* Er = Erow0 + (size_t)min(m0 + col, M - 1) * C;
-#pragma unroll
-      for (int t = 0; t < CT; t++) b[t] = ld4(Er + 16 * t);
-    }
-    const int m = m0 + col;
-    float4 e4[RT];
-    if (eq_emb != nullptr && uniform_anchor) {
-#pragma unroll
-      for (int rt = 0; rt < RT; rt++) {
-        const int a = min((16 * rt + 4 * kq) / H, AH / H - 1);
-        e4[rt] = ld4(eq_emb + (((size_t)a * N + n) * M + min(m, M - 1)) * 4);
-      }
-    }
-    f32x4 acc[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; rt++) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < CT; t++) {
-      float4 a[RT];
-#pragma unroll
-      for (int rt = 0; rt < RT; rt++) a[rt] = afrag[(rt * CT + t) * 64 + lane];
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-#pragma unroll
-        for (int rt = 0; rt < RT; rt++)
-          acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(a[rt], i), f4get(b[t], i), acc[rt], 0, 0, 0);
-      }
-    }
-    if (m < M) {
-#pragma unroll
-      for (int rt = 0; rt < RT; rt++) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int row = 16 * rt + 4 * kq + j;
-          if (row < AH) {
-            float val = acc[rt][j];
-            if (eq_emb != nullptr) {
-              const float4 e = uniform_anchor ? e4[rt] : ld4(eq_emb + (((size_t)(row / H) * N + n) * M + m) * 4);
-              const float4 w = qe_s[row];
-              val += (w.x * e.x + w.y * e.y) + (w.z * e.z + w.w * e.w);
-            }
-            bias[((size_t)row * N + n) * Mp + m] = val;
-          }
+      for (int pass = 0; pass < RT * 2; pass++) {
+        const int row = pass * 8 + r8;
+        if (row < AH) {
+          const float4 v = *reinterpret_cast<const float4*>(stage + row * kStageStride + m4);
+          *reinterpret_cast<float4*>(bias_row + ((unsigned)row * bias_ah + (unsigned)((unit << 5) + m4))) = v;
         }
       }
-    }
-    if (PREFETCH && more) {
-#pragma unroll
-      for (int t = 0; t < CT; t++) b[t] = bn[t];
     }
   }
 }
@@ -189,8 +277,9 @@ __device__ __forceinline__ void flash_load(TileRegs<D>& r, const float* __restri
 
 // q/k point at the (anchor, head) slice (row strides q_rs / k_rs floats: they may be column blocks of a wider projection); v points at the TRANSPOSED values of the slice, vt[dd * Mp + key]
 // (keys zero-padded to Mp, a multiple of 32).  bias (may be null) points at the (ah) slice, row stride Mp.
-// The loads of tile t+step are issued before the MFMAs of tile t (two register sets).
-template <int D>
+// PREFETCH: the loads of tile t+step are issued before the MFMAs of tile t (two register sets); otherwise the loads of a tile
+// sit at the top of its iteration and latency is hidden by the other resident waves (fewer VGPRs, more waves per SIMD).
+template <int D, bool PREFETCH = true>
 __device__ __forceinline__ void flash_tiles(FlashState<D>& st, const float* __restrict__ q, const float* __restrict__ k,
                                             const float* __restrict__ v, const float* __restrict__ bias, int n0, int N, int M,
                                             int q_rs, int k_rs, int v_rs, int Mp, float scale, int tile_begin, int tile_step) {
@@ -204,11 +293,15 @@ __device__ __forceinline__ void flash_tiles(FlashState<D>& st, const float* __re
   const int tiles = (M + 31) >> 5;
   TileRegs<D> cur, nxt;
   int tile = tile_begin;
-  if (tile < tiles) flash_load<D>(cur, k, v, bias_row, tile << 5, M, k_rs, v_rs);
+  if (PREFETCH && tile < tiles) flash_load<D>(cur, k, v, bias_row, tile << 5, M, k_rs, v_rs);
   for (; tile < tiles; tile += tile_step) {
     const int m0 = tile << 5;
-    const bool more = tile + tile_step < tiles;
-    if (more) flash_load<D>(nxt, k, v, bias_row, (tile + tile_step) << 5, M, k_rs, v_rs);
+    const bool more = PREFETCH && tile + tile_step < tiles;
+    if (PREFETCH) {
+      if (more) flash_load<D>(nxt, k, v, bias_row, (tile + tile_step) << 5, M, k_rs, v_rs);
+    } else {
+      flash_load<D>(cur, k, v, bias_row, m0, M, k_rs, v_rs);
+    }
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; r++) s[r] = 0.f;
@@ -249,7 +342,7 @@ __device__ __forceinline__ void flash_tiles(FlashState<D>& st, const float* __re
 #pragma unroll
       for (int r = 0; r < 16; r++) st.o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.vv[dt * 16 + r], s[r], st.o[dt], 0, 0, 0);
     }
-    if (more) cur = nxt;
+    if (PREFETCH && more) cur = nxt;
   }
 }
 
@@ -329,26 +422,42 @@ __device__ __forceinline__ void flash_store(const FlashState<D>& st, float* __re
 struct AttnArgs {
   const float *q, *k, *v, *bias;
   float* out;
-  int N, M, C, H, Mp;
-  int q_rs, k_rs, v_rs;               // row strides of q, k (>= C) and of the transposed values (>= ceil32(M)) in floats
+  Stack S;
+  int C, H, A;
+  int q_rs, k_rs, v_rs;               // row strides of q, k (>= C) and of the transposed values in floats
   long long q_sa, k_sa, v_sa, o_sa;   // anchor strides in floats (0 = shared by all anchors)
   float scale;
+  int QT;                             // 32-query tiles of the largest cloud
+  int G;                              // groups = clouds * anchors * heads
 };
 
-// grid (ceil(N/32), H, A_out); NW waves split the key tiles of one (anchor, head, 32-query tile)
-template <int D, int NW, int MINW>
+// One workgroup per (cloud, anchor, head, 32-query tile); its NW waves split the key tiles and merge through LDS.
+// XCD-aware flat grid: workgroup i runs on XCD i % 8 (round-robin dispatch), so group g = (cloud, anchor, head) is pinned
+// to XCD g % 8 and the K / V^T of a group (re-read by all of its query tiles) stay in ONE L2.
+template <int D, int NW, int MINW, bool PREFETCH>
 __global__ __launch_bounds__(64 * NW, MINW) void attention_kernel(AttnArgs p) {
   __shared__ float sm[64 * NW], sl[64 * NW];
   __shared__ float so[NW * FlashState<D>::DT * 16 * 64];
-  const int n0 = blockIdx.x * 32, h = blockIdx.y, a = blockIdx.z;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int gslot = j / p.QT, qt = j - gslot * p.QT;
+  const int g = gslot * 8 + xcd;
+  if (g >= p.G) return;
+  const int AH = p.A * p.H;
+  const int ci = g / AH, ah = g - ci * AH;
+  const int a = ah / p.H, h = ah - a * p.H;
+  const StackCloud cl = stack_pick(p.S, ci);
+  const int n0 = qt * 32;
+  if (n0 >= cl.N) return;
   const int wave = threadIdx.x >> 6;
   FlashState<D> st;
   flash_init(st);
-  const float* bias = p.bias ? p.bias + ((size_t)(a * p.H + h) * p.N) * p.Mp : nullptr;
-  flash_tiles<D>(st, p.q + a * p.q_sa + h * D, p.k + a * p.k_sa + h * D, p.v + a * p.v_sa + (size_t)h * D * p.v_rs, bias, n0, p.N, p.M, p.q_rs,
-                 p.k_rs, p.v_rs, p.Mp, p.scale, wave, NW);
+  const float* bias = p.bias ? p.bias + cl.bias_off + ((size_t)ah * cl.N) * cl.Mp : nullptr;
+  flash_tiles<D, PREFETCH>(st, p.q + a * p.q_sa + (size_t)cl.q_start * p.q_rs + h * D,
+                           p.k + a * p.k_sa + (size_t)cl.k_start * p.k_rs + h * D,
+                           p.v + a * p.v_sa + (size_t)h * D * p.v_rs + cl.k_start, bias, n0, cl.N, cl.M, p.q_rs, p.k_rs, p.v_rs,
+                           cl.Mp, p.scale, wave, NW);
   flash_merge<D, NW>(st, sm, sl, so);
-  if (wave == 0) flash_store<D>(st, p.out + a * p.o_sa + h * D, n0, p.N, p.C, 1.f, false);
+  if (wave == 0) flash_store<D>(st, p.out + a * p.o_sa + (size_t)cl.q_start * p.C + h * D, n0, cl.N, p.C, 1.f, false);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -510,40 +619,53 @@ static int g_bias_split = 0;
 // tuning hooks (benchmarks only): kernel variant / m-split override; 0 = default
 extern "C" void se3_debug_set_bias_variant(int variant, int split) { g_bias_variant = variant; g_bias_split = split; }
 
-extern "C" int se3_rpe_bias_fwd(const float* qp, const float* qe, int row_stride, int64_t anchor_stride, const float* emb,
-                                const float* eq_emb, int N, int M, int C, int AH, int H, int bias_row_stride, float* bias,
-                                void* stream) {
-  SE3_REQUIRE(qp && emb && bias, SE3_ERR_INVALID_ARG, "rpe_bias: null pointer");
-  SE3_REQUIRE(row_stride % 4 == 0 && row_stride >= H * C, SE3_ERR_INVALID_ARG, "rpe_bias: folded-query row stride");
-  SE3_REQUIRE((qe == nullptr) == (eq_emb == nullptr), SE3_ERR_INVALID_ARG, "rpe_bias: qe and eq_emb go together");
-  SE3_REQUIRE(N >= 1 && M >= 1 && AH >= 1 && AH <= 32 && H >= 1 && AH % H == 0, SE3_ERR_UNSUPPORTED,
-              "rpe_bias: N %d M %d AH %d H %d", N, M, AH, H);
-  SE3_REQUIRE(bias_row_stride >= M, SE3_ERR_INVALID_ARG, "rpe_bias: bias row stride < M");
-  hipStream_t st = (hipStream_t)stream;
-  int split = (768 + N - 1) / N;
-  const int tiles = (M + 15) / 16;
-  if (split > (tiles + 3) / 4) split = (tiles + 3) / 4;
-  if (split < 1) split = 1;
-  if (g_bias_split > 0) split = g_bias_split;
-  dim3 grid((unsigned)N, (unsigned)split);
-#define SE3_BIAS_ARGS qp, qe, row_stride, anchor_stride, emb, eq_emb, N, M, AH, H, bias_row_stride, bias
+static int device_cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+static int launch_rpe_bias(const float* qp, const float* qe, int row_stride, int64_t anchor_stride, Stack& S, int C, int AH,
+                           int H, float* bias, hipStream_t st) {
+  long long total = 0;
+  for (int c = 0; c < S.n; c++) {
+    const StackCloud& cl = S.c[c];
+    // 32-bit lane offsets inside a cloud's embedding row block / equivariant embedding / logits block
+    SE3_REQUIRE((long long)cl.M * C < (1ll << 31) && (long long)(AH / H) * cl.N * cl.M * 4 < (1ll << 31) &&
+                    (long long)AH * cl.N * cl.Mp < (1ll << 31),
+                SE3_ERR_UNSUPPORTED, "rpe_bias: cloud %d too large for 32-bit offsets (N %d, M %d)", c, cl.N, cl.M);
+    S.c[c].unit_begin = (int)total;
+    total += (long long)cl.N * (cl.Mp / 32);
+  }
+  SE3_REQUIRE(total < (1ll << 31), SE3_ERR_UNSUPPORTED, "rpe_bias: too many (row, key tile) units");
+  S.total_units = (int)total;
+  // one resident round: 3 workgroups of 4 waves per CU (LDS: fragments + staging), each with a balanced range of units
+  int wgs = 3 * device_cu_count();
+  if (g_bias_split > 0) wgs = g_bias_split * device_cu_count();
+  if (wgs > (total + 3) / 4) wgs = (int)((total + 3) / 4);
+  if (wgs < 1) wgs = 1;
+  dim3 grid((unsigned)wgs);
+#define SE3_BIAS_ARGS qp, qe, row_stride, anchor_stride, S, AH, H, bias
+#define SE3_BIAS_LAUNCH_RT(CT, RT)                                                                                   \
+  if (qe == nullptr) {                                                                                               \
+    if (g_bias_variant == 2) rpe_bias_kernel<CT, RT, 2, false, true><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS);           \
+    else rpe_bias_kernel<CT, RT, 3, false, true><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS);                               \
+  } else if (H % 4 == 0) {                                                                                           \
+    if (g_bias_variant == 2) rpe_bias_kernel<CT, RT, 2, true, true><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS);            \
+    else rpe_bias_kernel<CT, RT, 3, true, true><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS);                                \
+  } else {                                                                                                           \
+    rpe_bias_kernel<CT, RT, 2, true, false><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS);                                    \
+  }
 #define SE3_BIAS_LAUNCH(CT)                                                                                          \
   if (AH <= 16) {                                                                                                    \
-    switch (g_bias_variant) {                                                                                        \
-      case 1: rpe_bias_kernel<CT, 1, true, 2><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS); break;                           \
-      case 2: rpe_bias_kernel<CT, 1, true, 3><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS); break;                           \
-      case 3: rpe_bias_kernel<CT, 1, false, 3><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS); break;                          \
-      case 4: rpe_bias_kernel<CT, 1, false, 5><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS); break;                          \
-      default: rpe_bias_kernel<CT, 1, false, 4><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS); break;                         \
-    }                                                                                                                \
+    SE3_BIAS_LAUNCH_RT(CT, 1)                                                                                        \
   } else {                                                                                                           \
-    switch (g_bias_variant) {                                                                                        \
-      case 1: rpe_bias_kernel<CT, 2, true, 2><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS); break;                           \
-      case 2: rpe_bias_kernel<CT, 2, true, 3><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS); break;                           \
-      case 3: rpe_bias_kernel<CT, 2, false, 3><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS); break;                          \
-      case 4: rpe_bias_kernel<CT, 2, false, 5><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS); break;                          \
-      default: rpe_bias_kernel<CT, 2, false, 4><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS); break;                         \
-    }                                                                                                                \
+    SE3_BIAS_LAUNCH_RT(CT, 2)                                                                                        \
   }
   switch (C) {
     case 32: SE3_BIAS_LAUNCH(2) break;
@@ -555,7 +677,70 @@ extern "C" int se3_rpe_bias_fwd(const float* qp, const float* qe, int row_stride
       return SE3_ERR_UNSUPPORTED;
   }
 #undef SE3_BIAS_LAUNCH
+#undef SE3_BIAS_LAUNCH_RT
+#undef SE3_BIAS_ARGS
   SE3_CHECK_LAUNCH("rpe_bias");
+  return SE3_OK;
+}
+
+extern "C" int se3_rpe_bias_fwd(const float* qp, const float* qe, int row_stride, int64_t anchor_stride, const float* emb,
+                                const float* eq_emb, int N, int M, int C, int AH, int H, int bias_row_stride, float* bias,
+                                void* stream) {
+  SE3_REQUIRE(qp && emb && bias, SE3_ERR_INVALID_ARG, "rpe_bias: null pointer");
+  SE3_REQUIRE(row_stride % 4 == 0 && row_stride >= H * C, SE3_ERR_INVALID_ARG, "rpe_bias: folded-query row stride");
+  SE3_REQUIRE((qe == nullptr) == (eq_emb == nullptr), SE3_ERR_INVALID_ARG, "rpe_bias: qe and eq_emb go together");
+  SE3_REQUIRE(N >= 1 && M >= 1 && AH >= 1 && AH <= 32 && H >= 1 && AH % H == 0, SE3_ERR_UNSUPPORTED,
+              "rpe_bias: N %d M %d AH %d H %d", N, M, AH, H);
+  SE3_REQUIRE(bias_row_stride >= M && bias_row_stride % 32 == 0, SE3_ERR_INVALID_ARG,
+              "rpe_bias: the logits row stride must be a multiple of 32 covering M (all of it is written, zeros beyond M)");
+  Stack S{};
+  S.n = 1;
+  S.c[0] = StackCloud{emb, eq_emb, 0, 0, N, M, bias_row_stride, 0, 0};
+  return launch_rpe_bias(qp, qe, row_stride, anchor_stride, S, C, AH, H, bias, (hipStream_t)stream);
+}
+
+extern "C" int se3_rpe_bias_stack_fwd(const float* qp, const float* qe, int row_stride, int64_t anchor_stride,
+                                      const float* const* emb_ptrs, const float* const* eq_ptrs, const int64_t* q_starts,
+                                      const int64_t* q_lengths, const int64_t* k_lengths, const int64_t* bias_offsets,
+                                      int num_clouds, int C, int AH, int H, float* bias, void* stream) {
+  SE3_REQUIRE(qp && emb_ptrs && q_starts && q_lengths && k_lengths && bias_offsets && bias, SE3_ERR_INVALID_ARG,
+              "rpe_bias_stack: null pointer");
+  SE3_REQUIRE(num_clouds >= 1 && num_clouds <= kMaxClouds, SE3_ERR_UNSUPPORTED, "rpe_bias_stack: %d clouds (1..%d)", num_clouds,
+              kMaxClouds);
+  SE3_REQUIRE(row_stride % 4 == 0 && row_stride >= H * C, SE3_ERR_INVALID_ARG, "rpe_bias_stack: folded-query row stride");
+  SE3_REQUIRE(AH >= 1 && AH <= 32 && H >= 1 && AH % H == 0, SE3_ERR_UNSUPPORTED, "rpe_bias_stack: AH %d H %d", AH, H);
+  Stack S{};
+  S.n = num_clouds;
+  for (int c = 0; c < num_clouds; c++) {
+    SE3_REQUIRE(emb_ptrs[c] != nullptr && q_lengths[c] >= 1 && k_lengths[c] >= 1 && q_starts[c] >= 0 && bias_offsets[c] >= 0 &&
+                    bias_offsets[c] % 4 == 0,
+                SE3_ERR_INVALID_ARG, "rpe_bias_stack: cloud %d descriptor", c);
+    SE3_REQUIRE((qe == nullptr) == (eq_ptrs == nullptr || eq_ptrs[c] == nullptr), SE3_ERR_INVALID_ARG,
+                "rpe_bias_stack: qe and the equivariant embeddings go together");
+    const int M = (int)k_lengths[c];
+    S.c[c] = StackCloud{emb_ptrs[c], qe ? eq_ptrs[c] : nullptr, (int)q_starts[c], 0, (int)q_lengths[c], M, ((M + 31) / 32) * 32,
+                        0, (long long)bias_offsets[c]};
+  }
+  return launch_rpe_bias(qp, qe, row_stride, anchor_stride, S, C, AH, H, bias, (hipStream_t)stream);
+}
+
+static int launch_attention(AttnArgs& p, hipStream_t st) {
+  int qt = 1;
+  for (int c = 0; c < p.S.n; c++) qt = (p.S.c[c].N + 31) / 32 > qt ? (p.S.c[c].N + 31) / 32 : qt;
+  p.QT = qt;
+  p.G = p.S.n * p.A * p.H;
+  dim3 grid((unsigned)(8 * ((p.G + 7) / 8) * qt));
+  int rc = dispatch_head_dim(p.C / p.H, [&](auto d) {
+    constexpr int D = decltype(d)::value;
+    switch (g_attn_variant) {      // tuning hook; default: loads at the top of each key tile, 3 workgroups (12 waves) per CU
+      case 1: attention_kernel<D, 4, 2, true><<<grid, 256, 0, st>>>(p); break;
+      case 2: attention_kernel<D, 6, 2, false><<<grid, 384, 0, st>>>(p); break;
+      case 3: attention_kernel<D, 2, 3, false><<<grid, 128, 0, st>>>(p); break;
+      default: attention_kernel<D, 4, 3, false><<<grid, 256, 0, st>>>(p); break;
+    }
+  }, "attention");
+  if (rc != SE3_OK) return rc;
+  SE3_CHECK_LAUNCH("attention");
   return SE3_OK;
 }
 
@@ -571,25 +756,48 @@ extern "C" int se3_attention_fwd(const float* q, const float* k, const float* v,
   SE3_REQUIRE(num_anchors >= 1 && N >= 1 && M >= 1 && H >= 1 && C % H == 0, SE3_ERR_INVALID_ARG, "attention: bad sizes");
   SE3_REQUIRE(bias == nullptr || (bias_row_stride >= ((M + 31) / 32) * 32 && bias_row_stride % 4 == 0), SE3_ERR_INVALID_ARG,
               "attention: bias rows must be padded to a multiple of 4 covering ceil32(M)");
-  AttnArgs p{q, k, v, bias, out, N, M, C, H, bias_row_stride, q_row_stride, k_row_stride, v_row_stride, q_anchor_stride, k_anchor_stride,
-             v_anchor_stride, out_anchor_stride, scale};
-  dim3 grid((unsigned)((N + 31) / 32), (unsigned)H, (unsigned)num_anchors);
-  hipStream_t st = (hipStream_t)stream;
-  const bool wide = (M + 31) / 32 >= 6;      // enough key tiles to feed 8 waves per (anchor, head, query tile)
-  int rc = dispatch_head_dim(C / H, [&](auto d) {
-    constexpr int D = decltype(d)::value;
-    (void)wide;
-    switch (g_attn_variant) {
-      case 1: attention_kernel<D, 3, 1><<<grid, 192, 0, st>>>(p); break;
-      case 2: attention_kernel<D, 4, 1><<<grid, 256, 0, st>>>(p); break;
-      case 3: attention_kernel<D, 2, 1><<<grid, 128, 0, st>>>(p); break;
-      case 4: attention_kernel<D, 6, 1><<<grid, 384, 0, st>>>(p); break;
-      default: attention_kernel<D, 4, 2><<<grid, 256, 0, st>>>(p); break;
-    }
-  }, "attention");
-  if (rc != SE3_OK) return rc;
-  SE3_CHECK_LAUNCH("attention");
-  return SE3_OK;
+  AttnArgs p{};
+  p.q = q; p.k = k; p.v = v; p.bias = bias; p.out = out;
+  p.S.n = 1;
+  p.S.c[0] = StackCloud{nullptr, nullptr, 0, 0, N, M, bias_row_stride, 0, 0};
+  p.C = C; p.H = H; p.A = num_anchors;
+  p.q_rs = q_row_stride; p.k_rs = k_row_stride; p.v_rs = v_row_stride;
+  p.q_sa = q_anchor_stride; p.k_sa = k_anchor_stride; p.v_sa = v_anchor_stride; p.o_sa = out_anchor_stride;
+  p.scale = scale;
+  return launch_attention(p, (hipStream_t)stream);
+}
+
+extern "C" int se3_attention_stack_fwd(const float* q, const float* k, const float* vt, const float* bias,
+                                       const int64_t* q_starts, const int64_t* q_lengths, const int64_t* k_starts,
+                                       const int64_t* k_lengths, const int64_t* bias_offsets, int num_clouds, int num_anchors,
+                                       int C, int H, int q_row_stride, int k_row_stride, int v_row_stride,
+                                       int64_t q_anchor_stride, int64_t k_anchor_stride, int64_t v_anchor_stride,
+                                       int64_t out_anchor_stride, float scale, float* out, void* stream) {
+  SE3_REQUIRE(q && k && vt && out && q_starts && q_lengths && k_starts && k_lengths, SE3_ERR_INVALID_ARG,
+              "attention_stack: null pointer");
+  SE3_REQUIRE((bias == nullptr) == (bias_offsets == nullptr), SE3_ERR_INVALID_ARG,
+              "attention_stack: bias and bias_offsets go together");
+  SE3_REQUIRE(num_clouds >= 1 && num_clouds <= kMaxClouds, SE3_ERR_UNSUPPORTED, "attention_stack: %d clouds (1..%d)", num_clouds,
+              kMaxClouds);
+  SE3_REQUIRE(num_anchors >= 1 && H >= 1 && C % H == 0, SE3_ERR_INVALID_ARG, "attention_stack: bad sizes");
+  SE3_REQUIRE(q_row_stride >= C && k_row_stride >= C && q_row_stride % 4 == 0 && k_row_stride % 4 == 0 && v_row_stride % 4 == 0,
+              SE3_ERR_INVALID_ARG, "attention_stack: row strides must be multiples of 4 (q/k >= C)");
+  AttnArgs p{};
+  p.q = q; p.k = k; p.v = vt; p.bias = bias; p.out = out;
+  p.S.n = num_clouds;
+  for (int c = 0; c < num_clouds; c++) {
+    const int N = (int)q_lengths[c], M = (int)k_lengths[c], Mp = ((M + 31) / 32) * 32;
+    SE3_REQUIRE(N >= 1 && M >= 1 && q_starts[c] >= 0 && k_starts[c] >= 0 && k_starts[c] % 4 == 0 && k_starts[c] + Mp <= v_row_stride,
+                SE3_ERR_INVALID_ARG, "attention_stack: cloud %d: key columns must start at a multiple of 4 and ceil32(M) fit the value rows", c);
+    SE3_REQUIRE(bias == nullptr || (bias_offsets[c] >= 0 && bias_offsets[c] % 4 == 0), SE3_ERR_INVALID_ARG,
+                "attention_stack: cloud %d logits offset", c);
+    p.S.c[c] = StackCloud{nullptr, nullptr, (int)q_starts[c], (int)k_starts[c], N, M, Mp, 0, bias ? (long long)bias_offsets[c] : 0};
+  }
+  p.C = C; p.H = H; p.A = num_anchors;
+  p.q_rs = q_row_stride; p.k_rs = k_row_stride; p.v_rs = v_row_stride;
+  p.q_sa = q_anchor_stride; p.k_sa = k_anchor_stride; p.v_sa = v_anchor_stride; p.o_sa = out_anchor_stride;
+  p.scale = scale;
+  return launch_attention(p, (hipStream_t)stream);
 }
 
 extern "C" int se3_cross_eq_stats(const float* q, const float* k, int A, int N, int M, int C, int H, float scale,

@@ -167,7 +167,7 @@ def pack_rows(xs, multiple=32):
 def rpe_self_attention_packed(x, starts, lengths, embs, eq_embs, w_stack, b_stack, offs, w_v, b_v, num_heads):
     """RPE self attention of several clouds at once.  x ([A,] R, C): the clouds' rows packed at `starts` (multiples of 32) with
     `lengths`; ONE stacked GEMM yields q, k and the folded queries of all clouds, ONE GEMM the transposed values; the two
-    attention kernels run per cloud on strided views.  Returns hidden ([A,] R, C) (padding rows are zero)."""
+    attention kernels run once for all clouds (stack mode).  Returns hidden ([A,] R, C) (padding rows are zero)."""
     H = num_heads
     C = x.shape[-1]
     x3 = x if x.dim() == 3 else x.unsqueeze(0)
@@ -175,12 +175,12 @@ def rpe_self_attention_packed(x, starts, lengths, embs, eq_embs, w_stack, b_stac
     A_, R_ = x3.shape[0], x3.shape[1]
     vt = torch.baddbmm(b_v[None, :, None].expand(A_, C, R_), w_v[None].expand(A_, C, C), x3.transpose(1, 2))   # (A, C, R)
     hidden = torch.zeros_like(x3)
-    for s0, n, emb, eq in zip(starts, lengths, embs, eq_embs):
-        rows = proj[:, s0:s0 + n]
-        qe = rows[..., offs['qe']:offs['qe'] + 4 * H] if eq is not None else None
-        bias = _ops.rpe_bias(rows[..., offs['qp']:offs['qp'] + H * C], qe, emb, eq, H)
-        _ops.attention(rows[..., offs['q']:offs['q'] + C], rows[..., offs['k']:offs['k'] + C],
-                       vt[:, :, s0:s0 + _ops.key_stride(n)], bias, H, out=hidden[:, s0:s0 + n], tag='rpe')
+    has_eq = eq_embs[0] is not None
+    qe = proj[..., offs['qe']:offs['qe'] + 4 * H] if has_eq else None
+    bias, bias_offs = _ops.rpe_bias_stack(proj[..., offs['qp']:offs['qp'] + H * C], qe, embs, eq_embs if has_eq else None,
+                                          starts, lengths, H)
+    _ops.attention_stack(proj[..., offs['q']:offs['q'] + C], proj[..., offs['k']:offs['k'] + C], vt, bias, bias_offs,
+                         starts, lengths, starts, lengths, H, hidden, tag='rpe')
     return hidden if x.dim() == 3 else hidden[0]
 
 

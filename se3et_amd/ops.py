@@ -361,6 +361,94 @@ def rpe_bias(qp, qe, emb, eq_emb, num_heads):
     return bias
 
 
+def _i64_array(values):
+    return (ctypes.c_int64 * len(values))(*[int(v) for v in values])
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def stack_bias_offsets(lengths, key_lengths, AH):
+    """Float offsets of the per-cloud (A*H, N_c, ceil32(M_c)) logits blocks in one workspace, and its total size."""
+    offs, total = [], 0
+    for n, m in zip(lengths, key_lengths):
+        offs.append(total)
+        total += AH * int(n) * key_stride(int(m))
+    return offs, total
+
+
+def rpe_bias_stack(qp, qe, embs, eq_embs, starts, lengths, num_heads):
+    """Stack mode of rpe_bias: qp ([A,] R, H*C) [qe ([A,] R, 4*H)] hold the folded queries of all clouds (cloud c = rows
+    starts[c] .. + lengths[c]); embs[c] (N_c, N_c, C), eq_embs[c] (A, N_c, N_c, 4) or None.  ONE launch; returns the flat
+    logits workspace and the per-cloud block offsets (block c: (A*H, N_c, ceil32(N_c)))."""
+    H = num_heads
+    C = embs[0].shape[-1]
+    qp3, A, R, rs, sa = _rows_view(qp, 'qp', H * C)
+    has_eq = qe is not None
+    qe_ptr = None
+    if has_eq:
+        qe3, Ae, Re, rs_e, sa_e = _rows_view(qe, 'qe', 4 * H)
+        if (Ae, Re, rs_e, sa_e) != (A, R, rs, sa):
+            raise RuntimeError('rpe_bias_stack: qe must be a column block of the same projection as qp')
+        qe_ptr = qe3.data_ptr()
+    if A * H > 32 or C % 16:
+        raise RuntimeError('rpe_bias_stack: anchors*heads must be <= 32 and C a multiple of 16')
+    embs = [_req(e, torch.float32, 'embed_qk', 3) for e in embs]
+    survey_bytes = 0
+    for c, (e, n) in enumerate(zip(embs, lengths)):
+        if tuple(e.shape) != (n, n, C) or starts[c] + n > R:
+            raise RuntimeError('rpe_bias_stack: cloud %d: embedding %s for %d rows at %d of %d' % (c, tuple(e.shape), n, starts[c], R))
+        survey_bytes += 4 * (4 * A * n * C + n * n * C + (A * n * n * 4 if has_eq else 0))
+    eqs = None
+    if has_eq:
+        eqs = [_req(e, torch.float32, 'embed_eq', 4) for e in eq_embs]
+        for e, n in zip(eqs, lengths):
+            if tuple(e.shape) != (A, n, n, 4):
+                raise RuntimeError('rpe_bias_stack: equivariant embedding shape %s' % (tuple(e.shape),))
+    offs, total = stack_bias_offsets(lengths, lengths, A * H)
+    bias = torch.empty((total,), dtype=torch.float32, device=qp3.device)
+    with _timed('rpe_bias_kernel', survey_bytes, 'eq' if has_eq else 'inv'):
+        check(lib().se3_rpe_bias_stack_fwd(qp3.data_ptr(), qe_ptr, rs, sa, _ptr_array(embs), _ptr_array(eqs) if has_eq else None,
+                                           _i64_array(starts), _i64_array(lengths), _i64_array(lengths), _i64_array(offs),
+                                           len(embs), C, A * H, H, bias.data_ptr(), _stream()), 'se3_rpe_bias_stack_fwd')
+    return bias, offs
+
+
+def attention_stack(q, k, vt, bias, bias_offsets, q_starts, q_lengths, k_starts, k_lengths, num_heads, out, tag=None):
+    """Stack mode of attention: q ([A,] R, C), k ([A,] R, C) packed rows, vt ([A,] C, Rk) transposed values addressed by key
+    column, out ([A,] R, C) with contiguous rows; cloud c: queries q_starts[c] .. + q_lengths[c], keys k_starts[c] .. +
+    k_lengths[c] (k_starts multiples of 4, ceil32(k_lengths[c]) columns readable).  bias: flat workspace of rpe_bias_stack or None."""
+    H = num_heads
+    q3, Aq, R, q_rs, q_sa = _rows_view(q, 'q')
+    C = q3.shape[-1]
+    k3, Ak, Rk, k_rs, k_sa = _rows_view(k, 'k', C)
+    v3 = vt if vt.dim() == 3 else vt.unsqueeze(0)
+    if not v3.is_cuda or v3.dtype != torch.float32 or v3.stride(-1) != 1 or v3.stride(-2) % 4 or v3.data_ptr() % 16:
+        v3 = v3.contiguous()
+    Av, v_rs = v3.shape[0], v3.stride(1)
+    if v3.shape[1] != C:
+        raise RuntimeError('attention_stack: transposed values %s do not match C=%d' % (tuple(v3.shape), C))
+    A = max(Aq, Ak, Av)
+    o3 = out if out.dim() == 3 else out.unsqueeze(0)
+    if o3.shape[0] != A or o3.shape[2] != C or o3.stride(-1) != 1 or o3.stride(-2) != C or o3.dtype != torch.float32:
+        raise RuntimeError('attention_stack: out must be (A, rows, C) float32 with contiguous rows')
+    for c in range(len(q_starts)):
+        if q_starts[c] + q_lengths[c] > min(R, o3.shape[1]) or k_starts[c] + k_lengths[c] > Rk or \
+                k_starts[c] + key_stride(k_lengths[c]) > v3.shape[2]:
+            raise RuntimeError('attention_stack: cloud %d exceeds the packed rows / value columns' % c)
+    if bias is not None and (not bias.is_cuda or bias.dtype != torch.float32 or not bias.is_contiguous()):
+        raise RuntimeError('attention_stack: bias must be a contiguous float32 GPU workspace')
+    with _timed('attention_kernel' if tag is None else 'attention_kernel@' + tag, 0):
+        check(lib().se3_attention_stack_fwd(q3.data_ptr(), k3.data_ptr(), v3.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                            _i64_array(q_starts), _i64_array(q_lengths), _i64_array(k_starts), _i64_array(k_lengths),
+                                            _i64_array(bias_offsets) if bias is not None else None, len(q_starts), A, C, H,
+                                            q_rs, k_rs, v_rs, q_sa if Aq > 1 else 0, k_sa if Ak > 1 else 0,
+                                            v3.stride(0) if Av > 1 else 0, o3.stride(0) if A > 1 else 0,
+                                            1.0 / math.sqrt(C // H), o3.data_ptr(), _stream()), 'se3_attention_stack_fwd')
+    return out
+
+
 def cross_attention(q, k, vt, num_heads):
     """HIP: plain cross attention; vt (C, Mp) or (A, C, Mp) transposed values (per-anchor values share the scores)."""
     out = attention(q, k, vt, None, num_heads)

@@ -168,6 +168,48 @@ def test_rpe_attention_matches_oracle(A, N, C, H, eq):
     assert_close(scores.cpu(), want_scores, 1e-4, 'rpe attention scores')
 
 
+@pytest.mark.parametrize('A,lengths,C,H,eq', [(6, (59, 53), 32, 4, True), (6, (382, 350), 256, 4, True), (1, (304, 382), 256, 4, False),
+                                              (6, (100,), 128, 4, True), (1, (33, 17, 64), 128, 4, False), (3, (17, 40), 64, 2, True),
+                                              (6, (40, 31, 65, 32), 64, 4, True)])
+def test_rpe_self_attention_stack_matches_oracle(A, lengths, C, H, eq):
+    """Stack mode (all clouds of a pair in ONE launch per kernel, se3_rpe_bias_stack_fwd + se3_attention_stack_fwd) against the
+    oracle run cloud by cloud; also pins the composed [q | k | W_p^T q | W_eq^T q] projection."""
+    from oracle import se3et_oracle as O
+    from se3et_amd import functional as SF
+    g = torch.Generator().manual_seed(11)
+    st = _attn_state(C, eq)
+    xs = [torch.randn((A, n, C) if A > 1 else (n, C), generator=g) for n in lengths]
+    embs = [torch.randn(n, n, C, generator=g) for n in lengths]
+    eqs = [torch.randn(A, n, n, 4, generator=g) if eq else None for n in lengths]
+    w_stack, b_stack, offs = SF.compose_self_attention_weights(st['l.proj_q.weight'], st['l.proj_q.bias'], st['l.proj_k.weight'],
+                                                               st['l.proj_k.bias'], st['l.proj_p.weight'],
+                                                               st['l.proj_eq.weight'] if eq else None, H)
+    packed, starts = SF.pack_rows([x.cuda() for x in xs])
+    got = SF.rpe_self_attention_packed(packed, starts, list(lengths), [e.cuda() for e in embs],
+                                       [e.cuda() if e is not None else None for e in eqs], w_stack.cuda(), b_stack.cuda(), offs,
+                                       st['l.proj_v.weight'].cuda(), st['l.proj_v.bias'].cuda(), H).cpu()
+    for x, emb, e, s0, n in zip(xs, embs, eqs, starts, lengths):
+        want, _ = O.rpe_attention(st, 'l.', x, x, emb, e, H)
+        assert_close(got[..., s0:s0 + n, :], want, 1e-4, 'stack-mode rpe attention, cloud at row %d' % s0)
+    pad = torch.ones(got.shape[-2], dtype=torch.bool)
+    for s0, n in zip(starts, lengths):
+        pad[s0:s0 + n] = False
+    assert float(got[..., pad, :].abs().max()) == 0.0 if pad.any() else True
+
+
+def test_stack_mode_rejects_bad_descriptors():
+    from se3et_amd import ops
+    q = torch.zeros(1, 64, 32, device='cuda')
+    vt = torch.zeros(1, 32, 64, device='cuda')
+    out = torch.zeros(1, 64, 32, device='cuda')
+    with pytest.raises(RuntimeError):          # more clouds than one launch takes
+        ops.attention_stack(q, q, vt, None, None, [0] * 5, [8] * 5, [0] * 5, [8] * 5, 4, out)
+    with pytest.raises(RuntimeError):          # cloud beyond the packed rows
+        ops.attention_stack(q, q, vt, None, None, [32], [40], [32], [40], 4, out)
+    with pytest.raises(RuntimeError):          # key columns must start at a multiple of 4
+        ops.attention_stack(q, q, vt, None, None, [0], [8], [2], [8], 4, out)
+
+
 def test_rpe_attention_matches_reference_fixture(golden_dir):
     from se3et_amd import functional as SF
     g = _golden(golden_dir)
