@@ -34,7 +34,8 @@ extern "C" {
 const char* se3_version(void);
 const char* se3_last_error(void);   /* text of the last failure on the calling thread */
 void se3_debug_set_bias_variant(int variant, int split);
-void se3_debug_set_attention_variant(int variant);         /* benchmark tuning hook of se3_attention_fwd; 0 = default */   /* benchmark tuning hook of se3_rpe_bias_fwd; (0, 0) = default */
+void se3_debug_set_attention_variant(int variant);
+void se3_debug_set_attention_profile(long long* stamps);    /* variant 9: device buffer, 32 clock64() stamps per wave */         /* benchmark tuning hook of se3_attention_fwd; 0 = default */   /* benchmark tuning hook of se3_rpe_bias_fwd; (0, 0) = default */
 
 /* ---- A2: stack-mode radius neighbour search ---------------------------------------------------------------
  * Replaces geotransformer.ext.radius_neighbors (geotransformer/extensions/pybind.cpp:6-11,

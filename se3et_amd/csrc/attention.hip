@@ -346,6 +346,129 @@ __device__ __forceinline__ void flash_tiles(FlashState<D>& st, const float* __re
   }
 }
 
+// Variant of flash_tiles for the attention kernel: the workgroup's 32-query tile sits in LDS (q_s[(2 u + half) * 32 + c32] =
+// float4 q[n0 + c32][8 u + 4 half ..], shared by the waves, conflict-free ds_read_b128); every operand of a key tile is requested
+// one phase or one tile ahead of its use, each into registers that have just been consumed (no second register set, no spills
+// at 3 workgroups = 12 waves per CU; a single scratch reload would cost a vmcnt(0) drain in the middle of the tile).
+#define SE3_STAMP(slot)                                                    \
+  if (PROF) {                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+    if (prof != nullptr && (threadIdx.x & 63) == 0) prof[slot] = clock64(); \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+  }
+template <int D, bool HAS_BIAS, bool PROF = false>
+__device__ __forceinline__ void flash_tiles_qlds(FlashState<D>& st, const float4* q_s, const float* __restrict__ k,
+                                                 const float* __restrict__ v, const float* __restrict__ bias, int n0, int N, int M,
+                                                 int k_rs, int v_rs, int Mp, float scale, int tile_begin, int tile_step,
+                                                 long long* prof = nullptr) {
+  constexpr int DT = FlashState<D>::DT, KU = FlashState<D>::KU;
+  const int lane = threadIdx.x & 63, half = lane >> 5, c32 = lane & 31;
+  const int nq = min(n0 + c32, N - 1);
+  const float* bias_row = HAS_BIAS ? bias + (size_t)nq * Mp : nullptr;
+  const int tiles = (M + 31) >> 5;
+  if (tile_begin >= tiles) return;
+  float4 kf[KU], b4[4];
+  {
+    const float* kr = k + (size_t)min((tile_begin << 5) + c32, M - 1) * k_rs + 4 * half;
+#pragma unroll
+    for (int u = 0; u < KU; u++) kf[u] = ld4(kr + 8 * u);
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+      b4[g] = HAS_BIAS ? ld4(bias_row + (tile_begin << 5) + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  int pslot = 2;
+  for (int tile = tile_begin; tile < tiles; tile += tile_step) {
+    const int m0 = tile << 5;
+    const int tn = min(tile + tile_step, tiles - 1);      // the last iteration re-requests its own tile: branch-free
+    float vv[DT * 16];
+    SE3_STAMP(pslot)
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; r++) s[r] = 0.f;
+    float4 qf = q_s[half * 32 + c32];
+#pragma unroll
+    for (int u = 0; u < KU; u++) {
+      // the LDS read of fragment u+1 is issued in front of the 4 dependent MFMAs of fragment u (in-order issue: behind
+      // them it would expose the LDS latency once per fragment)
+      float4 qn;
+      if (u + 1 < KU) qn = q_s[(2 * (u + 1) + half) * 32 + c32];
+#pragma unroll
+      for (int i = 0; i < 4; i++) s = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(kf[u], i), f4get(qf, i), s, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (u + 1 < KU) qf = qn;
+    }
+    // (1) V^T of this tile, (2) K fragment of the next tile -- straight into the registers the S MFMAs just read.  The
+    // compiler fences keep the requests here (values used in the next iteration are otherwise sunk to the loop latch, i.e.
+    // issued right in front of their first use).
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) {
+      const int dd = 32 * dt + c32;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {          // keys m0 + 8 g + 4 half .. +3 are contiguous in the transposed values
+        const float4 t = dd < D ? ld4(v + (size_t)dd * v_rs + m0 + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+        vv[dt * 16 + 4 * g + 0] = t.x;
+        vv[dt * 16 + 4 * g + 1] = t.y;
+        vv[dt * 16 + 4 * g + 2] = t.z;
+        vv[dt * 16 + 4 * g + 3] = t.w;
+      }
+    }
+    {
+      const float* kr = k + (size_t)min((tn << 5) + c32, M - 1) * k_rs + 4 * half;
+#pragma unroll
+      for (int u = 0; u < KU; u++) kf[u] = ld4(kr + 8 * u);
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // s[r] = S^T[key = (r&3) + 8 (r>>2) + 4 half][query = c32]
+    float mx = -INFINITY;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int key = m0 + 8 * g + 4 * half + j;
+        float val = (s[4 * g + j] + f4get(b4[g], j)) * scale;
+        val = key < M ? val : -INFINITY;
+        s[4 * g + j] = val;
+        mx = fmaxf(mx, val);
+      }
+    }
+    // (3) the logits of the next tile, into the registers just consumed.  They were written by the previous kernel on other
+    // XCDs and come from the memory side (about two S phases away): requested a full tile ahead, and last, because the
+    // VMEM counter is in-order -- the P.V phase below waits for V^T only.
+    __builtin_amdgcn_sched_barrier(0);
+    if (HAS_BIAS) {
+#pragma unroll
+      for (int g = 0; g < 4; g++) b4[g] = ld4(bias_row + (tn << 5) + 8 * g + 4 * half);
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    SE3_STAMP(pslot + 1)
+    const float m_new = fmaxf(st.m, mx);
+    const float alpha = __expf(st.m - m_new);        // st.m = -inf on the first tile -> 0
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      s[r] = __expf(s[r] - m_new);
+      ps += s[r];
+    }
+    ps += __shfl_xor(ps, 32);
+    st.l = st.l * alpha + ps;
+    st.m = m_new;
+    SE3_STAMP(pslot + 2)
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) st.o[dt][r] *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; r++) st.o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[dt * 16 + r], s[r], st.o[dt], 0, 0, 0);
+    }
+    SE3_STAMP(pslot + 3)
+    pslot += 4;
+  }
+}
+
 template <int D>
 __device__ __forceinline__ void flash_init(FlashState<D>& st) {
   st.m = -INFINITY;
@@ -394,6 +517,47 @@ __device__ __forceinline__ void flash_merge(FlashState<D>& st, float* sm, float*
   }
 }
 
+// Merge the states of the NW waves through LDS and write the normalised output tile; every wave reduces and stores its own
+// share of the output columns (groups of 4 consecutive channels), so the tail of the workgroup is NW-way parallel.
+template <int D, int NW>
+__device__ __forceinline__ void flash_merge_store(const FlashState<D>& st, float* sm, float* sl, float* so,
+                                                  float* __restrict__ out, int n0, int N, int C) {
+  constexpr int DT = FlashState<D>::DT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, c32 = lane & 31;
+  sm[wave * 64 + lane] = st.m;
+  sl[wave * 64 + lane] = st.l;
+#pragma unroll
+  for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) so[((wave * DT + dt) * 16 + r) * 64 + lane] = st.o[dt][r];
+  __syncthreads();
+  float mt = -INFINITY;
+#pragma unroll
+  for (int w = 0; w < NW; w++) mt = fmaxf(mt, sm[w * 64 + lane]);
+  float lt = 0.f;
+  float f[NW];
+#pragma unroll
+  for (int w = 0; w < NW; w++) {
+    f[w] = __expf(sm[w * 64 + lane] - mt);
+    lt += sl[w * 64 + lane] * f[w];
+  }
+  const float inv = 1.f / lt;
+  const int nq = n0 + c32;
+  for (int gi = wave; gi < DT * 4; gi += NW) {          // register group gi = 4 consecutive channels 32 dt + 8 g + 4 half ..
+    const int dt = gi >> 2, g = gi & 3;
+    const int dd = 32 * dt + 8 * g + 4 * half;
+    float val[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float acc = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; w++) acc += so[((w * DT + dt) * 16 + 4 * g + j) * 64 + lane] * f[w];
+      val[j] = acc * inv;
+    }
+    if (nq < N && dd < D) *reinterpret_cast<float4*>(out + (size_t)nq * C + dd) = make_float4(val[0], val[1], val[2], val[3]);
+  }
+}
+
 template <int D>
 __device__ __forceinline__ void flash_store(const FlashState<D>& st, float* __restrict__ out, int n0, int N, int C,
                                             float weight, bool accumulate) {
@@ -429,15 +593,17 @@ struct AttnArgs {
   float scale;
   int QT;                             // 32-query tiles of the largest cloud
   int G;                              // groups = clouds * anchors * heads
+  long long* prof;                    // profiling hook (attention variant 9): 32 stamps per wave, else null
 };
 
 // One workgroup per (cloud, anchor, head, 32-query tile); its NW waves split the key tiles and merge through LDS.
 // XCD-aware flat grid: workgroup i runs on XCD i % 8 (round-robin dispatch), so group g = (cloud, anchor, head) is pinned
 // to XCD g % 8 and the K / V^T of a group (re-read by all of its query tiles) stay in ONE L2.
-template <int D, int NW, int MINW, bool PREFETCH>
+template <int D, int NW, int MINW, int MODE>      // MODE 0: loads at the tile top; 1: full double buffering; 2: Q in LDS + K prefetch
 __global__ __launch_bounds__(64 * NW, MINW) void attention_kernel(AttnArgs p) {
   __shared__ float sm[64 * NW], sl[64 * NW];
   __shared__ float so[NW * FlashState<D>::DT * 16 * 64];
+  __shared__ float4 q_s[MODE >= 2 ? (D / 8) * 2 * 32 : 1];
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int gslot = j / p.QT, qt = j - gslot * p.QT;
   const int g = gslot * 8 + xcd;
@@ -452,12 +618,32 @@ __global__ __launch_bounds__(64 * NW, MINW) void attention_kernel(AttnArgs p) {
   FlashState<D> st;
   flash_init(st);
   const float* bias = p.bias ? p.bias + cl.bias_off + ((size_t)ah * cl.N) * cl.Mp : nullptr;
-  flash_tiles<D, PREFETCH>(st, p.q + a * p.q_sa + (size_t)cl.q_start * p.q_rs + h * D,
-                           p.k + a * p.k_sa + (size_t)cl.k_start * p.k_rs + h * D,
-                           p.v + a * p.v_sa + (size_t)h * D * p.v_rs + cl.k_start, bias, n0, cl.N, cl.M, p.q_rs, p.k_rs, p.v_rs,
-                           cl.Mp, p.scale, wave, NW);
-  flash_merge<D, NW>(st, sm, sl, so);
-  if (wave == 0) flash_store<D>(st, p.out + a * p.o_sa + (size_t)cl.q_start * p.C + h * D, n0, cl.N, p.C, 1.f, false);
+  const float* q = p.q + a * p.q_sa + (size_t)cl.q_start * p.q_rs + h * D;
+  const float* k = p.k + a * p.k_sa + (size_t)cl.k_start * p.k_rs + h * D;
+  const float* v = p.v + a * p.v_sa + (size_t)h * D * p.v_rs + cl.k_start;
+  long long* prof = nullptr;         // MODE 3 (profiling hook): 32 clock64() stamps per wave
+  if (MODE == 3 && p.prof != nullptr) {
+    prof = p.prof + ((size_t)blockIdx.x * NW + wave) * 32;
+    if ((threadIdx.x & 63) == 0) prof[0] = clock64();
+  }
+  if (MODE >= 2) {
+    for (int i = threadIdx.x; i < (D / 8) * 2 * 32; i += 64 * NW) {
+      const int c32 = i & 31, uh = i >> 5;
+      q_s[i] = ld4(q + (size_t)min(n0 + c32, cl.N - 1) * p.q_rs + 8 * (uh >> 1) + 4 * (uh & 1));
+    }
+    __syncthreads();
+    if (MODE == 3 && prof != nullptr && (threadIdx.x & 63) == 0) prof[1] = clock64();
+    if (p.bias != nullptr)
+      flash_tiles_qlds<D, true, MODE == 3>(st, q_s, k, v, bias, n0, cl.N, cl.M, p.k_rs, p.v_rs, cl.Mp, p.scale, wave, NW, prof);
+    else
+      flash_tiles_qlds<D, false, MODE == 3>(st, q_s, k, v, bias, n0, cl.N, cl.M, p.k_rs, p.v_rs, cl.Mp, p.scale, wave, NW, prof);
+    if (MODE == 3 && prof != nullptr && (threadIdx.x & 63) == 0) prof[29] = clock64();
+  } else {
+    flash_tiles<D, MODE == 1>(st, q, k, v, bias, n0, cl.N, cl.M, p.q_rs, p.k_rs, p.v_rs, cl.Mp, p.scale, wave, NW);
+  }
+  if (MODE == 3 && prof != nullptr && (threadIdx.x & 63) == 0) prof[30] = clock64();
+  flash_merge_store<D, NW>(st, sm, sl, so, p.out + a * p.o_sa + (size_t)cl.q_start * p.C + h * D, n0, cl.N, p.C);
+  if (MODE == 3 && prof != nullptr && (threadIdx.x & 63) == 0) prof[31] = clock64();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -613,7 +799,9 @@ int dispatch_head_dim(int D, F&& f, const char* what) {
 }  // namespace
 
 static int g_attn_variant = 0;
+static long long* g_attn_prof = nullptr;
 extern "C" void se3_debug_set_attention_variant(int variant) { g_attn_variant = variant; }
+extern "C" void se3_debug_set_attention_profile(long long* stamps) { g_attn_prof = stamps; }
 static int g_bias_variant = 0;
 static int g_bias_split = 0;
 // tuning hooks (benchmarks only): kernel variant / m-split override; 0 = default
@@ -732,11 +920,12 @@ static int launch_attention(AttnArgs& p, hipStream_t st) {
   dim3 grid((unsigned)(8 * ((p.G + 7) / 8) * qt));
   int rc = dispatch_head_dim(p.C / p.H, [&](auto d) {
     constexpr int D = decltype(d)::value;
-    switch (g_attn_variant) {      // tuning hook; default: loads at the top of each key tile, 3 workgroups (12 waves) per CU
-      case 1: attention_kernel<D, 4, 2, true><<<grid, 256, 0, st>>>(p); break;
-      case 2: attention_kernel<D, 6, 2, false><<<grid, 384, 0, st>>>(p); break;
-      case 3: attention_kernel<D, 2, 3, false><<<grid, 128, 0, st>>>(p); break;
-      default: attention_kernel<D, 4, 3, false><<<grid, 256, 0, st>>>(p); break;
+    switch (g_attn_variant) {      // tuning hook
+      case 1: attention_kernel<D, 4, 2, 1><<<grid, 256, 0, st>>>(p); break;
+      case 2: attention_kernel<D, 4, 3, 0><<<grid, 256, 0, st>>>(p); break;
+      case 3: attention_kernel<D, 6, 2, 2><<<grid, 384, 0, st>>>(p); break;
+      case 9: p.prof = g_attn_prof; attention_kernel<D, 4, 3, 3><<<grid, 256, 0, st>>>(p); break;
+      default: attention_kernel<D, 4, 3, 2><<<grid, 256, 0, st>>>(p); break;
     }
   }, "attention");
   if (rc != SE3_OK) return rc;

@@ -71,10 +71,10 @@ if __name__ == '__main__':
     torch.cuda.synchronize()
     shapes = [(6, (382, 350), True), (1, (382, 350), False), (6, (382,), True)]
     for A, lengths, eq in shapes:
-        for bv, sp, av in ((0, 0, 0), (2, 2, 1), (0, 8, 2), (0, 1, 3), (2, 0, 4), (0, 0, 5)):
+        for bv, sp, av in ((0, 0, 0), (2, 2, 1), (0, 8, 2), (0, 1, 3), (2, 0, 4)):
             run(A, lengths, eq, bv, sp, av, iters=1, check=True)
-    bias_cfgs = [(0, 0), (0, 2), (0, 4), (0, 6), (0, 9), (2, 2), (2, 4), (2, 3), (0, 5)]
-    attn_cfgs = [0, 1, 2, 3, 4, 5]
+    bias_cfgs = [(0, 0), (0, 2), (0, 6), (2, 2), (0, 3)]
+    attn_cfgs = [0, 1, 2, 3, 4]
     res = {}
     for rep in range(3):
         order = [(s, b) for s in range(len(shapes)) for b in range(len(bias_cfgs))]
