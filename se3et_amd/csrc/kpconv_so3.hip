@@ -26,17 +26,36 @@ struct ConvTables {
   int ridx[kA][kA];     // [a][r] -> t
 };
 
+// The slot tables of the SE3ET configuration (kanchor 6, 15 kernel points; se3et_amd/tables.py kernel_slot_table /
+// anchor_slot_table, pinned against the reference in tests/test_oracle_golden.py).  With them as compile-time constants the
+// 90 (k, r) slot accumulations per column are plain adds; tables passed at run time cost ~1500 select / compare instructions
+// per column (dynamic register indexing), 2.7x the neighbour loop itself.
+__device__ constexpr int kBuiltinKidx[kK][kA] = {{0, 1, 1, 1, 1, 2}, {1, 0, 1, 2, 1, 1}, {1, 1, 0, 1, 2, 1}, {1, 2, 1, 0, 1, 1},
+                                                 {1, 1, 2, 1, 0, 1}, {2, 1, 1, 1, 1, 0}, {3, 3, 3, 4, 4, 4}, {3, 4, 3, 3, 4, 4},
+                                                 {3, 4, 4, 3, 3, 4}, {3, 3, 4, 4, 3, 4}, {4, 3, 3, 4, 4, 3}, {4, 4, 3, 3, 4, 3},
+                                                 {4, 4, 4, 3, 3, 3}, {4, 3, 4, 4, 3, 3}, {5, 5, 5, 5, 5, 5}};
+__device__ constexpr int kBuiltinRidx[kA][kA] = {{0, 3, 3, 3, 3, 5}, {1, 0, 4, 5, 2, 1}, {2, 2, 0, 4, 5, 4},
+                                                 {3, 5, 2, 0, 4, 3}, {4, 4, 5, 2, 0, 2}, {5, 1, 1, 1, 1, 0}};
+
+template <bool BUILTIN>
 __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restrict__ q_pts, const float* __restrict__ s_pts,
                                                             const int64_t* __restrict__ idx, const float* __restrict__ x,
                                                             ConvTables T, float inv_sigma, int64_t P, int64_t Ns, int NN,
                                                             int Cin, float* __restrict__ G) {
   __shared__ float w[kMaxNN][kK + 1];
   __shared__ int64_t nb[kMaxNN];
+  __shared__ unsigned xrow[kMaxNN];      // element offset of the neighbour's feature row (clamped: invalid rows carry weight 0)
   const int64_t p = blockIdx.x;
+  const int cols = kA * Cin;
   const float qx = q_pts[3 * p], qy = q_pts[3 * p + 1], qz = q_pts[3 * p + 2];
-  for (int n = threadIdx.x; n < NN; n += blockDim.x) nb[n] = idx[p * NN + n];
+  const int NN8 = (NN + 7) & ~7;
+  for (int n = threadIdx.x; n < NN8; n += blockDim.x) {
+    const int64_t j = n < NN ? idx[p * NN + n] : -1;
+    nb[n] = j;
+    xrow[n] = (j >= 0 && j < Ns) ? (unsigned)j * (unsigned)cols : 0u;
+  }
   __syncthreads();
-  for (int e = threadIdx.x; e < NN * kK; e += blockDim.x) {
+  for (int e = threadIdx.x; e < NN8 * kK; e += blockDim.x) {
     const int n = e / kK, k = e - n * kK;
     const int64_t j = nb[n];
     float v = 0.f;
@@ -48,26 +67,39 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
     w[n][k] = v;
   }
   __syncthreads();
-  const int cols = kA * Cin;
   for (int col = threadIdx.x; col < cols; col += blockDim.x) {
     const int a = col / Cin, c = col - a * Cin;
     float f[kK];
 #pragma unroll
     for (int k = 0; k < kK; k++) f[k] = 0.f;
-    for (int n = 0; n < NN; n++) {
-      const int64_t j = nb[n];
-      if (j < 0 || j >= Ns) continue;
-      const float xv = x[j * cols + col];
+    // 8 gathered rows in flight per thread (the loop is otherwise one L2 round trip per neighbour); padded / shadow
+    // neighbours read row 0 with weight 0, so the body is branch-free
+    for (int n0 = 0; n0 < NN8; n0 += 8) {
+      float xv[8];
 #pragma unroll
-      for (int k = 0; k < kK; k++) f[k] = fmaf(w[n][k], xv, f[k]);
+      for (int u = 0; u < 8; u++) xv[u] = x[xrow[n0 + u] + (unsigned)col];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+#pragma unroll
+        for (int k = 0; k < kK; k++) f[k] = fmaf(w[n0 + u][k], xv[u], f[k]);
+      }
     }
     float* Gp = G + p * (int64_t)(kA * kS * kA) * Cin;
 #pragma unroll
     for (int r = 0; r < kA; r++) {
       float s[kS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      int t;
+      if (BUILTIN) {
 #pragma unroll
-      for (int k = 0; k < kK; k++) s[T.kidx[k][r]] += f[k];
-      const int t = T.ridx[a][r];
+        for (int k = 0; k < kK; k++) s[kBuiltinKidx[k][r]] += f[k];
+        t = 0;
+#pragma unroll
+        for (int aa = 0; aa < kA; aa++) t = a == aa ? kBuiltinRidx[aa][r] : t;
+      } else {
+#pragma unroll
+        for (int k = 0; k < kK; k++) s[T.kidx[k][r]] += f[k];
+        t = T.ridx[a][r];
+      }
 #pragma unroll
       for (int sl = 0; sl < kS; sl++) Gp[((int64_t)(r * kS + sl) * kA + t) * Cin + c] = s[sl];
     }
@@ -103,8 +135,17 @@ extern "C" int se3_kpconv_so3_gather(const float* q_pts, const float* s_pts, con
   if (num_queries == 0) return SE3_OK;
   const int cols = kA * in_channels;
   const int threads = cols >= 256 ? 256 : (cols >= 128 ? 128 : 64);
-  kpconv_gather_kernel<<<(unsigned)num_queries, threads, 0, (hipStream_t)stream>>>(
-      q_pts, s_pts, idx, x, T, 1.0f / sigma, num_queries, num_support, num_neighbors, in_channels, G);
+  bool builtin = true;
+  for (int k = 0; k < kK; k++)
+    for (int r = 0; r < kA; r++) builtin = builtin && T.kidx[k][r] == kBuiltinKidx[k][r];
+  for (int a = 0; a < kA; a++)
+    for (int r = 0; r < kA; r++) builtin = builtin && T.ridx[a][r] == kBuiltinRidx[a][r];
+  if (builtin)
+    kpconv_gather_kernel<true><<<(unsigned)num_queries, threads, 0, (hipStream_t)stream>>>(
+        q_pts, s_pts, idx, x, T, 1.0f / sigma, num_queries, num_support, num_neighbors, in_channels, G);
+  else
+    kpconv_gather_kernel<false><<<(unsigned)num_queries, threads, 0, (hipStream_t)stream>>>(
+        q_pts, s_pts, idx, x, T, 1.0f / sigma, num_queries, num_support, num_neighbors, in_channels, G);
   SE3_CHECK_LAUNCH("kpconv_so3_gather");
   return SE3_OK;
 }
