@@ -57,6 +57,65 @@ __global__ __launch_bounds__(kGNLanes* kGNRows) void gn_partial_kernel(const flo
   }
 }
 
+// Throughput version of the partial pass for power-of-two channel counts (16 .. 1024): float4 loads, Q = C / 4 channel quads
+// across the block and 256 / Q row lanes, 8 rows in flight per thread, tree merge over the row lanes.  The chunking is a
+// pure function of (rows, C), so the result does not depend on scheduling.
+__device__ __forceinline__ void wf_push(WF& w, float v) {
+  w.n += 1.f;
+  const float d = v - w.mean;
+  w.mean += d * __frcp_rn(w.n);
+  w.m2 += d * (v - w.mean);
+}
+
+__global__ __launch_bounds__(256) void gn_partial4_kernel(const float* __restrict__ x, int64_t rows, int C, int nchunks,
+                                                          float* __restrict__ part) {
+  __shared__ WF sh[256][4];
+  const int Q = C >> 2, RL = 256 / Q;
+  const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
+  const int64_t per = (rows + nchunks - 1) / nchunks;
+  const int64_t r0 = (int64_t)blockIdx.x * per, r1 = min(rows, r0 + per);
+  WF w[4] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+  const float4* xq = reinterpret_cast<const float4*>(x) + q;
+  int64_t r = r0 + rl;
+  for (; r + 7 * RL < r1; r += 8 * RL) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = xq[(r + u * RL) * Q];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      wf_push(w[0], v[u].x);
+      wf_push(w[1], v[u].y);
+      wf_push(w[2], v[u].z);
+      wf_push(w[3], v[u].w);
+    }
+  }
+  for (; r < r1; r += RL) {
+    const float4 v = xq[r * Q];
+    wf_push(w[0], v.x);
+    wf_push(w[1], v.y);
+    wf_push(w[2], v.z);
+    wf_push(w[3], v.w);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) sh[threadIdx.x][k] = w[k];
+  __syncthreads();
+  for (int s = RL >> 1; s > 0; s >>= 1) {
+    if (rl < s) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) sh[threadIdx.x][k] = wf_merge(sh[threadIdx.x][k], sh[threadIdx.x + s * Q][k]);
+    }
+    __syncthreads();
+  }
+  if (rl == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const WF o = sh[threadIdx.x][k];
+      float* p = part + ((int64_t)blockIdx.x * C + 4 * q + k) * 3;
+      p[0] = o.n; p[1] = o.mean; p[2] = o.m2;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, int C, int groups, int nchunks,
                                                           float eps, float* __restrict__ stats) {
   __shared__ WF sh[256];
@@ -217,10 +276,21 @@ inline unsigned grid_for(int64_t work, int tpb) {
 
 }  // namespace
 
+static bool gn_fast_path(int channels) { return channels >= 16 && channels <= 1024 && (channels & (channels - 1)) == 0; }
+
+// row chunks of the partial pass: a pure function of the problem size (the statistics must not depend on scheduling)
+static int64_t gn_chunks(int64_t rows, int channels) {
+  if (gn_fast_path(channels)) {
+    const int64_t row_lanes = 256 / (channels / 4);
+    int64_t n = rows / (8 * row_lanes) + 1;           // >= 8 rows per row lane
+    return n > 256 ? 256 : n;                         // one block per CU; more chunks only move time into the finalize pass
+  }
+  int64_t n = rows / 64 + 1;
+  return n > 256 ? 256 : n;
+}
+
 extern "C" size_t se3_group_norm_workspace_bytes(int64_t rows, int channels, int groups) {
-  int64_t nchunks = rows / 64 + 1;
-  if (nchunks > 256) nchunks = 256;
-  return (size_t)(nchunks * channels * 3 + 2 * groups) * sizeof(float) + 256;
+  return (size_t)(gn_chunks(rows, channels) * channels * 3 + 2 * groups) * sizeof(float) + 256;
 }
 
 extern "C" int se3_group_norm_fwd(const float* x, const float* residual, const float* weight, const float* bias,
@@ -231,13 +301,16 @@ extern "C" int se3_group_norm_fwd(const float* x, const float* residual, const f
               "group_norm: rows %lld channels %d groups %d", (long long)rows, channels, groups);
   SE3_REQUIRE(workspace_bytes >= se3_group_norm_workspace_bytes(rows, channels, groups), SE3_ERR_WORKSPACE,
               "group_norm: workspace too small");
-  int64_t nchunks = rows / 64 + 1;
-  if (nchunks > 256) nchunks = 256;
+  const int64_t nchunks = gn_chunks(rows, channels);
   float* part = (float*)workspace;
   float* stats = part + nchunks * channels * 3;
   hipStream_t st = (hipStream_t)stream;
-  dim3 g1((unsigned)nchunks, (unsigned)se3_cdiv(channels, kGNLanes));
-  gn_partial_kernel<<<g1, kGNLanes * kGNRows, 0, st>>>(x, rows, channels, (int)nchunks, part);
+  if (gn_fast_path(channels) && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    gn_partial4_kernel<<<(unsigned)nchunks, 256, 0, st>>>(x, rows, channels, (int)nchunks, part);
+  } else {
+    dim3 g1((unsigned)nchunks, (unsigned)se3_cdiv(channels, kGNLanes));
+    gn_partial_kernel<<<g1, kGNLanes * kGNRows, 0, st>>>(x, rows, channels, (int)nchunks, part);
+  }
   gn_finalize_kernel<<<groups, 256, 0, st>>>(part, channels, groups, (int)nchunks, eps, stats);
   const int64_t work = (channels % 4 == 0) ? rows * channels / 4 : rows * channels;
   gn_apply_kernel<<<grid_for(work, 256), 256, 0, st>>>(x, residual, weight, bias, stats, rows, channels, groups,
