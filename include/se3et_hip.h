@@ -33,9 +33,11 @@ extern "C" {
 /* Library / build identification. */
 const char* se3_version(void);
 const char* se3_last_error(void);   /* text of the last failure on the calling thread */
+/* Benchmark tuning / profiling hooks (process-global, defaults 0): kernel variant + workgroups per CU of the relative-position
+ * kernel; variant of the attention kernel; variant 9 of the attention kernel writes 32 clock64() stamps per wave to `stamps`. */
 void se3_debug_set_bias_variant(int variant, int split);
 void se3_debug_set_attention_variant(int variant);
-void se3_debug_set_attention_profile(long long* stamps);    /* variant 9: device buffer, 32 clock64() stamps per wave */         /* benchmark tuning hook of se3_attention_fwd; 0 = default */   /* benchmark tuning hook of se3_rpe_bias_fwd; (0, 0) = default */
+void se3_debug_set_attention_profile(long long* stamps);
 
 /* ---- A2: stack-mode radius neighbour search ---------------------------------------------------------------
  * Replaces geotransformer.ext.radius_neighbors (geotransformer/extensions/pybind.cpp:6-11,
@@ -155,6 +157,17 @@ int se3_attention_stack_fwd(const float* q, const float* k, const float* vt, con
                             const int64_t* bias_offsets, int num_clouds, int num_anchors, int C, int H, int q_row_stride,
                             int k_row_stride, int v_row_stride, int64_t q_anchor_stride, int64_t k_anchor_stride,
                             int64_t v_anchor_stride, int64_t out_anchor_stride, float scale, float* out, void* stream);
+
+/* The whole stack-mode RPE self-attention call (the reference's RPEMultiHeadAttention.forward up to the output projection,
+ * rpe_transformer.py:39-131, for all clouds of the pair): se3_rpe_bias_stack_fwd into `logits_workspace` followed by
+ * se3_attention_stack_fwd, launched back to back.  Queries and keys of cloud c are the packed rows starts[c] .. + lengths[c]
+ * (starts multiples of 4, ceil32(lengths[c]) value columns readable); logits_workspace holds
+ * sum_c A*H * lengths[c] * ceil32(lengths[c]) floats. */
+int se3_rpe_self_attention_stack_fwd(const float* q, const float* k, const float* vt, const float* qp, const float* qe,
+                                     int row_stride, int64_t anchor_stride, int v_row_stride, int64_t v_anchor_stride,
+                                     const float* const* emb_ptrs, const float* const* eq_ptrs, const int64_t* starts,
+                                     const int64_t* lengths, int num_clouds, int num_anchors, int C, int H,
+                                     float* logits_workspace, int64_t out_anchor_stride, float* out, void* stream);
 
 /* ---- D4/D5: anchor-equivariant cross attention (MultiHeadAttentionEQ, 'a_soft' / 'r_soft') ----------------------------
  * Replaces geotransformer/modules/transformer/vanilla_transformer.py:247-476,506-577,751-870.  q (A, N, C), k/v (A, M, C).

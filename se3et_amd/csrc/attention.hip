@@ -989,6 +989,29 @@ extern "C" int se3_attention_stack_fwd(const float* q, const float* k, const flo
   return launch_attention(p, (hipStream_t)stream);
 }
 
+extern "C" int se3_rpe_self_attention_stack_fwd(const float* q, const float* k, const float* vt, const float* qp,
+                                                const float* qe, int row_stride, int64_t anchor_stride, int v_row_stride,
+                                                int64_t v_anchor_stride, const float* const* emb_ptrs,
+                                                const float* const* eq_ptrs, const int64_t* starts, const int64_t* lengths,
+                                                int num_clouds, int num_anchors, int C, int H, float* logits_workspace,
+                                                int64_t out_anchor_stride, float* out, void* stream) {
+  SE3_REQUIRE(starts && lengths && logits_workspace, SE3_ERR_INVALID_ARG, "rpe_self_attention_stack: null pointer");
+  SE3_REQUIRE(num_clouds >= 1 && num_clouds <= kMaxClouds, SE3_ERR_UNSUPPORTED, "rpe_self_attention_stack: %d clouds (1..%d)",
+              num_clouds, kMaxClouds);
+  int64_t offsets[kMaxClouds];
+  int64_t total = 0;
+  for (int c = 0; c < num_clouds; c++) {
+    offsets[c] = total;
+    total += (int64_t)num_anchors * H * lengths[c] * (((lengths[c] + 31) / 32) * 32);
+  }
+  int rc = se3_rpe_bias_stack_fwd(qp, qe, row_stride, anchor_stride, emb_ptrs, eq_ptrs, starts, lengths, lengths, offsets,
+                                  num_clouds, C, num_anchors * H, H, logits_workspace, stream);
+  if (rc != SE3_OK) return rc;
+  return se3_attention_stack_fwd(q, k, vt, logits_workspace, starts, lengths, starts, lengths, offsets, num_clouds, num_anchors,
+                                 C, H, row_stride, row_stride, v_row_stride, anchor_stride, anchor_stride, v_anchor_stride,
+                                 out_anchor_stride, 1.0f / sqrtf((float)(C / H)), out, stream);
+}
+
 extern "C" int se3_cross_eq_stats(const float* q, const float* k, int A, int N, int M, int C, int H, float scale,
                                   float* partial, int* num_partials_per_pair, void* stream) {
   SE3_REQUIRE(q && k && partial && num_partials_per_pair, SE3_ERR_INVALID_ARG, "cross_eq_stats: null pointer");

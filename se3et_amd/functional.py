@@ -175,12 +175,7 @@ def rpe_self_attention_packed(x, starts, lengths, embs, eq_embs, w_stack, b_stac
     A_, R_ = x3.shape[0], x3.shape[1]
     vt = torch.baddbmm(b_v[None, :, None].expand(A_, C, R_), w_v[None].expand(A_, C, C), x3.transpose(1, 2))   # (A, C, R)
     hidden = torch.zeros_like(x3)
-    has_eq = eq_embs[0] is not None
-    qe = proj[..., offs['qe']:offs['qe'] + 4 * H] if has_eq else None
-    bias, bias_offs = _ops.rpe_bias_stack(proj[..., offs['qp']:offs['qp'] + H * C], qe, embs, eq_embs if has_eq else None,
-                                          starts, lengths, H)
-    _ops.attention_stack(proj[..., offs['q']:offs['q'] + C], proj[..., offs['k']:offs['k'] + C], vt, bias, bias_offs,
-                         starts, lengths, starts, lengths, H, hidden, tag='rpe')
+    _ops.rpe_self_attention_stack(proj, offs, vt, embs, eq_embs, starts, lengths, H, hidden)
     return hidden if x.dim() == 3 else hidden[0]
 
 

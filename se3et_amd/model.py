@@ -5,6 +5,8 @@ the SE3ET forward (experiments/se3ete.3dmatch/model.py:20-227) and the per-varia
 with load_state_dict(strict=True)."""
 from types import SimpleNamespace
 
+import threading
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -127,7 +129,8 @@ class SE3ET(nn.Module):
                                                      correspondence_limit=f.correspondence_limit,
                                                      num_refinement_steps=f.num_refinement_steps)
         self.optimal_transport = LearnableLogOptimalTransport(cfg.model.num_sinkhorn_iterations)
-        self._valid_host = None
+        self._tls = threading.local()       # per-thread pinned scratch (pairs may be processed by several host threads)
+        self.stage_hook = None              # optional callable invoked between backbone and transformer (pipelined drivers)
 
     @torch.no_grad()
     def forward(self, data_dict, with_registration=True):
@@ -144,15 +147,18 @@ class SE3ET(nn.Module):
         ref_knn_pts = SF.gather_rows_padded(ref_f, ref_knn)
         src_knn_pts = SF.gather_rows_padded(src_f, src_knn)
         # number of non-empty nodes, fetched asynchronously (read only after the transformer, when it has long arrived)
-        if self._valid_host is None:
-            self._valid_host = torch.empty(2, dtype=torch.int64).pin_memory()
-        self._valid_host.copy_(torch.stack((ref_nm.sum(), src_nm.sum())), non_blocking=True)
+        valid_host = getattr(self._tls, 'valid_host', None)
+        if valid_host is None:
+            valid_host = self._tls.valid_host = torch.empty(2, dtype=torch.int64).pin_memory()
+        valid_host.copy_(torch.stack((ref_nm.sum(), src_nm.sum())), non_blocking=True)
         valid_event = torch.cuda.Event()
         valid_event.record()
 
         feats_list = self.backbone(feats, data_dict)
         feats_c, feats_f = feats_list[-1], feats_list[0]
         out['feats_c'], out['feats_f'] = feats_c, feats_f
+        if self.stage_hook is not None:
+            self.stage_hook()
 
         r, s, _, _, _, _ = self.transformer(ref_c.unsqueeze(0), src_c.unsqueeze(0), feats_c[:n_c].unsqueeze(0),
                                             feats_c[n_c:].unsqueeze(0))
@@ -161,7 +167,7 @@ class SE3ET(nn.Module):
         out['ref_feats_f'], out['src_feats_f'] = feats_f[:n_f], feats_f[n_f:]
 
         valid_event.synchronize()
-        all_valid = self._valid_host.tolist() == [ref_c.shape[0], src_c.shape[0]]
+        all_valid = valid_host.tolist() == [ref_c.shape[0], src_c.shape[0]]
         ri, si, node_scores = self.coarse_matching(r, s, ref_nm, src_nm, all_valid=all_valid)
         out['ref_node_corr_indices'], out['src_node_corr_indices'], out['node_corr_scores'] = ri, si, node_scores
 

@@ -21,11 +21,11 @@ class _timed:
     def __enter__(self):
         if KERNEL_TIMINGS is not None:
             self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            self.e0.record(torch.cuda.current_stream())
+            self.e0.record()
 
     def __exit__(self, *exc):
         if KERNEL_TIMINGS is not None:
-            self.e1.record(torch.cuda.current_stream())
+            self.e1.record()
             KERNEL_TIMINGS.setdefault(self.name, []).append((self.e0, self.e1, self.nbytes))
             if self.kind is not None:
                 KERNEL_TIMINGS.setdefault(self.name + '/' + self.kind, []).append((self.e0, self.e1, self.nbytes))
@@ -34,7 +34,14 @@ class _timed:
         return False
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream (torch.cuda.current_stream() costs ~10 us of host time per call; the raw getter
+    well under 1 us -- with ~150 launches per pair that is 1.5 ms of the host's 10 ms)."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -220,7 +227,7 @@ def neighbor_max_pool(x, idx):
     return out
 
 
-_gn_workspace = {}       # per device; calls are ordered on the (single) launch stream
+_gn_workspace = {}       # (device, stream) -> partial-statistics workspace
 
 
 def group_norm_rows(x, weight, bias, groups, eps, leaky_slope, residual):
@@ -233,14 +240,16 @@ def group_norm_rows(x, weight, bias, groups, eps, leaky_slope, residual):
         if residual.shape != x.shape:
             raise RuntimeError('group_norm_rows: residual shape mismatch')
     ws_bytes = lib().se3_group_norm_workspace_bytes(rows, C, groups)
-    ws = _gn_workspace.get(x.device)
-    if ws is None or ws.numel() < ws_bytes:        # zero-initialised once; the kernel keeps its arrival counter at zero
-        ws = torch.zeros((max(ws_bytes, 1 << 20),), dtype=torch.uint8, device=x.device)
-        _gn_workspace[x.device] = ws
+    stream = _stream()
+    key = (x.device, stream.value)                 # one workspace per launch stream (calls on a stream are ordered)
+    ws = _gn_workspace.get(key)
+    if ws is None or ws.numel() < ws_bytes:
+        ws = torch.empty((max(ws_bytes, 1 << 20),), dtype=torch.uint8, device=x.device)
+        _gn_workspace[key] = ws
     out = torch.empty_like(x)
     check(lib().se3_group_norm_fwd(x.data_ptr(), residual.data_ptr() if residual is not None else None, weight.data_ptr(),
                                    bias.data_ptr(), rows, C, int(groups), float(eps), 1 if leaky_slope is not None else 0,
-                                   float(leaky_slope or 0.0), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+                                   float(leaky_slope or 0.0), out.data_ptr(), ws.data_ptr(), ws.numel(), stream),
           'se3_group_norm_fwd')
     return out
 
@@ -446,6 +455,52 @@ def attention_stack(q, k, vt, bias, bias_offsets, q_starts, q_lengths, k_starts,
                                             q_rs, k_rs, v_rs, q_sa if Aq > 1 else 0, k_sa if Ak > 1 else 0,
                                             v3.stride(0) if Av > 1 else 0, o3.stride(0) if A > 1 else 0,
                                             1.0 / math.sqrt(C // H), o3.data_ptr(), _stream()), 'se3_attention_stack_fwd')
+    return out
+
+
+def rpe_self_attention_stack(proj, offs, vt, embs, eq_embs, starts, lengths, num_heads, out):
+    """The stack-mode RPE self-attention call: proj ([A,] R, 2C + HC [+ 4H]) is the stacked projection [q | k | W_p^T q | W_eq^T q]
+    of the packed rows (column offsets `offs`), vt ([A,] C, R) the transposed values, embs[c] (N_c, N_c, C), eq_embs[c]
+    (A, N_c, N_c, 4) or None; out ([A,] R, C) receives the rows of every cloud.  Both kernels (relative-position logits, then
+    softmax.V) are launched back to back from one C call; timed as one unit when bench.py enables timing."""
+    H = num_heads
+    C = embs[0].shape[-1]
+    p3, A, R, rs, sa = _rows_view(proj, 'proj')
+    has_eq = eq_embs is not None and eq_embs[0] is not None
+    if offs['qp'] + H * C > p3.shape[-1] or (has_eq and offs['qe'] + 4 * H > p3.shape[-1]):
+        raise RuntimeError('rpe_self_attention_stack: projection narrower than its column offsets')
+    if A * H > 32 or C % 16:
+        raise RuntimeError('rpe_self_attention_stack: anchors*heads must be <= 32 and C a multiple of 16')
+    v3 = vt if vt.dim() == 3 else vt.unsqueeze(0)
+    if not v3.is_cuda or v3.dtype != torch.float32 or v3.stride(-1) != 1 or v3.stride(-2) % 4 or v3.data_ptr() % 16 or \
+            v3.shape[0] != A or v3.shape[1] != C:
+        raise RuntimeError('rpe_self_attention_stack: vt must be a float32 (A, C, rows) GPU tensor with 16-byte aligned rows')
+    o3 = out if out.dim() == 3 else out.unsqueeze(0)
+    if o3.shape[0] != A or o3.shape[2] != C or o3.stride(-1) != 1 or o3.stride(-2) != C or o3.dtype != torch.float32:
+        raise RuntimeError('rpe_self_attention_stack: out must be (A, rows, C) float32 with contiguous rows')
+    embs = [_req(e, torch.float32, 'embed_qk', 3) for e in embs]
+    survey_bytes, total = 0, 0
+    for c, (e, n) in enumerate(zip(embs, lengths)):
+        if tuple(e.shape) != (n, n, C) or starts[c] % 4 or starts[c] + n > min(R, o3.shape[1]) or \
+                starts[c] + key_stride(n) > v3.shape[2]:
+            raise RuntimeError('rpe_self_attention_stack: cloud %d: embedding %s, %d rows at %d of %d' % (c, tuple(e.shape), n, starts[c], R))
+        survey_bytes += 4 * (4 * A * n * C + n * n * C + (A * n * n * 4 if has_eq else 0))
+        total += A * H * n * key_stride(n)
+    eqs = None
+    if has_eq:
+        eqs = [_req(e, torch.float32, 'embed_eq', 4) for e in eq_embs]
+        for e, n in zip(eqs, lengths):
+            if tuple(e.shape) != (A, n, n, 4):
+                raise RuntimeError('rpe_self_attention_stack: equivariant embedding shape %s' % (tuple(e.shape),))
+    logits = torch.empty((total,), dtype=torch.float32, device=p3.device)
+    base = p3.data_ptr()
+    col = lambda name: base + 4 * offs[name]
+    with _timed('rpe_self_attention_call', survey_bytes, 'eq' if has_eq else 'inv'):
+        check(lib().se3_rpe_self_attention_stack_fwd(col('q'), col('k'), v3.data_ptr(), col('qp'), col('qe') if has_eq else None,
+                                                     rs, sa, v3.stride(1), v3.stride(0) if A > 1 else 0, _ptr_array(embs),
+                                                     _ptr_array(eqs) if has_eq else None, _i64_array(starts), _i64_array(lengths),
+                                                     len(embs), A, C, H, logits.data_ptr(), o3.stride(0) if A > 1 else 0,
+                                                     o3.data_ptr(), _stream()), 'se3_rpe_self_attention_stack_fwd')
     return out
 
 
