@@ -44,6 +44,7 @@ def main():
     args = ap.parse_args()
 
     from se3et_amd import ops as se3_ops
+    from se3et_amd import _lib as se3_lib
     from se3et_amd import sharding
     from se3et_amd.data import precompute_data_stack_mode
     from se3et_amd.model import create_model, load_synthetic_weights, make_cfg
@@ -108,6 +109,7 @@ def main():
     torch.cuda.synchronize()
     sharding.barrier(dev)
     se3_ops.KERNEL_TIMINGS = {}
+    se3_lib.lib().se3_debug_kernel_timing(1)        # every RPE attention launch gets its own HIP event pair
     t0 = time.perf_counter()
     run_all(list(range(args.warmup, total_steps)))
     torch.cuda.synchronize()
@@ -115,27 +117,46 @@ def main():
     elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
     timings, se3_ops.KERNEL_TIMINGS = se3_ops.KERNEL_TIMINGS, None
 
-    def agg(name):
-        recs = timings.get(name, [])
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
-        nbytes = sum(nb for _, _, nb in recs)
-        return len(recs), ms, nbytes
-
-    # one RPE self-attention call = rpe_bias_kernel (streams the embeddings) + attention_kernel (softmax.V), launched back to
-    # back by one C-ABI call for both clouds of the pair and bracketed by ONE HIP-event pair on the launch stream
-    n_call, ms_call, bytes_call = agg('rpe_self_attention_call')
-    achieved = bytes_call / (ms_call * 1e-3) / 1e9 if ms_call > 0 else 0.0
-    traffic = sum(PMC_TRAFFIC_RATIO[k] * agg('rpe_self_attention_call/' + k)[2] for k in PMC_TRAFFIC_RATIO) / max(n_call, 1)
+    # One RPE self-attention call = rpe_bias_kernel (streams the embeddings) + attention_kernel (softmax.V), launched back to
+    # back by one C-ABI call for both clouds of the pair.  Each launch carries its own start / stop HIP event pair on the
+    # launch stream (hipExtLaunchKernelGGL: the dispatch's begin / end timestamps); the call's time is the sum of the two.
+    import ctypes
+    calls = timings.get('rpe_self_attention_calls', [])
+    cap = 4 * len(calls) + 64 * args.steps
+    us = (ctypes.c_float * cap)()
+    tags = (ctypes.c_int * cap)()
+    se3_lib.lib().se3_debug_kernel_timing(0)
+    n_ev = se3_lib.lib().se3_debug_kernel_timing_collect(us, tags, cap)
+    per_call, i = [], 0
+    while i < n_ev:                                   # tag 1 (logits kernel) is always followed by its tag-2 attention launch
+        if tags[i] == 1 and i + 1 < n_ev and tags[i + 1] == 2:
+            per_call.append((us[i], us[i + 1]))
+            i += 2
+        else:
+            i += 1                                    # attention launches of the cross-attention layers
+    if len(per_call) != len(calls):
+        raise SystemExit('bench.py: %d timed RPE calls for %d recorded calls' % (len(per_call), len(calls)))
+    kinds = {'eq': [0, 0.0, 0.0, 0.0], 'inv': [0, 0.0, 0.0, 0.0]}      # count, bytes, bias us, attention us
+    for (nbytes, kind), (t_bias, t_attn) in zip(calls, per_call):
+        k = kinds[kind]
+        k[0] += 1; k[1] += nbytes; k[2] += t_bias; k[3] += t_attn
+    n_call = len(calls)
+    bytes_call = sum(k[1] for k in kinds.values())
+    us_call = sum(k[2] + k[3] for k in kinds.values())
+    achieved = bytes_call / (us_call * 1e-6) / 1e9 if us_call > 0 else 0.0
+    traffic = sum(PMC_TRAFFIC_RATIO[name] * k[1] for name, k in kinds.items()) / max(n_call, 1)
     roofline = {
         'kernel': 'RPE self-attention call = rpe_bias_kernel + attention_kernel (both clouds of a pair per launch)',
         'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': int(traffic),
         'traffic_source': 'bytes per call; PMC FETCH_SIZE(x2 on the streaming kernel)+WRITE_SIZE per algorithmic byte from '
                           'profiles/r01_pmc_attention.csv, applied to the calls of this run',
-        'launches': n_call, 'avg_us': round(ms_call * 1e3 / max(n_call, 1), 2),
+        'launches': n_call, 'avg_us': round(us_call / max(n_call, 1), 2),
         'algorithmic_bytes_per_launch': int(bytes_call / max(n_call, 1)),
-        'eq_call_avg_us': round(agg('rpe_self_attention_call/eq')[1] * 1e3 / max(agg('rpe_self_attention_call/eq')[0], 1), 2),
-        'inv_call_avg_us': round(agg('rpe_self_attention_call/inv')[1] * 1e3 / max(agg('rpe_self_attention_call/inv')[0], 1), 2),
+        'rpe_bias_kernel_avg_us': round(sum(k[2] for k in kinds.values()) / max(n_call, 1), 2),
+        'attention_kernel_avg_us': round(sum(k[3] for k in kinds.values()) / max(n_call, 1), 2),
+        'eq_call_avg_us': round((kinds['eq'][2] + kinds['eq'][3]) / max(kinds['eq'][0], 1), 2),
+        'inv_call_avg_us': round((kinds['inv'][2] + kinds['inv'][3]) / max(kinds['inv'][0], 1), 2),
     }
 
     cpu_baseline = None

@@ -38,6 +38,11 @@ const char* se3_last_error(void);   /* text of the last failure on the calling t
 void se3_debug_set_bias_variant(int variant, int split);
 void se3_debug_set_attention_variant(int variant);
 void se3_debug_set_attention_profile(long long* stamps);
+/* Per-launch timing of the two RPE self-attention kernels (bench.py): while enabled every launch carries its own start / stop
+ * HIP event pair (hipExtLaunchKernelGGL) on the launch stream; collect() waits for them, returns the count and fills the
+ * durations (us) and tags (1 = relative-position logits kernel, 2 = attention kernel) in launch order. */
+void se3_debug_kernel_timing(int enable);
+int se3_debug_kernel_timing_collect(float* microseconds, int* tags, int capacity);
 
 /* ---- A2: stack-mode radius neighbour search ---------------------------------------------------------------
  * Replaces geotransformer.ext.radius_neighbors (geotransformer/extensions/pybind.cpp:6-11,

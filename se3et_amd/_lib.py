@@ -17,6 +17,8 @@ SIGNATURES = {
     'se3_debug_set_bias_variant': (None, [_i32, _i32]),
     'se3_debug_set_attention_variant': (None, [_i32]),
     'se3_debug_set_attention_profile': (None, [_vp]),
+    'se3_debug_kernel_timing': (None, [_i32]),
+    'se3_debug_kernel_timing_collect': (_i32, [_vp, _vp, _i32]),
     'se3_radius_neighbors': (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _f32, _i32, _vp, _vp, _vp]),
     'se3_radius_grid_workspace_bytes': (_sz, [_i64, _i32]),
     'se3_radius_grid_build': (_i32, [_vp, _i64, _vp, _i32, _f32, _vp, _sz, _vp]),

@@ -16,7 +16,9 @@
 //                      sums per workgroup (deterministic two-stage reduction).
 //   cross_eq_apply     out[a] = sum_e W[a, e] softmax_m(S[a, e]) v_e (vanilla_transformer.py:812-818; r_soft collapsed from
 //                      24 rotations to the (A, A) anchor pairs, :506-577,839-845).
+#include <hip/hip_ext.h>
 #include <type_traits>
+#include <vector>
 #include "common.h"
 
 namespace {
@@ -798,6 +800,52 @@ int dispatch_head_dim(int D, F&& f, const char* what) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------------
+// per-launch kernel timing (bench.py): with timing enabled the two RPE self-attention kernels are launched through
+// hipExtLaunchKernelGGL with a start / stop HIP event pair each, recorded on the launch stream; the events carry the dispatch's
+// own begin / end timestamps (what rocprofv3 --kernel-trace reports), without the marker-packet and dispatch-gap overhead of
+// hipEventRecord brackets.
+// ---------------------------------------------------------------------------------------------------------------------
+struct TimedLaunch {
+  hipEvent_t start, stop;
+  int tag;              // 1 = rpe_bias_kernel, 2 = attention_kernel
+};
+static bool g_time_kernels = false;
+static std::vector<TimedLaunch> g_timed;
+
+template <typename K, typename... Args>
+static void launch_kernel(int tag, K kernel, dim3 grid, dim3 block, hipStream_t st, Args... args) {
+  if (g_time_kernels) {
+    TimedLaunch t{nullptr, nullptr, tag};
+    if (hipEventCreate(&t.start) == hipSuccess && hipEventCreate(&t.stop) == hipSuccess) {
+      hipExtLaunchKernelGGL(kernel, grid, block, 0, st, t.start, t.stop, 0, args...);
+      g_timed.push_back(t);
+      return;
+    }
+  }
+  hipLaunchKernelGGL(kernel, grid, block, 0, st, args...);
+}
+
+extern "C" void se3_debug_kernel_timing(int enable) { g_time_kernels = enable != 0; }
+
+// Waits for the recorded launches, writes their durations (microseconds) and tags in launch order, releases the events and
+// returns the number of launches recorded (entries beyond `capacity` are dropped).
+extern "C" int se3_debug_kernel_timing_collect(float* microseconds, int* tags, int capacity) {
+  int n = 0;
+  for (const TimedLaunch& t : g_timed) {
+    float ms = 0.f;
+    if (hipEventSynchronize(t.stop) == hipSuccess && hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess && n < capacity) {
+      microseconds[n] = ms * 1e3f;
+      tags[n] = t.tag;
+      n++;
+    }
+    (void)hipEventDestroy(t.start);
+    (void)hipEventDestroy(t.stop);
+  }
+  g_timed.clear();
+  return n;
+}
+
 static int g_attn_variant = 0;
 static long long* g_attn_prof = nullptr;
 extern "C" void se3_debug_set_attention_variant(int variant) { g_attn_variant = variant; }
@@ -841,13 +889,13 @@ static int launch_rpe_bias(const float* qp, const float* qe, int row_stride, int
 #define SE3_BIAS_ARGS qp, qe, row_stride, anchor_stride, S, AH, H, bias
 #define SE3_BIAS_LAUNCH_RT(CT, RT)                                                                                   \
   if (qe == nullptr) {                                                                                               \
-    if (g_bias_variant == 2) rpe_bias_kernel<CT, RT, 2, false, true><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS);           \
-    else rpe_bias_kernel<CT, RT, 3, false, true><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS);                               \
+    if (g_bias_variant == 2) launch_kernel(1, rpe_bias_kernel<CT, RT, 2, false, true>, grid, dim3(256), st, SE3_BIAS_ARGS);           \
+    else launch_kernel(1, rpe_bias_kernel<CT, RT, 3, false, true>, grid, dim3(256), st, SE3_BIAS_ARGS);                               \
   } else if (H % 4 == 0) {                                                                                           \
-    if (g_bias_variant == 2) rpe_bias_kernel<CT, RT, 2, true, true><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS);            \
-    else rpe_bias_kernel<CT, RT, 3, true, true><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS);                                \
+    if (g_bias_variant == 2) launch_kernel(1, rpe_bias_kernel<CT, RT, 2, true, true>, grid, dim3(256), st, SE3_BIAS_ARGS);            \
+    else launch_kernel(1, rpe_bias_kernel<CT, RT, 3, true, true>, grid, dim3(256), st, SE3_BIAS_ARGS);                                \
   } else {                                                                                                           \
-    rpe_bias_kernel<CT, RT, 2, true, false><<<grid, 256, 0, st>>>(SE3_BIAS_ARGS);                                    \
+    launch_kernel(1, rpe_bias_kernel<CT, RT, 2, true, false>, grid, dim3(256), st, SE3_BIAS_ARGS);                                    \
   }
 #define SE3_BIAS_LAUNCH(CT)                                                                                          \
   if (AH <= 16) {                                                                                                    \
@@ -921,11 +969,11 @@ static int launch_attention(AttnArgs& p, hipStream_t st) {
   int rc = dispatch_head_dim(p.C / p.H, [&](auto d) {
     constexpr int D = decltype(d)::value;
     switch (g_attn_variant) {      // tuning hook
-      case 1: attention_kernel<D, 4, 2, 1><<<grid, 256, 0, st>>>(p); break;
-      case 2: attention_kernel<D, 4, 3, 0><<<grid, 256, 0, st>>>(p); break;
-      case 3: attention_kernel<D, 6, 2, 2><<<grid, 384, 0, st>>>(p); break;
-      case 9: p.prof = g_attn_prof; attention_kernel<D, 4, 3, 3><<<grid, 256, 0, st>>>(p); break;
-      default: attention_kernel<D, 4, 3, 2><<<grid, 256, 0, st>>>(p); break;
+      case 1: launch_kernel(2, attention_kernel<D, 4, 2, 1>, grid, dim3(256), st, p); break;
+      case 2: launch_kernel(2, attention_kernel<D, 4, 3, 0>, grid, dim3(256), st, p); break;
+      case 3: launch_kernel(2, attention_kernel<D, 6, 2, 2>, grid, dim3(384), st, p); break;
+      case 9: p.prof = g_attn_prof; launch_kernel(2, attention_kernel<D, 4, 3, 3>, grid, dim3(256), st, p); break;
+      default: launch_kernel(2, attention_kernel<D, 4, 3, 2>, grid, dim3(256), st, p); break;
     }
   }, "attention");
   if (rc != SE3_OK) return rc;
