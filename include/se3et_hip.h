@@ -92,18 +92,22 @@ int se3_log_sinkhorn_fwd(const float* scores, const uint8_t* row_masks, const ui
  * Replaces GroupNormEPN (geotransformer/modules/e2pn/blocks_epn.py:684-701) and kpconv GroupNorm
  * (geotransformer/modules/kpconv/modules.py:34-51) plus the activation / shortcut add that follows them
  * (blocks_epn.py:660-664, 741-742, 838-852).  x (rows, channels): every leading dim (points, anchors) is a row; the
- * statistics of a group span all rows.  residual may be NULL.  out = act(norm(x) * weight + bias + residual). */
+ * statistics of a group span all rows.  residual may be NULL.  out = act(norm(x + x_bias) * weight + bias + residual);
+ * x_bias (channels, may be NULL) is the bias of the linear layer that produced x (the UnaryBlock mlp): folding it in here lets
+ * that GEMM run bias-free. */
 size_t se3_group_norm_workspace_bytes(int64_t rows, int channels, int groups);
-int se3_group_norm_fwd(const float* x, const float* residual, const float* weight, const float* bias, int64_t rows,
-                       int channels, int groups, float eps, int apply_leaky_relu, float slope, float* out,
+int se3_group_norm_fwd(const float* x, const float* x_bias, const float* residual, const float* weight, const float* bias,
+                       int64_t rows, int channels, int groups, float eps, int apply_leaky_relu, float slope, float* out,
                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- D6: LayerNorm(hidden + residual) ---------------------------------------------------------------------------
  * Replaces the residual + nn.LayerNorm tails of geotransformer/modules/transformer/rpe_transformer.py:163-164,
  * vanilla_transformer.py:910-911 and output_layer.py:21,46.  hidden (rows, channels); residual (residual_rows,
- * channels) is broadcast with row % residual_rows (anchor broadcast). */
-int se3_add_layer_norm_fwd(const float* hidden, const float* residual, const float* weight, const float* bias,
-                           int64_t rows, int64_t residual_rows, int channels, float eps, float* out, void* stream);
+ * channels) is broadcast with row % residual_rows (anchor broadcast).  hidden_bias (channels, may be NULL) is added to hidden
+ * first: the bias of the output / FFN linear that produced it. */
+int se3_add_layer_norm_fwd(const float* hidden, const float* hidden_bias, const float* residual, const float* weight,
+                           const float* bias, int64_t rows, int64_t residual_rows, int channels, float eps, float* out,
+                           void* stream);
 
 /* ---- B2/B3: padded row gather and neighbour max pooling ------------------------------------------------------------
  * Replace nearest_upsample (geotransformer/modules/kpconv/functional.py:6-22), the zero-padded patch gathers of

@@ -116,16 +116,21 @@ __global__ __launch_bounds__(256) void gn_partial4_kernel(const float* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, int C, int groups, int nchunks,
-                                                          float eps, float* __restrict__ stats) {
+// xb (may be null): per-channel constant added to x before the normalisation (the bias of the linear layer that produced x);
+// it shifts the per-channel partial means and leaves the M2 terms unchanged, so only this pass sees it.  Output: the affine
+// map of every channel, y = x * scale[c] + shift[c] with scale = rstd_g w[c], shift = b[c] + (xb[c] - mean_g) scale.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ xb,
+                                                          const float* __restrict__ gw, const float* __restrict__ gb, int C,
+                                                          int groups, int nchunks, float eps, float* __restrict__ affine) {
   __shared__ WF sh[256];
+  __shared__ float mean_s, rstd_s;
   const int g = blockIdx.x, cpg = C / groups;
   const int total = nchunks * cpg;
   WF w = {0.f, 0.f, 0.f};
   for (int i = threadIdx.x; i < total; i += 256) {
     const int chunk = i / cpg, c = g * cpg + (i - chunk * cpg);
     const float* p = part + ((int64_t)chunk * C + c) * 3;
-    WF o = {p[0], p[1], p[2]};
+    WF o = {p[0], p[1] + (xb ? xb[c] : 0.f), p[2]};
     w = wf_merge(w, o);
   }
   sh[threadIdx.x] = w;
@@ -136,16 +141,21 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   }
   if (threadIdx.x == 0) {
     const WF r = sh[0];
-    stats[2 * g] = r.mean;
-    stats[2 * g + 1] = 1.0f / sqrtf(r.m2 / r.n + eps);
+    mean_s = r.mean;
+    rstd_s = 1.0f / sqrtf(r.m2 / r.n + eps);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < cpg; i += 256) {
+    const int c = g * cpg + i;
+    const float scale = rstd_s * gw[c];
+    affine[c] = scale;
+    affine[C + c] = gb[c] + ((xb ? xb[c] : 0.f) - mean_s) * scale;
   }
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
-                                                       const float* __restrict__ w, const float* __restrict__ b,
-                                                       const float* __restrict__ stats, int64_t rows, int C, int groups,
-                                                       int has_slope, float slope, float* __restrict__ y) {
-  const int cpg = C / groups;
+                                                       const float* __restrict__ affine, int64_t rows, int C, int has_slope,
+                                                       float slope, float* __restrict__ y) {
   const int64_t total = rows * C;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   if ((C & 3) == 0) {
@@ -153,25 +163,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
       const int c0 = (int)((i << 2) % C);
       const float4 v = reinterpret_cast<const float4*>(x)[i];
-      float o[4] = {v.x, v.y, v.z, v.w};
-      float rr[4] = {0.f, 0.f, 0.f, 0.f};
+      const float4 sc = *reinterpret_cast<const float4*>(affine + c0), sf = *reinterpret_cast<const float4*>(affine + C + c0);
+      float4 o = make_float4(v.x * sc.x + sf.x, v.y * sc.y + sf.y, v.z * sc.z + sf.z, v.w * sc.w + sf.w);
       if (res) {
         const float4 t = reinterpret_cast<const float4*>(res)[i];
-        rr[0] = t.x; rr[1] = t.y; rr[2] = t.z; rr[3] = t.w;
+        o = make_float4(o.x + t.x, o.y + t.y, o.z + t.z, o.w + t.w);
       }
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int c = c0 + k, g = c / cpg;
-        float t = (o[k] - stats[2 * g]) * stats[2 * g + 1] * w[c] + b[c] + rr[k];
-        if (has_slope) t = t > 0.f ? t : t * slope;
-        o[k] = t;
+      if (has_slope) {
+        o.x = o.x > 0.f ? o.x : o.x * slope;
+        o.y = o.y > 0.f ? o.y : o.y * slope;
+        o.z = o.z > 0.f ? o.z : o.z * slope;
+        o.w = o.w > 0.f ? o.w : o.w * slope;
       }
-      reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+      reinterpret_cast<float4*>(y)[i] = o;
     }
   } else {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-      const int c = (int)(i % C), g = c / cpg;
-      float t = (x[i] - stats[2 * g]) * stats[2 * g + 1] * w[c] + b[c] + (res ? res[i] : 0.f);
+      const int c = (int)(i % C);
+      float t = x[i] * affine[c] + affine[C + c] + (res ? res[i] : 0.f);
       if (has_slope) t = t > 0.f ? t : t * slope;
       y[i] = t;
     }
@@ -182,9 +191,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 // LayerNorm(hidden + residual): one wavefront per row; residual row index = row % res_rows (broadcast over anchors)
 // ---------------------------------------------------------------------------------------------------------------------
 template <int VPL>   // float4 vectors per lane: C <= 256 * VPL
-__global__ __launch_bounds__(256) void add_ln_kernel(const float* __restrict__ h, const float* __restrict__ res,
-                                                     const float* __restrict__ w, const float* __restrict__ b, int64_t rows,
-                                                     int64_t res_rows, int C, float eps, float* __restrict__ y) {
+__global__ __launch_bounds__(256) void add_ln_kernel(const float* __restrict__ h, const float* __restrict__ hb,
+                                                     const float* __restrict__ res, const float* __restrict__ w,
+                                                     const float* __restrict__ b, int64_t rows, int64_t res_rows, int C,
+                                                     float eps, float* __restrict__ y) {
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -198,7 +208,8 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float* __restrict__ h
     const int i = lane + 64 * k;
     if (i < C4) {
       const float4 a = hp[i], r = rp[i];
-      v[k] = make_float4(a.x + r.x, a.y + r.y, a.z + r.z, a.w + r.w);
+      const float4 c = hb ? reinterpret_cast<const float4*>(hb)[i] : make_float4(0.f, 0.f, 0.f, 0.f);   // bias of the producing linear
+      v[k] = make_float4((a.x + c.x) + r.x, (a.y + c.y) + r.y, (a.z + c.z) + r.z, (a.w + c.w) + r.w);
       s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
     } else {
       v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -290,12 +301,13 @@ static int64_t gn_chunks(int64_t rows, int channels) {
 }
 
 extern "C" size_t se3_group_norm_workspace_bytes(int64_t rows, int channels, int groups) {
-  return (size_t)(gn_chunks(rows, channels) * channels * 3 + 2 * groups) * sizeof(float) + 256;
+  (void)groups;
+  return (size_t)(gn_chunks(rows, channels) * channels * 3 + 2 * channels) * sizeof(float) + 256;
 }
 
-extern "C" int se3_group_norm_fwd(const float* x, const float* residual, const float* weight, const float* bias,
-                                  int64_t rows, int channels, int groups, float eps, int apply_leaky_relu, float slope,
-                                  float* out, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int se3_group_norm_fwd(const float* x, const float* x_bias, const float* residual, const float* weight,
+                                  const float* bias, int64_t rows, int channels, int groups, float eps, int apply_leaky_relu,
+                                  float slope, float* out, void* workspace, size_t workspace_bytes, void* stream) {
   SE3_REQUIRE(x && weight && bias && out && workspace, SE3_ERR_INVALID_ARG, "group_norm: null pointer");
   SE3_REQUIRE(rows >= 1 && channels >= 1 && groups >= 1 && channels % groups == 0, SE3_ERR_INVALID_ARG,
               "group_norm: rows %lld channels %d groups %d", (long long)rows, channels, groups);
@@ -311,17 +323,16 @@ extern "C" int se3_group_norm_fwd(const float* x, const float* residual, const f
     dim3 g1((unsigned)nchunks, (unsigned)se3_cdiv(channels, kGNLanes));
     gn_partial_kernel<<<g1, kGNLanes * kGNRows, 0, st>>>(x, rows, channels, (int)nchunks, part);
   }
-  gn_finalize_kernel<<<groups, 256, 0, st>>>(part, channels, groups, (int)nchunks, eps, stats);
+  gn_finalize_kernel<<<groups, 256, 0, st>>>(part, x_bias, weight, bias, channels, groups, (int)nchunks, eps, stats);
   const int64_t work = (channels % 4 == 0) ? rows * channels / 4 : rows * channels;
-  gn_apply_kernel<<<grid_for(work, 256), 256, 0, st>>>(x, residual, weight, bias, stats, rows, channels, groups,
-                                                      apply_leaky_relu, slope, out);
+  gn_apply_kernel<<<grid_for(work, 256), 256, 0, st>>>(x, residual, stats, rows, channels, apply_leaky_relu, slope, out);
   SE3_CHECK_LAUNCH("group_norm");
   return SE3_OK;
 }
 
-extern "C" int se3_add_layer_norm_fwd(const float* hidden, const float* residual, const float* weight, const float* bias,
-                                      int64_t rows, int64_t residual_rows, int channels, float eps, float* out,
-                                      void* stream) {
+extern "C" int se3_add_layer_norm_fwd(const float* hidden, const float* hidden_bias, const float* residual,
+                                      const float* weight, const float* bias, int64_t rows, int64_t residual_rows,
+                                      int channels, float eps, float* out, void* stream) {
   SE3_REQUIRE(hidden && residual && weight && bias && out, SE3_ERR_INVALID_ARG, "add_layer_norm: null pointer");
   SE3_REQUIRE(channels % 4 == 0 && channels >= 4 && channels <= 2048, SE3_ERR_UNSUPPORTED,
               "add_layer_norm: channels %d (need a multiple of 4 up to 2048)", channels);
@@ -331,13 +342,13 @@ extern "C" int se3_add_layer_norm_fwd(const float* hidden, const float* residual
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)se3_cdiv(rows, 4);
   if (channels <= 256)
-    add_ln_kernel<1><<<grid, 256, 0, st>>>(hidden, residual, weight, bias, rows, residual_rows, channels, eps, out);
+    add_ln_kernel<1><<<grid, 256, 0, st>>>(hidden, hidden_bias, residual, weight, bias, rows, residual_rows, channels, eps, out);
   else if (channels <= 512)
-    add_ln_kernel<2><<<grid, 256, 0, st>>>(hidden, residual, weight, bias, rows, residual_rows, channels, eps, out);
+    add_ln_kernel<2><<<grid, 256, 0, st>>>(hidden, hidden_bias, residual, weight, bias, rows, residual_rows, channels, eps, out);
   else if (channels <= 1024)
-    add_ln_kernel<4><<<grid, 256, 0, st>>>(hidden, residual, weight, bias, rows, residual_rows, channels, eps, out);
+    add_ln_kernel<4><<<grid, 256, 0, st>>>(hidden, hidden_bias, residual, weight, bias, rows, residual_rows, channels, eps, out);
   else
-    add_ln_kernel<8><<<grid, 256, 0, st>>>(hidden, residual, weight, bias, rows, residual_rows, channels, eps, out);
+    add_ln_kernel<8><<<grid, 256, 0, st>>>(hidden, hidden_bias, residual, weight, bias, rows, residual_rows, channels, eps, out);
   SE3_CHECK_LAUNCH("add_layer_norm");
   return SE3_OK;
 }

@@ -23,8 +23,15 @@ def _hip(fn):
 # ---------------------------------------------------------------------------------------------------------------------
 # dense layers (library GEMMs) and small glue
 # ---------------------------------------------------------------------------------------------------------------------
+mm = _ops.mm
+
+
 def linear(x, weight, bias=None, relu=False):
-    """Library GEMM x W^T + b; with relu=True the activation rides in the GEMM epilogue (one launch)."""
+    """Library GEMM x W^T [+ b]; with relu=True the activation rides in the GEMM epilogue (one launch)."""
+    if bias is None and not relu:
+        if x.dim() == 2:
+            return mm(x, weight.t())
+        return mm(x.reshape(-1, x.shape[-1]), weight.t()).view(x.shape[:-1] + (weight.shape[0],))
     if relu and bias is not None and x.dim() >= 2:
         x2 = x.reshape(-1, x.shape[-1])
         return torch._addmm_activation(bias, x2, weight.t(), use_gelu=False).reshape(x.shape[:-1] + (weight.shape[0],))
@@ -52,9 +59,9 @@ def project_values_transposed(x, w_v, b_v):
     return torch.baddbmm(b_v[None, :, None].expand(A, C, Mp), w_v[None].expand(A, C, C), xp.transpose(1, 2))
 
 
-def add_layer_norm(hidden, residual, weight, bias, eps=1e-5):
-    """LayerNorm(hidden + residual) over the last dim (residual may broadcast over a leading anchor dim)."""
-    return _ops.add_layer_norm(hidden, residual, weight, bias, eps)
+def add_layer_norm(hidden, residual, weight, bias, eps=1e-5, hidden_bias=None):
+    """LayerNorm(hidden [+ hidden_bias] + residual) over the last dim (residual may broadcast over a leading anchor dim)."""
+    return _ops.add_layer_norm(hidden, residual, weight, bias, eps, hidden_bias)
 
 
 def anchor_max(x, dim=1):
@@ -78,10 +85,10 @@ def apply_transform(points, T):
 # ---------------------------------------------------------------------------------------------------------------------
 # B: backbone ops
 # ---------------------------------------------------------------------------------------------------------------------
-def group_norm_rows(x, weight, bias, groups, eps, leaky_slope=None, residual=None):
+def group_norm_rows(x, weight, bias, groups, eps, leaky_slope=None, residual=None, x_bias=None):
     """GroupNorm over (rows x channels-in-group) for x (..., C) with ALL leading dims pooled into the statistics
     (GroupNormEPN / kpconv GroupNorm), optionally `+ residual` then LeakyReLU, fused in one pass."""
-    return _ops.group_norm_rows(x, weight, bias, groups, eps, leaky_slope, residual)
+    return _ops.group_norm_rows(x, weight, bias, groups, eps, leaky_slope, residual, x_bias)
 
 
 def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, sigma):

@@ -71,9 +71,9 @@ class GroupNormEPN(nn.Module):
         self.num_groups, self.num_channels = num_groups, num_channels
         self.norm = nn.GroupNorm(num_groups, num_channels)      # parameter container (names: norm.weight / norm.bias)
 
-    def forward(self, x, leaky_slope=None, residual=None):
+    def forward(self, x, leaky_slope=None, residual=None, x_bias=None):
         return SF.group_norm_rows(x, self.norm.weight, self.norm.bias, self.num_groups, self.norm.eps, leaky_slope,
-                                  residual)
+                                  residual, x_bias)
 
 
 class UnaryBlockEPN(nn.Module):
@@ -85,10 +85,10 @@ class UnaryBlockEPN(nn.Module):
 
     def forward(self, x, batch=None, residual=None, final_slope=None):
         """`residual`/`final_slope` fuse the bottleneck tail lrelu(norm(mlp(x)) + shortcut) into the norm kernel."""
-        x = SF.linear(x, self.mlp.weight, self.mlp.bias)
+        x = SF.linear(x, self.mlp.weight)                    # the mlp bias is applied inside the GroupNorm kernels
         if residual is not None or final_slope is not None:
-            return self.norm(x, leaky_slope=final_slope, residual=residual)
-        return self.norm(x, leaky_slope=None if self.no_relu else 0.1)
+            return self.norm(x, leaky_slope=final_slope, residual=residual, x_bias=self.mlp.bias)
+        return self.norm(x, leaky_slope=None if self.no_relu else 0.1, x_bias=self.mlp.bias)
 
 
 class LastUnaryBlockEPN(nn.Module):

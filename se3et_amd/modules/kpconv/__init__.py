@@ -16,8 +16,8 @@ class GroupNorm(nn.Module):
         self.num_groups, self.num_channels = num_groups, num_channels
         self.norm = nn.GroupNorm(num_groups, num_channels)
 
-    def forward(self, x, leaky_slope=None):
-        return SF.group_norm_rows(x, self.norm.weight, self.norm.bias, self.num_groups, self.norm.eps, leaky_slope, None)
+    def forward(self, x, leaky_slope=None, x_bias=None):
+        return SF.group_norm_rows(x, self.norm.weight, self.norm.bias, self.num_groups, self.norm.eps, leaky_slope, None, x_bias)
 
 
 class UnaryBlock(nn.Module):
@@ -30,7 +30,7 @@ class UnaryBlock(nn.Module):
         self.has_relu = has_relu
 
     def forward(self, x):
-        return self.norm(SF.linear(x, self.mlp.weight, self.mlp.bias), leaky_slope=0.1 if self.has_relu else None)
+        return self.norm(SF.linear(x, self.mlp.weight), leaky_slope=0.1 if self.has_relu else None, x_bias=self.mlp.bias)
 
 
 class LastUnaryBlock(nn.Module):

@@ -61,9 +61,10 @@ class AttentionOutput(nn.Module):
         self.norm = nn.LayerNorm(d_model)
 
     def forward(self, input_states):
-        hidden = SF.linear(SF.linear(input_states, self.expand.weight, self.expand.bias, relu=True),
-                           self.squeeze.weight, self.squeeze.bias)
-        return SF.add_layer_norm(hidden, input_states, self.norm.weight, self.norm.bias, self.norm.eps)
+        # the squeeze bias is applied inside the add+LayerNorm kernel (bias-free GEMMs take the cheap library path)
+        hidden = SF.linear(SF.linear(input_states, self.expand.weight, self.expand.bias, relu=True), self.squeeze.weight)
+        return SF.add_layer_norm(hidden, input_states, self.norm.weight, self.norm.bias, self.norm.eps,
+                                 hidden_bias=self.squeeze.bias)
 
 
 class RotCompressOutput(nn.Module):
@@ -83,9 +84,8 @@ class RotCompressOutput(nn.Module):
         b, a, n, c = input_states.shape
         mx = SF.anchor_max(input_states, dim=1)
         flat = input_states.permute(0, 2, 1, 3).reshape(b, n, a * c)
-        hidden = SF.linear(SF.linear(flat, self.expand.weight, self.expand.bias, relu=True), self.squeeze.weight,
-                           self.squeeze.bias)
-        return SF.add_layer_norm(hidden, mx, self.norm.weight, self.norm.bias, self.norm.eps)
+        hidden = SF.linear(SF.linear(flat, self.expand.weight, self.expand.bias, relu=True), self.squeeze.weight)
+        return SF.add_layer_norm(hidden, mx, self.norm.weight, self.norm.bias, self.norm.eps, hidden_bias=self.squeeze.bias)
 
 
 class RPEMultiHeadAttention(nn.Module):
@@ -158,13 +158,14 @@ class RPEAttentionLayer(nn.Module):
         hidden, scores = self.attention(input_states, memory_states, memory_states, position_states,
                                         key_weights=memory_weights, key_masks=memory_masks,
                                         attention_factors=attention_factors, embed_eq=equiv_states)
-        hidden = SF.linear(hidden, self.linear.weight, self.linear.bias)
-        return SF.add_layer_norm(hidden, input_states, self.norm.weight, self.norm.bias, self.norm.eps), scores
+        hidden = SF.linear(hidden, self.linear.weight)
+        return SF.add_layer_norm(hidden, input_states, self.norm.weight, self.norm.bias, self.norm.eps,
+                                 hidden_bias=self.linear.bias), scores
 
     def forward_packed(self, x, starts, lengths, embs, eq_embs):
         hidden = self.attention.forward_packed(x, starts, lengths, embs, eq_embs)
-        hidden = SF.linear(hidden, self.linear.weight, self.linear.bias)
-        return SF.add_layer_norm(hidden, x, self.norm.weight, self.norm.bias, self.norm.eps)
+        hidden = SF.linear(hidden, self.linear.weight)
+        return SF.add_layer_norm(hidden, x, self.norm.weight, self.norm.bias, self.norm.eps, hidden_bias=self.linear.bias)
 
 
 class RPETransformerLayer(nn.Module):
@@ -287,10 +288,11 @@ class AttentionLayer(nn.Module):
         hidden, scores = self.attention(input_states, memory_states, value_states, key_weights=memory_weights,
                                         key_masks=memory_masks, attention_factors=attention_factors,
                                         attention_masks=attention_masks, gt_indices=gt_indices, gt_overlap=gt_overlap)
-        hidden = SF.linear(hidden, self.linear.weight, self.linear.bias)
+        hidden = SF.linear(hidden, self.linear.weight)
         if hidden.dim() == input_states.dim() + 1:           # (B, A, N, C) hidden on a (B, N, C) query: broadcast residual
             input_states = input_states.unsqueeze(1)
-        return SF.add_layer_norm(hidden, input_states, self.norm.weight, self.norm.bias, self.norm.eps), scores
+        return SF.add_layer_norm(hidden, input_states, self.norm.weight, self.norm.bias, self.norm.eps,
+                                 hidden_bias=self.linear.bias), scores
 
 
 class TransformerLayer(nn.Module):

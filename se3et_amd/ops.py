@@ -9,6 +9,27 @@ import torch
 from ._lib import check, lib
 
 
+# Library GEMM dispatch: through torch a GEMM with a bias epilogue goes to hipBLASLt (descriptor set-up + heuristic query,
+# ~19 us of host time per call), a plain mm to rocBLAS (~7 us) once rocBLAS is the preferred BLAS -- with ~130 GEMMs per pair
+# that is the largest host item.  Callers that can fold the bias into the kernel consuming the product (add+LayerNorm,
+# GroupNorm) therefore call linear(x, w) without bias.  Process-wide torch setting, set on import of this package.
+_HAS_BLAS_SWITCH = hasattr(torch.backends.cuda, 'preferred_blas_library')
+if _HAS_BLAS_SWITCH:
+    torch.backends.cuda.preferred_blas_library('cublas')          # 'cublas' = rocBLAS on ROCm
+_BIG_GEMM_FLOP = 2.0e9     # above this the hipBLASLt kernels win (KPConv GEMMs: up to 2.7x faster than rocBLAS's choice)
+
+
+def mm(a, b):
+    """a (M, K) @ b (K, N) through the cheaper-to-dispatch rocBLAS path, or hipBLASLt for the few large products."""
+    if _HAS_BLAS_SWITCH and 2.0 * a.shape[0] * a.shape[1] * b.shape[1] > _BIG_GEMM_FLOP:
+        torch.backends.cuda.preferred_blas_library('cublaslt')
+        try:
+            return torch.mm(a, b)
+        finally:
+            torch.backends.cuda.preferred_blas_library('cublas')
+    return torch.mm(a, b)
+
+
 # ---- optional per-kernel timing with HIP events on the launch stream (enabled by bench.py) -----------------------------
 TIMING_TAG = None             # optional tag (e.g. 'self') set by callers that want a separate bucket
 KERNEL_TIMINGS = None          # dict name -> list of (start_event, end_event, algorithmic_bytes) while enabled
@@ -187,8 +208,9 @@ def log_optimal_transport(scores, row_masks, col_masks, alpha, num_iterations, i
     return out
 
 
-def add_layer_norm(hidden, residual, weight, bias, eps):
-    """HIP (csrc/rowops.hip): LayerNorm(hidden + residual); residual may lack leading (anchor) dims of hidden."""
+def add_layer_norm(hidden, residual, weight, bias, eps, hidden_bias=None):
+    """HIP (csrc/rowops.hip): LayerNorm(hidden [+ hidden_bias] + residual); residual may lack leading (anchor) dims of hidden;
+    hidden_bias (C,) is the bias of the linear layer that produced hidden (its GEMM then runs bias-free)."""
     hidden = _req(hidden.contiguous(), torch.float32, 'hidden')
     C = hidden.shape[-1]
     if residual.shape != hidden.shape:
@@ -199,8 +221,9 @@ def add_layer_norm(hidden, residual, weight, bias, eps):
     residual = _req(residual.contiguous(), torch.float32, 'residual')
     rows, res_rows = hidden.numel() // C, residual.numel() // C
     out = torch.empty_like(hidden)
-    check(lib().se3_add_layer_norm_fwd(hidden.data_ptr(), residual.data_ptr(), weight.data_ptr(), bias.data_ptr(), rows,
-                                       res_rows, C, float(eps), out.data_ptr(), _stream()), 'se3_add_layer_norm_fwd')
+    check(lib().se3_add_layer_norm_fwd(hidden.data_ptr(), hidden_bias.data_ptr() if hidden_bias is not None else None,
+                                       residual.data_ptr(), weight.data_ptr(), bias.data_ptr(), rows, res_rows, C, float(eps),
+                                       out.data_ptr(), _stream()), 'se3_add_layer_norm_fwd')
     return out
 
 
@@ -230,8 +253,9 @@ def neighbor_max_pool(x, idx):
 _gn_workspace = {}       # (device, stream) -> partial-statistics workspace
 
 
-def group_norm_rows(x, weight, bias, groups, eps, leaky_slope, residual):
-    """HIP (csrc/rowops.hip): GroupNorm with statistics over all leading dims, fused residual add + LeakyReLU."""
+def group_norm_rows(x, weight, bias, groups, eps, leaky_slope, residual, x_bias=None):
+    """HIP (csrc/rowops.hip): GroupNorm of x [+ x_bias] with statistics over all leading dims, fused residual add + LeakyReLU;
+    x_bias (C,) is the bias of the linear layer that produced x (its GEMM then runs bias-free)."""
     x = _req(x.contiguous(), torch.float32, 'x')
     C = x.shape[-1]
     rows = x.numel() // C
@@ -247,7 +271,8 @@ def group_norm_rows(x, weight, bias, groups, eps, leaky_slope, residual):
         ws = torch.empty((max(ws_bytes, 1 << 20),), dtype=torch.uint8, device=x.device)
         _gn_workspace[key] = ws
     out = torch.empty_like(x)
-    check(lib().se3_group_norm_fwd(x.data_ptr(), residual.data_ptr() if residual is not None else None, weight.data_ptr(),
+    check(lib().se3_group_norm_fwd(x.data_ptr(), x_bias.data_ptr() if x_bias is not None else None,
+                                   residual.data_ptr() if residual is not None else None, weight.data_ptr(),
                                    bias.data_ptr(), rows, C, int(groups), float(eps), 1 if leaky_slope is not None else 0,
                                    float(leaky_slope or 0.0), out.data_ptr(), ws.data_ptr(), ws.numel(), stream),
           'se3_group_norm_fwd')
@@ -285,7 +310,7 @@ def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, s
     check(lib().se3_kpconv_so3_gather(q_pts.data_ptr(), s_pts.data_ptr(), idx.data_ptr(), x.data_ptr(), kp.data_ptr(),
                                       kt.data_ptr(), rt.data_ptr(), float(sigma), P, Ns, NN, Cin, G.data_ptr(), _stream()),
           'se3_kpconv_so3_gather')
-    return torch.mm(G, weights.reshape(36 * Cin, Cout)).view(P, 6, Cout)
+    return mm(G, weights.reshape(36 * Cin, Cout)).view(P, 6, Cout)
 
 
 def key_stride(M):

@@ -66,6 +66,11 @@ def test_group_norm_matches_oracle(rows, A, C, G):
     assert_close(got, want, 1e-5, 'group norm')
     got2 = SF.group_norm_rows(x.cuda(), w.cuda(), b.cuda(), G, 1e-5, 0.1, res.cuda()).cpu()
     assert_close(got2, torch.nn.functional.leaky_relu(want + res, 0.1), 1e-5, 'group norm + residual + lrelu')
+    # bias of the producing linear folded into the kernels: GN(x + xb) with x passed bias-free
+    xb = torch.randn(C, generator=g) * 3
+    want3 = (O.group_norm_epn(x + xb, w, b, G) if A > 1 else O.group_norm_flat(x + xb, w, b, G))
+    got3 = SF.group_norm_rows(x.cuda(), w.cuda(), b.cuda(), G, 1e-5, 0.1, res.cuda(), x_bias=xb.cuda()).cpu()
+    assert_close(got3, torch.nn.functional.leaky_relu(want3 + res, 0.1), 1e-5, 'group norm with folded input bias')
 
 
 @pytest.mark.parametrize('A,N,C', [(6, 382, 256), (1, 59, 32), (6, 53, 128), (1, 300, 1024)])
@@ -79,6 +84,10 @@ def test_add_layer_norm_matches_torch(A, N, C):
     want = torch.nn.functional.layer_norm(h + rr, (C,), w, b, 1e-5)
     got = SF.add_layer_norm(h.cuda(), rr.cuda(), w.cuda(), b.cuda(), 1e-5).cpu()
     assert_close(got, want, 1e-5, 'add+LN')
+    hb = torch.randn(C, generator=g) * 2
+    want2 = torch.nn.functional.layer_norm(h + hb + rr, (C,), w, b, 1e-5)
+    got2 = SF.add_layer_norm(h.cuda(), rr.cuda(), w.cuda(), b.cuda(), 1e-5, hidden_bias=hb.cuda()).cpu()
+    assert_close(got2, want2, 1e-5, 'add+LN with folded linear bias')
 
 
 def test_gather_and_max_pool_match_oracle():
