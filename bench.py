@@ -39,7 +39,9 @@ def main():
     ap.add_argument('--pair', default='c2_5k')
     ap.add_argument('--cpu-baseline-pairs', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--switch-interval', type=float, default=2e-4)
+    ap.add_argument('--switch-interval', type=float, default=1e-3)
+    ap.add_argument('--prefetch', type=int, default=0, help='build the pyramid of the next pair on a second host thread / HIP '
+                    'stream while the current pair runs through the model (the reference does this in DataLoader workers)')
     ap.add_argument('--inflight', type=int, default=1, help='pairs in flight per GPU: host threads, one HIP stream each')
     args = ap.parse_args()
 
@@ -84,9 +86,49 @@ def main():
                 step(i)
             stream.synchronize()
 
+    def run_prefetched(indices):
+        # the reference builds the pyramid in DataLoader workers while the model runs (geotransformer/utils/data.py collate);
+        # here a second host thread + HIP stream builds the pyramid of pair i+1 (sync-heavy, GPU-light) while the main
+        # thread / stream runs pair i through the model
+        import queue
+        q = queue.Queue(maxsize=2)
+        side = streams[-1]
+
+        def producer():
+            with torch.cuda.stream(side):
+                for i in indices:
+                    pts, lens = pairs[i]
+                    data = precompute_data_stack_mode(pts, lens, b.num_stages, b.init_voxel_size, b.init_radius,
+                                                      cfg.neighbor_limits)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    q.put((data, ev))
+            q.put(None)
+
+        th = threading.Thread(target=producer)
+        th.start()
+        main = torch.cuda.current_stream()
+        keep = []
+        while True:
+            item = q.get()
+            if item is None:
+                break
+            data, ev = item
+            main.wait_event(ev)
+            for key in ('points', 'neighbors', 'subsampling', 'upsampling'):
+                for t in data[key]:
+                    t.record_stream(main)          # allocated on the side stream, consumed on the main stream
+            data['features'] = feats
+            model(data)
+            keep = [data] + keep[:1]
+        th.join()
+
     def run_all(indices):
         P = max(1, args.inflight)
         if P == 1:
+            if args.prefetch:
+                run_prefetched(indices)
+                return
             for i in indices:
                 step(i)
             return
@@ -96,8 +138,8 @@ def main():
         for t in threads:
             t.join()
 
-    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.inflight))]
-    if args.inflight > 1:
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.inflight) + 1)]
+    if args.inflight > 1 or args.prefetch:
         sys.setswitchinterval(args.switch_interval)   # default 5 ms: a host thread would hold the interpreter for half a pair
     # untimed: clock ramp-up of a cold GPU (a fresh box idles at low clocks), then the W warm-up steps
     ramp = torch.randn(4096, 4096, device=dev)
@@ -173,7 +215,7 @@ def main():
             'config': {'workload': 'SE3ET-E forward (pyramid + backbone + transformer + matching + Sinkhorn + LGR) on '
                                    'synthetic %d+%d-point pairs, one pair per rank per step' % (n, n),
                        'variant': args.variant, 'pair_preset': args.pair, 'sharding': 'pairs round-robin over ranks, no collective',
-                       'pairs_in_flight_per_gpu': max(1, args.inflight)},
+                       'pairs_in_flight_per_gpu': max(1, args.inflight), 'pyramid_prefetch': bool(args.prefetch)},
             'roofline': roofline, 'cpu_baseline': cpu_baseline,
         }
         print(json.dumps(line), flush=True)
