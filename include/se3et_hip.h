@@ -100,6 +100,14 @@ int se3_group_norm_fwd(const float* x, const float* x_bias, const float* residua
                        int64_t rows, int channels, int groups, float eps, int apply_leaky_relu, float slope, float* out,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* Segmented form: segment_row_offsets_host (num_segments + 1 entries, HOST, first 0, last rows) cuts the rows into independent
+ * ranges with their own statistics -- one registration pair each when several pairs share a launch (the reference normalises
+ * per pair because it runs one pair per forward).  num_segments <= 16. */
+int se3_group_norm_segments_fwd(const float* x, const float* x_bias, const float* residual, const float* weight,
+                                const float* bias, int64_t rows, int channels, int groups,
+                                const int64_t* segment_row_offsets_host, int num_segments, float eps, int apply_leaky_relu,
+                                float slope, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- D6: LayerNorm(hidden + residual) ---------------------------------------------------------------------------
  * Replaces the residual + nn.LayerNorm tails of geotransformer/modules/transformer/rpe_transformer.py:163-164,
  * vanilla_transformer.py:910-911 and output_layer.py:21,46.  hidden (rows, channels); residual (residual_rows,

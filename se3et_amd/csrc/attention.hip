@@ -32,7 +32,7 @@ __device__ __forceinline__ float f4get(const float4& v, int i) { return i == 0 ?
 // ---------------------------------------------------------------------------------------------------------------------
 // stack mode: the clouds of a pair (ref, src) share one launch
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kMaxClouds = 4;
+constexpr int kMaxClouds = 16;
 struct StackCloud {
   const float* emb;     // (N, M, C) geometric embedding (bias kernel only)
   const float* eq;      // (A, N, M, 4) equivariant embedding or null
@@ -47,21 +47,19 @@ struct Stack {
   int total_units;
 };
 
+// idx is wave-uniform: the descriptor is read from the kernel-argument segment with scalar loads at a computed offset
 __device__ __forceinline__ StackCloud stack_pick(const Stack& S, int idx) {
-  StackCloud r = S.c[0];
-#pragma unroll
-  for (int i = 1; i < kMaxClouds; i++) {      // field-wise scalar selects (an indexed copy would go through scratch)
-    const bool hit = idx == i;
-    r.emb = hit ? S.c[i].emb : r.emb;
-    r.eq = hit ? S.c[i].eq : r.eq;
-    r.q_start = hit ? S.c[i].q_start : r.q_start;
-    r.k_start = hit ? S.c[i].k_start : r.k_start;
-    r.N = hit ? S.c[i].N : r.N;
-    r.M = hit ? S.c[i].M : r.M;
-    r.Mp = hit ? S.c[i].Mp : r.Mp;
-    r.unit_begin = hit ? S.c[i].unit_begin : r.unit_begin;
-    r.bias_off = hit ? S.c[i].bias_off : r.bias_off;
-  }
+  const StackCloud& c = S.c[idx];
+  StackCloud r;
+  r.emb = c.emb;
+  r.eq = c.eq;
+  r.q_start = c.q_start;
+  r.k_start = c.k_start;
+  r.N = c.N;
+  r.M = c.M;
+  r.Mp = c.Mp;
+  r.unit_begin = c.unit_begin;
+  r.bias_off = c.bias_off;
   return r;
 }
 
@@ -158,9 +156,8 @@ __global__ __launch_bounds__(256, MINW) void rpe_bias_kernel(const float* __rest
   const int f_end = (int)((long long)(blockIdx.x + 1) * S.total_units / gridDim.x);
   while (f < f_end) {
     int ci = 0;
-#pragma unroll
-    for (int i = 1; i < kMaxClouds; i++)
-      if (i < S.n && f >= S.c[i].unit_begin) ci = i;
+    for (int i = 1; i < S.n; i++)
+      if (f >= S.c[i].unit_begin) ci = i;
     const StackCloud cl = stack_pick(S, ci);
     const int units = cl.Mp >> 5;
     const int rel = f - cl.unit_begin;

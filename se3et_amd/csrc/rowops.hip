@@ -29,16 +29,56 @@ __device__ __forceinline__ WF wf_merge(WF a, WF b) {
   return r;
 }
 
+// Segments: independent row ranges of one stacked tensor, each with its own statistics (one registration pair each when
+// several pairs share a launch; the reference normalises per pair because it runs one pair per forward).
+constexpr int kGNMaxSegments = 16;
+struct SegTable {
+  int n;
+  long long row_begin[kGNMaxSegments + 1];
+  int chunk_begin[kGNMaxSegments + 1];
+};
+__device__ __forceinline__ int seg_of_chunk(const SegTable& T, int chunk) {
+  int s = 0;
+#pragma unroll
+  for (int i = 1; i < kGNMaxSegments; i++)
+    if (i < T.n && chunk >= T.chunk_begin[i]) s = i;
+  return s;
+}
+__device__ __forceinline__ int seg_of_row(const SegTable& T, long long row) {
+  int s = 0;
+#pragma unroll
+  for (int i = 1; i < kGNMaxSegments; i++)
+    if (i < T.n && row >= T.row_begin[i]) s = i;
+  return s;
+}
+// the rows [r0, r1) of global chunk `chunk`
+__device__ __forceinline__ void chunk_rows(const SegTable& T, int chunk, long long& r0, long long& r1) {
+  const int s = seg_of_chunk(T, chunk);
+  long long b0 = T.row_begin[0], b1 = T.row_begin[1];
+  int c0 = T.chunk_begin[0], c1 = T.chunk_begin[1];
+#pragma unroll
+  for (int i = 1; i < kGNMaxSegments; i++)
+    if (s == i) {
+      b0 = T.row_begin[i];
+      b1 = T.row_begin[i + 1];
+      c0 = T.chunk_begin[i];
+      c1 = T.chunk_begin[i + 1];
+    }
+  const long long per = (b1 - b0 + (c1 - c0) - 1) / (c1 - c0);
+  r0 = b0 + (long long)(chunk - c0) * per;
+  r1 = min(b1, r0 + per);
+}
+
 constexpr int kGNLanes = 64;   // channels per block
 constexpr int kGNRows = 4;     // row lanes per block
 
-__global__ __launch_bounds__(kGNLanes* kGNRows) void gn_partial_kernel(const float* __restrict__ x, int64_t rows, int C,
-                                                                       int nchunks, float* __restrict__ part) {
+__global__ __launch_bounds__(kGNLanes* kGNRows) void gn_partial_kernel(const float* __restrict__ x, SegTable T, int C,
+                                                                       float* __restrict__ part) {
   __shared__ WF sh[kGNRows][kGNLanes];
   const int cl = threadIdx.x & (kGNLanes - 1), rl = threadIdx.x / kGNLanes;
   const int c = blockIdx.y * kGNLanes + cl;
-  const int64_t per = (rows + nchunks - 1) / nchunks;
-  const int64_t r0 = (int64_t)blockIdx.x * per, r1 = min(rows, r0 + per);
+  long long r0, r1;
+  chunk_rows(T, blockIdx.x, r0, r1);
   WF w = {0.f, 0.f, 0.f};
   if (c < C)
     for (int64_t r = r0 + rl; r < r1; r += kGNRows) {
@@ -67,16 +107,16 @@ __device__ __forceinline__ void wf_push(WF& w, float v) {
   w.m2 += d * (v - w.mean);
 }
 
-__global__ __launch_bounds__(256) void gn_partial4_kernel(const float* __restrict__ x, int64_t rows, int C, int nchunks,
+__global__ __launch_bounds__(256) void gn_partial4_kernel(const float* __restrict__ x, SegTable T, int C,
                                                           float* __restrict__ part) {
   __shared__ WF sh[256][4];
   const int Q = C >> 2, RL = 256 / Q;
   const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
-  const int64_t per = (rows + nchunks - 1) / nchunks;
-  const int64_t r0 = (int64_t)blockIdx.x * per, r1 = min(rows, r0 + per);
+  long long r0, r1;
+  chunk_rows(T, blockIdx.x, r0, r1);
   WF w[4] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
   const float4* xq = reinterpret_cast<const float4*>(x) + q;
-  int64_t r = r0 + rl;
+  long long r = r0 + rl;
   for (; r + 7 * RL < r1; r += 8 * RL) {
     float4 v[8];
 #pragma unroll
@@ -121,14 +161,22 @@ __global__ __launch_bounds__(256) void gn_partial4_kernel(const float* __restric
 // map of every channel, y = x * scale[c] + shift[c] with scale = rstd_g w[c], shift = b[c] + (xb[c] - mean_g) scale.
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ xb,
                                                           const float* __restrict__ gw, const float* __restrict__ gb, int C,
-                                                          int groups, int nchunks, float eps, float* __restrict__ affine) {
+                                                          int groups, SegTable T, float eps, float* __restrict__ affine) {
   __shared__ WF sh[256];
   __shared__ float mean_s, rstd_s;
-  const int g = blockIdx.x, cpg = C / groups;
-  const int total = nchunks * cpg;
+  const int g = blockIdx.x, cpg = C / groups, seg = blockIdx.y;
+  int cb = T.chunk_begin[0], ce = T.chunk_begin[1];
+#pragma unroll
+  for (int i = 1; i < kGNMaxSegments; i++)
+    if (seg == i) {
+      cb = T.chunk_begin[i];
+      ce = T.chunk_begin[i + 1];
+    }
+  affine += (size_t)seg * 2 * C;
+  const int total = (ce - cb) * cpg;
   WF w = {0.f, 0.f, 0.f};
   for (int i = threadIdx.x; i < total; i += 256) {
-    const int chunk = i / cpg, c = g * cpg + (i - chunk * cpg);
+    const int chunk = cb + i / cpg, c = g * cpg + (i % cpg);
     const float* p = part + ((int64_t)chunk * C + c) * 3;
     WF o = {p[0], p[1] + (xb ? xb[c] : 0.f), p[2]};
     w = wf_merge(w, o);
@@ -154,14 +202,16 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
-                                                       const float* __restrict__ affine, int64_t rows, int C, int has_slope,
-                                                       float slope, float* __restrict__ y) {
+                                                       const float* __restrict__ affine_all, SegTable T, int64_t rows, int C,
+                                                       int has_slope, float slope, float* __restrict__ y) {
   const int64_t total = rows * C;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   if ((C & 3) == 0) {
     const int64_t total4 = total >> 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
-      const int c0 = (int)((i << 2) % C);
+      const int64_t row = (i << 2) / C;
+      const int c0 = (int)((i << 2) - row * C);
+      const float* affine = affine_all + (size_t)(T.n > 1 ? seg_of_row(T, row) : 0) * 2 * C;
       const float4 v = reinterpret_cast<const float4*>(x)[i];
       const float4 sc = *reinterpret_cast<const float4*>(affine + c0), sf = *reinterpret_cast<const float4*>(affine + C + c0);
       float4 o = make_float4(v.x * sc.x + sf.x, v.y * sc.y + sf.y, v.z * sc.z + sf.z, v.w * sc.w + sf.w);
@@ -179,7 +229,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     }
   } else {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-      const int c = (int)(i % C);
+      const int64_t row = i / C;
+      const int c = (int)(i - row * C);
+      const float* affine = affine_all + (size_t)(T.n > 1 ? seg_of_row(T, row) : 0) * 2 * C;
       float t = x[i] * affine[c] + affine[C + c] + (res ? res[i] : 0.f);
       if (has_slope) t = t > 0.f ? t : t * slope;
       y[i] = t;
@@ -290,44 +342,74 @@ inline unsigned grid_for(int64_t work, int tpb) {
 static bool gn_fast_path(int channels) { return channels >= 16 && channels <= 1024 && (channels & (channels - 1)) == 0; }
 
 // row chunks of the partial pass: a pure function of the problem size (the statistics must not depend on scheduling)
-static int64_t gn_chunks(int64_t rows, int channels) {
+static int64_t gn_chunks(int64_t rows, int channels, int cap) {
+  int64_t n;
   if (gn_fast_path(channels)) {
     const int64_t row_lanes = 256 / (channels / 4);
-    int64_t n = rows / (8 * row_lanes) + 1;           // >= 8 rows per row lane
-    return n > 256 ? 256 : n;                         // one block per CU; more chunks only move time into the finalize pass
+    n = rows / (8 * row_lanes) + 1;           // >= 8 rows per row lane
+  } else {
+    n = rows / 64 + 1;
   }
-  int64_t n = rows / 64 + 1;
-  return n > 256 ? 256 : n;
+  return n > cap ? cap : n;                  // ~one block per CU in total; more chunks only move time into the finalize pass
 }
 
 extern "C" size_t se3_group_norm_workspace_bytes(int64_t rows, int channels, int groups) {
-  (void)groups;
-  return (size_t)(gn_chunks(rows, channels) * channels * 3 + 2 * channels) * sizeof(float) + 256;
+  (void)rows;
+  (void)groups;   // upper bound over any segmentation: <= 256 + 16 chunk partials, 16 affine tables
+  return (size_t)((256 + kGNMaxSegments) * channels * 3 + kGNMaxSegments * 2 * channels) * sizeof(float) + 256;
+}
+
+extern "C" int se3_group_norm_segments_fwd(const float* x, const float* x_bias, const float* residual, const float* weight,
+                                           const float* bias, int64_t rows, int channels, int groups,
+                                           const int64_t* segment_row_offsets_host, int num_segments, float eps,
+                                           int apply_leaky_relu, float slope, float* out, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+  SE3_REQUIRE(x && weight && bias && out && workspace, SE3_ERR_INVALID_ARG, "group_norm: null pointer");
+  SE3_REQUIRE(rows >= 1 && channels >= 1 && groups >= 1 && channels % groups == 0, SE3_ERR_INVALID_ARG,
+              "group_norm: rows %lld channels %d groups %d", (long long)rows, channels, groups);
+  SE3_REQUIRE(num_segments >= 1 && num_segments <= kGNMaxSegments && (num_segments == 1 || segment_row_offsets_host),
+              SE3_ERR_UNSUPPORTED, "group_norm: %d segments (1..%d)", num_segments, kGNMaxSegments);
+  SE3_REQUIRE(workspace_bytes >= se3_group_norm_workspace_bytes(rows, channels, groups), SE3_ERR_WORKSPACE,
+              "group_norm: workspace too small");
+  SegTable T{};
+  T.n = num_segments;
+  const int cap = 256 / num_segments > 8 ? 256 / num_segments : 8;
+  int chunks = 0;
+  for (int sgm = 0; sgm < num_segments; sgm++) {
+    const int64_t b0 = num_segments == 1 ? 0 : segment_row_offsets_host[sgm];
+    const int64_t b1 = num_segments == 1 ? rows : segment_row_offsets_host[sgm + 1];
+    SE3_REQUIRE(b1 > b0 && b0 >= 0 && b1 <= rows, SE3_ERR_INVALID_ARG, "group_norm: segment %d rows [%lld, %lld)", sgm,
+                (long long)b0, (long long)b1);
+    T.row_begin[sgm] = b0;
+    T.row_begin[sgm + 1] = b1;
+    T.chunk_begin[sgm] = chunks;
+    chunks += (int)gn_chunks(b1 - b0, channels, cap);
+    T.chunk_begin[sgm + 1] = chunks;
+  }
+  SE3_REQUIRE(T.row_begin[0] == 0 && T.row_begin[num_segments] == rows, SE3_ERR_INVALID_ARG,
+              "group_norm: the segments must cover all rows");
+  float* part = (float*)workspace;
+  float* affine = part + (size_t)(256 + kGNMaxSegments) * channels * 3;
+  hipStream_t st = (hipStream_t)stream;
+  if (gn_fast_path(channels) && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    gn_partial4_kernel<<<(unsigned)chunks, 256, 0, st>>>(x, T, channels, part);
+  } else {
+    dim3 g1((unsigned)chunks, (unsigned)se3_cdiv(channels, kGNLanes));
+    gn_partial_kernel<<<g1, kGNLanes * kGNRows, 0, st>>>(x, T, channels, part);
+  }
+  gn_finalize_kernel<<<dim3((unsigned)groups, (unsigned)num_segments), 256, 0, st>>>(part, x_bias, weight, bias, channels,
+                                                                                      groups, T, eps, affine);
+  const int64_t work = (channels % 4 == 0) ? rows * channels / 4 : rows * channels;
+  gn_apply_kernel<<<grid_for(work, 256), 256, 0, st>>>(x, residual, affine, T, rows, channels, apply_leaky_relu, slope, out);
+  SE3_CHECK_LAUNCH("group_norm");
+  return SE3_OK;
 }
 
 extern "C" int se3_group_norm_fwd(const float* x, const float* x_bias, const float* residual, const float* weight,
                                   const float* bias, int64_t rows, int channels, int groups, float eps, int apply_leaky_relu,
                                   float slope, float* out, void* workspace, size_t workspace_bytes, void* stream) {
-  SE3_REQUIRE(x && weight && bias && out && workspace, SE3_ERR_INVALID_ARG, "group_norm: null pointer");
-  SE3_REQUIRE(rows >= 1 && channels >= 1 && groups >= 1 && channels % groups == 0, SE3_ERR_INVALID_ARG,
-              "group_norm: rows %lld channels %d groups %d", (long long)rows, channels, groups);
-  SE3_REQUIRE(workspace_bytes >= se3_group_norm_workspace_bytes(rows, channels, groups), SE3_ERR_WORKSPACE,
-              "group_norm: workspace too small");
-  const int64_t nchunks = gn_chunks(rows, channels);
-  float* part = (float*)workspace;
-  float* stats = part + nchunks * channels * 3;
-  hipStream_t st = (hipStream_t)stream;
-  if (gn_fast_path(channels) && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
-    gn_partial4_kernel<<<(unsigned)nchunks, 256, 0, st>>>(x, rows, channels, (int)nchunks, part);
-  } else {
-    dim3 g1((unsigned)nchunks, (unsigned)se3_cdiv(channels, kGNLanes));
-    gn_partial_kernel<<<g1, kGNLanes * kGNRows, 0, st>>>(x, rows, channels, (int)nchunks, part);
-  }
-  gn_finalize_kernel<<<groups, 256, 0, st>>>(part, x_bias, weight, bias, channels, groups, (int)nchunks, eps, stats);
-  const int64_t work = (channels % 4 == 0) ? rows * channels / 4 : rows * channels;
-  gn_apply_kernel<<<grid_for(work, 256), 256, 0, st>>>(x, residual, stats, rows, channels, apply_leaky_relu, slope, out);
-  SE3_CHECK_LAUNCH("group_norm");
-  return SE3_OK;
+  return se3_group_norm_segments_fwd(x, x_bias, residual, weight, bias, rows, channels, groups, nullptr, 1, eps,
+                                     apply_leaky_relu, slope, out, workspace, workspace_bytes, stream);
 }
 
 extern "C" int se3_add_layer_norm_fwd(const float* hidden, const float* hidden_bias, const float* residual,

@@ -85,10 +85,10 @@ def apply_transform(points, T):
 # ---------------------------------------------------------------------------------------------------------------------
 # B: backbone ops
 # ---------------------------------------------------------------------------------------------------------------------
-def group_norm_rows(x, weight, bias, groups, eps, leaky_slope=None, residual=None, x_bias=None):
+def group_norm_rows(x, weight, bias, groups, eps, leaky_slope=None, residual=None, x_bias=None, segments=None):
     """GroupNorm over (rows x channels-in-group) for x (..., C) with ALL leading dims pooled into the statistics
     (GroupNormEPN / kpconv GroupNorm), optionally `+ residual` then LeakyReLU, fused in one pass."""
-    return _ops.group_norm_rows(x, weight, bias, groups, eps, leaky_slope, residual, x_bias)
+    return _ops.group_norm_rows(x, weight, bias, groups, eps, leaky_slope, residual, x_bias, segments)
 
 
 def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, sigma):

@@ -253,9 +253,10 @@ def neighbor_max_pool(x, idx):
 _gn_workspace = {}       # (device, stream) -> partial-statistics workspace
 
 
-def group_norm_rows(x, weight, bias, groups, eps, leaky_slope, residual, x_bias=None):
+def group_norm_rows(x, weight, bias, groups, eps, leaky_slope, residual, x_bias=None, segments=None):
     """HIP (csrc/rowops.hip): GroupNorm of x [+ x_bias] with statistics over all leading dims, fused residual add + LeakyReLU;
-    x_bias (C,) is the bias of the linear layer that produced x (its GEMM then runs bias-free)."""
+    x_bias (C,) is the bias of the linear layer that produced x (its GEMM then runs bias-free).  segments: optional row
+    offsets (S + 1 host ints, rows = all leading dims flattened) of independently normalised row ranges (one per pair)."""
     x = _req(x.contiguous(), torch.float32, 'x')
     C = x.shape[-1]
     rows = x.numel() // C
@@ -268,14 +269,15 @@ def group_norm_rows(x, weight, bias, groups, eps, leaky_slope, residual, x_bias=
     key = (x.device, stream.value)                 # one workspace per launch stream (calls on a stream are ordered)
     ws = _gn_workspace.get(key)
     if ws is None or ws.numel() < ws_bytes:
-        ws = torch.empty((max(ws_bytes, 1 << 20),), dtype=torch.uint8, device=x.device)
+        ws = torch.empty((max(ws_bytes, 1 << 22),), dtype=torch.uint8, device=x.device)
         _gn_workspace[key] = ws
     out = torch.empty_like(x)
-    check(lib().se3_group_norm_fwd(x.data_ptr(), x_bias.data_ptr() if x_bias is not None else None,
-                                   residual.data_ptr() if residual is not None else None, weight.data_ptr(),
-                                   bias.data_ptr(), rows, C, int(groups), float(eps), 1 if leaky_slope is not None else 0,
-                                   float(leaky_slope or 0.0), out.data_ptr(), ws.data_ptr(), ws.numel(), stream),
-          'se3_group_norm_fwd')
+    nseg = 1 if segments is None else len(segments) - 1
+    check(lib().se3_group_norm_segments_fwd(x.data_ptr(), x_bias.data_ptr() if x_bias is not None else None,
+                                            residual.data_ptr() if residual is not None else None, weight.data_ptr(),
+                                            bias.data_ptr(), rows, C, int(groups), _i64_array(segments) if nseg > 1 else None,
+                                            nseg, float(eps), 1 if leaky_slope is not None else 0, float(leaky_slope or 0.0),
+                                            out.data_ptr(), ws.data_ptr(), ws.numel(), stream), 'se3_group_norm_segments_fwd')
     return out
 
 

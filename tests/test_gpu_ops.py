@@ -71,6 +71,15 @@ def test_group_norm_matches_oracle(rows, A, C, G):
     want3 = (O.group_norm_epn(x + xb, w, b, G) if A > 1 else O.group_norm_flat(x + xb, w, b, G))
     got3 = SF.group_norm_rows(x.cuda(), w.cuda(), b.cuda(), G, 1e-5, 0.1, res.cuda(), x_bias=xb.cuda()).cpu()
     assert_close(got3, torch.nn.functional.leaky_relu(want3 + res, 0.1), 1e-5, 'group norm with folded input bias')
+    # segments: independent statistics per row range (several pairs in one launch) == one call per range
+    if rows >= 64:
+        cuts = [0, rows // 3, rows // 3 + 7, rows]
+        seg_rows = [c * (A if A > 1 else 1) for c in cuts]
+        got4 = SF.group_norm_rows(x.cuda(), w.cuda(), b.cuda(), G, 1e-5, 0.1, res.cuda(), x_bias=xb.cuda(), segments=seg_rows).cpu()
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            xs = x[lo:hi] + xb
+            ws_ = (O.group_norm_epn(xs, w, b, G) if A > 1 else O.group_norm_flat(xs, w, b, G))
+            assert_close(got4[lo:hi], torch.nn.functional.leaky_relu(ws_ + res[lo:hi], 0.1), 1e-5, 'segmented group norm')
 
 
 @pytest.mark.parametrize('A,N,C', [(6, 382, 256), (1, 59, 32), (6, 53, 128), (1, 300, 1024)])
@@ -212,7 +221,7 @@ def test_stack_mode_rejects_bad_descriptors():
     vt = torch.zeros(1, 32, 64, device='cuda')
     out = torch.zeros(1, 64, 32, device='cuda')
     with pytest.raises(RuntimeError):          # more clouds than one launch takes
-        ops.attention_stack(q, q, vt, None, None, [0] * 5, [8] * 5, [0] * 5, [8] * 5, 4, out)
+        ops.attention_stack(q, q, vt, None, None, [0] * 17, [8] * 17, [0] * 17, [8] * 17, 4, out)
     with pytest.raises(RuntimeError):          # cloud beyond the packed rows
         ops.attention_stack(q, q, vt, None, None, [32], [40], [32], [40], 4, out)
     with pytest.raises(RuntimeError):          # key columns must start at a multiple of 4
