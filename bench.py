@@ -39,6 +39,7 @@ def main():
     ap.add_argument('--pair', default='c2_5k')
     ap.add_argument('--cpu-baseline-pairs', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--batch', type=int, default=1, help='registration pairs per forward (se3et_amd.batched), 1..8')
     ap.add_argument('--switch-interval', type=float, default=1e-3)
     ap.add_argument('--prefetch', type=int, default=0, help='build the pyramid of the next pair on a second host thread / HIP '
                     'stream while the current pair runs through the model (the reference does this in DataLoader workers)')
@@ -61,20 +62,26 @@ def main():
     cfg = make_cfg(args.variant)
     model = load_synthetic_weights(create_model(cfg)).to(dev).eval()
     total_steps = args.steps + args.warmup
-    # this rank's pairs, uploaded before the timed region (global pair index = step * world + rank)
+    PB = max(1, args.batch)
+    # this rank's pairs, uploaded before the timed region (global pair index = (step * world + rank) * batch + j); with
+    # --batch B the clouds of B pairs are stacked ref0, src0, ref1, src1, ... and go through ONE forward
     pairs = []
     for s in range(total_steps):
-        ref, src, _ = make_pair(args.pair, index=s * world + rank)
-        pts = torch.from_numpy(np.concatenate([ref, src], 0)).to(dev)
-        pairs.append((pts, torch.tensor([len(ref), len(src)], dtype=torch.int64)))
+        clouds = []
+        for j in range(PB):
+            ref, src, _ = make_pair(args.pair, index=(s * world + rank) * PB + j)
+            clouds += [ref, src]
+        pts = torch.from_numpy(np.concatenate(clouds, 0)).to(dev)
+        pairs.append((pts, torch.tensor([len(c) for c in clouds], dtype=torch.int64)))
     feats = torch.ones((pairs[0][0].shape[0], 1), dtype=torch.float32, device=dev)
     b = cfg.backbone
+    from se3et_amd.batched import forward_pairs
 
     def step(i):
         pts, lens = pairs[i]
         data = precompute_data_stack_mode(pts, lens, b.num_stages, b.init_voxel_size, b.init_radius, cfg.neighbor_limits)
         data['features'] = feats
-        return model(data)
+        return model(data) if PB == 1 else forward_pairs(model, data)
 
     import threading
 
@@ -208,14 +215,14 @@ def main():
     if rank == 0:
         n, dims, _ = PAIR_PRESETS[args.pair]
         line = {
-            'metric': 'point-cloud pairs/sec (fwd), SE3ET-E 5k-pt pairs', 'value': round(world * args.steps / elapsed, 3),
+            'metric': 'point-cloud pairs/sec (fwd), SE3ET-E 5k-pt pairs', 'value': round(world * args.steps * PB / elapsed, 3),
             'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'SE3ET-E forward (pyramid + backbone + transformer + matching + Sinkhorn + LGR) on '
-                                   'synthetic %d+%d-point pairs, one pair per rank per step' % (n, n),
+                                   'synthetic %d+%d-point pairs, %d pair(s) per rank per step' % (n, n, PB),
                        'variant': args.variant, 'pair_preset': args.pair, 'sharding': 'pairs round-robin over ranks, no collective',
-                       'pairs_in_flight_per_gpu': max(1, args.inflight), 'pyramid_prefetch': bool(args.prefetch)},
+                       'pairs_per_forward': PB, 'pairs_in_flight_per_gpu': max(1, args.inflight), 'pyramid_prefetch': bool(args.prefetch)},
             'roofline': roofline, 'cpu_baseline': cpu_baseline,
         }
         print(json.dumps(line), flush=True)

@@ -50,8 +50,9 @@ int se3_debug_kernel_timing_collect(float* microseconds, int* tags, int capacity
  * truncation of modules/ops/radius_search.py:25-27.
  * For every query the support points of the same batch element with d2 = (dx*dx + dy*dy) + dz*dz < radius*radius
  * (float32, unfused) are ranked by (d2, index); the first `limit` indices go to neighbors[q * limit + j], unused
- * entries are filled with ns (the total support count).  *max_count receives max over queries of the number of
- * in-radius points (the caller keeps min(limit, *max_count) columns).  q_lengths_host / s_lengths_host are HOST
+ * entries are filled with ns (the total support count).  max_count (`batch` int32, DEVICE) receives per batch element the
+ * max over its queries of the number of in-radius points (the caller keeps min(limit, max over the elements) columns; with
+ * several registration pairs stacked, a pair's own width is the max over its two clouds).  q_lengths_host / s_lengths_host are HOST
  * arrays of `batch` int64.  limit <= SE3_MAX_NEIGHBOR_LIMIT. */
 int se3_radius_neighbors(const float* q_points, int64_t nq, const float* s_points, int64_t ns,
                          const int64_t* q_lengths_host, const int64_t* s_lengths_host, int batch, float radius,

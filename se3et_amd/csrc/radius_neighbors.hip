@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kWaves* SE3_WAVE) void radius_search_kernel(
       const bool have = best[j] != ~0ull;
       out[(q0 + qi) * limit + lane] = have ? (int64_t)(unsigned)(best[j] & 0xffffffffull) : ns_total;
     }
-    if (lane == 0) atomicMax(max_count, count[j]);
+    if (lane == 0) atomicMax(max_count + b, count[j]);
   }
 }
 
@@ -136,7 +136,7 @@ extern "C" int se3_radius_neighbors(const float* q_points, int64_t nq, const flo
   SE3_REQUIRE(qs == nq && ss == ns, SE3_ERR_INVALID_ARG, "radius_neighbors: lengths sum (%lld,%lld) != sizes (%lld,%lld)",
               (long long)qs, (long long)ss, (long long)nq, (long long)ns);
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(max_count, 0, sizeof(int32_t), st) != hipSuccess) {
+  if (hipMemsetAsync(max_count, 0, sizeof(int32_t) * batch, st) != hipSuccess) {
     se3_set_error("radius_neighbors: memset failed");
     return SE3_ERR_LAUNCH;
   }
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void radius_grid_search_kernel(const float* __
     }
   }
   if (lane < limit) out[gq * limit + lane] = (best != ~0ull) ? (int64_t)(unsigned)(best & 0xffffffffull) : ns_total;
-  if (lane == 0) atomicMax(max_count, count);
+  if (lane == 0) atomicMax(max_count + b, count);
 }
 
 int fill_batch_table(BatchTable* bt, const int64_t* q_len, const int64_t* s_len, int batch, int64_t nq, int64_t ns,
@@ -425,7 +425,7 @@ extern "C" int se3_radius_neighbors_grid(const float* q_points, int64_t nq, cons
   GridLayout G;
   grid_carve(ns, batch, (char*)grid_workspace, &G);
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(max_count, 0, sizeof(int32_t), st) != hipSuccess) {
+  if (hipMemsetAsync(max_count, 0, sizeof(int32_t) * batch, st) != hipSuccess) {
     se3_set_error("radius_neighbors_grid: memset failed");
     return SE3_ERR_LAUNCH;
   }

@@ -315,7 +315,8 @@ __global__ __launch_bounds__(256) void neighbor_max_kernel(const float* __restri
       float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
       for (int j = 0; j < nn; j++) {
         const int64_t s = nb[j];
-        const float4 v = (s >= 0 && s < n) ? reinterpret_cast<const float4*>(x + s * width)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s < 0) continue;           // column beyond the pair's own table width (several pairs stacked): not a neighbour at all
+        const float4 v = s < n ? reinterpret_cast<const float4*>(x + s * width)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
         best = make_float4(fmaxf(best.x, v.x), fmaxf(best.y, v.y), fmaxf(best.z, v.z), fmaxf(best.w, v.w));
       }
       reinterpret_cast<float4*>(out + r * width)[c] = best;
@@ -325,7 +326,8 @@ __global__ __launch_bounds__(256) void neighbor_max_kernel(const float* __restri
       float best = -INFINITY;
       for (int j = 0; j < nn; j++) {
         const int64_t s = nb[j];
-        best = fmaxf(best, (s >= 0 && s < n) ? x[s * width + c] : 0.f);
+        if (s < 0) continue;
+        best = fmaxf(best, s < n ? x[s * width + c] : 0.f);
       }
       out[r * width + c] = best;
     }

@@ -11,7 +11,8 @@ from .modules.ops import grid_subsample
 
 
 def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, neighbor_limits):
-    """points (N, 3) float32 GPU tensor (ref rows then src rows), lengths (2,) int64 (host).  Returns the dict of lists
+    """points (N, 3) float32 GPU tensor (ref rows then src rows; several pairs may be stacked: ref0, src0, ref1, src1, ...),
+    lengths (2 B,) int64 (host).  Returns the dict of lists
     {'points', 'lengths', 'neighbors', 'subsampling', 'upsampling'}; `lengths` entries are host int64 tensors."""
     assert num_stages == len(neighbor_limits)
     if not points.is_cuda:
@@ -21,15 +22,14 @@ def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, 
     for i in range(num_stages):
         if i > 0:
             points, lengths, _ = grid_subsample(points, lengths, None, voxel_size)
-        if i == num_stages - 1:
-            n0, n1 = int(lengths[0]), int(lengths[1])
-            if n0 > 2000:
-                points = torch.cat((points[:2000], points[n0:]), 0)
-                n0 = 2000
-            if n1 > 2000:
-                points = points[:n0 + 2000]
-                n1 = 2000
-            lengths = torch.tensor([n0, n1], dtype=torch.int64)
+        if i == num_stages - 1 and int(lengths.max()) > 2000:
+            # the reference keeps at most 2000 superpoints per cloud (utils/data.py:40-48); any number of stacked clouds here
+            keep, start = [], 0
+            for n in lengths.tolist():
+                keep.append(points[start:start + min(n, 2000)])
+                start += n
+            points = torch.cat(keep, 0)
+            lengths = torch.clamp(lengths, max=2000)
         points_list.append(points.contiguous())
         lengths_list.append(lengths)
         voxel_size *= 2
@@ -56,11 +56,27 @@ def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, 
             jobs.append(('upsampling', _ops.radius_neighbors(cur, sub, cl, sl, radius * 2, neighbor_limits[i + 1],
                                                              grid=grid_for(i + 1, radius * 2))))
         radius *= 2
-    counts = torch.stack([mc for _, (_, mc) in jobs]).cpu().tolist()
+    counts = torch.stack([mc for _, (_, mc) in jobs]).cpu()                       # (jobs, clouds)
+    num_pairs = counts.shape[1] // 2
+    pair_counts = counts.view(counts.shape[0], num_pairs, 2).amax(2).tolist() if counts.shape[1] % 2 == 0 else None
     out = {'points': points_list, 'lengths': lengths_list, 'neighbors': [], 'subsampling': [], 'upsampling': []}
-    for (kind, (full, _)), c in zip(jobs, counts):
-        width = min(full.shape[1], int(c))
-        out[kind].append(full if width == full.shape[1] else full[:, :width].contiguous())
+    stage_of = {'neighbors': lambda k: k, 'subsampling': lambda k: k + 1, 'upsampling': lambda k: k}
+    for j, (kind, (full, _)) in enumerate(jobs):
+        width = min(full.shape[1], int(counts[j].max()))
+        table = full if width == full.shape[1] else full[:, :width].contiguous()
+        if pair_counts is not None and num_pairs > 1 and min(pair_counts[j]) < width:
+            # several pairs stacked: a pair processed alone would have kept only min(limit, ITS max count) columns; columns
+            # beyond that are marked -1 (ignored by every consumer, unlike the padding index Ns which selects the zero row)
+            q_lengths = lengths_list[stage_of[kind](len(out[kind]))]
+            row = 0
+            for p in range(num_pairs):
+                rows_p = int(q_lengths[2 * p] + q_lengths[2 * p + 1])
+                if pair_counts[j][p] < width:
+                    if table is full:
+                        table = full.clone()
+                    table[row:row + rows_p, pair_counts[j][p]:] = -1
+                row += rows_p
+        out[kind].append(table)
     return out
 
 

@@ -7,6 +7,8 @@ library raises (se3et_amd._lib).
 """
 import math
 
+import threading
+
 import torch
 import torch.nn.functional as F
 
@@ -85,9 +87,35 @@ def apply_transform(points, T):
 # ---------------------------------------------------------------------------------------------------------------------
 # B: backbone ops
 # ---------------------------------------------------------------------------------------------------------------------
+class norm_segments:
+    """Context: while active, GroupNorm over a stacked tensor whose first dim is one of `point_offsets` keys (the stacked point
+    count of a pyramid stage) normalises every pair separately: {points_in_stage: [0, end of pair 0, end of pair 1, ...]}.
+    Thread-local (pairs may be processed by several host threads)."""
+    _tls = threading.local()
+
+    def __init__(self, point_offsets):
+        self.point_offsets = point_offsets
+
+    def __enter__(self):
+        self.prev = getattr(norm_segments._tls, 'current', None)
+        norm_segments._tls.current = self.point_offsets
+        return self
+
+    def __exit__(self, *exc):
+        norm_segments._tls.current = self.prev
+        return False
+
+
 def group_norm_rows(x, weight, bias, groups, eps, leaky_slope=None, residual=None, x_bias=None, segments=None):
     """GroupNorm over (rows x channels-in-group) for x (..., C) with ALL leading dims pooled into the statistics
     (GroupNormEPN / kpconv GroupNorm), optionally `+ residual` then LeakyReLU, fused in one pass."""
+    if segments is None:
+        ctx = getattr(norm_segments._tls, 'current', None)
+        if ctx is not None:
+            offs = ctx.get(x.shape[0])
+            if offs is not None and len(offs) > 2:
+                mult = x.numel() // x.shape[-1] // x.shape[0]
+                segments = [o * mult for o in offs]
     return _ops.group_norm_rows(x, weight, bias, groups, eps, leaky_slope, residual, x_bias, segments)
 
 

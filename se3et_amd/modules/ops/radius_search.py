@@ -9,5 +9,5 @@ def radius_search(q_points, s_points, q_lengths, s_lengths, radius, neighbor_lim
     if neighbor_limit <= 0 or neighbor_limit > 64:
         raise RuntimeError('radius_search: neighbor_limit must be in [1, 64] on the HIP path')
     full, max_count = _ops.radius_neighbors(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit)
-    width = min(int(neighbor_limit), int(max_count))
+    width = min(int(neighbor_limit), int(max_count.max()))
     return full if width == full.shape[1] else full[:, :width].contiguous()

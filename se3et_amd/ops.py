@@ -113,7 +113,7 @@ class RadiusGrid:
             raise RuntimeError('q_lengths and s_lengths differ in batch size')
         nq = q_points.shape[0]
         out = torch.empty((nq, limit), dtype=torch.int64, device=q_points.device)
-        max_count = torch.empty((), dtype=torch.int32, device=q_points.device)
+        max_count = torch.empty((nb,), dtype=torch.int32, device=q_points.device)
         check(lib().se3_radius_neighbors_grid(q_points.data_ptr(), nq, ql, self.lengths, self.ns, self.batch, self.ws.data_ptr(),
                                               self.radius, int(limit), out.data_ptr(), max_count.data_ptr(), _stream()),
               'se3_radius_neighbors_grid')
@@ -121,7 +121,8 @@ class RadiusGrid:
 
 
 def radius_neighbors(q_points, s_points, q_lengths, s_lengths, radius, limit, grid=None):
-    """Returns (neighbors (Nq, limit) int64 padded with Ns, max_count 0-d int32 device tensor).  Large supports go through
+    """Returns (neighbors (Nq, limit) int64 padded with Ns, max_count (batch,) int32 device tensor: per cloud the largest
+    in-radius count).  Large supports go through
     a uniform grid (pass a prebuilt RadiusGrid to share it between searches); results are identical either way."""
     _req(q_points, torch.float32, 'q_points', 2)
     _req(s_points, torch.float32, 's_points', 2)
@@ -137,7 +138,7 @@ def radius_neighbors(q_points, s_points, q_lengths, s_lengths, radius, limit, gr
         raise RuntimeError('q_lengths and s_lengths differ in batch size')
     nq, ns = q_points.shape[0], s_points.shape[0]
     out = torch.empty((nq, limit), dtype=torch.int64, device=q_points.device)
-    max_count = torch.empty((), dtype=torch.int32, device=q_points.device)
+    max_count = torch.empty((nb,), dtype=torch.int32, device=q_points.device)
     check(lib().se3_radius_neighbors(q_points.data_ptr(), nq, s_points.data_ptr(), ns, ql, sl, nb, float(radius),
                                      int(limit), out.data_ptr(), max_count.data_ptr(), _stream()),
           'se3_radius_neighbors')

@@ -73,3 +73,60 @@ def test_real_width_model_matches_reference(golden_dir, variant, fixture):
     model, dd, out = _run(variant, str(g['pair']), synth_seed=int(g['synth_seed']))
     assert np.array_equal(np.stack([l.numpy() for l in dd['lengths']]), g['lengths'])
     _check_outputs(out, g, full=False)
+
+
+@pytest.mark.parametrize('variant,preset,num_pairs', [('micro_e', 'micro', 2), ('micro_i', 'micro', 3), ('se3ete', 'c1_2k', 2)])
+def test_multi_pair_forward_equals_single_pair_forward(variant, preset, num_pairs):
+    """se3et_amd.batched.forward_pairs (B pairs stacked through pyramid, backbone and transformer) against the single-pair
+    forward of the same pairs: identical pyramids per pair, features to float32 round-off (the only arithmetic difference is
+    the shape-dependent summation order inside library GEMMs and the GroupNorm partial sums)."""
+    from se3et_amd.batched import forward_pairs
+    from se3et_amd.data import precompute_data_stack_mode
+    from se3et_amd.model import create_model, load_synthetic_weights, make_cfg
+    from se3et_amd.synthetic import make_pair
+    cfg = make_cfg(variant)
+    model = load_synthetic_weights(create_model(cfg)).cuda().eval()
+    b = cfg.backbone
+    clouds, singles = [], []
+    for p in range(num_pairs):
+        ref, src, _ = make_pair(preset, index=p)
+        clouds += [ref, src]
+        pts = torch.from_numpy(np.concatenate([ref, src], 0)).cuda()
+        d = precompute_data_stack_mode(pts, torch.tensor([len(ref), len(src)]), b.num_stages, b.init_voxel_size, b.init_radius,
+                                       cfg.neighbor_limits)
+        d['features'] = torch.ones((pts.shape[0], 1), device='cuda')
+        singles.append((d, model(d)))
+    pts = torch.from_numpy(np.concatenate(clouds, 0)).cuda()
+    dd = precompute_data_stack_mode(pts, torch.tensor([len(c) for c in clouds]), b.num_stages, b.init_voxel_size, b.init_radius,
+                                    cfg.neighbor_limits)
+    dd['features'] = torch.ones((pts.shape[0], 1), device='cuda')
+    # the stacked pyramid restricted to a pair is the pair's own pyramid (points bit-exact, tables equal as neighbour sets)
+    for s in range(b.num_stages):
+        lens = dd['lengths'][s].tolist()
+        start = 0
+        for p, (d, _) in enumerate(singles):
+            n = lens[2 * p] + lens[2 * p + 1]
+            assert d['lengths'][s].tolist() == lens[2 * p:2 * p + 2]
+            assert torch.equal(dd['points'][s][start:start + n], d['points'][s])
+            got = dd['neighbors'][s][start:start + n]
+            want = d['neighbors'][s]
+            total, own = dd['points'][s].shape[0], d['points'][s].shape[0]
+            g = torch.where((got < 0) | (got >= total), torch.full_like(got, own), got - start)[:, :want.shape[1]]
+            assert_neighbors_equal(g.cpu(), want.cpu(), d['points'][s].cpu(), d['points'][s].cpu(), context='stage %d pair %d' % (s, p))
+            assert bool(((dd['neighbors'][s][start:start + n][:, want.shape[1]:] < 0) |
+                         (dd['neighbors'][s][start:start + n][:, want.shape[1]:] >= total)).all())
+            start += n
+    outs = forward_pairs(model, dd)
+    assert len(outs) == num_pairs
+    for p, ((_, want), got) in enumerate(zip(singles, outs)):
+        for key in ('feats_c', 'feats_f', 'ref_feats_c', 'src_feats_c'):
+            assert_close(got[key].cpu(), want[key].cpu(), 2e-5, 'pair %d %s' % (p, key))
+        assert_pairs_equal_up_to_ties((got['ref_node_corr_indices'], got['src_node_corr_indices']), got['node_corr_scores'],
+                                      (want['ref_node_corr_indices'].cpu(), want['src_node_corr_indices'].cpu()),
+                                      want['node_corr_scores'].cpu(), rtol=2e-4, context='pair %d node correspondences' % p)
+        if torch.equal(got['ref_node_corr_indices'], want['ref_node_corr_indices']) and \
+                torch.equal(got['src_node_corr_indices'], want['src_node_corr_indices']):
+            valid = want['matching_scores'] > -1e11
+            assert torch.equal(got['matching_scores'] > -1e11, valid)
+            assert float((got['matching_scores'][valid] - want['matching_scores'][valid]).abs().max()) < 2e-3
+            assert_close(got['estimated_transform'].cpu(), want['estimated_transform'].cpu(), 2e-3, 'pair %d transform' % p)
