@@ -2,13 +2,15 @@
 """Benchmark of the SE3ET hot path on MI355X:  python bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json configs[1]): SE3ET-E forward on synthetic 5k+5k point-cloud pairs (3DMatch-sized), fp32,
-name-keyed synthetic weights.  A step = one registration pair per rank: on-GPU stage pyramid (grid subsampling + 10
-radius searches) -> E2PN backbone -> geometric transformer -> superpoint matching -> Sinkhorn -> local-to-global
-registration.  The raw pairs are resident in HBM before the timed region.  Pairs are sharded round-robin over ranks with
-no collective on the data path (weak scaling); the job time is the MAX over ranks.
+name-keyed synthetic weights.  A step = one batch of `--batch` (default 8) registration pairs per rank through ONE forward
+(se3et_amd.batched: clouds stacked ref0, src0, ref1, ...; per pair the results of the single-pair forward): on-GPU stage
+pyramid (grid subsampling + 10 radius searches) -> E2PN backbone -> geometric transformer -> superpoint matching ->
+Sinkhorn -> local-to-global registration.  `--batch 1` runs the reference-shaped single-pair forward.  The raw pairs are
+resident in HBM before the timed region.  Pairs are sharded over ranks with no collective on the data path (weak scaling);
+the job time is the MAX over ranks; value = pairs / second over all ranks.
 
-Prints ONE JSON line: pairs/s plus a `roofline` object for the RPE self-attention kernels (HIP events on the launch
-stream, live over the timed region) and a `cpu_baseline` object (the CPU oracle timed on this box's host cores)."""
+Prints ONE JSON line: pairs/s plus a `roofline` object for the RPE self-attention kernels (per-launch HIP events on the
+launch stream, live over the timed region) and a `cpu_baseline` object (the CPU oracle timed on this box's host cores)."""
 import argparse
 import json
 import os
@@ -33,13 +35,14 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_M
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=40)
-    ap.add_argument('--warmup', type=int, default=8)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--variant', default='se3ete')
     ap.add_argument('--pair', default='c2_5k')
     ap.add_argument('--cpu-baseline-pairs', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--batch', type=int, default=1, help='registration pairs per forward (se3et_amd.batched), 1..8')
+    ap.add_argument('--batch', type=int, default=8, help='registration pairs per forward / step (se3et_amd.batched), 1..8; '
+                    '1 = the single-pair forward of the reference API')
     ap.add_argument('--switch-interval', type=float, default=1e-3)
     ap.add_argument('--prefetch', type=int, default=0, help='build the pyramid of the next pair on a second host thread / HIP '
                     'stream while the current pair runs through the model (the reference does this in DataLoader workers)')
