@@ -213,6 +213,18 @@ int se3_geo_embedding_fwd(const float* points, const int64_t* knn, int N, int C,
                           const float* div_term, const float* wigner_d1, int num_anchors, float* emb, float* eq_emb,
                           void* stream);
 
+/* ---- G1 / E3: nearest-neighbour selections on the superpoint level ----------------------------------------------------
+ * se3_knn3: knn (N, 3) int64 = the 3 nearest OTHER points of every point (get_embedding_indices,
+ * geotransformer/modules/geotransformer/geotransformer.py:69-90: topk(k + 1) of the distance map, first column dropped).
+ * se3_point_to_node_partition replaces point_to_node_partition (geotransformer/modules/ops/pointcloud_partition.py:60-107):
+ * point_to_node (N) int64 = nearest node of every point; node_masks (M) uint8 = node owns at least one point;
+ * node_knn_indices (M, limit) int64 = the `limit` nearest of the node's OWN points in ascending distance, padded with N;
+ * node_knn_masks (M, limit) uint8.  Distances as pairwise_distance (modules/ops/pairwise_distance.py:4-30), ties by index.
+ * limit <= 64. */
+int se3_knn3(const float* points, int N, int64_t* knn, void* stream);
+int se3_point_to_node_partition(const float* points, const float* nodes, int N, int M, int limit, int64_t* point_to_node,
+                                uint8_t* node_masks, int64_t* node_knn_indices, uint8_t* node_knn_masks, void* stream);
+
 /* ---- E2: superpoint matching scores --------------------------------------------------------------------------------
  * Replaces the score part of SuperPointMatching.forward (geotransformer/modules/geotransformer/superpoint_matching.py:31-39):
  * scores[n, m] = exp(-clamp(2 - 2 ref[n].src[m], 0)), optionally dual-normalised (S / rowsum * S / colsum).

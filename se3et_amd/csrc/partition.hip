@@ -1,0 +1,145 @@
+// E3 / G1 helpers: nearest-neighbour selections on the superpoint level, one launch each instead of a distance matrix + torch.topk.
+//
+//   se3_knn3                     the 3 nearest OTHER points of every point of a cloud (GeometricStructureEmbedding.get_embedding_indices,
+//                                geotransformer/modules/geotransformer/geotransformer.py:69-90: topk(k+1) of the distance map, first column
+//                                dropped)
+//   se3_point_to_node_partition  point_to_node_partition (geotransformer/modules/ops/pointcloud_partition.py:60-107): every fine point
+//                                goes to its nearest node; every node lists the `limit` nearest of ITS OWN points, padded with N
+//
+// Distances follow pairwise_distance (modules/ops/pairwise_distance.py:4-30): (|x|^2 - 2 x.y) + |y|^2, clamped at 0; ties are
+// ordered by index.  One wave per query row, candidates strided over the lanes, sorted lists kept one entry per lane.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float sq_norm(float x, float y, float z) { return (x * x + y * y) + z * z; }
+__device__ __forceinline__ float pair_dist(float qx, float qy, float qz, float q2, float sx, float sy, float sz, float s2) {
+  const float dot = fmaf(qz, sz, fmaf(qy, sy, qx * sx));
+  return fmaxf((q2 - 2.f * dot) + s2, 0.f);
+}
+__device__ __forceinline__ unsigned long long make_key(float d, unsigned idx) {
+  return ((unsigned long long)__float_as_uint(d) << 32) | idx;            // d >= 0: float bits order like the values
+}
+__device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int src) {
+  const unsigned lo = __shfl((unsigned)(v & 0xffffffffull), src), hi = __shfl((unsigned)(v >> 32), src);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long shfl_up1(unsigned long long v) {
+  const unsigned lo = __shfl_up((unsigned)(v & 0xffffffffull), 1), hi = __shfl_up((unsigned)(v >> 32), 1);
+  return ((unsigned long long)hi << 32) | lo;
+}
+// insert `cand` (valid on the lanes where has != 0) one at a time into the wave-wide ascending list `best` (lane = rank)
+__device__ __forceinline__ void wave_insert(unsigned long long& best, unsigned long long cand, bool has) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long pending = __ballot(has);
+  while (pending) {
+    const int src = __ffsll((long long)pending) - 1;
+    pending &= pending - 1;
+    const unsigned long long c = shfl64(cand, src);
+    const int pos = __popcll(__ballot(best < c));
+    const unsigned long long up = shfl_up1(best);
+    if (lane == pos) best = c;
+    else if (lane > pos) best = up;
+  }
+}
+
+__global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ p, int N, int64_t* __restrict__ knn) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= N) return;
+  const float qx = p[3 * i], qy = p[3 * i + 1], qz = p[3 * i + 2], q2 = sq_norm(qx, qy, qz);
+  unsigned long long best = ~0ull;          // lanes 0..3 hold the 4 smallest (distance, index) keys
+  for (int j0 = 0; j0 < N; j0 += 64) {
+    const int j = j0 + lane;
+    unsigned long long c = ~0ull;
+    if (j < N) {
+      const float sx = p[3 * j], sy = p[3 * j + 1], sz = p[3 * j + 2];
+      c = make_key(pair_dist(qx, qy, qz, q2, sx, sy, sz, sq_norm(sx, sy, sz)), (unsigned)j);
+    }
+    const unsigned long long worst = shfl64(best, 3);            // only the 4 smallest matter
+    wave_insert(best, c, j < N && c < worst);
+  }
+  // the reference drops the first column of topk(k + 1) (the point itself at distance 0)
+  if (lane >= 1 && lane <= 3) knn[(size_t)i * 3 + lane - 1] = best == ~0ull ? (int64_t)i : (int64_t)(unsigned)(best & 0xffffffffull);
+}
+
+__global__ __launch_bounds__(256) void nearest_node_kernel(const float* __restrict__ pts, const float* __restrict__ nodes, int N,
+                                                           int M, int64_t* __restrict__ point_to_node,
+                                                           unsigned char* __restrict__ node_masks) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= N) return;
+  const float px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2], p2 = sq_norm(px, py, pz);
+  unsigned long long best = ~0ull;
+  for (int m = lane; m < M; m += 64) {
+    const float nx = nodes[3 * m], ny = nodes[3 * m + 1], nz = nodes[3 * m + 2];
+    // pairwise_distance(nodes, points): x = node, y = point
+    const unsigned long long c = make_key(pair_dist(nx, ny, nz, sq_norm(nx, ny, nz), px, py, pz, p2), (unsigned)m);
+    best = c < best ? c : best;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)(best & 0xffffffffull), o), hi = __shfl_xor((unsigned)(best >> 32), o);
+    const unsigned long long c = ((unsigned long long)hi << 32) | lo;
+    best = c < best ? c : best;
+  }
+  if (lane == 0) {
+    const unsigned m = (unsigned)(best & 0xffffffffull);
+    point_to_node[i] = (int64_t)m;
+    node_masks[m] = 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void node_knn_kernel(const float* __restrict__ pts, const float* __restrict__ nodes,
+                                                       const int64_t* __restrict__ point_to_node, int N, int M, int limit,
+                                                       int64_t* __restrict__ knn, unsigned char* __restrict__ knn_masks) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const float nx = nodes[3 * m], ny = nodes[3 * m + 1], nz = nodes[3 * m + 2], n2 = sq_norm(nx, ny, nz);
+  unsigned long long best = ~0ull;          // lane r = r-th nearest own point
+  for (int j0 = 0; j0 < N; j0 += 64) {
+    const int j = j0 + lane;
+    const bool own = j < N && point_to_node[j] == (int64_t)m;
+    unsigned long long c = ~0ull;
+    if (own) {
+      const float px = pts[3 * j], py = pts[3 * j + 1], pz = pts[3 * j + 2];
+      c = make_key(pair_dist(nx, ny, nz, n2, px, py, pz, sq_norm(px, py, pz)), (unsigned)j);
+    }
+    wave_insert(best, c, own);
+  }
+  if (lane < limit) {
+    const bool have = best != ~0ull;
+    knn[(size_t)m * limit + lane] = have ? (int64_t)(unsigned)(best & 0xffffffffull) : (int64_t)N;
+    knn_masks[(size_t)m * limit + lane] = have ? 1 : 0;
+  }
+}
+
+}  // namespace
+
+extern "C" int se3_knn3(const float* points, int N, int64_t* knn, void* stream) {
+  SE3_REQUIRE(points && knn, SE3_ERR_INVALID_ARG, "knn3: null pointer");
+  SE3_REQUIRE(N >= 1, SE3_ERR_INVALID_ARG, "knn3: N %d", N);
+  knn3_kernel<<<(unsigned)se3_cdiv(N, 4), 256, 0, (hipStream_t)stream>>>(points, N, knn);
+  SE3_CHECK_LAUNCH("knn3");
+  return SE3_OK;
+}
+
+extern "C" int se3_point_to_node_partition(const float* points, const float* nodes, int N, int M, int limit,
+                                           int64_t* point_to_node, uint8_t* node_masks, int64_t* node_knn_indices,
+                                           uint8_t* node_knn_masks, void* stream) {
+  SE3_REQUIRE(points && nodes && point_to_node && node_masks && node_knn_indices && node_knn_masks, SE3_ERR_INVALID_ARG,
+              "point_to_node_partition: null pointer");
+  SE3_REQUIRE(N >= 1 && M >= 1 && limit >= 1 && limit <= 64, SE3_ERR_UNSUPPORTED,
+              "point_to_node_partition: N %d M %d limit %d (limit <= 64)", N, M, limit);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(node_masks, 0, (size_t)M, st) != hipSuccess) {
+    se3_set_error("point_to_node_partition: memset failed");
+    return SE3_ERR_LAUNCH;
+  }
+  nearest_node_kernel<<<(unsigned)se3_cdiv(N, 4), 256, 0, st>>>(points, nodes, N, M, point_to_node, node_masks);
+  node_knn_kernel<<<(unsigned)se3_cdiv(M, 4), 256, 0, st>>>(points, nodes, point_to_node, N, M, limit, node_knn_indices,
+                                                          node_knn_masks);
+  SE3_CHECK_LAUNCH("point_to_node_partition");
+  return SE3_OK;
+}

@@ -604,9 +604,8 @@ def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, 
         raise RuntimeError('geometric_embedding: angle_k must be 3 on the HIP path')
     N, C = points.shape[0], w_d.shape[0]
     # 3 nearest other points (the reference takes top-(k+1) of the distance map and drops the first column)
-    sq = (points * points).sum(-1)
-    dist = (sq[:, None] - 2 * (points @ points.t()) + sq[None, :]).clamp_(min=0.0)
-    knn = dist.topk(k + 1, dim=1, largest=False)[1][:, 1:].contiguous()
+    knn = torch.empty((N, 3), dtype=torch.int64, device=points.device)
+    check(lib().se3_knn3(points.data_ptr(), N, knn.data_ptr(), _stream()), 'se3_knn3')
     tab_d = _embedding_table(w_d, b_d, div_term, _EMB_D_RANGE, _EMB_D_PER_UNIT)
     tab_a = _embedding_table(w_a, b_a, div_term, 180.0 / sigma_a + 1.0, _EMB_A_PER_UNIT)
     emb = torch.empty((N, N, C), dtype=torch.float32, device=points.device)
@@ -623,6 +622,22 @@ def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, 
                                       emb.data_ptr(), eq.data_ptr() if eq is not None else None, _stream()),
           'se3_geo_embedding_fwd')
     return emb if eq is None else (emb, eq)
+
+
+def point_to_node_partition(points, nodes, point_limit):
+    """HIP (csrc/partition.hip): (point_to_node (N,) int64, node_masks (M,) bool, node_knn_indices (M, K) int64 padded with N,
+    node_knn_masks (M, K) bool) -- nearest node per point, the K nearest own points per node."""
+    points = _req(points.contiguous(), torch.float32, 'points', 2)
+    nodes = _req(nodes.contiguous(), torch.float32, 'nodes', 2)
+    N, M, K = points.shape[0], nodes.shape[0], int(point_limit)
+    dev = points.device
+    p2n = torch.empty((N,), dtype=torch.int64, device=dev)
+    masks = torch.empty((M,), dtype=torch.bool, device=dev)
+    knn = torch.empty((M, K), dtype=torch.int64, device=dev)
+    knn_masks = torch.empty((M, K), dtype=torch.bool, device=dev)
+    check(lib().se3_point_to_node_partition(points.data_ptr(), nodes.data_ptr(), N, M, K, p2n.data_ptr(), masks.data_ptr(),
+                                            knn.data_ptr(), knn_masks.data_ptr(), _stream()), 'se3_point_to_node_partition')
+    return p2n, masks, knn, knn_masks
 
 
 def superpoint_scores(ref_feats, src_feats, dual_normalization):

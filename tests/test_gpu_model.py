@@ -121,9 +121,18 @@ def test_multi_pair_forward_equals_single_pair_forward(variant, preset, num_pair
     for p, ((_, want), got) in enumerate(zip(singles, outs)):
         for key in ('feats_c', 'feats_f', 'ref_feats_c', 'src_feats_c'):
             assert_close(got[key].cpu(), want[key].cpu(), 2e-5, 'pair %d %s' % (p, key))
-        assert_pairs_equal_up_to_ties((got['ref_node_corr_indices'], got['src_node_corr_indices']), got['node_corr_scores'],
-                                      (want['ref_node_corr_indices'].cpu(), want['src_node_corr_indices'].cpu()),
-                                      want['node_corr_scores'].cpu(), rtol=2e-4, context='pair %d node correspondences' % p)
+        # the same superpoint pairs with the same scores; a pair may only be missing if its score sits at the top-k cut-off
+        sw = dict(zip(zip(want['ref_node_corr_indices'].tolist(), want['src_node_corr_indices'].tolist()),
+                      want['node_corr_scores'].tolist()))
+        sg = dict(zip(zip(got['ref_node_corr_indices'].tolist(), got['src_node_corr_indices'].tolist()),
+                      got['node_corr_scores'].tolist()))
+        assert len(sw) == len(sg)
+        cut = min(sw.values())
+        for key in set(sw) | set(sg):
+            if key in sw and key in sg:
+                assert abs(sw[key] - sg[key]) <= 2e-4 * sw[key], 'pair %d: score of %s' % (p, key)
+            else:
+                assert abs(sw.get(key, sg.get(key)) - cut) <= 2e-4 * cut, 'pair %d: %s missing on one side' % (p, key)
         if torch.equal(got['ref_node_corr_indices'], want['ref_node_corr_indices']) and \
                 torch.equal(got['src_node_corr_indices'], want['src_node_corr_indices']):
             valid = want['matching_scores'] > -1e11

@@ -414,3 +414,34 @@ def test_weighted_procrustes_matches_oracle():
     assert abs(float(torch.det(T[:3, :3])) - 1) < 1e-4
     want = O.weighted_procrustes(p[None], q[None], torch.ones(1, 50))[0]
     assert_close(T, want, 1e-3, 'reflection case')
+
+
+@pytest.mark.parametrize('N,M,K', [(2500, 382, 64), (700, 59, 64), (300, 300, 16), (5000, 7, 64)])
+def test_point_to_node_partition_matches_oracle(N, M, K):
+    """csrc/partition.hip against the oracle's restatement of pointcloud_partition.py:60-107 (exact: indices and masks)."""
+    from oracle import se3et_oracle as O
+    from se3et_amd.modules.ops import point_to_node_partition
+    g = torch.Generator().manual_seed(13)
+    pts = torch.rand(N, 3, generator=g) * torch.tensor([1.5, 1.2, 1.0])
+    nodes = pts[torch.randperm(N, generator=g)[:M]] + 0.01 * torch.randn(M, 3, generator=g)
+    want = O.point_to_node_partition(pts, nodes, K)
+    got = point_to_node_partition(pts.cuda(), nodes.cuda(), K)
+    names = ('point_to_node', 'node_masks', 'node_knn_indices', 'node_knn_masks')
+    for name, a, b in zip(names, got, want):
+        assert torch.equal(a.cpu(), b), name
+
+
+@pytest.mark.parametrize('N', [382, 59, 5, 1500])
+def test_knn3_matches_oracle(N):
+    from oracle import se3et_oracle as O
+    from se3et_amd import ops
+    from se3et_amd._lib import lib, check
+    g = torch.Generator().manual_seed(17)
+    pts = torch.rand(N, 3, generator=g) * 2.0
+    dist = O.pairwise_distance(pts, pts)
+    want = dist.topk(4, dim=1, largest=False)[1][:, 1:]
+    p = pts.cuda()
+    knn = torch.empty((N, 3), dtype=torch.int64, device='cuda')
+    check(lib().se3_knn3(p.data_ptr(), N, knn.data_ptr(), None), 'se3_knn3')
+    torch.cuda.synchronize()
+    assert torch.equal(knn.cpu(), want)
