@@ -32,6 +32,7 @@ __device__ __forceinline__ WF wf_merge(WF a, WF b) {
 // Segments: independent row ranges of one stacked tensor, each with its own statistics (one registration pair each when
 // several pairs share a launch; the reference normalises per pair because it runs one pair per forward).
 constexpr int kGNMaxSegments = 16;
+constexpr int kGNMaxChunks = 1024;
 struct SegTable {
   int n;
   long long row_begin[kGNMaxSegments + 1];
@@ -348,7 +349,7 @@ static int64_t gn_chunks(int64_t rows, int channels, int cap) {
   int64_t n;
   if (gn_fast_path(channels)) {
     const int64_t row_lanes = 256 / (channels / 4);
-    n = rows / (8 * row_lanes) + 1;           // >= 8 rows per row lane
+    n = rows / (32 * row_lanes) + 1;          // >= 32 rows per row lane
   } else {
     n = rows / 64 + 1;
   }
@@ -357,8 +358,8 @@ static int64_t gn_chunks(int64_t rows, int channels, int cap) {
 
 extern "C" size_t se3_group_norm_workspace_bytes(int64_t rows, int channels, int groups) {
   (void)rows;
-  (void)groups;   // upper bound over any segmentation: <= 256 + 16 chunk partials, 16 affine tables
-  return (size_t)((256 + kGNMaxSegments) * channels * 3 + kGNMaxSegments * 2 * channels) * sizeof(float) + 256;
+  (void)groups;   // upper bound over any segmentation: <= kGNMaxChunks + 16 chunk partials, 16 affine tables
+  return (size_t)((kGNMaxChunks + kGNMaxSegments) * channels * 3 + kGNMaxSegments * 2 * channels) * sizeof(float) + 256;
 }
 
 extern "C" int se3_group_norm_segments_fwd(const float* x, const float* x_bias, const float* residual, const float* weight,
@@ -375,7 +376,8 @@ extern "C" int se3_group_norm_segments_fwd(const float* x, const float* x_bias, 
               "group_norm: workspace too small");
   SegTable T{};
   T.n = num_segments;
-  const int cap = 256 / num_segments > 8 ? 256 / num_segments : 8;
+  // up to 4 blocks per CU in total for large tensors (a single block per CU is latency bound: 1 TB/s at 100 MB)
+  const int cap = kGNMaxChunks / num_segments > 8 ? kGNMaxChunks / num_segments : 8;
   int chunks = 0;
   for (int sgm = 0; sgm < num_segments; sgm++) {
     const int64_t b0 = num_segments == 1 ? 0 : segment_row_offsets_host[sgm];
@@ -391,7 +393,7 @@ extern "C" int se3_group_norm_segments_fwd(const float* x, const float* x_bias, 
   SE3_REQUIRE(T.row_begin[0] == 0 && T.row_begin[num_segments] == rows, SE3_ERR_INVALID_ARG,
               "group_norm: the segments must cover all rows");
   float* part = (float*)workspace;
-  float* affine = part + (size_t)(256 + kGNMaxSegments) * channels * 3;
+  float* affine = part + (size_t)(kGNMaxChunks + kGNMaxSegments) * channels * 3;
   hipStream_t st = (hipStream_t)stream;
   if (gn_fast_path(channels) && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
     gn_partial4_kernel<<<(unsigned)chunks, 256, 0, st>>>(x, T, channels, part);
