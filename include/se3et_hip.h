@@ -244,6 +244,12 @@ int se3_weighted_procrustes(const float* src_points, const float* ref_points, co
                             float eps, float* transforms, void* stream);
 int se3_count_inliers(const float* src_points, const float* ref_points, int64_t num_points, const float* transforms,
                       int num_transforms, float radius, int32_t* votes, void* stream);
+/* Mutual top-k correspondence mask (local_global_registration.py:104-131): mask[b, i, j] = 1 iff scores[b, i, j] is among the k
+ * largest of row i AND of column j of patch pair b (ties by index), exceeds `threshold`, and row_masks[b, i] & col_masks[b, j].
+ * scores (batch, rows, cols) float32, masks uint8; rows * cols <= 16384. */
+int se3_mutual_topk_mask(const float* scores, const uint8_t* row_masks, const uint8_t* col_masks, int batch, int rows, int cols,
+                         int k, float threshold, uint8_t* mask, void* stream);
+
 
 #ifdef __cplusplus
 }

@@ -45,6 +45,7 @@ SIGNATURES = {
     'se3_point_to_node_partition': (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'se3_superpoint_scores': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     'se3_weighted_procrustes': (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _f32, _f32, _vp, _vp]),
+    'se3_mutual_topk_mask': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     'se3_count_inliers': (_i32, [_vp, _vp, _i64, _vp, _i32, _f32, _vp, _vp]),
     'se3_log_sinkhorn_fwd': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
 }

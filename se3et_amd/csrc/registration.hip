@@ -184,6 +184,41 @@ __global__ __launch_bounds__(256) void vote_kernel(const float* __restrict__ src
   if (threadIdx.x == 0) votes[blockIdx.x] = shv[0] + shv[1] + shv[2] + shv[3];
 }
 
+// Mutual top-k correspondence mask of local_global_registration.py:104-131: entry (i, j) of patch pair b survives when it is among
+// the k largest of its row AND of its column (ties by index), both above the confidence threshold, and both points are valid.
+// One workgroup per patch pair, the (rows, cols) score matrix in LDS; replaces two torch.topk + two scatters per call.
+__global__ __launch_bounds__(256) void mutual_topk_kernel(const float* __restrict__ scores, const unsigned char* __restrict__ row_masks,
+                                                          const unsigned char* __restrict__ col_masks, int R, int C, int k,
+                                                          float threshold, unsigned char* __restrict__ out) {
+  extern __shared__ float sm[];              // R * C scores
+  const int b = blockIdx.x;
+  const float* S = scores + (size_t)b * R * C;
+  for (int i = threadIdx.x; i < R * C; i += 256) sm[i] = S[i];
+  __syncthreads();
+  for (int e = threadIdx.x; e < R * C; e += 256) {
+    const int i = e / C, j = e - i * C;
+    const float v = sm[e];
+    bool keep = v > threshold && row_masks[(size_t)b * R + i] && col_masks[(size_t)b * C + j];
+    if (keep) {
+      int ahead = 0;                         // entries of row i that precede (i, j) in a descending, index-stable order
+      for (int jj = 0; jj < C; jj++) {
+        const float o = sm[i * C + jj];
+        ahead += (o > v) || (o == v && jj < j);
+      }
+      keep = ahead < k;
+    }
+    if (keep) {
+      int ahead = 0;
+      for (int ii = 0; ii < R; ii++) {
+        const float o = sm[ii * C + j];
+        ahead += (o > v) || (o == v && ii < i);
+      }
+      keep = ahead < k;
+    }
+    out[(size_t)b * R * C + e] = keep ? 1 : 0;
+  }
+}
+
 }  // namespace
 
 extern "C" int se3_weighted_procrustes(const float* src_points, const float* ref_points, const float* scores,
@@ -207,3 +242,16 @@ extern "C" int se3_count_inliers(const float* src_points, const float* ref_point
   SE3_CHECK_LAUNCH("count_inliers");
   return SE3_OK;
 }
+
+extern "C" int se3_mutual_topk_mask(const float* scores, const uint8_t* row_masks, const uint8_t* col_masks, int batch, int rows,
+                                    int cols, int k, float threshold, uint8_t* mask, void* stream) {
+  SE3_REQUIRE(scores && row_masks && col_masks && mask, SE3_ERR_INVALID_ARG, "mutual_topk_mask: null pointer");
+  SE3_REQUIRE(batch >= 0 && rows >= 1 && cols >= 1 && k >= 1 && (size_t)rows * cols * sizeof(float) <= 64 * 1024, SE3_ERR_UNSUPPORTED,
+              "mutual_topk_mask: batch %d rows %d cols %d k %d (rows * cols <= 16384)", batch, rows, cols, k);
+  if (batch == 0) return SE3_OK;
+  mutual_topk_kernel<<<(unsigned)batch, 256, (size_t)rows * cols * sizeof(float), (hipStream_t)stream>>>(
+      scores, row_masks, col_masks, rows, cols, k, threshold, mask);
+  SE3_CHECK_LAUNCH("mutual_topk_mask");
+  return SE3_OK;
+}
+

@@ -245,6 +245,10 @@ def log_optimal_transport(scores, row_masks, col_masks, alpha, num_iterations, i
 # ---------------------------------------------------------------------------------------------------------------------
 # F1: registration (device-side Kabsch, csrc/registration.hip)
 # ---------------------------------------------------------------------------------------------------------------------
+def mutual_topk_mask(scores, row_masks, col_masks, k, threshold):
+    return _ops.mutual_topk_mask(scores, row_masks, col_masks, k, threshold)
+
+
 def weighted_procrustes(src, ref, scores, offsets, gate_transform=None, gate_radius=0.0, eps=1e-5):
     return _ops.weighted_procrustes(src, ref, scores, offsets, gate_transform, gate_radius, eps)
 

@@ -26,11 +26,7 @@ class LocalGlobalRegistration(nn.Module):
     def forward(self, ref_knn_points, src_knn_points, ref_knn_masks, src_knn_masks, score_mat, global_scores):
         score_mat = torch.exp(score_mat)
         B = score_mat.shape[0]
-        rs, ri = score_mat.topk(self.k, dim=2)
-        ss, si = score_mat.topk(self.k, dim=1)
-        corr = (torch.zeros_like(score_mat).scatter_(2, ri, rs) > self.confidence_threshold) & \
-               (torch.zeros_like(score_mat).scatter_(1, si, ss) > self.confidence_threshold) & \
-               (ref_knn_masks[:, :, None] & src_knn_masks[:, None, :])
+        corr = SF.mutual_topk_mask(score_mat, ref_knn_masks, src_knn_masks, self.k, self.confidence_threshold)
         b_idx, r_idx, c_idx = torch.nonzero(corr, as_tuple=True)           # one host sync (row-major, as the reference)
         ref_c, src_c = ref_knn_points[b_idx, r_idx].contiguous(), src_knn_points[b_idx, c_idx].contiguous()
         sc = score_mat[b_idx, r_idx, c_idx].contiguous()

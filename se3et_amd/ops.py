@@ -653,6 +653,21 @@ def superpoint_scores(ref_feats, src_feats, dual_normalization):
     return scores
 
 
+def mutual_topk_mask(scores, row_masks, col_masks, k, threshold):
+    """HIP (csrc/registration.hip): bool (B, R, C) mask of the entries that are among the k largest of their row and of their
+    column, above `threshold`, with valid row and column points."""
+    scores = _req(scores.contiguous(), torch.float32, 'scores', 3)
+    B, R, C = scores.shape
+    rm = row_masks.contiguous()
+    cm = col_masks.contiguous()
+    if rm.dtype != torch.bool or cm.dtype != torch.bool or tuple(rm.shape) != (B, R) or tuple(cm.shape) != (B, C):
+        raise RuntimeError('mutual_topk_mask: masks must be bool (B, R) / (B, C)')
+    out = torch.empty((B, R, C), dtype=torch.bool, device=scores.device)
+    check(lib().se3_mutual_topk_mask(scores.data_ptr(), rm.data_ptr(), cm.data_ptr(), B, R, C, int(k), float(threshold),
+                                     out.data_ptr(), _stream()), 'se3_mutual_topk_mask')
+    return out
+
+
 def weighted_procrustes(src, ref, scores, offsets, gate_transform=None, gate_radius=0.0, eps=1e-5):
     """HIP (csrc/registration.hip): one weighted Kabsch solve per segment of the stacked correspondences -> (S, 4, 4)."""
     src = _req(src.contiguous(), torch.float32, 'src', 2)
