@@ -200,6 +200,18 @@ int se3_cross_eq_mix(const float* partial, int num_partials_per_pair, int A, int
                      int num_rotations, float* mix, float* weights, void* stream);
 int se3_cross_eq_apply(const float* q, const float* k, const float* vt, const float* mix, int A, int N, int M, int C, int H,
                        int key_stride, float scale, float* out, void* stream);
+/* Stack mode: statistics, mixing weights and weighted attention of ALL pairs of a batch in three launches.  q (A, Rq, C) and
+ * k (A, Rk, C) hold the packed rows of all pairs (pair p: query rows q_starts[p] .. + q_lengths[p], key rows k_starts[p] .. +
+ * k_lengths[p]; row stride C, anchor strides given), vt (A, C, v_row_stride) the transposed values addressed by key column
+ * (k_starts multiples of 4, ceil32(k_lengths[p]) columns readable).  partial_workspace: num_pairs * A*A * max_p ceil(N_p/32)
+ * floats; mix (num_pairs, A, A); weights (num_pairs, A*A) for mode 0 / (num_pairs, num_rotations) for mode 1; out (A, Rq, C) in
+ * the packing of q.  num_pairs <= 16. */
+int se3_cross_eq_stack_fwd(const float* q, const float* k, const float* vt, const int64_t* q_starts, const int64_t* q_lengths,
+                           const int64_t* k_starts, const int64_t* k_lengths, int num_pairs, int A, int C, int H,
+                           int64_t q_anchor_stride, int64_t k_anchor_stride, int v_row_stride, int64_t v_anchor_stride, int mode,
+                           const int64_t* trace_idx, int num_rotations, float* partial_workspace, float* mix, float* weights,
+                           float* out, void* stream);
+
 
 /* ---- G1/G2: geometric structure embedding --------------------------------------------------------------------------
  * Replaces GeometricStructureEmbedding.forward (geotransformer/modules/geotransformer/geotransformer.py:57-121 with

@@ -76,15 +76,12 @@ def _cross_eq(layer, Pq, Pk, xq, xk):
     H = att.num_heads
     q = SF.linear(xq, att.proj_q.weight, att.proj_q.bias)
     k = SF.linear(xk, att.proj_k.weight, att.proj_k.bias)
-    v = SF.linear(xk, att.proj_v.weight, att.proj_v.bias)
+    A, C = xk.shape[0], q.shape[-1]
+    w_v, b_v = att.proj_v.weight, att.proj_v.bias
+    vt = torch.baddbmm(b_v[None, :, None].expand(A, C, xk.shape[1]), w_v[None].expand(A, C, C), xk.transpose(1, 2))
     hidden = torch.zeros_like(q)
-    mixes = []
-    for (sq, nq), (sk, nk) in zip(zip(Pq.starts, Pq.lengths), zip(Pk.starts, Pk.lengths)):
-        Mp = _ops.key_stride(nk)
-        vt = F.pad(v[:, sk:sk + nk], (0, 0, 0, Mp - nk)).transpose(1, 2).contiguous()
-        out, _, mix = _ops.cross_attention_eq(q[:, sq:sq + nq], k[:, sk:sk + nk], vt, H, att.attn_mode, att.trace_idx_ori)
-        hidden[:, sq:sq + nq] = out
-        mixes.append(mix)
+    mixes, _ = _ops.cross_attention_eq_stack(q, k, vt, Pq.starts, Pq.lengths, Pk.starts, Pk.lengths, H, att.attn_mode,
+                                             att.trace_idx_ori, hidden)
     al = layer.attention
     hidden = SF.linear(hidden, al.linear.weight)
     hidden = SF.add_layer_norm(hidden, xq, al.norm.weight, al.norm.bias, al.norm.eps, hidden_bias=al.linear.bias)

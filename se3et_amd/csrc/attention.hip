@@ -732,14 +732,136 @@ __global__ __launch_bounds__(256) void cross_eq_apply_kernel(const float* __rest
   }
 }
 
+// ---- stack mode of the equivariant cross attention: all pairs of a batch per launch ------------------------------------------
+struct CrossEqArgs {
+  const float *q, *k, *vt;     // q (A, Rq, C), k (A, Rk, C) packed rows; vt (A, C, v_rs) transposed values addressed by key column
+  Stack S;                     // per pair: q_start, k_start, N, M (Mp = ceil32(M))
+  int A, C, H, QT;             // QT = 32-query tiles of the largest pair
+  long long q_sa, k_sa, v_sa;  // anchor strides (floats)
+  int v_rs;
+  float scale;
+};
+
+// grid (QT, A*A, pairs): partial[(pair*A*A + ae) * QT + qt] = sum over the tile's (n, m) of (mean_h S[a,e,h,n,m])^2
+template <int D>
+__global__ __launch_bounds__(256) void cross_eq_stats_stack_kernel(CrossEqArgs p, float* __restrict__ partial) {
+  constexpr int KU = D / 8;
+  __shared__ float red[4];
+  const int A = p.A, C = p.C, H = p.H;
+  const StackCloud cl = stack_pick(p.S, blockIdx.z);
+  const int N = cl.N, M = cl.M;
+  const int n0 = blockIdx.x * 32, ae = blockIdx.y, a = ae / A, e = ae - a * A;
+  float* dst = partial + ((size_t)blockIdx.z * A * A + ae) * gridDim.x + blockIdx.x;
+  if (n0 >= N) {
+    if (threadIdx.x == 0) *dst = 0.f;
+    return;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, c32 = lane & 31;
+  const int nq = min(n0 + c32, N - 1);
+  const int tiles = (M + 31) >> 5;
+  const float* qa = p.q + a * p.q_sa + (size_t)cl.q_start * C;
+  const float* ke = p.k + e * p.k_sa + (size_t)cl.k_start * C;
+  float total = 0.f;
+  for (int tile = wave; tile < tiles; tile += 4) {
+    const int m0 = tile << 5;
+    const int kr = min(m0 + c32, M - 1);
+    f32x16 mean;
+#pragma unroll
+    for (int r = 0; r < 16; r++) mean[r] = 0.f;
+    for (int h = 0; h < H; h++) {
+      const float* qh = qa + (size_t)nq * C + h * D;
+      const float* kh = ke + (size_t)kr * C + h * D;
+#pragma unroll
+      for (int u = 0; u < KU; u++) {
+        const float4 kf = ld4(kh + 8 * u + 4 * half), qf = ld4(qh + 8 * u + 4 * half);
+#pragma unroll
+        for (int i = 0; i < 4; i++) mean = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(kf, i), f4get(qf, i), mean, 0, 0, 0);
+      }
+    }
+    const float f = p.scale / (float)H;
+    const bool qok = n0 + c32 < N;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int key = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float val = mean[r] * f;
+      total += (qok && key < M) ? val * val : 0.f;
+    }
+  }
+  total = se3_wave_sum(total);
+  if (lane == 0) red[wave] = total;
+  __syncthreads();
+  if (threadIdx.x == 0) *dst = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// grid (QT, H, A * pairs), 64 NW threads: wave e handles key anchor e (NW = A = 6: no imbalance, half the serial chain of the
+// 4-wave version); out[a, n, h] = sum_e mix[pair, a, e] softmax_m(q_a.k_e * scale) v_e
+template <int D, int NW>
+__global__ __launch_bounds__(64 * NW) void cross_eq_apply_stack_kernel(CrossEqArgs p, const float* __restrict__ mix,
+                                                                       float* __restrict__ out) {
+  constexpr int DT = FlashState<D>::DT;
+  __shared__ float so[NW * DT * 16 * 64];
+  const int A = p.A, C = p.C;
+  const int pair = blockIdx.z / A, a = blockIdx.z - pair * A;
+  const StackCloud cl = stack_pick(p.S, pair);
+  const int n0 = blockIdx.x * 32, h = blockIdx.y;
+  if (n0 >= cl.N) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  FlashState<D> tot;
+  flash_init(tot);
+  for (int e = wave; e < A; e += NW) {
+    FlashState<D> st;
+    flash_init(st);
+    flash_tiles<D, false>(st, p.q + a * p.q_sa + (size_t)cl.q_start * C + h * D, p.k + e * p.k_sa + (size_t)cl.k_start * C + h * D,
+                          p.vt + e * p.v_sa + (size_t)h * D * p.v_rs + cl.k_start, nullptr, n0, cl.N, cl.M, C, C, p.v_rs, cl.Mp,
+                          p.scale, 0, 1);
+    const float w = mix[((size_t)pair * A + a) * A + e] / st.l;
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) tot.o[dt][r] += st.o[dt][r] * w;
+  }
+#pragma unroll
+  for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) so[((wave * DT + dt) * 16 + r) * 64 + lane] = tot.o[dt][r];
+  __syncthreads();
+  // every wave sums and stores its share of the output columns
+  const int half = lane >> 5, c32 = lane & 31, nq = n0 + c32;
+  float* op = out + ((size_t)a * p.q_sa) + (size_t)cl.q_start * C + h * D;
+  for (int gi = wave; gi < DT * 4; gi += NW) {
+    const int dt = gi >> 2, g = gi & 3;
+    const int dd = 32 * dt + 8 * g + 4 * half;
+    float val[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float acc = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; w++) acc += so[((w * DT + dt) * 16 + 4 * g + j) * 64 + lane];
+      val[j] = acc;
+    }
+    if (nq < cl.N && dd < D) *reinterpret_cast<float4*>(op + (size_t)nq * C + dd) = make_float4(val[0], val[1], val[2], val[3]);
+  }
+}
+
 // one workgroup: g[a,e] = sum_i partial[(a*A+e)*P + i] / (N M) -> mixing weights.
 //   mode 0 (a_soft): mix[a,e] = g[a,e] / sum_e g[a,e];  weights = mix (A*A values)
 //   mode 1 (r_soft): w[r] = mean_a g[a, trace[r,a]] normalised over r; mix[a,e] = sum_{r: trace[r,a]=e} w[r]; weights = w (R values)
+// grid = pairs: block b works on partial + b * A*A*P, mix + b * A*A, weights + b * (mode 0: A*A, mode 1: R); inv_nm: 1 / (N M)
+// of the pair, taken from the stack descriptor when S != nullptr
 __global__ __launch_bounds__(64) void cross_eq_mix_kernel(const float* __restrict__ partial, int P, float inv_nm, int A, int R,
                                                           const int64_t* __restrict__ trace, int mode, float* __restrict__ mix,
-                                                          float* __restrict__ weights) {
+                                                          float* __restrict__ weights, const Stack* __restrict__ S_dev, Stack S,
+                                                          int use_stack) {
   __shared__ float g[64], w[64], tot;
   const int t = threadIdx.x;
+  (void)S_dev;
+  if (use_stack) {
+    const StackCloud cl = stack_pick(S, blockIdx.x);
+    inv_nm = 1.0f / ((float)cl.N * (float)cl.M);
+  }
+  partial += (size_t)blockIdx.x * A * A * P;
+  mix += (size_t)blockIdx.x * A * A;
+  weights += (size_t)blockIdx.x * (mode == 0 ? A * A : R);
   if (t < A * A) {
     float acc = 0.f;
     for (int i = 0; i < P; i++) acc += partial[(size_t)t * P + i];
@@ -1078,8 +1200,49 @@ extern "C" int se3_cross_eq_mix(const float* partial, int num_partials_per_pair,
   SE3_REQUIRE(A >= 1 && A * A <= 64 && (mode == 0 || (mode == 1 && trace_idx && num_rotations >= 1 && num_rotations <= 64)),
               SE3_ERR_UNSUPPORTED, "cross_eq_mix: A %d mode %d rotations %d", A, mode, num_rotations);
   cross_eq_mix_kernel<<<1, 64, 0, (hipStream_t)stream>>>(partial, num_partials_per_pair, 1.0f / ((float)N * (float)M), A,
-                                                       num_rotations, trace_idx, mode, mix, weights);
+                                                       num_rotations, trace_idx, mode, mix, weights, nullptr, Stack{}, 0);
   SE3_CHECK_LAUNCH("cross_eq_mix");
+  return SE3_OK;
+}
+
+extern "C" int se3_cross_eq_stack_fwd(const float* q, const float* k, const float* vt, const int64_t* q_starts,
+                                      const int64_t* q_lengths, const int64_t* k_starts, const int64_t* k_lengths, int num_pairs,
+                                      int A, int C, int H, int64_t q_anchor_stride, int64_t k_anchor_stride, int v_row_stride,
+                                      int64_t v_anchor_stride, int mode, const int64_t* trace_idx, int num_rotations,
+                                      float* partial_workspace, float* mix, float* weights, float* out, void* stream) {
+  SE3_REQUIRE(q && k && vt && q_starts && q_lengths && k_starts && k_lengths && partial_workspace && mix && weights && out,
+              SE3_ERR_INVALID_ARG, "cross_eq_stack: null pointer");
+  SE3_REQUIRE(num_pairs >= 1 && num_pairs <= kMaxClouds, SE3_ERR_UNSUPPORTED, "cross_eq_stack: %d pairs (1..%d)", num_pairs, kMaxClouds);
+  SE3_REQUIRE(A >= 1 && A * A <= 64 && H >= 1 && C % H == 0 && v_row_stride % 4 == 0, SE3_ERR_INVALID_ARG, "cross_eq_stack: bad sizes");
+  SE3_REQUIRE(mode == 0 || (mode == 1 && trace_idx && num_rotations >= 1 && num_rotations <= 64), SE3_ERR_UNSUPPORTED,
+              "cross_eq_stack: mode %d rotations %d", mode, num_rotations);
+  CrossEqArgs p{};
+  p.q = q; p.k = k; p.vt = vt;
+  p.S.n = num_pairs;
+  int qt = 1;
+  for (int c = 0; c < num_pairs; c++) {
+    const int N = (int)q_lengths[c], M = (int)k_lengths[c], Mp = ((M + 31) / 32) * 32;
+    SE3_REQUIRE(N >= 1 && M >= 1 && q_starts[c] >= 0 && k_starts[c] >= 0 && k_starts[c] % 4 == 0 && k_starts[c] + Mp <= v_row_stride,
+                SE3_ERR_INVALID_ARG, "cross_eq_stack: pair %d descriptor", c);
+    p.S.c[c] = StackCloud{nullptr, nullptr, (int)q_starts[c], (int)k_starts[c], N, M, Mp, 0, 0};
+    qt = (N + 31) / 32 > qt ? (N + 31) / 32 : qt;
+  }
+  p.A = A; p.C = C; p.H = H; p.QT = qt;
+  p.q_sa = q_anchor_stride; p.k_sa = k_anchor_stride; p.v_sa = v_anchor_stride; p.v_rs = v_row_stride;
+  p.scale = 1.0f / sqrtf((float)(C / H));
+  hipStream_t st = (hipStream_t)stream;
+  int rc = dispatch_head_dim(C / H, [&](auto d) {
+    constexpr int D = decltype(d)::value;
+    cross_eq_stats_stack_kernel<D><<<dim3((unsigned)qt, (unsigned)(A * A), (unsigned)num_pairs), 256, 0, st>>>(p, partial_workspace);
+    cross_eq_mix_kernel<<<(unsigned)num_pairs, 64, 0, st>>>(partial_workspace, qt, 0.f, A, num_rotations, trace_idx, mode, mix,
+                                                         weights, nullptr, p.S, 1);
+    if (A <= 6)
+      cross_eq_apply_stack_kernel<D, 6><<<dim3((unsigned)qt, (unsigned)H, (unsigned)(A * num_pairs)), 384, 0, st>>>(p, mix, out);
+    else
+      cross_eq_apply_stack_kernel<D, 4><<<dim3((unsigned)qt, (unsigned)H, (unsigned)(A * num_pairs)), 256, 0, st>>>(p, mix, out);
+  }, "cross_eq_stack");
+  if (rc != SE3_OK) return rc;
+  SE3_CHECK_LAUNCH("cross_eq_stack");
   return SE3_OK;
 }
 

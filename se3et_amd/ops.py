@@ -569,6 +569,38 @@ def cross_attention_eq(q, k, vt, num_heads, mode, trace_idx):
     return out, ret, mix
 
 
+def cross_attention_eq_stack(q, k, vt, q_starts, q_lengths, k_starts, k_lengths, num_heads, mode, trace_idx, out):
+    """HIP: equivariant cross attention of all pairs of a batch (se3_cross_eq_stack_fwd).  q (A, Rq, C), k (A, Rk, C) packed rows,
+    vt (A, C, Rk) transposed values, out (A, Rq, C) (rows outside the pairs are left untouched).  Returns the per-pair mixing
+    matrices (P, A, A) and weights (P, A*A) ('a_soft') / (P, R) ('r_soft')."""
+    q = _req(q, torch.float32, 'q', 3)
+    k = _req(k, torch.float32, 'k', 3)
+    vt = _req(vt, torch.float32, 'vt', 3)
+    out = _req(out, torch.float32, 'out', 3)
+    A, Rq, C = q.shape
+    if k.shape[0] != A or k.shape[2] != C or tuple(vt.shape[:2]) != (A, C) or out.shape != q.shape:
+        raise RuntimeError('cross_attention_eq_stack: shapes q %s k %s vt %s out %s' % (tuple(q.shape), tuple(k.shape), tuple(vt.shape), tuple(out.shape)))
+    if mode not in ('a_soft', 'r_soft'):
+        raise RuntimeError('cross_attention_eq_stack: mode %r' % (mode,))
+    P = len(q_starts)
+    for p in range(P):
+        if q_starts[p] + q_lengths[p] > Rq or k_starts[p] + k_lengths[p] > k.shape[1] or k_starts[p] + key_stride(k_lengths[p]) > vt.shape[2]:
+            raise RuntimeError('cross_attention_eq_stack: pair %d exceeds the packed rows / value columns' % p)
+    trace_idx = _req(trace_idx.contiguous(), torch.int64, 'trace_idx', 2)
+    R = trace_idx.shape[0]
+    qt = max((int(n) + 31) // 32 for n in q_lengths)
+    dev = q.device
+    partial = torch.empty((P * A * A * qt,), dtype=torch.float32, device=dev)
+    mix = torch.empty((P, A, A), dtype=torch.float32, device=dev)
+    weights = torch.empty((P, A * A if mode == 'a_soft' else R), dtype=torch.float32, device=dev)
+    check(lib().se3_cross_eq_stack_fwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(), _i64_array(q_starts), _i64_array(q_lengths),
+                                       _i64_array(k_starts), _i64_array(k_lengths), P, A, C, int(num_heads), q.stride(0), k.stride(0),
+                                       vt.stride(1), vt.stride(0), 0 if mode == 'a_soft' else 1, trace_idx.data_ptr(), R,
+                                       partial.data_ptr(), mix.data_ptr(), weights.data_ptr(), out.data_ptr(), _stream()),
+          'se3_cross_eq_stack_fwd')
+    return mix, weights
+
+
 _EMB_D_RANGE, _EMB_D_PER_UNIT = 64.0, 64.0        # distance-index table: [0, 64) index units, 64 entries per unit
 _EMB_A_PER_UNIT = 64.0
 _emb_table_cache = {}
