@@ -50,8 +50,11 @@ __device__ float exact_eval(const float* __restrict__ W, const float* __restrict
   return acc;
 }
 
-constexpr int kMB = 8;     // m values per workgroup iteration (indices staged in LDS)
+constexpr int kMB = 16;    // m values per workgroup iteration (indices and interpolation weights staged in LDS)
 
+// Per (m, term) the table interval and the four Hermite weights are the same for all C channels: they are computed once by
+// the staging threads (4 terms x kMB values) and broadcast from LDS, which leaves two table reads and four FMAs per channel and
+// term in the channel loop (the kernel is VALU bound: ~150 instructions per output before, ~50 now).
 __global__ void geo_embedding_kernel(const float* __restrict__ pts, const int64_t* __restrict__ knn, int N, int C,
                                      const float2* __restrict__ tab_d, const float2* __restrict__ tab_a, EmbParams P,
                                      const float* __restrict__ Wd, const float* __restrict__ bd,
@@ -59,6 +62,8 @@ __global__ void geo_embedding_kernel(const float* __restrict__ pts, const int64_
                                      const float* __restrict__ div_term, const float* __restrict__ wigner_d1,
                                      float* __restrict__ emb, float* __restrict__ eq_emb, int A) {
   __shared__ float idx_s[kMB][4];
+  __shared__ float4 wt_s[kMB][4];         // (h00, h01, h h10, h h11) of term t (0 = distance, 1..3 = angles)
+  __shared__ int j_s[kMB][4];             // table interval, -1 = outside the table (exact evaluation)
   __shared__ float unit_s[kMB][3];
   const int n = blockIdx.x;
   const int m_per = (N + gridDim.y - 1) / gridDim.y;
@@ -77,7 +82,8 @@ __global__ void geo_embedding_kernel(const float* __restrict__ pts, const int64_
       const int m = min(m0 + (int)threadIdx.x, N - 1);
       const float qx = pts[3 * m], qy = pts[3 * m + 1], qz = pts[3 * m + 2];
       const float d2 = fmaxf(nn2 - 2.f * (px * qx + py * qy + pz * qz) + (qx * qx + qy * qy + qz * qz), 0.f);
-      idx_s[threadIdx.x][0] = sqrtf(d2) * P.sigma_d_inv;
+      float x[4];
+      x[0] = sqrtf(d2) * P.sigma_d_inv;
       const float vx = qx - px, vy = qy - py, vz = qz - pz;
 #pragma unroll
       for (int k = 0; k < 3; k++) {
@@ -85,7 +91,20 @@ __global__ void geo_embedding_kernel(const float* __restrict__ pts, const int64_
         const float sn = sqrtf(cx * cx + cy * cy + cz * cz);
         float cs = rx[k] * vx + ry[k] * vy + rz[k] * vz;
         cs = (cs == 0.f) ? 0.f : cs;      // torch.sum yields +0 for an all-(-0) sum (the n == m diagonal): atan2(0, +0) = 0, not pi
-        idx_s[threadIdx.x][1 + k] = atan2f(sn, cs) * P.factor_a;
+        x[1 + k] = atan2f(sn, cs) * P.factor_a;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const float inv_h = t == 0 ? P.d_inv_h : P.a_inv_h;
+        const int entries = t == 0 ? P.d_entries : P.a_entries;
+        const float u = x[t] * inv_h;
+        const int j = (int)floorf(u);
+        const bool ok = (j >= 0) && (j + 1 < entries);
+        const float tt = u - (float)j, h = 1.0f / inv_h;
+        const float t2 = tt * tt, t3 = t2 * tt;
+        idx_s[threadIdx.x][t] = x[t];
+        j_s[threadIdx.x][t] = ok ? j : -1;
+        wt_s[threadIdx.x][t] = make_float4(2.f * t3 - 3.f * t2 + 1.f, -2.f * t3 + 3.f * t2, h * (t3 - 2.f * t2 + tt), h * (t3 - t2));
       }
       // unit vector of p_n - p_m for the equivariant embedding (zero vector -> 0, as F.normalize with eps 1e-12)
       const float len = sqrtf(vx * vx + vy * vy + vz * vz);
@@ -96,17 +115,20 @@ __global__ void geo_embedding_kernel(const float* __restrict__ pts, const int64_
     const int cnt = min(kMB, m_end - m0);
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       for (int i = 0; i < cnt; i++) {
-        bool ok;
-        float fd = hermite(tab_d, C, c, idx_s[i][0], P.d_inv_h, P.d_entries, ok);
-        if (!ok) fd = exact_eval(Wd, bd, div_term, C, c, idx_s[i][0]);
-        float fa = -INFINITY;
+        float val[4];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-          float v = hermite(tab_a, C, c, idx_s[i][1 + k], P.a_inv_h, P.a_entries, ok);
-          if (!ok) v = exact_eval(Wa, ba, div_term, C, c, idx_s[i][1 + k]);
-          fa = fmaxf(fa, v);
+        for (int t = 0; t < 4; t++) {
+          const int j = j_s[i][t];
+          if (j >= 0) {                                     // wave-uniform
+            const float2* tab = t == 0 ? tab_d : tab_a;
+            const float2 p0 = tab[(size_t)j * C + c], p1 = tab[(size_t)(j + 1) * C + c];
+            const float4 w = wt_s[i][t];
+            val[t] = (w.x * p0.x + w.y * p1.x) + (w.z * p0.y + w.w * p1.y);
+          } else {
+            val[t] = t == 0 ? exact_eval(Wd, bd, div_term, C, c, idx_s[i][0]) : exact_eval(Wa, ba, div_term, C, c, idx_s[i][t]);
+          }
         }
-        emb[((size_t)n * N + (m0 + i)) * C + c] = fd + fa;
+        emb[((size_t)n * N + (m0 + i)) * C + c] = val[0] + fmaxf(fmaxf(val[1], val[2]), val[3]);
       }
     }
     if (eq_emb != nullptr) {
