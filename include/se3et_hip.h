@@ -232,7 +232,7 @@ int se3_geo_embedding_fwd(const float* points, const int64_t* knn, int N, int C,
  * point_to_node (N) int64 = nearest node of every point; node_masks (M) uint8 = node owns at least one point;
  * node_knn_indices (M, limit) int64 = the `limit` nearest of the node's OWN points in ascending distance, padded with N;
  * node_knn_masks (M, limit) uint8.  Distances as pairwise_distance (modules/ops/pairwise_distance.py:4-30), ties by index.
- * limit <= 64. */
+ * limit <= 128. */
 int se3_knn3(const float* points, int N, int64_t* knn, void* stream);
 int se3_point_to_node_partition(const float* points, const float* nodes, int N, int M, int limit, int64_t* point_to_node,
                                 uint8_t* node_masks, int64_t* node_knn_indices, uint8_t* node_knn_masks, void* stream);

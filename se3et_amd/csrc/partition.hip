@@ -90,6 +90,29 @@ __global__ __launch_bounds__(256) void nearest_node_kernel(const float* __restri
   }
 }
 
+// two-register version of wave_insert: a 128-entry ascending list, ranks 0..63 in b0, 64..127 in b1
+__device__ __forceinline__ void wave_insert2(unsigned long long& b0, unsigned long long& b1, unsigned long long cand, bool has) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long pending = __ballot(has);
+  while (pending) {
+    const int src = __ffsll((long long)pending) - 1;
+    pending &= pending - 1;
+    const unsigned long long c = shfl64(cand, src);
+    const int pos = __popcll(__ballot(b0 < c)) + __popcll(__ballot(b1 < c));
+    const unsigned long long up0 = shfl_up1(b0), up1 = shfl_up1(b1), carry = shfl64(b0, 63);
+    if (pos < 64) {
+      if (lane == pos) b0 = c;
+      else if (lane > pos) b0 = up0;
+      b1 = lane == 0 ? carry : up1;
+    } else {
+      const int p1 = pos - 64;
+      if (lane == p1) b1 = c;
+      else if (lane > p1) b1 = up1;
+    }
+  }
+}
+
+template <bool WIDE>        // WIDE: limit in (64, 128]
 __global__ __launch_bounds__(256) void node_knn_kernel(const float* __restrict__ pts, const float* __restrict__ nodes,
                                                        const int64_t* __restrict__ point_to_node, int N, int M, int limit,
                                                        int64_t* __restrict__ knn, unsigned char* __restrict__ knn_masks) {
@@ -97,7 +120,7 @@ __global__ __launch_bounds__(256) void node_knn_kernel(const float* __restrict__
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
   const float nx = nodes[3 * m], ny = nodes[3 * m + 1], nz = nodes[3 * m + 2], n2 = sq_norm(nx, ny, nz);
-  unsigned long long best = ~0ull;          // lane r = r-th nearest own point
+  unsigned long long best = ~0ull, best1 = ~0ull;          // lane r = r-th (64 + r-th) nearest own point
   for (int j0 = 0; j0 < N; j0 += 64) {
     const int j = j0 + lane;
     const bool own = j < N && point_to_node[j] == (int64_t)m;
@@ -106,12 +129,18 @@ __global__ __launch_bounds__(256) void node_knn_kernel(const float* __restrict__
       const float px = pts[3 * j], py = pts[3 * j + 1], pz = pts[3 * j + 2];
       c = make_key(pair_dist(nx, ny, nz, n2, px, py, pz, sq_norm(px, py, pz)), (unsigned)j);
     }
-    wave_insert(best, c, own);
+    if (WIDE) wave_insert2(best, best1, c, own);
+    else wave_insert(best, c, own);
   }
   if (lane < limit) {
     const bool have = best != ~0ull;
     knn[(size_t)m * limit + lane] = have ? (int64_t)(unsigned)(best & 0xffffffffull) : (int64_t)N;
     knn_masks[(size_t)m * limit + lane] = have ? 1 : 0;
+  }
+  if (WIDE && 64 + lane < limit) {
+    const bool have = best1 != ~0ull;
+    knn[(size_t)m * limit + 64 + lane] = have ? (int64_t)(unsigned)(best1 & 0xffffffffull) : (int64_t)N;
+    knn_masks[(size_t)m * limit + 64 + lane] = have ? 1 : 0;
   }
 }
 
@@ -130,16 +159,20 @@ extern "C" int se3_point_to_node_partition(const float* points, const float* nod
                                            uint8_t* node_knn_masks, void* stream) {
   SE3_REQUIRE(points && nodes && point_to_node && node_masks && node_knn_indices && node_knn_masks, SE3_ERR_INVALID_ARG,
               "point_to_node_partition: null pointer");
-  SE3_REQUIRE(N >= 1 && M >= 1 && limit >= 1 && limit <= 64, SE3_ERR_UNSUPPORTED,
-              "point_to_node_partition: N %d M %d limit %d (limit <= 64)", N, M, limit);
+  SE3_REQUIRE(N >= 1 && M >= 1 && limit >= 1 && limit <= 128, SE3_ERR_UNSUPPORTED,
+              "point_to_node_partition: N %d M %d limit %d (limit <= 128)", N, M, limit);
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(node_masks, 0, (size_t)M, st) != hipSuccess) {
     se3_set_error("point_to_node_partition: memset failed");
     return SE3_ERR_LAUNCH;
   }
   nearest_node_kernel<<<(unsigned)se3_cdiv(N, 4), 256, 0, st>>>(points, nodes, N, M, point_to_node, node_masks);
-  node_knn_kernel<<<(unsigned)se3_cdiv(M, 4), 256, 0, st>>>(points, nodes, point_to_node, N, M, limit, node_knn_indices,
-                                                          node_knn_masks);
+  if (limit <= 64)
+    node_knn_kernel<false><<<(unsigned)se3_cdiv(M, 4), 256, 0, st>>>(points, nodes, point_to_node, N, M, limit,
+                                                                    node_knn_indices, node_knn_masks);
+  else
+    node_knn_kernel<true><<<(unsigned)se3_cdiv(M, 4), 256, 0, st>>>(points, nodes, point_to_node, N, M, limit,
+                                                                   node_knn_indices, node_knn_masks);
   SE3_CHECK_LAUNCH("point_to_node_partition");
   return SE3_OK;
 }

@@ -8,9 +8,7 @@ def point_to_node_partition(points, nodes, point_limit, return_count=False):
     """Assign every fine point to its nearest node and give every node the `point_limit` nearest of ITS OWN points
     (geotransformer/modules/ops/pointcloud_partition.py:60-107).  Returns (point_to_node (N,), [node_sizes (M,)],
     node_masks (M,), node_knn_indices (M, K) padded with N, node_knn_masks (M, K)).  One C call (two kernels,
-    csrc/partition.hip) instead of the reference's (M, N) distance matrix + argmin + masked top-k."""
-    if point_limit > 64:
-        raise NotImplementedError('point_to_node_partition (HIP): point_limit <= 64')
+    csrc/partition.hip) instead of the reference's (M, N) distance matrix + argmin + masked top-k.  K <= 128."""
     point_to_node, node_masks, knn, knn_masks = _ops.point_to_node_partition(points, nodes, point_limit)
     if return_count:
         sizes = torch.bincount(point_to_node, minlength=nodes.shape[0])

@@ -75,7 +75,8 @@ def test_real_width_model_matches_reference(golden_dir, variant, fixture):
     _check_outputs(out, g, full=False)
 
 
-@pytest.mark.parametrize('variant,preset,num_pairs', [('micro_e', 'micro', 2), ('micro_i', 'micro', 3), ('se3ete', 'c1_2k', 2)])
+@pytest.mark.parametrize('variant,preset,num_pairs', [('micro_e', 'micro', 2), ('micro_i', 'micro', 3), ('se3ete', 'c1_2k', 2),
+                                                      ('se3ete', 'c2_5k', 3), ('se3eti', 'c2_5k', 2), ('se3eti_kitti', 'c3_20k', 2)])
 def test_multi_pair_forward_equals_single_pair_forward(variant, preset, num_pairs):
     """se3et_amd.batched.forward_pairs (B pairs stacked through pyramid, backbone and transformer) against the single-pair
     forward of the same pairs: identical pyramids per pair, features to float32 round-off (the only arithmetic difference is
