@@ -256,6 +256,16 @@ int se3_weighted_procrustes(const float* src_points, const float* ref_points, co
                             float eps, float* transforms, void* stream);
 int se3_count_inliers(const float* src_points, const float* ref_points, int64_t num_points, const float* transforms,
                       int num_transforms, float radius, int32_t* votes, void* stream);
+/* Several registration pairs at once: gate_per_segment != 0 -> gate_transforms holds one (4, 4) per segment (the pair's
+ * current estimate); range_begin / range_end (DEVICE int64, one per transform) restrict hypothesis t to the correspondences
+ * [range_begin[t], range_end[t]) of its own pair. */
+int se3_weighted_procrustes_segments(const float* src_points, const float* ref_points, const float* scores,
+                                     const int64_t* segment_offsets, int num_segments, const float* gate_transforms,
+                                     int gate_per_segment, float gate_radius, float eps, float* transforms, void* stream);
+int se3_count_inliers_ranges(const float* src_points, const float* ref_points, int64_t num_points, const float* transforms,
+                             int num_transforms, const int64_t* range_begin, const int64_t* range_end, float radius,
+                             int32_t* votes, void* stream);
+
 /* Mutual top-k correspondence mask (local_global_registration.py:104-131): mask[b, i, j] = 1 iff scores[b, i, j] is among the k
  * largest of row i AND of column j of patch pair b (ties by index), exceeds `threshold`, and row_masks[b, i] & col_masks[b, j].
  * scores (batch, rows, cols) float32, masks uint8; rows * cols <= 16384. */

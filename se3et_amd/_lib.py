@@ -48,6 +48,8 @@ SIGNATURES = {
     'se3_weighted_procrustes': (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _f32, _f32, _vp, _vp]),
     'se3_mutual_topk_mask': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     'se3_count_inliers': (_i32, [_vp, _vp, _i64, _vp, _i32, _f32, _vp, _vp]),
+    'se3_count_inliers_ranges': (_i32, [_vp, _vp, _i64, _vp, _i32, _vp, _vp, _f32, _vp, _vp]),
+    'se3_weighted_procrustes_segments': (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _f32, _f32, _vp, _vp]),
     'se3_log_sinkhorn_fwd': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
 }
 

@@ -156,6 +156,47 @@ def transformer_pairs(gt, points_c, lengths_c, feats_c):
     return outs[:B], outs[B:]
 
 
+def registration_pairs(lgr, patches):
+    """LocalGlobalRegistration.forward for several pairs at once (same arithmetic per pair; one host synchronisation in all).
+    patches[p] = (ref_knn_points (B_p, K, 3), src_knn_points, ref_knn_masks (B_p, K), src_knn_masks, score_mat (B_p, K, K) log).
+    Returns per pair (ref_corr_points, src_corr_points, corr_scores, estimated_transform)."""
+    P = len(patches)
+    nb = [t[0].shape[0] for t in patches]
+    dev = patches[0][0].device
+    ref_pts = torch.cat([t[0] for t in patches], 0)
+    src_pts = torch.cat([t[1] for t in patches], 0)
+    score = torch.exp(torch.cat([t[4] for t in patches], 0))
+    BT = score.shape[0]
+    corr = SF.mutual_topk_mask(score, torch.cat([t[2] for t in patches], 0), torch.cat([t[3] for t in patches], 0), lgr.k,
+                               lgr.confidence_threshold)
+    b_idx, r_idx, c_idx = torch.nonzero(corr, as_tuple=True)                # the one host sync; patch-major = pair-major
+    ref_c, src_c = ref_pts[b_idx, r_idx].contiguous(), src_pts[b_idx, c_idx].contiguous()
+    sc = score[b_idx, r_idx, c_idx].contiguous()
+    counts = torch.bincount(b_idx, minlength=BT)
+    offsets = torch.zeros(BT + 1, dtype=torch.int64, device=dev)
+    offsets[1:] = torch.cumsum(counts, 0)
+    patch_off = _offsets(nb)                                                  # host: patches of pair p = [patch_off[p], patch_off[p+1])
+    bounds = offsets[torch.tensor(patch_off, device=dev)]                     # (P + 1,) correspondence range of every pair
+    pair_of_patch = torch.repeat_interleave(torch.arange(P, device=dev), torch.tensor(nb, device=dev))
+    # local hypotheses: one weighted Procrustes per patch pair, voted on by the correspondences of ITS pair
+    Ts = SF.weighted_procrustes(src_c, ref_c, sc, offsets)
+    votes = SF.count_inliers(src_c, ref_c, Ts, lgr.acceptance_radius, bounds[pair_of_patch], bounds[pair_of_patch + 1])
+    votes = torch.where(counts >= lgr.correspondence_threshold, votes, torch.full_like(votes, -1))
+    if len(set(nb)) == 1:
+        v = votes.view(P, nb[0])
+        best = torch.argmax(v, 1) + torch.arange(P, device=dev) * nb[0]       # first maximum in patch order, per pair
+        any_valid = v.amax(1) >= 0
+    else:
+        best = torch.stack([torch.argmax(votes[patch_off[p]:patch_off[p + 1]]) + patch_off[p] for p in range(P)])
+        any_valid = torch.stack([votes[patch_off[p]:patch_off[p + 1]].max() >= 0 for p in range(P)])
+    T_all = SF.weighted_procrustes(src_c, ref_c, sc, bounds)                  # degenerate case: all correspondences of the pair
+    T = torch.where(any_valid[:, None, None], Ts[best], T_all)
+    for _ in range(lgr.num_refinement_steps):
+        T = SF.weighted_procrustes(src_c, ref_c, sc, bounds, gate_transform=T, gate_radius=lgr.acceptance_radius)
+    cuts = bounds.tolist()                                                    # second (tiny) sync: per-pair slices of the outputs
+    return [(ref_c[cuts[p]:cuts[p + 1]], src_c[cuts[p]:cuts[p + 1]], sc[cuts[p]:cuts[p + 1]], T[p]) for p in range(P)]
+
+
 @torch.no_grad()
 def forward_pairs(model, data_dict, with_registration=True):
     """Inference forward of B pairs stacked as ref0, src0, ref1, src1, ... (data_dict from se3et_amd.data with 2 B lengths).
@@ -222,12 +263,13 @@ def forward_pairs(model, data_dict, with_registration=True):
     sk = torch.cat([t[1] for t in patches], 0)
     scores = torch.einsum('bnd,bmd->bnm', rk, sk) / feats_f.shape[1] ** 0.5
     scores = model.optimal_transport(scores, torch.cat([t[2] for t in patches], 0), torch.cat([t[3] for t in patches], 0))
-    start = 0
+    start, per_pair = 0, []
     for out, n, t in zip(outs, counts, patches):
         sc = scores[start:start + n]
         start += n
         out['matching_scores'] = sc
-        if with_registration:
-            rc, scp, cs, T = model.fine_matching(t[4], t[5], t[2], t[3], sc[:, :-1, :-1], t[6])
+        per_pair.append((t[4], t[5], t[2], t[3], sc[:, :-1, :-1]))
+    if with_registration:
+        for out, (rc, scp, cs, T) in zip(outs, registration_pairs(model.fine_matching, per_pair)):
             out.update(ref_corr_points=rc, src_corr_points=scp, corr_scores=cs, estimated_transform=T)
     return outs

@@ -111,14 +111,14 @@ __device__ double block_sum(double v, double* sh) {
 // one workgroup per segment
 __global__ __launch_bounds__(256) void procrustes_kernel(const float* __restrict__ src, const float* __restrict__ ref,
                                                          const float* __restrict__ score, const int64_t* __restrict__ offsets,
-                                                         const float* __restrict__ T_prev, float radius, float eps,
-                                                         float* __restrict__ T_out) {
+                                                         const float* __restrict__ T_prev, int gate_stride, float radius,
+                                                         float eps, float* __restrict__ T_out) {
   __shared__ double sh[4];
   const int64_t b0 = offsets[blockIdx.x], b1 = offsets[blockIdx.x + 1];
   float Tp[12];
   const bool gate = T_prev != nullptr;
   if (gate)
-    for (int i = 0; i < 12; i++) Tp[i] = T_prev[i];
+    for (int i = 0; i < 12; i++) Tp[i] = T_prev[(size_t)blockIdx.x * gate_stride + i];     // gate_stride 0: one transform for all
   auto weight = [&](int64_t i) -> float {
     float w = score[i];
     w = w < 0.f ? 0.f : w;
@@ -165,13 +165,16 @@ __global__ __launch_bounds__(256) void procrustes_kernel(const float* __restrict
 
 // votes[b] = number of correspondences with |ref - T_b src| < radius ; inlier mask optional (for the chosen hypothesis)
 __global__ __launch_bounds__(256) void vote_kernel(const float* __restrict__ src, const float* __restrict__ ref, int64_t total,
-                                                   const float* __restrict__ T, float radius, int32_t* __restrict__ votes) {
+                                                   const float* __restrict__ T, const int64_t* __restrict__ range_begin,
+                                                   const int64_t* __restrict__ range_end, float radius,
+                                                   int32_t* __restrict__ votes) {
   __shared__ int shv[4];
+  const int64_t lo = range_begin ? range_begin[blockIdx.x] : 0, hi = range_end ? range_end[blockIdx.x] : total;
   const float* Tb = T + 16 * blockIdx.x;
   float Tp[12];
   for (int i = 0; i < 12; i++) Tp[i] = Tb[i];
   int cnt = 0;
-  for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
+  for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     const float sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
     const float dx = ref[3 * i] - (Tp[0] * sx + Tp[1] * sy + Tp[2] * sz + Tp[3]);
     const float dy = ref[3 * i + 1] - (Tp[4] * sx + Tp[5] * sy + Tp[6] * sz + Tp[7]);
@@ -221,26 +224,44 @@ __global__ __launch_bounds__(256) void mutual_topk_kernel(const float* __restric
 
 }  // namespace
 
-extern "C" int se3_weighted_procrustes(const float* src_points, const float* ref_points, const float* scores,
-                                       const int64_t* segment_offsets, int num_segments, const float* gate_transform,
-                                       float gate_radius, float eps, float* transforms, void* stream) {
+extern "C" int se3_weighted_procrustes_segments(const float* src_points, const float* ref_points, const float* scores,
+                                                const int64_t* segment_offsets, int num_segments, const float* gate_transforms,
+                                                int gate_per_segment, float gate_radius, float eps, float* transforms,
+                                                void* stream) {
   SE3_REQUIRE(src_points && ref_points && scores && segment_offsets && transforms, SE3_ERR_INVALID_ARG,
               "weighted_procrustes: null pointer");
   SE3_REQUIRE(num_segments >= 0, SE3_ERR_INVALID_ARG, "weighted_procrustes: negative segment count");
   if (num_segments == 0) return SE3_OK;
   procrustes_kernel<<<num_segments, 256, 0, (hipStream_t)stream>>>(src_points, ref_points, scores, segment_offsets,
-                                                                   gate_transform, gate_radius, eps, transforms);
+                                                                   gate_transforms, gate_per_segment ? 16 : 0, gate_radius, eps,
+                                                                   transforms);
   SE3_CHECK_LAUNCH("weighted_procrustes");
+  return SE3_OK;
+}
+
+extern "C" int se3_weighted_procrustes(const float* src_points, const float* ref_points, const float* scores,
+                                       const int64_t* segment_offsets, int num_segments, const float* gate_transform,
+                                       float gate_radius, float eps, float* transforms, void* stream) {
+  return se3_weighted_procrustes_segments(src_points, ref_points, scores, segment_offsets, num_segments, gate_transform, 0,
+                                          gate_radius, eps, transforms, stream);
+}
+
+extern "C" int se3_count_inliers_ranges(const float* src_points, const float* ref_points, int64_t num_points,
+                                        const float* transforms, int num_transforms, const int64_t* range_begin,
+                                        const int64_t* range_end, float radius, int32_t* votes, void* stream) {
+  SE3_REQUIRE(src_points && ref_points && transforms && votes, SE3_ERR_INVALID_ARG, "count_inliers: null pointer");
+  SE3_REQUIRE((range_begin == nullptr) == (range_end == nullptr), SE3_ERR_INVALID_ARG, "count_inliers: ranges go together");
+  if (num_transforms <= 0) return SE3_OK;
+  vote_kernel<<<num_transforms, 256, 0, (hipStream_t)stream>>>(src_points, ref_points, num_points, transforms, range_begin,
+                                                              range_end, radius, votes);
+  SE3_CHECK_LAUNCH("count_inliers");
   return SE3_OK;
 }
 
 extern "C" int se3_count_inliers(const float* src_points, const float* ref_points, int64_t num_points,
                                  const float* transforms, int num_transforms, float radius, int32_t* votes, void* stream) {
-  SE3_REQUIRE(src_points && ref_points && transforms && votes, SE3_ERR_INVALID_ARG, "count_inliers: null pointer");
-  if (num_transforms <= 0) return SE3_OK;
-  vote_kernel<<<num_transforms, 256, 0, (hipStream_t)stream>>>(src_points, ref_points, num_points, transforms, radius, votes);
-  SE3_CHECK_LAUNCH("count_inliers");
-  return SE3_OK;
+  return se3_count_inliers_ranges(src_points, ref_points, num_points, transforms, num_transforms, nullptr, nullptr, radius, votes,
+                                  stream);
 }
 
 extern "C" int se3_mutual_topk_mask(const float* scores, const uint8_t* row_masks, const uint8_t* col_masks, int batch, int rows,

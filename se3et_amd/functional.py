@@ -253,5 +253,5 @@ def weighted_procrustes(src, ref, scores, offsets, gate_transform=None, gate_rad
     return _ops.weighted_procrustes(src, ref, scores, offsets, gate_transform, gate_radius, eps)
 
 
-def count_inliers(src, ref, transforms, radius):
-    return _ops.count_inliers(src, ref, transforms, radius)
+def count_inliers(src, ref, transforms, radius, range_begin=None, range_end=None):
+    return _ops.count_inliers(src, ref, transforms, radius, range_begin, range_end)

@@ -701,7 +701,8 @@ def mutual_topk_mask(scores, row_masks, col_masks, k, threshold):
 
 
 def weighted_procrustes(src, ref, scores, offsets, gate_transform=None, gate_radius=0.0, eps=1e-5):
-    """HIP (csrc/registration.hip): one weighted Kabsch solve per segment of the stacked correspondences -> (S, 4, 4)."""
+    """HIP (csrc/registration.hip): one weighted Kabsch solve per segment of the stacked correspondences -> (S, 4, 4).
+    gate_transform: (4, 4) shared by all segments, or (S, 4, 4) one per segment (several pairs at once)."""
     src = _req(src.contiguous(), torch.float32, 'src', 2)
     ref = _req(ref.contiguous(), torch.float32, 'ref', 2)
     scores = _req(scores.contiguous(), torch.float32, 'scores', 1)
@@ -709,17 +710,30 @@ def weighted_procrustes(src, ref, scores, offsets, gate_transform=None, gate_rad
     S = offsets.shape[0] - 1
     T = torch.empty((S, 4, 4), dtype=torch.float32, device=src.device)
     gt = _req(gate_transform.contiguous(), torch.float32, 'gate_transform') if gate_transform is not None else None
-    check(lib().se3_weighted_procrustes(src.data_ptr(), ref.data_ptr(), scores.data_ptr(), offsets.data_ptr(), S,
-                                        gt.data_ptr() if gt is not None else None, float(gate_radius), float(eps),
-                                        T.data_ptr(), _stream()), 'se3_weighted_procrustes')
+    per_segment = gt is not None and gt.dim() == 3
+    if per_segment and gt.shape[0] != S:
+        raise RuntimeError('weighted_procrustes: %d gate transforms for %d segments' % (gt.shape[0], S))
+    check(lib().se3_weighted_procrustes_segments(src.data_ptr(), ref.data_ptr(), scores.data_ptr(), offsets.data_ptr(), S,
+                                                 gt.data_ptr() if gt is not None else None, 1 if per_segment else 0,
+                                                 float(gate_radius), float(eps), T.data_ptr(), _stream()),
+          'se3_weighted_procrustes_segments')
     return T
 
 
-def count_inliers(src, ref, transforms, radius):
+def count_inliers(src, ref, transforms, radius, range_begin=None, range_end=None):
+    """HIP: votes[t] = number of correspondences i (in [range_begin[t], range_end[t]) if given, else all) with
+    |ref_i - T_t src_i| < radius."""
     src = _req(src.contiguous(), torch.float32, 'src', 2)
     ref = _req(ref.contiguous(), torch.float32, 'ref', 2)
     transforms = _req(transforms.contiguous(), torch.float32, 'transforms', 3)
     votes = torch.empty((transforms.shape[0],), dtype=torch.int32, device=src.device)
-    check(lib().se3_count_inliers(src.data_ptr(), ref.data_ptr(), src.shape[0], transforms.data_ptr(), transforms.shape[0],
-                                  float(radius), votes.data_ptr(), _stream()), 'se3_count_inliers')
+    if range_begin is not None:
+        range_begin = _req(range_begin.contiguous(), torch.int64, 'range_begin', 1)
+        range_end = _req(range_end.contiguous(), torch.int64, 'range_end', 1)
+        if range_begin.shape[0] != transforms.shape[0] or range_end.shape[0] != transforms.shape[0]:
+            raise RuntimeError('count_inliers: one range per transform')
+    check(lib().se3_count_inliers_ranges(src.data_ptr(), ref.data_ptr(), src.shape[0], transforms.data_ptr(), transforms.shape[0],
+                                         range_begin.data_ptr() if range_begin is not None else None,
+                                         range_end.data_ptr() if range_end is not None else None, float(radius),
+                                         votes.data_ptr(), _stream()), 'se3_count_inliers_ranges')
     return votes
