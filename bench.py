@@ -24,11 +24,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # HBM traffic of one RPE self-attention call relative to its algorithmic bytes, from the rocprofv3 PMC passes committed as
-# profiles/r01_pmc_attention.csv (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of tests/pmc_attention.py at N=M=382,
-# gfx950 correction: FETCH_SIZE x2 for the 16-B/lane streaming reads of rpe_bias_kernel; attention_kernel counters raw):
-#   eq  call: (2*94707.4 + 27506.2 + 23539.2 + 4308.0) KiB = 250.6 MB  vs 172.8 MB algorithmic
-#   inv call: (2*75382.9 +  4622.0 +  2451.9 +  718.0) KiB = 162.4 MB  vs 151.0 MB algorithmic
-PMC_TRAFFIC_RATIO = {'eq': 250.6 / 172.8, 'inv': 162.4 / 151.0}
+# profiles/r01_pmc_attention.csv (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of tests/pmc_attention.py on the stack-mode
+# kernels at the bench shape, 16 clouds per launch; gfx950 correction: FETCH_SIZE x2 for the 16-B/lane streaming reads of
+# rpe_bias_kernel -- its invariant variant then reads 2241 MB for 2223 MB of embedding --, attention_kernel counters raw):
+#   eq  call: (2*1337081.7 + 162945.9 + 203184.0 + 35277.1) KiB = 3149.4 MB  vs 2549.0 MB algorithmic
+#   inv call: (2*1094146.4 +  25740.0 +  33736.0 +  5860.6) KiB = 2307.7 MB  vs 2222.9 MB algorithmic
+PMC_TRAFFIC_RATIO = {'eq': 3149.4 / 2549.0, 'inv': 2307.7 / 2222.9}
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s is achievable
 
 

@@ -1,15 +1,19 @@
-"""Runs the RPE self-attention kernels a few times (for rocprofv3 --pmc passes): python3 tests/pmc_attention.py"""
-import sys; sys.path.insert(0, '.')
+"""Runs the stack-mode RPE self-attention kernels a few times at the bench shape (8 pairs = 16 clouds per launch, N = 382 / 350,
+C = 256, H = 4; equivariant A = 6 and invariant A = 1) for the rocprofv3 --pmc passes:
+    rocprofv3 --pmc FETCH_SIZE  --output-format csv -d out_fetch -- python3 tests/pmc_attention.py
+    rocprofv3 --pmc WRITE_SIZE  --output-format csv -d out_write -- python3 tests/pmc_attention.py
+and prints the algorithmic bytes of one call of each kind."""
+import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import importlib.util
 import torch
-from se3et_amd import functional as SF
-g = torch.Generator(device='cuda').manual_seed(0)
-r = lambda *s: torch.randn(*s, device='cuda', generator=g)
-for (A, N, eq) in ((6, 382, True), (1, 382, False)):
-    C, H = 256, 4
-    q, k, v = r(A, N, C), r(A, N, C), r(A, N, C)
-    emb = r(N, N, C); eqe = r(A, N, N, 4) if eq else None
-    wp, weq = r(C, C) / 16, (r(C, 4) if eq else None)
-    if A == 1: q, k, v = q[0], k[0], v[0]
-    vt = SF.project_values_transposed(v, torch.eye(C, device='cuda'), torch.zeros(C, device='cuda'))
-    for _ in range(5): SF.rpe_attention(q, k, vt, emb, wp, eqe, weq, H, False)
+spec = importlib.util.spec_from_file_location('bas', 'tests/bench_attention_stack.py'); bas = importlib.util.module_from_spec(spec); spec.loader.exec_module(bas)
+C, H = 256, 4
+lengths = (382, 350) * 8
+for A, eq in ((6, True), (1, False)):
+    proj, vt, embs, eqs, starts = bas.setup(A, lengths, eq)
+    out = torch.zeros(A, proj.shape[1], C, device='cuda')
+    for _ in range(4):
+        bas.call(proj, vt, embs, eqs, starts, lengths, out)
+    nbytes = sum(4 * (4 * A * n * C + n * n * C + (A * n * n * 4 if eq else 0)) for n in lengths)
+    print('A=%d eq=%d: algorithmic bytes per call %d' % (A, eq, nbytes))
 torch.cuda.synchronize()
