@@ -47,6 +47,8 @@ def main():
     ap.add_argument('--switch-interval', type=float, default=1e-3)
     ap.add_argument('--prefetch', type=int, default=0, help='build the pyramid of the next pair on a second host thread / HIP '
                     'stream while the current pair runs through the model (the reference does this in DataLoader workers)')
+    ap.add_argument('--attention-dtype', default='float32', choices=['float32', 'bfloat16'], help="'bfloat16': geometric embedding "
+                    "stored in bf16 (BASELINE.json configs[2] 'bf16 attention'); the headline metric is quoted on float32")
     ap.add_argument('--inflight', type=int, default=1, help='pairs in flight per GPU: host threads, one HIP stream each')
     args = ap.parse_args()
 
@@ -63,7 +65,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
-    cfg = make_cfg(args.variant)
+    cfg = make_cfg(args.variant, attention_dtype=args.attention_dtype)
     model = load_synthetic_weights(create_model(cfg)).to(dev).eval()
     total_steps = args.steps + args.warmup
     PB = max(1, args.batch)
@@ -191,17 +193,19 @@ def main():
         raise SystemExit('bench.py: %d timed RPE calls for %d recorded calls' % (len(per_call), len(calls)))
     kinds = {'eq': [0, 0.0, 0.0, 0.0], 'inv': [0, 0.0, 0.0, 0.0]}      # count, bytes, bias us, attention us
     for (nbytes, kind), (t_bias, t_attn) in zip(calls, per_call):
-        k = kinds[kind]
+        k = kinds[kind.replace('_bf16', '')]
         k[0] += 1; k[1] += nbytes; k[2] += t_bias; k[3] += t_attn
     n_call = len(calls)
     bytes_call = sum(k[1] for k in kinds.values())
     us_call = sum(k[2] + k[3] for k in kinds.values())
     achieved = bytes_call / (us_call * 1e-6) / 1e9 if us_call > 0 else 0.0
     traffic = sum(PMC_TRAFFIC_RATIO[name] * k[1] for name, k in kinds.items()) / max(n_call, 1)
+    if args.attention_dtype != 'float32':
+        traffic = None                 # the PMC passes were taken on the f32 kernels
     roofline = {
         'kernel': 'RPE self-attention call = rpe_bias_kernel + attention_kernel (both clouds of a pair per launch)',
         'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-        'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': int(traffic),
+        'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None if traffic is None else int(traffic),
         'traffic_source': 'bytes per call; PMC FETCH_SIZE(x2 on the streaming kernel)+WRITE_SIZE per algorithmic byte from '
                           'profiles/r01_pmc_attention.csv, applied to the calls of this run',
         'launches': n_call, 'avg_us': round(us_call / max(n_call, 1), 2),
@@ -222,11 +226,13 @@ def main():
             'metric': 'point-cloud pairs/sec (fwd), SE3ET-E 5k-pt pairs', 'value': round(world * args.steps * PB / elapsed, 3),
             'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f32' if args.attention_dtype == 'float32' else 'f32 (geometric embedding stored in bf16)',
+            'data': 'synthetic',
             'config': {'workload': 'SE3ET-E forward (pyramid + backbone + transformer + matching + Sinkhorn + LGR) on '
                                    'synthetic %d+%d-point pairs, %d pair(s) per rank per step' % (n, n, PB),
                        'variant': args.variant, 'pair_preset': args.pair, 'sharding': 'pairs round-robin over ranks, no collective',
-                       'pairs_per_forward': PB, 'pairs_in_flight_per_gpu': max(1, args.inflight), 'pyramid_prefetch': bool(args.prefetch)},
+                       'pairs_per_forward': PB, 'pairs_in_flight_per_gpu': max(1, args.inflight), 'pyramid_prefetch': bool(args.prefetch),
+                       'attention_dtype': args.attention_dtype},
             'roofline': roofline, 'cpu_baseline': cpu_baseline,
         }
         print(json.dumps(line), flush=True)

@@ -165,7 +165,7 @@ int se3_attention_fwd(const float* q, const float* k, const float* vt, const flo
  * key rows k_starts[c] .. + k_lengths[c] (self attention: the same rows; k_starts multiples of 32 because the transposed
  * values vt (anchors, C, v_row_stride) are addressed by key column).  emb_ptrs[c] -> (N_c, M_c, C), eq_ptrs[c] -> (A, N_c, M_c, 4)
  * or NULL (all clouds alike).  The logits of cloud c are the block bias + bias_offsets[c] of shape (A*H, N_c, ceil32(M_c)).
- * All arrays are HOST arrays of num_clouds (<= 4) entries.  out is (anchors, rows, C) in the packed row order. */
+ * All arrays are HOST arrays of num_clouds (<= 16) entries.  out is (anchors, rows, C) in the packed row order. */
 int se3_rpe_bias_stack_fwd(const float* qp, const float* qe, int row_stride, int64_t anchor_stride,
                            const float* const* emb_ptrs, const float* const* eq_ptrs, const int64_t* q_starts,
                            const int64_t* q_lengths, const int64_t* k_lengths, const int64_t* bias_offsets, int num_clouds,
@@ -186,6 +186,20 @@ int se3_rpe_self_attention_stack_fwd(const float* q, const float* k, const float
                                      const float* const* emb_ptrs, const float* const* eq_ptrs, const int64_t* starts,
                                      const int64_t* lengths, int num_clouds, int num_anchors, int C, int H,
                                      float* logits_workspace, int64_t out_anchor_stride, float* out, void* stream);
+
+/* bf16 geometric embedding (BASELINE.json configs[2]: "bf16 attention"): the same two calls with emb_ptrs[c] -> (N_c, M_c, C)
+ * bfloat16 (16-byte aligned, C a multiple of 32), which halves the N*M*C term of the call's HBM bytes.  Queries, keys, values,
+ * the equivariant embedding, the logits and the output stay float32; the folded queries are split into bf16 hi + lo parts
+ * inside the kernel, so the only rounding is the stored embedding itself (2^-9 relative per element). */
+int se3_rpe_bias_stack_bf16_fwd(const float* qp, const float* qe, int row_stride, int64_t anchor_stride,
+                                const uint16_t* const* emb_ptrs, const float* const* eq_ptrs, const int64_t* q_starts,
+                                const int64_t* q_lengths, const int64_t* k_lengths, const int64_t* bias_offsets, int num_clouds,
+                                int C, int AH, int H, float* bias, void* stream);
+int se3_rpe_self_attention_stack_bf16_fwd(const float* q, const float* k, const float* vt, const float* qp, const float* qe,
+                                          int row_stride, int64_t anchor_stride, int v_row_stride, int64_t v_anchor_stride,
+                                          const uint16_t* const* emb_ptrs, const float* const* eq_ptrs, const int64_t* starts,
+                                          const int64_t* lengths, int num_clouds, int num_anchors, int C, int H,
+                                          float* logits_workspace, int64_t out_anchor_stride, float* out, void* stream);
 
 /* ---- D4/D5: anchor-equivariant cross attention (MultiHeadAttentionEQ, 'a_soft' / 'r_soft') ----------------------------
  * Replaces geotransformer/modules/transformer/vanilla_transformer.py:247-476,506-577,751-870.  q (A, N, C), k/v (A, M, C).
@@ -224,6 +238,12 @@ int se3_geo_embedding_fwd(const float* points, const int64_t* knn, int N, int C,
                           float sigma_d, float sigma_a, const float* w_d, const float* b_d, const float* w_a, const float* b_a,
                           const float* div_term, const float* wigner_d1, int num_anchors, float* emb, float* eq_emb,
                           void* stream);
+/* Same, emb (N, N, C) written as bfloat16 (round to nearest even of the float32 value); eq_emb stays float32. */
+int se3_geo_embedding_bf16_fwd(const float* points, const int64_t* knn, int N, int C, const float* table_d, int d_entries,
+                               float d_entries_per_unit, const float* table_a, int a_entries, float a_entries_per_unit,
+                               float sigma_d, float sigma_a, const float* w_d, const float* b_d, const float* w_a,
+                               const float* b_a, const float* div_term, const float* wigner_d1, int num_anchors, uint16_t* emb,
+                               float* eq_emb, void* stream);
 
 /* ---- G1 / E3: nearest-neighbour selections on the superpoint level ----------------------------------------------------
  * se3_knn3: knn (N, 3) int64 = the 3 nearest OTHER points of every point (get_embedding_indices,

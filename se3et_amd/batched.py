@@ -100,9 +100,9 @@ def transformer_pairs(gt, points_c, lengths_c, feats_c):
         args = (pts, emb_mod.embedding.div_term, emb_mod.proj_d.weight, emb_mod.proj_d.bias, emb_mod.proj_a.weight,
                 emb_mod.proj_a.bias, emb_mod.sigma_d, emb_mod.sigma_a, emb_mod.angle_k)
         if gt.n_level_equiv > 0:
-            e, q = SF.geometric_embedding(*args, wigner_d1=emb_mod.anchors_wignerD[1])
+            e, q = SF.geometric_embedding(*args, wigner_d1=emb_mod.anchors_wignerD[1], dtype=emb_mod.embedding_dtype)
         else:
-            e, q = SF.geometric_embedding(*args), None
+            e, q = SF.geometric_embedding(*args, dtype=emb_mod.embedding_dtype), None
         embs.append(e)
         eqs.append(q)
     # packing: all refs first, then all srcs, so that both halves are contiguous row ranges of one tensor

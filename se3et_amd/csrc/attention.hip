@@ -25,6 +25,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float f4get(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
@@ -66,6 +67,20 @@ __device__ __forceinline__ StackCloud stack_pick(const Stack& S, int idx) {
 // =====================================================================================================================
 // rpe_bias_kernel
 // =====================================================================================================================
+// round-to-nearest-even bf16 of x, and of the remainder x - hi (finite inputs)
+__device__ __forceinline__ unsigned bf16_bits(float x) {
+  unsigned u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ void split_bf16x4(const float4& v, uint2& hi, uint2& lo) {
+  const unsigned h0 = bf16_bits(v.x), h1 = bf16_bits(v.y), h2 = bf16_bits(v.z), h3 = bf16_bits(v.w);
+  const unsigned l0 = bf16_bits(v.x - __uint_as_float(h0 << 16)), l1 = bf16_bits(v.y - __uint_as_float(h1 << 16));
+  const unsigned l2 = bf16_bits(v.z - __uint_as_float(h2 << 16)), l3 = bf16_bits(v.w - __uint_as_float(h3 << 16));
+  hi = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+  lo = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+}
+
 constexpr int kStageStride = 36;     // floats per staged logits row (32 keys + 4: the 4 lane groups of a store hit disjoint banks)
 
 // One 16-key tile of the relative-position logits: 4 RT MFMAs per 16-channel chunk against the LDS-resident folded queries;
@@ -75,15 +90,20 @@ constexpr int kStageStride = 36;     // floats per staged logits row (32 keys + 
 // Erow / eq_row are wave-uniform bases; EQ / UA are compile-time because a run-time branch around the e4 loads would put
 // their s_waitcnt vmcnt(0) at the top of every tile and drain the prefetched loads.  UA (H % 4 == 0): the 4 rows a lane owns
 // in a row tile share one anchor.
-template <int CT, int RT, bool NEXT, bool EQ, bool UA>
-__device__ __forceinline__ void bias_tile(float4 (&b)[CT], const float4* afrag, const float4* qe_s, float* stage, int col0,
-                                          const float* Erow, const float* eq_row, unsigned eq_anchor_stride, int tile,
+// BF: the embedding is stored in bf16.  In 4-byte words the address pattern is the f32 one with half the row stride and half
+// the chunks (a lane's 16-byte load = 8 consecutive channels = its B operand of v_mfma_f32_16x16x32_bf16); the folded queries
+// are split into bf16 hi + lo fragments (two MFMAs per chunk and row tile: the query side stays exact to 2^-16).
+template <int CT, int RT, bool NEXT, bool EQ, bool UA, bool BF>
+__device__ __forceinline__ void bias_tile(float4 (&b)[BF ? CT / 2 : CT], const float4* afrag, const float4* qe_s, float* stage,
+                                          int col0, const float* Erow, const float* eq_row, unsigned eq_anchor_stride, int tile,
                                           int next_tile, int M, int AH, int H) {
-  constexpr int C = CT * 16;
+  constexpr int CTB = BF ? CT / 2 : CT;      // 16-byte register chunks per tile and lane
+  constexpr int CE = CTB * 16;               // embedding row stride in 4-byte words
+  constexpr int NF = BF ? 2 * RT : RT;       // A fragments per chunk (bf16: hi and lo)
   const int lane = threadIdx.x & 63, col = lane & 15, kq = lane >> 4;
   asm volatile("" ::: "memory");        // keeps the LDS fragment reads inside the tile loop (otherwise hoisted and spilled)
   const int m = (tile << 4) + col;
-  const float* Enext = Erow + ((unsigned)min((next_tile << 4) + col, M - 1) * C + 4 * kq);     // chunk t at +16 t (immediate)
+  const float* Enext = Erow + ((unsigned)min((next_tile << 4) + col, M - 1) * CE + 4 * kq);     // chunk t at +16 t (immediate)
   float4 e4[RT];
   if (EQ && UA) {
 #pragma unroll
@@ -92,33 +112,43 @@ __device__ __forceinline__ void bias_tile(float4 (&b)[CT], const float4* afrag, 
       e4[rt] = ld4(eq_row + ((unsigned)a * eq_anchor_stride + (unsigned)min(m, M - 1) * 4));
     }
   }
-  f32x4 acc[RT];
+  f32x4 acc[RT], acc_lo[RT];
 #pragma unroll
-  for (int rt = 0; rt < RT; rt++) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float4 a[RT];
+  for (int rt = 0; rt < RT; rt++) acc[rt] = acc_lo[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 a[NF];
 #pragma unroll
-  for (int rt = 0; rt < RT; rt++) a[rt] = afrag[(rt * CT) * 64 + lane];
+  for (int f = 0; f < NF; f++) a[f] = afrag[(f * CTB) * 64 + lane];
 #pragma unroll
-  for (int t = 0; t < CT; t++) {
-    // one scheduling group per channel chunk: [LDS fragments of chunk t+1] [4 RT MFMAs of chunk t] [reload of b[t]]; the
-    // barrier keeps the machine scheduler from sinking the 16 reloads behind the last MFMA (which would undo the prefetch)
-    float4 an[RT];
-    if (t + 1 < CT) {
+  for (int t = 0; t < CTB; t++) {
+    // one scheduling group per chunk: [LDS fragments of chunk t+1] [the MFMAs of chunk t] [reload of b[t]]; the barrier keeps
+    // the machine scheduler from sinking the reloads behind the last MFMA (which would undo the prefetch)
+    float4 an[NF];
+    if (t + 1 < CTB) {
 #pragma unroll
-      for (int rt = 0; rt < RT; rt++) an[rt] = afrag[(rt * CT + t + 1) * 64 + lane];
+      for (int f = 0; f < NF; f++) an[f] = afrag[(f * CTB + t + 1) * 64 + lane];
     }
     const float4 bt = b[t];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
+    if (BF) {
+      const bf16x8 bb = __builtin_bit_cast(bf16x8, bt);
 #pragma unroll
       for (int rt = 0; rt < RT; rt++)
-        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(a[rt], i), f4get(bt, i), acc[rt], 0, 0, 0);
+        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[rt]), bb, acc[rt], 0, 0, 0);
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++)
+        acc_lo[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[RT + rt]), bb, acc_lo[rt], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+          acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(a[rt], i), f4get(bt, i), acc[rt], 0, 0, 0);
+      }
     }
     if (NEXT) b[t] = ld4(Enext + 16 * t);
     __builtin_amdgcn_sched_barrier(0);
-    if (t + 1 < CT) {
+    if (t + 1 < CTB) {
 #pragma unroll
-      for (int rt = 0; rt < RT; rt++) a[rt] = an[rt];
+      for (int f = 0; f < NF; f++) a[f] = an[f];
     }
   }
 #pragma unroll
@@ -126,7 +156,7 @@ __device__ __forceinline__ void bias_tile(float4 (&b)[CT], const float4* afrag, 
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int row = 16 * rt + 4 * kq + j;      // rows >= AH: zero queries, never written out
-      float val = acc[rt][j];
+      float val = BF ? acc[rt][j] + acc_lo[rt][j] : acc[rt][j];
       if (EQ) {
         const float4 e = UA ? e4[rt]
                             : ld4(eq_row + ((unsigned)min(row / H, AH / H - 1) * eq_anchor_stride + (unsigned)min(m, M - 1) * 4));
@@ -142,12 +172,13 @@ __device__ __forceinline__ void bias_tile(float4 (&b)[CT], const float4* afrag, 
 // range [w U / G, (w+1) U / G) and walks it row segment by row segment (the folded queries of the segment's row are staged
 // in LDS in MFMA-fragment order); inside a segment the 4 waves stride over the units.  A unit = two 16-key tiles whose
 // logits are collected in a wave-private LDS block and written out as full 128-byte row segments (float4 per lane).
-template <int CT, int RT, int MINW, bool EQ, bool UA>
+template <int CT, int RT, int MINW, bool EQ, bool UA, bool BF = false>
 __global__ __launch_bounds__(256, MINW) void rpe_bias_kernel(const float* __restrict__ qp, const float* __restrict__ qe,
                                                              int qp_rs, long long qp_sa, Stack S, int AH, int H,
                                                              float* __restrict__ bias) {
   constexpr int C = CT * 16;
-  __shared__ float4 afrag[RT * CT * 64];
+  constexpr int CTB = BF ? CT / 2 : CT, CE = CTB * 16;      // 16-byte chunks per tile and lane, row stride in 4-byte words
+  __shared__ float4 afrag[RT * CT * 64];                    // bf16: hi fragments, then lo fragments (same size)
   __shared__ float4 qe_s[32];
   __shared__ __attribute__((aligned(16))) float stage_s[4 * RT * 16 * kStageStride];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, kq = lane >> 4;
@@ -165,7 +196,7 @@ __global__ __launch_bounds__(256, MINW) void rpe_bias_kernel(const float* __rest
     const int u_hi = min(units, u_lo + (f_end - f));
     f += u_hi - u_lo;
 
-    const float* Erow = cl.emb + (size_t)n * cl.M * C;           // wave-uniform base of the embedding row block
+    const float* Erow = cl.emb + (size_t)n * cl.M * CE;          // wave-uniform base of the embedding row block
     int unit = u_lo + wave;
     // Issue order (the VMEM counter is in-order): folded queries of packed row q_start + n first, then the wave's first
     // embedding tile; the queries are waited for and written to LDS while the tile is still in flight.
@@ -189,19 +220,32 @@ __global__ __launch_bounds__(256, MINW) void rpe_bias_kernel(const float* __rest
       const int a = threadIdx.x / H, h = threadIdx.x - a * H;
       qev = ld4(qe + (size_t)a * qp_sa + qrow + 4 * h);
     }
-    float4 b[CT];
+    float4 b[CTB];
     if (unit < u_hi) {
-      const float* E0 = Erow + ((unsigned)min((unit << 5) + col, cl.M - 1) * C + 4 * kq);
+      const float* E0 = Erow + ((unsigned)min((unit << 5) + col, cl.M - 1) * CE + 4 * kq);
 #pragma unroll
-      for (int t = 0; t < CT; t++) b[t] = ld4(E0 + 16 * t);
+      for (int t = 0; t < CTB; t++) b[t] = ld4(E0 + 16 * t);
     }
     __syncthreads();                      // the previous segment's fragment reads are done
 #pragma unroll
     for (int u = 0; u < QI; u++) {
       const int i = threadIdx.x + 256 * u;
       const int row = i % (RT * 16), c4 = i / (RT * 16);
-      const int t = c4 >> 2, kk = c4 & 3;
-      if (i < QTOT) afrag[((row >> 4) * CT + t) * 64 + kk * 16 + (row & 15)] = qv[u];
+      if (BF) {
+        // bf16 fragment (rt, t32)[kq * 16 + r] = channels 32 t32 + 8 kq .. +7 of row 16 rt + r: this float4 is one 8-byte half
+        const int t32 = c4 >> 3, kk = (c4 >> 1) & 3, hf = c4 & 1;
+        uint2 hi, lo;
+        split_bf16x4(qv[u], hi, lo);
+        uint2* af2 = reinterpret_cast<uint2*>(afrag);
+        const int slot = ((((row >> 4) * CTB + t32) * 64 + kk * 16 + (row & 15)) << 1) + hf;
+        if (i < QTOT) {
+          af2[slot] = hi;
+          af2[slot + RT * CTB * 64 * 2] = lo;
+        }
+      } else {
+        const int t = c4 >> 2, kk = c4 & 3;
+        if (i < QTOT) afrag[((row >> 4) * CT + t) * 64 + kk * 16 + (row & 15)] = qv[u];
+      }
     }
     if (threadIdx.x < 32) qe_s[threadIdx.x] = qev;
     __syncthreads();
@@ -212,11 +256,11 @@ __global__ __launch_bounds__(256, MINW) void rpe_bias_kernel(const float* __rest
     const unsigned bias_ah = (unsigned)cl.N * cl.Mp;
     for (; unit < u_hi; unit += 4) {
       const int t0 = unit << 1;
-      bias_tile<CT, RT, true, EQ, UA>(b, afrag, qe_s, stage, 0, Erow, eq_row, eq_sa, t0, t0 + 1, cl.M, AH, H);
+      bias_tile<CT, RT, true, EQ, UA, BF>(b, afrag, qe_s, stage, 0, Erow, eq_row, eq_sa, t0, t0 + 1, cl.M, AH, H);
       if (unit + 4 < u_hi)
-        bias_tile<CT, RT, true, EQ, UA>(b, afrag, qe_s, stage, 16, Erow, eq_row, eq_sa, t0 + 1, t0 + 8, cl.M, AH, H);
+        bias_tile<CT, RT, true, EQ, UA, BF>(b, afrag, qe_s, stage, 16, Erow, eq_row, eq_sa, t0 + 1, t0 + 8, cl.M, AH, H);
       else
-        bias_tile<CT, RT, false, EQ, UA>(b, afrag, qe_s, stage, 16, Erow, eq_row, eq_sa, t0 + 1, t0 + 1, cl.M, AH, H);
+        bias_tile<CT, RT, false, EQ, UA, BF>(b, afrag, qe_s, stage, 16, Erow, eq_row, eq_sa, t0 + 1, t0 + 1, cl.M, AH, H);
       // the unit's (rows, 32 keys) block: 8 lanes cover one row's 128 bytes
       const int r8 = lane >> 3, m4 = (lane & 7) * 4;
 #pragma unroll
@@ -986,7 +1030,7 @@ static int device_cu_count() {
 }
 
 static int launch_rpe_bias(const float* qp, const float* qe, int row_stride, int64_t anchor_stride, Stack& S, int C, int AH,
-                           int H, float* bias, hipStream_t st) {
+                           int H, float* bias, hipStream_t st, bool emb_bf16 = false) {
   long long total = 0;
   for (int c = 0; c < S.n; c++) {
     const StackCloud& cl = S.c[c];
@@ -1007,7 +1051,11 @@ static int launch_rpe_bias(const float* qp, const float* qe, int row_stride, int
   dim3 grid((unsigned)wgs);
 #define SE3_BIAS_ARGS qp, qe, row_stride, anchor_stride, S, AH, H, bias
 #define SE3_BIAS_LAUNCH_RT(CT, RT)                                                                                   \
-  if (qe == nullptr) {                                                                                               \
+  if (emb_bf16) {                                                                                                    \
+    if (qe == nullptr) launch_kernel(1, rpe_bias_kernel<CT, RT, 3, false, true, true>, grid, dim3(256), st, SE3_BIAS_ARGS);           \
+    else if (H % 4 == 0) launch_kernel(1, rpe_bias_kernel<CT, RT, 3, true, true, true>, grid, dim3(256), st, SE3_BIAS_ARGS);          \
+    else launch_kernel(1, rpe_bias_kernel<CT, RT, 2, true, false, true>, grid, dim3(256), st, SE3_BIAS_ARGS);                         \
+  } else if (qe == nullptr) {                                                                                               \
     if (g_bias_variant == 2) launch_kernel(1, rpe_bias_kernel<CT, RT, 2, false, true>, grid, dim3(256), st, SE3_BIAS_ARGS);           \
     else launch_kernel(1, rpe_bias_kernel<CT, RT, 3, false, true>, grid, dim3(256), st, SE3_BIAS_ARGS);                               \
   } else if (H % 4 == 0) {                                                                                           \
@@ -1054,10 +1102,10 @@ extern "C" int se3_rpe_bias_fwd(const float* qp, const float* qe, int row_stride
   return launch_rpe_bias(qp, qe, row_stride, anchor_stride, S, C, AH, H, bias, (hipStream_t)stream);
 }
 
-extern "C" int se3_rpe_bias_stack_fwd(const float* qp, const float* qe, int row_stride, int64_t anchor_stride,
-                                      const float* const* emb_ptrs, const float* const* eq_ptrs, const int64_t* q_starts,
-                                      const int64_t* q_lengths, const int64_t* k_lengths, const int64_t* bias_offsets,
-                                      int num_clouds, int C, int AH, int H, float* bias, void* stream) {
+static int rpe_bias_stack(const float* qp, const float* qe, int row_stride, int64_t anchor_stride, const void* const* emb_ptrs,
+                          const float* const* eq_ptrs, const int64_t* q_starts, const int64_t* q_lengths,
+                          const int64_t* k_lengths, const int64_t* bias_offsets, int num_clouds, int C, int AH, int H,
+                          float* bias, void* stream, bool emb_bf16) {
   SE3_REQUIRE(qp && emb_ptrs && q_starts && q_lengths && k_lengths && bias_offsets && bias, SE3_ERR_INVALID_ARG,
               "rpe_bias_stack: null pointer");
   SE3_REQUIRE(num_clouds >= 1 && num_clouds <= kMaxClouds, SE3_ERR_UNSUPPORTED, "rpe_bias_stack: %d clouds (1..%d)", num_clouds,
@@ -1073,10 +1121,29 @@ extern "C" int se3_rpe_bias_stack_fwd(const float* qp, const float* qe, int row_
     SE3_REQUIRE((qe == nullptr) == (eq_ptrs == nullptr || eq_ptrs[c] == nullptr), SE3_ERR_INVALID_ARG,
                 "rpe_bias_stack: qe and the equivariant embeddings go together");
     const int M = (int)k_lengths[c];
-    S.c[c] = StackCloud{emb_ptrs[c], qe ? eq_ptrs[c] : nullptr, (int)q_starts[c], 0, (int)q_lengths[c], M, ((M + 31) / 32) * 32,
+    SE3_REQUIRE(((uintptr_t)emb_ptrs[c] & 15) == 0, SE3_ERR_INVALID_ARG, "rpe_bias_stack: embedding %d is not 16-byte aligned", c);
+    S.c[c] = StackCloud{static_cast<const float*>(emb_ptrs[c]), qe ? eq_ptrs[c] : nullptr, (int)q_starts[c], 0, (int)q_lengths[c], M, ((M + 31) / 32) * 32,
                         0, (long long)bias_offsets[c]};
   }
-  return launch_rpe_bias(qp, qe, row_stride, anchor_stride, S, C, AH, H, bias, (hipStream_t)stream);
+  return launch_rpe_bias(qp, qe, row_stride, anchor_stride, S, C, AH, H, bias, (hipStream_t)stream, emb_bf16);
+}
+
+extern "C" int se3_rpe_bias_stack_fwd(const float* qp, const float* qe, int row_stride, int64_t anchor_stride,
+                                      const float* const* emb_ptrs, const float* const* eq_ptrs, const int64_t* q_starts,
+                                      const int64_t* q_lengths, const int64_t* k_lengths, const int64_t* bias_offsets,
+                                      int num_clouds, int C, int AH, int H, float* bias, void* stream) {
+  return rpe_bias_stack(qp, qe, row_stride, anchor_stride, reinterpret_cast<const void* const*>(emb_ptrs), eq_ptrs, q_starts,
+                        q_lengths, k_lengths, bias_offsets, num_clouds, C, AH, H, bias, stream, false);
+}
+
+extern "C" int se3_rpe_bias_stack_bf16_fwd(const float* qp, const float* qe, int row_stride, int64_t anchor_stride,
+                                           const uint16_t* const* emb_ptrs, const float* const* eq_ptrs,
+                                           const int64_t* q_starts, const int64_t* q_lengths, const int64_t* k_lengths,
+                                           const int64_t* bias_offsets, int num_clouds, int C, int AH, int H, float* bias,
+                                           void* stream) {
+  SE3_REQUIRE(C % 32 == 0, SE3_ERR_UNSUPPORTED, "rpe_bias_stack_bf16: channels %d not a multiple of 32", C);
+  return rpe_bias_stack(qp, qe, row_stride, anchor_stride, reinterpret_cast<const void* const*>(emb_ptrs), eq_ptrs, q_starts,
+                        q_lengths, k_lengths, bias_offsets, num_clouds, C, AH, H, bias, stream, true);
 }
 
 static int launch_attention(AttnArgs& p, hipStream_t st) {
@@ -1156,12 +1223,12 @@ extern "C" int se3_attention_stack_fwd(const float* q, const float* k, const flo
   return launch_attention(p, (hipStream_t)stream);
 }
 
-extern "C" int se3_rpe_self_attention_stack_fwd(const float* q, const float* k, const float* vt, const float* qp,
-                                                const float* qe, int row_stride, int64_t anchor_stride, int v_row_stride,
-                                                int64_t v_anchor_stride, const float* const* emb_ptrs,
-                                                const float* const* eq_ptrs, const int64_t* starts, const int64_t* lengths,
-                                                int num_clouds, int num_anchors, int C, int H, float* logits_workspace,
-                                                int64_t out_anchor_stride, float* out, void* stream) {
+static int rpe_self_attention_stack(const float* q, const float* k, const float* vt, const float* qp, const float* qe,
+                                    int row_stride, int64_t anchor_stride, int v_row_stride, int64_t v_anchor_stride,
+                                    const void* const* emb_ptrs, const float* const* eq_ptrs, const int64_t* starts,
+                                    const int64_t* lengths, int num_clouds, int num_anchors, int C, int H,
+                                    float* logits_workspace, int64_t out_anchor_stride, float* out, void* stream,
+                                    bool emb_bf16) {
   SE3_REQUIRE(starts && lengths && logits_workspace, SE3_ERR_INVALID_ARG, "rpe_self_attention_stack: null pointer");
   SE3_REQUIRE(num_clouds >= 1 && num_clouds <= kMaxClouds, SE3_ERR_UNSUPPORTED, "rpe_self_attention_stack: %d clouds (1..%d)",
               num_clouds, kMaxClouds);
@@ -1171,12 +1238,36 @@ extern "C" int se3_rpe_self_attention_stack_fwd(const float* q, const float* k, 
     offsets[c] = total;
     total += (int64_t)num_anchors * H * lengths[c] * (((lengths[c] + 31) / 32) * 32);
   }
-  int rc = se3_rpe_bias_stack_fwd(qp, qe, row_stride, anchor_stride, emb_ptrs, eq_ptrs, starts, lengths, lengths, offsets,
-                                  num_clouds, C, num_anchors * H, H, logits_workspace, stream);
+  int rc = rpe_bias_stack(qp, qe, row_stride, anchor_stride, emb_ptrs, eq_ptrs, starts, lengths, lengths, offsets, num_clouds, C,
+                          num_anchors * H, H, logits_workspace, stream, emb_bf16);
   if (rc != SE3_OK) return rc;
   return se3_attention_stack_fwd(q, k, vt, logits_workspace, starts, lengths, starts, lengths, offsets, num_clouds, num_anchors,
                                  C, H, row_stride, row_stride, v_row_stride, anchor_stride, anchor_stride, v_anchor_stride,
                                  out_anchor_stride, 1.0f / sqrtf((float)(C / H)), out, stream);
+}
+
+extern "C" int se3_rpe_self_attention_stack_fwd(const float* q, const float* k, const float* vt, const float* qp,
+                                                const float* qe, int row_stride, int64_t anchor_stride, int v_row_stride,
+                                                int64_t v_anchor_stride, const float* const* emb_ptrs,
+                                                const float* const* eq_ptrs, const int64_t* starts, const int64_t* lengths,
+                                                int num_clouds, int num_anchors, int C, int H, float* logits_workspace,
+                                                int64_t out_anchor_stride, float* out, void* stream) {
+  return rpe_self_attention_stack(q, k, vt, qp, qe, row_stride, anchor_stride, v_row_stride, v_anchor_stride,
+                                  reinterpret_cast<const void* const*>(emb_ptrs), eq_ptrs, starts, lengths, num_clouds,
+                                  num_anchors, C, H, logits_workspace, out_anchor_stride, out, stream, false);
+}
+
+extern "C" int se3_rpe_self_attention_stack_bf16_fwd(const float* q, const float* k, const float* vt, const float* qp,
+                                                     const float* qe, int row_stride, int64_t anchor_stride, int v_row_stride,
+                                                     int64_t v_anchor_stride, const uint16_t* const* emb_ptrs,
+                                                     const float* const* eq_ptrs, const int64_t* starts,
+                                                     const int64_t* lengths, int num_clouds, int num_anchors, int C, int H,
+                                                     float* logits_workspace, int64_t out_anchor_stride, float* out,
+                                                     void* stream) {
+  SE3_REQUIRE(C % 32 == 0, SE3_ERR_UNSUPPORTED, "rpe_self_attention_stack_bf16: channels %d not a multiple of 32", C);
+  return rpe_self_attention_stack(q, k, vt, qp, qe, row_stride, anchor_stride, v_row_stride, v_anchor_stride,
+                                  reinterpret_cast<const void* const*>(emb_ptrs), eq_ptrs, starts, lengths, num_clouds,
+                                  num_anchors, C, H, logits_workspace, out_anchor_stride, out, stream, true);
 }
 
 extern "C" int se3_cross_eq_stats(const float* q, const float* k, int A, int N, int M, int C, int H, float scale,

@@ -60,7 +60,9 @@ __global__ void geo_embedding_kernel(const float* __restrict__ pts, const int64_
                                      const float* __restrict__ Wd, const float* __restrict__ bd,
                                      const float* __restrict__ Wa, const float* __restrict__ ba,
                                      const float* __restrict__ div_term, const float* __restrict__ wigner_d1,
-                                     float* __restrict__ emb, float* __restrict__ eq_emb, int A) {
+                                     void* __restrict__ emb_out, int emb_bf16, float* __restrict__ eq_emb, int A) {
+  float* emb = static_cast<float*>(emb_out);
+  unsigned short* emb16 = static_cast<unsigned short*>(emb_out);
   __shared__ float idx_s[kMB][4];
   __shared__ float4 wt_s[kMB][4];         // (h00, h01, h h10, h h11) of term t (0 = distance, 1..3 = angles)
   __shared__ int j_s[kMB][4];             // table interval, -1 = outside the table (exact evaluation)
@@ -128,7 +130,14 @@ __global__ void geo_embedding_kernel(const float* __restrict__ pts, const int64_
             val[t] = t == 0 ? exact_eval(Wd, bd, div_term, C, c, idx_s[i][0]) : exact_eval(Wa, ba, div_term, C, c, idx_s[i][t]);
           }
         }
-        emb[((size_t)n * N + (m0 + i)) * C + c] = val[0] + fmaxf(fmaxf(val[1], val[2]), val[3]);
+        const float e = val[0] + fmaxf(fmaxf(val[1], val[2]), val[3]);
+        if (emb_bf16) {                                       // round to nearest even (values are finite)
+          unsigned u = __float_as_uint(e);
+          u += 0x7fffu + ((u >> 16) & 1u);
+          emb16[((size_t)n * N + (m0 + i)) * C + c] = (unsigned short)(u >> 16);
+        } else {
+          emb[((size_t)n * N + (m0 + i)) * C + c] = e;
+        }
       }
     }
     if (eq_emb != nullptr) {
@@ -150,11 +159,11 @@ __global__ void geo_embedding_kernel(const float* __restrict__ pts, const int64_
 
 }  // namespace
 
-extern "C" int se3_geo_embedding_fwd(const float* points, const int64_t* knn, int N, int C, const float* table_d,
-                                     int d_entries, float d_entries_per_unit, const float* table_a, int a_entries,
-                                     float a_entries_per_unit, float sigma_d, float sigma_a, const float* w_d,
-                                     const float* b_d, const float* w_a, const float* b_a, const float* div_term,
-                                     const float* wigner_d1, int num_anchors, float* emb, float* eq_emb, void* stream) {
+static int geo_embedding(const float* points, const int64_t* knn, int N, int C, const float* table_d, int d_entries,
+                         float d_entries_per_unit, const float* table_a, int a_entries, float a_entries_per_unit,
+                         float sigma_d, float sigma_a, const float* w_d, const float* b_d, const float* w_a, const float* b_a,
+                         const float* div_term, const float* wigner_d1, int num_anchors, void* emb, int emb_bf16,
+                         float* eq_emb, void* stream) {
   SE3_REQUIRE(points && knn && table_d && table_a && w_d && b_d && w_a && b_a && div_term && emb, SE3_ERR_INVALID_ARG,
               "geo_embedding: null pointer");
   SE3_REQUIRE(N >= 1 && C >= 2 && C % 2 == 0 && d_entries >= 2 && a_entries >= 2, SE3_ERR_INVALID_ARG, "geo_embedding: bad sizes");
@@ -172,7 +181,26 @@ extern "C" int se3_geo_embedding_fwd(const float* points, const int64_t* knn, in
   const int threads = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
   geo_embedding_kernel<<<grid, threads, 0, (hipStream_t)stream>>>(
       points, knn, N, C, reinterpret_cast<const float2*>(table_d), reinterpret_cast<const float2*>(table_a), P, w_d, b_d, w_a,
-      b_a, div_term, wigner_d1, emb, eq_emb, num_anchors);
+      b_a, div_term, wigner_d1, emb, emb_bf16, eq_emb, num_anchors);
   SE3_CHECK_LAUNCH("geo_embedding");
   return SE3_OK;
+}
+
+extern "C" int se3_geo_embedding_fwd(const float* points, const int64_t* knn, int N, int C, const float* table_d,
+                                     int d_entries, float d_entries_per_unit, const float* table_a, int a_entries,
+                                     float a_entries_per_unit, float sigma_d, float sigma_a, const float* w_d,
+                                     const float* b_d, const float* w_a, const float* b_a, const float* div_term,
+                                     const float* wigner_d1, int num_anchors, float* emb, float* eq_emb, void* stream) {
+  return geo_embedding(points, knn, N, C, table_d, d_entries, d_entries_per_unit, table_a, a_entries, a_entries_per_unit, sigma_d,
+                       sigma_a, w_d, b_d, w_a, b_a, div_term, wigner_d1, num_anchors, emb, 0, eq_emb, stream);
+}
+
+extern "C" int se3_geo_embedding_bf16_fwd(const float* points, const int64_t* knn, int N, int C, const float* table_d,
+                                          int d_entries, float d_entries_per_unit, const float* table_a, int a_entries,
+                                          float a_entries_per_unit, float sigma_d, float sigma_a, const float* w_d,
+                                          const float* b_d, const float* w_a, const float* b_a, const float* div_term,
+                                          const float* wigner_d1, int num_anchors, uint16_t* emb, float* eq_emb,
+                                          void* stream) {
+  return geo_embedding(points, knn, N, C, table_d, d_entries, d_entries_per_unit, table_a, a_entries, a_entries_per_unit, sigma_d,
+                       sigma_a, w_d, b_d, w_a, b_a, div_term, wigner_d1, num_anchors, emb, 1, eq_emb, stream);
 }

@@ -34,7 +34,9 @@ VARIANTS = {
 }
 
 
-def make_cfg(variant='se3ete'):
+def make_cfg(variant='se3ete', attention_dtype='float32'):
+    """attention_dtype (not a reference key): 'float32' = the reference's arithmetic; 'bfloat16' stores the geometric embedding
+    of the RPE self-attention layers in bf16 (BASELINE.json configs[2], 'bf16 attention')."""
     init_dim, out_dim, gn, gt_in, hidden, gt_out, blocks, n_eq, stages, voxel, base_radius = VARIANTS[variant]
     ns = SimpleNamespace
     kitti = variant.endswith('kitti')
@@ -51,7 +53,8 @@ def make_cfg(variant='se3ete'):
     cfg.coarse_matching = ns(num_targets=128, overlap_threshold=0.1, num_correspondences=256, dual_normalization=True)
     cfg.geotransformer = ns(input_dim=gt_in, hidden_dim=hidden, output_dim=gt_out, num_heads=4, blocks=list(blocks),
                             sigma_d=4.8 if kitti else 0.2, sigma_a=15, angle_k=3, supervise_rotation=False,
-                            reduction_a='max', align_mode='0', alternative_impl=False, n_level_equiv=n_eq)
+                            reduction_a='max', align_mode='0', alternative_impl=False, n_level_equiv=n_eq,
+                            attention_dtype=attention_dtype)
     cfg.fine_matching = ns(topk=2 if kitti else 3, acceptance_radius=0.6 if kitti else 0.1, mutual=True,
                            confidence_threshold=0.05, use_dustbin=False, use_global_score=False,
                            correspondence_threshold=3, correspondence_limit=None, num_refinement_steps=5)
@@ -119,6 +122,8 @@ class SE3ET(nn.Module):
                                                 g.sigma_a, g.angle_k, supervise_rotation=g.supervise_rotation,
                                                 reduction_a=g.reduction_a, na=cfg.epn.kanchor, align_mode=g.align_mode,
                                                 alternative_impl=g.alternative_impl, n_level_equiv=g.n_level_equiv)
+        self.transformer.embedding.embedding_dtype = {'float32': torch.float32, 'bfloat16': torch.bfloat16}[
+            getattr(g, 'attention_dtype', 'float32')]
         self.coarse_matching = SuperPointMatching(cfg.coarse_matching.num_correspondences,
                                                   cfg.coarse_matching.dual_normalization)
         f = cfg.fine_matching

@@ -9,7 +9,9 @@ from ..transformer import SinusoidalPositionalEmbedding, RPEConditionalTransform
 
 class GeometricStructureEmbedding(nn.Module):
     """E[n, m] = proj_d(sin-emb(|p_n - p_m| / sigma_d)) + max_k proj_a(sin-emb(angle_k(n, m) / sigma_a)) and, when
-    n_level_equiv > 0, the anchor-rotated l <= 1 spherical harmonics of p_n - p_m (B, A, N, M, 4)."""
+    n_level_equiv > 0, the anchor-rotated l <= 1 spherical harmonics of p_n - p_m (B, A, N, M, 4).
+    `embedding_dtype` (attribute, default torch.float32 = the reference's arithmetic): torch.bfloat16 stores E rounded to
+    bf16, which halves the dominant HBM term of every RPE self-attention call ('bf16 attention', BASELINE.json configs[2])."""
 
     def __init__(self, hidden_dim, sigma_d, sigma_a, angle_k, reduction_a='max', kanchor=1, n_level_equiv=0):
         super().__init__()
@@ -23,6 +25,7 @@ class GeometricStructureEmbedding(nn.Module):
         self.proj_d = nn.Linear(hidden_dim, hidden_dim)
         self.proj_a = nn.Linear(hidden_dim, hidden_dim)
         self.n_level_equiv, self.kanchor, self.reduction_a = n_level_equiv, kanchor, reduction_a
+        self.embedding_dtype = torch.float32
         if n_level_equiv > 0 and kanchor is not None and kanchor > 1:
             if kanchor != 6:
                 raise NotImplementedError('kanchor=%d' % kanchor)
@@ -35,9 +38,9 @@ class GeometricStructureEmbedding(nn.Module):
         args = (points[0], self.embedding.div_term, self.proj_d.weight, self.proj_d.bias, self.proj_a.weight,
                 self.proj_a.bias, self.sigma_d, self.sigma_a, self.angle_k)
         if self.n_level_equiv > 0:
-            emb, eq = SF.geometric_embedding(*args, wigner_d1=self.anchors_wignerD[1])
+            emb, eq = SF.geometric_embedding(*args, wigner_d1=self.anchors_wignerD[1], dtype=self.embedding_dtype)
             return emb.unsqueeze(0), eq.unsqueeze(0)
-        return SF.geometric_embedding(*args).unsqueeze(0)
+        return SF.geometric_embedding(*args, dtype=self.embedding_dtype).unsqueeze(0)
 
 
 class GeometricTransformer(nn.Module):

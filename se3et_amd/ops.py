@@ -415,6 +415,14 @@ def stack_bias_offsets(lengths, key_lengths, AH):
     return offs, total
 
 
+def _embedding_list(embs, C):
+    """(bytes per element, contiguous GPU tensors): the geometric embeddings of a call are all float32 or all bfloat16."""
+    dt = embs[0].dtype
+    if dt not in (torch.float32, torch.bfloat16) or (dt == torch.bfloat16 and C % 32):
+        raise RuntimeError('embed_qk must be float32, or bfloat16 with C a multiple of 32')
+    return (4 if dt == torch.float32 else 2), [_req(e, dt, 'embed_qk', 3) for e in embs]
+
+
 def rpe_bias_stack(qp, qe, embs, eq_embs, starts, lengths, num_heads):
     """Stack mode of rpe_bias: qp ([A,] R, H*C) [qe ([A,] R, 4*H)] hold the folded queries of all clouds (cloud c = rows
     starts[c] .. + lengths[c]); embs[c] (N_c, N_c, C), eq_embs[c] (A, N_c, N_c, 4) or None.  ONE launch; returns the flat
@@ -431,12 +439,12 @@ def rpe_bias_stack(qp, qe, embs, eq_embs, starts, lengths, num_heads):
         qe_ptr = qe3.data_ptr()
     if A * H > 32 or C % 16:
         raise RuntimeError('rpe_bias_stack: anchors*heads must be <= 32 and C a multiple of 16')
-    embs = [_req(e, torch.float32, 'embed_qk', 3) for e in embs]
+    esize, embs = _embedding_list(embs, C)
     survey_bytes = 0
     for c, (e, n) in enumerate(zip(embs, lengths)):
         if tuple(e.shape) != (n, n, C) or starts[c] + n > R:
             raise RuntimeError('rpe_bias_stack: cloud %d: embedding %s for %d rows at %d of %d' % (c, tuple(e.shape), n, starts[c], R))
-        survey_bytes += 4 * (4 * A * n * C + n * n * C + (A * n * n * 4 if has_eq else 0))
+        survey_bytes += 4 * (4 * A * n * C + (A * n * n * 4 if has_eq else 0)) + esize * n * n * C
     eqs = None
     if has_eq:
         eqs = [_req(e, torch.float32, 'embed_eq', 4) for e in eq_embs]
@@ -446,9 +454,10 @@ def rpe_bias_stack(qp, qe, embs, eq_embs, starts, lengths, num_heads):
     offs, total = stack_bias_offsets(lengths, lengths, A * H)
     bias = torch.empty((total,), dtype=torch.float32, device=qp3.device)
     with _timed('rpe_bias_kernel', survey_bytes, 'eq' if has_eq else 'inv'):
-        check(lib().se3_rpe_bias_stack_fwd(qp3.data_ptr(), qe_ptr, rs, sa, _ptr_array(embs), _ptr_array(eqs) if has_eq else None,
-                                           _i64_array(starts), _i64_array(lengths), _i64_array(lengths), _i64_array(offs),
-                                           len(embs), C, A * H, H, bias.data_ptr(), _stream()), 'se3_rpe_bias_stack_fwd')
+        entry = lib().se3_rpe_bias_stack_fwd if esize == 4 else lib().se3_rpe_bias_stack_bf16_fwd
+        check(entry(qp3.data_ptr(), qe_ptr, rs, sa, _ptr_array(embs), _ptr_array(eqs) if has_eq else None, _i64_array(starts),
+                    _i64_array(lengths), _i64_array(lengths), _i64_array(offs), len(embs), C, A * H, H, bias.data_ptr(),
+                    _stream()), 'se3_rpe_bias_stack_fwd')
     return bias, offs
 
 
@@ -506,13 +515,13 @@ def rpe_self_attention_stack(proj, offs, vt, embs, eq_embs, starts, lengths, num
     o3 = out if out.dim() == 3 else out.unsqueeze(0)
     if o3.shape[0] != A or o3.shape[2] != C or o3.stride(-1) != 1 or o3.stride(-2) != C or o3.dtype != torch.float32:
         raise RuntimeError('rpe_self_attention_stack: out must be (A, rows, C) float32 with contiguous rows')
-    embs = [_req(e, torch.float32, 'embed_qk', 3) for e in embs]
+    esize, embs = _embedding_list(embs, C)
     survey_bytes, total = 0, 0
     for c, (e, n) in enumerate(zip(embs, lengths)):
         if tuple(e.shape) != (n, n, C) or starts[c] % 4 or starts[c] + n > min(R, o3.shape[1]) or \
                 starts[c] + key_stride(n) > v3.shape[2]:
             raise RuntimeError('rpe_self_attention_stack: cloud %d: embedding %s, %d rows at %d of %d' % (c, tuple(e.shape), n, starts[c], R))
-        survey_bytes += 4 * (4 * A * n * C + n * n * C + (A * n * n * 4 if has_eq else 0))
+        survey_bytes += 4 * (4 * A * n * C + (A * n * n * 4 if has_eq else 0)) + esize * n * n * C
         total += A * H * n * key_stride(n)
     eqs = None
     if has_eq:
@@ -524,12 +533,12 @@ def rpe_self_attention_stack(proj, offs, vt, embs, eq_embs, starts, lengths, num
     base = p3.data_ptr()
     col = lambda name: base + 4 * offs[name]
     if KERNEL_TIMINGS is not None:       # bench.py pairs these with the library's per-launch HIP events, in call order
-        KERNEL_TIMINGS.setdefault('rpe_self_attention_calls', []).append((survey_bytes, 'eq' if has_eq else 'inv'))
-    check(lib().se3_rpe_self_attention_stack_fwd(col('q'), col('k'), v3.data_ptr(), col('qp'), col('qe') if has_eq else None,
-                                                 rs, sa, v3.stride(1), v3.stride(0) if A > 1 else 0, _ptr_array(embs),
-                                                 _ptr_array(eqs) if has_eq else None, _i64_array(starts), _i64_array(lengths),
-                                                 len(embs), A, C, H, logits.data_ptr(), o3.stride(0) if A > 1 else 0,
-                                                 o3.data_ptr(), _stream()), 'se3_rpe_self_attention_stack_fwd')
+        KERNEL_TIMINGS.setdefault('rpe_self_attention_calls', []).append((survey_bytes, ('eq' if has_eq else 'inv') + ('' if esize == 4 else '_bf16')))
+    entry = lib().se3_rpe_self_attention_stack_fwd if esize == 4 else lib().se3_rpe_self_attention_stack_bf16_fwd
+    check(entry(col('q'), col('k'), v3.data_ptr(), col('qp'), col('qe') if has_eq else None, rs, sa, v3.stride(1),
+                v3.stride(0) if A > 1 else 0, _ptr_array(embs), _ptr_array(eqs) if has_eq else None, _i64_array(starts),
+                _i64_array(lengths), len(embs), A, C, H, logits.data_ptr(), o3.stride(0) if A > 1 else 0, o3.data_ptr(),
+                _stream()), 'se3_rpe_self_attention_stack_fwd')
     return out
 
 
@@ -629,8 +638,9 @@ def _embedding_table(weight, bias, div_term, x_max, per_unit):
     return tab
 
 
-def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, k, wigner_d1=None):
-    """HIP (csrc/geo_embedding.hip).  Returns emb (N, N, C), or (emb, eq_emb (A, N, N, 4)) when wigner_d1 is given."""
+def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, k, wigner_d1=None, dtype=torch.float32):
+    """HIP (csrc/geo_embedding.hip).  Returns emb (N, N, C), or (emb, eq_emb (A, N, N, 4)) when wigner_d1 is given.
+    dtype: torch.float32, or torch.bfloat16 for the 'bf16 attention' mode (emb stored rounded; eq_emb stays float32)."""
     points = _req(points.contiguous(), torch.float32, 'points', 2)
     if k != 3:
         raise RuntimeError('geometric_embedding: angle_k must be 3 on the HIP path')
@@ -640,19 +650,20 @@ def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, 
     check(lib().se3_knn3(points.data_ptr(), N, knn.data_ptr(), _stream()), 'se3_knn3')
     tab_d = _embedding_table(w_d, b_d, div_term, _EMB_D_RANGE, _EMB_D_PER_UNIT)
     tab_a = _embedding_table(w_a, b_a, div_term, 180.0 / sigma_a + 1.0, _EMB_A_PER_UNIT)
-    emb = torch.empty((N, N, C), dtype=torch.float32, device=points.device)
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError('geometric_embedding: dtype must be float32 or bfloat16')
+    emb = torch.empty((N, N, C), dtype=dtype, device=points.device)
     eq = None
     A = 0
     if wigner_d1 is not None:
         A = wigner_d1.shape[0]
         eq = torch.empty((A, N, N, 4), dtype=torch.float32, device=points.device)
         wigner_d1 = wigner_d1.detach().contiguous()
-    check(lib().se3_geo_embedding_fwd(points.data_ptr(), knn.data_ptr(), N, C, tab_d.data_ptr(), tab_d.shape[0],
-                                      _EMB_D_PER_UNIT, tab_a.data_ptr(), tab_a.shape[0], _EMB_A_PER_UNIT, float(sigma_d),
-                                      float(sigma_a), w_d.data_ptr(), b_d.data_ptr(), w_a.data_ptr(), b_a.data_ptr(),
-                                      div_term.data_ptr(), wigner_d1.data_ptr() if eq is not None else None, A,
-                                      emb.data_ptr(), eq.data_ptr() if eq is not None else None, _stream()),
-          'se3_geo_embedding_fwd')
+    entry = lib().se3_geo_embedding_fwd if dtype == torch.float32 else lib().se3_geo_embedding_bf16_fwd
+    check(entry(points.data_ptr(), knn.data_ptr(), N, C, tab_d.data_ptr(), tab_d.shape[0], _EMB_D_PER_UNIT, tab_a.data_ptr(),
+                tab_a.shape[0], _EMB_A_PER_UNIT, float(sigma_d), float(sigma_a), w_d.data_ptr(), b_d.data_ptr(), w_a.data_ptr(),
+                b_a.data_ptr(), div_term.data_ptr(), wigner_d1.data_ptr() if eq is not None else None, A, emb.data_ptr(),
+                eq.data_ptr() if eq is not None else None, _stream()), 'se3_geo_embedding_fwd')
     return emb if eq is None else (emb, eq)
 
 

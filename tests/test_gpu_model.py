@@ -9,11 +9,11 @@ from helpers import assert_close, assert_neighbors_equal, assert_pairs_equal_up_
 pytestmark = pytest.mark.gpu
 
 
-def _run(variant, pair, state=None, synth_seed=None):
+def _run(variant, pair, state=None, synth_seed=None, attention_dtype='float32'):
     from se3et_amd.data import registration_collate_fn_stack_mode
     from se3et_amd.model import create_model, load_synthetic_weights, make_cfg
     from se3et_amd.synthetic import make_pair
-    cfg = make_cfg(variant)
+    cfg = make_cfg(variant, attention_dtype=attention_dtype)
     model = create_model(cfg)
     if state is not None:
         model.load_state_dict(state, strict=True)
@@ -73,6 +73,50 @@ def test_real_width_model_matches_reference(golden_dir, variant, fixture):
     model, dd, out = _run(variant, str(g['pair']), synth_seed=int(g['synth_seed']))
     assert np.array_equal(np.stack([l.numpy() for l in dd['lengths']]), g['lengths'])
     _check_outputs(out, g, full=False)
+
+
+@pytest.mark.parametrize('variant,fixture', [('se3ete2', 'synthw_se3ete2.npz'), ('se3eti2', 'synthw_se3eti2.npz')])
+def test_bf16_attention_model_stays_close_to_the_reference(golden_dir, variant, fixture):
+    """BASELINE.json configs[2] ('bf16 attention'): with the geometric embedding stored in bf16 (2^-9 relative rounding per
+    element, everything else f32) the outputs stay within 1e-2 (max-norm relative) of the genuine reference's f32 outputs and
+    the estimated transform within 1e-2; the kernel itself is exact to 1e-4 on the rounded embedding (test_gpu_ops.py)."""
+    g = np.load(golden_dir + '/' + fixture)
+    model, dd, out = _run(variant, str(g['pair']), synth_seed=int(g['synth_seed']), attention_dtype='bfloat16')
+    assert model.transformer.embedding.embedding_dtype == torch.bfloat16
+    assert_close(out['ref_feats_c'].cpu(), g['out/ref_feats_c'], 1e-2, 'ref_feats_c (bf16 attention)')
+    assert_close(out['src_feats_c'].cpu(), g['out/src_feats_c'], 1e-2, 'src_feats_c (bf16 attention)')
+    assert_close(out['feats_f'].cpu()[::8], g['out/feats_f'], 1e-4, 'feats_f (backbone only: unaffected)')
+    assert_close(out['estimated_transform'].cpu(), g['out/estimated_transform'], 1e-2, 'estimated_transform (bf16 attention)')
+
+
+def test_bf16_attention_kitti_sized_pair():
+    """configs[2] at its full size (SE3ET-I KITTI configuration, 20k + 20k points): bf16-attention forward vs the f32 forward of
+    the same model, single pair and two pairs per forward."""
+    from se3et_amd.batched import forward_pairs
+    from se3et_amd.data import precompute_data_stack_mode
+    from se3et_amd.synthetic import make_pair
+    model, dd, out32 = _run('se3eti_kitti', 'c3_20k', synth_seed=0)
+    emb = model.transformer.embedding
+    emb.embedding_dtype = torch.bfloat16
+    out16 = model(dd)
+    assert_close(out16['ref_feats_c'], out32['ref_feats_c'], 1e-2, 'ref_feats_c (bf16 vs f32 attention)')
+    assert_close(out16['src_feats_c'], out32['src_feats_c'], 1e-2, 'src_feats_c (bf16 vs f32 attention)')
+    assert_close(out16['estimated_transform'], out32['estimated_transform'], 1e-2, 'estimated_transform (bf16 vs f32 attention)')
+    clouds = []
+    for j in range(2):
+        ref, src, _ = make_pair('c3_20k', index=j)
+        clouds += [ref, src]
+    pts = torch.from_numpy(np.concatenate(clouds, 0)).cuda()
+    lens = torch.tensor([len(c) for c in clouds], dtype=torch.int64)
+    b = model.cfg.backbone
+    data = precompute_data_stack_mode(pts, lens, b.num_stages, b.init_voxel_size, b.init_radius, model.cfg.neighbor_limits)
+    data['features'] = torch.ones((pts.shape[0], 1), device='cuda')
+    outs16 = forward_pairs(model, data)
+    emb.embedding_dtype = torch.float32
+    outs32 = forward_pairs(model, data)
+    for o16, o32 in zip(outs16, outs32):
+        assert_close(o16['ref_feats_c'], o32['ref_feats_c'], 1e-2, 'batched ref_feats_c (bf16 vs f32 attention)')
+        assert_close(o16['estimated_transform'], o32['estimated_transform'], 1e-2, 'batched estimated_transform')
 
 
 @pytest.mark.parametrize('variant,preset,num_pairs', [('micro_e', 'micro', 2), ('micro_i', 'micro', 3), ('se3ete', 'c1_2k', 2),

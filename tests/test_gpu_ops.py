@@ -215,6 +215,31 @@ def test_rpe_self_attention_stack_matches_oracle(A, lengths, C, H, eq):
     assert float(got[..., pad, :].abs().max()) == 0.0 if pad.any() else True
 
 
+@pytest.mark.parametrize('A,lengths,C,H,eq', [(6, (59, 53), 32, 4, True), (6, (382, 350), 256, 4, True), (1, (304, 382), 256, 4, False),
+                                              (1, (33, 17, 64), 128, 4, False), (3, (17, 40), 64, 2, True)])
+def test_rpe_self_attention_stack_bf16_embedding_matches_oracle(A, lengths, C, H, eq):
+    """'bf16 attention' (BASELINE.json configs[2]): the geometric embedding is STORED in bf16 and read by
+    se3_rpe_self_attention_stack_bf16_fwd; everything else stays f32 (the folded queries are split hi + lo inside the kernel).
+    Against the oracle on the same rounded embedding the f32 tolerance holds."""
+    from oracle import se3et_oracle as O
+    from se3et_amd import functional as SF
+    g = torch.Generator().manual_seed(12)
+    st = _attn_state(C, eq)
+    xs = [torch.randn((A, n, C) if A > 1 else (n, C), generator=g) for n in lengths]
+    embs = [torch.randn(n, n, C, generator=g).to(torch.bfloat16) for n in lengths]
+    eqs = [torch.randn(A, n, n, 4, generator=g) if eq else None for n in lengths]
+    w_stack, b_stack, offs = SF.compose_self_attention_weights(st['l.proj_q.weight'], st['l.proj_q.bias'], st['l.proj_k.weight'],
+                                                               st['l.proj_k.bias'], st['l.proj_p.weight'],
+                                                               st['l.proj_eq.weight'] if eq else None, H)
+    packed, starts = SF.pack_rows([x.cuda() for x in xs])
+    got = SF.rpe_self_attention_packed(packed, starts, list(lengths), [e.cuda() for e in embs],
+                                       [e.cuda() if e is not None else None for e in eqs], w_stack.cuda(), b_stack.cuda(), offs,
+                                       st['l.proj_v.weight'].cuda(), st['l.proj_v.bias'].cuda(), H).cpu()
+    for x, emb, e, s0, n in zip(xs, embs, eqs, starts, lengths):
+        want, _ = O.rpe_attention(st, 'l.', x, x, emb.float(), e, H)
+        assert_close(got[..., s0:s0 + n, :], want, 1e-4, 'stack-mode rpe attention with a bf16 embedding, cloud at row %d' % s0)
+
+
 def test_stack_mode_rejects_bad_descriptors():
     from se3et_amd import ops
     q = torch.zeros(1, 64, 32, device='cuda')
@@ -323,6 +348,24 @@ def test_geometric_embedding_matches_oracle(N, C, eq):
     assert_close(emb, want, 2e-3, 'geometric embedding (diagonal noise)')
     if eq:
         assert_close(out[1].cpu(), O.equiv_embedding(st, 'e.', pts), 1e-5, 'equivariant embedding')
+
+
+def test_geometric_embedding_bf16_is_the_rounded_f32_embedding():
+    """se3_geo_embedding_bf16_fwd stores round-to-nearest-even(bf16) of exactly the value the f32 entry writes."""
+    from se3et_amd import functional as SF
+    from se3et_amd import tables
+    g = torch.Generator().manual_seed(9)
+    N, C = 211, 256
+    pts = (torch.rand(N, 3, generator=g) * torch.tensor([1.5, 1.2, 1.0])).cuda()
+    div = torch.exp(torch.arange(0, C, 2).float() * (-np.log(10000.0) / C)).cuda()
+    w = [(torch.randn(C, C, generator=g) / C ** 0.5).cuda() for _ in range(2)]
+    b = [(torch.randn(C, generator=g) * 0.1).cuda() for _ in range(2)]
+    w1 = torch.from_numpy(tables.wigner_tables()[1]).cuda()
+    e32, q32 = SF.geometric_embedding(pts, div, w[0], b[0], w[1], b[1], 0.2, 15.0, 3, wigner_d1=w1)
+    e16, q16 = SF.geometric_embedding(pts, div, w[0], b[0], w[1], b[1], 0.2, 15.0, 3, wigner_d1=w1, dtype=torch.bfloat16)
+    assert e16.dtype == torch.bfloat16 and q16.dtype == torch.float32
+    assert torch.equal(e16, e32.to(torch.bfloat16))
+    assert torch.equal(q16, q32)
 
 
 def test_geometric_embedding_out_of_table_range():
