@@ -83,11 +83,13 @@ def main():
     b = cfg.backbone
     from se3et_amd.batched import forward_pairs
 
-    def step(i):
-        pts, lens = pairs[i]
-        data = precompute_data_stack_mode(pts, lens, b.num_stages, b.init_voxel_size, b.init_radius, cfg.neighbor_limits)
+    def forward(data):
         data['features'] = feats
         return model(data) if PB == 1 else forward_pairs(model, data)
+
+    def step(i):
+        pts, lens = pairs[i]
+        return forward(precompute_data_stack_mode(pts, lens, b.num_stages, b.init_voxel_size, b.init_radius, cfg.neighbor_limits))
 
     import threading
 
@@ -131,8 +133,7 @@ def main():
             for key in ('points', 'neighbors', 'subsampling', 'upsampling'):
                 for t in data[key]:
                     t.record_stream(main)          # allocated on the side stream, consumed on the main stream
-            data['features'] = feats
-            model(data)
+            forward(data)
             keep = [data] + keep[:1]
         th.join()
 
