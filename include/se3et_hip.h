@@ -256,6 +256,13 @@ int se3_geo_embedding_bf16_fwd(const float* points, const int64_t* knn, int N, i
 int se3_knn3(const float* points, int N, int64_t* knn, void* stream);
 int se3_point_to_node_partition(const float* points, const float* nodes, int N, int M, int limit, int64_t* point_to_node,
                                 uint8_t* node_masks, int64_t* node_knn_indices, uint8_t* node_knn_masks, void* stream);
+/* Stack mode: the same partition for num_clouds (<= 16) clouds in one launch per kernel.  points / nodes are the stacked fine
+ * points / superpoints of all clouds (cloud c: point_lengths[c] points, node_lengths[c] nodes; HOST arrays).  All outputs use
+ * GLOBAL indices into the stacked arrays: point_to_node (total points) = nearest node of the point's own cloud;
+ * node_knn_indices (total nodes, limit) padded with the total point count; masks as above. */
+int se3_point_to_node_partition_stack(const float* points, const float* nodes, const int64_t* point_lengths,
+                                      const int64_t* node_lengths, int num_clouds, int limit, int64_t* point_to_node,
+                                      uint8_t* node_masks, int64_t* node_knn_indices, uint8_t* node_knn_masks, void* stream);
 
 /* ---- E2: superpoint matching scores --------------------------------------------------------------------------------
  * Replaces the score part of SuperPointMatching.forward (geotransformer/modules/geotransformer/superpoint_matching.py:31-39):
@@ -263,6 +270,17 @@ int se3_point_to_node_partition(const float* points, const float* nodes, int N, 
  * ref (N, C), src (M, C) L2-normalised; workspace: N + M floats. */
 int se3_superpoint_scores(const float* ref_feats, const float* src_feats, int N, int M, int C, int dual_normalization,
                           float* scores, float* workspace, void* stream);
+/* Stack mode: the score matrices of num_pairs (<= 16) registration pairs in one launch per kernel.  feats (rows, C): the
+ * L2-normalised superpoint features of all clouds; pair p: ref rows ref_rows[p] .. + ref_lengths[p], src rows src_rows[p] .. +
+ * src_lengths[p]; node_masks (uint8): entries ref_mask_offsets[p] + n / src_mask_offsets[p] + m tell whether the node owns a
+ * fine point -- nodes with mask 0 are absent (superpoint_matching.py:24-29 drops them before scoring): they do not enter the
+ * normalisation sums and their scores are -1.  scores (num_pairs, score_stride): pair p's (N_p, M_p) matrix row-major at the
+ * start of row p, -1 beyond it, so that ONE top-k over the rows selects per pair.  workspace: sum(N_p) + sum(M_p) floats.
+ * All arrays are HOST arrays. */
+int se3_superpoint_scores_stack(const float* feats, const uint8_t* node_masks, const int64_t* ref_rows, const int64_t* src_rows,
+                                const int64_t* ref_lengths, const int64_t* src_lengths, const int64_t* ref_mask_offsets,
+                                const int64_t* src_mask_offsets, int num_pairs, int C, int dual_normalization,
+                                int64_t score_stride, float* scores, float* workspace, void* stream);
 
 /* ---- F1: weighted Procrustes / inlier voting for local-to-global registration -------------------------------------------
  * Replace weighted_procrustes (geotransformer/modules/registration/procrustes.py:6-73, SVD on the CPU in the reference) and

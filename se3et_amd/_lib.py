@@ -48,6 +48,8 @@ SIGNATURES = {
     'se3_knn3': (_i32, [_vp, _i32, _vp, _vp]),
     'se3_point_to_node_partition': (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'se3_superpoint_scores': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    'se3_superpoint_scores_stack': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp]),
+    'se3_point_to_node_partition_stack': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'se3_weighted_procrustes': (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _f32, _f32, _vp, _vp]),
     'se3_mutual_topk_mask': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     'se3_count_inliers': (_i32, [_vp, _vp, _i64, _vp, _i32, _f32, _vp, _vp]),

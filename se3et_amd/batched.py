@@ -13,7 +13,6 @@ import torch.nn.functional as F
 
 from . import functional as SF
 from . import ops as _ops
-from .modules.ops import point_to_node_partition
 from .modules.transformer import _block_is_eq
 
 
@@ -88,9 +87,10 @@ def _cross_eq(layer, Pq, Pk, xq, xk):
     return layer.output(hidden), mixes
 
 
-def transformer_pairs(gt, points_c, lengths_c, feats_c):
+def transformer_pairs(gt, points_c, lengths_c, feats_c, packed=False):
     """Batched GeometricTransformer.forward: points_c (P, 3) / feats_c (P, A, C_in) stacked superpoints of 2 B clouds with
-    `lengths_c`.  Returns (ref_feats [B tensors (N_i, C_out)], src_feats [B tensors])."""
+    `lengths_c`.  Returns (ref_feats [B tensors (N_i, C_out)], src_feats [B tensors]), or with packed=True the packed rows
+    (R, C_out) and their _Packed layout (clouds ref0 .. ref(B-1), src0 .. src(B-1))."""
     offs = _offsets(lengths_c)
     clouds = [points_c[offs[c]:offs[c + 1]] for c in range(len(lengths_c))]
     B = len(clouds) // 2
@@ -152,23 +152,29 @@ def transformer_pairs(gt, points_c, lengths_c, feats_c):
                 X = torch.cat((tr.rotcompress(y0[None])[0], tr.rotcompress(y1p[None])[0]), 0)
                 X_eq = None
     X = SF.linear(X, gt.out_proj.weight, gt.out_proj.bias)
+    if packed:
+        return X, PA
     outs = PA.unpack(X)
     return outs[:B], outs[B:]
 
 
-def registration_pairs(lgr, patches):
+def registration_pairs(lgr, patches, stacked=None):
     """LocalGlobalRegistration.forward for several pairs at once (same arithmetic per pair; one host synchronisation in all).
     patches[p] = (ref_knn_points (B_p, K, 3), src_knn_points, ref_knn_masks (B_p, K), src_knn_masks, score_mat (B_p, K, K) log).
     Returns per pair (ref_corr_points, src_corr_points, corr_scores, estimated_transform)."""
     P = len(patches)
     nb = [t[0].shape[0] for t in patches]
     dev = patches[0][0].device
-    ref_pts = torch.cat([t[0] for t in patches], 0)
-    src_pts = torch.cat([t[1] for t in patches], 0)
-    score = torch.exp(torch.cat([t[4] for t in patches], 0))
+    if stacked is not None:                # the caller already holds the pair-major concatenations
+        ref_pts, src_pts, ref_masks, src_masks, log_score = stacked
+    else:
+        ref_pts = torch.cat([t[0] for t in patches], 0)
+        src_pts = torch.cat([t[1] for t in patches], 0)
+        ref_masks, src_masks = torch.cat([t[2] for t in patches], 0), torch.cat([t[3] for t in patches], 0)
+        log_score = torch.cat([t[4] for t in patches], 0)
+    score = torch.exp(log_score)
     BT = score.shape[0]
-    corr = SF.mutual_topk_mask(score, torch.cat([t[2] for t in patches], 0), torch.cat([t[3] for t in patches], 0), lgr.k,
-                               lgr.confidence_threshold)
+    corr = SF.mutual_topk_mask(score, ref_masks, src_masks, lgr.k, lgr.confidence_threshold)
     b_idx, r_idx, c_idx = torch.nonzero(corr, as_tuple=True)                # the one host sync; patch-major = pair-major
     ref_c, src_c = ref_pts[b_idx, r_idx].contiguous(), src_pts[b_idx, c_idx].contiguous()
     sc = score[b_idx, r_idx, c_idx].contiguous()
@@ -220,49 +226,63 @@ def forward_pairs(model, data_dict, with_registration=True):
     len_c, len_f = lengths[-1].tolist(), lengths[1].tolist()
     oc, of = _offsets(len_c), _offsets(len_f)
 
-    ref_c_feats, src_c_feats = transformer_pairs(model.transformer, points_c, len_c, feats_c)
-
-    outs, parts = [], []
+    X, PA = transformer_pairs(model.transformer, points_c, len_c, feats_c, packed=True)
+    Xn = F.normalize(X, p=2, dim=1)                       # all clouds at once (the padding rows of the packing stay zero)
+    dev = X.device
+    K = model.num_points_in_patch
+    # every fine point to its nearest superpoint, every superpoint's K nearest own points: all clouds in one call, GLOBAL indices
+    _, node_masks, knn, knn_masks = _ops.point_to_node_partition_stack(points_f, points_c, len_f, len_c, K)
+    csum = torch.cumsum(node_masks, 0)
+    ends = torch.tensor([o - 1 for o in oc[1:]], device=dev)
+    upto = csum[ends]
+    valid = (upto - torch.cat((upto.new_zeros(1), upto[:-1]))).tolist()      # non-empty nodes per cloud: ONE host sync
+    ref_rows, src_rows = PA.starts[:B], PA.starts[B:]
+    Ns, Ms = [len_c[2 * p] for p in range(B)], [len_c[2 * p + 1] for p in range(B)]
+    ref_off, src_off = [oc[2 * p] for p in range(B)], [oc[2 * p + 1] for p in range(B)]
+    cm = model.coarse_matching
+    S = _ops.superpoint_scores_stack(Xn, node_masks, ref_rows, src_rows, Ns, Ms, ref_off, src_off, cm.dual_normalization)
+    ks = [min(cm.num_correspondences, valid[2 * p] * valid[2 * p + 1]) for p in range(B)]
+    if len(set(ks)) == 1:
+        node_scores, flat = S.topk(k=ks[0], dim=1, largest=True)             # (B, k): one selection for all pairs
+        Mt = torch.tensor(Ms, device=dev)[:, None]
+        ri = torch.div(flat, Mt, rounding_mode='floor')
+        si = flat - ri * Mt
+        gr = (ri + torch.tensor(ref_off, device=dev)[:, None]).view(-1)      # global superpoint indices, pair-major
+        gs = (si + torch.tensor(src_off, device=dev)[:, None]).view(-1)
+        ri, si, node_scores = list(ri), list(si), list(node_scores)
+    else:                                                                     # pairs with fewer valid superpoint pairs than k
+        ri, si, node_scores = [], [], []
+        for p in range(B):
+            v, flat = S[p, :Ns[p] * Ms[p]].topk(k=ks[p], largest=True)
+            r = torch.div(flat, Ms[p], rounding_mode='floor')
+            ri.append(r)
+            si.append(flat - r * Ms[p])
+            node_scores.append(v)
+        gr = torch.cat([r + o for r, o in zip(ri, ref_off)])
+        gs = torch.cat([c + o for c, o in zip(si, src_off)])
+    ref_ck, src_ck = knn[gr], knn[gs]                                         # (sum k, K) global fine-point indices
+    ref_cm, src_cm = knn_masks[gr], knn_masks[gs]
+    ref_cp, src_cp = SF.gather_rows_padded(points_f, ref_ck), SF.gather_rows_padded(points_f, src_ck)
+    rk, sk = SF.gather_rows_padded(feats_f, ref_ck), SF.gather_rows_padded(feats_f, src_ck)
+    outs, patches = [], []
+    po = _offsets(ks)
     for p in range(B):
         r, s = 2 * p, 2 * p + 1
-        ref_c, src_c = points_c[oc[r]:oc[r + 1]], points_c[oc[s]:oc[s + 1]]
-        ref_f, src_f = points_f[of[r]:of[r + 1]], points_f[of[s]:of[s + 1]]
-        _, ref_nm, ref_knn, ref_km = point_to_node_partition(ref_f, ref_c, model.num_points_in_patch)
-        _, src_nm, src_knn, src_km = point_to_node_partition(src_f, src_c, model.num_points_in_patch)
-        parts.append((ref_nm, ref_knn, ref_km, src_nm, src_knn, src_km))
-    # number of non-empty nodes of every cloud: ONE host synchronisation for all pairs
-    valid = torch.stack([m.sum() for t in parts for m in (t[0], t[3])]).tolist()
-    patches = []
-    for p in range(B):
-        r, s = 2 * p, 2 * p + 1
-        ref_c, src_c = points_c[oc[r]:oc[r + 1]], points_c[oc[s]:oc[s + 1]]
-        ref_f, src_f = points_f[of[r]:of[r + 1]], points_f[of[s]:of[s + 1]]
-        fr, fs = feats_f[of[r]:of[r + 1]], feats_f[of[s]:of[s + 1]]
-        out = dict(ref_points_c=ref_c, src_points_c=src_c, ref_points_f=ref_f, src_points_f=src_f,
-                   feats_c=feats_c[oc[r]:oc[s + 1]], feats_f=feats_f[of[r]:of[s + 1]])
-        ref_nm, ref_knn, ref_km, src_nm, src_knn, src_km = parts[p]
-        ref_knn_pts = SF.gather_rows_padded(ref_f, ref_knn)
-        src_knn_pts = SF.gather_rows_padded(src_f, src_knn)
-        rf, sf = F.normalize(ref_c_feats[p], p=2, dim=1), F.normalize(src_c_feats[p], p=2, dim=1)
-        out.update(ref_feats_c=rf, src_feats_c=sf, ref_feats_f=fr, src_feats_f=fs)
-        all_valid = valid[2 * p] == ref_c.shape[0] and valid[2 * p + 1] == src_c.shape[0]
-        ri, si, node_scores = model.coarse_matching(rf, sf, ref_nm, src_nm, all_valid=all_valid)
-        out.update(ref_node_corr_indices=ri, src_node_corr_indices=si, node_corr_scores=node_scores)
-        ref_ck, src_ck = ref_knn[ri], src_knn[si]
-        ref_cm, src_cm = ref_km[ri], src_km[si]
-        ref_cp, src_cp = ref_knn_pts[ri], src_knn_pts[si]
-        rk = SF.gather_rows_padded(fr, ref_ck)
-        sk = SF.gather_rows_padded(fs, src_ck)
-        out.update(ref_node_corr_knn_points=ref_cp, src_node_corr_knn_points=src_cp, ref_node_corr_knn_masks=ref_cm,
-                   src_node_corr_knn_masks=src_cm)
-        patches.append((rk, sk, ref_cm, src_cm, ref_cp, src_cp, node_scores))
-        outs.append(out)
+        a, b = po[p], po[p + 1]
+        outs.append(dict(
+            ref_points_c=points_c[oc[r]:oc[r + 1]], src_points_c=points_c[oc[s]:oc[s + 1]],
+            ref_points_f=points_f[of[r]:of[r + 1]], src_points_f=points_f[of[s]:of[s + 1]],
+            feats_c=feats_c[oc[r]:oc[s + 1]], feats_f=feats_f[of[r]:of[s + 1]],
+            ref_feats_c=Xn[ref_rows[p]:ref_rows[p] + Ns[p]], src_feats_c=Xn[src_rows[p]:src_rows[p] + Ms[p]],
+            ref_feats_f=feats_f[of[r]:of[r + 1]], src_feats_f=feats_f[of[s]:of[s + 1]],
+            ref_node_corr_indices=ri[p], src_node_corr_indices=si[p], node_corr_scores=node_scores[p],
+            ref_node_corr_knn_points=ref_cp[a:b], src_node_corr_knn_points=src_cp[a:b],
+            ref_node_corr_knn_masks=ref_cm[a:b], src_node_corr_knn_masks=src_cm[a:b]))
+        patches.append((None, None, ref_cm[a:b], src_cm[a:b], ref_cp[a:b], src_cp[a:b], node_scores[p]))
+    counts = ks
     # all patch pairs of all registration pairs through ONE Sinkhorn launch
-    counts = [t[0].shape[0] for t in patches]
-    rk = torch.cat([t[0] for t in patches], 0)
-    sk = torch.cat([t[1] for t in patches], 0)
     scores = torch.einsum('bnd,bmd->bnm', rk, sk) / feats_f.shape[1] ** 0.5
-    scores = model.optimal_transport(scores, torch.cat([t[2] for t in patches], 0), torch.cat([t[3] for t in patches], 0))
+    scores = model.optimal_transport(scores, ref_cm, src_cm)
     start, per_pair = 0, []
     for out, n, t in zip(outs, counts, patches):
         sc = scores[start:start + n]
@@ -270,6 +290,7 @@ def forward_pairs(model, data_dict, with_registration=True):
         out['matching_scores'] = sc
         per_pair.append((t[4], t[5], t[2], t[3], sc[:, :-1, :-1]))
     if with_registration:
-        for out, (rc, scp, cs, T) in zip(outs, registration_pairs(model.fine_matching, per_pair)):
+        stacked = (ref_cp, src_cp, ref_cm, src_cm, scores[:, :-1, :-1])
+        for out, (rc, scp, cs, T) in zip(outs, registration_pairs(model.fine_matching, per_pair, stacked)):
             out.update(ref_corr_points=rc, src_corr_points=scp, corr_scores=cs, estimated_transform=T)
     return outs

@@ -54,7 +54,139 @@ __global__ void sp_normalize_kernel(float* __restrict__ S, const float* __restri
   S[i] = (s / rowsum[n]) * (s / colsum[m]);
 }
 
+// ---- stack mode: the superpoint pairs of several registration pairs in one launch per kernel -----------------------------
+constexpr int kMaxMatchPairs = 16;
+struct MatchPairs {
+  int ref_row[kMaxMatchPairs], src_row[kMaxMatchPairs];       // first row of the pair's ref / src superpoints in `feats`
+  int N[kMaxMatchPairs], M[kMaxMatchPairs];
+  int ref_mask[kMaxMatchPairs], src_mask[kMaxMatchPairs];     // first entry of the pair's node masks in `node_masks`
+  int row0[kMaxMatchPairs + 1];                               // prefix sums of N (flat ref-row index -> pair)
+  int col0[kMaxMatchPairs + 1];                               // prefix sums of M
+  int n;
+};
+
+// one workgroup per (pair, reference row); raw scores into the pair's row of the padded (B, stride) output, row sums over the
+// valid columns into the workspace.  Nodes with mask 0 (no fine point) are absent, as the reference drops them beforehand.
+__global__ __launch_bounds__(256) void sp_scores_stack_kernel(const float* __restrict__ feats, const unsigned char* __restrict__ masks,
+                                                              MatchPairs T, int C, int64_t stride, float* __restrict__ S,
+                                                              float* __restrict__ rowsum) {
+  extern __shared__ float rf[];
+  __shared__ float part[4];
+  int p = 0;
+  for (int k = 1; k < T.n; k++)
+    if ((int)blockIdx.x >= T.row0[k]) p = k;
+  const int n = blockIdx.x - T.row0[p], M = T.M[p];
+  if (!masks[T.ref_mask[p] + n]) return;
+  const float* ref = feats + (size_t)(T.ref_row[p] + n) * C;
+  for (int c = threadIdx.x; c < C; c += 256) rf[c] = ref[c];
+  __syncthreads();
+  float* Srow = S + (size_t)p * stride + (size_t)n * M;
+  const unsigned char* cm = masks + T.src_mask[p];
+  float rs = 0.f;
+  for (int m = threadIdx.x; m < M; m += 256) {
+    const float4* sp = reinterpret_cast<const float4*>(feats + (size_t)(T.src_row[p] + m) * C);
+    float acc = 0.f;
+    for (int c4 = 0; c4 < C / 4; c4++) {
+      const float4 v = sp[c4];
+      acc += (rf[4 * c4] * v.x + rf[4 * c4 + 1] * v.y) + (rf[4 * c4 + 2] * v.z + rf[4 * c4 + 3] * v.w);
+    }
+    const float s = cm[m] ? __expf(-fmaxf(2.f - 2.f * acc, 0.f)) : 0.f;
+    Srow[m] = s;
+    rs += s;
+  }
+  rs = se3_wave_sum(rs);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = rs;
+  __syncthreads();
+  if (threadIdx.x == 0) rowsum[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(256) void sp_colsum_stack_kernel(const float* __restrict__ S, const unsigned char* __restrict__ masks,
+                                                              MatchPairs T, int64_t stride, float* __restrict__ colsum) {
+  __shared__ float part[4][64];
+  const int p = blockIdx.y, N = T.N[p], M = T.M[p];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int m = blockIdx.x * 64 + cl;
+  if (blockIdx.x * 64 >= M) return;
+  const float* Sp = S + (size_t)p * stride;
+  const unsigned char* rm = masks + T.ref_mask[p];
+  float cs = 0.f;
+  if (m < M)
+    for (int n = rl; n < N; n += 4) cs += rm[n] ? Sp[(size_t)n * M + m] : 0.f;
+  part[rl][cl] = cs;
+  __syncthreads();
+  if (rl == 0 && m < M) colsum[T.col0[p] + m] = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+}
+
+// dual normalisation in place; absent nodes and the padding beyond N * M get -1 (below every score), so that one top-k over
+// the padded rows selects per pair
+__global__ void sp_normalize_stack_kernel(float* __restrict__ S, const unsigned char* __restrict__ masks, MatchPairs T,
+                                          int64_t stride, const float* __restrict__ rowsum, const float* __restrict__ colsum,
+                                          int dual) {
+  const int p = blockIdx.y, N = T.N[p], M = T.M[p];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= stride) return;
+  float* Sp = S + (size_t)p * stride;
+  if (i >= (int64_t)N * M) {
+    Sp[i] = -1.f;
+    return;
+  }
+  const int n = (int)(i / M), m = (int)(i - (int64_t)n * M);
+  if (!masks[T.ref_mask[p] + n] || !masks[T.src_mask[p] + m]) {
+    Sp[i] = -1.f;
+    return;
+  }
+  if (dual) {
+    const float s = Sp[i];
+    Sp[i] = (s / rowsum[T.row0[p] + n]) * (s / colsum[T.col0[p] + m]);
+  }
+}
+
 }  // namespace
+
+extern "C" int se3_superpoint_scores_stack(const float* feats, const uint8_t* node_masks, const int64_t* ref_rows,
+                                           const int64_t* src_rows, const int64_t* ref_lengths, const int64_t* src_lengths,
+                                           const int64_t* ref_mask_offsets, const int64_t* src_mask_offsets, int num_pairs, int C,
+                                           int dual_normalization, int64_t score_stride, float* scores, float* workspace,
+                                           void* stream) {
+  SE3_REQUIRE(feats && node_masks && ref_rows && src_rows && ref_lengths && src_lengths && ref_mask_offsets && src_mask_offsets &&
+                  scores && workspace, SE3_ERR_INVALID_ARG, "superpoint_scores_stack: null pointer");
+  SE3_REQUIRE(num_pairs >= 1 && num_pairs <= kMaxMatchPairs && C >= 4 && C % 4 == 0 && C <= 4096, SE3_ERR_UNSUPPORTED,
+              "superpoint_scores_stack: %d pairs (1..%d), C %d", num_pairs, kMaxMatchPairs, C);
+  MatchPairs T{};
+  T.n = num_pairs;
+  int64_t rows = 0, cols = 0;
+  int max_m = 0;
+  for (int p = 0; p < num_pairs; p++) {
+    SE3_REQUIRE(ref_lengths[p] >= 1 && src_lengths[p] >= 1 && ref_lengths[p] * src_lengths[p] <= score_stride &&
+                    ref_rows[p] >= 0 && src_rows[p] >= 0 && ref_mask_offsets[p] >= 0 && src_mask_offsets[p] >= 0,
+                SE3_ERR_INVALID_ARG, "superpoint_scores_stack: pair %d descriptor", p);
+    T.ref_row[p] = (int)ref_rows[p];
+    T.src_row[p] = (int)src_rows[p];
+    T.N[p] = (int)ref_lengths[p];
+    T.M[p] = (int)src_lengths[p];
+    T.ref_mask[p] = (int)ref_mask_offsets[p];
+    T.src_mask[p] = (int)src_mask_offsets[p];
+    T.row0[p] = (int)rows;
+    T.col0[p] = (int)cols;
+    rows += ref_lengths[p];
+    cols += src_lengths[p];
+    max_m = T.M[p] > max_m ? T.M[p] : max_m;
+  }
+  T.row0[num_pairs] = (int)rows;
+  T.col0[num_pairs] = (int)cols;
+  SE3_REQUIRE(score_stride < (1ll << 31), SE3_ERR_UNSUPPORTED, "superpoint_scores_stack: %lld scores per pair", (long long)score_stride);
+  hipStream_t st = (hipStream_t)stream;
+  float* rowsum = workspace;               // rows floats
+  float* colsum = workspace + rows;        // cols floats
+  sp_scores_stack_kernel<<<(unsigned)rows, 256, C * sizeof(float), st>>>(feats, node_masks, T, C, score_stride, scores, rowsum);
+  if (dual_normalization)
+    sp_colsum_stack_kernel<<<dim3((unsigned)((max_m + 63) / 64), (unsigned)num_pairs), 256, 0, st>>>(scores, node_masks, T,
+                                                                                                  score_stride, colsum);
+  sp_normalize_stack_kernel<<<dim3((unsigned)((score_stride + 255) / 256), (unsigned)num_pairs), 256, 0, st>>>(
+      scores, node_masks, T, score_stride, rowsum, colsum, dual_normalization ? 1 : 0);
+  SE3_CHECK_LAUNCH("superpoint_scores_stack");
+  return SE3_OK;
+}
 
 extern "C" int se3_superpoint_scores(const float* ref_feats, const float* src_feats, int N, int M, int C,
                                      int dual_normalization, float* scores, float* workspace, void* stream) {

@@ -144,7 +144,120 @@ __global__ __launch_bounds__(256) void node_knn_kernel(const float* __restrict__
   }
 }
 
+// ---- stack mode: the clouds of several pairs in one launch -------------------------------------------------------------
+constexpr int kMaxPartClouds = 16;
+struct PartClouds {
+  int p0[kMaxPartClouds + 1];     // first point of cloud c in the stacked point array (p0[n] = total points)
+  int m0[kMaxPartClouds + 1];     // first node of cloud c in the stacked node array
+  int n;
+};
+
+// point i -> its cloud's nearest node (GLOBAL node index)
+__global__ __launch_bounds__(256) void nearest_node_stack_kernel(const float* __restrict__ pts, const float* __restrict__ nodes,
+                                                                 PartClouds T, int64_t* __restrict__ point_to_node,
+                                                                 unsigned char* __restrict__ node_masks) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= T.p0[T.n]) return;
+  int c = 0;
+  for (int k = 1; k < T.n; k++)
+    if (i >= T.p0[k]) c = k;
+  const int mb = T.m0[c], me = T.m0[c + 1];
+  const float px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2], p2 = sq_norm(px, py, pz);
+  unsigned long long best = ~0ull;
+  for (int m = mb + lane; m < me; m += 64) {
+    const float nx = nodes[3 * m], ny = nodes[3 * m + 1], nz = nodes[3 * m + 2];
+    const unsigned long long cand = make_key(pair_dist(nx, ny, nz, sq_norm(nx, ny, nz), px, py, pz, p2), (unsigned)m);
+    best = cand < best ? cand : best;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)(best & 0xffffffffull), o), hi = __shfl_xor((unsigned)(best >> 32), o);
+    const unsigned long long cand = ((unsigned long long)hi << 32) | lo;
+    best = cand < best ? cand : best;
+  }
+  if (lane == 0) {
+    const unsigned m = (unsigned)(best & 0xffffffffull);
+    point_to_node[i] = (int64_t)m;
+    node_masks[m] = 1;
+  }
+}
+
+// node m (global) -> the `limit` nearest of its own points (GLOBAL point indices, padded with the total point count)
+template <bool WIDE>
+__global__ __launch_bounds__(256) void node_knn_stack_kernel(const float* __restrict__ pts, const float* __restrict__ nodes,
+                                                             const int64_t* __restrict__ point_to_node, PartClouds T, int limit,
+                                                             int64_t* __restrict__ knn, unsigned char* __restrict__ knn_masks) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= T.m0[T.n]) return;
+  int c = 0;
+  for (int k = 1; k < T.n; k++)
+    if (m >= T.m0[k]) c = k;
+  const int pb = T.p0[c], pe = T.p0[c + 1], total = T.p0[T.n];
+  const float nx = nodes[3 * m], ny = nodes[3 * m + 1], nz = nodes[3 * m + 2], n2 = sq_norm(nx, ny, nz);
+  unsigned long long best = ~0ull, best1 = ~0ull;
+  for (int j0 = pb; j0 < pe; j0 += 64) {
+    const int j = j0 + lane;
+    const bool own = j < pe && point_to_node[j] == (int64_t)m;
+    unsigned long long cand = ~0ull;
+    if (own) {
+      const float px = pts[3 * j], py = pts[3 * j + 1], pz = pts[3 * j + 2];
+      cand = make_key(pair_dist(nx, ny, nz, n2, px, py, pz, sq_norm(px, py, pz)), (unsigned)j);
+    }
+    if (WIDE) wave_insert2(best, best1, cand, own);
+    else wave_insert(best, cand, own);
+  }
+  if (lane < limit) {
+    const bool have = best != ~0ull;
+    knn[(size_t)m * limit + lane] = have ? (int64_t)(unsigned)(best & 0xffffffffull) : (int64_t)total;
+    knn_masks[(size_t)m * limit + lane] = have ? 1 : 0;
+  }
+  if (WIDE && 64 + lane < limit) {
+    const bool have = best1 != ~0ull;
+    knn[(size_t)m * limit + 64 + lane] = have ? (int64_t)(unsigned)(best1 & 0xffffffffull) : (int64_t)total;
+    knn_masks[(size_t)m * limit + 64 + lane] = have ? 1 : 0;
+  }
+}
+
 }  // namespace
+
+extern "C" int se3_point_to_node_partition_stack(const float* points, const float* nodes, const int64_t* point_lengths,
+                                                 const int64_t* node_lengths, int num_clouds, int limit,
+                                                 int64_t* point_to_node, uint8_t* node_masks, int64_t* node_knn_indices,
+                                                 uint8_t* node_knn_masks, void* stream) {
+  SE3_REQUIRE(points && nodes && point_lengths && node_lengths && point_to_node && node_masks && node_knn_indices && node_knn_masks,
+              SE3_ERR_INVALID_ARG, "point_to_node_partition_stack: null pointer");
+  SE3_REQUIRE(num_clouds >= 1 && num_clouds <= kMaxPartClouds && limit >= 1 && limit <= 128, SE3_ERR_UNSUPPORTED,
+              "point_to_node_partition_stack: %d clouds (1..%d), limit %d (<= 128)", num_clouds, kMaxPartClouds, limit);
+  PartClouds T{};
+  T.n = num_clouds;
+  int64_t np = 0, nm = 0;
+  for (int c = 0; c < num_clouds; c++) {
+    SE3_REQUIRE(point_lengths[c] >= 1 && node_lengths[c] >= 1, SE3_ERR_INVALID_ARG, "point_to_node_partition_stack: empty cloud %d", c);
+    T.p0[c] = (int)np;
+    T.m0[c] = (int)nm;
+    np += point_lengths[c];
+    nm += node_lengths[c];
+  }
+  SE3_REQUIRE(np < (1ll << 31) && nm < (1ll << 31), SE3_ERR_UNSUPPORTED, "point_to_node_partition_stack: too many points");
+  T.p0[num_clouds] = (int)np;
+  T.m0[num_clouds] = (int)nm;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(node_masks, 0, (size_t)nm, st) != hipSuccess) {
+    se3_set_error("point_to_node_partition_stack: memset failed");
+    return SE3_ERR_LAUNCH;
+  }
+  nearest_node_stack_kernel<<<(unsigned)se3_cdiv(np, 4), 256, 0, st>>>(points, nodes, T, point_to_node, node_masks);
+  if (limit <= 64)
+    node_knn_stack_kernel<false><<<(unsigned)se3_cdiv(nm, 4), 256, 0, st>>>(points, nodes, point_to_node, T, limit,
+                                                                            node_knn_indices, node_knn_masks);
+  else
+    node_knn_stack_kernel<true><<<(unsigned)se3_cdiv(nm, 4), 256, 0, st>>>(points, nodes, point_to_node, T, limit,
+                                                                           node_knn_indices, node_knn_masks);
+  SE3_CHECK_LAUNCH("point_to_node_partition_stack");
+  return SE3_OK;
+}
 
 extern "C" int se3_knn3(const float* points, int N, int64_t* knn, void* stream) {
   SE3_REQUIRE(points && knn, SE3_ERR_INVALID_ARG, "knn3: null pointer");

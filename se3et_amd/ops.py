@@ -683,6 +683,48 @@ def point_to_node_partition(points, nodes, point_limit):
     return p2n, masks, knn, knn_masks
 
 
+def point_to_node_partition_stack(points, nodes, point_lengths, node_lengths, point_limit):
+    """HIP (csrc/partition.hip), all clouds in one launch per kernel: stacked fine points / superpoints with per-cloud lengths
+    (host lists).  GLOBAL indices: (point_to_node (P,), node_masks (M,) bool, node_knn_indices (M, K) padded with P,
+    node_knn_masks (M, K) bool)."""
+    points = _req(points.contiguous(), torch.float32, 'points', 2)
+    nodes = _req(nodes.contiguous(), torch.float32, 'nodes', 2)
+    if len(point_lengths) != len(node_lengths) or sum(point_lengths) != points.shape[0] or sum(node_lengths) != nodes.shape[0]:
+        raise RuntimeError('point_to_node_partition_stack: lengths do not add up to the stacked arrays')
+    P, M, K = points.shape[0], nodes.shape[0], int(point_limit)
+    dev = points.device
+    p2n = torch.empty((P,), dtype=torch.int64, device=dev)
+    masks = torch.empty((M,), dtype=torch.bool, device=dev)
+    knn = torch.empty((M, K), dtype=torch.int64, device=dev)
+    knn_masks = torch.empty((M, K), dtype=torch.bool, device=dev)
+    check(lib().se3_point_to_node_partition_stack(points.data_ptr(), nodes.data_ptr(), _i64_array(point_lengths),
+                                                  _i64_array(node_lengths), len(point_lengths), K, p2n.data_ptr(), masks.data_ptr(),
+                                                  knn.data_ptr(), knn_masks.data_ptr(), _stream()), 'se3_point_to_node_partition_stack')
+    return p2n, masks, knn, knn_masks
+
+
+def superpoint_scores_stack(feats, node_masks, ref_rows, src_rows, ref_lengths, src_lengths, ref_mask_offsets, src_mask_offsets,
+                            dual_normalization):
+    """HIP (csrc/matching.hip), all pairs in one launch per kernel: feats (rows, C) unit superpoint features, node_masks bool
+    (nodes,); per pair (host lists) the first ref / src row, the counts and the first ref / src entry of node_masks.  Returns
+    (B, max_p N_p * M_p) scores: pair p's (N_p, M_p) matrix at the start of row p, -1 for absent nodes and beyond."""
+    feats = _req(feats.contiguous(), torch.float32, 'feats', 2)
+    node_masks = _req(node_masks.contiguous(), torch.bool, 'node_masks', 1)
+    B, C = len(ref_rows), feats.shape[1]
+    for p in range(B):
+        if ref_rows[p] + ref_lengths[p] > feats.shape[0] or src_rows[p] + src_lengths[p] > feats.shape[0] or \
+                ref_mask_offsets[p] + ref_lengths[p] > node_masks.shape[0] or src_mask_offsets[p] + src_lengths[p] > node_masks.shape[0]:
+            raise RuntimeError('superpoint_scores_stack: pair %d exceeds the feature rows / node masks' % p)
+    stride = max(n * m for n, m in zip(ref_lengths, src_lengths))
+    scores = torch.empty((B, stride), dtype=torch.float32, device=feats.device)
+    ws = torch.empty((sum(ref_lengths) + sum(src_lengths),), dtype=torch.float32, device=feats.device)
+    check(lib().se3_superpoint_scores_stack(feats.data_ptr(), node_masks.data_ptr(), _i64_array(ref_rows), _i64_array(src_rows),
+                                            _i64_array(ref_lengths), _i64_array(src_lengths), _i64_array(ref_mask_offsets),
+                                            _i64_array(src_mask_offsets), B, C, 1 if dual_normalization else 0, stride,
+                                            scores.data_ptr(), ws.data_ptr(), _stream()), 'se3_superpoint_scores_stack')
+    return scores
+
+
 def superpoint_scores(ref_feats, src_feats, dual_normalization):
     """HIP (csrc/matching.hip): exp(-||f_r - f_s||^2) on unit features with dual normalisation."""
     ref_feats = _req(ref_feats.contiguous(), torch.float32, 'ref_feats', 2)

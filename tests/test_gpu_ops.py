@@ -486,6 +486,68 @@ def test_point_to_node_partition_matches_oracle(N, M, K):
         assert bool((p2n[g] == m).all()) and len(set(g.tolist())) == len(g), 'node %d: foreign or repeated points' % m
 
 
+@pytest.mark.parametrize('K', [64, 128])
+def test_point_to_node_partition_stack_equals_per_cloud_calls(K):
+    """se3_point_to_node_partition_stack (all clouds in one launch per kernel, global indices) against one
+    se3_point_to_node_partition call per cloud."""
+    from se3et_amd import ops
+    g = torch.Generator().manual_seed(21)
+    plen, nlen = [2500, 1800, 700, 300, 64], [382, 304, 59, 7, 90]          # the last cloud has more nodes than points
+    pts = [torch.rand(n, 3, generator=g) * torch.tensor([1.5, 1.2, 1.0]) + 3.0 * c for c, n in enumerate(plen)]
+    nodes = [p[torch.randperm(len(p), generator=g)[:m]] if m <= len(p) else torch.rand(m, 3, generator=g) + 3.0 * c
+             for c, (p, m) in enumerate(zip(pts, nlen))]
+    P, M = torch.cat(pts).cuda(), torch.cat(nodes).cuda()
+    p2n, masks, knn, km = ops.point_to_node_partition_stack(P, M, plen, nlen, K)
+    p0 = m0 = 0
+    for p, nd in zip(pts, nodes):
+        a, b, c, d = ops.point_to_node_partition(p.cuda(), nd.cuda(), K)
+        n, m = len(p), len(nd)
+        assert torch.equal(p2n[p0:p0 + n], a + m0)
+        assert torch.equal(masks[m0:m0 + m], b)
+        want = torch.where(c == n, torch.full_like(c, P.shape[0]), c + p0)
+        assert torch.equal(knn[m0:m0 + m], want)
+        assert torch.equal(km[m0:m0 + m], d)
+        p0 += n
+        m0 += m
+
+
+@pytest.mark.parametrize('masked', [False, True])
+def test_superpoint_scores_stack_equals_per_pair_calls(masked):
+    """se3_superpoint_scores_stack (all pairs in one launch per kernel, padded rows, absent nodes = -1) against
+    se3_superpoint_scores per pair on the compacted features (the reference drops empty nodes before scoring,
+    superpoint_matching.py:24-29)."""
+    from se3et_amd import ops
+    g = torch.Generator().manual_seed(22)
+    C = 256
+    Ns, Ms = [382, 59, 16], [304, 53, 14]
+    rows = 1010                                      # the pairs sit at arbitrary row offsets of one feature array
+    feats = torch.nn.functional.normalize(torch.randn(rows, C, generator=g), dim=1).cuda()
+    ref_rows, src_rows = [0, 400, 520], [700, 460, 540]
+    node_masks = torch.ones(sum(Ns) + sum(Ms), dtype=torch.bool)
+    if masked:
+        node_masks[torch.randperm(len(node_masks), generator=g)[:60]] = False
+    ref_off, src_off, o = [], [], 0
+    for n, m in zip(Ns, Ms):
+        ref_off.append(o)
+        src_off.append(o + n)
+        o += n + m
+    S = ops.superpoint_scores_stack(feats, node_masks.cuda(), ref_rows, src_rows, Ns, Ms, ref_off, src_off, True)
+    assert S.shape == (3, max(n * m for n, m in zip(Ns, Ms)))
+    for p, (n, m) in enumerate(zip(Ns, Ms)):
+        rm, sm = node_masks[ref_off[p]:ref_off[p] + n], node_masks[src_off[p]:src_off[p] + m]
+        ri, si = torch.nonzero(rm)[:, 0].cuda(), torch.nonzero(sm)[:, 0].cuda()
+        want = ops.superpoint_scores(feats[ref_rows[p]:ref_rows[p] + n][ri].contiguous(), feats[src_rows[p]:src_rows[p] + m][si].contiguous(), True)
+        got = S[p, :n * m].view(n, m)
+        sub = got[ri][:, si]
+        if masked:
+            assert_close(sub.cpu(), want.cpu(), 1e-6, 'stack-mode superpoint scores, pair %d' % p)
+        else:
+            assert torch.equal(sub, want)
+        absent = torch.ones(n, m, dtype=torch.bool)
+        absent[rm[:, None] & sm[None, :]] = False
+        assert bool((got.cpu()[absent] == -1).all()) and bool((S[p, n * m:] == -1).all())
+
+
 @pytest.mark.parametrize('N', [382, 59, 5, 1500])
 def test_knn3_matches_oracle(N):
     from oracle import se3et_oracle as O
