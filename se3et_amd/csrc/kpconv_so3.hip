@@ -49,10 +49,17 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
   const int cols = kA * Cin;
   const float qx = q_pts[3 * p], qy = q_pts[3 * p + 1], qz = q_pts[3 * p + 2];
   const int NN8 = (NN + 7) & ~7;
-  for (int n = threadIdx.x; n < NN8; n += blockDim.x) {
+  __shared__ int last_s;                 // 1 + position of the last valid neighbour
+  if (threadIdx.x < 64) {                // NN8 <= 64: the first wave fills the table
+    const int n = threadIdx.x;
     const int64_t j = n < NN ? idx[p * NN + n] : -1;
-    nb[n] = j;
-    xrow[n] = (j >= 0 && j < Ns) ? (unsigned)j * (unsigned)cols : 0u;
+    const bool valid = j >= 0 && j < Ns;
+    if (n < NN8) {
+      nb[n] = j;
+      xrow[n] = valid ? (unsigned)j * (unsigned)cols : 0u;
+    }
+    const unsigned long long m = __ballot(valid);
+    if (n == 0) last_s = m ? 64 - __clzll((long long)m) : 0;
   }
   __syncthreads();
   for (int e = threadIdx.x; e < NN8 * kK; e += blockDim.x) {
@@ -67,6 +74,10 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
     w[n][k] = v;
   }
   __syncthreads();
+  // the tables are padded at the end (sorted by distance, then the padding index / the -1 width marker): only the leading valid
+  // entries carry weight, so the loop stops after the last valid one (rounded up to the 8 rows in flight; skipped terms are
+  // exact zeros, the sums are unchanged)
+  const int NV8 = (last_s + 7) & ~7;
   for (int col = threadIdx.x; col < cols; col += blockDim.x) {
     const int a = col / Cin, c = col - a * Cin;
     float f[kK];
@@ -74,7 +85,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
     for (int k = 0; k < kK; k++) f[k] = 0.f;
     // 8 gathered rows in flight per thread (the loop is otherwise one L2 round trip per neighbour); padded / shadow
     // neighbours read row 0 with weight 0, so the body is branch-free
-    for (int n0 = 0; n0 < NN8; n0 += 8) {
+    for (int n0 = 0; n0 < NV8; n0 += 8) {
       float xv[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) xv[u] = x[xrow[n0 + u] + (unsigned)col];

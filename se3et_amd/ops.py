@@ -286,15 +286,16 @@ _host_table_cache = {}
 
 
 def _host_table(t, dtype):
-    """Constant module tables (kernel points, permutation indices) as host arrays; cached per tensor version."""
-    key = (t.data_ptr(), t._version, tuple(t.shape))
+    """Constant module tables (kernel points, permutation indices) as host arrays; cached per tensor object and version (the
+    entry holds a weak reference: a freed tensor's address and id can be handed to another tensor with other values)."""
+    key = (id(t), t._version, tuple(t.shape))
     hit = _host_table_cache.get(key)
-    if hit is None:
-        hit = t.detach().to('cpu', dtype).contiguous()
+    if hit is None or hit[1]() is not t:
+        hit = (t.detach().to('cpu', dtype).contiguous(), weakref.ref(t))
         if len(_host_table_cache) > 256:
             _host_table_cache.clear()
         _host_table_cache[key] = hit
-    return hit
+    return hit[0]
 
 
 def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, sigma):
