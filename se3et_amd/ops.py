@@ -20,8 +20,12 @@ _BIG_GEMM_FLOP = 2.0e9     # above this the hipBLASLt kernels win (KPConv GEMMs:
 
 
 def mm(a, b):
-    """a (M, K) @ b (K, N) through the cheaper-to-dispatch rocBLAS path, or hipBLASLt for the few large products."""
-    if _HAS_BLAS_SWITCH and 2.0 * a.shape[0] * a.shape[1] * b.shape[1] > _BIG_GEMM_FLOP:
+    """a (M, K) @ b (K, N) through the cheaper-to-dispatch rocBLAS path, or hipBLASLt where its kernels win: the large products
+    with a row-major right operand (the KPConv (P*6, 36 Cin) @ (36 Cin, Cout) products) and K <= 32.  For the dense layers
+    x @ W^T (transposed view of the (N, K) weight) rocBLAS's kernels are the faster ones at every size measured
+    (tests/micro/unary_gemm_backends.py: 1.0-1.4x of the HBM / MFMA bound against 1.1-2.6x)."""
+    big = 2.0 * a.shape[0] * a.shape[1] * b.shape[1] > _BIG_GEMM_FLOP
+    if _HAS_BLAS_SWITCH and big and (b.stride(-1) == 1 or a.shape[1] <= 32):
         torch.backends.cuda.preferred_blas_library('cublaslt')
         try:
             return torch.mm(a, b)
@@ -286,12 +290,14 @@ _host_table_cache = {}
 
 
 def _host_table(t, dtype):
-    """Constant module tables (kernel points, permutation indices) as host arrays; cached per tensor object and version (the
-    entry holds a weak reference: a freed tensor's address and id can be handed to another tensor with other values)."""
-    key = (id(t), t._version, tuple(t.shape))
+    """Constant module tables (kernel points, permutation indices) as host arrays, cached per owning tensor object, view and
+    version.  The entry holds a weak reference to the owner (the module's parameter / buffer; for a view, its base): a freed
+    tensor's address and id can be handed to another tensor with other values, so neither alone identifies the table."""
+    base = t._base if t._base is not None else t
+    key = (id(base), base._version, t.data_ptr(), tuple(t.shape), tuple(t.stride()))
     hit = _host_table_cache.get(key)
-    if hit is None or hit[1]() is not t:
-        hit = (t.detach().to('cpu', dtype).contiguous(), weakref.ref(t))
+    if hit is None or hit[1]() is not base:
+        hit = (t.detach().to('cpu', dtype).contiguous(), weakref.ref(base))
         if len(_host_table_cache) > 256:
             _host_table_cache.clear()
         _host_table_cache[key] = hit
