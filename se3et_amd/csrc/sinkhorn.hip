@@ -10,9 +10,27 @@
 
 namespace {
 
+// butterfly exchange inside an aligned group of LANES (4 or 8) lanes on the DPP path (no LDS permute)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int LANES>
+__device__ __forceinline__ float group_max(float m) {
+  if (LANES == 8) m = fmaxf(m, dpp_mov<0x141>(m));      // row_half_mirror: lane i <-> 7 - i
+  m = fmaxf(m, dpp_mov<0x4E>(m));                       // quad_perm [2, 3, 0, 1]
+  return fmaxf(m, dpp_mov<0xB1>(m));                    // quad_perm [1, 0, 3, 2]
+}
+template <int LANES>
+__device__ __forceinline__ float group_sum(float s) {
+  if (LANES == 8) s += dpp_mov<0x141>(s);
+  s += dpp_mov<0x4E>(s);
+  return s + dpp_mov<0xB1>(s);
+}
+
 constexpr int kThreads = 576;      // 9 waves: (65 rows) x 8 lanes, or (129 rows) x 4 lanes
 
-template <int LANES, int EPL>      // lanes cooperating on one row/column, entries per lane
+template <int LANES, int EPL>      // lanes cooperating on one row/column (4 or 8), entries per lane
 __global__ __launch_bounds__(kThreads) void sinkhorn_kernel(const float* __restrict__ scores,
                                                             const uint8_t* __restrict__ row_masks,
                                                             const uint8_t* __restrict__ col_masks,
@@ -75,13 +93,11 @@ __global__ __launch_bounds__(kThreads) void sinkhorn_kernel(const float* __restr
         t[e] = (j < C1) ? zr[e] + v[j] : -INFINITY;
         m = fmaxf(m, t[e]);
       }
-#pragma unroll
-      for (int o = LANES / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      m = group_max<LANES>(m);
       float s = 0.f;
 #pragma unroll
-      for (int e = 0; e < EPL; e++) s += expf(t[e] - m);
-#pragma unroll
-      for (int o = LANES / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      for (int e = 0; e < EPL; e++) s += __expf(t[e] - m);
+      s = group_sum<LANES>(s);
       if (sub == 0 && owner < R1) u[owner] = log_mu[owner] - (logf(s) + m);
     }
     __syncthreads();
@@ -93,13 +109,11 @@ __global__ __launch_bounds__(kThreads) void sinkhorn_kernel(const float* __restr
         t[e] = (i < R1) ? zc[e] + u[i] : -INFINITY;
         m = fmaxf(m, t[e]);
       }
-#pragma unroll
-      for (int o = LANES / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      m = group_max<LANES>(m);
       float s = 0.f;
 #pragma unroll
-      for (int e = 0; e < EPL; e++) s += expf(t[e] - m);
-#pragma unroll
-      for (int o = LANES / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      for (int e = 0; e < EPL; e++) s += __expf(t[e] - m);
+      s = group_sum<LANES>(s);
       if (sub == 0 && owner < C1) v[owner] = log_nu[owner] - (logf(s) + m);
     }
     __syncthreads();
