@@ -218,13 +218,15 @@ int se3_cross_eq_apply(const float* q, const float* k, const float* vt, const fl
  * k (A, Rk, C) hold the packed rows of all pairs (pair p: query rows q_starts[p] .. + q_lengths[p], key rows k_starts[p] .. +
  * k_lengths[p]; row stride C, anchor strides given), vt (A, C, v_row_stride) the transposed values addressed by key column
  * (k_starts multiples of 4, ceil32(k_lengths[p]) columns readable).  partial_workspace: num_pairs * A*A * max_p ceil(N_p/32)
- * floats; mix (num_pairs, A, A); weights (num_pairs, A*A) for mode 0 / (num_pairs, num_rotations) for mode 1; out (A, Rq, C) in
+ * floats; with sums_given != 0 its first num_pairs * A*A floats already hold sum_{n,m} (mean_h S[a,e,h,n,m])^2 of every
+ * (pair, a, e) and the statistics launch is skipped (mean_h S = (scale/H) q_a[n].k_e[m] over all C channels, so the caller can
+ * get the sums from two Gram matrices per pair: (scale/H)^2 <Q_a^T Q_a, K_e^T K_e>_F -- 3.5x fewer flops, library GEMMs); mix (num_pairs, A, A); weights (num_pairs, A*A) for mode 0 / (num_pairs, num_rotations) for mode 1; out (A, Rq, C) in
  * the packing of q.  num_pairs <= 16. */
 int se3_cross_eq_stack_fwd(const float* q, const float* k, const float* vt, const int64_t* q_starts, const int64_t* q_lengths,
                            const int64_t* k_starts, const int64_t* k_lengths, int num_pairs, int A, int C, int H,
                            int64_t q_anchor_stride, int64_t k_anchor_stride, int v_row_stride, int64_t v_anchor_stride, int mode,
-                           const int64_t* trace_idx, int num_rotations, float* partial_workspace, float* mix, float* weights,
-                           float* out, void* stream);
+                           const int64_t* trace_idx, int num_rotations, int sums_given, float* partial_workspace, float* mix,
+                           float* weights, float* out, void* stream);
 
 
 /* ---- G1/G2: geometric structure embedding --------------------------------------------------------------------------

@@ -41,7 +41,7 @@ SIGNATURES = {
     'se3_rpe_self_attention_stack_bf16_fwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp]),
     'se3_cross_eq_stats': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     'se3_cross_eq_mix': (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
-    'se3_cross_eq_stack_fwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'se3_cross_eq_stack_fwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _i64, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'se3_cross_eq_apply': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     'se3_geo_embedding_fwd': (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _f32, _vp, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     'se3_geo_embedding_bf16_fwd': (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _f32, _vp, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),

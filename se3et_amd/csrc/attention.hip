@@ -1300,7 +1300,8 @@ extern "C" int se3_cross_eq_stack_fwd(const float* q, const float* k, const floa
                                       const int64_t* q_lengths, const int64_t* k_starts, const int64_t* k_lengths, int num_pairs,
                                       int A, int C, int H, int64_t q_anchor_stride, int64_t k_anchor_stride, int v_row_stride,
                                       int64_t v_anchor_stride, int mode, const int64_t* trace_idx, int num_rotations,
-                                      float* partial_workspace, float* mix, float* weights, float* out, void* stream) {
+                                      int sums_given, float* partial_workspace, float* mix, float* weights, float* out,
+                                      void* stream) {
   SE3_REQUIRE(q && k && vt && q_starts && q_lengths && k_starts && k_lengths && partial_workspace && mix && weights && out,
               SE3_ERR_INVALID_ARG, "cross_eq_stack: null pointer");
   SE3_REQUIRE(num_pairs >= 1 && num_pairs <= kMaxClouds, SE3_ERR_UNSUPPORTED, "cross_eq_stack: %d pairs (1..%d)", num_pairs, kMaxClouds);
@@ -1324,8 +1325,11 @@ extern "C" int se3_cross_eq_stack_fwd(const float* q, const float* k, const floa
   hipStream_t st = (hipStream_t)stream;
   int rc = dispatch_head_dim(C / H, [&](auto d) {
     constexpr int D = decltype(d)::value;
-    cross_eq_stats_stack_kernel<D><<<dim3((unsigned)qt, (unsigned)(A * A), (unsigned)num_pairs), 256, 0, st>>>(p, partial_workspace);
-    cross_eq_mix_kernel<<<(unsigned)num_pairs, 64, 0, st>>>(partial_workspace, qt, 0.f, A, num_rotations, trace_idx, mode, mix,
+    // sums_given: partial_workspace already holds sum_{n,m} (mean_h S[a,e,h,n,m])^2 per (pair, a, e) (the caller computed it from
+    // Gram matrices: mean_h S = (scale / H) q_a[n].k_e[m] over all C channels, so the sum is (scale/H)^2 <Q_a^T Q_a, K_e^T K_e>)
+    if (!sums_given)
+      cross_eq_stats_stack_kernel<D><<<dim3((unsigned)qt, (unsigned)(A * A), (unsigned)num_pairs), 256, 0, st>>>(p, partial_workspace);
+    cross_eq_mix_kernel<<<(unsigned)num_pairs, 64, 0, st>>>(partial_workspace, sums_given ? 1 : qt, 0.f, A, num_rotations, trace_idx, mode, mix,
                                                          weights, nullptr, p.S, 1);
     if (A <= 6)
       cross_eq_apply_stack_kernel<D, 6><<<dim3((unsigned)qt, (unsigned)H, (unsigned)(A * num_pairs)), 384, 0, st>>>(p, mix, out);

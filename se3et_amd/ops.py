@@ -585,6 +585,32 @@ def cross_attention_eq(q, k, vt, num_heads, mode, trace_idx):
     return out, ret, mix
 
 
+_pair_rows_cache = {}
+
+
+def _pair_rows(starts, lengths, device):
+    """(P * W,) row indices and a (1, P, W, 1) 0/1 mask that cut the packed rows of P clouds into P windows of W rows."""
+    key = (tuple(int(s) for s in starts), tuple(int(n) for n in lengths), str(device))
+    hit = _pair_rows_cache.get(key)
+    if hit is None:
+        W = max(key[1])
+        idx = torch.tensor([[s + min(j, n - 1) for j in range(W)] for s, n in zip(key[0], key[1])], dtype=torch.int64)
+        mask = torch.tensor([[1.0 if j < n else 0.0 for j in range(W)] for n in key[1]], dtype=torch.float32)
+        hit = (idx.view(-1).to(device), mask.view(1, len(key[1]), W, 1).to(device), W)
+        if len(_pair_rows_cache) > 64:
+            _pair_rows_cache.clear()
+        _pair_rows_cache[key] = hit
+    return hit
+
+
+def _gram_per_pair(x, starts, lengths):
+    """x (A, R, C) packed rows -> (A, P, C, C): X_p^T X_p over the rows of every pair (library GEMM)."""
+    idx, mask, W = _pair_rows(starts, lengths, x.device)
+    A, P, C = x.shape[0], len(starts), x.shape[2]
+    win = x.index_select(1, idx).view(A * P, W, C)
+    return torch.bmm((win * mask.view(1, P, W, 1).expand(A, P, W, 1).reshape(A * P, W, 1)).transpose(1, 2), win).view(A, P, C, C)
+
+
 def cross_attention_eq_stack(q, k, vt, q_starts, q_lengths, k_starts, k_lengths, num_heads, mode, trace_idx, out):
     """HIP: equivariant cross attention of all pairs of a batch (se3_cross_eq_stack_fwd).  q (A, Rq, C), k (A, Rk, C) packed rows,
     vt (A, C, Rk) transposed values, out (A, Rq, C) (rows outside the pairs are left untouched).  Returns the per-pair mixing
@@ -604,14 +630,18 @@ def cross_attention_eq_stack(q, k, vt, q_starts, q_lengths, k_starts, k_lengths,
             raise RuntimeError('cross_attention_eq_stack: pair %d exceeds the packed rows / value columns' % p)
     trace_idx = _req(trace_idx.contiguous(), torch.int64, 'trace_idx', 2)
     R = trace_idx.shape[0]
-    qt = max((int(n) + 31) // 32 for n in q_lengths)
     dev = q.device
-    partial = torch.empty((P * A * A * qt,), dtype=torch.float32, device=dev)
+    # anchor-pair statistics sum_{n,m} (mean_h S[a,e,h,n,m])^2: the head mean of the per-head dot products is the dot product
+    # over all C channels, so the sum is (scale / H)^2 <Q_a^T Q_a, K_e^T K_e>_F -- two Gram products per pair instead of the
+    # (A*A, N, M) score pass of se3_cross_eq_stats (vanilla_transformer.py:380-389,425-426 computes the scores themselves)
+    f = 1.0 / (math.sqrt(C // int(num_heads)) * int(num_heads))
+    gq, gk = _gram_per_pair(q, q_starts, q_lengths), _gram_per_pair(k, k_starts, k_lengths)
+    partial = torch.bmm(gq.view(A, P, C * C).transpose(0, 1), gk.view(A, P, C * C).permute(1, 2, 0)) * (f * f)      # (P, A, A)
     mix = torch.empty((P, A, A), dtype=torch.float32, device=dev)
     weights = torch.empty((P, A * A if mode == 'a_soft' else R), dtype=torch.float32, device=dev)
     check(lib().se3_cross_eq_stack_fwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(), _i64_array(q_starts), _i64_array(q_lengths),
                                        _i64_array(k_starts), _i64_array(k_lengths), P, A, C, int(num_heads), q.stride(0), k.stride(0),
-                                       vt.stride(1), vt.stride(0), 0 if mode == 'a_soft' else 1, trace_idx.data_ptr(), R,
+                                       vt.stride(1), vt.stride(0), 0 if mode == 'a_soft' else 1, trace_idx.data_ptr(), R, 1,
                                        partial.data_ptr(), mix.data_ptr(), weights.data_ptr(), out.data_ptr(), _stream()),
           'se3_cross_eq_stack_fwd')
     return mix, weights
