@@ -228,6 +228,8 @@ if __name__ == '__main__':
         gen_synthw('se3ete2.3dmatch', 'synthw_se3ete2.npz')
         gen_synthw('se3eti2.3dmatch', 'synthw_se3eti2.npz')
         gen_synthw('se3ete.3dmatch', 'synthw_se3ete.npz')
+    if 'kitti' in which or 'synthw' in which:
+        gen_synthw('se3eti.kitti', 'synthw_se3eti_kitti.npz', pair='c3_4k')
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, 'KiB')
