@@ -252,13 +252,8 @@ def run_cpu_baseline(model, cfg, args):
     cores = max(1, min(avail, 16))          # the small CPU ops of this path stop scaling (and thrash) beyond ~16 threads
     torch.set_num_threads(cores)
     state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    g, b = cfg.geotransformer, cfg.backbone
-    oc = O.OracleConfig(num_stages=b.num_stages, init_voxel_size=b.init_voxel_size, base_radius=b.base_radius,
-                        group_norm=b.group_norm, init_dim=b.init_dim, output_dim=b.output_dim,
-                        neighbor_limits=list(cfg.neighbor_limits), num_points_in_patch=cfg.model.num_points_in_patch,
-                        gt_hidden_dim=g.hidden_dim, gt_num_heads=g.num_heads, blocks=list(g.blocks), sigma_d=g.sigma_d,
-                        sigma_a=g.sigma_a, angle_k=g.angle_k, n_level_equiv=g.n_level_equiv,
-                        lgr_topk=cfg.fine_matching.topk, lgr_acceptance_radius=cfg.fine_matching.acceptance_radius)
+    b = cfg.backbone
+    oc = O.OracleConfig.from_model_cfg(cfg)
 
     def one(i):
         ref, src, _ = make_pair(args.pair, index=i)

@@ -13,6 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import functional as SF
+from . import tables
 from .modules.e2pn import InvOutBlockEPN, LiftBlockEPN, ResnetBottleneckBlockEPN, SimpleBlockEPN
 from .modules.geotransformer import GeometricTransformer, LocalGlobalRegistration, SuperPointMatching
 from .modules.kpconv import LastUnaryBlock, UnaryBlock, nearest_upsample
@@ -134,6 +135,17 @@ class SE3ET(nn.Module):
                                                      correspondence_limit=f.correspondence_limit,
                                                      num_refinement_steps=f.num_refinement_steps)
         self.optimal_transport = LearnableLogOptimalTransport(cfg.model.num_sinkhorn_iterations)
+        if cfg.variant.endswith('kitti'):
+            # The reference's KITTI model always constructs its rotation-supervision and anchor-matching heads
+            # (experiments/se3eti.kitti/model.py:82-87) although the forward only reaches them with supervise_rotation /
+            # anchor_matching (both off in its config).  They are carried as parameter holders so that a reference checkpoint
+            # loads with strict=True; nothing here evaluates them.
+            C, na = g.output_dim, cfg.epn.kanchor
+            self.rotation_supervision = nn.ModuleDict({'proj_q': nn.Linear(C, C), 'proj_k': nn.Linear(C, C)})
+            pi = nn.Module()
+            pi.anchors = nn.Parameter(torch.from_numpy(tables.rotations().astype('float32')), requires_grad=False)
+            pi.fc1, pi.batch_norm, pi.fc2 = nn.Linear(na * C, na * C), nn.BatchNorm1d(na * C), nn.Linear(na * C, C)
+            self.permutation_invariant = pi
         self._tls = threading.local()       # per-thread pinned scratch (pairs may be processed by several host threads)
         self.stage_hook = None              # optional callable invoked between backbone and transformer (pipelined drivers)
 

@@ -122,7 +122,8 @@ def test_per_op_fixtures(golden_dir):
         assert float((sk[valid] - want[valid]).abs().max()) < 1e-5 * float(want[valid].abs().max())
 
 
-@pytest.mark.parametrize('variant,fixture', [('se3ete2', 'synthw_se3ete2.npz'), ('se3eti2', 'synthw_se3eti2.npz')])
+@pytest.mark.parametrize('variant,fixture', [('se3ete2', 'synthw_se3ete2.npz'), ('se3eti2', 'synthw_se3eti2.npz'),
+                                             ('se3eti_kitti', 'synthw_se3eti_kitti.npz')])
 def test_real_width_forward_matches_reference(golden_dir, variant, fixture):
     """Oracle + the product's own state-dict construction (tables, names, shapes) + name-keyed synthetic weights."""
     from oracle import se3et_oracle as O
@@ -139,10 +140,9 @@ def test_real_width_forward_matches_reference(golden_dir, variant, fixture):
         assert tuple(sd[n].shape) == want and str(sd[n].dtype) == 'torch.' + str(dt), n
     ref, src, _ = make_pair(str(g['pair']))
     pts = torch.from_numpy(np.concatenate([ref, src], 0))
-    b, t = cfg.backbone, cfg.geotransformer
-    oc = O.OracleConfig(init_dim=b.init_dim, output_dim=b.output_dim, group_norm=b.group_norm, gt_hidden_dim=t.hidden_dim,
-                        blocks=list(t.blocks), n_level_equiv=t.n_level_equiv)
-    data = O.precompute(pts, torch.tensor([len(ref), len(src)]), 4, b.init_voxel_size, b.init_radius, cfg.neighbor_limits)
+    b = cfg.backbone
+    oc = O.OracleConfig.from_model_cfg(cfg)
+    data = O.precompute(pts, torch.tensor([len(ref), len(src)]), b.num_stages, b.init_voxel_size, b.init_radius, cfg.neighbor_limits)
     assert np.array_equal(np.stack([l.numpy() for l in data['lengths']]), g['lengths'])
     data['features'] = torch.ones((pts.shape[0], 1))
     with torch.no_grad():
