@@ -17,6 +17,7 @@
 //   cross_eq_apply     out[a] = sum_e W[a, e] softmax_m(S[a, e]) v_e (vanilla_transformer.py:812-818; r_soft collapsed from
 //                      24 rotations to the (A, A) anchor pairs, :506-577,839-845).
 #include <hip/hip_ext.h>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 #include "common.h"
@@ -975,12 +976,14 @@ struct TimedLaunch {
 };
 static bool g_time_kernels = false;
 static std::vector<TimedLaunch> g_timed;
+static std::recursive_mutex g_timed_mutex;      // several host threads may launch (one HIP stream each)
 
 template <typename K, typename... Args>
 static void launch_kernel(int tag, K kernel, dim3 grid, dim3 block, hipStream_t st, Args... args) {
   if (g_time_kernels) {
     TimedLaunch t{nullptr, nullptr, tag};
     if (hipEventCreate(&t.start) == hipSuccess && hipEventCreate(&t.stop) == hipSuccess) {
+      std::lock_guard<std::recursive_mutex> lock(g_timed_mutex);
       hipExtLaunchKernelGGL(kernel, grid, block, 0, st, t.start, t.stop, 0, args...);
       g_timed.push_back(t);
       return;
@@ -994,6 +997,7 @@ extern "C" void se3_debug_kernel_timing(int enable) { g_time_kernels = enable !=
 // Waits for the recorded launches, writes their durations (microseconds) and tags in launch order, releases the events and
 // returns the number of launches recorded (entries beyond `capacity` are dropped).
 extern "C" int se3_debug_kernel_timing_collect(float* microseconds, int* tags, int capacity) {
+  std::lock_guard<std::recursive_mutex> lock(g_timed_mutex);
   int n = 0;
   for (const TimedLaunch& t : g_timed) {
     float ms = 0.f;
@@ -1238,6 +1242,9 @@ static int rpe_self_attention_stack(const float* q, const float* k, const float*
     offsets[c] = total;
     total += (int64_t)num_anchors * H * lengths[c] * (((lengths[c] + 31) / 32) * 32);
   }
+  // the two timed launches of one call stay adjacent in the record even when several host threads launch
+  std::unique_lock<std::recursive_mutex> lock(g_timed_mutex, std::defer_lock);
+  if (g_time_kernels) lock.lock();
   int rc = rpe_bias_stack(qp, qe, row_stride, anchor_stride, emb_ptrs, eq_ptrs, starts, lengths, lengths, offsets, num_clouds, C,
                           num_anchors * H, H, logits_workspace, stream, emb_bf16);
   if (rc != SE3_OK) return rc;

@@ -2,6 +2,7 @@
 (device / dtype / contiguity -> RuntimeError), allocates outputs with torch (device memory stays owned by
 PyTorch) and launches the HIP kernels on the current torch stream."""
 import ctypes
+import threading
 import weakref
 
 import torch
@@ -37,6 +38,7 @@ def mm(a, b):
 # ---- optional per-kernel timing with HIP events on the launch stream (enabled by bench.py) -----------------------------
 TIMING_TAG = None             # optional tag (e.g. 'self') set by callers that want a separate bucket
 KERNEL_TIMINGS = None          # dict name -> list of (start_event, end_event, algorithmic_bytes) while enabled
+_TIMING_LOCK = threading.Lock()
 
 
 class _timed:
@@ -539,9 +541,15 @@ def rpe_self_attention_stack(proj, offs, vt, embs, eq_embs, starts, lengths, num
     logits = torch.empty((total,), dtype=torch.float32, device=p3.device)
     base = p3.data_ptr()
     col = lambda name: base + 4 * offs[name]
-    if KERNEL_TIMINGS is not None:       # bench.py pairs these with the library's per-launch HIP events, in call order
-        KERNEL_TIMINGS.setdefault('rpe_self_attention_calls', []).append((survey_bytes, ('eq' if has_eq else 'inv') + ('' if esize == 4 else '_bf16')))
     entry = lib().se3_rpe_self_attention_stack_fwd if esize == 4 else lib().se3_rpe_self_attention_stack_bf16_fwd
+    if KERNEL_TIMINGS is not None:       # bench.py pairs these with the library's per-launch HIP events, in call order
+        with _TIMING_LOCK:               # (host threads with one stream each: the record and the launches stay in one order)
+            KERNEL_TIMINGS.setdefault('rpe_self_attention_calls', []).append((survey_bytes, ('eq' if has_eq else 'inv') + ('' if esize == 4 else '_bf16')))
+            check(entry(col('q'), col('k'), v3.data_ptr(), col('qp'), col('qe') if has_eq else None, rs, sa, v3.stride(1),
+                        v3.stride(0) if A > 1 else 0, _ptr_array(embs), _ptr_array(eqs) if has_eq else None, _i64_array(starts),
+                        _i64_array(lengths), len(embs), A, C, H, logits.data_ptr(), o3.stride(0) if A > 1 else 0, o3.data_ptr(),
+                        _stream()), 'se3_rpe_self_attention_stack_fwd')
+        return out
     check(entry(col('q'), col('k'), v3.data_ptr(), col('qp'), col('qe') if has_eq else None, rs, sa, v3.stride(1),
                 v3.stride(0) if A > 1 else 0, _ptr_array(embs), _ptr_array(eqs) if has_eq else None, _i64_array(starts),
                 _i64_array(lengths), len(embs), A, C, H, logits.data_ptr(), o3.stride(0) if A > 1 else 0, o3.data_ptr(),
