@@ -178,12 +178,12 @@ def registration_pairs(lgr, patches, stacked=None):
     b_idx, r_idx, c_idx = torch.nonzero(corr, as_tuple=True)                # the one host sync; patch-major = pair-major
     ref_c, src_c = ref_pts[b_idx, r_idx].contiguous(), src_pts[b_idx, c_idx].contiguous()
     sc = score[b_idx, r_idx, c_idx].contiguous()
-    counts = torch.bincount(b_idx, minlength=BT)
+    counts = torch.zeros(BT, dtype=torch.int64, device=dev).index_add_(0, b_idx, torch.ones_like(b_idx))   # (bincount syncs)
     offsets = torch.zeros(BT + 1, dtype=torch.int64, device=dev)
     offsets[1:] = torch.cumsum(counts, 0)
     patch_off = _offsets(nb)                                                  # host: patches of pair p = [patch_off[p], patch_off[p+1])
-    bounds = offsets[torch.tensor(patch_off, device=dev)]                     # (P + 1,) correspondence range of every pair
-    pair_of_patch = torch.repeat_interleave(torch.arange(P, device=dev), torch.tensor(nb, device=dev))
+    bounds = offsets[_ops.to_device(patch_off, torch.int64, dev)]             # (P + 1,) correspondence range of every pair
+    pair_of_patch = _ops.to_device([p for p in range(P) for _ in range(nb[p])], torch.int64, dev)
     # local hypotheses: one weighted Procrustes per patch pair, voted on by the correspondences of ITS pair
     Ts = SF.weighted_procrustes(src_c, ref_c, sc, offsets)
     votes = SF.count_inliers(src_c, ref_c, Ts, lgr.acceptance_radius, bounds[pair_of_patch], bounds[pair_of_patch + 1])
@@ -233,7 +233,7 @@ def forward_pairs(model, data_dict, with_registration=True):
     # every fine point to its nearest superpoint, every superpoint's K nearest own points: all clouds in one call, GLOBAL indices
     _, node_masks, knn, knn_masks = _ops.point_to_node_partition_stack(points_f, points_c, len_f, len_c, K)
     csum = torch.cumsum(node_masks, 0)
-    ends = torch.tensor([o - 1 for o in oc[1:]], device=dev)
+    ends = _ops.to_device([o - 1 for o in oc[1:]], torch.int64, dev)
     upto = csum[ends]
     valid = (upto - torch.cat((upto.new_zeros(1), upto[:-1]))).tolist()      # non-empty nodes per cloud: ONE host sync
     ref_rows, src_rows = PA.starts[:B], PA.starts[B:]
@@ -244,11 +244,11 @@ def forward_pairs(model, data_dict, with_registration=True):
     ks = [min(cm.num_correspondences, valid[2 * p] * valid[2 * p + 1]) for p in range(B)]
     if len(set(ks)) == 1:
         node_scores, flat = S.topk(k=ks[0], dim=1, largest=True)             # (B, k): one selection for all pairs
-        Mt = torch.tensor(Ms, device=dev)[:, None]
+        Mt = _ops.to_device(Ms, torch.int64, dev)[:, None]
         ri = torch.div(flat, Mt, rounding_mode='floor')
         si = flat - ri * Mt
-        gr = (ri + torch.tensor(ref_off, device=dev)[:, None]).view(-1)      # global superpoint indices, pair-major
-        gs = (si + torch.tensor(src_off, device=dev)[:, None]).view(-1)
+        gr = (ri + _ops.to_device(ref_off, torch.int64, dev)[:, None]).view(-1)      # global superpoint indices, pair-major
+        gs = (si + _ops.to_device(src_off, torch.int64, dev)[:, None]).view(-1)
         ri, si, node_scores = list(ri), list(si), list(node_scores)
     else:                                                                     # pairs with fewer valid superpoint pairs than k
         ri, si, node_scores = [], [], []

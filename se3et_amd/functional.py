@@ -26,6 +26,7 @@ def _hip(fn):
 # dense layers (library GEMMs) and small glue
 # ---------------------------------------------------------------------------------------------------------------------
 mm = _ops.mm
+to_device = _ops.to_device
 
 
 def linear(x, weight, bias=None, relu=False):

@@ -32,17 +32,17 @@ class LocalGlobalRegistration(nn.Module):
         sc = score_mat[b_idx, r_idx, c_idx].contiguous()
         total = sc.shape[0]
         dev = sc.device
-        counts = torch.bincount(b_idx, minlength=B)
+        counts = torch.zeros(B, dtype=torch.int64, device=dev).index_add_(0, b_idx, torch.ones_like(b_idx))   # (bincount syncs)
         offsets = torch.zeros(B + 1, dtype=torch.int64, device=dev)
         offsets[1:] = torch.cumsum(counts, 0)
-        whole = torch.tensor([0, total], dtype=torch.int64, device=dev)
+        whole = SF.to_device([0, total], torch.int64, dev)
         # local hypotheses: one weighted Procrustes per patch pair (patches below the threshold never win the vote)
         Ts = SF.weighted_procrustes(src_c, ref_c, sc, offsets)
         votes = SF.count_inliers(src_c, ref_c, Ts, self.acceptance_radius)
         votes = torch.where(counts >= self.correspondence_threshold, votes, torch.full_like(votes, -1))
         best = torch.argmax(votes)                       # first maximum in patch order, stays on the device
         any_valid = votes.max() >= 0
-        T0 = Ts[best]
+        T0 = Ts.index_select(0, best.view(1))[0]          # (indexing with a 0-dim device tensor would synchronise)
         # degenerate case (no patch pair with enough correspondences): start from all correspondences instead
         T_all = SF.weighted_procrustes(src_c, ref_c, sc, whole)[0]
         T_init = torch.where(any_valid, T0, T_all)

@@ -407,6 +407,13 @@ def rpe_bias(qp, qe, emb, eq_emb, num_heads):
     return bias
 
 
+def to_device(values, dtype, device):
+    """Small host list -> device tensor through pinned memory and an asynchronous copy.  `torch.tensor(values, device=...)`
+    copies from pageable memory, which makes the host wait for everything queued on the stream (a full synchronisation per
+    index table)."""
+    return torch.tensor(values, dtype=dtype).pin_memory().to(device, non_blocking=True)
+
+
 def _i64_array(values):
     return (ctypes.c_int64 * len(values))(*[int(v) for v in values])
 
@@ -602,9 +609,9 @@ def _pair_rows(starts, lengths, device):
     hit = _pair_rows_cache.get(key)
     if hit is None:
         W = max(key[1])
-        idx = torch.tensor([[s + min(j, n - 1) for j in range(W)] for s, n in zip(key[0], key[1])], dtype=torch.int64)
-        mask = torch.tensor([[1.0 if j < n else 0.0 for j in range(W)] for n in key[1]], dtype=torch.float32)
-        hit = (idx.view(-1).to(device), mask.view(1, len(key[1]), W, 1).to(device), W)
+        idx = to_device([s + min(j, n - 1) for s, n in zip(key[0], key[1]) for j in range(W)], torch.int64, device)
+        mask = to_device([1.0 if j < n else 0.0 for n in key[1] for j in range(W)], torch.float32, device)
+        hit = (idx, mask.view(1, len(key[1]), W, 1), W)
         if len(_pair_rows_cache) > 64:
             _pair_rows_cache.clear()
         _pair_rows_cache[key] = hit
