@@ -126,6 +126,12 @@ int se3_gather_rows_padded(const float* x, const int64_t* idx, int64_t n, int64_
                            void* stream);
 int se3_neighbor_max_pool(const float* x, const int64_t* idx, int64_t n, int64_t m, int nn, int64_t width, float* out,
                           void* stream);
+/* Maximum over the anchor axis (InvOutBlockEPN, geotransformer/modules/e2pn/blocks_epn.py:908-926; the anchor 'amax' between
+ * equivariant and invariant transformer blocks, transformer/conditional_transformer.py:282-283,299-302):
+ * out[r, c] = max_a x[a * anchor_stride + r * row_stride + c], out (rows, channels) contiguous.  Serves (A, R, C)
+ * (anchor_stride = R*C, row_stride = C) and (R, A, C) (anchor_stride = C, row_stride = A*C).  num_anchors = 6, channels % 4 == 0. */
+int se3_anchor_max(const float* x, int num_anchors, int64_t rows, int channels, int64_t anchor_stride, int64_t row_stride,
+                   float* out, void* stream);
 
 /* ---- B1: E2PN anchor-group KPConv (KPConvInterSO3), neighbour-gather stage ---------------------------------------
  * Replaces feat_gather_by_perm + the (k, a) part of the weight contraction of

@@ -335,6 +335,27 @@ __global__ __launch_bounds__(256) void neighbor_max_kernel(const float* __restri
   }
 }
 
+// out[r, c] = max_a x[a * anchor_stride + r * row_stride + c]: the maximum over the anchor axis of (A, R, C) or (R, A, C) features
+// (InvOutBlockEPN, blocks_epn.py:908-926; the 'amax' between equivariant and invariant transformer blocks,
+// conditional_transformer.py:282-283,299-302).  float4 per thread, the A reads of a thread in flight together.
+template <int A>
+__global__ __launch_bounds__(256) void anchor_max_kernel(const float* __restrict__ x, int64_t rows, int C4, int64_t anchor_stride,
+                                                         int64_t row_stride, float* __restrict__ out) {
+  const int64_t total = rows * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / C4;
+    const int c4 = (int)(i - r * C4);
+    const float* p = x + r * row_stride + 4 * c4;
+    float4 v[A];
+#pragma unroll
+    for (int a = 0; a < A; a++) v[a] = *reinterpret_cast<const float4*>(p + a * anchor_stride);
+    float4 m = v[0];
+#pragma unroll
+    for (int a = 1; a < A; a++) m = make_float4(fmaxf(m.x, v[a].x), fmaxf(m.y, v[a].y), fmaxf(m.z, v[a].z), fmaxf(m.w, v[a].w));
+    reinterpret_cast<float4*>(out)[i] = m;
+  }
+}
+
 inline unsigned grid_for(int64_t work, int tpb) {
   int64_t g = se3_cdiv(work, tpb);
   return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -445,6 +466,22 @@ extern "C" int se3_gather_rows_padded(const float* x, const int64_t* idx, int64_
   if (m * width == 0) return SE3_OK;
   gather_rows_kernel<<<grid_for(m * width, 256), 256, 0, (hipStream_t)stream>>>(x, idx, n, m, width, out);
   SE3_CHECK_LAUNCH("gather_rows_padded");
+  return SE3_OK;
+}
+
+extern "C" int se3_anchor_max(const float* x, int num_anchors, int64_t rows, int channels, int64_t anchor_stride,
+                              int64_t row_stride, float* out, void* stream) {
+  SE3_REQUIRE(x && out, SE3_ERR_INVALID_ARG, "anchor_max: null pointer");
+  SE3_REQUIRE(num_anchors == 6 && channels >= 4 && channels % 4 == 0 && anchor_stride % 4 == 0 && row_stride % 4 == 0 &&
+                  (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+              SE3_ERR_UNSUPPORTED, "anchor_max: %d anchors (6), %d channels (multiple of 4), 16-byte aligned rows", num_anchors,
+              channels);
+  if (rows <= 0) return SE3_OK;
+  const int64_t work = rows * (channels / 4);
+  const int64_t blocks = se3_cdiv(work, 256);
+  anchor_max_kernel<6><<<(unsigned)(blocks > 16384 ? 16384 : blocks), 256, 0, (hipStream_t)stream>>>(x, rows, channels / 4,
+                                                                                                  anchor_stride, row_stride, out);
+  SE3_CHECK_LAUNCH("anchor_max");
   return SE3_OK;
 }
 

@@ -246,6 +246,18 @@ def gather_rows_padded(x, idx):
     return out
 
 
+def anchor_max(x, dim):
+    """HIP (csrc/rowops.hip): maximum over the anchor axis `dim` of a 3-D float32 tensor with 6 anchors, (A, R, C) -> (R, C) or
+    (R, A, C) -> (R, C); other layouts go through torch."""
+    if x.dim() != 3 or x.shape[dim] != 6 or dim not in (0, 1) or x.dtype != torch.float32 or not x.is_cuda or x.shape[2] % 4 or \
+            x.stride(2) != 1 or x.stride(0) % 4 or x.stride(1) % 4 or x.data_ptr() % 16:
+        return x.amax(dim)
+    rows, C = x.shape[1 - dim], x.shape[2]
+    out = torch.empty((rows, C), dtype=torch.float32, device=x.device)
+    check(lib().se3_anchor_max(x.data_ptr(), 6, rows, C, x.stride(dim), x.stride(1 - dim), out.data_ptr(), _stream()), 'se3_anchor_max')
+    return out
+
+
 def neighbor_max_pool(x, idx):
     x = _req(x.contiguous(), torch.float32, 'x')
     idx = _req(idx.contiguous(), torch.int64, 'idx', 2)

@@ -99,6 +99,16 @@ def test_add_layer_norm_matches_torch(A, N, C):
     assert_close(got2, want2, 1e-5, 'add+LN with folded linear bias')
 
 
+@pytest.mark.parametrize('shape,dim', [((6, 5760, 256), 0), ((5003, 6, 64), 1), ((6, 37, 32), 0), ((1, 6, 4), 1)])
+def test_anchor_max_equals_torch(shape, dim):
+    from se3et_amd import functional as SF
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(3)).cuda()
+    assert torch.equal(SF.anchor_max(x, dim=dim), x.amax(dim))
+    wide = torch.randn(shape[0], shape[1], 2 * shape[2], generator=torch.Generator().manual_seed(4)).cuda()
+    view = wide[:, :, shape[2]:]                      # strided view (column block of a wider tensor)
+    assert torch.equal(SF.anchor_max(view, dim=dim), view.amax(dim))
+
+
 def test_gather_and_max_pool_match_oracle():
     from oracle import se3et_oracle as O
     from se3et_amd import functional as SF
