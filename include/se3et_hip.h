@@ -262,6 +262,9 @@ int se3_geo_embedding_bf16_fwd(const float* points, const int64_t* knn, int N, i
  * node_knn_masks (M, limit) uint8.  Distances as pairwise_distance (modules/ops/pairwise_distance.py:4-30), ties by index.
  * limit <= 128. */
 int se3_knn3(const float* points, int N, int64_t* knn, void* stream);
+/* se3_knn3 for num_clouds (<= 16) stacked clouds in one launch: points (sum lengths, 3), lengths HOST array; knn (sum lengths, 3)
+ * holds indices LOCAL to the point's own cloud. */
+int se3_knn3_stack(const float* points, const int64_t* lengths, int num_clouds, int64_t* knn, void* stream);
 int se3_point_to_node_partition(const float* points, const float* nodes, int N, int M, int limit, int64_t* point_to_node,
                                 uint8_t* node_masks, int64_t* node_knn_indices, uint8_t* node_knn_masks, void* stream);
 /* Stack mode: the same partition for num_clouds (<= 16) clouds in one launch per kernel.  points / nodes are the stacked fine

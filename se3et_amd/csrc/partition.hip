@@ -152,6 +152,33 @@ struct PartClouds {
   int n;
 };
 
+// all clouds of a batch in one launch: point i looks only at the points of its own cloud; LOCAL indices (0 .. N_c - 1)
+__global__ __launch_bounds__(256) void knn3_stack_table_kernel(const float* __restrict__ pts, PartClouds T, int num_clouds,
+                                                               int total, int64_t* __restrict__ knn) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= total) return;
+  int c = 0;
+  for (int k = 1; k < num_clouds; k++)
+    if (i >= T.p0[k]) c = k;
+  const int b0 = T.p0[c], N = T.p0[c + 1] - b0;
+  const float* p = pts + 3 * (size_t)b0;
+  const int li = i - b0;
+  const float qx = p[3 * li], qy = p[3 * li + 1], qz = p[3 * li + 2], q2 = sq_norm(qx, qy, qz);
+  unsigned long long best = ~0ull;
+  for (int j0 = 0; j0 < N; j0 += 64) {
+    const int j = j0 + lane;
+    unsigned long long cand = ~0ull;
+    if (j < N) {
+      const float sx = p[3 * j], sy = p[3 * j + 1], sz = p[3 * j + 2];
+      cand = make_key(pair_dist(qx, qy, qz, q2, sx, sy, sz, sq_norm(sx, sy, sz)), (unsigned)j);
+    }
+    const unsigned long long worst = shfl64(best, 3);
+    wave_insert(best, cand, j < N && cand < worst);
+  }
+  if (lane >= 1 && lane <= 3) knn[(size_t)i * 3 + lane - 1] = best == ~0ull ? (int64_t)li : (int64_t)(unsigned)(best & 0xffffffffull);
+}
+
 // point i -> its cloud's nearest node (GLOBAL node index)
 __global__ __launch_bounds__(256) void nearest_node_stack_kernel(const float* __restrict__ pts, const float* __restrict__ nodes,
                                                                  PartClouds T, int64_t* __restrict__ point_to_node,
@@ -264,6 +291,24 @@ extern "C" int se3_knn3(const float* points, int N, int64_t* knn, void* stream) 
   SE3_REQUIRE(N >= 1, SE3_ERR_INVALID_ARG, "knn3: N %d", N);
   knn3_kernel<<<(unsigned)se3_cdiv(N, 4), 256, 0, (hipStream_t)stream>>>(points, N, knn);
   SE3_CHECK_LAUNCH("knn3");
+  return SE3_OK;
+}
+
+extern "C" int se3_knn3_stack(const float* points, const int64_t* lengths, int num_clouds, int64_t* knn, void* stream) {
+  SE3_REQUIRE(points && lengths && knn, SE3_ERR_INVALID_ARG, "knn3_stack: null pointer");
+  SE3_REQUIRE(num_clouds >= 1 && num_clouds <= kMaxPartClouds, SE3_ERR_UNSUPPORTED, "knn3_stack: %d clouds (1..%d)", num_clouds,
+              kMaxPartClouds);
+  PartClouds T{};
+  int64_t total = 0;
+  for (int c = 0; c < num_clouds; c++) {
+    SE3_REQUIRE(lengths[c] >= 1, SE3_ERR_INVALID_ARG, "knn3_stack: empty cloud %d", c);
+    T.p0[c] = (int)total;
+    total += lengths[c];
+  }
+  SE3_REQUIRE(total < (1ll << 31), SE3_ERR_UNSUPPORTED, "knn3_stack: too many points");
+  T.p0[num_clouds] = (int)total;
+  knn3_stack_table_kernel<<<(unsigned)se3_cdiv(total, 4), 256, 0, (hipStream_t)stream>>>(points, T, num_clouds, (int)total, knn);
+  SE3_CHECK_LAUNCH("knn3_stack");
   return SE3_OK;
 }
 

@@ -133,10 +133,10 @@ def sinusoidal_embedding(idx, div_term):
     return torch.cat((torch.sin(om), torch.cos(om)), 2).reshape(*idx.shape, 2 * div_term.numel())
 
 
-def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, k, wigner_d1=None, dtype=torch.float32):
+def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, k, wigner_d1=None, dtype=torch.float32, knn=None):
     """E (N, N, C) [and the equivariant embedding (A, N, N, 4) when the Wigner-D^1 table is given] in one kernel; dtype
     torch.bfloat16 stores E rounded to bf16 ('bf16 attention', BASELINE.json configs[2])."""
-    return _ops.geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, k, wigner_d1, dtype)
+    return _ops.geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, k, wigner_d1, dtype, knn)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

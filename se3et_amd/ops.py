@@ -702,7 +702,17 @@ def _embedding_table(weight, bias, div_term, x_max, per_unit):
     return tab
 
 
-def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, k, wigner_d1=None, dtype=torch.float32):
+def knn3_stack(points, lengths):
+    """HIP (csrc/partition.hip): the 3 nearest other points of every point of several stacked clouds, indices local to the cloud."""
+    points = _req(points.contiguous(), torch.float32, 'points', 2)
+    if sum(lengths) != points.shape[0]:
+        raise RuntimeError('knn3_stack: lengths do not add up to the stacked points')
+    knn = torch.empty((points.shape[0], 3), dtype=torch.int64, device=points.device)
+    check(lib().se3_knn3_stack(points.data_ptr(), _i64_array(lengths), len(lengths), knn.data_ptr(), _stream()), 'se3_knn3_stack')
+    return knn
+
+
+def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, k, wigner_d1=None, dtype=torch.float32, knn=None):
     """HIP (csrc/geo_embedding.hip).  Returns emb (N, N, C), or (emb, eq_emb (A, N, N, 4)) when wigner_d1 is given.
     dtype: torch.float32, or torch.bfloat16 for the 'bf16 attention' mode (emb stored rounded; eq_emb stays float32)."""
     points = _req(points.contiguous(), torch.float32, 'points', 2)
@@ -710,8 +720,13 @@ def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, 
         raise RuntimeError('geometric_embedding: angle_k must be 3 on the HIP path')
     N, C = points.shape[0], w_d.shape[0]
     # 3 nearest other points (the reference takes top-(k+1) of the distance map and drops the first column)
-    knn = torch.empty((N, 3), dtype=torch.int64, device=points.device)
-    check(lib().se3_knn3(points.data_ptr(), N, knn.data_ptr(), _stream()), 'se3_knn3')
+    if knn is None:
+        knn = torch.empty((N, 3), dtype=torch.int64, device=points.device)
+        check(lib().se3_knn3(points.data_ptr(), N, knn.data_ptr(), _stream()), 'se3_knn3')
+    else:                            # precomputed for all clouds of a batch (knn3_stack)
+        knn = _req(knn, torch.int64, 'knn', 2)
+        if tuple(knn.shape) != (N, 3):
+            raise RuntimeError('geometric_embedding: knn must be (N, 3)')
     tab_d = _embedding_table(w_d, b_d, div_term, _EMB_D_RANGE, _EMB_D_PER_UNIT)
     tab_a = _embedding_table(w_a, b_a, div_term, 180.0 / sigma_a + 1.0, _EMB_A_PER_UNIT)
     if dtype not in (torch.float32, torch.bfloat16):

@@ -558,6 +558,21 @@ def test_superpoint_scores_stack_equals_per_pair_calls(masked):
         assert bool((got.cpu()[absent] == -1).all()) and bool((S[p, n * m:] == -1).all())
 
 
+def test_knn3_stack_equals_per_cloud_calls():
+    from se3et_amd import ops
+    from se3et_amd._lib import lib, check
+    g = torch.Generator().manual_seed(31)
+    lens = [382, 350, 59, 1, 5, 1500, 2]
+    pts = torch.cat([torch.rand(n, 3, generator=g) + 2.0 * c for c, n in enumerate(lens)]).cuda()
+    got = ops.knn3_stack(pts, lens)
+    o = 0
+    for n in lens:
+        want = torch.empty((n, 3), dtype=torch.int64, device='cuda')
+        check(lib().se3_knn3(pts[o:o + n].contiguous().data_ptr(), n, want.data_ptr(), ops._stream()), 'se3_knn3')
+        assert torch.equal(got[o:o + n], want)
+        o += n
+
+
 @pytest.mark.parametrize('N', [382, 59, 5, 1500])
 def test_knn3_matches_oracle(N):
     from oracle import se3et_oracle as O
