@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
         t = T.ridx[a][r];
       }
 #pragma unroll
-      for (int sl = 0; sl < kS; sl++) Gp[((int64_t)(r * kS + sl) * kA + t) * Cin + c] = s[sl];
+      for (int sl = 0; sl < kS; sl++) __builtin_nontemporal_store(s[sl], &Gp[((int64_t)(r * kS + sl) * kA + t) * Cin + c]);
     }
   }
 }
