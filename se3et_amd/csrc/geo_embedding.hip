@@ -134,9 +134,9 @@ __global__ void geo_embedding_kernel(const float* __restrict__ pts, const int64_
         if (emb_bf16) {                                       // round to nearest even (values are finite)
           unsigned u = __float_as_uint(e);
           u += 0x7fffu + ((u >> 16) & 1u);
-          emb16[((size_t)n * N + (m0 + i)) * C + c] = (unsigned short)(u >> 16);
+          __builtin_nontemporal_store((unsigned short)(u >> 16), &emb16[((size_t)n * N + (m0 + i)) * C + c]);
         } else {
-          emb[((size_t)n * N + (m0 + i)) * C + c] = e;
+          __builtin_nontemporal_store(e, &emb[((size_t)n * N + (m0 + i)) * C + c]);
         }
       }
     }
