@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # HBM traffic of one RPE self-attention call relative to its algorithmic bytes, from the rocprofv3 PMC passes committed as
-# profiles/r01_pmc_attention.csv (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of tests/pmc_attention.py on the stack-mode
+# profiles/r01_pmc_attention.csv (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of tools/pmc_attention.py on the stack-mode
 # kernels at the bench shape, 16 clouds per launch; gfx950 correction: FETCH_SIZE x2 for the 16-B/lane streaming reads of
 # rpe_bias_kernel -- its invariant variant then reads 2241 MB for 2223 MB of embedding --, attention_kernel counters raw):
 #   eq  call: (2*1337081.7 + 162945.9 + 203184.0 + 35277.1) KiB = 3149.4 MB  vs 2549.0 MB algorithmic

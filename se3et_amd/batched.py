@@ -227,6 +227,7 @@ def forward_pairs(model, data_dict, with_registration=True):
     points_c, points_f = data_dict['points'][-1], data_dict['points'][1]
     len_c, len_f = lengths[-1].tolist(), lengths[1].tolist()
     oc, of = _offsets(len_c), _offsets(len_f)
+    points_0, o0 = data_dict['points'][0], _offsets(lengths[0].tolist())
 
     X, PA = transformer_pairs(model.transformer, points_c, len_c, feats_c, packed=True)
     Xn = F.normalize(X, p=2, dim=1)                       # all clouds at once (the padding rows of the packing stay zero)
@@ -274,6 +275,7 @@ def forward_pairs(model, data_dict, with_registration=True):
         outs.append(dict(
             ref_points_c=points_c[oc[r]:oc[r + 1]], src_points_c=points_c[oc[s]:oc[s + 1]],
             ref_points_f=points_f[of[r]:of[r + 1]], src_points_f=points_f[of[s]:of[s + 1]],
+            ref_points=points_0[o0[r]:o0[r + 1]], src_points=points_0[o0[s]:o0[s + 1]],
             feats_c=feats_c[oc[r]:oc[s + 1]], feats_f=feats_f[of[r]:of[s + 1]],
             ref_feats_c=Xn[ref_rows[p]:ref_rows[p] + Ns[p]], src_feats_c=Xn[src_rows[p]:src_rows[p] + Ms[p]],
             ref_feats_f=feats_f[of[r]:of[r + 1]], src_feats_f=feats_f[of[s]:of[s + 1]],

@@ -157,7 +157,102 @@ __global__ void geo_embedding_kernel(const float* __restrict__ pts, const int64_
   }
 }
 
+// ---- table construction on the device -------------------------------------------------------------------------------
+// tab (entries, C, 2) = (f, f') of f(x) = W emb(x) + b at x = j / per_unit, accumulated in float64.  The kernel is launched in
+// front of EVERY embedding call and validates the table against the CURRENT weights by content: every workgroup hashes
+// (W, b, div_term, sizes) -- 260 KB from L2 -- and returns at once when the hash equals the one stored with the table; otherwise
+// all workgroups rebuild their entries and the last one to finish publishes the new hash.  No host-side version bookkeeping
+// can go stale (in-place writes through .data, module.to(), load_state_dict, optimizer steps all change the content), no
+// host synchronisation, capturable in a graph.
+struct TableState { unsigned long long fp; unsigned int done; unsigned int pad; };
+constexpr int kTabE = 8;              // table entries per workgroup
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long h) {
+  h ^= h >> 33; h *= 0xff51afd7ed558ccdULL; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ULL; h ^= h >> 33;
+  return h;
+}
+
+__global__ void __launch_bounds__(256) embedding_table_refresh_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                                                      const float* __restrict__ div_term, int C, int entries,
+                                                                      float per_unit, float2* __restrict__ tab,
+                                                                      TableState* __restrict__ st) {
+  extern __shared__ double lds_d[];                       // emb[kTabE][C], demb[kTabE][C]
+  __shared__ unsigned long long part[4];
+  // 1. content hash (order-sensitive: position-keyed mixing, summed)
+  unsigned long long h = 0;
+  const int nW = C * C, total = nW + C + C / 2;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const float v = i < nW ? W[i] : (i < nW + C ? b[i - nW] : div_term[i - nW - C]);
+    h += mix64((unsigned long long)__float_as_uint(v) | ((unsigned long long)(unsigned)(i + 1) << 32));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)h, o), hi = __shfl_xor((unsigned)(h >> 32), o);
+    h += ((unsigned long long)hi << 32) | lo;
+  }
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = h;
+  __syncthreads();
+  unsigned long long fp = part[0] + part[1] + part[2] + part[3];
+  fp = mix64(fp ^ ((unsigned long long)(unsigned)entries << 32) ^ (unsigned long long)__float_as_uint(per_unit) ^
+             ((unsigned long long)(unsigned)C << 20)) | 1ULL;          // never 0: a zero-initialised state never matches
+  if (__hip_atomic_load(&st->fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fp) return;
+  // 2. rebuild this workgroup's entries
+  double* emb = lds_d;
+  double* demb = lds_d + kTabE * C;
+  const int e0 = blockIdx.x * kTabE;
+  for (int t = threadIdx.x; t < kTabE * (C / 2); t += 256) {
+    const int e = t / (C / 2), i = t - e * (C / 2);
+    const double w = (double)div_term[i];
+    const double om = ((double)(e0 + e) / (double)per_unit) * w;
+    double s, c;
+    sincos(om, &s, &c);
+    emb[e * C + 2 * i] = s;      emb[e * C + 2 * i + 1] = c;
+    demb[e * C + 2 * i] = c * w; demb[e * C + 2 * i + 1] = -s * w;
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < C; o += 256) {
+    double f[kTabE], df[kTabE];
+#pragma unroll
+    for (int e = 0; e < kTabE; e++) { f[e] = 0.0; df[e] = 0.0; }
+    const float* row = W + (size_t)o * C;
+    for (int c = 0; c < C; c += 2) {
+      const float2 w2 = *reinterpret_cast<const float2*>(row + c);
+      const double w0 = w2.x, w1 = w2.y;
+#pragma unroll
+      for (int e = 0; e < kTabE; e++) {
+        f[e] += w0 * emb[e * C + c] + w1 * emb[e * C + c + 1];
+        df[e] += w0 * demb[e * C + c] + w1 * demb[e * C + c + 1];
+      }
+    }
+    const double bo = (double)b[o];
+#pragma unroll
+    for (int e = 0; e < kTabE; e++)
+      if (e0 + e < entries) tab[(size_t)(e0 + e) * C + o] = make_float2((float)(f[e] + bo), (float)df[e]);
+  }
+  // 3. the last workgroup to finish publishes the hash (modulo: concurrent rebuilds of the same table stay consistent)
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned prev = atomicAdd(&st->done, 1u);
+    if (prev % gridDim.x == gridDim.x - 1) __hip_atomic_store(&st->fp, fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 }  // namespace
+
+extern "C" int se3_embedding_table_refresh(const float* weight, const float* bias, const float* div_term, int C, int entries,
+                                           float entries_per_unit, float* table, void* state, void* stream) {
+  SE3_REQUIRE(weight && bias && div_term && table && state, SE3_ERR_INVALID_ARG, "embedding_table_refresh: null pointer");
+  SE3_REQUIRE(C >= 2 && C % 2 == 0 && C <= 1024 && entries >= 2 && entries_per_unit > 0.f, SE3_ERR_INVALID_ARG,
+              "embedding_table_refresh: bad sizes");
+  const unsigned grid = (unsigned)((entries + kTabE - 1) / kTabE);
+  const size_t lds = (size_t)2 * kTabE * C * sizeof(double);
+  embedding_table_refresh_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(weight, bias, div_term, C, entries, entries_per_unit,
+                                                                         reinterpret_cast<float2*>(table),
+                                                                         static_cast<TableState*>(state));
+  SE3_CHECK_LAUNCH("embedding_table_refresh");
+  return SE3_OK;
+}
 
 static int geo_embedding(const float* points, const int64_t* knn, int N, int C, const float* table_d, int d_entries,
                          float d_entries_per_unit, const float* table_a, int a_entries, float a_entries_per_unit,

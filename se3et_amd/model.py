@@ -151,13 +151,18 @@ class SE3ET(nn.Module):
 
     @torch.no_grad()
     def forward(self, data_dict, with_registration=True):
-        """Inference forward of one pair.  data_dict: output of se3et_amd.data (GPU tensors, host lengths)."""
+        """INFERENCE forward of one pair (runs under torch.no_grad: the kernels have no autograd; the training step lives in
+        se3et_amd.training).  data_dict: output of se3et_amd.data (GPU tensors, host lengths).  Output keys are the reference's
+        (experiments/se3ete.3dmatch/model.py:79-227) except the ground-truth keys gt_node_corr_indices / gt_node_corr_overlaps,
+        which need `transform` and are produced by se3et_amd.training.node_correspondences."""
         out = {}
         feats = data_dict['features']
         n_c, n_f = int(data_dict['lengths'][-1][0]), int(data_dict['lengths'][1][0])
         points_c, points_f = data_dict['points'][-1], data_dict['points'][1]
         ref_c, src_c, ref_f, src_f = points_c[:n_c], points_c[n_c:], points_f[:n_f], points_f[n_f:]
-        out.update(ref_points_c=ref_c, src_points_c=src_c, ref_points_f=ref_f, src_points_f=src_f)
+        n_0 = int(data_dict['lengths'][0][0])
+        out.update(ref_points_c=ref_c, src_points_c=src_c, ref_points_f=ref_f, src_points_f=src_f,
+                   ref_points=data_dict['points'][0][:n_0], src_points=data_dict['points'][0][n_0:])
 
         _, ref_nm, ref_knn, ref_km = point_to_node_partition(ref_f, ref_c, self.num_points_in_patch)
         _, src_nm, src_knn, src_km = point_to_node_partition(src_f, src_c, self.num_points_in_patch)

@@ -24,7 +24,7 @@ def mm(a, b):
     """a (M, K) @ b (K, N) through the cheaper-to-dispatch rocBLAS path, or hipBLASLt where its kernels win: the large products
     with a row-major right operand (the KPConv (P*6, 36 Cin) @ (36 Cin, Cout) products) and K <= 32.  For the dense layers
     x @ W^T (transposed view of the (N, K) weight) rocBLAS's kernels are the faster ones at every size measured
-    (tests/micro/unary_gemm_backends.py: 1.0-1.4x of the HBM / MFMA bound against 1.1-2.6x)."""
+    (tools/micro/unary_gemm_backends.py: 1.0-1.4x of the HBM / MFMA bound against 1.1-2.6x)."""
     big = 2.0 * a.shape[0] * a.shape[1] * b.shape[1] > _BIG_GEMM_FLOP
     if _HAS_BLAS_SWITCH and big and (b.stride(-1) == 1 or a.shape[1] <= 32):
         torch.backends.cuda.preferred_blas_library('cublaslt')
@@ -680,25 +680,27 @@ _emb_table_cache = {}
 
 
 def _embedding_table(weight, bias, div_term, x_max, per_unit):
-    """(entries, C, 2): f(x) = W emb(x) + b and f'(x) at x = j / per_unit, j = 0 .. x_max * per_unit (two library GEMMs,
-    cached per weight version -- rebuilt automatically after an optimizer step)."""
-    key = (id(weight), weight._version, id(bias), bias._version, float(x_max), float(per_unit))
+    """(entries, C, 2): f(x) = W emb(x) + b and f'(x) at x = j / per_unit, j = 0 .. x_max * per_unit, built and VALIDATED ON THE
+    DEVICE by se3_embedding_table_refresh in front of every use: the kernel hashes the current weight values and rebuilds the
+    table when they differ from the ones it was built from.  The host cache below only holds the buffers (keyed by the
+    storage addresses): identity / version bookkeeping of the Parameters plays no role, so `p.data.copy_()`, `module.to()`,
+    `load_state_dict` and optimizer steps can never leave a stale table behind."""
+    weight, bias, div_term = weight.detach(), bias.detach(), div_term.detach()
+    for t, name in ((weight, 'weight'), (bias, 'bias'), (div_term, 'div_term')):
+        _req(t, torch.float32, 'embedding ' + name)
+    C = weight.shape[0]
+    n = int(math.ceil(x_max * per_unit)) + 2
+    key = (str(weight.device), weight.data_ptr(), bias.data_ptr(), div_term.data_ptr(), C, n, float(per_unit))
     hit = _emb_table_cache.get(key)
-    tab = hit[0] if hit is not None and hit[1]() is weight and hit[2]() is bias else None     # ids can be recycled
-    if tab is None:
-        n = int(math.ceil(x_max * per_unit)) + 2
-        x = torch.arange(n, device=weight.device, dtype=torch.float64) / per_unit
-        om = x[:, None] * div_term.double()[None, :]                                   # (n, C/2)
-        s, c = torch.sin(om), torch.cos(om)
-        emb = torch.stack((s, c), 2).reshape(n, -1)                                    # sin/cos interleaved
-        demb = torch.stack((c, -s), 2).reshape(n, -1) * div_term.double().repeat_interleave(2)[None, :]
-        w = weight.detach().double()
-        f = emb @ w.t() + bias.detach().double()
-        df = demb @ w.t()
-        tab = torch.stack((f, df), 2).float().contiguous()
+    if hit is None:
+        hit = (torch.empty((n, C, 2), dtype=torch.float32, device=weight.device),
+               torch.zeros((16,), dtype=torch.uint8, device=weight.device))
         if len(_emb_table_cache) > 16:
             _emb_table_cache.clear()
-        _emb_table_cache[key] = (tab, weakref.ref(weight), weakref.ref(bias))
+        _emb_table_cache[key] = hit
+    tab, state = hit
+    check(lib().se3_embedding_table_refresh(weight.data_ptr(), bias.data_ptr(), div_term.data_ptr(), C, n, float(per_unit),
+                                            tab.data_ptr(), state.data_ptr(), _stream()), 'se3_embedding_table_refresh')
     return tab
 
 

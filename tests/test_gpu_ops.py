@@ -400,6 +400,41 @@ def test_geometric_embedding_out_of_table_range():
     assert_close(got[off], want[off], 2e-3, 'embedding, exact path')
 
 
+def test_geometric_embedding_follows_in_place_weight_updates():
+    """The tabulated W emb(x) + b is validated against the CURRENT weight values on the device before every use: writes that
+    keep the Parameter's identity, version counter and address (`p.data.copy_`), a module moved to another dtype and back, and
+    load_state_dict must all be reflected by the next forward (a host-side cache keyed on id/_version went stale)."""
+    from oracle import se3et_oracle as O
+    from se3et_amd.modules.geotransformer.geotransformer import GeometricStructureEmbedding
+    g = torch.Generator().manual_seed(10)
+    N, C = 97, 64
+    pts = torch.rand(N, 3, generator=g)
+    mod = GeometricStructureEmbedding(C, 0.2, 15, 3, kanchor=6, n_level_equiv=0).cuda()
+    cfg = O.OracleConfig()
+    off = ~torch.eye(N, dtype=torch.bool)
+
+    def want():
+        st = {'e.' + k: v.detach().cpu() for k, v in mod.state_dict().items()}
+        return O.geometric_embedding(st, 'e.', pts, cfg)
+
+    first = mod(pts.cuda().unsqueeze(0))[0].cpu()
+    assert_close(first[off], want()[off], 1e-4, 'initial weights')
+    version = mod.proj_d.weight._version
+    mod.proj_d.weight.data.copy_(torch.randn(C, C, generator=g) / C ** 0.5)          # same id, same _version, same address
+    assert mod.proj_d.weight._version == version
+    second = mod(pts.cuda().unsqueeze(0))[0].cpu()
+    assert float((second - first).abs().max()) > 1e-2
+    assert_close(second[off], want()[off], 1e-4, 'after proj_d.weight.data.copy_')
+    mod.proj_a.bias.data.add_(0.25)
+    third = mod(pts.cuda().unsqueeze(0))[0].cpu()
+    assert_close(third[off], want()[off], 1e-4, 'after proj_a.bias.data.add_')
+    sd = {k: (torch.randn(v.shape, generator=g) * 0.1 if k.startswith('proj_') else v.cpu()) for k, v in mod.state_dict().items()}
+    mod.load_state_dict(sd)
+    mod = mod.cpu().cuda()                                                            # module.to(): new storage, same Parameters
+    fourth = mod(pts.cuda().unsqueeze(0))[0].cpu()
+    assert_close(fourth[off], want()[off], 1e-4, 'after load_state_dict + device round trip')
+
+
 def test_geometric_embedding_matches_reference_fixture(golden_dir):
     from se3et_amd import functional as SF
     g = _golden(golden_dir)

@@ -1,4 +1,4 @@
-"""Micro-benchmark of the RPE self-attention kernels (not a test): python tests/bench_attention.py"""
+"""Micro-benchmark of the RPE self-attention kernels (not a test): python tools/bench_attention.py"""
 import sys; sys.path.insert(0, '.')
 import math, torch
 from se3et_amd import ops

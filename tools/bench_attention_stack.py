@@ -1,4 +1,4 @@
-"""Micro-benchmark of the stack-mode RPE self-attention kernels (not a test): python tests/bench_attention_stack.py"""
+"""Micro-benchmark of the stack-mode RPE self-attention kernels (not a test): python tools/bench_attention_stack.py"""
 import sys; sys.path.insert(0, '.')
 import random, time
 import torch

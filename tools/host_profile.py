@@ -1,4 +1,4 @@
-"""Host-side cost per component (no sync inside): python tests/host_profile.py"""
+"""Host-side cost per component (no sync inside): python tools/host_profile.py"""
 import sys, time; sys.path.insert(0, '.')
 import numpy as np, torch, collections
 from se3et_amd.data import precompute_data_stack_mode

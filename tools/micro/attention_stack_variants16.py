@@ -1,7 +1,7 @@
 """Kernel variants of the stack-mode RPE self-attention call at the bench shape (16 clouds per launch); not a test."""
 import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import importlib.util, time, torch
-spec = importlib.util.spec_from_file_location('bas', 'tests/bench_attention_stack.py'); bas = importlib.util.module_from_spec(spec); spec.loader.exec_module(bas)
+spec = importlib.util.spec_from_file_location('bas', 'tools/bench_attention_stack.py'); bas = importlib.util.module_from_spec(spec); spec.loader.exec_module(bas)
 from se3et_amd._lib import lib
 x = torch.randn(4096, 4096, device='cuda'); t0 = time.time()
 while time.time() - t0 < 1.5: y = x @ x

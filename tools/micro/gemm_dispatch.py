@@ -1,4 +1,4 @@
-"""Host cost of a GEMM dispatch through torch on ROCm (not a test): python tests/micro/gemm_dispatch.py"""
+"""Host cost of a GEMM dispatch through torch on ROCm (not a test): python tools/micro/gemm_dispatch.py"""
 import os, sys, time
 import torch
 import torch.nn.functional as F

@@ -1,4 +1,4 @@
-"""Per-step timeline of the pairs-in-flight pipeline (not a test): python tests/pipeline_probe.py [P]"""
+"""Per-step timeline of the pairs-in-flight pipeline (not a test): python tools/pipeline_probe.py [P]"""
 import sys, time, threading; sys.path.insert(0, '.')
 import numpy as np, torch
 from se3et_amd.data import precompute_data_stack_mode

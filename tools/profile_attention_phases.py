@@ -1,4 +1,4 @@
-"""Phase profile of attention_kernel (profiling hook, attention variant 9; not a test): python tests/profile_attention_phases.py
+"""Phase profile of attention_kernel (profiling hook, attention variant 9; not a test): python tools/profile_attention_phases.py
 Per wave 32 clock64() stamps: 0 start, 1 after Q staging, per key tile t (2+4t ..): top, after S + logits, after softmax,
 after P.V issue; 29 after the tile loop (= 30), 31 after merge + store."""
 import sys; sys.path.insert(0, '.')
@@ -6,7 +6,7 @@ import importlib.util, ctypes, time
 import torch
 from se3et_amd import ops
 from se3et_amd._lib import lib
-spec = importlib.util.spec_from_file_location('bas', 'tests/bench_attention_stack.py'); bas = importlib.util.module_from_spec(spec); spec.loader.exec_module(bas)
+spec = importlib.util.spec_from_file_location('bas', 'tools/bench_attention_stack.py'); bas = importlib.util.module_from_spec(spec); spec.loader.exec_module(bas)
 C, H = 256, 4
 x = torch.randn(4096, 4096, device='cuda'); t0 = time.time()
 while time.time() - t0 < 1.0: y = x @ x
