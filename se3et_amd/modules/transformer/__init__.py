@@ -346,6 +346,9 @@ class RPEConditionalTransformer(nn.Module):
         self.layers = nn.ModuleList(layers)
         if 'cross_r_soft' in self.blocks:
             self.rotcompress = RotCompressOutput(d_model, dropout, activation_fn, na=na)
+        # optional callable(block index, output of the layer's FIRST call = ref direction); what a forward hook on
+        # `layers[i]` sees in the reference (self layers run both clouds in one packed pass here, so hooks cannot)
+        self.layer_tap = None
 
     def eq2inv_soft(self, feats0, feats1, mix0):
         """feats1 re-expressed in the frame that the ref<-src rotation weights prefer (sum_r w0[r] feats1[trace[r, a]] =
@@ -365,20 +368,28 @@ class RPEConditionalTransformer(nn.Module):
                 eq = block == 'self_eq'
                 feats0, feats1 = layer.forward_pair(src0, src1, embeddings0, embeddings1, equiv_embed0 if eq else None,
                                                     equiv_embed1 if eq else None)
+                if self.layer_tap is not None:
+                    self.layer_tap(i, feats0)
                 if eq and nxt == 'cross':
                     feats0_eq, feats1_eq = feats0, feats1
                     feats0, feats1 = SF.anchor_max(feats0_eq, dim=1), SF.anchor_max(feats1_eq, dim=1)
             elif block == 'cross':
                 if nxt == 'self_eq' or (nxt is None and self.blocks[i - 1] == 'self_eq'):
                     feats0_eq, _ = layer(feats0, feats1, feats1_eq)
+                    if self.layer_tap is not None:
+                        self.layer_tap(i, feats0_eq)
                     feats0 = SF.anchor_max(feats0_eq, dim=1)
                     feats1_eq, _ = layer(feats1, feats0, feats0_eq)
                     feats1 = SF.anchor_max(feats1_eq, dim=1)
                 else:
                     feats0, _ = layer(feats0, feats1)
+                    if self.layer_tap is not None:
+                        self.layer_tap(i, feats0)
                     feats1, _ = layer(feats1, feats0)
             else:
                 feats0, s0 = layer(feats0, feats1)
+                if self.layer_tap is not None:
+                    self.layer_tap(i, feats0)
                 feats1, s1 = layer(feats1, feats0)
                 if block == 'cross_r_soft' and nxt is not None and not _block_is_eq(nxt):
                     feats0_eq = feats1_eq = None

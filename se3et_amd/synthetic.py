@@ -16,6 +16,7 @@ PAIR_PRESETS = {
     'c2_5k': (5000, (1.5, 1.2, 1.0), 0.005),
     'c3_20k': (20000, (60.0, 40.0, 4.0), 0.05),
     'c3_4k': (4000, (30.0, 20.0, 4.0), 0.05),        # KITTI configuration at fixture size
+    'cap_30k': (30000, (8.0, 6.0, 4.0), 0.005),      # 3DMatch configuration on a hall: > 2000 superpoints per cloud (the cap)
 }
 
 

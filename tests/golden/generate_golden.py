@@ -13,6 +13,9 @@ Fixtures
                            pyramid, per-op inputs/outputs captured with forward hooks, and model outputs
   synthw_<variant>.npz     real-width configs with name-keyed synthetic weights (se3et_amd.synthetic.synth_tensor):
                            state-dict names/shapes + outputs only (weights are regenerated from the names)
+  c2_se3ete_5k.npz         BASELINE.json configs[1] at FULL size: SE3ET-E on the 5k+5k pairs 0..7 (the pairs of one bench step),
+                           synthetic weights; per-layer outputs and index-table checksums for pair 0
+  c3_se3eti_kitti_20k.npz  BASELINE.json configs[2] at FULL size: SE3ET-I (KITTI configuration) on the 20k+20k pair
 """
 import os
 import sys
@@ -125,7 +128,7 @@ def _hook(store, name, keep_inputs=True):
     return f
 
 
-def run_model(variant, micro, synth_seed=None, pair='micro'):
+def run_model(variant, micro, synth_seed=None, pair='micro', index=0, light=False):
     make_cfg, create_model = ref_shims.load_experiment(variant)
     cfg = make_cfg()
     if micro:
@@ -139,11 +142,19 @@ def run_model(variant, micro, synth_seed=None, pair='micro'):
             if k.rsplit('.', 1)[-1] in LEARNED_LEAVES and sd[k].dtype == torch.float32 and 'anchors' not in k:
                 sd[k] = torch.from_numpy(np.asarray(synth_tensor(k, sd[k].shape, synth_seed)))
         model.load_state_dict(sd)
-    ref, src, T = make_pair(pair)
+    ref, src, T = make_pair(pair, index=index)
     dd = collate(ref, src, T, cfg.backbone.num_stages, cfg.backbone.init_voxel_size, cfg.backbone.init_radius,
                  [38, 36, 36, 38, 38][:cfg.backbone.num_stages])
     ops = {}
     tr = model.transformer.transformer
+    if light:          # full-size pairs: layer outputs only (the attention hooks would keep the (N, N, C) embeddings per layer)
+        for i, layer in enumerate(tr.layers):
+            layer.register_forward_hook(_hook(ops, 'layer_%d' % i, keep_inputs=False), with_kwargs=True)
+        feats = {}
+        model.backbone.register_forward_hook(lambda m, a, o: feats.update(c=o[-1], f=o[0]))
+        with torch.no_grad():
+            out = model(dd)
+        return cfg, model, (ref, src, T), dd, ops, feats, out
     model.backbone.encoder2_2.interso3.conv.register_forward_hook(_hook(ops, 'kpconv_2_2'), with_kwargs=True)
     model.backbone.encoder2_1.interso3.conv.register_forward_hook(_hook(ops, 'kpconv_2_1'), with_kwargs=True)
     model.backbone.encoder1_1.register_forward_hook(_hook(ops, 'simple_1_1'), with_kwargs=True)
@@ -215,6 +226,71 @@ def gen_synthw(variant, fname, pair='micro'):
     np.savez_compressed(os.path.join(HERE, fname), **res)
 
 
+def _index_checksum(t):
+    """Order-sensitive checksum of an index array: sum of value * ((position mod 65521) + 1) mod 2^61 - 1 (as gen_precompute)."""
+    v = np.asarray(t).astype(np.uint64).reshape(-1)
+    w = (np.arange(v.size, dtype=np.uint64) % np.uint64(65521)) + np.uint64(1)
+    return int((v * w).sum() % np.uint64(2 ** 61 - 1))
+
+
+def gen_fullsize(variant, fname, pair, num_pairs, row_step=8):
+    """BASELINE.json configs at their FULL size through the genuine reference (name-keyed synthetic weights, seed 7): per pair
+    index the final outputs (coarse features complete, everything else as strided slices + float64 sums), for pair 0 also the
+    output of every transformer layer (first call = ref direction) and the checksums of all pyramid index tables."""
+    res = {'pair': np.array(pair), 'synth_seed': np.int64(7), 'num_pairs': np.int64(num_pairs), 'row_step': np.int64(row_step)}
+    for index in range(num_pairs):
+        cfg, model, (ref, src, T), dd, ops, feats, out = run_model(variant, micro=False, synth_seed=7, pair=pair, index=index,
+                                                                    light=True)
+        P = 'p%d/' % index
+        res[P + 'lengths'] = np.stack([_np(l) for l in dd['lengths']])
+        res[P + 'feats_c'] = _np(feats['c'])[::row_step, :, ::4] if index == 0 else _np(feats['c'])[::4 * row_step, :, ::8]
+        res[P + 'feats_c_sum'] = np.float64(feats['c'].double().sum())
+        res[P + 'feats_c_abs'] = np.float64(feats['c'].double().abs().max())
+        res[P + 'feats_f'] = _np(feats['f'])[::4 * row_step] if index == 0 else _np(feats['f'])[::16 * row_step]
+        res[P + 'feats_f_sum'] = np.float64(feats['f'].double().sum())
+        res[P + 'feats_f_abs'] = np.float64(feats['f'].double().abs().max())
+        for k in ('ref_feats_c', 'src_feats_c'):
+            res[P + k] = _np(out[k]) if index == 0 else _np(out[k])[::row_step]
+            res[P + k + '_sum'] = np.float64(out[k].double().sum())
+        for k in ('ref_node_corr_indices', 'src_node_corr_indices', 'estimated_transform'):
+            res[P + k] = _np(out[k])
+        res[P + 'num_corr'] = np.int64(out['ref_corr_points'].shape[0])
+        res[P + 'corr_score_sum'] = np.float64(out['corr_scores'].double().sum())
+        ms = out['matching_scores']
+        res[P + 'matching_scores_head'] = _np(ms[:4])
+        res[P + 'matching_scores_rowsum'] = _np(ms[:, :-1, :-1].exp().sum((1, 2)))
+        if index == 0:
+            res['blocks'] = np.array(cfg.geotransformer.blocks)
+            for name, rec in ops.items():
+                t = torch.from_numpy(rec['out0'])
+                res['op/%s/out0' % name] = rec['out0'][..., ::row_step, :]
+                res['op/%s/sum' % name] = np.float64(t.double().sum())
+                res['op/%s/abs' % name] = np.float64(t.double().abs().max())
+            for key in ('neighbors', 'subsampling', 'upsampling'):
+                res['checksum/' + key] = np.array([_index_checksum(t.numpy()) for t in dd[key]], dtype=np.uint64)
+                res['width/' + key] = np.array([t.shape[1] for t in dd[key]])
+                # the same with every row sorted first: invariant to the order inside groups of equal float32 distance, which
+                # the reference leaves to an unstable std::sort
+                res['rowset/' + key] = np.array([_index_checksum(np.sort(t.numpy(), 1)) for t in dd[key]], dtype=np.uint64)
+            res['points_last'] = _np(dd['points'][-1])
+        print(fname, 'pair', index, 'done', flush=True)
+    np.savez_compressed(os.path.join(HERE, fname), **res)
+
+
+def gen_precompute_cap():
+    """The 2000-superpoint cap of the coarsest stage (geotransformer/utils/data.py:34-43) through the genuine collate."""
+    ref_shims.install()
+    ref, src, T = make_pair('cap_30k')
+    dd = collate(ref, src, T, 4, 0.025, 0.0625, [38, 36, 36, 38])
+    res = {'lengths': np.stack([_np(l) for l in dd['lengths']]), 'points_last': _np(dd['points'][-1])}
+    for key in ('neighbors', 'subsampling', 'upsampling'):
+        res['checksum/' + key] = np.array([_index_checksum(t.numpy()) for t in dd[key]], dtype=np.uint64)
+        res['rowset/' + key] = np.array([_index_checksum(np.sort(t.numpy(), 1)) for t in dd[key]], dtype=np.uint64)
+        res['width/' + key] = np.array([t.shape[1] for t in dd[key]])
+    print('cap_30k stage lengths', res['lengths'].tolist())
+    np.savez_compressed(os.path.join(HERE, 'precompute_cap.npz'), **res)
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['tables', 'precompute', 'micro', 'synthw']
     if 'tables' in which:
@@ -230,6 +306,12 @@ if __name__ == '__main__':
         gen_synthw('se3ete.3dmatch', 'synthw_se3ete.npz')
     if 'kitti' in which or 'synthw' in which:
         gen_synthw('se3eti.kitti', 'synthw_se3eti_kitti.npz', pair='c3_4k')
+    if 'cap' in which:
+        gen_precompute_cap()
+    if 'fullsize' in which:
+        gen_fullsize('se3ete.3dmatch', 'c2_se3ete_5k.npz', 'c2_5k', 8)
+    if 'fullsize_kitti' in which or 'fullsize' in which:
+        gen_fullsize('se3eti.kitti', 'c3_se3eti_kitti_20k.npz', 'c3_20k', 1)
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, 'KiB')

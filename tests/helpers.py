@@ -64,3 +64,11 @@ def assert_pairs_equal_up_to_ties(idx_a, scores_a, idx_b, scores_b, rtol=1e-5, c
         if abs(float(sb[i]) - boundary) > rtol * abs(boundary):       # the last tie group may be cut differently
             assert sorted(pa[i:j]) == sorted(pb[i:j]), '%s: pairs %d..%d differ' % (context, i, j)
         i = j
+
+
+def index_checksum(t):
+    """Order-sensitive checksum of an index array: sum of value * ((flat position mod 65521) + 1) mod 2^61 - 1 -- the formula
+    tests/golden/generate_golden.py applied to the reference's tables."""
+    v = np.asarray(t).astype(np.uint64).reshape(-1)
+    w = (np.arange(v.size, dtype=np.uint64) % np.uint64(65521)) + np.uint64(1)
+    return int((v * w).sum() % np.uint64(2 ** 61 - 1))

@@ -151,3 +151,58 @@ def test_real_width_forward_matches_reference(golden_dir, variant, fixture):
     assert_close(out['ref_feats_c'], g['out/ref_feats_c'], 1e-5, 'ref_feats_c')
     assert_close(out['src_feats_c'], g['out/src_feats_c'], 1e-5, 'src_feats_c')
     assert_close(out['estimated_transform'], g['out/estimated_transform'], 1e-3, 'estimated_transform')
+
+
+def test_precompute_cap_matches_reference(golden_dir):
+    """The 2000-superpoint cap of the last stage (geotransformer/utils/data.py:34-43) on the cap_30k pair."""
+    from helpers import index_checksum
+    from oracle import se3et_oracle as O
+    from se3et_amd.synthetic import make_pair
+    g = np.load(golden_dir + '/precompute_cap.npz')
+    ref, src, _ = make_pair('cap_30k')
+    pts = torch.from_numpy(np.concatenate([ref, src], 0))
+    out = O.precompute(pts, torch.tensor([len(ref), len(src)]), 4, 0.025, 0.0625, [38, 36, 36, 38])
+    assert out['lengths'][-1].tolist() == [2000, 2000]
+    assert np.array_equal(np.stack([l.numpy() for l in out['lengths']]), g['lengths'])
+    assert torch.equal(out['points'][-1], torch.from_numpy(g['points_last']))
+    for key in ('neighbors', 'subsampling', 'upsampling'):
+        assert [t.shape[1] for t in out[key]] == g['width/' + key].tolist()
+        for i, t in enumerate(out[key]):
+            assert index_checksum(np.sort(t.numpy(), 1)) == int(g['rowset/' + key][i]), '%s[%d]' % (key, i)
+
+
+def test_c2_fullsize_forward_matches_reference(golden_dir):
+    """BASELINE.json configs[1] at its own size (SE3ET-E, 5k+5k pair 0, 382 / 304 superpoints): the oracle against the genuine
+    reference -- pyramid tables by checksum, every transformer layer, features, correspondences, transform."""
+    from helpers import index_checksum
+    from oracle import se3et_oracle as O
+    from se3et_amd.model import create_model, load_synthetic_weights, make_cfg
+    from se3et_amd.synthetic import make_pair
+    g = np.load(golden_dir + '/c2_se3ete_5k.npz')
+    cfg = make_cfg('se3ete')
+    sd = {k: v.detach() for k, v in load_synthetic_weights(create_model(cfg), int(g['synth_seed'])).state_dict().items()}
+    ref, src, _ = make_pair(str(g['pair']))
+    pts = torch.from_numpy(np.concatenate([ref, src], 0))
+    b = cfg.backbone
+    oc = O.OracleConfig.from_model_cfg(cfg)
+    data = O.precompute(pts, torch.tensor([len(ref), len(src)]), b.num_stages, b.init_voxel_size, b.init_radius, cfg.neighbor_limits)
+    assert np.array_equal(np.stack([l.numpy() for l in data['lengths']]), g['p0/lengths'])
+    for key in ('neighbors', 'subsampling', 'upsampling'):
+        for i, t in enumerate(data[key]):
+            assert index_checksum(t.numpy()) == int(g['checksum/' + key][i]), '%s[%d]' % (key, i)
+    data['features'] = torch.ones((pts.shape[0], 1))
+    taps = {}
+    with torch.no_grad():
+        out = O.forward(sd, oc, data, layer_tap=lambda i, t: taps.__setitem__(i, t))
+    rs = int(g['row_step'])
+    for i, block in enumerate(g['blocks']):
+        assert_close(taps[i][..., ::rs, :], g['op/layer_%d/out0' % i][0], 1e-5, 'layer %d (%s)' % (i, block))
+    assert_close(out['feats_c'][::rs, :, ::4], g['p0/feats_c'], 1e-5, 'feats_c')
+    assert_close(out['ref_feats_c'], g['p0/ref_feats_c'], 1e-5, 'ref_feats_c')
+    assert_close(out['src_feats_c'], g['p0/src_feats_c'], 1e-5, 'src_feats_c')
+    ri, si = torch.from_numpy(g['p0/ref_node_corr_indices']).long(), torch.from_numpy(g['p0/src_node_corr_indices']).long()
+    assert_pairs_equal_up_to_ties((out['ref_node_corr_indices'], out['src_node_corr_indices']), out['node_corr_scores'],
+                                  (ri, si), out['node_corr_scores'], rtol=1e-5, context='c2 node correspondences')
+    if sorted(zip(ri.tolist(), si.tolist())) == sorted(zip(out['ref_node_corr_indices'].tolist(), out['src_node_corr_indices'].tolist())):
+        assert out['ref_corr_points'].shape[0] == int(g['p0/num_corr'])
+        assert_close(out['estimated_transform'], g['p0/estimated_transform'], 1e-4, 'estimated_transform')
