@@ -10,7 +10,14 @@ resident in HBM before the timed region.  Pairs are sharded over ranks with no c
 the job time is the MAX over ranks; value = pairs / second over all ranks.
 
 Prints ONE JSON line: pairs/s plus a `roofline` object for the RPE self-attention kernels (per-launch HIP events on the
-launch stream, live over the timed region) and a `cpu_baseline` object (the CPU oracle timed on this box's host cores)."""
+launch stream, live over the timed region), a `cpu_baseline` object (the CPU oracle timed on this box's host cores) and a
+`single_pair` object (the reference-shaped one-pair-per-forward path: pairs/s, kernel launches, host synchronisations).
+
+Multi-GPU: one process per GPU.  Under `torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE in the environment) every process
+is one rank.  Started directly with `--gpus N > 1`, this process only LAUNCHES: before anything touches a GPU it starts N fresh
+child processes of itself (the reference's one-process-per-GPU launch, geotransformer/engine/base_trainer.py:66-78), one rank
+each, rendezvous on 127.0.0.1, prints rank 0's JSON line and exits with the worst child status.  `--gpus 8 --batch 8` is
+BASELINE.json configs[3] (64 independent pairs per step, 8 per rank)."""
 import argparse
 import json
 import os
@@ -33,6 +40,36 @@ PMC_TRAFFIC_RATIO = {'eq': 3149.4 / 2549.0, 'inv': 2307.7 / 2222.9}
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s is achievable
 
 
+def launch_ranks(n, argv):
+    """Parent of a self-launched multi-GPU run: N children `python bench.py <argv>`, one rank each.  Never initialises a GPU."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC (RCCL across processes on this driver)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode]
+    for p in procs[1:]:
+        try:
+            codes.append(p.wait(timeout=600))
+        except subprocess.TimeoutExpired:
+            p.kill()                                                # exactly the child started above
+            codes.append(-9)
+    for line in out.decode().splitlines():           # stdout carries the ONE JSON line; library chatter goes to stderr
+        print(line, file=sys.stdout if line.lstrip().startswith('{') else sys.stderr, flush=True)
+    bad = [c for c in codes if c != 0]
+    return 0 if not bad else (bad[0] if bad[0] > 0 else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -50,7 +87,17 @@ def main():
     ap.add_argument('--attention-dtype', default='float32', choices=['float32', 'bfloat16'], help="'bfloat16': geometric embedding "
                     "stored in bf16 (BASELINE.json configs[2] 'bf16 attention'); the headline metric is quoted on float32")
     ap.add_argument('--inflight', type=int, default=1, help='pairs in flight per GPU: host threads, one HIP stream each')
+    ap.add_argument('--single-pair-steps', type=int, default=16, help='pairs of the one-pair-per-forward measurement reported as '
+                    '`single_pair` (rank 0 at --gpus 1 only; 0 = skip)')
+    ap.add_argument('--fake-device', action='store_true', help='launcher self-test: gloo rendezvous, sharding, barriers and the '
+                    'MAX-over-ranks clock run for real, the step is a host sleep (no GPU needed; tests/test_bench_launch.py)')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        if not args.fake_device and torch.cuda.device_count() < args.gpus:      # device_count() does not initialise the GPU
+            raise SystemExit('bench.py: --gpus %d but only %d device(s) visible' % (args.gpus, torch.cuda.device_count()))
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.fake_device:
+        return run_fake(args)
 
     from se3et_amd import ops as se3_ops
     from se3et_amd import _lib as se3_lib
@@ -61,7 +108,7 @@ def main():
 
     rank, world, local = sharding.init_distributed('nccl')
     if world != args.gpus:
-        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
@@ -217,9 +264,13 @@ def main():
         'inv_call_avg_us': round((kinds['inv'][2] + kinds['inv'][3]) / max(kinds['inv'][0], 1), 2),
     }
 
+    single_pair = None
+    if rank == 0 and args.gpus == 1 and args.single_pair_steps > 0:
+        single_pair = run_single_pair(model, cfg, args, dev, feats)
     cpu_baseline = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(model, cfg, args)
+    ranks_seen = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
 
     if rank == 0:
         n, dims, _ = PAIR_PRESETS[args.pair]
@@ -230,15 +281,107 @@ def main():
             'vs_baseline': None, 'dtype': 'f32' if args.attention_dtype == 'float32' else 'f32 (geometric embedding stored in bf16)',
             'data': 'synthetic',
             'config': {'workload': 'SE3ET-E forward (pyramid + backbone + transformer + matching + Sinkhorn + LGR) on '
-                                   'synthetic %d+%d-point pairs, %d pair(s) per rank per step' % (n, n, PB),
+                                   'synthetic %d+%d-point pairs, %d pair(s) per rank per step' % (n, n, PB) +
+                                   (' = BASELINE.json configs[3]: 64 independent pairs per step over 8 GPUs' if world == 8 and PB == 8 else ''),
+                       'ranks_seen': ranks_seen,
                        'variant': args.variant, 'pair_preset': args.pair, 'sharding': 'pairs round-robin over ranks, no collective',
                        'pairs_per_forward': PB, 'pairs_in_flight_per_gpu': max(1, args.inflight), 'pyramid_prefetch': bool(args.prefetch),
                        'attention_dtype': args.attention_dtype},
-            'roofline': roofline, 'cpu_baseline': cpu_baseline,
+            'roofline': roofline, 'cpu_baseline': cpu_baseline, 'single_pair': single_pair,
         }
         print(json.dumps(line), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+
+
+def run_fake(args):
+    """--fake-device: everything of the multi-process contract except the GPU (rendezvous over gloo, round-robin sharding,
+    barrier + MAX-over-ranks clock, one JSON line from rank 0)."""
+    from se3et_amd import sharding
+    rank, world, _ = sharding.init_distributed('gloo')
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    PB = max(1, args.batch)
+    mine = sharding.shard_pairs((args.steps + args.warmup) * world * PB, rank, world)     # pair indices of this rank
+    sharding.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (rank + 1))
+    sharding.barrier()
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0)
+    total = sharding.sum_over_ranks(len(mine))
+    if rank == 0:
+        print(json.dumps({'metric': 'launcher self-test (no GPU work)', 'value': round(world * args.steps * PB / elapsed, 3),
+                          'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+                          'vs_baseline': None, 'dtype': 'none', 'data': 'none (fake device)',
+                          'config': {'workload': 'fake device', 'ranks_seen': torch.distributed.get_world_size() if world > 1 else 1,
+                                     'pairs_sharded': int(total), 'pairs_per_forward': PB}}), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+def run_single_pair(model, cfg, args, dev, feats_unused):
+    """The reference-shaped path (one pair per forward, experiments/se3ete.3dmatch/model.py:86-98) on the same workload:
+    pairs/s over `--single-pair-steps` pairs after 3 warm-up pairs; host synchronisations of one forward (torch's sync-debug
+    mode: every blocking copy / .item() / nonzero) and, when no external profiler is attached, kernel launches and summed
+    kernel time of one forward from torch.profiler."""
+    import warnings
+    from se3et_amd.data import precompute_data_stack_mode
+    from se3et_amd.synthetic import make_pair
+    b = cfg.backbone
+    n_pairs = args.single_pair_steps + 3
+    inputs = []
+    for i in range(n_pairs):
+        ref, src, _ = make_pair(args.pair, index=1000 + i)
+        inputs.append((torch.from_numpy(np.concatenate([ref, src], 0)).to(dev), torch.tensor([len(ref), len(src)], dtype=torch.int64)))
+    ones = torch.ones((inputs[0][0].shape[0], 1), dtype=torch.float32, device=dev)
+
+    def one(i):
+        pts, lens = inputs[i]
+        data = precompute_data_stack_mode(pts, lens, b.num_stages, b.init_voxel_size, b.init_radius, cfg.neighbor_limits)
+        data['features'] = ones
+        return model(data)
+
+    for i in range(3):
+        one(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(3, n_pairs):
+        one(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.single_pair_steps
+    syncs = [0]
+    with warnings.catch_warnings():
+        warnings.simplefilter('always')
+        show = warnings.showwarning
+        warnings.showwarning = lambda *a, **k: syncs.__setitem__(0, syncs[0] + 1)
+        torch.cuda.set_sync_debug_mode('warn')
+        try:
+            one(0)
+        finally:
+            torch.cuda.set_sync_debug_mode('default')
+            warnings.showwarning = show
+    torch.cuda.synchronize()
+    launches = gpu_ms = None
+    profiled = any(k.startswith('ROCPROF') for k in os.environ) or 'rocprof' in os.environ.get('LD_PRELOAD', '')
+    if not profiled:
+        try:
+            from torch.profiler import ProfilerActivity, profile
+            with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+                one(1)
+                torch.cuda.synchronize()
+            kernels = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA and 'Memcpy' not in e.name
+                       and 'Memset' not in e.name]
+            if kernels:
+                launches = len(kernels)
+                gpu_ms = round(sum(e.device_time_total if hasattr(e, 'device_time_total') else e.cuda_time_total for e in kernels) / 1e3, 3)
+        except Exception as exc:          # the profiler is a diagnostic, never a reason to lose the bench line
+            print('bench.py: torch.profiler unavailable (%s)' % exc, file=sys.stderr)
+    return {'pairs_per_s': round(1.0 / dt, 2), 'ms_per_pair': round(dt * 1e3, 3), 'pairs': args.single_pair_steps,
+            'host_syncs': syncs[0], 'launches': launches, 'gpu_kernel_ms': gpu_ms,
+            'host_ms': None if gpu_ms is None else round(max(dt * 1e3 - gpu_ms, 0.0), 3),
+            'note': 'one pair per forward incl. on-GPU pyramid and LGR; host_ms = wall time per pair not covered by kernel time'}
 
 
 def run_cpu_baseline(model, cfg, args):
