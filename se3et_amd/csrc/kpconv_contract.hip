@@ -1,0 +1,282 @@
+// B1: E2PN anchor-group kernel-point convolution (KPConvInterSO3), contraction stage on the matrix cores.
+//
+// Reference: geotransformer/modules/e2pn/blocks_epn.py:454-546 (forward) with the weight permutation tables of :228-332:
+//   out[p, r, d] = sum_{k, a, c} F[p, k, a, c] W[kidx[k, r], ridx[a, r], c, d],   F[p, k, a, c] = sum_n w[p, n, k] x[idx[p, n], a, c]
+// (F = the kernel-point sums of csrc/kpconv_so3.hip).  Summing the (k, a) slices that share a weight slot under output anchor r first,
+//   G[p, r, (s, t), c] = sum_{k: kidx[k, r] = s} F[p, k, a: ridx[a, r] = t, c],        out[(p, r), d] = G[(p, r), (s, t, c)] . W[(s, t, c), d]
+// is one GEMM with 2.5x fewer flops than the reference's expanded form.  Round 1 wrote G (P*6, 36 Cin) to HBM (1.2 - 2.9 GB per call)
+// and multiplied it with a library GEMM at the f32 MFMA rate.  This kernel never forms G in memory:
+//   * the gather kernel leaves F (2.4x smaller than G) in tile order [channel chunk][point][k*6 + a][8 channels];
+//   * a workgroup owns 16 points (= six 16-row MFMA tiles, one per output anchor r) and streams the channel chunks; per K-step of
+//     4 weight slots x 8 channels its waves build the G fragments from the F tile in LDS (1 or 4 adds per element: the C4 orbits of the
+//     kernel points) directly in MFMA operand order;
+//   * the product runs on the bf16 matrix cores at f32 accuracy: every f32 operand is split into three bf16 pieces
+//     (a = a1 + a2 + a3 exactly: 3 x 8 significant bits), the weights once per call (se3_kpconv_split_weights), G on the fly, and the six
+//     products a1 b1, a1 b2, a2 b1, a1 b3, a2 b2, a3 b1 (everything above 2^-24 relative) accumulate in f32:
+//     6 x v_mfma_f32_16x16x32_bf16 = 96 cycles for what 8 x v_mfma_f32_16x16x4_f32 do in 256.
+// Waves split the output columns (each B fragment is used by all six row tiles), the weight fragments are streamed from L2 in lane order
+// (1 KB per fragment, pre-arranged by the split kernel) and each workgroup reads them exactly once.
+#include "common.h"
+
+namespace {
+
+constexpr int kK = 15, kA = 6, kS = 6;
+constexpr int kTP = 16;                       // points per workgroup tile
+constexpr int kCC = 8;                        // channels per chunk
+constexpr int kSlots = kS * kA;               // 36 weight slots (s, t)
+constexpr int kKS = kSlots / 4;               // K-steps per channel chunk: 4 slots x 8 channels = 32
+constexpr int kRow = kK * kA * kCC;           // 720 floats of F per point and chunk
+constexpr int kRowPad = kRow + 4;             // LDS stride per point: 2896 B = 16 B x 181 (odd: conflict-free b128 reads over 16 points)
+constexpr int kZeroOff = kTP * kRowPad;       // float offset of an 8-float zero block (absent orbit members)
+constexpr int kFTileFloats = kTP * kRowPad + 8;
+
+// slot tables of the SE3ET configuration (se3et_amd/tables.py; identical to csrc/kpconv_so3.hip)
+__device__ constexpr int kKidx[kK][kA] = {{0, 1, 1, 1, 1, 2}, {1, 0, 1, 2, 1, 1}, {1, 1, 0, 1, 2, 1}, {1, 2, 1, 0, 1, 1},
+                                          {1, 1, 2, 1, 0, 1}, {2, 1, 1, 1, 1, 0}, {3, 3, 3, 4, 4, 4}, {3, 4, 3, 3, 4, 4},
+                                          {3, 4, 4, 3, 3, 4}, {3, 3, 4, 4, 3, 4}, {4, 3, 3, 4, 4, 3}, {4, 4, 3, 3, 4, 3},
+                                          {4, 4, 4, 3, 3, 3}, {4, 3, 4, 4, 3, 3}, {5, 5, 5, 5, 5, 5}};
+__device__ constexpr int kRidx[kA][kA] = {{0, 3, 3, 3, 3, 5}, {1, 0, 4, 5, 2, 1}, {2, 2, 0, 4, 5, 4},
+                                          {3, 5, 2, 0, 4, 3}, {4, 4, 5, 2, 0, 2}, {5, 1, 1, 1, 1, 0}};
+// K order of the slots: the 18 slots whose kernel-point orbit has ONE member (s in {0, 2, 5}) first, then the 18 with FOUR (s in {1, 3, 4}):
+// K-steps 0..3 read one F row per element, 5..8 four, step 4 is mixed (absent members read the zero block).
+__host__ __device__ constexpr int slot_at(int pos) {
+  const int single[3] = {0, 2, 5}, quad[3] = {1, 3, 4};
+  return pos < 18 ? single[pos / 6] * 6 + pos % 6 : quad[(pos - 18) / 6] * 6 + (pos - 18) % 6;
+}
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {      // round-to-nearest-even pair -> one dword (v_cvt_pk_bf16_f32)
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  bf16x2 v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// a[0..7] (f32) -> three bf16x8 fragments with a = p1 + p2 + p3 (to 2^-25 |a|)
+__device__ __forceinline__ void split3(const float (&a)[8], uint4& p1, uint4& p2, uint4& p3) {
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float x0 = a[2 * i], x1 = a[2 * i + 1];
+    h[i] = pack_bf16(x0, x1);
+    const float r0 = x0 - bf16_lo(h[i]), r1 = x1 - bf16_hi(h[i]);
+    m[i] = pack_bf16(r0, r1);
+    const float q0 = r0 - bf16_lo(m[i]), q1 = r1 - bf16_hi(m[i]);
+    l[i] = pack_bf16(q0, q1);
+  }
+  p1 = make_uint4(h[0], h[1], h[2], h[3]);
+  p2 = make_uint4(m[0], m[1], m[2], m[3]);
+  p3 = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+// ---- weights: (36 Cin, Cout) f32, row (s*6 + t) * Cin + c  ->  bf16 fragments [K-step][column tile][piece][lane][8] ---------------------
+__global__ void kpconv_split_weights_kernel(const float* __restrict__ W, int Cin, int Cout, uint4* __restrict__ Wf) {
+  const int NT = Cout / 16;
+  const int64_t frag = blockIdx.x;                    // (K-step, column tile)
+  const int ksg = (int)(frag / NT), nt = (int)(frag % NT);
+  const int cc = ksg / kKS, ks = ksg % kKS;
+  const int lane = threadIdx.x, kb = lane >> 4, n = nt * 16 + (lane & 15);
+  const int st = slot_at(4 * ks + kb);
+  float w[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) w[j] = W[((int64_t)st * Cin + cc * kCC + j) * Cout + n];
+  uint4 p1, p2, p3;
+  split3(w, p1, p2, p3);
+  uint4* dst = Wf + frag * 3 * 64 + lane;
+  dst[0] = p1;
+  dst[64] = p2;
+  dst[128] = p3;
+}
+
+// ---- contraction -------------------------------------------------------------------------------------------------------------------
+struct SlotEntry { unsigned short off[4]; };           // float offsets (k*6 + a) * 8 of the orbit members inside a point's F row
+
+template <int NTW>      // column tiles per wave
+__global__ __launch_bounds__(256, 2) void kpconv_contract_kernel(const float* __restrict__ F, const uint4* __restrict__ Wf,
+                                                                  int64_t P, int64_t P16, int Cin, int Cout, int nt_per_block,
+                                                                  float* __restrict__ out) {
+  extern __shared__ __align__(16) float lds[];
+  float* ftile = lds;                                                   // [16 points][724] + zero block
+  uint4* abuf = reinterpret_cast<uint4*>(lds + kFTileFloats);           // [6 r][3 pieces][64 lanes]
+  SlotEntry* tab = reinterpret_cast<SlotEntry*>(abuf + kA * 3 * 64);    // [9 K-steps][6 r][4 kb]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NT = Cout / 16;
+  const int nt0 = blockIdx.y * nt_per_block + wave * NTW;               // first column tile of this wave
+  const bool active = wave * NTW < nt_per_block;
+  const int64_t p0 = (int64_t)blockIdx.x * kTP;
+
+  // slot table: for (K-step, output anchor r, lane quarter kb) the F-row offsets of the orbit members of slot (s, t) under r
+  for (int e = tid; e < kKS * kA * 4; e += 256) {
+    const int kb = e & 3, r = (e >> 2) % kA, ks = e / (4 * kA);
+    const int st = slot_at(4 * ks + kb), s = st / kA, t = st % kA;
+    int a = 0;
+    for (int aa = 0; aa < kA; aa++) a = kRidx[aa][r] == t ? aa : a;
+    SlotEntry en;
+    int cnt = 0;
+    for (int k = 0; k < kK; k++)
+      if (kKidx[k][r] == s && cnt < 4) en.off[cnt++] = (unsigned short)((k * kA + a) * kCC);
+    for (; cnt < 4; cnt++) en.off[cnt] = 0xffffu;                       // absent member
+    tab[e] = en;
+  }
+  if (tid < 8) ftile[kZeroOff + tid] = 0.f;
+
+  f32x4 acc[kA][NTW];
+#pragma unroll
+  for (int r = 0; r < kA; r++)
+#pragma unroll
+    for (int n = 0; n < NTW; n++) acc[r][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int chunks = Cin / kCC;
+  const int prow = lane & 15, kb = lane >> 4;
+  const float* frow = ftile + prow * kRowPad;
+  for (int cc = 0; cc < chunks; cc++) {
+    __syncthreads();                                                    // the previous chunk's F tile is no longer read
+    {   // F tile of this chunk: 16 x 2880 contiguous bytes in global memory -> padded point rows in LDS
+      const float4* src = reinterpret_cast<const float4*>(F + ((int64_t)cc * P16 + p0) * kRow);
+      for (int q = tid; q < kTP * (kRow / 4); q += 256) {
+        const int pt = q / (kRow / 4), w4 = q - pt * (kRow / 4);
+        *reinterpret_cast<float4*>(ftile + pt * kRowPad + 4 * w4) = src[q];
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int ks = 0; ks < kKS; ks++) {
+      const int64_t ksg = (int64_t)cc * kKS + ks;
+      // weight fragments of this K-step (requested first: they arrive while the G fragments are built)
+      uint4 b[NTW][3];
+      if (active) {
+#pragma unroll
+        for (int n = 0; n < NTW; n++) {
+          const uint4* src = Wf + ((ksg * NT + nt0 + n) * 3) * 64 + lane;
+#pragma unroll
+          for (int pc = 0; pc < 3; pc++) b[n][pc] = src[pc * 64];
+        }
+      }
+      // G fragments: six (r) row tiles over four waves
+      for (int r = wave; r < kA; r += 4) {
+        const SlotEntry en = tab[(ks * kA + r) * 4 + kb];
+        float v[8];
+        {
+          const float4 x0 = *reinterpret_cast<const float4*>(frow + en.off[0]);
+          const float4 x1 = *reinterpret_cast<const float4*>(frow + en.off[0] + 4);
+          v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+        }
+        if (ks >= 4) {                                                  // block-uniform: K-steps 0..3 hold single-member slots only
+#pragma unroll
+          for (int j = 1; j < 4; j++) {
+            const float* sp = en.off[j] == 0xffffu ? ftile + kZeroOff : frow + en.off[j];
+            const float4 x0 = *reinterpret_cast<const float4*>(sp);
+            const float4 x1 = *reinterpret_cast<const float4*>(sp + 4);
+            v[0] += x0.x; v[1] += x0.y; v[2] += x0.z; v[3] += x0.w; v[4] += x1.x; v[5] += x1.y; v[6] += x1.z; v[7] += x1.w;
+          }
+        }
+        uint4 p1, p2, p3;
+        split3(v, p1, p2, p3);
+        uint4* dst = abuf + (r * 3) * 64 + lane;
+        dst[0] = p1;
+        dst[64] = p2;
+        dst[128] = p3;
+      }
+      __syncthreads();
+      if (active) {
+#pragma unroll
+        for (int r = 0; r < kA; r++) {
+          const uint4* ap = abuf + (r * 3) * 64 + lane;
+          const bf16x8 a1 = __builtin_bit_cast(bf16x8, ap[0]), a2 = __builtin_bit_cast(bf16x8, ap[64]),
+                       a3 = __builtin_bit_cast(bf16x8, ap[128]);
+#pragma unroll
+          for (int n = 0; n < NTW; n++) {
+            const bf16x8 b1 = __builtin_bit_cast(bf16x8, b[n][0]), b2 = __builtin_bit_cast(bf16x8, b[n][1]),
+                         b3 = __builtin_bit_cast(bf16x8, b[n][2]);
+            f32x4 c = acc[r][n];
+            // smallest terms first
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, c, 0, 0, 0);
+            acc[r][n] = c;
+          }
+        }
+      }
+      __syncthreads();                                                  // abuf is rewritten by the next K-step
+    }
+  }
+  if (active) {
+    // accumulator tile: lane holds column (lane & 15), rows (lane >> 4) * 4 + i  = points of the tile
+#pragma unroll
+    for (int r = 0; r < kA; r++)
+#pragma unroll
+      for (int n = 0; n < NTW; n++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int64_t p = p0 + (lane >> 4) * 4 + i;
+          if (p < P) out[(p * kA + r) * Cout + (nt0 + n) * 16 + (lane & 15)] = acc[r][n][i];
+        }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t se3_kpconv_weight_fragments_bytes(int in_channels, int out_channels) {
+  if (in_channels <= 0 || out_channels <= 0 || in_channels % kCC || out_channels % 16) return 0;
+  return (size_t)(in_channels / kCC) * kKS * (out_channels / 16) * 3 * 64 * sizeof(uint4);
+}
+
+extern "C" int se3_kpconv_split_weights(const float* weights, int in_channels, int out_channels, void* fragments, void* stream) {
+  SE3_REQUIRE(weights && fragments, SE3_ERR_INVALID_ARG, "kpconv_split_weights: null pointer");
+  SE3_REQUIRE(in_channels > 0 && in_channels % kCC == 0 && out_channels > 0 && out_channels % 16 == 0, SE3_ERR_UNSUPPORTED,
+              "kpconv_split_weights: channels (%d, %d) must be multiples of (8, 16)", in_channels, out_channels);
+  const int64_t frags = (int64_t)(in_channels / kCC) * kKS * (out_channels / 16);
+  kpconv_split_weights_kernel<<<(unsigned)frags, 64, 0, (hipStream_t)stream>>>(weights, in_channels, out_channels,
+                                                                              static_cast<uint4*>(fragments));
+  SE3_CHECK_LAUNCH("kpconv_split_weights");
+  return SE3_OK;
+}
+
+extern "C" int se3_kpconv_so3_contract(const float* F, const void* weight_fragments, int64_t num_queries, int in_channels,
+                                       int out_channels, float* out, void* stream) {
+  SE3_REQUIRE(F && weight_fragments && out, SE3_ERR_INVALID_ARG, "kpconv_so3_contract: null pointer");
+  SE3_REQUIRE(in_channels > 0 && in_channels % kCC == 0 && out_channels >= 16 && out_channels % 16 == 0, SE3_ERR_UNSUPPORTED,
+              "kpconv_so3_contract: channels (%d, %d) must be multiples of (8, 16)", in_channels, out_channels);
+  if (num_queries == 0) return SE3_OK;
+  const int NT = out_channels / 16;
+  const int64_t tiles = se3_cdiv(num_queries, kTP), P16 = tiles * kTP;
+  // column tiles per wave / per workgroup: a workgroup covers up to 16 column tiles (4 waves x 4); wide layers with few row tiles are
+  // split over the columns as well so that the grid fills the chip (the G fragments are then built once per column split)
+  int per_block;
+  if (NT <= 4) {
+    per_block = NT;                                            // one column tile per wave, NT active waves
+  } else {
+    SE3_REQUIRE(NT % 8 == 0, SE3_ERR_UNSUPPORTED, "kpconv_so3_contract: %d output channels (need <= 64 or a multiple of 128)",
+                out_channels);
+    per_block = NT % 16 == 0 ? 16 : 8;
+    while (per_block > 4 && tiles * (NT / per_block) < 3 * 256) per_block /= 2;
+  }
+  const int ntw = per_block >= 16 ? 4 : (per_block >= 8 ? 2 : 1);
+  const dim3 grid((unsigned)tiles, (unsigned)(NT / per_block));
+  const size_t lds = (size_t)kFTileFloats * 4 + (size_t)kA * 3 * 64 * 16 + (size_t)kKS * kA * 4 * sizeof(SlotEntry);
+  const uint4* Wf = static_cast<const uint4*>(weight_fragments);
+  hipStream_t st = (hipStream_t)stream;
+  static bool lds_attr_set = false;      // > 64 KB of dynamic LDS needs the opt-in once per kernel
+  if (!lds_attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kpconv_contract_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kpconv_contract_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kpconv_contract_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    lds_attr_set = true;
+  }
+  if (ntw == 4)
+    kpconv_contract_kernel<4><<<grid, 256, lds, st>>>(F, Wf, num_queries, P16, in_channels, out_channels, per_block, out);
+  else if (ntw == 2)
+    kpconv_contract_kernel<2><<<grid, 256, lds, st>>>(F, Wf, num_queries, P16, in_channels, out_channels, per_block, out);
+  else
+    kpconv_contract_kernel<1><<<grid, 256, lds, st>>>(F, Wf, num_queries, P16, in_channels, out_channels, per_block, out);
+  SE3_CHECK_LAUNCH("kpconv_so3_contract");
+  return SE3_OK;
+}

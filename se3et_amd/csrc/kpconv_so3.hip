@@ -37,11 +37,13 @@ __device__ constexpr int kBuiltinKidx[kK][kA] = {{0, 1, 1, 1, 1, 2}, {1, 0, 1, 2
 __device__ constexpr int kBuiltinRidx[kA][kA] = {{0, 3, 3, 3, 3, 5}, {1, 0, 4, 5, 2, 1}, {2, 2, 0, 4, 5, 4},
                                                  {3, 5, 2, 0, 4, 3}, {4, 4, 5, 2, 0, 2}, {5, 1, 1, 1, 1, 0}};
 
-template <bool BUILTIN>
+// FOUT: leave the kernel-point sums F themselves for the matrix-core contraction (csrc/kpconv_contract.hip) in its tile order
+// [channel chunk of 8][point (padded to 16)][k * 6 + a][8 channels] instead of the 2.4x larger slot sums G.
+template <bool BUILTIN, bool FOUT = false>
 __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restrict__ q_pts, const float* __restrict__ s_pts,
                                                             const int64_t* __restrict__ idx, const float* __restrict__ x,
                                                             ConvTables T, float inv_sigma, int64_t P, int64_t Ns, int NN,
-                                                            int Cin, float* __restrict__ G) {
+                                                            int Cin, float* __restrict__ G, int64_t P16 = 0) {
   __shared__ float w[kMaxNN][kK + 1];
   __shared__ int64_t nb[kMaxNN];
   __shared__ unsigned xrow[kMaxNN];      // element offset of the neighbour's feature row (clamped: invalid rows carry weight 0)
@@ -94,6 +96,12 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
 #pragma unroll
         for (int k = 0; k < kK; k++) f[k] = fmaf(w[n0 + u][k], xv[u], f[k]);
       }
+    }
+    if (FOUT) {
+      float* Fp = G + (((int64_t)(c >> 3) * P16 + p) * (kK * kA) + a) * 8 + (c & 7);
+#pragma unroll
+      for (int k = 0; k < kK; k++) Fp[k * kA * 8] = f[k];
+      continue;
     }
     float* Gp = G + p * (int64_t)(kA * kS * kA) * Cin;
 #pragma unroll
@@ -158,5 +166,27 @@ extern "C" int se3_kpconv_so3_gather(const float* q_pts, const float* s_pts, con
     kpconv_gather_kernel<false><<<(unsigned)num_queries, threads, 0, (hipStream_t)stream>>>(
         q_pts, s_pts, idx, x, T, 1.0f / sigma, num_queries, num_support, num_neighbors, in_channels, G);
   SE3_CHECK_LAUNCH("kpconv_so3_gather");
+  return SE3_OK;
+}
+
+// Same gather, output F (ceil16(P) rows, layout [Cin / 8][ceil16(P)][15 * 6][8]) for se3_kpconv_so3_contract.
+extern "C" int se3_kpconv_so3_gather_points(const float* q_pts, const float* s_pts, const int64_t* idx, const float* x,
+                                            const float* kernel_points_host, float sigma, int64_t num_queries, int64_t num_support,
+                                            int num_neighbors, int in_channels, float* F, void* stream) {
+  SE3_REQUIRE(q_pts && s_pts && idx && x && kernel_points_host && F, SE3_ERR_INVALID_ARG, "kpconv_so3_gather_points: null pointer");
+  SE3_REQUIRE(num_neighbors >= 1 && num_neighbors <= kMaxNN, SE3_ERR_UNSUPPORTED,
+              "kpconv_so3_gather_points: %d neighbours (max %d)", num_neighbors, kMaxNN);
+  SE3_REQUIRE(in_channels >= 8 && in_channels % 8 == 0 && sigma > 0.f, SE3_ERR_INVALID_ARG,
+              "kpconv_so3_gather_points: channels must be a multiple of 8");
+  if (num_queries == 0) return SE3_OK;
+  ConvTables T = {};
+  for (int k = 0; k < kK; k++)
+    for (int d = 0; d < 3; d++) T.kp[k][d] = kernel_points_host[3 * k + d];
+  const int cols = kA * in_channels;
+  const int threads = cols >= 256 ? 256 : (cols >= 128 ? 128 : 64);
+  const int64_t P16 = (num_queries + 15) / 16 * 16;
+  kpconv_gather_kernel<true, true><<<(unsigned)num_queries, threads, 0, (hipStream_t)stream>>>(
+      q_pts, s_pts, idx, x, T, 1.0f / sigma, num_queries, num_support, num_neighbors, in_channels, F, P16);
+  SE3_CHECK_LAUNCH("kpconv_so3_gather_points");
   return SE3_OK;
 }

@@ -318,9 +318,29 @@ def _host_table(t, dtype):
     return hit[0]
 
 
+KPCONV_MATRIX_CORE = True        # False: round-1 path (slot sums G in HBM + library GEMM), kept for narrow layers and for A/B timing
+_BUILTIN_KIDX = [[0, 1, 1, 1, 1, 2], [1, 0, 1, 2, 1, 1], [1, 1, 0, 1, 2, 1], [1, 2, 1, 0, 1, 1], [1, 1, 2, 1, 0, 1], [2, 1, 1, 1, 1, 0],
+                 [3, 3, 3, 4, 4, 4], [3, 4, 3, 3, 4, 4], [3, 4, 4, 3, 3, 4], [3, 3, 4, 4, 3, 4], [4, 3, 3, 4, 4, 3], [4, 4, 3, 3, 4, 3],
+                 [4, 4, 4, 3, 3, 3], [4, 3, 4, 4, 3, 3], [5, 5, 5, 5, 5, 5]]
+_BUILTIN_RIDX = [[0, 3, 3, 3, 3, 5], [1, 0, 4, 5, 2, 1], [2, 2, 0, 4, 5, 4], [3, 5, 2, 0, 4, 3], [4, 4, 5, 2, 0, 2], [5, 1, 1, 1, 1, 0]]
+_builtin_checked = {}
+
+
+def _builtin_slot_tables(kt, rt):
+    """True when the module's (k, r) -> s and (a, r) -> t tables are the SE3ET configuration compiled into the matrix-core kernel."""
+    key = (kt.data_ptr(), rt.data_ptr())
+    hit = _builtin_checked.get(key)
+    if hit is None:
+        hit = kt.tolist() == _BUILTIN_KIDX and rt.tolist() == _BUILTIN_RIDX
+        if len(_builtin_checked) > 64:
+            _builtin_checked.clear()
+        _builtin_checked[key] = hit
+    return hit
+
+
 def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, sigma):
-    """HIP gather of the slot-summed neighbourhood features (csrc/kpconv_so3.hip) + one library GEMM with the
-    (36 Cin, Cout) weight matrix."""
+    """Matrix-core path (csrc/kpconv_contract.hip) for channel counts that are multiples of (8, 16); otherwise the HIP gather of
+    the slot-summed neighbourhood features (csrc/kpconv_so3.hip) + one library GEMM with the (36 Cin, Cout) weight matrix."""
     x = _req(x.contiguous(), torch.float32, 'x', 3)
     q_pts, s_pts = _req(q_pts.contiguous(), torch.float32, 'q_pts', 2), _req(s_pts.contiguous(), torch.float32, 's_pts', 2)
     idx = _req(idx.contiguous(), torch.int64, 'neighb_inds', 2)
@@ -330,6 +350,21 @@ def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, s
     if A != 6 or tuple(weights.shape[:3]) != (6, 6, Cin) or Ns != s_pts.shape[0]:
         raise RuntimeError('kpconv_inter_so3: inconsistent shapes')
     kp, kt, rt = _host_table(kernel_points, torch.float32), _host_table(kidx, torch.int64), _host_table(ridx, torch.int64)
+    nt = Cout // 16
+    if KPCONV_MATRIX_CORE and Cin % 8 == 0 and Cout % 16 == 0 and (nt <= 4 or nt % 8 == 0) and _builtin_slot_tables(kt, rt):
+        # matrix-core path: F (P16, 90, Cin) in tile order -> slot sums on the fly -> bf16x6 MFMA at f32 accuracy (csrc/kpconv_contract.hip)
+        stream = _stream()
+        P16 = (P + 15) // 16 * 16
+        Fk = torch.empty((P16 * 90 * Cin,), dtype=torch.float32, device=x.device)
+        check(lib().se3_kpconv_so3_gather_points(q_pts.data_ptr(), s_pts.data_ptr(), idx.data_ptr(), x.data_ptr(), kp.data_ptr(),
+                                                 float(sigma), P, Ns, NN, Cin, Fk.data_ptr(), stream), 'se3_kpconv_so3_gather_points')
+        w = _req(weights.detach().contiguous(), torch.float32, 'weights', 4)
+        Wf = torch.empty((lib().se3_kpconv_weight_fragments_bytes(Cin, Cout),), dtype=torch.uint8, device=x.device)
+        check(lib().se3_kpconv_split_weights(w.data_ptr(), Cin, Cout, Wf.data_ptr(), stream), 'se3_kpconv_split_weights')
+        out = torch.empty((P, 6, Cout), dtype=torch.float32, device=x.device)
+        check(lib().se3_kpconv_so3_contract(Fk.data_ptr(), Wf.data_ptr(), P, Cin, Cout, out.data_ptr(), stream),
+              'se3_kpconv_so3_contract')
+        return out
     G = torch.empty((P * 6, 36 * Cin), dtype=torch.float32, device=x.device)
     check(lib().se3_kpconv_so3_gather(q_pts.data_ptr(), s_pts.data_ptr(), idx.data_ptr(), x.data_ptr(), kp.data_ptr(),
                                       kt.data_ptr(), rt.data_ptr(), float(sigma), P, Ns, NN, Cin, G.data_ptr(), _stream()),

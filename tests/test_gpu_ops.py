@@ -132,7 +132,8 @@ def _conv_state(Cin, Cout, radius, seed=0):
 
 
 @pytest.mark.parametrize('P,Ns,NN,Cin,Cout', [(700, 900, 19, 1, 16), (500, 500, 35, 32, 32), (300, 800, 36, 64, 64),
-                                              (120, 120, 38, 256, 256), (257, 300, 13, 8, 8)])
+                                              (120, 120, 38, 256, 256), (257, 300, 13, 8, 8), (1000, 1000, 36, 128, 128),
+                                              (333, 400, 20, 16, 16), (50, 64, 38, 512, 512), (37, 64, 12, 64, 32)])
 def test_kpconv_matches_oracle(P, Ns, NN, Cin, Cout):
     from oracle import se3et_oracle as O
     from se3et_amd import functional as SF
@@ -149,6 +150,44 @@ def test_kpconv_matches_oracle(P, Ns, NN, Cin, Cout):
     got = SF.kpconv_inter_so3(x.cuda(), q_pts.cuda(), s_pts.cuda(), idx.cuda(), st['kernel_points'].cuda(),
                               st['weights'].cuda(), st['kidx_rot'][:, 0, :].cuda(), st['ridx_rot'][0].cuda(), sigma).cpu()
     assert_close(got, want, 1e-4, 'kpconv')
+
+
+@pytest.mark.parametrize('P,Ns,NN,Cin,Cout', [(500, 500, 35, 32, 32), (2001, 2500, 36, 128, 128), (129, 200, 38, 256, 256)])
+def test_kpconv_matrix_core_path_has_f32_accuracy(P, Ns, NN, Cin, Cout):
+    """The bf16 matrix-core contraction (three-way operand splits, six products: csrc/kpconv_contract.hip) against the f32 path
+    (slot sums + library f32 GEMM) on the same inputs: agreement at f32 round-off level (1e-5 of the max), and both against a float64
+    evaluation of the same formula, where the split path must not be worse than 2x the f32 path's own error."""
+    from se3et_amd import functional as SF
+    from se3et_amd import ops
+    g = torch.Generator().manual_seed(14)
+    radius, sigma = 0.0625, 0.05
+    s_pts = torch.rand(Ns, 3, generator=g) * 0.3
+    q_pts = s_pts[torch.randperm(Ns, generator=g)[:P]].contiguous()
+    d = ((q_pts[:, None] - s_pts[None]) ** 2).sum(-1)
+    idx = d.topk(NN, dim=1, largest=False)[1]
+    idx[d.gather(1, idx) > radius ** 2] = Ns
+    x = torch.randn(Ns, 6, Cin, generator=g)
+    st = _conv_state(Cin, Cout, radius)
+    args = (x.cuda(), q_pts.cuda(), s_pts.cuda(), idx.cuda(), st['kernel_points'].cuda(), st['weights'].cuda(),
+            st['kidx_rot'][:, 0, :].cuda(), st['ridx_rot'][0].cuda(), sigma)
+    assert ops.KPCONV_MATRIX_CORE
+    new = SF.kpconv_inter_so3(*args).cpu()
+    ops.KPCONV_MATRIX_CORE = False
+    try:
+        old = SF.kpconv_inter_so3(*args).cpu()
+    finally:
+        ops.KPCONV_MATRIX_CORE = True
+    assert_close(new, old, 1e-5, 'matrix-core path vs f32 path')
+    # float64 evaluation of out = sum_{k,a,c} F[k,a,c] W[kidx[k,r], ridx[a,r], c, d]
+    xs = torch.cat((x, torch.zeros(1, 6, Cin))).double()
+    sp = torch.cat((s_pts, torch.full((1, 3), 1e6))).double()
+    nb = sp[idx] - q_pts.double()[:, None]
+    w = (1 - (nb[:, :, None] - st['kernel_points'].double()[None, None]).norm(dim=-1) / sigma).clamp(min=0)      # (P, NN, K)
+    Fk = torch.einsum('pnk,pnac->pkac', w, xs[idx])
+    W = st['weights'].double()[st['kidx_rot'][:, 0, :][:, None, :], st['ridx_rot'][0][None, :, :]]                # (K, A, R, Cin, Cout)
+    ref = torch.einsum('pkac,karcd->prd', Fk, W)
+    e_new, e_old = float((new.double() - ref).abs().max()), float((old.double() - ref).abs().max())
+    assert e_new <= max(2 * e_old, 2e-6 * float(ref.abs().max())), (e_new, e_old)
 
 
 def test_kpconv_matches_reference_fixture(golden_dir):

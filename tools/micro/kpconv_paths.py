@@ -1,0 +1,43 @@
+"""KPConv per stage at the bench shape (8 pairs per forward): round-1 path (slot sums G + library f32 GEMM) against the matrix-core
+path (F + bf16x6 contraction).  python tools/micro/kpconv_paths.py"""
+import sys; sys.path.insert(0, '.')
+import numpy as np, torch
+from se3et_amd import ops, functional as SF, tables
+from se3et_amd.data import precompute_data_stack_mode
+from se3et_amd.model import make_cfg
+from se3et_amd.synthetic import make_pair
+dev = torch.device('cuda'); cfg = make_cfg('se3ete'); b = cfg.backbone
+clouds = []
+for j in range(8):
+    ref, src, _ = make_pair('c2_5k', index=j); clouds += [ref, src]
+pts = torch.from_numpy(np.concatenate(clouds, 0)).to(dev)
+dd = precompute_data_stack_mode(pts, torch.tensor([len(c) for c in clouds]), b.num_stages, b.init_voxel_size, b.init_radius, cfg.neighbor_limits)
+kidx = torch.from_numpy(tables.kernel_slot_table()).to(dev); ridx = torch.from_numpy(tables.anchor_slot_table()).to(dev)
+def timeit(f, n=10):
+    f(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+# (query stage, support stage, table, Cin = Cout, sigma scale)
+calls = [(0, 0, 'neighbors', 32), (1, 0, 'subsampling', 32), (1, 1, 'neighbors', 64), (1, 1, 'neighbors', 64), (2, 1, 'subsampling', 64),
+         (2, 2, 'neighbors', 128), (2, 2, 'neighbors', 128), (3, 2, 'subsampling', 128), (3, 3, 'neighbors', 256), (3, 3, 'neighbors', 256)]
+tot = {'old': 0.0, 'new': 0.0}
+g = torch.Generator(device='cpu').manual_seed(0)
+for qs, ss, tab, C in calls:
+    q, s = dd['points'][qs], dd['points'][ss]
+    idx = dd[tab][qs if tab == 'neighbors' else ss]
+    x = torch.randn(s.shape[0], 6, C, generator=g).to(dev)
+    w = (torch.randn(6, 6, C, C, generator=g) / (36 * C) ** 0.5).to(dev)
+    kp = torch.from_numpy(tables.kernel_points(b.init_radius * 2 ** ss)).to(dev)
+    sig = b.init_sigma * 2 ** ss
+    res = {}
+    for name, flag in (('old', False), ('new', True)):
+        ops.KPCONV_MATRIX_CORE = flag
+        res[name] = timeit(lambda: SF.kpconv_inter_so3(x, q, s, idx, kp, w, kidx, ridx, sig))
+        tot[name] += res[name]
+    ops.KPCONV_MATRIX_CORE = True
+    gf = 2.0 * 6 * q.shape[0] * 36 * C * C / 1e9
+    print('P %6d NN %2d C %3d  old %.3f ms  new %.3f ms  (%.0f GF: new = %.0f TF/s f32-equivalent)' % (q.shape[0], idx.shape[1], C, res['old'], res['new'], gf, gf / res['new']))
+print('total old %.2f ms  new %.2f ms per 8 pairs' % (tot['old'], tot['new']))
