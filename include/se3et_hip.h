@@ -145,7 +145,8 @@ int se3_kpconv_so3_gather(const float* q_pts, const float* s_pts, const int64_t*
                           void* stream);
 
 /* Matrix-core form of the same convolution (csrc/kpconv_contract.hip), channels multiples of (8, 16): the gather leaves the
- * kernel-point sums F[p, k, a, c] = sum_n w[p, n, k] x[idx[p, n], a, c] in tile order [Cin / 8][ceil16(P)][15 * 6][8] (2.4x smaller
+ * kernel-point sums F[p, k, a, c] = sum_n w[p, n, k] x[idx[p, n], a, c] in tile order [Cin / 8][ceil16(P)][732] (se3_kpconv_points_floats
+ * floats; a row = 15 * 6 * 8 values + 8 zeros + 4 pad; 2.4x smaller
  * than the slot sums of se3_kpconv_so3_gather; kernel-point / anchor slot tables = the SE3ET configuration, compiled in);
  * se3_kpconv_split_weights re-arranges weights (36 Cin, Cout) -- KPConvInterSO3.weights (6, 6, Cin, Cout) flattened -- into
  * three-piece bf16 MFMA fragments (`fragments`: se3_kpconv_weight_fragments_bytes bytes, rebuilt per call: no stale copies);
@@ -155,6 +156,7 @@ int se3_kpconv_so3_gather(const float* q_pts, const float* s_pts, const int64_t*
 int se3_kpconv_so3_gather_points(const float* q_pts, const float* s_pts, const int64_t* idx, const float* x,
                                  const float* kernel_points_host, float sigma, int64_t num_queries, int64_t num_support,
                                  int num_neighbors, int in_channels, float* F, void* stream);
+size_t se3_kpconv_points_floats(int64_t num_queries, int in_channels);
 size_t se3_kpconv_weight_fragments_bytes(int in_channels, int out_channels);
 int se3_kpconv_split_weights(const float* weights, int in_channels, int out_channels, void* fragments, void* stream);
 int se3_kpconv_so3_contract(const float* F, const void* weight_fragments, int64_t num_queries, int in_channels, int out_channels,

@@ -6,7 +6,7 @@
 //   G[p, r, (s, t), c] = sum_{k: kidx[k, r] = s} F[p, k, a: ridx[a, r] = t, c],        out[(p, r), d] = G[(p, r), (s, t, c)] . W[(s, t, c), d]
 // is one GEMM with 2.5x fewer flops than the reference's expanded form.  Round 1 wrote G (P*6, 36 Cin) to HBM (1.2 - 2.9 GB per call)
 // and multiplied it with a library GEMM at the f32 MFMA rate.  This kernel never forms G in memory:
-//   * the gather kernel leaves F (2.4x smaller than G) in tile order [channel chunk][point][k*6 + a][8 channels];
+//   * the gather kernel leaves F (2.4x smaller than G) in tile order [channel chunk][point][732] (15 x 6 x 8 values, zero slot, pad);
 //   * a workgroup owns 16 points (= six 16-row MFMA tiles, one per output anchor r) and streams the channel chunks; per K-step of
 //     4 weight slots x 8 channels its waves build the G fragments from the F tile in LDS (1 or 4 adds per element: the C4 orbits of the
 //     kernel points) directly in MFMA operand order;
@@ -17,6 +17,7 @@
 // Waves split the output columns (each B fragment is used by all six row tiles), the weight fragments are streamed from L2 in lane order
 // (1 KB per fragment, pre-arranged by the split kernel) and each workgroup reads them exactly once.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -26,9 +27,14 @@ constexpr int kCC = 8;                        // channels per chunk
 constexpr int kSlots = kS * kA;               // 36 weight slots (s, t)
 constexpr int kKS = kSlots / 4;               // K-steps per channel chunk: 4 slots x 8 channels = 32
 constexpr int kRow = kK * kA * kCC;           // 720 floats of F per point and chunk
-constexpr int kRowPad = kRow + 4;             // LDS stride per point: 2896 B = 16 B x 181 (odd: conflict-free b128 reads over 16 points)
-constexpr int kZeroOff = kTP * kRowPad;       // float offset of an 8-float zero block (absent orbit members)
-constexpr int kFTileFloats = kTP * kRowPad + 8;
+// Row stride per point, in global memory AND in LDS (a tile is one linear 46.8 KB copy): 720 values + an 8-float zero slot (absent orbit
+// members of single-member slots read it) + 4 pad = 732 floats = 2928 B = 16 B x 183 (odd: conflict-free b128 reads over 16 points).
+constexpr int kRowPad = 732;
+constexpr int kZeroSlot = kRow;               // float offset of the zero slot inside a row
+constexpr int kTileFloats = kTP * kRowPad;    // 11712 floats = 2928 float4
+constexpr int kFTileFloats = kTileFloats;
+constexpr int kTilePieces = (kTileFloats * 4 + 1023) / 1024;      // 46 LDS-DMA pieces of 1 KB (64 lanes x 16 B)
+constexpr int kTileLds = kTilePieces * 256;   // floats per F buffer in LDS of the wide kernel (whole pieces: 256 B beyond the tile)
 
 // slot tables of the SE3ET configuration (se3et_amd/tables.py; identical to csrc/kpconv_so3.hip)
 __device__ constexpr int kKidx[kK][kA] = {{0, 1, 1, 1, 1, 2}, {1, 0, 1, 2, 1, 1}, {1, 1, 0, 1, 2, 1}, {1, 2, 1, 0, 1, 1},
@@ -116,14 +122,16 @@ __global__ __launch_bounds__(256, 2) void kpconv_contract_kernel(const float* __
     const int st = slot_at(4 * ks + kb), s = st / kA, t = st % kA;
     int a = 0;
     for (int aa = 0; aa < kA; aa++) a = kRidx[aa][r] == t ? aa : a;
-    SlotEntry en;
+    unsigned long long packed = (unsigned long long)kZeroSlot * 0x0001000100010001ull;   // four 16-bit offsets; absent member = zero slot
     int cnt = 0;
     for (int k = 0; k < kK; k++)
-      if (kKidx[k][r] == s && cnt < 4) en.off[cnt++] = (unsigned short)((k * kA + a) * kCC);
-    for (; cnt < 4; cnt++) en.off[cnt] = 0xffffu;                       // absent member
-    tab[e] = en;
+      if (kKidx[k][r] == s && cnt < 4) {
+        const unsigned long long off = (unsigned long long)((k * kA + a) * kCC);
+        packed = (packed & ~(0xffffull << (16 * cnt))) | (off << (16 * cnt));
+        cnt++;
+      }
+    reinterpret_cast<unsigned long long*>(tab)[e] = packed;
   }
-  if (tid < 8) ftile[kZeroOff + tid] = 0.f;
 
   f32x4 acc[kA][NTW];
 #pragma unroll
@@ -137,11 +145,8 @@ __global__ __launch_bounds__(256, 2) void kpconv_contract_kernel(const float* __
   for (int cc = 0; cc < chunks; cc++) {
     __syncthreads();                                                    // the previous chunk's F tile is no longer read
     {   // F tile of this chunk: 16 x 2880 contiguous bytes in global memory -> padded point rows in LDS
-      const float4* src = reinterpret_cast<const float4*>(F + ((int64_t)cc * P16 + p0) * kRow);
-      for (int q = tid; q < kTP * (kRow / 4); q += 256) {
-        const int pt = q / (kRow / 4), w4 = q - pt * (kRow / 4);
-        *reinterpret_cast<float4*>(ftile + pt * kRowPad + 4 * w4) = src[q];
-      }
+      const float4* src = reinterpret_cast<const float4*>(F + ((int64_t)cc * P16 + p0) * kRowPad);
+      for (int q = tid; q < kTileFloats / 4; q += 256) reinterpret_cast<float4*>(ftile)[q] = src[q];
     }
     __syncthreads();
 #pragma unroll 1
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void kpconv_contract_kernel(const float* __
         if (ks >= 4) {                                                  // block-uniform: K-steps 0..3 hold single-member slots only
 #pragma unroll
           for (int j = 1; j < 4; j++) {
-            const float* sp = en.off[j] == 0xffffu ? ftile + kZeroOff : frow + en.off[j];
+            const float* sp = frow + en.off[j];
             const float4 x0 = *reinterpret_cast<const float4*>(sp);
             const float4 x1 = *reinterpret_cast<const float4*>(sp + 4);
             v[0] += x0.x; v[1] += x0.y; v[2] += x0.z; v[3] += x0.w; v[4] += x1.x; v[5] += x1.y; v[6] += x1.z; v[7] += x1.w;
@@ -222,7 +227,260 @@ __global__ __launch_bounds__(256, 2) void kpconv_contract_kernel(const float* __
   }
 }
 
+
+// ---- wide layers (>= 128 output channels per workgroup): 8 waves in two groups that alternate roles ------------------------------------
+// Waves w and w + 4 share a SIMD.  Every K-step has two halves separated by a barrier: in the first, group X (waves 0..3) multiplies step
+// g while group Y (waves 4..7) builds G-fragment sets 0..2 of step g + 1, requests its own weight fragments and copies a slice of the next
+// channel chunk's F tile; in the second half the roles swap (X builds sets 3..5).  So each SIMD always has one wave on the matrix pipe
+// and one on the VALU / LDS side, instead of both doing the same thing in lockstep behind a common barrier.
+template <int NTW>      // column tiles per wave (8 waves: 8 * NTW column tiles per workgroup)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void kpconv_contract_wide_kernel(const float* __restrict__ F, const uint4* __restrict__ Wf,
+                                                                       int64_t P, int64_t P16, int Cin, int Cout,
+                                                                       float* __restrict__ out, int dbg) {
+  extern __shared__ __align__(16) float lds[];
+  float* fbuf = lds;                                                    // [2][16 points][732]
+  uint4* abuf = reinterpret_cast<uint4*>(lds + 2 * kTileLds);           // [2][6 r][3 pieces][64 lanes]
+  SlotEntry* tab = reinterpret_cast<SlotEntry*>(abuf + 2 * kA * 3 * 64);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2, wg = wave & 3;                             // role group, wave inside the group
+  const int NT = Cout / 16;
+  const int nt0 = (blockIdx.y * 8 + wave) * NTW;
+  const int64_t p0 = (int64_t)blockIdx.x * kTP;
+  for (int e = tid; e < kKS * kA * 4; e += 512) {
+    const int kb = e & 3, r = (e >> 2) % kA, ks = e / (4 * kA);
+    const int st = slot_at(4 * ks + kb), s = st / kA, t = st % kA;
+    int a = 0;
+    for (int aa = 0; aa < kA; aa++) a = kRidx[aa][r] == t ? aa : a;
+    unsigned long long packed = (unsigned long long)kZeroSlot * 0x0001000100010001ull;   // four 16-bit offsets; absent member = zero slot
+    int cnt = 0;
+    for (int k = 0; k < kK; k++)
+      if (kKidx[k][r] == s && cnt < 4) {
+        const unsigned long long off = (unsigned long long)((k * kA + a) * kCC);
+        packed = (packed & ~(0xffffull << (16 * cnt))) | (off << (16 * cnt));
+        cnt++;
+      }
+    reinterpret_cast<unsigned long long*>(tab)[e] = packed;
+  }
+  const int chunks = Cin / kCC;
+  const int prow = lane & 15, kb = lane >> 4;
+  {   // F tile of chunk 0
+    const float4* src = reinterpret_cast<const float4*>(F + p0 * kRowPad);
+    for (int q = tid; q < kTileFloats / 4; q += 512) reinterpret_cast<float4*>(fbuf)[q] = src[q];
+  }
+  __syncthreads();
+
+  // G fragments of K-step `ks`, output anchor r, built in one go (prologue only)
+  auto build = [&](const float* fb, uint4* ab, int ks, int r) {
+    const float* frow = fb + prow * kRowPad;
+    const SlotEntry en = tab[(ks * kA + r) * 4 + kb];
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float* sp = frow + en.off[j];
+      const float4 x0 = *reinterpret_cast<const float4*>(sp);
+      const float4 x1 = *reinterpret_cast<const float4*>(sp + 4);
+      v[0] += x0.x; v[1] += x0.y; v[2] += x0.z; v[3] += x0.w; v[4] += x1.x; v[5] += x1.y; v[6] += x1.z; v[7] += x1.w;
+    }
+    uint4 p1, p2, p3;
+    split3(v, p1, p2, p3);
+    uint4* dst = ab + (r * 3) * 64 + lane;
+    dst[0] = p1;
+    dst[64] = p2;
+    dst[128] = p3;
+  };
+  if (wave < kA) build(fbuf, abuf, 0, wave);
+
+  const int64_t steps = (int64_t)chunks * kKS;
+  f32x4 acc[kA][NTW];
+#pragma unroll
+  for (int r = 0; r < kA; r++)
+#pragma unroll
+    for (int n = 0; n < NTW; n++) acc[r][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // weight fragments: b = the step being multiplied, bn = the following step, requested a full K-step (three halves) before its first use:
+  // one half is shorter than an L2 / HBM round trip under load
+  uint4 b[NTW][3], bn[NTW][3];
+  auto load_b = [&](int64_t g) {
+    if (dbg & 16) g = 0;                         // timing experiment: the same fragments every step (no weight stream)
+    const int64_t gc = g < steps ? g : steps - 1;
+#pragma unroll
+    for (int n = 0; n < NTW; n++) {
+      const uint4* src = Wf + ((gc * NT + nt0 + n) * 3) * 64 + lane;
+#pragma unroll
+      for (int pc = 0; pc < 3; pc++) bn[n][pc] = src[pc * 64];
+    }
+  };
+  auto rotate_b = [&]() {
+#pragma unroll
+    for (int n = 0; n < NTW; n++)
+#pragma unroll
+      for (int pc = 0; pc < 3; pc++) b[n][pc] = bn[n][pc];
+  };
+  auto multiply = [&](const uint4* ab) {
+    bf16x8 a1[kA], a2[kA], a3[kA];
+    if (dbg & 4) ab = abuf + (lane & 1) * 64;        // timing experiment: every fragment from two addresses (no LDS bandwidth)
+    // read order = order of first use (a3, a1, a2): the first MFMAs start when a third of the fragments has arrived
+#pragma unroll
+    for (int r = 0; r < kA; r++) a3[r] = __builtin_bit_cast(bf16x8, ab[(r * 3 + 2) * 64 + lane]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < kA; r++) a1[r] = __builtin_bit_cast(bf16x8, ab[(r * 3) * 64 + lane]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < kA; r++) a2[r] = __builtin_bit_cast(bf16x8, ab[(r * 3 + 1) * 64 + lane]);
+    // all 18 fragment reads are issued before the first MFMA (the compiler otherwise pairs each read with the MFMA that needs it and
+    // exposes one LDS round trip per MFMA); the MFMAs then wait with counted lgkmcnt as the fragments arrive
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 0; n < NTW; n++) {
+      const bf16x8 b1 = __builtin_bit_cast(bf16x8, b[n][0]), b2 = __builtin_bit_cast(bf16x8, b[n][1]),
+                   b3 = __builtin_bit_cast(bf16x8, b[n][2]);
+      // product-major: consecutive MFMAs go to different accumulators (no dependent back-to-back issue); smallest terms first
+#pragma unroll
+      for (int r = 0; r < kA; r++) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[r], b1, acc[r][n], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < kA; r++) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[r], b3, acc[r][n], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < kA; r++) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[r], b2, acc[r][n], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < kA; r++) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[r], b1, acc[r][n], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < kA; r++) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[r], b2, acc[r][n], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < kA; r++) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[r], b1, acc[r][n], 0, 0, 0);
+    }
+  };
+
+  // ---- builder pipeline (three stages, one per build half of this wave; no LDS round trip is waited for inside a half) ---------------
+  //   stage 0: slot-table entry of step g + 3        -> en_next
+  //   stage 1: F rows of step g + 2 (uses en of the previous half) -> xr[0..7]  (absent orbit members read the zero block)
+  //   stage 2: add, split, write the fragments of step g + 1 from the rows requested one half earlier
+  // Builder waves: group Y waves 4..6 own output anchors r = 0..2 (first halves), group X waves 0..2 own r = 3..5 (second halves).
+  const bool builder = wg < 3;
+  const int rfix = grp == 1 ? wg : 3 + wg;
+  float4 xr[8];
+  SlotEntry en_next;
+  auto read_rows = [&](const float* fb, const SlotEntry en) {
+    const float* frow = fb + prow * kRowPad;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float* sp = frow + en.off[j];
+      xr[2 * j] = *reinterpret_cast<const float4*>(sp);
+      xr[2 * j + 1] = *reinterpret_cast<const float4*>(sp + 4);
+    }
+  };
+  auto finish = [&](uint4* ab) {
+    float v[8];
+    v[0] = (xr[0].x + xr[2].x) + (xr[4].x + xr[6].x); v[1] = (xr[0].y + xr[2].y) + (xr[4].y + xr[6].y);
+    v[2] = (xr[0].z + xr[2].z) + (xr[4].z + xr[6].z); v[3] = (xr[0].w + xr[2].w) + (xr[4].w + xr[6].w);
+    v[4] = (xr[1].x + xr[3].x) + (xr[5].x + xr[7].x); v[5] = (xr[1].y + xr[3].y) + (xr[5].y + xr[7].y);
+    v[6] = (xr[1].z + xr[3].z) + (xr[5].z + xr[7].z); v[7] = (xr[1].w + xr[3].w) + (xr[5].w + xr[7].w);
+    uint4 p1, p2, p3;
+    split3(v, p1, p2, p3);
+    uint4* dst = ab + (rfix * 3) * 64 + lane;
+    dst[0] = p1;
+    dst[64] = p2;
+    dst[128] = p3;
+  };
+  auto tab_entry = [&](int ksq) {              // table entry of K-step position ksq (0..8) for this lane
+    return tab[(ksq * kA + rfix) * 4 + kb];
+  };
+  // prime: rows of step 1, table entry of step 2 (F chunk 0 holds steps 0..8; one-chunk layers have >= 9 steps)
+  if (builder) {
+    read_rows(fbuf, tab_entry(1));
+    en_next = tab_entry(2);
+  }
+
+  load_b(0);
+  if (grp == 0) {                      // X multiplies step 0 in the first half of the first K-step
+    rotate_b();
+    load_b(1);
+  }
+  __syncthreads();
+
+  int cc = 0, ks = 0;
+#pragma unroll 1
+  for (int64_t g = 0; g < steps; g++) {
+    const int cur = (int)(g & 1);
+    uint4* anext = abuf + (cur ^ 1) * kA * 3 * 64;
+    const uint4* acur = abuf + cur * kA * 3 * 64;
+    // F buffer that holds step g + 2 (the next chunk's tile is complete after step ks = 6 of this chunk, see below)
+    const int cc2 = ks + 2 >= kKS ? cc + 1 : cc;
+    const float* f2 = fbuf + (cc2 & 1) * kTileLds;
+    const int ks3 = ks + 3 >= kKS ? ks + 3 - kKS : ks + 3;
+    // The NEXT channel chunk's F tile goes global -> LDS by LDS-DMA (no registers, no store pass), requested by all eight waves at the
+    // first K-step of a chunk: 46 pieces of 1 KB, lane-linear on both sides (global rows have the LDS row stride).  Its first readers
+    // are the row requests of K-step 7; every wave retires its pieces long before that (the weight-fragment waits of K-step 1 drain
+    // them: requests complete in order), and the barriers in between publish them to the other waves.
+    if (ks == 0 && cc + 1 < chunks && !(dbg & 64)) {
+      const float* gsrc = F + ((int64_t)(cc + 1) * P16 + p0) * kRowPad;
+      float* ldst = fbuf + ((cc + 1) & 1) * kTileLds;
+#pragma unroll
+      for (int i = 0; i < (kTilePieces + 7) / 8; i++) {
+        const int piece = i * 8 + wave;
+        if (piece < kTilePieces)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + piece * 256 + lane * 4),
+                                           (__attribute__((address_space(3))) void*)(ldst + piece * 256), 16, 0, 0);
+      }
+    }
+#define SE3_BUILD_HALF()                                                                                  \
+    if (builder && !(dbg & 1)) {                                                                          \
+      if (g + 1 < steps) finish(anext);                                                                   \
+      read_rows(f2, en_next);                                                                             \
+      en_next = tab_entry(ks3);                                                                           \
+    }
+    // End of a build half: only the LDS WRITES (three fragment stores) must have landed before the barrier; the nine
+    // younger reads (eight F rows, one table entry) of the next stage stay in flight across it (LDS operations of a wave complete in
+    // order, so lgkmcnt(9) retires exactly the writes).  A plain __syncthreads() waits lgkmcnt(0) = one LDS round trip per half.
+#define SE3_BUILD_FENCE()                                                                                 \
+    if (builder && !(dbg & 1)) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");                         \
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ---- first half: X multiplies step g, Y prepares
+    if (grp == 0) {
+      if (!(dbg & 2)) multiply(acur);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
+      if (!(dbg & 32)) {
+      rotate_b();                                      // Y multiplies step g in the second half
+      load_b(g + 1);
+      }
+      SE3_BUILD_HALF()
+      SE3_BUILD_FENCE()
+    }
+    if (!(dbg & 8)) __builtin_amdgcn_s_barrier();
+    // ---- second half: Y multiplies step g, X prepares
+    if (grp == 1) {
+      if (!(dbg & 2)) multiply(acur);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
+      if (!(dbg & 32)) {
+      rotate_b();                                      // X multiplies step g + 1 in the next first half
+      load_b(g + 2);
+      }
+      SE3_BUILD_HALF()
+      SE3_BUILD_FENCE()
+    }
+    if (!(dbg & 8)) __builtin_amdgcn_s_barrier();
+    if (++ks == kKS) { ks = 0; cc++; }
+  }
+#undef SE3_BUILD_HALF
+#undef SE3_BUILD_FENCE
+#pragma unroll
+  for (int r = 0; r < kA; r++)
+#pragma unroll
+    for (int n = 0; n < NTW; n++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int64_t p = p0 + (lane >> 4) * 4 + i;
+        if (p < P) out[(p * kA + r) * Cout + (nt0 + n) * 16 + (lane & 15)] = acc[r][n][i];
+      }
+}
+
 }  // namespace
+
+extern "C" size_t se3_kpconv_points_floats(int64_t num_queries, int in_channels) {
+  if (num_queries < 0 || in_channels <= 0 || in_channels % kCC) return 0;
+  return (size_t)(in_channels / kCC) * (size_t)(se3_cdiv(num_queries, kTP) * kTP) * kRowPad + 64;      // + one partial DMA piece
+}
 
 extern "C" size_t se3_kpconv_weight_fragments_bytes(int in_channels, int out_channels) {
   if (in_channels <= 0 || out_channels <= 0 || in_channels % kCC || out_channels % 16) return 0;
@@ -250,33 +508,35 @@ extern "C" int se3_kpconv_so3_contract(const float* F, const void* weight_fragme
   const int64_t tiles = se3_cdiv(num_queries, kTP), P16 = tiles * kTP;
   // column tiles per wave / per workgroup: a workgroup covers up to 16 column tiles (4 waves x 4); wide layers with few row tiles are
   // split over the columns as well so that the grid fills the chip (the G fragments are then built once per column split)
-  int per_block;
-  if (NT <= 4) {
-    per_block = NT;                                            // one column tile per wave, NT active waves
-  } else {
-    SE3_REQUIRE(NT % 8 == 0, SE3_ERR_UNSUPPORTED, "kpconv_so3_contract: %d output channels (need <= 64 or a multiple of 128)",
-                out_channels);
-    per_block = NT % 16 == 0 ? 16 : 8;
-    while (per_block > 4 && tiles * (NT / per_block) < 3 * 256) per_block /= 2;
-  }
-  const int ntw = per_block >= 16 ? 4 : (per_block >= 8 ? 2 : 1);
-  const dim3 grid((unsigned)tiles, (unsigned)(NT / per_block));
-  const size_t lds = (size_t)kFTileFloats * 4 + (size_t)kA * 3 * 64 * 16 + (size_t)kKS * kA * 4 * sizeof(SlotEntry);
   const uint4* Wf = static_cast<const uint4*>(weight_fragments);
   hipStream_t st = (hipStream_t)stream;
   static bool lds_attr_set = false;      // > 64 KB of dynamic LDS needs the opt-in once per kernel
+  const size_t lds_small = (size_t)kFTileFloats * 4 + (size_t)kA * 3 * 64 * 16 + (size_t)kKS * kA * 4 * sizeof(SlotEntry);
+  const size_t lds_wide = (size_t)(2 * kTileLds) * 4 + (size_t)2 * kA * 3 * 64 * 16 + (size_t)kKS * kA * 4 * sizeof(SlotEntry);
   if (!lds_attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kpconv_contract_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kpconv_contract_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kpconv_contract_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kpconv_contract_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kpconv_contract_wide_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kpconv_contract_wide_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide);
     lds_attr_set = true;
   }
-  if (ntw == 4)
-    kpconv_contract_kernel<4><<<grid, 256, lds, st>>>(F, Wf, num_queries, P16, in_channels, out_channels, per_block, out);
-  else if (ntw == 2)
-    kpconv_contract_kernel<2><<<grid, 256, lds, st>>>(F, Wf, num_queries, P16, in_channels, out_channels, per_block, out);
-  else
-    kpconv_contract_kernel<1><<<grid, 256, lds, st>>>(F, Wf, num_queries, P16, in_channels, out_channels, per_block, out);
+  if (NT <= 4) {
+    // narrow layers: 4 waves, one column tile per wave
+    const dim3 grid((unsigned)tiles, 1u);
+    kpconv_contract_kernel<1><<<grid, 256, lds_small, st>>>(F, Wf, num_queries, P16, in_channels, out_channels, NT, out);
+  } else {
+    SE3_REQUIRE(NT % 8 == 0, SE3_ERR_UNSUPPORTED, "kpconv_so3_contract: %d output channels (need <= 64 or a multiple of 128)",
+                out_channels);
+    // 8 waves x NTW column tiles per workgroup; layers with few row tiles use the narrower workgroup so that the grid fills the chip
+    static const char* force = getenv("SE3_KPCONV_NTW");
+    static const char* dbgs = getenv("SE3_KPCONV_DBG");
+    const int dbg = dbgs ? atoi(dbgs) : 0;
+    const bool two = NT % 16 == 0 && (force ? force[0] == '2' : tiles >= 2 * 256);
+    const dim3 grid((unsigned)tiles, (unsigned)(NT / (two ? 16 : 8)));
+    if (two)
+      kpconv_contract_wide_kernel<2><<<grid, 512, lds_wide, st>>>(F, Wf, num_queries, P16, in_channels, out_channels, out, dbg);
+    else
+      kpconv_contract_wide_kernel<1><<<grid, 512, lds_wide, st>>>(F, Wf, num_queries, P16, in_channels, out_channels, out, dbg);
+  }
   SE3_CHECK_LAUNCH("kpconv_so3_contract");
   return SE3_OK;
 }

@@ -19,6 +19,7 @@
 namespace {
 
 constexpr int kK = 15, kA = 6, kS = 6, kMaxNN = 64;
+constexpr int kFRow = 732;            // floats per (point, 8-channel chunk) row of the F layout (csrc/kpconv_contract.hip: kRowPad)
 
 struct ConvTables {
   float kp[kK][3];
@@ -97,8 +98,8 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
         for (int k = 0; k < kK; k++) f[k] = fmaf(w[n0 + u][k], xv[u], f[k]);
       }
     }
-    if (FOUT) {
-      float* Fp = G + (((int64_t)(c >> 3) * P16 + p) * (kK * kA) + a) * 8 + (c & 7);
+    if (FOUT) {      // row of (point, channel chunk): 15 x 6 x 8 values, an 8-float zero slot, 4 pad = kFRow floats
+      float* Fp = G + ((int64_t)(c >> 3) * P16 + p) * kFRow + a * 8 + (c & 7);
 #pragma unroll
       for (int k = 0; k < kK; k++) Fp[k * kA * 8] = f[k];
       continue;
@@ -121,6 +122,12 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
       }
 #pragma unroll
       for (int sl = 0; sl < kS; sl++) __builtin_nontemporal_store(s[sl], &Gp[((int64_t)(r * kS + sl) * kA + t) * Cin + c]);
+    }
+  }
+  if (FOUT) {        // zero slot + pad of every row of this point
+    for (int e = threadIdx.x; e < (Cin >> 3) * (kFRow - kK * kA * 8); e += blockDim.x) {
+      const int cc = e / (kFRow - kK * kA * 8), w = e - cc * (kFRow - kK * kA * 8);
+      G[((int64_t)cc * P16 + p) * kFRow + kK * kA * 8 + w] = 0.f;
     }
   }
 }
@@ -169,7 +176,7 @@ extern "C" int se3_kpconv_so3_gather(const float* q_pts, const float* s_pts, con
   return SE3_OK;
 }
 
-// Same gather, output F (ceil16(P) rows, layout [Cin / 8][ceil16(P)][15 * 6][8]) for se3_kpconv_so3_contract.
+// Same gather, output F for se3_kpconv_so3_contract: layout [Cin / 8][ceil16(P)][732] (732 = 15 * 6 * 8 values + 8 zeros + 4 pad).
 extern "C" int se3_kpconv_so3_gather_points(const float* q_pts, const float* s_pts, const int64_t* idx, const float* x,
                                             const float* kernel_points_host, float sigma, int64_t num_queries, int64_t num_support,
                                             int num_neighbors, int in_channels, float* F, void* stream) {

@@ -2,6 +2,7 @@
 (device / dtype / contiguity -> RuntimeError), allocates outputs with torch (device memory stays owned by
 PyTorch) and launches the HIP kernels on the current torch stream."""
 import ctypes
+import os
 import threading
 import weakref
 
@@ -318,7 +319,20 @@ def _host_table(t, dtype):
     return hit[0]
 
 
-KPCONV_MATRIX_CORE = True        # False: round-1 path (slot sums G in HBM + library GEMM), kept for narrow layers and for A/B timing
+# KPConv contraction path: True = always the matrix-core kernels (csrc/kpconv_contract.hip) where the channel counts allow, False = always
+# the round-1 path (slot sums G in HBM + library f32 GEMM), 'auto' = per layer shape, whichever measured faster on MI355X at the bench
+# shape (tools/micro/kpconv_paths.py, profiles/r02_kpconv_paths.txt): today the 64 -> 64 layers (1.43 ms against 1.61 ms per call at 8 pairs).
+# Both paths agree to f32 round-off (tests/test_gpu_ops.py::test_kpconv_matrix_core_path_has_f32_accuracy).
+KPCONV_MATRIX_CORE = os.environ.get('SE3_KPCONV_PATH', 'auto')
+KPCONV_MATRIX_CORE = {'mfma': True, 'gemm': False}.get(KPCONV_MATRIX_CORE, 'auto')
+
+
+def _kpconv_use_matrix_core(Cin, Cout):
+    if KPCONV_MATRIX_CORE == 'auto':
+        return Cin == 64 and Cout == 64
+    return bool(KPCONV_MATRIX_CORE)
+
+
 _BUILTIN_KIDX = [[0, 1, 1, 1, 1, 2], [1, 0, 1, 2, 1, 1], [1, 1, 0, 1, 2, 1], [1, 2, 1, 0, 1, 1], [1, 1, 2, 1, 0, 1], [2, 1, 1, 1, 1, 0],
                  [3, 3, 3, 4, 4, 4], [3, 4, 3, 3, 4, 4], [3, 4, 4, 3, 3, 4], [3, 3, 4, 4, 3, 4], [4, 3, 3, 4, 4, 3], [4, 4, 3, 3, 4, 3],
                  [4, 4, 4, 3, 3, 3], [4, 3, 4, 4, 3, 3], [5, 5, 5, 5, 5, 5]]
@@ -351,11 +365,10 @@ def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, s
         raise RuntimeError('kpconv_inter_so3: inconsistent shapes')
     kp, kt, rt = _host_table(kernel_points, torch.float32), _host_table(kidx, torch.int64), _host_table(ridx, torch.int64)
     nt = Cout // 16
-    if KPCONV_MATRIX_CORE and Cin % 8 == 0 and Cout % 16 == 0 and (nt <= 4 or nt % 8 == 0) and _builtin_slot_tables(kt, rt):
+    if _kpconv_use_matrix_core(Cin, Cout) and Cin % 8 == 0 and Cout % 16 == 0 and (nt <= 4 or nt % 8 == 0) and _builtin_slot_tables(kt, rt):
         # matrix-core path: F (P16, 90, Cin) in tile order -> slot sums on the fly -> bf16x6 MFMA at f32 accuracy (csrc/kpconv_contract.hip)
         stream = _stream()
-        P16 = (P + 15) // 16 * 16
-        Fk = torch.empty((P16 * 90 * Cin,), dtype=torch.float32, device=x.device)
+        Fk = torch.empty((lib().se3_kpconv_points_floats(P, Cin),), dtype=torch.float32, device=x.device)
         check(lib().se3_kpconv_so3_gather_points(q_pts.data_ptr(), s_pts.data_ptr(), idx.data_ptr(), x.data_ptr(), kp.data_ptr(),
                                                  float(sigma), P, Ns, NN, Cin, Fk.data_ptr(), stream), 'se3_kpconv_so3_gather_points')
         w = _req(weights.detach().contiguous(), torch.float32, 'weights', 4)

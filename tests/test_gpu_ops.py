@@ -137,6 +137,7 @@ def _conv_state(Cin, Cout, radius, seed=0):
 def test_kpconv_matches_oracle(P, Ns, NN, Cin, Cout):
     from oracle import se3et_oracle as O
     from se3et_amd import functional as SF
+    from se3et_amd import ops
     g = torch.Generator().manual_seed(4)
     radius, sigma = 0.0625, 0.05
     s_pts = torch.rand(Ns, 3, generator=g) * 0.3
@@ -147,9 +148,15 @@ def test_kpconv_matches_oracle(P, Ns, NN, Cin, Cout):
     x = torch.randn(Ns, 6, Cin, generator=g)
     st = _conv_state(Cin, Cout, radius)
     want = O.kpconv_inter_so3({'c.' + k: v for k, v in st.items()}, 'c.', q_pts, s_pts, idx, x, sigma)
-    got = SF.kpconv_inter_so3(x.cuda(), q_pts.cuda(), s_pts.cuda(), idx.cuda(), st['kernel_points'].cuda(),
-                              st['weights'].cuda(), st['kidx_rot'][:, 0, :].cuda(), st['ridx_rot'][0].cuda(), sigma).cpu()
-    assert_close(got, want, 1e-4, 'kpconv')
+    saved = ops.KPCONV_MATRIX_CORE
+    try:
+        for path in (True, False):        # matrix-core kernels (where the channel counts allow) and the gather + library GEMM path
+            ops.KPCONV_MATRIX_CORE = path
+            got = SF.kpconv_inter_so3(x.cuda(), q_pts.cuda(), s_pts.cuda(), idx.cuda(), st['kernel_points'].cuda(),
+                                      st['weights'].cuda(), st['kidx_rot'][:, 0, :].cuda(), st['ridx_rot'][0].cuda(), sigma).cpu()
+            assert_close(got, want, 1e-4, 'kpconv (matrix core %s)' % path)
+    finally:
+        ops.KPCONV_MATRIX_CORE = saved
 
 
 @pytest.mark.parametrize('P,Ns,NN,Cin,Cout', [(500, 500, 35, 32, 32), (2001, 2500, 36, 128, 128), (129, 200, 38, 256, 256)])
@@ -170,13 +177,14 @@ def test_kpconv_matrix_core_path_has_f32_accuracy(P, Ns, NN, Cin, Cout):
     st = _conv_state(Cin, Cout, radius)
     args = (x.cuda(), q_pts.cuda(), s_pts.cuda(), idx.cuda(), st['kernel_points'].cuda(), st['weights'].cuda(),
             st['kidx_rot'][:, 0, :].cuda(), st['ridx_rot'][0].cuda(), sigma)
-    assert ops.KPCONV_MATRIX_CORE
-    new = SF.kpconv_inter_so3(*args).cpu()
-    ops.KPCONV_MATRIX_CORE = False
+    saved = ops.KPCONV_MATRIX_CORE
     try:
+        ops.KPCONV_MATRIX_CORE = True
+        new = SF.kpconv_inter_so3(*args).cpu()
+        ops.KPCONV_MATRIX_CORE = False
         old = SF.kpconv_inter_so3(*args).cpu()
     finally:
-        ops.KPCONV_MATRIX_CORE = True
+        ops.KPCONV_MATRIX_CORE = saved
     assert_close(new, old, 1e-5, 'matrix-core path vs f32 path')
     # float64 evaluation of out = sum_{k,a,c} F[k,a,c] W[kidx[k,r], ridx[a,r], c, d]
     xs = torch.cat((x, torch.zeros(1, 6, Cin))).double()

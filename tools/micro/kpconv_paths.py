@@ -1,6 +1,6 @@
 """KPConv per stage at the bench shape (8 pairs per forward): round-1 path (slot sums G + library f32 GEMM) against the matrix-core
 path (F + bf16x6 contraction).  python tools/micro/kpconv_paths.py"""
-import sys; sys.path.insert(0, '.')
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from se3et_amd import ops, functional as SF, tables
 from se3et_amd.data import precompute_data_stack_mode
@@ -37,7 +37,7 @@ for qs, ss, tab, C in calls:
         ops.KPCONV_MATRIX_CORE = flag
         res[name] = timeit(lambda: SF.kpconv_inter_so3(x, q, s, idx, kp, w, kidx, ridx, sig))
         tot[name] += res[name]
-    ops.KPCONV_MATRIX_CORE = True
+    ops.KPCONV_MATRIX_CORE = 'auto'
     gf = 2.0 * 6 * q.shape[0] * 36 * C * C / 1e9
     print('P %6d NN %2d C %3d  old %.3f ms  new %.3f ms  (%.0f GF: new = %.0f TF/s f32-equivalent)' % (q.shape[0], idx.shape[1], C, res['old'], res['new'], gf, gf / res['new']))
 print('total old %.2f ms  new %.2f ms per 8 pairs' % (tot['old'], tot['new']))
