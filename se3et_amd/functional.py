@@ -12,6 +12,7 @@ import threading
 import torch
 import torch.nn.functional as F
 
+from . import autograd as AG
 from . import ops as _ops
 
 HIP_OPS = set()          # filled below as kernels are bound; tests assert the hot ops are in here
@@ -31,6 +32,9 @@ to_device = _ops.to_device
 
 def linear(x, weight, bias=None, relu=False):
     """Library GEMM x W^T [+ b]; with relu=True the activation rides in the GEMM epilogue (one launch)."""
+    if AG.needs_grad(x, weight, bias):                      # training: the same library GEMM through torch's own autograd
+        y = F.linear(x, weight, bias)
+        return F.relu(y) if relu else y
     if bias is None and not relu:
         if x.dim() == 2:
             return mm(x, weight.t())
@@ -44,6 +48,8 @@ def linear(x, weight, bias=None, relu=False):
 
 def project_qk(x, w_q, b_q, w_k, b_k):
     """q and k projections of the same tensor as ONE library GEMM with stacked weights -> (q, k)."""
+    if AG.needs_grad(x, w_q, b_q, w_k, b_k):
+        return F.linear(x, w_q, b_q), F.linear(x, w_k, b_k)
     qk = F.linear(x, torch.cat((w_q, w_k), 0), torch.cat((b_q, b_k), 0))
     C = w_q.shape[0]
     return qk[..., :C].contiguous(), qk[..., C:].contiguous()
@@ -64,21 +70,30 @@ def project_values_transposed(x, w_v, b_v):
 
 def add_layer_norm(hidden, residual, weight, bias, eps=1e-5, hidden_bias=None):
     """LayerNorm(hidden [+ hidden_bias] + residual) over the last dim (residual may broadcast over a leading anchor dim)."""
+    if AG.needs_grad(hidden, residual, weight, bias, hidden_bias):
+        return AG.differentiable(lambda h, r, w, b, hb: _ops.add_layer_norm(h, r.contiguous() if r.shape == h.shape else r.reshape(r.shape[-2:]), w, b, eps, hb),
+                                 lambda h, r, w, b, hb: AG.add_layer_norm(h, r, w, b, hb, eps), 1, hidden, residual, weight, bias, hidden_bias)
     return _ops.add_layer_norm(hidden, residual, weight, bias, eps, hidden_bias)
 
 
 def anchor_max(x, dim=1):
     """Maximum over the anchor axis (6 anchors: one HIP launch; anything else: torch)."""
+    if AG.needs_grad(x):
+        return x.amax(dim)
     return _ops.anchor_max(x, dim) if x.dim() == 3 else x.amax(dim)
 
 
 def gather_rows_padded(x, idx):
     """x[idx] where idx == x.shape[0] addresses an implicit all-zero row."""
+    if AG.needs_grad(x):
+        return AG.differentiable(_ops.gather_rows_padded, AG.gather_rows_padded, 1, x, idx)
     return _ops.gather_rows_padded(x, idx)
 
 
 def neighbor_max_pool(x, idx):
     """max over the neighbour rows of x (P_s, ...) for each query (idx (P_q, NN), padding row = zeros)."""
+    if AG.needs_grad(x):
+        return AG.differentiable(_ops.neighbor_max_pool, AG.neighbor_max_pool, 1, x, idx)
     return _ops.neighbor_max_pool(x, idx)
 
 
@@ -118,10 +133,18 @@ def group_norm_rows(x, weight, bias, groups, eps, leaky_slope=None, residual=Non
             if offs is not None and len(offs) > 2:
                 mult = x.numel() // x.shape[-1] // x.shape[0]
                 segments = [o * mult for o in offs]
+    if AG.needs_grad(x, weight, bias, residual, x_bias):
+        return AG.differentiable(lambda x_, w, b, r, xb: _ops.group_norm_rows(x_, w, b, groups, eps, leaky_slope, r, xb, segments),
+                                 lambda x_, w, b, r, xb: AG.group_norm_rows(x_, w, b, r, xb, groups, eps, leaky_slope, segments),
+                                 1, x, weight, bias, residual, x_bias)
     return _ops.group_norm_rows(x, weight, bias, groups, eps, leaky_slope, residual, x_bias, segments)
 
 
 def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, sigma):
+    if AG.needs_grad(x, weights):
+        return AG.differentiable(lambda x_, w: _ops.kpconv_inter_so3(x_, q_pts, s_pts, idx, kernel_points, w, kidx, ridx, sigma),
+                                 lambda x_, w: AG.kpconv_inter_so3(x_, q_pts, s_pts, idx, kernel_points.detach(), w, kidx, ridx, sigma),
+                                 1, x, weights)
     return _ops.kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, sigma)
 
 
@@ -136,6 +159,18 @@ def sinusoidal_embedding(idx, div_term):
 def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, k, wigner_d1=None, dtype=torch.float32, knn=None):
     """E (N, N, C) [and the equivariant embedding (A, N, N, 4) when the Wigner-D^1 table is given] in one kernel; dtype
     torch.bfloat16 stores E rounded to bf16 ('bf16 attention', BASELINE.json configs[2])."""
+    if AG.needs_grad(w_d, b_d, w_a, b_a):
+        if dtype != torch.float32:
+            raise RuntimeError('geometric_embedding: training runs in float32')
+        if knn is None:
+            knn = _ops.knn3_stack(points.contiguous(), [points.shape[0]])
+        hip = lambda wd, bd, wa, ba: _ops.geometric_embedding(points, div_term, wd, bd, wa, ba, sigma_d, sigma_a, k, wigner_d1, dtype, knn)
+        ref = lambda wd, bd, wa, ba: AG.geometric_embedding(points, div_term, wd, bd, wa, ba, knn, sigma_d, sigma_a)
+        if wigner_d1 is None:
+            return AG.differentiable(hip, ref, 1, w_d, b_d, w_a, b_a)
+        # the equivariant embedding has no learned inputs: second output of the kernel, constant for autograd
+        emb, eq = AG.differentiable(hip, lambda *a: (ref(*a), points.new_zeros(1)), 2, w_d, b_d, w_a, b_a)
+        return emb, eq.detach()
     return _ops.geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, k, wigner_d1, dtype, knn)
 
 
@@ -147,6 +182,11 @@ def rpe_attention(q, k, vt, emb, w_p, eq_emb, w_eq, num_heads, return_scores=Fal
     (A, N, M, 4) or None.  softmax_m((q.k + q.(W_p emb) + q.(W_eq eq_emb)) / sqrt(d)) v with the position terms folded onto
     the query side (q.(W e + b) = (W^T q).e + q.b; the q.b term is constant along m and cancels in the softmax).
     Convenience form (the layers use `rpe_self_attention_packed`, which gets q, k and the folded queries from ONE GEMM)."""
+    if AG.needs_grad(q, k, vt, emb, w_p, w_eq):
+        hidden = AG.differentiable(lambda q_, k_, v_, e_, wp, ee, we: rpe_attention(q_, k_, v_, e_, wp, ee, we, num_heads)[0],
+                                   lambda q_, k_, v_, e_, wp, ee, we: AG.rpe_attention(q_, k_, v_, e_, wp, ee, we, num_heads),
+                                   1, q, k, vt, emb, w_p, eq_emb, w_eq)
+        return hidden, None
     anchored = q.dim() == 3
     q3 = q if anchored else q.unsqueeze(0)
     A, N, C = q3.shape
@@ -219,6 +259,9 @@ def rpe_self_attention_packed(x, starts, lengths, embs, eq_embs, w_stack, b_stac
 
 def cross_attention(q, k, vt, num_heads):
     """q (N, C), k (M, C), vt (C, Mp) or (A, C, Mp) -> (N, C) or (A, N, C)."""
+    if AG.needs_grad(q, k, vt):
+        return AG.differentiable(lambda q_, k_, v_: _ops.cross_attention(q_, k_, v_, num_heads),
+                                 lambda q_, k_, v_: AG.cross_attention(q_, k_, v_, num_heads), 1, q, k, vt)
     return _ops.cross_attention(q, k, vt, num_heads)
 
 
@@ -226,6 +269,9 @@ def cross_attention_eq(q, k, vt, num_heads, mode, trace_idx):
     """q (A, N, C), k (A, M, C), vt (A, C, Mp).  Returns (hidden (A, N, C), weights, mix): weights = g/sum_e g (A, A) for
     'a_soft', w (R,) for 'r_soft'; mix (A, A) = the anchor-pair weights actually applied (for r_soft the 24 rotation weights
     collapsed onto anchor pairs, mix[a, e] = sum_{r: trace[r, a] = e} w[r])."""
+    if AG.needs_grad(q, k, vt):
+        return AG.differentiable(lambda q_, k_, v_, t_: _ops.cross_attention_eq(q_, k_, v_, num_heads, mode, t_),
+                                 lambda q_, k_, v_, t_: AG.cross_attention_eq(q_, k_, v_, t_, num_heads, mode), 3, q, k, vt, trace_idx)
     return _ops.cross_attention_eq(q, k, vt, num_heads, mode, trace_idx)
 
 
@@ -242,6 +288,10 @@ def superpoint_scores(ref_feats, src_feats, dual_normalization=True):
 
 
 def log_optimal_transport(scores, row_masks, col_masks, alpha, num_iterations, inf):
+    if AG.needs_grad(scores, alpha):
+        return AG.differentiable(lambda s_, a_, rm, cm: _ops.log_optimal_transport(s_, rm, cm, a_, num_iterations, inf),
+                                 lambda s_, a_, rm, cm: AG.log_optimal_transport(s_, a_, rm, cm, num_iterations, inf),
+                                 1, scores, alpha, row_masks, col_masks)
     return _ops.log_optimal_transport(scores, row_masks, col_masks, alpha, num_iterations, inf)
 
 

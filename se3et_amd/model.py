@@ -59,6 +59,12 @@ def make_cfg(variant='se3ete', attention_dtype='float32'):
     cfg.fine_matching = ns(topk=2 if kitti else 3, acceptance_radius=0.6 if kitti else 0.1, mutual=True,
                            confidence_threshold=0.05, use_dustbin=False, use_global_score=False,
                            correspondence_threshold=3, correspondence_limit=None, num_refinement_steps=5)
+    # training (experiments/<variant>/config.py: coarse_loss, fine_loss, loss, optim)
+    cfg.coarse_loss = ns(positive_margin=0.1, negative_margin=1.4, positive_optimal=0.1, negative_optimal=1.4, log_scale=40 if kitti else 24,
+                         positive_overlap=0.1)
+    cfg.fine_loss = ns(positive_radius=0.6 if kitti else 0.05)
+    cfg.loss = ns(weight_coarse_loss=1.0, weight_fine_loss=1.0)
+    cfg.optim = ns(lr=1e-4, lr_decay=0.95, lr_decay_steps=4 if kitti else 1, weight_decay=1e-6, max_epoch=160 if kitti else 40, grad_acc_steps=1)
     cfg.neighbor_limits = [38, 36, 36, 38, 38][:stages]
     return cfg
 
@@ -148,9 +154,19 @@ class SE3ET(nn.Module):
             self.permutation_invariant = pi
         self._tls = threading.local()       # per-thread pinned scratch (pairs may be processed by several host threads)
         self.stage_hook = None              # optional callable invoked between backbone and transformer (pipelined drivers)
+        self.emit_ground_truth = False      # inference: also emit gt_node_corr_indices / _overlaps when data_dict has 'transform'
 
-    @torch.no_grad()
-    def forward(self, data_dict, with_registration=True):
+    def forward(self, data_dict, with_registration=True, train=False, targets=None, rng=None):
+        """`train=False`: INFERENCE forward (no autograd), below.  `train=True`: the training forward of the reference
+        (experiments/se3ete.3dmatch/model.py:110-131,172-178) with autograd through the HIP ops (se3et_amd.autograd): ground-truth
+        superpoint correspondences from data_dict['transform'], fine matching on (at most 128 randomly selected) ground-truth
+        patch pairs -- `targets` = (ref_indices, src_indices) overrides the random selection, `rng` seeds it."""
+        if train:
+            return self._forward(data_dict, with_registration, True, targets, rng)
+        with torch.no_grad():
+            return self._forward(data_dict, with_registration, False, None, None)
+
+    def _forward(self, data_dict, with_registration, train, targets, rng):
         """INFERENCE forward of one pair (runs under torch.no_grad: the kernels have no autograd; the training step lives in
         se3et_amd.training).  data_dict: output of se3et_amd.data (GPU tensors, host lengths).  Output keys are the reference's
         (experiments/se3ete.3dmatch/model.py:79-227) except the ground-truth keys gt_node_corr_indices / gt_node_corr_overlaps,
@@ -168,6 +184,12 @@ class SE3ET(nn.Module):
         _, src_nm, src_knn, src_km = point_to_node_partition(src_f, src_c, self.num_points_in_patch)
         ref_knn_pts = SF.gather_rows_padded(ref_f, ref_knn)
         src_knn_pts = SF.gather_rows_padded(src_f, src_knn)
+        if train or (self.emit_ground_truth and 'transform' in data_dict):
+            # ground-truth superpoint correspondences (the reference computes them in every forward; they need the transform)
+            from .training import node_correspondences
+            gi, go = node_correspondences(ref_c, src_c, ref_knn_pts, src_knn_pts, data_dict['transform'],
+                                          self.cfg.model.ground_truth_matching_radius, ref_nm, src_nm, ref_km, src_km)
+            out['gt_node_corr_indices'], out['gt_node_corr_overlaps'] = gi, go
         # number of non-empty nodes, fetched asynchronously (read only after the transformer, when it has long arrived)
         valid_host = getattr(self._tls, 'valid_host', None)
         if valid_host is None:
@@ -190,8 +212,17 @@ class SE3ET(nn.Module):
 
         valid_event.synchronize()
         all_valid = valid_host.tolist() == [ref_c.shape[0], src_c.shape[0]]
-        ri, si, node_scores = self.coarse_matching(r, s, ref_nm, src_nm, all_valid=all_valid)
+        ri, si, node_scores = self.coarse_matching(r.detach(), s.detach(), ref_nm, src_nm, all_valid=all_valid)
         out['ref_node_corr_indices'], out['src_node_corr_indices'], out['node_corr_scores'] = ri, si, node_scores
+        if train:          # fine matching on ground-truth patch pairs (model.py:172-178, superpoint_target.py)
+            from .training import select_targets
+            cm = self.cfg.coarse_matching
+            if targets is not None:
+                ri, si = targets[0].to(ri.device), targets[1].to(ri.device)
+                node_scores = torch.ones(ri.shape[0], device=ri.device)
+            else:
+                ri, si, node_scores = select_targets(out['gt_node_corr_indices'], out['gt_node_corr_overlaps'], cm.num_targets,
+                                                     cm.overlap_threshold, rng)
 
         ref_ck, src_ck = ref_knn[ri], src_knn[si]
         ref_cm, src_cm = ref_km[ri], src_km[si]
@@ -204,7 +235,8 @@ class SE3ET(nn.Module):
         scores = self.optimal_transport(scores, ref_cm, src_cm)
         out['matching_scores'] = scores
         if with_registration:
-            rc, sc, cs, T = self.fine_matching(ref_cp, src_cp, ref_cm, src_cm, scores[:, :-1, :-1], node_scores)
+            with torch.no_grad():
+                rc, sc, cs, T = self.fine_matching(ref_cp, src_cp, ref_cm, src_cm, scores.detach()[:, :-1, :-1], node_scores)
             out.update(ref_corr_points=rc, src_corr_points=sc, corr_scores=cs, estimated_transform=T)
         return out
 

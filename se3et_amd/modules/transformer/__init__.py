@@ -366,8 +366,13 @@ class RPEConditionalTransformer(nn.Module):
             if 'self' in block:
                 src0, src1 = (feats0_eq, feats1_eq) if feats0_eq is not None and feats1_eq is not None else (feats0, feats1)
                 eq = block == 'self_eq'
-                feats0, feats1 = layer.forward_pair(src0, src1, embeddings0, embeddings1, equiv_embed0 if eq else None,
-                                                    equiv_embed1 if eq else None)
+                if torch.is_grad_enabled() and (src0.requires_grad or src1.requires_grad):
+                    # training: one cloud per call through the ops that carry a backward (se3et_amd.autograd)
+                    feats0, _ = layer(src0, src0, embeddings0, equiv_states=equiv_embed0 if eq else None)
+                    feats1, _ = layer(src1, src1, embeddings1, equiv_states=equiv_embed1 if eq else None)
+                else:
+                    feats0, feats1 = layer.forward_pair(src0, src1, embeddings0, embeddings1, equiv_embed0 if eq else None,
+                                                        equiv_embed1 if eq else None)
                 if self.layer_tap is not None:
                     self.layer_tap(i, feats0)
                 if eq and nxt == 'cross':

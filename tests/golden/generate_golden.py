@@ -13,6 +13,9 @@ Fixtures
                            pyramid, per-op inputs/outputs captured with forward hooks, and model outputs
   synthw_<variant>.npz     real-width configs with name-keyed synthetic weights (se3et_amd.synthetic.synth_tensor):
                            state-dict names/shapes + outputs only (weights are regenerated from the names)
+  train_micro_se3ete.npz / train_micro_se3eti.npz
+                           training step of the micro models (configs[4] pieces): losses, ground-truth correspondences, gradient
+                           norms of all parameters, a few complete gradients, parameter checksum after one Adam step
   c2_se3ete_5k.npz         BASELINE.json configs[1] at FULL size: SE3ET-E on the 5k+5k pairs 0..7 (the pairs of one bench step),
                            synthetic weights; per-layer outputs and index-table checksums for pair 0
   c3_se3eti_kitti_20k.npz  BASELINE.json configs[2] at FULL size: SE3ET-I (KITTI configuration) on the 20k+20k pair
@@ -291,6 +294,63 @@ def gen_precompute_cap():
     np.savez_compressed(os.path.join(HERE, 'precompute_cap.npz'), **res)
 
 
+def gen_train(variant, fname, micro=True, pair='micro'):
+    """BASELINE.json configs[4] pieces through the genuine reference in TRAINING mode: forward with ground-truth superpoint
+    targets, OverallLoss (weighted circle loss + fine NLL), backward, one Adam step.  Stored: the loss values, the ground-truth
+    correspondences, the gradient norm of every parameter and a few complete gradients, the total norm, and a parameter checksum
+    after the optimizer step.  Micro config with the reference-initialised weights of micro_se3ete.npz (seed 0)."""
+    make_cfg, create_model = ref_shims.load_experiment(variant)
+    import loss as loss_mod                     # experiments/<variant>/loss.py
+    cfg = make_cfg()
+    if micro:
+        cfg.backbone.init_dim, cfg.backbone.output_dim, cfg.backbone.group_norm = 8, 32, 4
+        cfg.geotransformer.input_dim, cfg.geotransformer.hidden_dim, cfg.geotransformer.output_dim = 128, 32, 32
+    torch.manual_seed(0)
+    model = create_model(cfg).train()
+    loss_fn = loss_mod.OverallLoss(cfg)
+    ref, src, T = make_pair(pair)
+    dd = collate(ref, src, T, cfg.backbone.num_stages, cfg.backbone.init_voxel_size, cfg.backbone.init_radius,
+                 [38, 36, 36, 38, 38][:cfg.backbone.num_stages])
+    np.random.seed(0)
+    opt = torch.optim.Adam(model.parameters(), lr=cfg.optim.lr, weight_decay=cfg.optim.weight_decay)
+    target = {}
+    model.coarse_target.register_forward_hook(lambda m, a, o: target.update(ref=o[0], src=o[1], overlaps=o[2]))
+    out = model(dd)
+    losses = loss_fn(out, dd)
+    opt.zero_grad()
+    losses['loss'].backward()
+    res = {'ref': ref, 'src': src, 'transform': T, 'lr': np.float64(cfg.optim.lr), 'weight_decay': np.float64(cfg.optim.weight_decay)}
+    for k in ('loss', 'c_loss', 'f_loss'):
+        res['loss/' + k] = np.float64(losses[k].detach())
+    res['gt_node_corr_indices'] = _np(out['gt_node_corr_indices'])
+    res['target/ref'], res['target/src'], res['target/overlaps'] = _np(target['ref']), _np(target['src']), _np(target['overlaps'])
+    res['gt_node_corr_overlaps'] = _np(out['gt_node_corr_overlaps'])
+    res['ref_node_corr_knn_masks_sum'] = np.int64(out['ref_node_corr_knn_masks'].sum())
+    res['matching_scores_shape'] = np.array(out['matching_scores'].shape)
+    names, norms = [], []
+    total = 0.0
+    for n, p_ in model.named_parameters():
+        if p_.grad is None:
+            continue
+        names.append(n)
+        g = p_.grad.double()
+        norms.append(float(g.norm()))
+        total += float((g * g).sum())
+    res['grad/names'], res['grad/norms'], res['grad/total_norm'] = np.array(names), np.array(norms), np.float64(total ** 0.5)
+    for n in ('backbone.encoder1_1.interso3.conv.weights', 'backbone.encoder4_3.unary2.mlp.weight',
+              'transformer.embedding.proj_d.weight', 'transformer.transformer.layers.0.attention.attention.proj_eq.weight',
+              'transformer.transformer.layers.3.attention.attention.proj_q.weight', 'transformer.out_proj.weight',
+              'optimal_transport.alpha', 'transformer.transformer.rotcompress.expand.weight'):
+        if n in dict(model.named_parameters()) and dict(model.named_parameters())[n].grad is not None:
+            res['grad/full/' + n] = _np(dict(model.named_parameters())[n].grad)
+    opt.step()
+    res['after_step/param_sum'] = np.float64(sum(float(p_.detach().double().sum()) for p_ in model.parameters()))
+    res['after_step/out_proj_weight'] = _np(model.transformer.out_proj.weight)
+    print(fname, 'loss', float(losses['loss']), 'c', float(losses['c_loss']), 'f', float(losses['f_loss']), 'gt corr',
+          out['gt_node_corr_indices'].shape[0], 'total grad norm', total ** 0.5)
+    np.savez_compressed(os.path.join(HERE, fname), **res)
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['tables', 'precompute', 'micro', 'synthw']
     if 'tables' in which:
@@ -306,6 +366,9 @@ if __name__ == '__main__':
         gen_synthw('se3ete.3dmatch', 'synthw_se3ete.npz')
     if 'kitti' in which or 'synthw' in which:
         gen_synthw('se3eti.kitti', 'synthw_se3eti_kitti.npz', pair='c3_4k')
+    if 'train' in which:
+        gen_train('se3ete.3dmatch', 'train_micro_se3ete.npz')
+        gen_train('se3eti.3dmatch', 'train_micro_se3eti.npz')
     if 'cap' in which:
         gen_precompute_cap()
     if 'fullsize' in which:

@@ -1,0 +1,147 @@
+"""GPU: the training step (BASELINE.json configs[4] pieces) -- autograd through the HIP ops against the genuine reference's
+forward + OverallLoss + backward + Adam step on the micro models (tests/golden/train_micro_*.npz).  Tolerances: losses 1e-4
+relative, gradient norms 1e-3 relative."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(variant, fixture, golden_dir):
+    from se3et_amd.data import registration_collate_fn_stack_mode
+    from se3et_amd.model import create_model, make_cfg
+    g = np.load(golden_dir + '/' + fixture)
+    w = np.load(golden_dir + '/' + fixture.replace('train_', ''))                # reference-initialised weights (seed 0)
+    cfg = make_cfg(variant)
+    model = create_model(cfg)
+    model.load_state_dict({k[3:]: torch.from_numpy(w[k]) for k in w.files if k.startswith('sd/')}, strict=True)
+    model = model.cuda().train()
+    d = dict(ref_points=g['ref'], src_points=g['src'], ref_feats=np.ones((len(g['ref']), 1), np.float32),
+             src_feats=np.ones((len(g['src']), 1), np.float32), transform=g['transform'])
+    b = cfg.backbone
+    dd = registration_collate_fn_stack_mode([d], b.num_stages, b.init_voxel_size, b.init_radius, cfg.neighbor_limits)
+    return g, cfg, model, dd
+
+
+@pytest.mark.parametrize('variant,fixture', [('micro_e', 'train_micro_se3ete.npz'), ('micro_i', 'train_micro_se3eti.npz')])
+def test_training_step_matches_reference(golden_dir, variant, fixture):
+    from se3et_amd.training import OverallLoss, make_optimizer
+    g, cfg, model, dd = _setup(variant, fixture, golden_dir)
+    targets = (torch.from_numpy(g['target/ref']).long(), torch.from_numpy(g['target/src']).long())
+    out = model(dd, train=True, targets=targets)
+    # ground-truth superpoint correspondences: same pairs, same overlaps
+    want = {(int(a), int(b)): float(o) for (a, b), o in zip(g['gt_node_corr_indices'], g['gt_node_corr_overlaps'])}
+    got = {(int(a), int(b)): float(o) for (a, b), o in zip(out['gt_node_corr_indices'].tolist(), out['gt_node_corr_overlaps'].tolist())}
+    assert set(got) == set(want)
+    assert max(abs(got[k] - want[k]) for k in want) < 1e-6
+    assert tuple(out['matching_scores'].shape) == tuple(g['matching_scores_shape'])
+    losses = OverallLoss(cfg)(out, dd)
+    for k in ('loss', 'c_loss', 'f_loss'):
+        assert abs(float(losses[k]) - float(g['loss/' + k])) <= 1e-4 * abs(float(g['loss/' + k])), (k, float(losses[k]), float(g['loss/' + k]))
+    opt = make_optimizer(model, cfg)
+    opt.zero_grad()
+    losses['loss'].backward()
+    params = dict(model.named_parameters())
+    names, norms = [str(n) for n in g['grad/names']], g['grad/norms']
+    assert {n for n, p in params.items() if p.grad is not None} == set(names)
+    total = 0.0
+    big = float(norms.max())
+    for n, want_norm in zip(names, norms):
+        gn = float(params[n].grad.double().norm())
+        total += gn * gn
+        # 1e-3 relative for every parameter whose gradient matters, absolute floor for the tiny ones
+        assert abs(gn - want_norm) <= 1e-3 * want_norm + 1e-5 * big, (n, gn, float(want_norm))
+    assert abs(total ** 0.5 - float(g['grad/total_norm'])) <= 1e-3 * float(g['grad/total_norm'])
+    for key in g.files:
+        if key.startswith('grad/full/'):
+            assert_close(params[key[len('grad/full/'):]].grad.cpu(), g[key], 2e-3, key)
+    opt.step()
+    assert_close(model.transformer.out_proj.weight.detach().cpu(), g['after_step/out_proj_weight'], 1e-4, 'out_proj.weight after Adam')
+    psum = sum(float(p.detach().double().sum()) for p in model.parameters())
+    assert abs(psum - float(g['after_step/param_sum'])) <= 1e-4 * abs(float(g['after_step/param_sum'])) + 1e-2
+
+
+def test_restatements_match_the_kernels():
+    """Forward values of the PyTorch restatements used for backward (se3et_amd/autograd.py) against the kernels they stand in for."""
+    from se3et_amd import autograd as AG
+    from se3et_amd import functional as SF
+    from se3et_amd import ops, tables
+    g = torch.Generator().manual_seed(21)
+    dev = 'cuda'
+    rn = lambda *s: torch.randn(*s, generator=g).to(dev)
+    # KPConv
+    P, Ns, NN, Cin, Cout = 300, 400, 20, 16, 16
+    s_pts = (torch.rand(Ns, 3, generator=g) * 0.3).to(dev)
+    q_pts = s_pts[:P].contiguous()
+    d = ((q_pts[:, None] - s_pts[None]) ** 2).sum(-1)
+    idx = d.topk(NN, dim=1, largest=False)[1]
+    idx[d.gather(1, idx) > 0.0625 ** 2] = Ns
+    x, w = rn(Ns, 6, Cin), rn(6, 6, Cin, Cout) / (36 * Cin) ** 0.5
+    kp = torch.from_numpy(tables.kernel_points(0.0625)).to(dev)
+    kidx, ridx = torch.from_numpy(tables.kernel_slot_table()).to(dev), torch.from_numpy(tables.anchor_slot_table()).to(dev)
+    assert_close(AG.kpconv_inter_so3(x, q_pts, s_pts, idx, kp, w, kidx, ridx, 0.05), SF.kpconv_inter_so3(x, q_pts, s_pts, idx, kp, w, kidx, ridx, 0.05), 1e-5, 'kpconv')
+    # GroupNorm (+ bias, residual, LeakyReLU), max-pool, add + LayerNorm
+    y, gw, gb, res, xb = rn(P, 6, 32), rn(32), rn(32), rn(P, 6, 32), rn(32)
+    assert_close(AG.group_norm_rows(y, gw, gb, res, xb, 4, 1e-5, 0.1, None), SF.group_norm_rows(y, gw, gb, 4, 1e-5, 0.1, res, xb), 1e-5, 'group norm')
+    assert_close(AG.neighbor_max_pool(x, idx), SF.neighbor_max_pool(x, idx), 1e-6, 'max pool')
+    h, r = rn(6, 77, 32), rn(77, 32)
+    assert_close(AG.add_layer_norm(h, r, gw, gb, xb, 1e-5), SF.add_layer_norm(h, r, gw, gb, 1e-5, xb), 1e-5, 'add + layer norm')
+    # embeddings and attention
+    N, C, H = 61, 32, 4
+    pts = (torch.rand(N, 3, generator=g)).to(dev)
+    div = torch.exp(torch.arange(0, C, 2).float() * (-np.log(10000.0) / C)).to(dev)
+    wd, bd, wa, ba = rn(C, C) / C ** 0.5, rn(C) * 0.1, rn(C, C) / C ** 0.5, rn(C) * 0.1
+    w1 = torch.from_numpy(tables.wigner_tables()[1]).to(dev)
+    knn = ops.knn3_stack(pts, [N])
+    emb, eq = SF.geometric_embedding(pts, div, wd, bd, wa, ba, 0.2, 15.0, 3, wigner_d1=w1, knn=knn)
+    off = ~torch.eye(N, dtype=torch.bool, device=dev)
+    assert_close(AG.geometric_embedding(pts, div, wd, bd, wa, ba, knn, 0.2, 15.0)[off], emb[off], 1e-4, 'geometric embedding')
+    q, k, v, wp, we = rn(6, N, C), rn(6, N, C), rn(6, N, C), rn(C, C) / C ** 0.5, rn(C, 4) * 0.5
+    vt = SF.project_values_transposed(v, torch.eye(C, device=dev), torch.zeros(C, device=dev))
+    assert_close(AG.rpe_attention(q, k, vt, emb, wp, eq, we, H), SF.rpe_attention(q, k, vt, emb, wp, eq, we, H)[0], 1e-4, 'rpe attention (eq)')
+    assert_close(AG.rpe_attention(q[0], k[0], vt[0], emb, wp, None, None, H), SF.rpe_attention(q[0], k[0], vt[0], emb, wp, None, None, H)[0], 1e-4, 'rpe attention')
+    M = 53
+    k2, v2 = rn(6, M, C), rn(6, M, C)
+    vt2 = SF.project_values_transposed(v2, torch.eye(C, device=dev), torch.zeros(C, device=dev))
+    assert_close(AG.cross_attention(q[0], k2[0], vt2[0], H), SF.cross_attention(q[0], k2[0], vt2[0], H), 1e-4, 'cross attention')
+    assert_close(AG.cross_attention(q[0], k2[0], vt2, H), SF.cross_attention(q[0], k2[0], vt2, H), 1e-4, 'cross attention, anchor values')
+    trace = torch.from_numpy(tables.trace_indices()[0]).to(dev)
+    for mode in ('a_soft', 'r_soft'):
+        got, want = AG.cross_attention_eq(q, k2, vt2, trace, H, mode), SF.cross_attention_eq(q, k2, vt2, H, mode, trace)
+        for a, b_, name in zip(got, want, ('hidden', 'weights', 'mix')):
+            assert_close(a, b_, 1e-4, 'cross attention eq %s %s' % (mode, name))
+    # Sinkhorn
+    sc = rn(9, 20, 24)
+    rm, cm = torch.rand(9, 20, generator=g).to(dev) > 0.2, torch.rand(9, 24, generator=g).to(dev) > 0.2
+    al = torch.tensor(0.7, device=dev)
+    got, want = AG.log_optimal_transport(sc, al, rm, cm, 100, 1e12), SF.log_optimal_transport(sc, rm, cm, al, 100, 1e12)
+    valid = want > -1e11
+    assert torch.equal(got > -1e11, valid)
+    assert float((got[valid] - want[valid]).abs().max()) <= 1e-4 * float(want[valid].abs().max())
+
+
+def test_gradients_of_one_wrapped_op_against_finite_differences():
+    """The kernel-forward / restatement-backward wrapper on one op (KPConv): directional derivative by central differences of the
+    KERNEL forward against the autograd gradient (the two sides of `differentiable` describe the same function)."""
+    from se3et_amd import functional as SF
+    from se3et_amd import tables
+    g = torch.Generator().manual_seed(22)
+    P, NN, Cin, Cout = 120, 12, 8, 16
+    pts = (torch.rand(P, 3, generator=g) * 0.2).cuda()
+    idx = ((pts[:, None] - pts[None]) ** 2).sum(-1).topk(NN, dim=1, largest=False)[1]
+    x = torch.randn(P, 6, Cin, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(6, 6, Cin, Cout, generator=g) / (36 * Cin) ** 0.5).cuda().requires_grad_(True)
+    kp = torch.from_numpy(tables.kernel_points(0.0625)).cuda()
+    kidx, ridx = torch.from_numpy(tables.kernel_slot_table()).cuda(), torch.from_numpy(tables.anchor_slot_table()).cuda()
+    f = lambda x_, w_: SF.kpconv_inter_so3(x_, pts, pts, idx, kp, w_, kidx, ridx, 0.05)
+    c = torch.randn(P, 6, Cout, generator=g).cuda()
+    (f(x, w) * c).sum().backward()
+    dx, dw = torch.randn(x.shape, generator=g).cuda(), torch.randn(w.shape, generator=g).cuda()
+    eps = 1e-2
+    with torch.no_grad():
+        fd = ((f(x + eps * dx, w + eps * dw) - f(x - eps * dx, w - eps * dw)) * c).sum() / (2 * eps)
+    an = (x.grad * dx).sum() + (w.grad * dw).sum()
+    assert abs(float(fd) - float(an)) <= 2e-3 * abs(float(an)), (float(fd), float(an))
