@@ -40,7 +40,7 @@ PMC_TRAFFIC_RATIO = {'eq': 3149.4 / 2549.0, 'inv': 2307.7 / 2222.9}
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s is achievable
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, script=None):
     """Parent of a self-launched multi-GPU run: N children `python bench.py <argv>`, one rank each.  Never initialises a GPU."""
     import socket
     import subprocess
@@ -54,7 +54,7 @@ def launch_ranks(n, argv):
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port))
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC (RCCL across processes on this driver)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script or __file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
     codes = [procs[0].returncode]

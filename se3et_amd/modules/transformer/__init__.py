@@ -142,6 +142,13 @@ class RPEMultiHeadAttention(nn.Module):
                                           _one(embed_eq, 'embed_eq') if use_eq else None,
                                           self.proj_eq.weight if use_eq else None, self.num_heads,
                                           return_scores=self.return_scores)
+        if torch.is_grad_enabled() and hidden.requires_grad:
+            # the position-projection biases are constant along the softmax axis (no effect on the output): they stay in the graph with
+            # an exactly-zero gradient, as in the reference, so that the optimizer treats them the same way (weight decay)
+            zero = self.proj_p.bias.sum() * 0.0
+            if use_eq:
+                zero = zero + self.proj_eq.bias.sum() * 0.0
+            hidden = hidden + zero
         return hidden.unsqueeze(0), (scores.unsqueeze(0) if scores is not None else None)
 
 

@@ -1,0 +1,72 @@
+"""Training-step benchmark (BASELINE.json configs[4]): SE3ET-E forward + backward + Adam on synthetic 5k+5k pairs, one pair per rank
+and step, DistributedDataParallel over RCCL when --gpus > 1 (self-launching like bench.py).
+    python tools/train_bench.py --gpus 1 --steps 5 --warmup 2 [--pair c2_5k] [--variant se3ete]
+Prints one JSON line: seconds per step (MAX over ranks), pairs/s over all ranks, the loss of the last step."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--variant', default='se3ete')
+    ap.add_argument('--pair', default='c2_5k')
+    args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        import bench
+        raise SystemExit(bench.launch_ranks(args.gpus, sys.argv[1:], script=__file__))
+    from se3et_amd import sharding
+    from se3et_amd.data import registration_collate_fn_stack_mode
+    from se3et_amd.model import create_model, load_synthetic_weights, make_cfg
+    from se3et_amd.synthetic import make_pair
+    from se3et_amd.training import OverallLoss, distributed_model, make_optimizer, train_step
+    rank, world, local = sharding.init_distributed('nccl')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    cfg = make_cfg(args.variant)
+    model = load_synthetic_weights(create_model(cfg)).to(dev).train()
+    net = distributed_model(model, dev) if world > 1 else model
+    loss_fn, opt = OverallLoss(cfg), make_optimizer(net, cfg, world)
+    b = cfg.backbone
+    rng = np.random.RandomState(rank)
+    batches = []
+    for s in range(args.steps + args.warmup):
+        ref, src, T = make_pair(args.pair, index=s * world + rank)
+        d = dict(ref_points=ref, src_points=src, ref_feats=np.ones((len(ref), 1), np.float32), src_feats=np.ones((len(src), 1), np.float32),
+                 transform=T)
+        batches.append(d)
+    def step(i):
+        dd = registration_collate_fn_stack_mode([batches[i]], b.num_stages, b.init_voxel_size, b.init_radius, cfg.neighbor_limits, device=dev)
+        return train_step(net, dd, loss_fn, opt, rng=rng)[0]
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    sharding.barrier(dev)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        losses = step(i)
+    torch.cuda.synchronize()
+    sharding.barrier(dev)
+    dt = sharding.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        print(json.dumps({'metric': 'training step (fwd + bwd + Adam), %s on %s pairs' % (args.variant, args.pair), 's_per_step': round(dt / args.steps, 4),
+                          'pairs_per_s': round(world * args.steps / dt, 3), 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                          'loss': float(losses['loss'].detach()), 'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+                          'backward': 'PyTorch restatements on the GPU (se3et_amd/autograd.py)', 'data': 'synthetic'}), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
