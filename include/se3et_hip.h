@@ -347,6 +347,39 @@ int se3_mutual_topk_mask(const float* scores, const uint8_t* row_masks, const ui
                          int k, float threshold, uint8_t* mask, void* stream);
 
 
+
+/* ---- EPN toolkit (vgtk) equivalents: SURVEY section 8f row 4 -------------------------------------------------------------------------
+ * Replace the CUDA extensions vgtk.cuda.{gathering, grouping, zpconv} (geotransformer/modules/e2pn/vgtk/vgtk/cuda: gathering_cuda.cpp,
+ * grouping_cuda.cpp, zpconv_cuda.cpp and their *_kernel.cu) entry for entry: same tensor layouts (channel-first, int32 indices), same
+ * edge cases; float sums are gathers in a fixed order (the reference scatters with atomicAdd), errors come back as status codes, every
+ * launch takes a stream.  Called from se3et_amd/vgtk.py (mirror of vgtk/spconv/functional.py, vgtk/pc/sample.py).
+ *   gather_points: out[b, c, j] = points[b, c, idx[b, j]]; backward scatter-adds in ascending j           (gathering_cuda_kernel.cu:42-98)
+ *   ball_query: the first nsample support indices (ascending) within `radius` of each query, a short list repeats itself, a list short
+ *     by exactly one keeps a trailing 0, an empty one is all 0                                            (grouping_cuda_kernel.cu:52-99)
+ *   furthest_point_sampling: idxs[b, 0] = 0, then iteratively the point furthest from the chosen set; points with |p|^2 <= 1e-3 are
+ *     never chosen; exact ties resolve as in the reference's block reduction; temp_workspace (b, n) floats (grouping_cuda_kernel.cu:337-452)
+ *   inter_zpconv: out[b, c, k, p, a] = sum_n w[b, p, a, k, n] feats[b, c, nbr[b, p, a, k, n], a]; backward = its transpose
+ *     (workspace: se3_vgtk_inter_zpconv_bwd_workspace_bytes)                                               (zpconv_cuda_kernel.cu:32-116)
+ *   intra_zpconv: out[b, c, k, p, a] = sum_n w[a, k, n] feats[b, c, p, nbr[a, n]]; backward = its transpose (zpconv_cuda_kernel.cu:119-195) */
+int se3_vgtk_gather_points_fwd(const float* points, const int32_t* idx, int batch, int channels, int num_points, int num_indices,
+                               float* out, void* stream);
+int se3_vgtk_gather_points_bwd(const float* grad_out, const int32_t* idx, int batch, int channels, int num_points, int num_indices,
+                               float* grad_points, void* stream);
+int se3_vgtk_ball_query(const float* new_xyz, const float* xyz, int batch, int num_support, int num_queries, float radius, int nsample,
+                        int32_t* idx, void* stream);
+int se3_vgtk_furthest_point_sampling(const float* dataset, int batch, int num_points, int num_samples, float* temp_workspace,
+                                     int32_t* idxs, void* stream);
+int se3_vgtk_inter_zpconv_fwd(const int32_t* neighbors, const float* weights, const float* feats, int batch, int num_samples,
+                              int num_support, int num_anchors, int kernel_size, int num_nn, int channels, float* out, void* stream);
+size_t se3_vgtk_inter_zpconv_bwd_workspace_bytes(int batch, int num_samples, int num_support, int num_anchors, int kernel_size, int num_nn);
+int se3_vgtk_inter_zpconv_bwd(const int32_t* neighbors, const float* weights, const float* grad_out, int batch, int num_samples,
+                              int num_support, int num_anchors, int kernel_size, int num_nn, int channels, float* grad_feats,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int se3_vgtk_intra_zpconv_fwd(const int32_t* neighbors, const float* weights, const float* feats, int batch, int num_points,
+                              int anchors_in, int anchors_out, int kernel_size, int num_nn, int channels, float* out, void* stream);
+int se3_vgtk_intra_zpconv_bwd(const int32_t* neighbors, const float* weights, const float* grad_out, int batch, int num_points,
+                              int anchors_in, int anchors_out, int kernel_size, int num_nn, int channels, float* grad_feats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,15 @@ SIGNATURES = {
     'se3_count_inliers': (_i32, [_vp, _vp, _i64, _vp, _i32, _f32, _vp, _vp]),
     'se3_count_inliers_ranges': (_i32, [_vp, _vp, _i64, _vp, _i32, _vp, _vp, _f32, _vp, _vp]),
     'se3_weighted_procrustes_segments': (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _f32, _f32, _vp, _vp]),
+    'se3_vgtk_gather_points_fwd': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    'se3_vgtk_gather_points_bwd': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    'se3_vgtk_ball_query': (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
+    'se3_vgtk_furthest_point_sampling': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    'se3_vgtk_inter_zpconv_fwd': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    'se3_vgtk_inter_zpconv_bwd_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32, _i32, _i32]),
+    'se3_vgtk_inter_zpconv_bwd': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
+    'se3_vgtk_intra_zpconv_fwd': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    'se3_vgtk_intra_zpconv_bwd': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     'se3_log_sinkhorn_fwd': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
 }
 

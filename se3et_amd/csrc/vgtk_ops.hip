@@ -1,0 +1,381 @@
+// gfx950 equivalents of the EPN toolkit's CUDA extensions (geotransformer/modules/e2pn/vgtk/vgtk/cuda).
+// BASELINE.json names them as a replaced subsystem; no SE3ET model reaches them, so the bar here is semantics,
+// determinism and a clean C ABI, not peak bandwidth:
+//   gathering_cuda_kernel.cu:42-98     gather_points forward / backward           -> se3_vgtk_gather_points_fwd / _bwd
+//   grouping_cuda_kernel.cu:52-99      ball_query                                 -> se3_vgtk_ball_query
+//   grouping_cuda_kernel.cu:337-452    furthest_point_sampling                    -> se3_vgtk_furthest_point_sampling
+//   zpconv_cuda_kernel.cu:32-116       spherical_conv (inter) forward / backward  -> se3_vgtk_inter_zpconv_fwd / _bwd
+//   zpconv_cuda_kernel.cu:119-195      intraspherical_conv forward / backward     -> se3_vgtk_intra_zpconv_fwd / _bwd
+// Layouts, index types (int32) and edge-case behaviour follow the reference kernels; what differs is HOW: every sum is a gather in a
+// fixed order (the reference scatters with atomicAdd, so its float results depend on the execution order), launches take a stream, and
+// errors are returned instead of printed.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+// ---- gather_points ------------------------------------------------------------------------------------------------------------------
+__global__ void gather_points_fwd_kernel(const float* __restrict__ points, const int* __restrict__ idx, int c, int n, int m,
+                                         float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;        // (channel, index) of batch blockIdx.y, index fastest
+  const int b = blockIdx.y;
+  if (e >= (int64_t)c * m) return;
+  const int ci = (int)(e / m), j = (int)(e - (int64_t)ci * m);
+  out[((int64_t)b * c + ci) * m + j] = points[((int64_t)b * c + ci) * n + idx[(int64_t)b * m + j]];
+}
+
+// grad_points[b, c, i] = sum_{j: idx[b, j] = i} grad_out[b, c, j], summed in ascending j (one thread per (b, c) row walks the indices)
+__global__ void gather_points_bwd_kernel(const float* __restrict__ grad_out, const int* __restrict__ idx, int batch, int c, int n, int m,
+                                         float* __restrict__ grad_points) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;                   // b * c + ci
+  if (row >= batch * c) return;
+  const int b = row / c;
+  float* gp = grad_points + (int64_t)row * n;
+  for (int i = 0; i < n; i++) gp[i] = 0.f;
+  const float* go = grad_out + (int64_t)row * m;
+  const int* ib = idx + (int64_t)b * m;
+  for (int j = 0; j < m; j++) gp[ib[j]] += go[j];
+}
+
+// ---- ball_query: the first `nsample` support points (ascending index) with d^2 < r^2; short lists repeat cyclically ---------------------
+// One wave per query: 64 candidates per round, ballot + prefix count keep the index order.
+__global__ void ball_query_kernel(const float* __restrict__ new_xyz, const float* __restrict__ xyz, int n, int m, float radius2,
+                                  int nsample, int* __restrict__ idx) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (j >= m) return;
+  const float* q = new_xyz + (int64_t)b * 3 * m;
+  const float* s = xyz + (int64_t)b * 3 * n;
+  int* out = idx + ((int64_t)b * m + j) * nsample;
+  const float qx = q[j], qy = q[m + j], qz = q[2 * m + j];
+  int cnt = 0;
+  for (int k0 = 0; k0 < n && cnt < nsample; k0 += 64) {
+    const int k = k0 + lane;
+    bool hit = false;
+    if (k < n) {
+      const float dx = qx - s[k], dy = qy - s[n + k], dz = qz - s[2 * n + k];
+      hit = dx * dx + dy * dy + dz * dz < radius2;       // (dx^2 + dy^2) + dz^2, the reference's association
+    }
+    const unsigned long long mask = __ballot(hit);
+    const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+    if (hit && pos < nsample) out[pos] = k;
+    cnt += __popcll(mask);
+  }
+  cnt = min(cnt, nsample);
+  // grouping_cuda_kernel.cu:87-92: `if (cnt < nsample - 1)` repeat the found ones; a list that is short by exactly one keeps its last
+  // slot as allocated by the caller (zero), an empty list copies zeros onto itself
+  __builtin_amdgcn_wave_barrier();
+  if (cnt < nsample - 1 && lane == 0) {
+    if (cnt == 0) {
+      for (int k = 0; k < nsample; k++) out[k] = 0;
+    } else {
+      for (int k = 0; k + cnt < nsample; k++) out[k + cnt] = out[k];
+    }
+  } else if (cnt == nsample - 1 && lane == 0) {
+    out[nsample - 1] = 0;
+  }
+}
+
+// ---- furthest point sampling ----------------------------------------------------------------------------------------------------------
+// One workgroup per cloud.  The reference's result depends on its reduction shape on exact distance ties: thread t of `bs` threads
+// (bs = 2^floor(log2 n), at most 1024) scans k = t, t + bs, ... keeping the FIRST maximum, the tree keeps the lower thread on ties.
+// Equivalent selection key, used here with any workgroup size: (distance descending, k mod bs ascending, k ascending).
+struct FpsBest { float d; int t; int k; };
+__device__ __forceinline__ bool fps_better(const FpsBest& a, const FpsBest& b) {      // a strictly preferred over b
+  if (a.d != b.d) return a.d > b.d;
+  if (a.t != b.t) return a.t < b.t;
+  return a.k < b.k;
+}
+
+__global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ dataset, int n, int m, int bs, float* __restrict__ temp,
+                                                    int* __restrict__ idxs) {
+  __shared__ FpsBest red[16];
+  __shared__ int chosen;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* x = dataset + (int64_t)b * 3 * n;
+  float* tp = temp + (int64_t)b * n;
+  int* out = idxs + (int64_t)b * m;
+  for (int k = tid; k < n; k += blockDim.x) tp[k] = 1e10f;
+  int old = 0;
+  if (tid == 0) out[0] = 0;
+  __syncthreads();
+  for (int j = 1; j < m; j++) {
+    const float x1 = x[old], y1 = x[n + old], z1 = x[2 * n + old];
+    FpsBest best = {-1.f, 0, 0};            // the reference starts every thread at (best = -1, besti = 0)
+    best.t = 1 << 30;
+    for (int k = tid; k < n; k += blockDim.x) {
+      const float x2 = x[k], y2 = x[n + k], z2 = x[2 * n + k];
+      if (x2 * x2 + y2 * y2 + z2 * z2 <= 1e-3f) continue;
+      const float dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
+      const float d2 = fminf(dx * dx + dy * dy + dz * dz, tp[k]);
+      tp[k] = d2;
+      const FpsBest c = {d2, k % bs, k};
+      if (fps_better(c, best)) best = c;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      FpsBest c;
+      c.d = __shfl_xor(best.d, o); c.t = __shfl_xor(best.t, o); c.k = __shfl_xor(best.k, o);
+      if (fps_better(c, best)) best = c;
+    }
+    if (lane == 0) red[wave] = best;
+    __syncthreads();
+    if (tid == 0) {
+      FpsBest r = red[0];
+      for (int w = 1; w < (int)(blockDim.x >> 6); w++)
+        if (fps_better(red[w], r)) r = red[w];
+      chosen = r.d < 0.f ? 0 : r.k;          // nothing selectable (all points at the origin): index 0, as the reference
+      out[j] = chosen;
+    }
+    __syncthreads();
+    old = chosen;
+  }
+}
+
+// ---- inter (spherical) convolution grouping -----------------------------------------------------------------------------------------------
+// out[b, c, k, p, a] = sum_n w[b, p, a, k, n] feats[b, c, nbr[b, p, a, k, n], a]   (n ascending)
+__global__ void inter_zpconv_fwd_kernel(const int* __restrict__ nbr, const float* __restrict__ w, const float* __restrict__ feats,
+                                        int np, int nq, int na, int ks, int ann, int c_in, float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;        // ((p * na + a) * ks + k) of batch blockIdx.y
+  const int b = blockIdx.y;
+  if (e >= (int64_t)np * na * ks) return;
+  const int k = (int)(e % ks), a = (int)((e / ks) % na), p = (int)(e / ((int64_t)ks * na));
+  const int* nb = nbr + ((int64_t)b * np * na * ks + e) * ann;
+  const float* wb = w + ((int64_t)b * np * na * ks + e) * ann;
+  for (int ci = 0; ci < c_in; ci++) {
+    const float* f = feats + (((int64_t)b * c_in + ci) * nq) * na + a;
+    float acc = 0.f;
+    for (int ni = 0; ni < ann; ni++) acc += wb[ni] * f[(int64_t)nb[ni] * na];
+    out[((((int64_t)b * c_in + ci) * ks + k) * np + p) * na + a] = acc;
+  }
+}
+
+// Backward = the transposed sum grad_feats[b, c, q, a] = sum_{(p, k, n): nbr = q} w grad_out[b, c, k, p, a].  Deterministic without float
+// atomics: the entries are bucketed by their target (b, q, a) with INTEGER atomics (counts and slots: any order), every bucket is then
+// sorted by entry index and summed in that order.
+__global__ void inter_bucket_count_kernel(const int* __restrict__ nbr, int64_t entries_per_batch, int np, int nq, int na, int ks, int ann,
+                                          int* __restrict__ count) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (e >= entries_per_batch) return;
+  const int a = (int)((e / ((int64_t)ann * ks)) % na);
+  const int q = nbr[(int64_t)b * entries_per_batch + e];
+  if (q >= 0 && q < nq) atomicAdd(&count[((int64_t)b * nq + q) * na + a], 1);
+}
+
+__global__ void exclusive_scan_kernel(const int* __restrict__ count, int64_t total, int64_t* __restrict__ offsets) {
+  // single workgroup, chunked: offsets[i] = sum_{j < i} count[j], offsets[total] = grand total
+  __shared__ int64_t carry, part[1024];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < total; base += 1024) {
+    const int64_t i = base + threadIdx.x;
+    const int64_t v = i < total ? count[i] : 0;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int64_t t = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
+      __syncthreads();
+      part[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < total) offsets[i] = carry + part[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) offsets[total] = carry;
+}
+
+__global__ void inter_bucket_fill_kernel(const int* __restrict__ nbr, int64_t entries_per_batch, int nq, int na, int ks, int ann,
+                                         const int64_t* __restrict__ offsets, int* __restrict__ cursor, int* __restrict__ bucket) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (e >= entries_per_batch) return;
+  const int a = (int)((e / ((int64_t)ann * ks)) % na);
+  const int q = nbr[(int64_t)b * entries_per_batch + e];
+  if (q < 0 || q >= nq) return;
+  const int64_t t = ((int64_t)b * nq + q) * na + a;
+  bucket[offsets[t] + atomicAdd(&cursor[t], 1)] = (int)e;
+}
+
+__global__ void inter_zpconv_bwd_kernel(const float* __restrict__ w, const float* __restrict__ grad_out, int64_t entries_per_batch, int np,
+                                        int nq, int na, int ks, int ann, int c_in, const int64_t* __restrict__ offsets,
+                                        int* __restrict__ bucket, float* __restrict__ grad_feats) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;        // q * na + a of batch blockIdx.y
+  const int64_t targets = (int64_t)nq * na;
+  const int b = blockIdx.y;
+  if (t >= targets) return;
+  const int64_t tt = (int64_t)b * targets + t;
+  const int a = (int)(t % na);
+  const int64_t lo = offsets[tt], hi = offsets[tt + 1];
+  int* bk = bucket + lo;
+  const int cnt = (int)(hi - lo);
+  for (int i = 1; i < cnt; i++) {          // insertion sort by entry index: the summation order is the entry order
+    const int v = bk[i];
+    int j = i - 1;
+    while (j >= 0 && bk[j] > v) { bk[j + 1] = bk[j]; j--; }
+    bk[j + 1] = v;
+  }
+  for (int ci = 0; ci < c_in; ci++) {
+    float acc = 0.f;
+    for (int i = 0; i < cnt; i++) {
+      const int64_t e = bk[i];
+      const int k = (int)((e / ann) % ks), p = (int)(e / ((int64_t)ann * ks * na));
+      acc += w[(int64_t)b * entries_per_batch + e] * grad_out[((((int64_t)b * c_in + ci) * ks + k) * np + p) * na + a];
+    }
+    grad_feats[(((int64_t)b * c_in + ci) * nq + t / na) * na + a] = acc;
+  }
+}
+
+// ---- intra (anchor-axis) convolution grouping ---------------------------------------------------------------------------------------------
+// out[b, c, k, p, a] = sum_n w[a, k, n] feats[b, c, p, nbr[a, n]]
+__global__ void intra_zpconv_fwd_kernel(const int* __restrict__ nbr, const float* __restrict__ w, const float* __restrict__ feats, int np,
+                                        int na_in, int na_out, int ks, int ann, int c_in, float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;        // ((ci * ks + k) * np + p) * na_out + a
+  const int b = blockIdx.y;
+  if (e >= (int64_t)c_in * ks * np * na_out) return;
+  const int a = (int)(e % na_out), p = (int)((e / na_out) % np), k = (int)((e / ((int64_t)na_out * np)) % ks);
+  const int ci = (int)(e / ((int64_t)na_out * np * ks));
+  const float* f = feats + (((int64_t)b * c_in + ci) * np + p) * na_in;
+  float acc = 0.f;
+  for (int ni = 0; ni < ann; ni++) acc += w[((int64_t)a * ks + k) * ann + ni] * f[nbr[a * ann + ni]];
+  out[(int64_t)b * c_in * ks * np * na_out + e] = acc;
+}
+
+// grad_feats[b, c, p, qa] = sum_{(a, k, n): nbr[a, n] = qa} w[a, k, n] grad_out[b, c, k, p, a]   (a, k, n ascending)
+__global__ void intra_zpconv_bwd_kernel(const int* __restrict__ nbr, const float* __restrict__ w, const float* __restrict__ grad_out, int np,
+                                        int na_in, int na_out, int ks, int ann, int c_in, float* __restrict__ grad_feats) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;        // (ci * np + p) * na_in + qa
+  const int b = blockIdx.y;
+  if (e >= (int64_t)c_in * np * na_in) return;
+  const int qa = (int)(e % na_in), p = (int)((e / na_in) % np), ci = (int)(e / ((int64_t)na_in * np));
+  const float* g = grad_out + ((int64_t)b * c_in + ci) * ks * np * na_out;
+  float acc = 0.f;
+  for (int a = 0; a < na_out; a++)
+    for (int k = 0; k < ks; k++)
+      for (int ni = 0; ni < ann; ni++)
+        if (nbr[a * ann + ni] == qa) acc += w[((int64_t)a * ks + k) * ann + ni] * g[((int64_t)k * np + p) * na_out + a];
+  grad_feats[(int64_t)b * c_in * np * na_in + e] = acc;
+}
+
+}  // namespace
+
+extern "C" int se3_vgtk_gather_points_fwd(const float* points, const int32_t* idx, int batch, int channels, int num_points,
+                                          int num_indices, float* out, void* stream) {
+  SE3_REQUIRE(points && idx && out, SE3_ERR_INVALID_ARG, "vgtk_gather_points_fwd: null pointer");
+  SE3_REQUIRE(batch >= 1 && channels >= 1 && num_points >= 1 && num_indices >= 0, SE3_ERR_INVALID_ARG, "vgtk_gather_points_fwd: bad sizes");
+  if (num_indices == 0) return SE3_OK;
+  const dim3 grid((unsigned)se3_cdiv((int64_t)channels * num_indices, 256), (unsigned)batch);
+  gather_points_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(points, idx, channels, num_points, num_indices, out);
+  SE3_CHECK_LAUNCH("vgtk_gather_points_fwd");
+  return SE3_OK;
+}
+
+extern "C" int se3_vgtk_gather_points_bwd(const float* grad_out, const int32_t* idx, int batch, int channels, int num_points,
+                                          int num_indices, float* grad_points, void* stream) {
+  SE3_REQUIRE(grad_out && idx && grad_points, SE3_ERR_INVALID_ARG, "vgtk_gather_points_bwd: null pointer");
+  SE3_REQUIRE(batch >= 1 && channels >= 1 && num_points >= 1 && num_indices >= 0, SE3_ERR_INVALID_ARG, "vgtk_gather_points_bwd: bad sizes");
+  gather_points_bwd_kernel<<<(unsigned)se3_cdiv((int64_t)batch * channels, 64), 64, 0, (hipStream_t)stream>>>(
+      grad_out, idx, batch, channels, num_points, num_indices, grad_points);
+  SE3_CHECK_LAUNCH("vgtk_gather_points_bwd");
+  return SE3_OK;
+}
+
+extern "C" int se3_vgtk_ball_query(const float* new_xyz, const float* xyz, int batch, int num_support, int num_queries, float radius,
+                                   int nsample, int32_t* idx, void* stream) {
+  SE3_REQUIRE(new_xyz && xyz && idx, SE3_ERR_INVALID_ARG, "vgtk_ball_query: null pointer");
+  SE3_REQUIRE(batch >= 1 && num_support >= 1 && num_queries >= 1 && nsample >= 1, SE3_ERR_INVALID_ARG, "vgtk_ball_query: bad sizes");
+  const dim3 grid((unsigned)se3_cdiv(num_queries, 4), (unsigned)batch);
+  ball_query_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(new_xyz, xyz, num_support, num_queries, radius * radius, nsample, idx);
+  SE3_CHECK_LAUNCH("vgtk_ball_query");
+  return SE3_OK;
+}
+
+extern "C" int se3_vgtk_furthest_point_sampling(const float* dataset, int batch, int num_points, int num_samples, float* temp_workspace,
+                                                int32_t* idxs, void* stream) {
+  SE3_REQUIRE(dataset && temp_workspace && idxs, SE3_ERR_INVALID_ARG, "vgtk_furthest_point_sampling: null pointer");
+  SE3_REQUIRE(batch >= 1 && num_points >= 1 && num_samples >= 0, SE3_ERR_INVALID_ARG, "vgtk_furthest_point_sampling: bad sizes");
+  if (num_samples == 0) return SE3_OK;
+  // the reference's thread count (grouping_cuda_kernel.cu:14-18, evaluated in double exactly as there): it shapes the tie order
+  const int pow2 = (int)(log((double)num_points) / log(2.0));
+  int bs = 1 << pow2;
+  bs = bs > 1024 ? 1024 : (bs < 1 ? 1 : bs);
+  const int threads = bs < 64 ? 64 : bs;
+  fps_kernel<<<(unsigned)batch, threads, 0, (hipStream_t)stream>>>(dataset, num_points, num_samples, bs, temp_workspace, idxs);
+  SE3_CHECK_LAUNCH("vgtk_furthest_point_sampling");
+  return SE3_OK;
+}
+
+extern "C" int se3_vgtk_inter_zpconv_fwd(const int32_t* neighbors, const float* weights, const float* feats, int batch, int num_samples,
+                                         int num_support, int num_anchors, int kernel_size, int num_nn, int channels, float* out,
+                                         void* stream) {
+  SE3_REQUIRE(neighbors && weights && feats && out, SE3_ERR_INVALID_ARG, "vgtk_inter_zpconv_fwd: null pointer");
+  SE3_REQUIRE(batch >= 1 && num_samples >= 1 && num_support >= 1 && num_anchors >= 1 && kernel_size >= 1 && num_nn >= 1 && channels >= 1,
+              SE3_ERR_INVALID_ARG, "vgtk_inter_zpconv_fwd: bad sizes");
+  const dim3 grid((unsigned)se3_cdiv((int64_t)num_samples * num_anchors * kernel_size, 256), (unsigned)batch);
+  inter_zpconv_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(neighbors, weights, feats, num_samples, num_support, num_anchors,
+                                                                  kernel_size, num_nn, channels, out);
+  SE3_CHECK_LAUNCH("vgtk_inter_zpconv_fwd");
+  return SE3_OK;
+}
+
+extern "C" size_t se3_vgtk_inter_zpconv_bwd_workspace_bytes(int batch, int num_samples, int num_support, int num_anchors, int kernel_size,
+                                                            int num_nn) {
+  const size_t targets = (size_t)batch * num_support * num_anchors, entries = (size_t)batch * num_samples * num_anchors * kernel_size * num_nn;
+  return targets * 4 * 2 + (targets + 1) * 8 + entries * 4 + 64;
+}
+
+extern "C" int se3_vgtk_inter_zpconv_bwd(const int32_t* neighbors, const float* weights, const float* grad_out, int batch, int num_samples,
+                                         int num_support, int num_anchors, int kernel_size, int num_nn, int channels, float* grad_feats,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  SE3_REQUIRE(neighbors && weights && grad_out && grad_feats && workspace, SE3_ERR_INVALID_ARG, "vgtk_inter_zpconv_bwd: null pointer");
+  SE3_REQUIRE(workspace_bytes >= se3_vgtk_inter_zpconv_bwd_workspace_bytes(batch, num_samples, num_support, num_anchors, kernel_size, num_nn),
+              SE3_ERR_INVALID_ARG, "vgtk_inter_zpconv_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t targets = (int64_t)batch * num_support * num_anchors;
+  const int64_t per_batch = (int64_t)num_samples * num_anchors * kernel_size * num_nn;
+  int64_t* offsets = static_cast<int64_t*>(workspace);                                   // (targets + 1), 8-byte aligned first
+  int* count = reinterpret_cast<int*>(offsets + targets + 1);
+  int* cursor = count + targets;
+  int* bucket = cursor + targets;
+  if (hipMemsetAsync(count, 0, (size_t)targets * 8, st) != hipSuccess) {
+    se3_set_error("vgtk_inter_zpconv_bwd: memset failed");
+    return SE3_ERR_LAUNCH;
+  }
+  const dim3 ge((unsigned)se3_cdiv(per_batch, 256), (unsigned)batch);
+  inter_bucket_count_kernel<<<ge, 256, 0, st>>>(neighbors, per_batch, num_samples, num_support, num_anchors, kernel_size, num_nn, count);
+  exclusive_scan_kernel<<<1, 1024, 0, st>>>(count, targets, offsets);
+  inter_bucket_fill_kernel<<<ge, 256, 0, st>>>(neighbors, per_batch, num_support, num_anchors, kernel_size, num_nn, offsets, cursor, bucket);
+  const dim3 gt((unsigned)se3_cdiv((int64_t)num_support * num_anchors, 64), (unsigned)batch);
+  inter_zpconv_bwd_kernel<<<gt, 64, 0, st>>>(weights, grad_out, per_batch, num_samples, num_support, num_anchors, kernel_size, num_nn, channels,
+                                              offsets, bucket, grad_feats);
+  SE3_CHECK_LAUNCH("vgtk_inter_zpconv_bwd");
+  return SE3_OK;
+}
+
+extern "C" int se3_vgtk_intra_zpconv_fwd(const int32_t* neighbors, const float* weights, const float* feats, int batch, int num_points,
+                                         int anchors_in, int anchors_out, int kernel_size, int num_nn, int channels, float* out,
+                                         void* stream) {
+  SE3_REQUIRE(neighbors && weights && feats && out, SE3_ERR_INVALID_ARG, "vgtk_intra_zpconv_fwd: null pointer");
+  SE3_REQUIRE(batch >= 1 && num_points >= 1 && anchors_in >= 1 && anchors_out >= 1 && kernel_size >= 1 && num_nn >= 1 && channels >= 1,
+              SE3_ERR_INVALID_ARG, "vgtk_intra_zpconv_fwd: bad sizes");
+  const dim3 grid((unsigned)se3_cdiv((int64_t)channels * kernel_size * num_points * anchors_out, 256), (unsigned)batch);
+  intra_zpconv_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(neighbors, weights, feats, num_points, anchors_in, anchors_out, kernel_size,
+                                                                  num_nn, channels, out);
+  SE3_CHECK_LAUNCH("vgtk_intra_zpconv_fwd");
+  return SE3_OK;
+}
+
+extern "C" int se3_vgtk_intra_zpconv_bwd(const int32_t* neighbors, const float* weights, const float* grad_out, int batch, int num_points,
+                                         int anchors_in, int anchors_out, int kernel_size, int num_nn, int channels, float* grad_feats,
+                                         void* stream) {
+  SE3_REQUIRE(neighbors && weights && grad_out && grad_feats, SE3_ERR_INVALID_ARG, "vgtk_intra_zpconv_bwd: null pointer");
+  SE3_REQUIRE(batch >= 1 && num_points >= 1 && anchors_in >= 1 && anchors_out >= 1 && kernel_size >= 1 && num_nn >= 1 && channels >= 1,
+              SE3_ERR_INVALID_ARG, "vgtk_intra_zpconv_bwd: bad sizes");
+  const dim3 grid((unsigned)se3_cdiv((int64_t)channels * num_points * anchors_in, 256), (unsigned)batch);
+  intra_zpconv_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(neighbors, weights, grad_out, num_points, anchors_in, anchors_out,
+                                                                  kernel_size, num_nn, channels, grad_feats);
+  SE3_CHECK_LAUNCH("vgtk_intra_zpconv_bwd");
+  return SE3_OK;
+}

@@ -1,0 +1,135 @@
+"""MI355X equivalents of the EPN toolkit's CUDA-backed functions.
+
+Mirror of the call sites of vgtk.cuda.{gathering, grouping, zpconv} in the reference:
+    vgtk/spconv/functional.py:102-129  Gathering (autograd)            -> Gathering, gather_points
+    vgtk/pc/sample.py:54-60            ball_query_index                -> ball_query_index
+    vgtk/pc/sample.py:62-80            furthest_sample_index           -> furthest_sample_index
+    vgtk/spconv/functional.py:314-335  InterZPConvGrouping (autograd)  -> InterZPConvGrouping, inter_zpconv_grouping
+    vgtk/spconv/functional.py:211-238  IntraZPConvGrouping (autograd)  -> IntraZPConvGrouping, intra_zpconv_grouping
+Same tensor layouts (channel-first float32, int32 indices), CUDA tensors only (on ROCm 'cuda' is the HIP device).  No SE3ET model
+calls these; they exist because BASELINE.json lists the vgtk CUDA ops as a replaced subsystem."""
+import torch
+
+from . import ops as _ops
+from ._lib import check, lib
+
+_req, _stream = _ops._req, _ops._stream
+
+
+def gather_points(points, idx):
+    """points (b, c, n) float32, idx (b, m) int32 -> (b, c, m)."""
+    points, idx = _req(points.contiguous(), torch.float32, 'points', 3), _req(idx.contiguous(), torch.int32, 'idx', 2)
+    b, c, n = points.shape
+    m = idx.shape[1]
+    out = torch.empty((b, c, m), dtype=torch.float32, device=points.device)
+    check(lib().se3_vgtk_gather_points_fwd(points.data_ptr(), idx.data_ptr(), b, c, n, m, out.data_ptr(), _stream()), 'se3_vgtk_gather_points_fwd')
+    return out
+
+
+class Gathering(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, idx):
+        ctx.save_for_backward(idx)
+        ctx.n = points.shape[2]
+        return gather_points(points, idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, = ctx.saved_tensors
+        g = _req(grad_out.contiguous(), torch.float32, 'grad_out', 3)
+        b, c, m = g.shape
+        grad = torch.empty((b, c, ctx.n), dtype=torch.float32, device=g.device)
+        check(lib().se3_vgtk_gather_points_bwd(g.data_ptr(), idx.data_ptr(), b, c, ctx.n, m, grad.data_ptr(), _stream()), 'se3_vgtk_gather_points_bwd')
+        return grad, None
+
+
+def ball_query_index(query_points, support_points, radius, n_sample):
+    """query (b, 3, m), support (b, 3, n) -> idx (b, m, n_sample) int32: the first n_sample support indices within `radius`."""
+    q, s = _req(query_points.contiguous(), torch.float32, 'query_points', 3), _req(support_points.contiguous(), torch.float32, 'support_points', 3)
+    b, _, m = q.shape
+    n = s.shape[2]
+    if q.shape[1] != 3 or s.shape[1] != 3 or s.shape[0] != b:
+        raise RuntimeError('ball_query_index: points must be (b, 3, n)')
+    idx = torch.empty((b, m, int(n_sample)), dtype=torch.int32, device=q.device)
+    check(lib().se3_vgtk_ball_query(q.data_ptr(), s.data_ptr(), b, n, m, float(radius), int(n_sample), idx.data_ptr(), _stream()), 'se3_vgtk_ball_query')
+    return idx
+
+
+def furthest_sample_index(pc, n_sample, lazy_sample=False):
+    """pc (b, 3, n) -> (b, n_sample) int32 indices of iterative furthest point sampling starting at point 0."""
+    if pc.shape[2] == n_sample or lazy_sample:                      # the reference's shortcut (vgtk/pc/sample.py:64-67)
+        return torch.arange(n_sample, device=pc.device).view(1, -1).expand(pc.shape[0], -1).int().contiguous()
+    pc = _req(pc.contiguous(), torch.float32, 'pc', 3)
+    b, _, n = pc.shape
+    temp = torch.empty((b, n), dtype=torch.float32, device=pc.device)
+    idx = torch.empty((b, int(n_sample)), dtype=torch.int32, device=pc.device)
+    check(lib().se3_vgtk_furthest_point_sampling(pc.data_ptr(), b, n, int(n_sample), temp.data_ptr(), idx.data_ptr(), _stream()),
+          'se3_vgtk_furthest_point_sampling')
+    return idx
+
+
+class InterZPConvGrouping(torch.autograd.Function):
+    """inter_idx, inter_w (b, np, na, ks, ann), feats (b, c, nq, na) -> (b, c, ks, np, na)."""
+
+    @staticmethod
+    def forward(ctx, inter_idx, inter_w, feats):
+        idx, w = _req(inter_idx.contiguous(), torch.int32, 'inter_idx', 5), _req(inter_w.contiguous(), torch.float32, 'inter_w', 5)
+        f = _req(feats.contiguous(), torch.float32, 'feats', 4)
+        b, np_, na, ks, ann = idx.shape
+        c, nq = f.shape[1], f.shape[2]
+        out = torch.empty((b, c, ks, np_, na), dtype=torch.float32, device=f.device)
+        check(lib().se3_vgtk_inter_zpconv_fwd(idx.data_ptr(), w.data_ptr(), f.data_ptr(), b, np_, nq, na, ks, ann, c, out.data_ptr(), _stream()),
+              'se3_vgtk_inter_zpconv_fwd')
+        ctx.save_for_backward(idx, w)
+        ctx.nq = nq
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, w = ctx.saved_tensors
+        g = _req(grad_out.contiguous(), torch.float32, 'grad_out', 5)
+        b, np_, na, ks, ann = idx.shape
+        c = g.shape[1]
+        grad = torch.empty((b, c, ctx.nq, na), dtype=torch.float32, device=g.device)
+        nbytes = lib().se3_vgtk_inter_zpconv_bwd_workspace_bytes(b, np_, ctx.nq, na, ks, ann)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=g.device)
+        check(lib().se3_vgtk_inter_zpconv_bwd(idx.data_ptr(), w.data_ptr(), g.data_ptr(), b, np_, ctx.nq, na, ks, ann, c, grad.data_ptr(),
+                                              ws.data_ptr(), nbytes, _stream()), 'se3_vgtk_inter_zpconv_bwd')
+        return None, None, grad
+
+
+def inter_zpconv_grouping(inter_idx, inter_w, feats):
+    return InterZPConvGrouping.apply(inter_idx, inter_w, feats)
+
+
+class IntraZPConvGrouping(torch.autograd.Function):
+    """intra_idx (na_out, ann) int32, intra_w (na_out, ks, ann), feats (b, c, np, na_in) -> (b, c, ks, np, na_out)."""
+
+    @staticmethod
+    def forward(ctx, intra_idx, intra_w, feats):
+        idx, w = _req(intra_idx.contiguous(), torch.int32, 'intra_idx', 2), _req(intra_w.contiguous(), torch.float32, 'intra_w', 3)
+        f = _req(feats.contiguous(), torch.float32, 'feats', 4)
+        na_out, ann = idx.shape
+        ks = w.shape[1]
+        b, c, np_, na_in = f.shape
+        out = torch.empty((b, c, ks, np_, na_out), dtype=torch.float32, device=f.device)
+        check(lib().se3_vgtk_intra_zpconv_fwd(idx.data_ptr(), w.data_ptr(), f.data_ptr(), b, np_, na_in, na_out, ks, ann, c, out.data_ptr(), _stream()),
+              'se3_vgtk_intra_zpconv_fwd')
+        ctx.save_for_backward(idx, w)
+        ctx.na_in = na_in
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, w = ctx.saved_tensors
+        g = _req(grad_out.contiguous(), torch.float32, 'grad_out', 5)
+        na_out, ann = idx.shape
+        b, c, ks, np_, _ = g.shape
+        grad = torch.empty((b, c, np_, ctx.na_in), dtype=torch.float32, device=g.device)
+        check(lib().se3_vgtk_intra_zpconv_bwd(idx.data_ptr(), w.data_ptr(), g.data_ptr(), b, np_, ctx.na_in, na_out, ks, ann, c, grad.data_ptr(),
+                                              _stream()), 'se3_vgtk_intra_zpconv_bwd')
+        return None, None, grad
+
+
+def intra_zpconv_grouping(intra_idx, intra_w, feats):
+    return IntraZPConvGrouping.apply(intra_idx, intra_w, feats)

@@ -16,6 +16,7 @@ Fixtures
   train_micro_se3ete.npz / train_micro_se3eti.npz
                            training step of the micro models (configs[4] pieces): losses, ground-truth correspondences, gradient
                            norms of all parameters, a few complete gradients, parameter checksum after one Adam step
+  vgtk_ops.npz             EPN toolkit ops through their importable PyTorch twins (inter grouping fwd + grad, gather)
   c2_se3ete_5k.npz         BASELINE.json configs[1] at FULL size: SE3ET-E on the 5k+5k pairs 0..7 (the pairs of one bench step),
                            synthetic weights; per-layer outputs and index-table checksums for pair 0
   c3_se3eti_kitti_20k.npz  BASELINE.json configs[2] at FULL size: SE3ET-I (KITTI configuration) on the 20k+20k pair
@@ -351,6 +352,27 @@ def gen_train(variant, fname, micro=True, pair='micro'):
     np.savez_compressed(os.path.join(HERE, fname), **res)
 
 
+def gen_vgtk():
+    """Inputs / outputs of the importable PyTorch twins of the EPN toolkit's CUDA kernels (vgtk/spconv/functional.py:373-399
+    inter_zpconv_grouping_naive, batched_index_select) on seeded random data, incl. the gradient of the inter grouping."""
+    ref_shims.install()
+    import vgtk.spconv.functional as L
+    g = torch.Generator().manual_seed(5)
+    b, p, q, a, ks, nn_, c = 2, 37, 53, 6, 5, 9, 7
+    idx = torch.randint(0, q, (b, p, nn_), generator=g)
+    w = torch.rand(b, p, a, ks, nn_, generator=g)
+    feats = torch.randn(b, c, q, a, generator=g, requires_grad=True)
+    out = L.inter_zpconv_grouping_naive(idx, w, feats)                       # (b, c, ks, p, a)
+    cot = torch.randn(out.shape, generator=g)
+    (out * cot).sum().backward()
+    pts = torch.randn(b, c, q, generator=g)
+    gi = torch.randint(0, q, (b, 41), generator=g)
+    gathered = L.batched_index_select(pts, 2, gi)
+    np.savez_compressed(os.path.join(HERE, 'vgtk_ops.npz'), inter_idx=idx.numpy().astype(np.int32), inter_w=_np(w), feats=_np(feats),
+                        inter_out=_np(out), cotangent=_np(cot), feats_grad=_np(feats.grad), points=_np(pts),
+                        gather_idx=gi.numpy().astype(np.int32), gathered=_np(gathered))
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['tables', 'precompute', 'micro', 'synthw']
     if 'tables' in which:
@@ -366,6 +388,8 @@ if __name__ == '__main__':
         gen_synthw('se3ete.3dmatch', 'synthw_se3ete.npz')
     if 'kitti' in which or 'synthw' in which:
         gen_synthw('se3eti.kitti', 'synthw_se3eti_kitti.npz', pair='c3_4k')
+    if 'vgtk' in which:
+        gen_vgtk()
     if 'train' in which:
         gen_train('se3ete.3dmatch', 'train_micro_se3ete.npz')
         gen_train('se3eti.3dmatch', 'train_micro_se3eti.npz')
