@@ -380,6 +380,17 @@ int se3_vgtk_intra_zpconv_fwd(const int32_t* neighbors, const float* weights, co
 int se3_vgtk_intra_zpconv_bwd(const int32_t* neighbors, const float* weights, const float* grad_out, int batch, int num_points,
                               int anchors_in, int anchors_out, int kernel_size, int num_nn, int channels, float* grad_feats, void* stream);
 
+
+/* ---- host-pointer variants of geotransformer.ext for DataLoader worker processes -----------------------------------------
+ * Same contract as ext.grid_subsampling / ext.radius_neighbors (extensions/pybind.cpp:6-18; CPU, contiguous float32 / int64 tensors):
+ * plain host memory in and out, no GPU, no global state, callable from forked workers.  grid: s_points / s_normals hold n rows, the first
+ * sum(s_lengths) are valid, in the reference's emission order.  radius: out == NULL computes *max_count only (the width the reference's
+ * result would have); otherwise out is (nq, limit) int64, rows ascending in distance, padded with ns.  Bound by se3et_amd/ext.py. */
+int se3_grid_subsample_host(const float* points, const float* normals, int64_t n, const int64_t* lengths, int batch, float voxel_size,
+                            float* s_points, float* s_normals, int64_t* s_lengths);
+int se3_radius_neighbors_host(const float* q_points, int64_t nq, const float* s_points, int64_t ns, const int64_t* q_lengths,
+                              const int64_t* s_lengths, int batch, float radius, int64_t limit, int64_t* out, int64_t* max_count);
+
 #ifdef __cplusplus
 }
 #endif

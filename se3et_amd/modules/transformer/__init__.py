@@ -12,7 +12,9 @@ Differences that are part of the design:
   * tensors keep the reference layout (B, [A,] N, C) with B == 1 per call (a registration pair is the unit of work);
   * the (B, [A,] H, N, M) attention-score tensors are NOT materialised: `scores` is returned as None unless the layer was
     built with `return_scores=True` (the reference returns them, the SE3ET model never reads them);
-  * options the SE3ET experiments never enable (dropout, key weights, attention factors/masks, '*_best' modes,
+  * key masks (`memory_masks` / `key_masks`, True = masked, the reference's -inf path) are honoured on the invariant RPE layers and on
+    plain cross attention by dropping the masked keys in front of the kernels;
+  * options the SE3ET experiments never enable (dropout, key weights, attention factors / attention masks, '*_best' modes,
     rotation supervision, alternative_impl) raise NotImplementedError instead of silently taking another path.
 """
 import math
@@ -130,8 +132,19 @@ class RPEMultiHeadAttention(nn.Module):
 
     def forward(self, input_q, input_k, input_v, embed_qk, key_weights=None, key_masks=None, attention_factors=None,
                 embed_eq=None):
-        _no(key_weights, 'key_weights'), _no(key_masks, 'key_masks'), _no(attention_factors, 'attention_factors')
+        _no(key_weights, 'key_weights'), _no(attention_factors, 'attention_factors')
         xq, xk, xv = _one(input_q, 'input_q'), _one(input_k, 'input_k'), _one(input_v, 'input_v')
+        keep = None
+        if key_masks is not None:
+            # key_masks (B, M), True = masked: the reference fills those logits with -inf (rpe_transformer.py:114-119), i.e. the softmax
+            # runs over the remaining keys -- done here by dropping the masked keys in front of the kernels.  For the equivariant layers
+            # the reference's mask is mis-broadcast onto the QUERY axis (whole rows -inf -> NaN): not reproduced.
+            if self.equivariant and self.d_equiv_embed > 0:
+                raise NotImplementedError('key_masks on an equivariant RPE layer: the reference masks whole query rows there (NaN output)')
+            keep = torch.nonzero(~_one(key_masks, 'key_masks'))[:, 0]
+            num_keys = xk.shape[-2]
+            xk, xv = xk.index_select(-2, keep), xv.index_select(-2, keep)
+            embed_qk = embed_qk.index_select(2, keep)
         q = SF.linear(xq, self.proj_q.weight, self.proj_q.bias)
         k = SF.linear(xk, self.proj_k.weight, self.proj_k.bias)
         v = SF.project_values_transposed(xv, self.proj_v.weight, self.proj_v.bias)
@@ -142,6 +155,9 @@ class RPEMultiHeadAttention(nn.Module):
                                           _one(embed_eq, 'embed_eq') if use_eq else None,
                                           self.proj_eq.weight if use_eq else None, self.num_heads,
                                           return_scores=self.return_scores)
+        if keep is not None and scores is not None:          # masked keys carry probability 0
+            full = scores.new_zeros(scores.shape[:-1] + (num_keys,))
+            scores = full.index_copy_(-1, keep, scores)
         if torch.is_grad_enabled() and hidden.requires_grad:
             # the position-projection biases are constant along the softmax axis (no effect on the output): they stay in the graph with
             # an exactly-zero gradient, as in the reference, so that the optimizer treats them the same way (weight decay)
@@ -215,10 +231,13 @@ class MultiHeadAttention(nn.Module):
 
     def forward(self, input_q, input_k, input_v, key_weights=None, key_masks=None, attention_factors=None,
                 attention_masks=None, gt_indices=None, gt_overlap=None):
-        _no(key_weights, 'key_weights'), _no(key_masks, 'key_masks'), _no(attention_factors, 'attention_factors')
+        _no(key_weights, 'key_weights'), _no(attention_factors, 'attention_factors')
         _no(attention_masks, 'attention_masks')
         xq, xk, xv = _one(input_q, 'input_q'), _one(input_k, 'input_k'), _one(input_v, 'input_v')
-        if xq is xk or (xq.data_ptr() == xk.data_ptr() and xq.shape == xk.shape):      # self attention: one stacked GEMM
+        if key_masks is not None:      # (B, M), True = masked -> -inf logits (vanilla_transformer.py:66-67) = softmax over the other keys
+            keep = torch.nonzero(~_one(key_masks, 'key_masks'))[:, 0]
+            xk, xv = xk.index_select(-2, keep), xv.index_select(-2, keep)
+        if key_masks is None and (xq is xk or (xq.data_ptr() == xk.data_ptr() and xq.shape == xk.shape)):      # self attention: one stacked GEMM
             q, k = SF.project_qk(xq, self.proj_q.weight, self.proj_q.bias, self.proj_k.weight, self.proj_k.bias)
         else:
             q = SF.linear(xq, self.proj_q.weight, self.proj_q.bias)

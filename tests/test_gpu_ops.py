@@ -497,6 +497,51 @@ def test_geometric_embedding_matches_reference_fixture(golden_dir):
     assert_close(eq.cpu(), g['op/embedding/out1'][0], 1e-5, 'eq embedding vs reference')
 
 
+def test_pairwise_distance_matches_reference_formula():
+    """E1 (modules/ops/pairwise_distance.py:4-30): x2 - 2xy + y2 (or 2 - 2xy for unit vectors), clamped at 0, channel-first option."""
+    from se3et_amd.modules.ops import pairwise_distance
+    g = torch.Generator().manual_seed(32)
+    x, y = torch.randn(3, 41, 16, generator=g), torch.randn(3, 29, 16, generator=g)
+    want = ((x[:, :, None] - y[:, None]) ** 2).sum(-1)
+    assert_close(pairwise_distance(x.cuda(), y.cuda()).cpu(), want, 1e-5, 'pairwise distance')
+    assert_close(pairwise_distance(x.transpose(1, 2).contiguous().cuda(), y.transpose(1, 2).contiguous().cuda(), channel_first=True).cpu(), want, 1e-5,
+                 'pairwise distance, channel first')
+    xn, yn = torch.nn.functional.normalize(x, dim=-1), torch.nn.functional.normalize(y, dim=-1)
+    assert_close(pairwise_distance(xn.cuda(), yn.cuda(), normalized=True).cpu(), ((xn[:, :, None] - yn[:, None]) ** 2).sum(-1), 1e-5, 'normalized')
+    assert float(pairwise_distance(xn.cuda(), xn.cuda(), normalized=True).min()) >= 0.0          # clamped: no negative round-off on the diagonal
+
+
+def test_key_masks_take_the_minus_infinity_path():
+    """memory_masks / key_masks (True = masked; -inf logits in the reference, rpe_transformer.py:114-119, vanilla_transformer.py:66-67)
+    on the invariant RPE layer (incl. the returned score tensor) and on plain cross attention, against the oracle."""
+    from oracle import se3et_oracle as O
+    from se3et_amd.modules.transformer import MultiHeadAttention, RPEMultiHeadAttention
+    g = torch.Generator().manual_seed(31)
+    N, M, C, H = 45, 45, 64, 4
+    st = _attn_state(C, False, seed=3)
+    x = torch.randn(N, C, generator=g)
+    emb = torch.randn(N, M, C, generator=g) * 0.5
+    masks = torch.rand(M, generator=g) < 0.3
+    att = RPEMultiHeadAttention(C, H, return_scores=True)
+    att.load_state_dict({k[2:]: v for k, v in st.items()})
+    att = att.cuda()
+    hidden, scores = att(x.cuda()[None], x.cuda()[None], x.cuda()[None], emb.cuda()[None], key_masks=masks.cuda()[None])
+    want_h, want_s = O.rpe_attention(st, 'l.', x, x, emb, None, H, masks=masks[None, None, :])
+    assert_close(hidden[0].cpu(), want_h, 1e-4, 'masked rpe attention')
+    assert_close(scores[0].cpu(), want_s, 1e-4, 'masked rpe attention scores')
+    assert float(scores[0][..., masks.cuda()].abs().max()) == 0.0
+    cross = MultiHeadAttention(C, H)
+    cross.load_state_dict({k[2:]: v for k, v in st.items() if 'proj_p' not in k})
+    cross = cross.cuda()
+    mem = torch.randn(M, C, generator=g)
+    got, _ = cross(x.cuda()[None], mem.cuda()[None], mem.cuda()[None], key_masks=masks.cuda()[None])
+    q, k, v = [torch.nn.functional.linear(t, st['l.proj_%s.weight' % n], st['l.proj_%s.bias' % n]).view(-1, H, C // H).transpose(0, 1)
+               for t, n in ((x, 'q'), (mem, 'k'), (mem, 'v'))]
+    s = (q @ k.transpose(1, 2) / (C // H) ** 0.5).masked_fill(masks[None, None, :], float('-inf'))
+    want = (torch.softmax(s, -1) @ v).transpose(0, 1).reshape(N, C)
+    assert_close(got[0].cpu(), want, 1e-4, 'masked cross attention')
+
+
 @pytest.mark.parametrize('N,M,C', [(382, 304, 256), (59, 53, 32), (1, 700, 128)])
 def test_superpoint_scores_match_oracle(N, M, C):
     from oracle import se3et_oracle as O
