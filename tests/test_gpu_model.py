@@ -47,8 +47,15 @@ def _check_outputs(out, g, full):
         got, want = out['matching_scores'][:8].cpu(), torch.from_numpy(g['out/matching_scores_head'])
         valid = want > -1e11
         assert torch.equal(got > -1e11, valid)
-        assert float((got[valid] - want[valid]).abs().max()) < 2e-3        # log-domain values of magnitude ~10
-    assert_close(out['estimated_transform'].cpu(), g['out/estimated_transform'], 2e-3, 'estimated_transform')
+        assert float((got[valid] - want[valid]).abs().max()) <= 1e-4 * float(want[valid].abs().max())      # log-domain transport scores
+    same_all = torch.equal(out['ref_node_corr_indices'].cpu(), ri) and torch.equal(out['src_node_corr_indices'].cpu(), si)
+    cs_got, cs_want = out['corr_scores'].cpu().double(), torch.from_numpy(g['out/corr_scores']).double()
+    if same_all and cs_got.shape == cs_want.shape and float((cs_got.sort()[0] - cs_want.sort()[0]).abs().max()) <= 1e-4 * float(cs_want.max()):
+        # identical correspondence set: the transform is a smooth function of it (1e-4)
+        assert_close(out['estimated_transform'].cpu(), g['out/estimated_transform'], 1e-4, 'estimated_transform')
+    else:
+        # a correspondence flipped at a threshold (mutual top-k / 0.05 confidence / top-256 cut-off): another set is fitted
+        assert_close(out['estimated_transform'].cpu(), g['out/estimated_transform'], 2e-3, 'estimated_transform (correspondence set differs)')
 
 
 @pytest.mark.parametrize('variant,fixture', [('micro_e', 'micro_se3ete.npz'), ('micro_i', 'micro_se3eti.npz')])
@@ -182,5 +189,6 @@ def test_multi_pair_forward_equals_single_pair_forward(variant, preset, num_pair
                 torch.equal(got['src_node_corr_indices'], want['src_node_corr_indices']):
             valid = want['matching_scores'] > -1e11
             assert torch.equal(got['matching_scores'] > -1e11, valid)
-            assert float((got['matching_scores'][valid] - want['matching_scores'][valid]).abs().max()) < 2e-3
-            assert_close(got['estimated_transform'].cpu(), want['estimated_transform'].cpu(), 2e-3, 'pair %d transform' % p)
+            assert float((got['matching_scores'][valid] - want['matching_scores'][valid]).abs().max()) <= 1e-4 * float(want['matching_scores'][valid].abs().max())
+            if got['ref_corr_points'].shape == want['ref_corr_points'].shape:
+                assert_close(got['estimated_transform'].cpu(), want['estimated_transform'].cpu(), 2e-3, 'pair %d transform' % p)

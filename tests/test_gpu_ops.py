@@ -32,9 +32,16 @@ def test_sinkhorn_matches_oracle(B, R, C, frac):
     valid = want > -1e11
     if frac > 0:
         assert torch.equal(got > -1e11, valid)
-        assert float((got[valid] - want[valid]).abs().max()) < 1e-3 * max(1.0, float(want[valid].abs().max())) * 0.1
-        # doubly-stochastic property of the transport plan (size independent)
-        p = torch.exp(got[:, :-1, :])
+        assert float((got[valid] - want[valid]).abs().max()) <= 1e-4 * float(want[valid].abs().max())
+        # marginals of the transport plan exp(out) (size independent; the last Sinkhorn half-step fixes the columns exactly, the rows
+        # have converged after 100 iterations): every valid point carries mass 1, the dustbins the number of valid points opposite
+        plan = torch.exp(got.double()) * valid
+        nvr, nvc = rm.sum(1).double(), cm.sum(1).double()
+        col, row = plan.sum(1), plan.sum(2)
+        assert float((col[:, :-1][cm] - 1).abs().max()) < 1e-4 and float((col[:, -1] - nvr).abs().max() / nvr.max()) < 1e-4
+        # rows: as converged as the oracle's own plan after the same 100 iterations (that residual is the algorithm's, ~1e-3 here)
+        wrow = (torch.exp(want.double()) * valid).sum(2)
+        assert float((row - wrow).abs().max() / nvc.max()) < 1e-4
     assert torch.isfinite(got).all()
 
 
@@ -525,7 +532,8 @@ def test_key_masks_take_the_minus_infinity_path():
     att = RPEMultiHeadAttention(C, H, return_scores=True)
     att.load_state_dict({k[2:]: v for k, v in st.items()})
     att = att.cuda()
-    hidden, scores = att(x.cuda()[None], x.cuda()[None], x.cuda()[None], emb.cuda()[None], key_masks=masks.cuda()[None])
+    with torch.no_grad():
+        hidden, scores = att(x.cuda()[None], x.cuda()[None], x.cuda()[None], emb.cuda()[None], key_masks=masks.cuda()[None])
     want_h, want_s = O.rpe_attention(st, 'l.', x, x, emb, None, H, masks=masks[None, None, :])
     assert_close(hidden[0].cpu(), want_h, 1e-4, 'masked rpe attention')
     assert_close(scores[0].cpu(), want_s, 1e-4, 'masked rpe attention scores')
@@ -534,7 +542,8 @@ def test_key_masks_take_the_minus_infinity_path():
     cross.load_state_dict({k[2:]: v for k, v in st.items() if 'proj_p' not in k})
     cross = cross.cuda()
     mem = torch.randn(M, C, generator=g)
-    got, _ = cross(x.cuda()[None], mem.cuda()[None], mem.cuda()[None], key_masks=masks.cuda()[None])
+    with torch.no_grad():
+        got, _ = cross(x.cuda()[None], mem.cuda()[None], mem.cuda()[None], key_masks=masks.cuda()[None])
     q, k, v = [torch.nn.functional.linear(t, st['l.proj_%s.weight' % n], st['l.proj_%s.bias' % n]).view(-1, H, C // H).transpose(0, 1)
                for t, n in ((x, 'q'), (mem, 'k'), (mem, 'v'))]
     s = (q @ k.transpose(1, 2) / (C // H) ** 0.5).masked_fill(masks[None, None, :], float('-inf'))
