@@ -266,9 +266,10 @@ int se3_geo_embedding_fwd(const float* points, const int64_t* knn, int N, int C,
                           void* stream);
 /* Builds / validates such a table on the device (replaces the caller-side GEMMs): table (entries, C, 2) float32 = (f, df/dx) of
  * f(x) = weight emb(x) + bias at x = j / entries_per_unit (float64 accumulation), emb = SinusoidalPositionalEmbedding
- * (transformer/positional_embedding.py:8-34) with div_term (C/2,).  state: 16 zero-initialised bytes owned by the caller next to
+ * (transformer/positional_embedding.py:8-34) with div_term (C/2,).  state: se3_embedding_table_state_bytes() zero-initialised bytes owned by the caller next to
  * the table; the kernel keeps a content hash of (weight, bias, div_term, sizes) there and returns immediately when the table
  * already belongs to the current values -- call it in front of every se3_geo_embedding_*_fwd; no host synchronisation. */
+size_t se3_embedding_table_state_bytes(void);
 int se3_embedding_table_refresh(const float* weight, const float* bias, const float* div_term, int C, int entries,
                                 float entries_per_unit, float* table, void* state, void* stream);
 /* Same, emb (N, N, C) written as bfloat16 (round to nearest even of the float32 value); eq_emb stays float32. */

@@ -50,6 +50,7 @@ SIGNATURES = {
     'se3_cross_eq_apply': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     'se3_geo_embedding_fwd': (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _f32, _vp, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     'se3_geo_embedding_bf16_fwd': (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _f32, _vp, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    'se3_embedding_table_state_bytes': (_sz, []),
     'se3_embedding_table_refresh': (_i32, [_vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp]),
     'se3_knn3': (_i32, [_vp, _i32, _vp, _vp]),
     'se3_knn3_stack': (_i32, [_vp, _vp, _i32, _vp, _vp]),

@@ -97,14 +97,16 @@ def transformer_pairs(gt, points_c, lengths_c, feats_c, packed=False):
     emb_mod = gt.embedding
     embs, eqs = [], []
     knn_all = _ops.knn3_stack(points_c, lengths_c)           # 3 nearest other superpoints, all clouds in one launch
+    tabs = _ops.embedding_tables(emb_mod.embedding.div_term, emb_mod.proj_d.weight, emb_mod.proj_d.bias, emb_mod.proj_a.weight,
+                                 emb_mod.proj_a.bias, emb_mod.sigma_a)      # validated against the weights once per forward
     for c, pts in enumerate(clouds):
         knn = knn_all[offs[c]:offs[c + 1]]
         args = (pts, emb_mod.embedding.div_term, emb_mod.proj_d.weight, emb_mod.proj_d.bias, emb_mod.proj_a.weight,
                 emb_mod.proj_a.bias, emb_mod.sigma_d, emb_mod.sigma_a, emb_mod.angle_k)
         if gt.n_level_equiv > 0:
-            e, q = SF.geometric_embedding(*args, wigner_d1=emb_mod.anchors_wignerD[1], dtype=emb_mod.embedding_dtype, knn=knn)
+            e, q = SF.geometric_embedding(*args, wigner_d1=emb_mod.anchors_wignerD[1], dtype=emb_mod.embedding_dtype, knn=knn, tables=tabs)
         else:
-            e, q = SF.geometric_embedding(*args, dtype=emb_mod.embedding_dtype, knn=knn), None
+            e, q = SF.geometric_embedding(*args, dtype=emb_mod.embedding_dtype, knn=knn, tables=tabs), None
         embs.append(e)
         eqs.append(q)
     # packing: all refs first, then all srcs, so that both halves are contiguous row ranges of one tensor

@@ -158,13 +158,15 @@ __global__ void geo_embedding_kernel(const float* __restrict__ pts, const int64_
 }
 
 // ---- table construction on the device -------------------------------------------------------------------------------
-// tab (entries, C, 2) = (f, f') of f(x) = W emb(x) + b at x = j / per_unit, accumulated in float64.  The kernel is launched in
-// front of EVERY embedding call and validates the table against the CURRENT weights by content: every workgroup hashes
-// (W, b, div_term, sizes) -- 260 KB from L2 -- and returns at once when the hash equals the one stored with the table; otherwise
-// all workgroups rebuild their entries and the last one to finish publishes the new hash.  No host-side version bookkeeping
-// can go stale (in-place writes through .data, module.to(), load_state_dict, optimizer steps all change the content), no
-// host synchronisation, capturable in a graph.
-struct TableState { unsigned long long fp; unsigned int done; unsigned int pad; };
+// tab (entries, C, 2) = (f, f') of f(x) = W emb(x) + b at x = j / per_unit, accumulated in float64.  Two launches in front of every
+// embedding call validate the table against the CURRENT weights by content: 64 workgroups hash disjoint slices of (W, b, div_term)
+// (position-keyed mixing, summed: independent of the slicing), then every workgroup of the build kernel adds the 64 partial hashes and
+// returns at once when the sum equals the hash stored with the table; otherwise all workgroups rebuild their entries and the last one
+// to finish publishes the new hash.  No host-side version bookkeeping can go stale (in-place writes through .data, module.to(),
+// load_state_dict, optimizer steps all change the content), no host synchronisation, capturable in a graph.  Cost when the table is
+// current: two launches of a few microseconds (a single-kernel form in which every workgroup hashed all 260 KB took 80 us).
+constexpr int kHashParts = 64;
+struct TableState { unsigned long long fp; unsigned int done; unsigned int pad; unsigned long long part[kHashParts]; };
 constexpr int kTabE = 8;              // table entries per workgroup
 
 __device__ __forceinline__ unsigned long long mix64(unsigned long long h) {
@@ -172,16 +174,12 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long h) {
   return h;
 }
 
-__global__ void __launch_bounds__(256) embedding_table_refresh_kernel(const float* __restrict__ W, const float* __restrict__ b,
-                                                                      const float* __restrict__ div_term, int C, int entries,
-                                                                      float per_unit, float2* __restrict__ tab,
-                                                                      TableState* __restrict__ st) {
-  extern __shared__ double lds_d[];                       // emb[kTabE][C], demb[kTabE][C]
+__global__ void __launch_bounds__(256) embedding_table_hash_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                                                   const float* __restrict__ div_term, int C, TableState* __restrict__ st) {
   __shared__ unsigned long long part[4];
-  // 1. content hash (order-sensitive: position-keyed mixing, summed)
   unsigned long long h = 0;
   const int nW = C * C, total = nW + C + C / 2;
-  for (int i = threadIdx.x; i < total; i += 256) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += kHashParts * 256) {
     const float v = i < nW ? W[i] : (i < nW + C ? b[i - nW] : div_term[i - nW - C]);
     h += mix64((unsigned long long)__float_as_uint(v) | ((unsigned long long)(unsigned)(i + 1) << 32));
   }
@@ -192,9 +190,29 @@ __global__ void __launch_bounds__(256) embedding_table_refresh_kernel(const floa
   }
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = h;
   __syncthreads();
-  unsigned long long fp = part[0] + part[1] + part[2] + part[3];
-  fp = mix64(fp ^ ((unsigned long long)(unsigned)entries << 32) ^ (unsigned long long)__float_as_uint(per_unit) ^
-             ((unsigned long long)(unsigned)C << 20)) | 1ULL;          // never 0: a zero-initialised state never matches
+  if (threadIdx.x == 0) st->part[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ void __launch_bounds__(256) embedding_table_refresh_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                                                      const float* __restrict__ div_term, int C, int entries,
+                                                                      float per_unit, float2* __restrict__ tab,
+                                                                      TableState* __restrict__ st) {
+  extern __shared__ double lds_d[];                       // emb[kTabE][C], demb[kTabE][C]
+  __shared__ unsigned long long fp_s;
+  // 1. content hash = sum of the partial hashes (embedding_table_hash_kernel, same stream)
+  if (threadIdx.x < 64) {
+    unsigned long long h = st->part[threadIdx.x];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned lo = __shfl_xor((unsigned)h, o), hi = __shfl_xor((unsigned)(h >> 32), o);
+      h += ((unsigned long long)hi << 32) | lo;
+    }
+    if (threadIdx.x == 0)
+      fp_s = mix64(h ^ ((unsigned long long)(unsigned)entries << 32) ^ (unsigned long long)__float_as_uint(per_unit) ^
+                   ((unsigned long long)(unsigned)C << 20)) | 1ULL;      // never 0: a zero-initialised state never matches
+  }
+  __syncthreads();
+  const unsigned long long fp = fp_s;
   if (__hip_atomic_load(&st->fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fp) return;
   // 2. rebuild this workgroup's entries
   double* emb = lds_d;
@@ -240,6 +258,8 @@ __global__ void __launch_bounds__(256) embedding_table_refresh_kernel(const floa
 
 }  // namespace
 
+extern "C" size_t se3_embedding_table_state_bytes(void) { return sizeof(TableState); }
+
 extern "C" int se3_embedding_table_refresh(const float* weight, const float* bias, const float* div_term, int C, int entries,
                                            float entries_per_unit, float* table, void* state, void* stream) {
   SE3_REQUIRE(weight && bias && div_term && table && state, SE3_ERR_INVALID_ARG, "embedding_table_refresh: null pointer");
@@ -247,6 +267,7 @@ extern "C" int se3_embedding_table_refresh(const float* weight, const float* bia
               "embedding_table_refresh: bad sizes");
   const unsigned grid = (unsigned)((entries + kTabE - 1) / kTabE);
   const size_t lds = (size_t)2 * kTabE * C * sizeof(double);
+  embedding_table_hash_kernel<<<kHashParts, 256, 0, (hipStream_t)stream>>>(weight, bias, div_term, C, static_cast<TableState*>(state));
   embedding_table_refresh_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(weight, bias, div_term, C, entries, entries_per_unit,
                                                                          reinterpret_cast<float2*>(table),
                                                                          static_cast<TableState*>(state));

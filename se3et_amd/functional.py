@@ -156,7 +156,7 @@ def sinusoidal_embedding(idx, div_term):
     return torch.cat((torch.sin(om), torch.cos(om)), 2).reshape(*idx.shape, 2 * div_term.numel())
 
 
-def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, k, wigner_d1=None, dtype=torch.float32, knn=None):
+def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, k, wigner_d1=None, dtype=torch.float32, knn=None, tables=None):
     """E (N, N, C) [and the equivariant embedding (A, N, N, 4) when the Wigner-D^1 table is given] in one kernel; dtype
     torch.bfloat16 stores E rounded to bf16 ('bf16 attention', BASELINE.json configs[2])."""
     if AG.needs_grad(w_d, b_d, w_a, b_a):
@@ -171,7 +171,7 @@ def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, 
         # the equivariant embedding has no learned inputs: second output of the kernel, constant for autograd
         emb, eq = AG.differentiable(hip, lambda *a: (ref(*a), points.new_zeros(1)), 2, w_d, b_d, w_a, b_a)
         return emb, eq.detach()
-    return _ops.geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, k, wigner_d1, dtype, knn)
+    return _ops.geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, k, wigner_d1, dtype, knn, tables)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

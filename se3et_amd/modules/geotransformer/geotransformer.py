@@ -32,15 +32,21 @@ class GeometricStructureEmbedding(nn.Module):
             self.anchors_wignerD = nn.ParameterList(
                 [nn.Parameter(torch.from_numpy(t), requires_grad=False) for t in tables.wigner_tables()])
 
-    def forward(self, points):
+    def tables(self):
+        """The tabulated proj_d / proj_a responses, validated against the current weights (once per forward is enough)."""
+        from ... import ops as _ops
+        return _ops.embedding_tables(self.embedding.div_term, self.proj_d.weight, self.proj_d.bias, self.proj_a.weight, self.proj_a.bias,
+                                     self.sigma_a)
+
+    def forward(self, points, tables=None):
         if points.shape[0] != 1:
             raise NotImplementedError('batch size must be 1')
         args = (points[0], self.embedding.div_term, self.proj_d.weight, self.proj_d.bias, self.proj_a.weight,
                 self.proj_a.bias, self.sigma_d, self.sigma_a, self.angle_k)
         if self.n_level_equiv > 0:
-            emb, eq = SF.geometric_embedding(*args, wigner_d1=self.anchors_wignerD[1], dtype=self.embedding_dtype)
+            emb, eq = SF.geometric_embedding(*args, wigner_d1=self.anchors_wignerD[1], dtype=self.embedding_dtype, tables=tables)
             return emb.unsqueeze(0), eq.unsqueeze(0)
-        return SF.geometric_embedding(*args, dtype=self.embedding_dtype).unsqueeze(0)
+        return SF.geometric_embedding(*args, dtype=self.embedding_dtype, tables=tables).unsqueeze(0)
 
 
 class GeometricTransformer(nn.Module):
@@ -68,12 +74,13 @@ class GeometricTransformer(nn.Module):
     def forward(self, ref_points, src_points, ref_feats, src_feats, ref_masks=None, src_masks=None, gt_indices=None,
                 gt_overlap=None, ref_normal=None, src_normal=None):
         """ref_feats (B, N, A, C) -> (B, N, C_out); returns the reference's 6-tuple (the last four are None)."""
+        tabs = self.embedding.tables()
         if self.n_level_equiv == 0:
-            ref_emb, src_emb = self.embedding(ref_points), self.embedding(src_points)
+            ref_emb, src_emb = self.embedding(ref_points, tabs), self.embedding(src_points, tabs)
             ref_eq = src_eq = None
         else:
-            ref_emb, ref_eq = self.embedding(ref_points)
-            src_emb, src_eq = self.embedding(src_points)
+            ref_emb, ref_eq = self.embedding(ref_points, tabs)
+            src_emb, src_eq = self.embedding(src_points, tabs)
         ref_feats = SF.linear(ref_feats.transpose(1, 2), self.in_proj.weight, self.in_proj.bias)
         src_feats = SF.linear(src_feats.transpose(1, 2), self.in_proj.weight, self.in_proj.bias)
         ref_feats, src_feats = self.transformer(ref_feats, src_feats, ref_emb, src_emb, masks0=ref_masks, masks1=src_masks,

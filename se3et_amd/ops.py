@@ -742,7 +742,7 @@ def _embedding_table(weight, bias, div_term, x_max, per_unit):
     hit = _emb_table_cache.get(key)
     if hit is None:
         hit = (torch.empty((n, C, 2), dtype=torch.float32, device=weight.device),
-               torch.zeros((16,), dtype=torch.uint8, device=weight.device))
+               torch.zeros((lib().se3_embedding_table_state_bytes(),), dtype=torch.uint8, device=weight.device))
         if len(_emb_table_cache) > 16:
             _emb_table_cache.clear()
         _emb_table_cache[key] = hit
@@ -762,7 +762,14 @@ def knn3_stack(points, lengths):
     return knn
 
 
-def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, k, wigner_d1=None, dtype=torch.float32, knn=None):
+def embedding_tables(div_term, w_d, b_d, w_a, b_a, sigma_a):
+    """The two validated tables (distance, angle) of a geometric embedding: pass them as `tables=` to several geometric_embedding calls of
+    one forward (all clouds of a batch) to validate the weights once instead of once per cloud."""
+    return (_embedding_table(w_d, b_d, div_term, _EMB_D_RANGE, _EMB_D_PER_UNIT),
+            _embedding_table(w_a, b_a, div_term, 180.0 / sigma_a + 1.0, _EMB_A_PER_UNIT))
+
+
+def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, k, wigner_d1=None, dtype=torch.float32, knn=None, tables=None):
     """HIP (csrc/geo_embedding.hip).  Returns emb (N, N, C), or (emb, eq_emb (A, N, N, 4)) when wigner_d1 is given.
     dtype: torch.float32, or torch.bfloat16 for the 'bf16 attention' mode (emb stored rounded; eq_emb stays float32)."""
     points = _req(points.contiguous(), torch.float32, 'points', 2)
@@ -777,8 +784,7 @@ def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, 
         knn = _req(knn, torch.int64, 'knn', 2)
         if tuple(knn.shape) != (N, 3):
             raise RuntimeError('geometric_embedding: knn must be (N, 3)')
-    tab_d = _embedding_table(w_d, b_d, div_term, _EMB_D_RANGE, _EMB_D_PER_UNIT)
-    tab_a = _embedding_table(w_a, b_a, div_term, 180.0 / sigma_a + 1.0, _EMB_A_PER_UNIT)
+    tab_d, tab_a = tables if tables is not None else embedding_tables(div_term, w_d, b_d, w_a, b_a, sigma_a)
     if dtype not in (torch.float32, torch.bfloat16):
         raise RuntimeError('geometric_embedding: dtype must be float32 or bfloat16')
     emb = torch.empty((N, N, C), dtype=dtype, device=points.device)
