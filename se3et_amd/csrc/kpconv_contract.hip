@@ -273,13 +273,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto build = [&](const float* fb, uint4* ab, int ks, int r) {
     const float* frow = fb + prow * kRowPad;
     const SlotEntry en = tab[(ks * kA + r) * 4 + kb];
-    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float v[8];
+    {
+      const float4 x0 = *reinterpret_cast<const float4*>(frow + en.off[0]);
+      const float4 x1 = *reinterpret_cast<const float4*>(frow + en.off[0] + 4);
+      v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+    }
+    if (ks >= 4) {                      // block-uniform: K-steps 0..3 hold single-member slots only (absent members: zero slot)
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const float* sp = frow + en.off[j];
-      const float4 x0 = *reinterpret_cast<const float4*>(sp);
-      const float4 x1 = *reinterpret_cast<const float4*>(sp + 4);
-      v[0] += x0.x; v[1] += x0.y; v[2] += x0.z; v[3] += x0.w; v[4] += x1.x; v[5] += x1.y; v[6] += x1.z; v[7] += x1.w;
+      for (int j = 1; j < 4; j++) {
+        const float* sp = frow + en.off[j];
+        const float4 x0 = *reinterpret_cast<const float4*>(sp);
+        const float4 x1 = *reinterpret_cast<const float4*>(sp + 4);
+        v[0] += x0.x; v[1] += x0.y; v[2] += x0.z; v[3] += x0.w; v[4] += x1.x; v[5] += x1.y; v[6] += x1.z; v[7] += x1.w;
+      }
     }
     uint4 p1, p2, p3;
     split3(v, p1, p2, p3);
@@ -350,45 +357,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   };
 
-  // ---- builder pipeline (three stages, one per build half of this wave; no LDS round trip is waited for inside a half) ---------------
-  //   stage 0: slot-table entry of step g + 3        -> en_next
-  //   stage 1: F rows of step g + 2 (uses en of the previous half) -> xr[0..7]  (absent orbit members read the zero block)
-  //   stage 2: add, split, write the fragments of step g + 1 from the rows requested one half earlier
   // Builder waves: group Y waves 4..6 own output anchors r = 0..2 (first halves), group X waves 0..2 own r = 3..5 (second halves).
   const bool builder = wg < 3;
   const int rfix = grp == 1 ? wg : 3 + wg;
-  float4 xr[8];
-  SlotEntry en_next;
-  auto read_rows = [&](const float* fb, const SlotEntry en) {
-    const float* frow = fb + prow * kRowPad;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const float* sp = frow + en.off[j];
-      xr[2 * j] = *reinterpret_cast<const float4*>(sp);
-      xr[2 * j + 1] = *reinterpret_cast<const float4*>(sp + 4);
-    }
-  };
-  auto finish = [&](uint4* ab) {
-    float v[8];
-    v[0] = (xr[0].x + xr[2].x) + (xr[4].x + xr[6].x); v[1] = (xr[0].y + xr[2].y) + (xr[4].y + xr[6].y);
-    v[2] = (xr[0].z + xr[2].z) + (xr[4].z + xr[6].z); v[3] = (xr[0].w + xr[2].w) + (xr[4].w + xr[6].w);
-    v[4] = (xr[1].x + xr[3].x) + (xr[5].x + xr[7].x); v[5] = (xr[1].y + xr[3].y) + (xr[5].y + xr[7].y);
-    v[6] = (xr[1].z + xr[3].z) + (xr[5].z + xr[7].z); v[7] = (xr[1].w + xr[3].w) + (xr[5].w + xr[7].w);
-    uint4 p1, p2, p3;
-    split3(v, p1, p2, p3);
-    uint4* dst = ab + (rfix * 3) * 64 + lane;
-    dst[0] = p1;
-    dst[64] = p2;
-    dst[128] = p3;
-  };
-  auto tab_entry = [&](int ksq) {              // table entry of K-step position ksq (0..8) for this lane
-    return tab[(ksq * kA + rfix) * 4 + kb];
-  };
-  // prime: rows of step 1, table entry of step 2 (F chunk 0 holds steps 0..8; one-chunk layers have >= 9 steps)
-  if (builder) {
-    read_rows(fbuf, tab_entry(1));
-    en_next = tab_entry(2);
-  }
 
   load_b(0);
   if (grp == 0) {                      // X multiplies step 0 in the first half of the first K-step
@@ -403,10 +374,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int cur = (int)(g & 1);
     uint4* anext = abuf + (cur ^ 1) * kA * 3 * 64;
     const uint4* acur = abuf + cur * kA * 3 * 64;
-    // F buffer that holds step g + 2 (the next chunk's tile is complete after step ks = 6 of this chunk, see below)
-    const int cc2 = ks + 2 >= kKS ? cc + 1 : cc;
-    const float* f2 = fbuf + (cc2 & 1) * kTileLds;
-    const int ks3 = ks + 3 >= kKS ? ks + 3 - kKS : ks + 3;
+    const int ks1 = ks + 1 == kKS ? 0 : ks + 1;
+    const int cc1 = ks + 1 == kKS ? cc + 1 : cc;           // chunk of step g + 1: its F tile arrived by LDS-DMA during this chunk
     // The NEXT channel chunk's F tile goes global -> LDS by LDS-DMA (no registers, no store pass), requested by all eight waves at the
     // first K-step of a chunk: 46 pieces of 1 KB, lane-linear on both sides (global rows have the LDS row stride).  Its first readers
     // are the row requests of K-step 7; every wave retires its pieces long before that (the weight-fragment waits of K-step 1 drain
@@ -422,18 +391,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                            (__attribute__((address_space(3))) void*)(ldst + piece * 256), 16, 0, 0);
       }
     }
+    // the builder's half: fragments of step g + 1, output anchor rfix, from the F buffer that holds that step (built in one go: a
+    // three-stage register pipeline across halves -- table entry, F rows, add / split / store -- was measured 25 % SLOWER: the extra
+    // live registers and the unconditional four-row reads cost more than the LDS round trips they hide)
 #define SE3_BUILD_HALF()                                                                                  \
-    if (builder && !(dbg & 1)) {                                                                          \
-      if (g + 1 < steps) finish(anext);                                                                   \
-      read_rows(f2, en_next);                                                                             \
-      en_next = tab_entry(ks3);                                                                           \
-    }
-    // End of a build half: only the LDS WRITES (three fragment stores) must have landed before the barrier; the nine
-    // younger reads (eight F rows, one table entry) of the next stage stay in flight across it (LDS operations of a wave complete in
-    // order, so lgkmcnt(9) retires exactly the writes).  A plain __syncthreads() waits lgkmcnt(0) = one LDS round trip per half.
+    if (builder && !(dbg & 1) && g + 1 < steps) build(fbuf + (cc1 & 1) * kTileLds, anext, ks1, rfix);
+    // End of a build half: the fragment stores must have landed before the barrier (raw s_barrier + explicit lgkmcnt wait; a plain
+    // __syncthreads() would also drain the VMEM queue, i.e. the weight fragments requested for the NEXT step).
 #define SE3_BUILD_FENCE()                                                                                 \
-    if (builder && !(dbg & 1)) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");                         \
-    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // ---- first half: X multiplies step g, Y prepares
     if (grp == 0) {
       if (!(dbg & 2)) multiply(acur);
