@@ -32,7 +32,6 @@ constexpr int kRow = kK * kA * kCC;           // 720 floats of F per point and c
 constexpr int kRowPad = 732;
 constexpr int kZeroSlot = kRow;               // float offset of the zero slot inside a row
 constexpr int kTileFloats = kTP * kRowPad;    // 11712 floats = 2928 float4
-constexpr int kFTileFloats = kTileFloats;
 constexpr int kTilePieces = (kTileFloats * 4 + 1023) / 1024;      // 46 LDS-DMA pieces of 1 KB (64 lanes x 16 B)
 constexpr int kTileLds = kTilePieces * 256;   // floats per F buffer in LDS of the wide kernel (whole pieces: 256 B beyond the tile)
 
@@ -102,131 +101,119 @@ __global__ void kpconv_split_weights_kernel(const float* __restrict__ W, int Cin
 // ---- contraction -------------------------------------------------------------------------------------------------------------------
 struct SlotEntry { unsigned short off[4]; };           // float offsets (k*6 + a) * 8 of the orbit members inside a point's F row
 
-template <int NTW>      // column tiles per wave
-__global__ __launch_bounds__(256, 2) void kpconv_contract_kernel(const float* __restrict__ F, const uint4* __restrict__ Wf,
-                                                                  int64_t P, int64_t P16, int Cin, int Cout, int nt_per_block,
-                                                                  float* __restrict__ out) {
-  extern __shared__ __align__(16) float lds[];
-  float* ftile = lds;                                                   // [16 points][724] + zero block
-  uint4* abuf = reinterpret_cast<uint4*>(lds + kFTileFloats);           // [6 r][3 pieces][64 lanes]
-  SlotEntry* tab = reinterpret_cast<SlotEntry*>(abuf + kA * 3 * 64);    // [9 K-steps][6 r][4 kb]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int NT = Cout / 16;
-  const int nt0 = blockIdx.y * nt_per_block + wave * NTW;               // first column tile of this wave
-  const bool active = wave * NTW < nt_per_block;
-  const int64_t p0 = (int64_t)blockIdx.x * kTP;
+// ---- narrow layers (<= 64 output channels): one wave per output anchor, fragments in registers ---------------------------------------------
+// With few output columns a K-step holds little matrix work per G fragment (6 MFMAs per column tile) and the kernel is bound by BUILDING
+// the fragments.  So the six row tiles (output anchors) go to six waves: wave r builds its own fragment of the K-step in registers and
+// multiplies it with all NT column tiles -- no fragment buffer in LDS, no barrier inside a channel chunk (the round's first narrow kernel
+// shared the G fragments through LDS behind three barriers per K-step: 1.6-1.8x slower).  Every wave reads the K-step's weight fragments
+// (NT x 3 KB, requested one K-step ahead) straight from global memory: the six waves of the three resident workgroups hit the same lines
+// in L1.  (Fetching them once per workgroup into a double-buffered LDS tile behind one barrier per K-step measured 1-15 % SLOWER: the
+// 12 KB per wave and K-step then come out of LDS, which the fragment builder is already loading.)
+__device__ __forceinline__ void build_fragment(const float* frow, const SlotEntry en, bool multi, bf16x8& a1, bf16x8& a2, bf16x8& a3) {
+  float v[8];
+  {
+    const float4 x0 = *reinterpret_cast<const float4*>(frow + en.off[0]);
+    const float4 x1 = *reinterpret_cast<const float4*>(frow + en.off[0] + 4);
+    v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+  }
+  if (multi) {                                                          // block-uniform: K-steps 0..3 hold single-member slots only
+#pragma unroll
+    for (int j = 1; j < 4; j++) {
+      const float* sp = frow + en.off[j];
+      const float4 x0 = *reinterpret_cast<const float4*>(sp);
+      const float4 x1 = *reinterpret_cast<const float4*>(sp + 4);
+      v[0] += x0.x; v[1] += x0.y; v[2] += x0.z; v[3] += x0.w; v[4] += x1.x; v[5] += x1.y; v[6] += x1.z; v[7] += x1.w;
+    }
+  }
+  uint4 p1, p2, p3;
+  split3(v, p1, p2, p3);
+  a1 = __builtin_bit_cast(bf16x8, p1); a2 = __builtin_bit_cast(bf16x8, p2); a3 = __builtin_bit_cast(bf16x8, p3);
+}
 
-  // slot table: for (K-step, output anchor r, lane quarter kb) the F-row offsets of the orbit members of slot (s, t) under r
-  for (int e = tid; e < kKS * kA * 4; e += 256) {
-    const int kb = e & 3, r = (e >> 2) % kA, ks = e / (4 * kA);
-    const int st = slot_at(4 * ks + kb), s = st / kA, t = st % kA;
+template <int NT, int RW>       // column tiles (16 output channels each), 1..4; output anchors per wave (1: 6 waves, 2: 3 waves)
+__global__ __launch_bounds__(384 / RW) __attribute__((amdgpu_waves_per_eu(RW == 1 ? 4 : 2, RW == 1 ? 5 : 3))) void kpconv_contract_rows_kernel(
+    const float* __restrict__ F, const uint4* __restrict__ Wf, int64_t P, int64_t P16, int Cin, int Cout, float* __restrict__ out) {
+  extern __shared__ __align__(16) float lds[];
+  float* ftile = lds;                                                   // [16 points][732]
+  SlotEntry* tab = reinterpret_cast<SlotEntry*>(lds + kTileFloats);     // [9 K-steps][6 r][4 kb]
+  const int tid = threadIdx.x, lane = tid & 63, r0 = (tid >> 6) * RW;   // wave = RW output anchors
+  const int64_t p0 = (int64_t)blockIdx.x * kTP;
+  for (int e = tid; e < kKS * kA * 4; e += 384 / RW) {
+    const int kbq = e & 3, rr = (e >> 2) % kA, ks = e / (4 * kA);
+    const int st = slot_at(4 * ks + kbq), sl = st / kA, t = st % kA;
     int a = 0;
-    for (int aa = 0; aa < kA; aa++) a = kRidx[aa][r] == t ? aa : a;
+    for (int aa = 0; aa < kA; aa++) a = kRidx[aa][rr] == t ? aa : a;
     unsigned long long packed = (unsigned long long)kZeroSlot * 0x0001000100010001ull;   // four 16-bit offsets; absent member = zero slot
     int cnt = 0;
     for (int k = 0; k < kK; k++)
-      if (kKidx[k][r] == s && cnt < 4) {
+      if (kKidx[k][rr] == sl && cnt < 4) {
         const unsigned long long off = (unsigned long long)((k * kA + a) * kCC);
         packed = (packed & ~(0xffffull << (16 * cnt))) | (off << (16 * cnt));
         cnt++;
       }
     reinterpret_cast<unsigned long long*>(tab)[e] = packed;
   }
-
-  f32x4 acc[kA][NTW];
+  f32x4 acc[RW][NT];
 #pragma unroll
-  for (int r = 0; r < kA; r++)
+  for (int q = 0; q < RW; q++)
 #pragma unroll
-    for (int n = 0; n < NTW; n++) acc[r][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
+    for (int n = 0; n < NT; n++) acc[q][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int chunks = Cin / kCC;
+  const int64_t steps = (int64_t)chunks * kKS;
   const int prow = lane & 15, kb = lane >> 4;
   const float* frow = ftile + prow * kRowPad;
+  constexpr int kFr = 3 * NT;                         // weight fragments of a K-step (a fragment = 64 lanes x 16 B, lane-linear)
+  uint4 bn[kFr];                                      // next K-step's fragments, in flight while this step is built and multiplied
+#pragma unroll
+  for (int f = 0; f < kFr; f++) bn[f] = Wf[f * 64 + lane];
+  int64_t g = 0;
   for (int cc = 0; cc < chunks; cc++) {
     __syncthreads();                                                    // the previous chunk's F tile is no longer read
-    {   // F tile of this chunk: 16 x 2880 contiguous bytes in global memory -> padded point rows in LDS
+    {
       const float4* src = reinterpret_cast<const float4*>(F + ((int64_t)cc * P16 + p0) * kRowPad);
-      for (int q = tid; q < kTileFloats / 4; q += 256) reinterpret_cast<float4*>(ftile)[q] = src[q];
+      for (int q = tid; q < kTileFloats / 4; q += 384 / RW) reinterpret_cast<float4*>(ftile)[q] = src[q];
     }
     __syncthreads();
 #pragma unroll 1
-    for (int ks = 0; ks < kKS; ks++) {
-      const int64_t ksg = (int64_t)cc * kKS + ks;
-      // weight fragments of this K-step (requested first: they arrive while the G fragments are built)
-      uint4 b[NTW][3];
-      if (active) {
+    for (int ks = 0; ks < kKS; ks++, g++) {
+      bf16x8 a1[RW], a2[RW], a3[RW];
 #pragma unroll
-        for (int n = 0; n < NTW; n++) {
-          const uint4* src = Wf + ((ksg * NT + nt0 + n) * 3) * 64 + lane;
+      for (int q = 0; q < RW; q++) build_fragment(frow, tab[(ks * kA + r0 + q) * 4 + kb], ks >= 4, a1[q], a2[q], a3[q]);
+      bf16x8 b[NT][3];
 #pragma unroll
-          for (int pc = 0; pc < 3; pc++) b[n][pc] = src[pc * 64];
-        }
+      for (int n = 0; n < NT; n++)
+#pragma unroll
+        for (int pc = 0; pc < 3; pc++) b[n][pc] = __builtin_bit_cast(bf16x8, bn[n * 3 + pc]);
+      {                                                                 // request step g + 1 (clamped: unconditional, so the compiler counts it)
+        const int64_t gq = g + 1 < steps ? g + 1 : steps - 1;
+        const uint4* src = Wf + gq * kFr * 64 + lane;
+#pragma unroll
+        for (int f = 0; f < kFr; f++) bn[f] = src[f * 64];
       }
-      // G fragments: six (r) row tiles over four waves
-      for (int r = wave; r < kA; r += 4) {
-        const SlotEntry en = tab[(ks * kA + r) * 4 + kb];
-        float v[8];
-        {
-          const float4 x0 = *reinterpret_cast<const float4*>(frow + en.off[0]);
-          const float4 x1 = *reinterpret_cast<const float4*>(frow + en.off[0] + 4);
-          v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-        }
-        if (ks >= 4) {                                                  // block-uniform: K-steps 0..3 hold single-member slots only
-#pragma unroll
-          for (int j = 1; j < 4; j++) {
-            const float* sp = frow + en.off[j];
-            const float4 x0 = *reinterpret_cast<const float4*>(sp);
-            const float4 x1 = *reinterpret_cast<const float4*>(sp + 4);
-            v[0] += x0.x; v[1] += x0.y; v[2] += x0.z; v[3] += x0.w; v[4] += x1.x; v[5] += x1.y; v[6] += x1.z; v[7] += x1.w;
-          }
-        }
-        uint4 p1, p2, p3;
-        split3(v, p1, p2, p3);
-        uint4* dst = abuf + (r * 3) * 64 + lane;
-        dst[0] = p1;
-        dst[64] = p2;
-        dst[128] = p3;
-      }
-      __syncthreads();
-      if (active) {
-#pragma unroll
-        for (int r = 0; r < kA; r++) {
-          const uint4* ap = abuf + (r * 3) * 64 + lane;
-          const bf16x8 a1 = __builtin_bit_cast(bf16x8, ap[0]), a2 = __builtin_bit_cast(bf16x8, ap[64]),
-                       a3 = __builtin_bit_cast(bf16x8, ap[128]);
-#pragma unroll
-          for (int n = 0; n < NTW; n++) {
-            const bf16x8 b1 = __builtin_bit_cast(bf16x8, b[n][0]), b2 = __builtin_bit_cast(bf16x8, b[n][1]),
-                         b3 = __builtin_bit_cast(bf16x8, b[n][2]);
-            f32x4 c = acc[r][n];
-            // smallest terms first
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, c, 0, 0, 0);
-            acc[r][n] = c;
-          }
-        }
-      }
-      __syncthreads();                                                  // abuf is rewritten by the next K-step
+      // product-major over the tiles: consecutive MFMAs go to different accumulators; smallest terms first
+#define SE3_PRODUCT(a_, pc_)                                                                                        \
+  _Pragma("unroll") for (int q = 0; q < RW; q++) _Pragma("unroll") for (int n = 0; n < NT; n++)                  \
+      acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_[q], b[n][pc_], acc[q][n], 0, 0, 0);
+      SE3_PRODUCT(a3, 0)
+      SE3_PRODUCT(a1, 2)
+      SE3_PRODUCT(a2, 1)
+      SE3_PRODUCT(a2, 0)
+      SE3_PRODUCT(a1, 1)
+      SE3_PRODUCT(a1, 0)
+#undef SE3_PRODUCT
     }
   }
-  if (active) {
-    // accumulator tile: lane holds column (lane & 15), rows (lane >> 4) * 4 + i  = points of the tile
+  // accumulator tile: lane holds column (lane & 15), rows (lane >> 4) * 4 + i = points of the tile
 #pragma unroll
-    for (int r = 0; r < kA; r++)
+  for (int q = 0; q < RW; q++)
 #pragma unroll
-      for (int n = 0; n < NTW; n++)
+    for (int n = 0; n < NT; n++)
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const int64_t p = p0 + (lane >> 4) * 4 + i;
-          if (p < P) out[(p * kA + r) * Cout + (nt0 + n) * 16 + (lane & 15)] = acc[r][n][i];
-        }
-  }
+      for (int i = 0; i < 4; i++) {
+        const int64_t p = p0 + (lane >> 4) * 4 + i;
+        if (p < P) out[(p * kA + r0 + q) * Cout + n * 16 + (lane & 15)] = acc[q][n][i];
+      }
 }
-
 
 // ---- wide layers (>= 128 output channels per workgroup): 8 waves in two groups that alternate roles ------------------------------------
 // Waves w and w + 4 share a SIMD.  Every K-step has two halves separated by a barrier: in the first, group X (waves 0..3) multiplies step
@@ -477,18 +464,25 @@ extern "C" int se3_kpconv_so3_contract(const float* F, const void* weight_fragme
   const uint4* Wf = static_cast<const uint4*>(weight_fragments);
   hipStream_t st = (hipStream_t)stream;
   static bool lds_attr_set = false;      // > 64 KB of dynamic LDS needs the opt-in once per kernel
-  const size_t lds_small = (size_t)kFTileFloats * 4 + (size_t)kA * 3 * 64 * 16 + (size_t)kKS * kA * 4 * sizeof(SlotEntry);
+  const size_t lds_small = (size_t)kTileFloats * 4 + (size_t)kKS * kA * 4 * sizeof(SlotEntry);
   const size_t lds_wide = (size_t)(2 * kTileLds) * 4 + (size_t)2 * kA * 3 * 64 * 16 + (size_t)kKS * kA * 4 * sizeof(SlotEntry);
   if (!lds_attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kpconv_contract_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kpconv_contract_wide_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kpconv_contract_wide_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide);
     lds_attr_set = true;
   }
   if (NT <= 4) {
-    // narrow layers: 4 waves, one column tile per wave
+    // narrow layers: one wave per output anchor, all column tiles per wave
     const dim3 grid((unsigned)tiles, 1u);
-    kpconv_contract_kernel<1><<<grid, 256, lds_small, st>>>(F, Wf, num_queries, P16, in_channels, out_channels, NT, out);
+    // anchors per wave: two halve the weight-fragment reads per MFMA (they bound the 64-column layers: 1.41 vs 1.46 ms per call at the
+    // bench shape) but leave 9 waves per CU, too few to hide the build latency of the cheaper 16/32-column layers (0.92 vs 0.86 ms)
+    static const char* rws = getenv("SE3_KPCONV_RW");
+    const int rw = rws ? atoi(rws) : (NT == 4 ? 2 : 1);
+#define SE3_ROWS(NT_)                                                                                                                \
+  if (rw == 2) kpconv_contract_rows_kernel<NT_, 2><<<grid, 192, lds_small, st>>>(F, Wf, num_queries, P16, in_channels, out_channels, out); \
+  else kpconv_contract_rows_kernel<NT_, 1><<<grid, 384, lds_small, st>>>(F, Wf, num_queries, P16, in_channels, out_channels, out);
+    if (NT == 4) { SE3_ROWS(4) } else if (NT == 3) { SE3_ROWS(3) } else if (NT == 2) { SE3_ROWS(2) } else { SE3_ROWS(1) }
+#undef SE3_ROWS
   } else {
     SE3_REQUIRE(NT % 8 == 0, SE3_ERR_UNSUPPORTED, "kpconv_so3_contract: %d output channels (need <= 64 or a multiple of 128)",
                 out_channels);

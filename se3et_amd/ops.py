@@ -321,7 +321,8 @@ def _host_table(t, dtype):
 
 # KPConv contraction path: True = always the matrix-core kernels (csrc/kpconv_contract.hip) where the channel counts allow, False = always
 # the round-1 path (slot sums G in HBM + library f32 GEMM), 'auto' = per layer shape, whichever measured faster on MI355X at the bench
-# shape (tools/micro/kpconv_paths.py, profiles/r02_kpconv_paths.txt): today the 64 -> 64 layers (1.43 ms against 1.61 ms per call at 8 pairs).
+# shape (tools/micro/kpconv_paths.py, profiles/r02_kpconv_paths.txt): today every layer with <= 64 output channels (32: 0.86 against 1.00 ms,
+# 64: 1.41 against 1.69 ms per call at 8 pairs); the 128 / 256-column layers stay on the library GEMM (1.6-1.8 against 1.2-1.3 ms).
 # Both paths agree to f32 round-off (tests/test_gpu_ops.py::test_kpconv_matrix_core_path_has_f32_accuracy).
 KPCONV_MATRIX_CORE = os.environ.get('SE3_KPCONV_PATH', 'auto')
 KPCONV_MATRIX_CORE = {'mfma': True, 'gemm': False}.get(KPCONV_MATRIX_CORE, 'auto')
@@ -329,7 +330,7 @@ KPCONV_MATRIX_CORE = {'mfma': True, 'gemm': False}.get(KPCONV_MATRIX_CORE, 'auto
 
 def _kpconv_use_matrix_core(Cin, Cout):
     if KPCONV_MATRIX_CORE == 'auto':
-        return Cin == 64 and Cout == 64
+        return Cout <= 64          # narrow layers: the one-wave-per-anchor kernel beats gather + library GEMM
     return bool(KPCONV_MATRIX_CORE)
 
 
