@@ -258,12 +258,15 @@ int se3_cross_eq_stack_fwd(const float* q, const float* k, const float* vt, cons
  * transformer/positional_embedding.py:8-34).  points (N, 3); knn (N, 3) int64: the 3 nearest other points of each point.
  * table_d / table_a: (entries, C, 2) float32 = (f, df/dx) of f(x) = W emb(x) + b sampled at x = j / entries_per_unit
  * (built by the caller with two small GEMMs); indices beyond a table fall back to the exact sinusoid sum with
- * w_* (C, C), b_* (C,), div_term (C/2,).  emb (N, N, C); eq_emb (num_anchors, N, N, 4) or NULL, wigner_d1 (num_anchors, 3, 3). */
+ * w_* (C, C), b_* (C,), div_term (C/2,).  emb (N, N, C); eq_emb (num_anchors, N, N, 4) or NULL, wigner_d1 (num_anchors, 3, 3).
+ * workspace: se3_geo_embedding_workspace_bytes(N) bytes of device scratch (per-pair index records), or NULL: the single-kernel form that
+ * needs none (2-3x slower: every table read then comes from L2). */
+size_t se3_geo_embedding_workspace_bytes(int N);
 int se3_geo_embedding_fwd(const float* points, const int64_t* knn, int N, int C, const float* table_d, int d_entries,
                           float d_entries_per_unit, const float* table_a, int a_entries, float a_entries_per_unit,
                           float sigma_d, float sigma_a, const float* w_d, const float* b_d, const float* w_a, const float* b_a,
                           const float* div_term, const float* wigner_d1, int num_anchors, float* emb, float* eq_emb,
-                          void* stream);
+                          void* workspace, size_t workspace_bytes, void* stream);
 /* Builds / validates such a table on the device (replaces the caller-side GEMMs): table (entries, C, 2) float32 = (f, df/dx) of
  * f(x) = weight emb(x) + bias at x = j / entries_per_unit (float64 accumulation), emb = SinusoidalPositionalEmbedding
  * (transformer/positional_embedding.py:8-34) with div_term (C/2,).  state: se3_embedding_table_state_bytes() zero-initialised bytes owned by the caller next to
@@ -277,7 +280,7 @@ int se3_geo_embedding_bf16_fwd(const float* points, const int64_t* knn, int N, i
                                float d_entries_per_unit, const float* table_a, int a_entries, float a_entries_per_unit,
                                float sigma_d, float sigma_a, const float* w_d, const float* b_d, const float* w_a,
                                const float* b_a, const float* div_term, const float* wigner_d1, int num_anchors, uint16_t* emb,
-                               float* eq_emb, void* stream);
+                               float* eq_emb, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- G1 / E3: nearest-neighbour selections on the superpoint level ----------------------------------------------------
  * se3_knn3: knn (N, 3) int64 = the 3 nearest OTHER points of every point (get_embedding_indices,

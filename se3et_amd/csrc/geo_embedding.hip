@@ -39,7 +39,7 @@ __device__ __forceinline__ float hermite(const float2* __restrict__ tab, int C, 
 }
 
 // exact evaluation W[c, :] . emb(x) + b[c] (fallback for indices outside the table)
-__device__ float exact_eval(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ div_term,
+__device__ __attribute__((noinline)) float exact_eval(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ div_term,
                             int C, int c, float x) {
   float acc = b[c];
   for (int i = 0; i < C / 2; i++) {
@@ -155,6 +155,189 @@ __global__ void geo_embedding_kernel(const float* __restrict__ pts, const int64_
       }
     }
   }
+}
+
+// ---- channel-slice form: the angle table of the slice lives in LDS ----------------------------------------------------------------
+// The kernel above reads 64 B of table per 4 B written, all of it from L2 (the tables are far larger than L1): at N = 358 that is
+// 2.1 GB per cloud at the ~15 TB/s the chip gathers from L2 -- 140 us, 0.95 TB/s of output.  Three of the four terms read the ANGLE table
+// (index range 180 / sigma_a + 1 units).  Here the work is split in two kernels:
+//   geo_pair_terms_kernel   one thread per (n, m, term): the index (distance / one of the three angles), its table interval and the four
+//                           Hermite weights -> a (N N, 4) record array (80 B per pair, L2 / Infinity-Cache resident); also writes Eeq.
+//   geo_embedding_slice_kernel   a workgroup owns kCS = 32 channels and a block of query rows and keeps its slice of the angle table
+//                           (entries x 256 B, 105 KB at 32 entries per unit) in LDS: the three angle terms cost 96 B of ds_read_b128 per
+//                           lane and pair, only the distance term still comes from L2 (16 B per output).  A lane owns two channels (one
+//                           float4 = (f, f') x 2 per table entry), 16 lanes one pair: a wave writes four full 128-byte lines per store.
+//                           A wave owns a contiguous run of pairs; their records travel global -> registers -> a wave-private LDS ring
+//                           in coalesced blocks of 16 pairs, two blocks ahead of their use, and are read back as 16-lane broadcasts.
+//                           No barrier after the table fill: the 16 waves of the one workgroup per CU run free.
+// Measured on the way (N = 358, us per cloud; the single-kernel form: 167): records staged in LDS behind a barrier per 64 pairs, 8 waves:
+// 174; records as per-lane vector loads (five broadcast 16-byte loads per pair cost the L1 return path as much as 5 KB of real data per
+// wave): 97; one pair per wave with the record in SGPRs through the scalar cache (every record a scalar-cache miss; the SGPR file holds
+// too few records to cover that latency): 96-113.
+constexpr int kCS = 32;      // channels per workgroup
+constexpr int kSliceThreads = 1024;
+constexpr int kRecBlock = 16;                                  // pairs per staged record block
+constexpr int kRecBytes = kRecBlock * (64 + 16);               // weights (4 float4) + intervals (int4) per pair
+
+__global__ __launch_bounds__(256) void geo_pair_terms_kernel(const float* __restrict__ pts, const int64_t* __restrict__ knn, int N,
+                                                             EmbParams P, const float* __restrict__ wigner_d1, int4* __restrict__ jrec,
+                                                             float4* __restrict__ wrec, float* __restrict__ eq_emb, int A) {
+  const int t = blockIdx.y;                                   // term: 0 = distance, 1..3 = angle to the k-th nearest neighbour
+  const unsigned pair = blockIdx.x * 256u + threadIdx.x;
+  if (pair >= (unsigned)N * (unsigned)N) return;
+  const int n = (int)(pair / (unsigned)N), m = (int)(pair - (unsigned)n * (unsigned)N);
+  const float px = pts[3 * n], py = pts[3 * n + 1], pz = pts[3 * n + 2];
+  const float qx = pts[3 * m], qy = pts[3 * m + 1], qz = pts[3 * m + 2];
+  const float vx = qx - px, vy = qy - py, vz = qz - pz;
+  float x, inv_h;
+  int entries;
+  if (t == 0) {
+    const float nn2 = px * px + py * py + pz * pz;
+    const float d2 = fmaxf(nn2 - 2.f * (px * qx + py * qy + pz * qz) + (qx * qx + qy * qy + qz * qz), 0.f);
+    x = sqrtf(d2) * P.sigma_d_inv;
+    inv_h = P.d_inv_h; entries = P.d_entries;
+    if (eq_emb != nullptr) {
+      // unit vector of p_n - p_m (zero vector -> 0, as F.normalize with eps 1e-12)
+      const float len = sqrtf(vx * vx + vy * vy + vz * vz);
+      const float inv = 1.f / fmaxf(len, 1e-12f);
+      const float ux = -vx * inv, uy = -vy * inv, uz = -vz * inv;
+      const float c1 = 0.4886025119029199f;        // sqrt(3 / (4 pi))
+      for (int a = 0; a < A; a++) {
+        const float* D = wigner_d1 + 9 * a;        // D^1_a (3, 3): out_c = sum_d D[c][d] Y1_d
+        float4 o;
+        o.x = 0.28209479177387814f;                // 1 / (2 sqrt(pi))
+        o.y = c1 * (D[0] * ux + D[1] * uy + D[2] * uz);
+        o.z = c1 * (D[3] * ux + D[4] * uy + D[5] * uz);
+        o.w = c1 * (D[6] * ux + D[7] * uy + D[8] * uz);
+        reinterpret_cast<float4*>(eq_emb)[(size_t)a * N * N + pair] = o;
+      }
+    }
+  } else {
+    const int64_t jn = knn[3 * n + (t - 1)];
+    const float rx = pts[3 * jn] - px, ry = pts[3 * jn + 1] - py, rz = pts[3 * jn + 2] - pz;
+    const float cx = ry * vz - rz * vy, cy = rz * vx - rx * vz, cz = rx * vy - ry * vx;
+    const float sn = sqrtf(cx * cx + cy * cy + cz * cz);
+    float cs = rx * vx + ry * vy + rz * vz;
+    cs = (cs == 0.f) ? 0.f : cs;        // see geo_embedding_kernel
+    x = atan2f(sn, cs) * P.factor_a;
+    inv_h = P.a_inv_h; entries = P.a_entries;
+  }
+  const float u = x * inv_h;
+  const int j = (int)floorf(u);
+  const bool ok = (j >= 0) && (j + 1 < entries);
+  const float tt = u - (float)j, h = 1.0f / inv_h;
+  const float t2 = tt * tt, t3 = t2 * tt;
+  reinterpret_cast<int*>(jrec)[(size_t)pair * 4 + t] = ok ? j : -1;
+  // outside the table: the index itself, for the exact evaluation
+  wrec[(size_t)pair * 4 + t] = ok ? make_float4(2.f * t3 - 3.f * t2 + 1.f, -2.f * t3 + 3.f * t2, h * (t3 - 2.f * t2 + tt), h * (t3 - t2))
+                                  : make_float4(x, 0.f, 0.f, 0.f);
+}
+
+struct ExactArgs { const float *Wd, *bd, *Wa, *ba, *div_term; };    // only the cold path (index outside a table) reads these
+
+template <bool BF16>
+__global__ __launch_bounds__(kSliceThreads) void geo_embedding_slice_kernel(
+    int N, int C, const float2* __restrict__ tab_d, const float2* __restrict__ tab_a, int a_entries, const int4* __restrict__ jrec,
+    const float4* __restrict__ wrec, ExactArgs X, void* __restrict__ emb_out, int rows_per_block) {
+  extern __shared__ __align__(16) float4 lds4[];
+  float4* atab = lds4 + (kSliceThreads / 64) * 2 * (kRecBytes / 16);                  // [a_entries][16]: channels 2 l, 2 l + 1 of the slice
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float4* ring = lds4 + wave * 2 * (kRecBytes / 16);                                  // [2][64 weights | 16 intervals] of this wave
+  const int c_base = blockIdx.x * kCS;
+  const int n0 = blockIdx.y * rows_per_block, n1 = min(N, n0 + rows_per_block);
+  if (n0 >= n1) return;
+  for (int i = tid; i < a_entries * 16; i += kSliceThreads) {
+    const int e = i >> 4, l = i & 15;
+    atab[i] = *reinterpret_cast<const float4*>(tab_a + (size_t)e * C + c_base + 2 * l);
+  }
+  __syncthreads();
+  const unsigned first = (unsigned)n0 * (unsigned)N, last = (unsigned)n1 * (unsigned)N;   // the block's pairs: contiguous (n, m) records
+  float* emb = static_cast<float*>(emb_out);
+  unsigned* emb16 = static_cast<unsigned*>(emb_out);
+  constexpr unsigned kWaves = kSliceThreads / 64;
+  const unsigned chunk = ((last - first + kWaves - 1) / kWaves + (kRecBlock - 1)) & ~(unsigned)(kRecBlock - 1);
+  const unsigned wbeg = first + (unsigned)wave * chunk;
+  if (wbeg >= last) return;
+  const unsigned wend = min(last, wbeg + chunk);
+  const int blocks = (int)((wend - wbeg + kRecBlock - 1) / kRecBlock);
+  const int l = lane & 15, grp = lane >> 4, c0 = c_base + 2 * l;
+  const float2* dcol = tab_d + c0;
+  const unsigned wlast = last * 4 - 1;
+  // record block b of this wave: lane -> one float4 of the 64 weights, lanes (l, any group) -> interval record l
+#define SE3_REQUEST(b_)                                                                      \
+  rw = wrec[min((wbeg + (unsigned)(b_) * kRecBlock) * 4 + (unsigned)lane, wlast)];          \
+  rj = jrec[min(wbeg + (unsigned)(b_) * kRecBlock + (unsigned)l, last - 1)];
+#define SE3_PUBLISH(b_)                                                                      \
+  {                                                                                          \
+    float4* dst = ring + ((b_) & 1) * (kRecBytes / 16);                                      \
+    dst[lane] = rw;                                                                          \
+    if (grp == 0) reinterpret_cast<int4*>(dst + 64)[l] = rj;                                 \
+  }
+  float4 rw;
+  int4 rj;
+  SE3_REQUEST(0)
+  SE3_PUBLISH(0)
+  // pipeline state: intervals and distance rows of the iteration about to be evaluated
+  int4 jc = reinterpret_cast<const int4*>(ring + 64)[grp];
+  float4 dc0, dc1;
+  {
+    const int jd = max(jc.x, 0);
+    dc0 = *reinterpret_cast<const float4*>(dcol + (size_t)jd * C);
+    dc1 = *reinterpret_cast<const float4*>(dcol + (size_t)(jd + 1) * C);
+  }
+  for (int blk = 0; blk < blocks; blk++) {
+    SE3_REQUEST(blk + 1)                                        // past the run: clamped, never used
+#pragma unroll
+    for (int sub = 0; sub < 4; sub++) {
+      if (sub == 3) SE3_PUBLISH(blk + 1)                        // the next iteration's intervals are read just below
+      const float4* cur = ring + (blk & 1) * (kRecBytes / 16);
+      // intervals of the next iteration -> its distance rows (L2) are requested one iteration ahead
+      const float4* nxt = sub == 3 ? ring + ((blk + 1) & 1) * (kRecBytes / 16) : cur;
+      const int4 jn = reinterpret_cast<const int4*>(nxt + 64)[((sub + 1) & 3) * 4 + grp];
+      const int jdn = max(jn.x, 0);
+      const float4 dn0 = *reinterpret_cast<const float4*>(dcol + (size_t)jdn * C);
+      const float4 dn1 = *reinterpret_cast<const float4*>(dcol + (size_t)(jdn + 1) * C);
+      // this iteration: pair = wbeg + 16 blk + 4 sub + grp
+      const unsigned pair = wbeg + (unsigned)(blk * kRecBlock + sub * 4 + grp);
+      const float4* wp = cur + (sub * 4 + grp) * 4;
+      const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
+      const int j1 = max(jc.y, 0), j2 = max(jc.z, 0), j3 = max(jc.w, 0);
+      const float4 a10 = atab[j1 * 16 + l], a11 = atab[(j1 + 1) * 16 + l];
+      const float4 a20 = atab[j2 * 16 + l], a21 = atab[(j2 + 1) * 16 + l];
+      const float4 a30 = atab[j3 * 16 + l], a31 = atab[(j3 + 1) * 16 + l];
+      // explicit roundings (no contraction): the f32 and bf16 instantiations must produce the same f32 value
+#define SE3_HERMITE(w_, f0_, g0_, f1_, g1_) \
+  __fadd_rn(__fmaf_rn((w_).x, f0_, __fmul_rn((w_).y, f1_)), __fmaf_rn((w_).z, g0_, __fmul_rn((w_).w, g1_)))
+      float x0 = SE3_HERMITE(w0, dc0.x, dc0.y, dc1.x, dc1.y), y0 = SE3_HERMITE(w0, dc0.z, dc0.w, dc1.z, dc1.w);
+      float x1 = SE3_HERMITE(w1, a10.x, a10.y, a11.x, a11.y), y1 = SE3_HERMITE(w1, a10.z, a10.w, a11.z, a11.w);
+      float x2 = SE3_HERMITE(w2, a20.x, a20.y, a21.x, a21.y), y2 = SE3_HERMITE(w2, a20.z, a20.w, a21.z, a21.w);
+      float x3 = SE3_HERMITE(w3, a30.x, a30.y, a31.x, a31.y), y3 = SE3_HERMITE(w3, a30.z, a30.w, a31.z, a31.w);
+#undef SE3_HERMITE
+      if ((jc.x | jc.y | jc.z | jc.w) < 0) {                   // cold: an index outside its table (the record then holds the index itself)
+        if (jc.x < 0) { x0 = exact_eval(X.Wd, X.bd, X.div_term, C, c0, w0.x); y0 = exact_eval(X.Wd, X.bd, X.div_term, C, c0 + 1, w0.x); }
+        if (jc.y < 0) { x1 = exact_eval(X.Wa, X.ba, X.div_term, C, c0, w1.x); y1 = exact_eval(X.Wa, X.ba, X.div_term, C, c0 + 1, w1.x); }
+        if (jc.z < 0) { x2 = exact_eval(X.Wa, X.ba, X.div_term, C, c0, w2.x); y2 = exact_eval(X.Wa, X.ba, X.div_term, C, c0 + 1, w2.x); }
+        if (jc.w < 0) { x3 = exact_eval(X.Wa, X.ba, X.div_term, C, c0, w3.x); y3 = exact_eval(X.Wa, X.ba, X.div_term, C, c0 + 1, w3.x); }
+      }
+      const float ex = __fadd_rn(x0, fmaxf(fmaxf(x1, x2), x3));
+      const float ey = __fadd_rn(y0, fmaxf(fmaxf(y1, y2), y3));
+      if (pair < wend) {
+        const size_t o = (size_t)pair * C + c0;
+        if (BF16) {                                            // round to nearest even (values are finite)
+          unsigned ux = __float_as_uint(ex), uy = __float_as_uint(ey);
+          ux += 0x7fffu + ((ux >> 16) & 1u);
+          uy += 0x7fffu + ((uy >> 16) & 1u);
+          __builtin_nontemporal_store((ux >> 16) | (uy & 0xffff0000u), &emb16[o >> 1]);
+        } else {
+          float2 e2 = make_float2(ex, ey);
+          __builtin_nontemporal_store(*reinterpret_cast<unsigned long long*>(&e2), reinterpret_cast<unsigned long long*>(emb + o));
+        }
+      }
+      jc = jn; dc0 = dn0; dc1 = dn1;
+    }
+  }
+#undef SE3_REQUEST
+#undef SE3_PUBLISH
 }
 
 // ---- table construction on the device -------------------------------------------------------------------------------
@@ -275,11 +458,14 @@ extern "C" int se3_embedding_table_refresh(const float* weight, const float* bia
   return SE3_OK;
 }
 
+// record workspace of the channel-slice form: (N N) int4 intervals + (N N, 4) float4 Hermite weights
+extern "C" size_t se3_geo_embedding_workspace_bytes(int N) { return (size_t)N * N * (sizeof(int4) + 4 * sizeof(float4)); }
+
 static int geo_embedding(const float* points, const int64_t* knn, int N, int C, const float* table_d, int d_entries,
                          float d_entries_per_unit, const float* table_a, int a_entries, float a_entries_per_unit,
                          float sigma_d, float sigma_a, const float* w_d, const float* b_d, const float* w_a, const float* b_a,
                          const float* div_term, const float* wigner_d1, int num_anchors, void* emb, int emb_bf16,
-                         float* eq_emb, void* stream) {
+                         float* eq_emb, void* workspace, size_t workspace_bytes, void* stream) {
   SE3_REQUIRE(points && knn && table_d && table_a && w_d && b_d && w_a && b_a && div_term && emb, SE3_ERR_INVALID_ARG,
               "geo_embedding: null pointer");
   SE3_REQUIRE(N >= 1 && C >= 2 && C % 2 == 0 && d_entries >= 2 && a_entries >= 2, SE3_ERR_INVALID_ARG, "geo_embedding: bad sizes");
@@ -290,6 +476,41 @@ static int geo_embedding(const float* points, const int64_t* knn, int N, int C, 
   P.factor_a = 180.0f / (sigma_a * 3.14159265358979323846f);
   P.d_inv_h = d_entries_per_unit; P.a_inv_h = a_entries_per_unit;
   P.d_entries = d_entries; P.a_entries = a_entries;
+  // channel-slice form when the angle table slice fits in LDS (SE3ET: 418 entries x 256 B) and the caller brought the record workspace;
+  // SE3_GEO_EMB=rows forces the form above
+  const size_t slice_lds = (size_t)a_entries * 16 * sizeof(float4) + (size_t)(kSliceThreads / 64) * 2 * kRecBytes;
+  static const char* form = getenv("SE3_GEO_EMB");
+  if (C % kCS == 0 && slice_lds <= 150 * 1024 && workspace != nullptr && !(form && form[0] == 'r')) {
+    SE3_REQUIRE(workspace_bytes >= se3_geo_embedding_workspace_bytes(N), SE3_ERR_WORKSPACE, "geo_embedding: workspace too small");
+    SE3_REQUIRE((long long)N * N < (1ll << 31) / 4, SE3_ERR_UNSUPPORTED, "geo_embedding: N = %d too large for the record index", N);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(geo_embedding_slice_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(geo_embedding_slice_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      attr_set = true;
+    }
+    const size_t pairs = (size_t)N * N;
+    int4* jrec = static_cast<int4*>(workspace);
+    float4* wrec = reinterpret_cast<float4*>(jrec + pairs);
+    geo_pair_terms_kernel<<<dim3((unsigned)((pairs + 255) / 256), 4u), 256, 0, (hipStream_t)stream>>>(points, knn, N, P, wigner_d1, jrec, wrec,
+                                                                                                    eq_emb, num_anchors);
+    // one workgroup per CU (LDS): row blocks so that slices x blocks is a multiple of the 256 CUs when N allows
+    const int slices = C / kCS;
+    int row_blocks = 256 / slices > 0 ? 256 / slices : 1;
+    if (row_blocks > N) row_blocks = N;
+    const int rows_per_block = (N + row_blocks - 1) / row_blocks;
+    row_blocks = (N + rows_per_block - 1) / rows_per_block;
+    const ExactArgs X{w_d, b_d, w_a, b_a, div_term};
+    const dim3 grid((unsigned)slices, (unsigned)row_blocks);
+    if (emb_bf16)
+      geo_embedding_slice_kernel<true><<<grid, kSliceThreads, slice_lds, (hipStream_t)stream>>>(
+          N, C, reinterpret_cast<const float2*>(table_d), reinterpret_cast<const float2*>(table_a), a_entries, jrec, wrec, X, emb, rows_per_block);
+    else
+      geo_embedding_slice_kernel<false><<<grid, kSliceThreads, slice_lds, (hipStream_t)stream>>>(
+          N, C, reinterpret_cast<const float2*>(table_d), reinterpret_cast<const float2*>(table_a), a_entries, jrec, wrec, X, emb, rows_per_block);
+    SE3_CHECK_LAUNCH("geo_embedding_slice");
+    return SE3_OK;
+  }
   int split = (1024 + N - 1) / N;
   if (split < 1) split = 1;
   if (split > (N + kMB - 1) / kMB) split = (N + kMB - 1) / kMB;
@@ -306,9 +527,10 @@ extern "C" int se3_geo_embedding_fwd(const float* points, const int64_t* knn, in
                                      int d_entries, float d_entries_per_unit, const float* table_a, int a_entries,
                                      float a_entries_per_unit, float sigma_d, float sigma_a, const float* w_d,
                                      const float* b_d, const float* w_a, const float* b_a, const float* div_term,
-                                     const float* wigner_d1, int num_anchors, float* emb, float* eq_emb, void* stream) {
+                                     const float* wigner_d1, int num_anchors, float* emb, float* eq_emb, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
   return geo_embedding(points, knn, N, C, table_d, d_entries, d_entries_per_unit, table_a, a_entries, a_entries_per_unit, sigma_d,
-                       sigma_a, w_d, b_d, w_a, b_a, div_term, wigner_d1, num_anchors, emb, 0, eq_emb, stream);
+                       sigma_a, w_d, b_d, w_a, b_a, div_term, wigner_d1, num_anchors, emb, 0, eq_emb, workspace, workspace_bytes, stream);
 }
 
 extern "C" int se3_geo_embedding_bf16_fwd(const float* points, const int64_t* knn, int N, int C, const float* table_d,
@@ -316,7 +538,7 @@ extern "C" int se3_geo_embedding_bf16_fwd(const float* points, const int64_t* kn
                                           float a_entries_per_unit, float sigma_d, float sigma_a, const float* w_d,
                                           const float* b_d, const float* w_a, const float* b_a, const float* div_term,
                                           const float* wigner_d1, int num_anchors, uint16_t* emb, float* eq_emb,
-                                          void* stream) {
+                                          void* workspace, size_t workspace_bytes, void* stream) {
   return geo_embedding(points, knn, N, C, table_d, d_entries, d_entries_per_unit, table_a, a_entries, a_entries_per_unit, sigma_d,
-                       sigma_a, w_d, b_d, w_a, b_a, div_term, wigner_d1, num_anchors, emb, 1, eq_emb, stream);
+                       sigma_a, w_d, b_d, w_a, b_a, div_term, wigner_d1, num_anchors, emb, 1, eq_emb, workspace, workspace_bytes, stream);
 }

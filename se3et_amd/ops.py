@@ -724,7 +724,7 @@ def cross_attention_eq_stack(q, k, vt, q_starts, q_lengths, k_starts, k_lengths,
 
 
 _EMB_D_RANGE, _EMB_D_PER_UNIT = 64.0, 64.0        # distance-index table: [0, 64) index units, 64 entries per unit
-_EMB_A_PER_UNIT = 64.0
+_EMB_A_PER_UNIT = 32.0                             # angle-index table: a 32-channel slice (418 entries x 256 B) fits in LDS; Hermite error h^4 / 384 |f''''| ~ 2.5e-9 |f''''|
 _emb_table_cache = {}
 
 
@@ -763,6 +763,19 @@ def knn3_stack(points, lengths):
     return knn
 
 
+_emb_ws = {}
+
+
+def _emb_workspace(device, nbytes):
+    """Per-pair record scratch of the embedding kernels, one buffer per launch stream (calls on a stream are ordered)."""
+    key = (device, _stream().value)
+    ws = _emb_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty((max(nbytes, 1 << 24),), dtype=torch.uint8, device=device)
+        _emb_ws[key] = ws
+    return ws
+
+
 def embedding_tables(div_term, w_d, b_d, w_a, b_a, sigma_a):
     """The two validated tables (distance, angle) of a geometric embedding: pass them as `tables=` to several geometric_embedding calls of
     one forward (all clouds of a batch) to validate the weights once instead of once per cloud."""
@@ -796,10 +809,11 @@ def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, 
         eq = torch.empty((A, N, N, 4), dtype=torch.float32, device=points.device)
         wigner_d1 = wigner_d1.detach().contiguous()
     entry = lib().se3_geo_embedding_fwd if dtype == torch.float32 else lib().se3_geo_embedding_bf16_fwd
+    ws = _emb_workspace(points.device, lib().se3_geo_embedding_workspace_bytes(N))
     check(entry(points.data_ptr(), knn.data_ptr(), N, C, tab_d.data_ptr(), tab_d.shape[0], _EMB_D_PER_UNIT, tab_a.data_ptr(),
                 tab_a.shape[0], _EMB_A_PER_UNIT, float(sigma_d), float(sigma_a), w_d.data_ptr(), b_d.data_ptr(), w_a.data_ptr(),
                 b_a.data_ptr(), div_term.data_ptr(), wigner_d1.data_ptr() if eq is not None else None, A, emb.data_ptr(),
-                eq.data_ptr() if eq is not None else None, _stream()), 'se3_geo_embedding_fwd')
+                eq.data_ptr() if eq is not None else None, ws.data_ptr(), ws.numel(), _stream()), 'se3_geo_embedding_fwd')
     return emb if eq is None else (emb, eq)
 
 
