@@ -161,7 +161,7 @@ __global__ void geo_embedding_kernel(const float* __restrict__ pts, const int64_
 // The kernel above reads 64 B of table per 4 B written, all of it from L2 (the tables are far larger than L1): at N = 358 that is
 // 2.1 GB per cloud at the ~15 TB/s the chip gathers from L2 -- 140 us, 0.95 TB/s of output.  Three of the four terms read the ANGLE table
 // (index range 180 / sigma_a + 1 units).  Here the work is split in two kernels:
-//   geo_pair_terms_kernel   one thread per (n, m, term): the index (distance / one of the three angles), its table interval and the four
+//   geo_pair_terms_kernel   one thread per (n, m): the index (distance / one of the three angles), its table interval and the four
 //                           Hermite weights -> a (N N, 4) record array (80 B per pair, L2 / Infinity-Cache resident); also writes Eeq.
 //   geo_embedding_slice_kernel   a workgroup owns kCS = 32 channels and a block of query rows and keeps its slice of the angle table
 //                           (entries x 256 B, 105 KB at 32 entries per unit) in LDS: the three angle terms cost 96 B of ds_read_b128 per
@@ -179,58 +179,63 @@ constexpr int kSliceThreads = 1024;
 constexpr int kRecBlock = 16;                                  // pairs per staged record block
 constexpr int kRecBytes = kRecBlock * (64 + 16);               // weights (4 float4) + intervals (int4) per pair
 
+__device__ __forceinline__ void pair_term_record(float x, float inv_h, int entries, int& j_out, float4& w_out) {
+  const float u = x * inv_h;
+  const int j = (int)floorf(u);
+  const bool ok = (j >= 0) && (j + 1 < entries);
+  const float tt = u - (float)j, h = 1.0f / inv_h;
+  const float t2 = tt * tt, t3 = t2 * tt;
+  j_out = ok ? j : -1;
+  // outside the table: the index itself, for the exact evaluation
+  w_out = ok ? make_float4(2.f * t3 - 3.f * t2 + 1.f, -2.f * t3 + 3.f * t2, h * (t3 - 2.f * t2 + tt), h * (t3 - t2)) : make_float4(x, 0.f, 0.f, 0.f);
+}
+
+// one thread per (n, m): the four indices, their table intervals and Hermite weights (80 contiguous bytes of records), and Eeq
 __global__ __launch_bounds__(256) void geo_pair_terms_kernel(const float* __restrict__ pts, const int64_t* __restrict__ knn, int N,
                                                              EmbParams P, const float* __restrict__ wigner_d1, int4* __restrict__ jrec,
                                                              float4* __restrict__ wrec, float* __restrict__ eq_emb, int A) {
-  const int t = blockIdx.y;                                   // term: 0 = distance, 1..3 = angle to the k-th nearest neighbour
   const unsigned pair = blockIdx.x * 256u + threadIdx.x;
   if (pair >= (unsigned)N * (unsigned)N) return;
   const int n = (int)(pair / (unsigned)N), m = (int)(pair - (unsigned)n * (unsigned)N);
   const float px = pts[3 * n], py = pts[3 * n + 1], pz = pts[3 * n + 2];
   const float qx = pts[3 * m], qy = pts[3 * m + 1], qz = pts[3 * m + 2];
   const float vx = qx - px, vy = qy - py, vz = qz - pz;
-  float x, inv_h;
-  int entries;
-  if (t == 0) {
+  int j[4];
+  float4 w[4];
+  {
     const float nn2 = px * px + py * py + pz * pz;
     const float d2 = fmaxf(nn2 - 2.f * (px * qx + py * qy + pz * qz) + (qx * qx + qy * qy + qz * qz), 0.f);
-    x = sqrtf(d2) * P.sigma_d_inv;
-    inv_h = P.d_inv_h; entries = P.d_entries;
-    if (eq_emb != nullptr) {
-      // unit vector of p_n - p_m (zero vector -> 0, as F.normalize with eps 1e-12)
-      const float len = sqrtf(vx * vx + vy * vy + vz * vz);
-      const float inv = 1.f / fmaxf(len, 1e-12f);
-      const float ux = -vx * inv, uy = -vy * inv, uz = -vz * inv;
-      const float c1 = 0.4886025119029199f;        // sqrt(3 / (4 pi))
-      for (int a = 0; a < A; a++) {
-        const float* D = wigner_d1 + 9 * a;        // D^1_a (3, 3): out_c = sum_d D[c][d] Y1_d
-        float4 o;
-        o.x = 0.28209479177387814f;                // 1 / (2 sqrt(pi))
-        o.y = c1 * (D[0] * ux + D[1] * uy + D[2] * uz);
-        o.z = c1 * (D[3] * ux + D[4] * uy + D[5] * uz);
-        o.w = c1 * (D[6] * ux + D[7] * uy + D[8] * uz);
-        reinterpret_cast<float4*>(eq_emb)[(size_t)a * N * N + pair] = o;
-      }
-    }
-  } else {
-    const int64_t jn = knn[3 * n + (t - 1)];
+    pair_term_record(sqrtf(d2) * P.sigma_d_inv, P.d_inv_h, P.d_entries, j[0], w[0]);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int64_t jn = knn[3 * n + k];
     const float rx = pts[3 * jn] - px, ry = pts[3 * jn + 1] - py, rz = pts[3 * jn + 2] - pz;
     const float cx = ry * vz - rz * vy, cy = rz * vx - rx * vz, cz = rx * vy - ry * vx;
     const float sn = sqrtf(cx * cx + cy * cy + cz * cz);
     float cs = rx * vx + ry * vy + rz * vz;
     cs = (cs == 0.f) ? 0.f : cs;        // see geo_embedding_kernel
-    x = atan2f(sn, cs) * P.factor_a;
-    inv_h = P.a_inv_h; entries = P.a_entries;
+    pair_term_record(atan2f(sn, cs) * P.factor_a, P.a_inv_h, P.a_entries, j[1 + k], w[1 + k]);
   }
-  const float u = x * inv_h;
-  const int j = (int)floorf(u);
-  const bool ok = (j >= 0) && (j + 1 < entries);
-  const float tt = u - (float)j, h = 1.0f / inv_h;
-  const float t2 = tt * tt, t3 = t2 * tt;
-  reinterpret_cast<int*>(jrec)[(size_t)pair * 4 + t] = ok ? j : -1;
-  // outside the table: the index itself, for the exact evaluation
-  wrec[(size_t)pair * 4 + t] = ok ? make_float4(2.f * t3 - 3.f * t2 + 1.f, -2.f * t3 + 3.f * t2, h * (t3 - 2.f * t2 + tt), h * (t3 - t2))
-                                  : make_float4(x, 0.f, 0.f, 0.f);
+  jrec[pair] = make_int4(j[0], j[1], j[2], j[3]);
+#pragma unroll
+  for (int t = 0; t < 4; t++) wrec[(size_t)pair * 4 + t] = w[t];
+  if (eq_emb != nullptr) {
+    // unit vector of p_n - p_m (zero vector -> 0, as F.normalize with eps 1e-12)
+    const float len = sqrtf(vx * vx + vy * vy + vz * vz);
+    const float inv = 1.f / fmaxf(len, 1e-12f);
+    const float ux = -vx * inv, uy = -vy * inv, uz = -vz * inv;
+    const float c1 = 0.4886025119029199f;        // sqrt(3 / (4 pi))
+    for (int a = 0; a < A; a++) {
+      const float* D = wigner_d1 + 9 * a;        // D^1_a (3, 3): out_c = sum_d D[c][d] Y1_d
+      float4 o;
+      o.x = 0.28209479177387814f;                // 1 / (2 sqrt(pi))
+      o.y = c1 * (D[0] * ux + D[1] * uy + D[2] * uz);
+      o.z = c1 * (D[3] * ux + D[4] * uy + D[5] * uz);
+      o.w = c1 * (D[6] * ux + D[7] * uy + D[8] * uz);
+      reinterpret_cast<float4*>(eq_emb)[(size_t)a * N * N + pair] = o;
+    }
+  }
 }
 
 struct ExactArgs { const float *Wd, *bd, *Wa, *ba, *div_term; };    // only the cold path (index outside a table) reads these
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(kSliceThreads) void geo_embedding_slice_kernel(
     int N, int C, const float2* __restrict__ tab_d, const float2* __restrict__ tab_a, int a_entries, const int4* __restrict__ jrec,
     const float4* __restrict__ wrec, ExactArgs X, void* __restrict__ emb_out, int rows_per_block) {
   extern __shared__ __align__(16) float4 lds4[];
-  float4* atab = lds4 + (kSliceThreads / 64) * 2 * (kRecBytes / 16);                  // [a_entries][16]: channels 2 l, 2 l + 1 of the slice
+  float4* atab = lds4 + (kSliceThreads / 64) * 2 * (kRecBytes / 16);                  // [a_entries][16]: (f, f, f', f') of channels 2 l, 2 l + 1
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float4* ring = lds4 + wave * 2 * (kRecBytes / 16);                                  // [2][64 weights | 16 intervals] of this wave
   const int c_base = blockIdx.x * kCS;
@@ -248,7 +253,8 @@ __global__ __launch_bounds__(kSliceThreads) void geo_embedding_slice_kernel(
   if (n0 >= n1) return;
   for (int i = tid; i < a_entries * 16; i += kSliceThreads) {
     const int e = i >> 4, l = i & 15;
-    atab[i] = *reinterpret_cast<const float4*>(tab_a + (size_t)e * C + c_base + 2 * l);
+    const float4 t = *reinterpret_cast<const float4*>(tab_a + (size_t)e * C + c_base + 2 * l);
+    atab[i] = make_float4(t.x, t.z, t.y, t.w);               // (f, f) (f', f') of the two channels: operand pairs of the packed FMAs
   }
   __syncthreads();
   const unsigned first = (unsigned)n0 * (unsigned)N, last = (unsigned)n1 * (unsigned)N;   // the block's pairs: contiguous (n, m) records
@@ -262,11 +268,13 @@ __global__ __launch_bounds__(kSliceThreads) void geo_embedding_slice_kernel(
   const int blocks = (int)((wend - wbeg + kRecBlock - 1) / kRecBlock);
   const int l = lane & 15, grp = lane >> 4, c0 = c_base + 2 * l;
   const float2* dcol = tab_d + c0;
-  const unsigned wlast = last * 4 - 1;
-  // record block b of this wave: lane -> one float4 of the 64 weights, lanes (l, any group) -> interval record l
-#define SE3_REQUEST(b_)                                                                      \
-  rw = wrec[min((wbeg + (unsigned)(b_) * kRecBlock) * 4 + (unsigned)lane, wlast)];          \
-  rj = jrec[min(wbeg + (unsigned)(b_) * kRecBlock + (unsigned)l, last - 1)];
+  // record block b of this wave: lane -> one float4 of the 64 weights, lanes (l, any group) -> interval record l.  Slots past the end of
+  // the run hold the run's LAST pair: those lanes recompute and re-store that pair's values, which keeps every store unconditional (a
+  // store inside a branch makes the number of outstanding vector-memory operations path dependent, and the compiler then drains them
+  // all -- the write acknowledgements included -- in front of every use of a prefetched load)
+#define SE3_REQUEST(b_)                                                                                       \
+  rw = wrec[min(wbeg + (unsigned)(b_) * kRecBlock + (unsigned)(lane >> 2), wend - 1) * 4 + (unsigned)(lane & 3)]; \
+  rj = jrec[min(wbeg + (unsigned)(b_) * kRecBlock + (unsigned)l, wend - 1)];
 #define SE3_PUBLISH(b_)                                                                      \
   {                                                                                          \
     float4* dst = ring + ((b_) & 1) * (kRecBytes / 16);                                      \
@@ -295,10 +303,11 @@ __global__ __launch_bounds__(kSliceThreads) void geo_embedding_slice_kernel(
       const float4* nxt = sub == 3 ? ring + ((blk + 1) & 1) * (kRecBytes / 16) : cur;
       const int4 jn = reinterpret_cast<const int4*>(nxt + 64)[((sub + 1) & 3) * 4 + grp];
       const int jdn = max(jn.x, 0);
-      const float4 dn0 = *reinterpret_cast<const float4*>(dcol + (size_t)jdn * C);
-      const float4 dn1 = *reinterpret_cast<const float4*>(dcol + (size_t)(jdn + 1) * C);
+      const float4 dn0 = *reinterpret_cast<const float4*>(dcol + (unsigned)jdn * (unsigned)C);      // 32-bit offsets (table < 4 GB)
+      const float4 dn1 = *reinterpret_cast<const float4*>(dcol + (unsigned)(jdn + 1) * (unsigned)C);
+      __builtin_amdgcn_sched_barrier(0);      // the store below stays YOUNGER than these loads: waiting for them must not wait for its acknowledgement
       // this iteration: pair = wbeg + 16 blk + 4 sub + grp
-      const unsigned pair = wbeg + (unsigned)(blk * kRecBlock + sub * 4 + grp);
+      const unsigned pair = min(wbeg + (unsigned)(blk * kRecBlock + sub * 4 + grp), wend - 1);
       const float4* wp = cur + (sub * 4 + grp) * 4;
       const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
       const int j1 = max(jc.y, 0), j2 = max(jc.z, 0), j3 = max(jc.w, 0);
@@ -309,9 +318,9 @@ __global__ __launch_bounds__(kSliceThreads) void geo_embedding_slice_kernel(
 #define SE3_HERMITE(w_, f0_, g0_, f1_, g1_) \
   __fadd_rn(__fmaf_rn((w_).x, f0_, __fmul_rn((w_).y, f1_)), __fmaf_rn((w_).z, g0_, __fmul_rn((w_).w, g1_)))
       float x0 = SE3_HERMITE(w0, dc0.x, dc0.y, dc1.x, dc1.y), y0 = SE3_HERMITE(w0, dc0.z, dc0.w, dc1.z, dc1.w);
-      float x1 = SE3_HERMITE(w1, a10.x, a10.y, a11.x, a11.y), y1 = SE3_HERMITE(w1, a10.z, a10.w, a11.z, a11.w);
-      float x2 = SE3_HERMITE(w2, a20.x, a20.y, a21.x, a21.y), y2 = SE3_HERMITE(w2, a20.z, a20.w, a21.z, a21.w);
-      float x3 = SE3_HERMITE(w3, a30.x, a30.y, a31.x, a31.y), y3 = SE3_HERMITE(w3, a30.z, a30.w, a31.z, a31.w);
+      float x1 = SE3_HERMITE(w1, a10.x, a10.z, a11.x, a11.z), y1 = SE3_HERMITE(w1, a10.y, a10.w, a11.y, a11.w);
+      float x2 = SE3_HERMITE(w2, a20.x, a20.z, a21.x, a21.z), y2 = SE3_HERMITE(w2, a20.y, a20.w, a21.y, a21.w);
+      float x3 = SE3_HERMITE(w3, a30.x, a30.z, a31.x, a31.z), y3 = SE3_HERMITE(w3, a30.y, a30.w, a31.y, a31.w);
 #undef SE3_HERMITE
       if ((jc.x | jc.y | jc.z | jc.w) < 0) {                   // cold: an index outside its table (the record then holds the index itself)
         if (jc.x < 0) { x0 = exact_eval(X.Wd, X.bd, X.div_term, C, c0, w0.x); y0 = exact_eval(X.Wd, X.bd, X.div_term, C, c0 + 1, w0.x); }
@@ -321,17 +330,15 @@ __global__ __launch_bounds__(kSliceThreads) void geo_embedding_slice_kernel(
       }
       const float ex = __fadd_rn(x0, fmaxf(fmaxf(x1, x2), x3));
       const float ey = __fadd_rn(y0, fmaxf(fmaxf(y1, y2), y3));
-      if (pair < wend) {
-        const size_t o = (size_t)pair * C + c0;
-        if (BF16) {                                            // round to nearest even (values are finite)
-          unsigned ux = __float_as_uint(ex), uy = __float_as_uint(ey);
-          ux += 0x7fffu + ((ux >> 16) & 1u);
-          uy += 0x7fffu + ((uy >> 16) & 1u);
-          __builtin_nontemporal_store((ux >> 16) | (uy & 0xffff0000u), &emb16[o >> 1]);
-        } else {
-          float2 e2 = make_float2(ex, ey);
-          __builtin_nontemporal_store(*reinterpret_cast<unsigned long long*>(&e2), reinterpret_cast<unsigned long long*>(emb + o));
-        }
+      const size_t o = (size_t)pair * C + c0;
+      if (BF16) {                                              // round to nearest even (values are finite)
+        unsigned ux = __float_as_uint(ex), uy = __float_as_uint(ey);
+        ux += 0x7fffu + ((ux >> 16) & 1u);
+        uy += 0x7fffu + ((uy >> 16) & 1u);
+        __builtin_nontemporal_store((ux >> 16) | (uy & 0xffff0000u), &emb16[o >> 1]);
+      } else {
+        float2 e2 = make_float2(ex, ey);
+        __builtin_nontemporal_store(*reinterpret_cast<unsigned long long*>(&e2), reinterpret_cast<unsigned long long*>(emb + o));
       }
       jc = jn; dc0 = dn0; dc1 = dn1;
     }
@@ -492,7 +499,7 @@ static int geo_embedding(const float* points, const int64_t* knn, int N, int C, 
     const size_t pairs = (size_t)N * N;
     int4* jrec = static_cast<int4*>(workspace);
     float4* wrec = reinterpret_cast<float4*>(jrec + pairs);
-    geo_pair_terms_kernel<<<dim3((unsigned)((pairs + 255) / 256), 4u), 256, 0, (hipStream_t)stream>>>(points, knn, N, P, wigner_d1, jrec, wrec,
+    geo_pair_terms_kernel<<<(unsigned)((pairs + 255) / 256), 256, 0, (hipStream_t)stream>>>(points, knn, N, P, wigner_d1, jrec, wrec,
                                                                                                     eq_emb, num_anchors);
     // one workgroup per CU (LDS): row blocks so that slices x blocks is a multiple of the 256 CUs when N allows
     const int slices = C / kCS;
