@@ -126,6 +126,10 @@ int se3_gather_rows_padded(const float* x, const int64_t* idx, int64_t n, int64_
                            void* stream);
 int se3_neighbor_max_pool(const float* x, const int64_t* idx, int64_t n, int64_t m, int nn, int64_t width, float* out,
                           void* stream);
+/* Backward of se3_neighbor_max_pool (autograd of torch.max over the gathered rows, blocks.py:93-110): dx (n, width) += dout of every row
+ * at its arg-max neighbour (first in table order on ties; nothing for the zero row of padded entries).  dx zero-initialised by the caller. */
+int se3_neighbor_max_pool_bwd(const float* x, const int64_t* idx, const float* dout, int64_t n, int64_t m, int nn, int64_t width,
+                              float* dx, void* stream);
 /* Maximum over the anchor axis (InvOutBlockEPN, geotransformer/modules/e2pn/blocks_epn.py:908-926; the anchor 'amax' between
  * equivariant and invariant transformer blocks, transformer/conditional_transformer.py:282-283,299-302):
  * out[r, c] = max_a x[a * anchor_stride + r * row_stride + c], out (rows, channels) contiguous.  Serves (A, R, C)
@@ -143,6 +147,12 @@ int se3_kpconv_so3_gather(const float* q_pts, const float* s_pts, const int64_t*
                           const float* kernel_points_host, const int64_t* kidx_host, const int64_t* ridx_host, float sigma,
                           int64_t num_queries, int64_t num_support, int num_neighbors, int in_channels, float* G,
                           void* stream);
+/* Backward of that stage with respect to x (training step, experiments/se3ete.3dmatch: autograd through blocks_epn.py:454-546): with
+ * dG = dout @ weights^T (num_queries * 6, 36 Cin) from a library GEMM, dx (num_support, 6, Cin) += gather^T(dG).  dx zero-initialised by
+ * the caller; accumulated with float atomics (summation order = arrival order).  The weight gradient is the library GEMM G^T @ dout. */
+int se3_kpconv_so3_gather_bwd(const float* q_pts, const float* s_pts, const int64_t* idx, const float* dG,
+                              const float* kernel_points_host, const int64_t* kidx_host, const int64_t* ridx_host, float sigma,
+                              int64_t num_queries, int64_t num_support, int num_neighbors, int in_channels, float* dx, void* stream);
 
 /* Matrix-core form of the same convolution (csrc/kpconv_contract.hip), channels multiples of (8, 16): the gather leaves the
  * kernel-point sums F[p, k, a, c] = sum_n w[p, n, k] x[idx[p, n], a, c] in tile order [Cin / 8][ceil16(P)][732] (se3_kpconv_points_floats

@@ -31,7 +31,9 @@ SIGNATURES = {
     'se3_add_layer_norm_fwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _f32, _vp, _vp]),
     'se3_gather_rows_padded': (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     'se3_neighbor_max_pool': (_i32, [_vp, _vp, _i64, _i64, _i32, _i64, _vp, _vp]),
+    'se3_neighbor_max_pool_bwd': (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i64, _vp, _vp]),
     'se3_kpconv_so3_gather': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _i32, _vp, _vp]),
+    'se3_kpconv_so3_gather_bwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _i32, _vp, _vp]),
     'se3_kpconv_so3_gather_points': (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _i32, _vp, _vp]),
     'se3_kpconv_points_floats': (_sz, [_i64, _i32]),
     'se3_kpconv_weight_fragments_bytes': (_sz, [_i32, _i32]),

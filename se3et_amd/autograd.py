@@ -1,7 +1,9 @@
 """Autograd for the HIP ops (BASELINE.json configs[4]).
 
-Forward = the gfx950 kernel, backward = reverse-mode differentiation of a PyTorch restatement of the SAME op, re-evaluated on the GPU
-inside backward ('until a backward kernel exists autograd runs through the PyTorch restatement').  Every
+Forward = the gfx950 kernel.  Backward: hand-written for the ops that dominated the step (KPConv: csrc/kpconv_so3.hip kpconv_scatter_kernel
++ two library GEMMs, 474 -> 5 ms per 5k+5k step; neighbour max-pool; padded row gather -- `hip_backward`), and for the others reverse-mode
+differentiation of a PyTorch restatement of the SAME op, re-evaluated on the GPU inside backward ('until a
+backward kernel exists autograd runs through the PyTorch restatement' -- `differentiable`).  Every
 restatement below is plain torch on GPU tensors -- nothing here runs on the CPU and nothing imports oracle/.  `differentiable(hip_fn,
 torch_fn, *tensors)` is the single mechanism: it calls the kernel under no_grad, keeps the inputs, and in backward builds the torch
 graph of `torch_fn` on detached copies and pulls the incoming gradients through it.  The restatements are pinned twice: forward
@@ -14,6 +16,16 @@ import math
 
 import torch
 import torch.nn.functional as F
+
+
+def _op_name(fn):
+    name = getattr(fn, '__name__', 'op')
+    if name == '<lambda>':       # the restatement the lambda forwards to
+        name = next((n for n in fn.__code__.co_names if n in globals() and callable(globals()[n])), name)
+    return name
+
+
+BACKWARD_TIMINGS = None      # dict op name -> list of (start_event, end_event) while enabled (tools/train_bench.py --profile)
 
 
 class _HipForwardTorchBackward(torch.autograd.Function):
@@ -31,6 +43,18 @@ class _HipForwardTorchBackward(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
+        if BACKWARD_TIMINGS is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            try:
+                return _HipForwardTorchBackward._backward(ctx, *grads)
+            finally:
+                e1.record()
+                BACKWARD_TIMINGS.setdefault(_op_name(ctx.torch_fn), []).append((e0, e1))
+        return _HipForwardTorchBackward._backward(ctx, *grads)
+
+    @staticmethod
+    def _backward(ctx, *grads):
         saved = list(ctx.saved_tensors)
         inputs, it = [], iter(saved)
         for present in ctx.present:
@@ -48,6 +72,35 @@ class _HipForwardTorchBackward(torch.autograd.Function):
         for t in leaves:
             result.append(next(gi) if (t is not None and t.requires_grad) else None)
         return tuple(result)
+
+
+class _HipForwardHipBackward(torch.autograd.Function):
+    """Forward and backward both hand-written: bwd_fn(grad_out, needs, *tensors) -> one gradient (or None) per tensor."""
+
+    @staticmethod
+    def forward(ctx, hip_fn, bwd_fn, name, *tensors):
+        ctx.bwd_fn, ctx.name = bwd_fn, name
+        ctx.save_for_backward(*tensors)
+        with torch.no_grad():
+            return hip_fn(*tensors)
+
+    @staticmethod
+    def backward(ctx, grad):
+        needs = ctx.needs_input_grad[3:]
+        if BACKWARD_TIMINGS is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        with torch.no_grad():
+            got = ctx.bwd_fn(grad, needs, *ctx.saved_tensors)
+        if BACKWARD_TIMINGS is not None:
+            e1.record()
+            BACKWARD_TIMINGS.setdefault(ctx.name + ' (HIP)', []).append((e0, e1))
+        return (None, None, None) + tuple(g if n else None for g, n in zip(got, needs))
+
+
+def hip_backward(hip_fn, bwd_fn, name, *tensors):
+    """hip_fn(*tensors) (one output) with the hand-written backward bwd_fn(grad_out, needs_input_grad, *tensors)."""
+    return _HipForwardHipBackward.apply(hip_fn, bwd_fn, name, *tensors)
 
 
 def needs_grad(*tensors):

@@ -132,6 +132,79 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
   }
 }
 
+// ---- backward with respect to the input features (BASELINE.json configs[4]: the training step) -----------------------------------------
+// Mirror of the gather kernel.  Given dG = dout W^T (the library GEMM on the slot-sum side, (P * 6, 36 Cin)):
+//   dF[k, a, c]     = sum_r dG[p, r, kidx[k, r], ridx[a, r], c]                 (the slot sums run backwards: 36 reads, 90 adds per column)
+//   dx[idx[p, n], a, c] += sum_k w[n, k] dF[k, a, c]                            (hardware float atomics: several queries share a support point)
+// One workgroup per query point, a thread owns feature column (a, c) as in the forward kernel.  The summation order over the queries
+// that share a support point is the arrival order of the atomics (run-to-run differences at f32 round-off level).
+template <bool BUILTIN>
+__global__ __launch_bounds__(256) void kpconv_scatter_kernel(const float* __restrict__ q_pts, const float* __restrict__ s_pts,
+                                                             const int64_t* __restrict__ idx, const float* __restrict__ dG,
+                                                             ConvTables T, float inv_sigma, int64_t P, int64_t Ns, int NN, int Cin,
+                                                             float* __restrict__ dx) {
+  __shared__ float w[kMaxNN][kK + 1];
+  __shared__ int64_t nb[kMaxNN];
+  const int64_t p = blockIdx.x;
+  const int cols = kA * Cin;
+  const float qx = q_pts[3 * p], qy = q_pts[3 * p + 1], qz = q_pts[3 * p + 2];
+  for (int n = threadIdx.x; n < NN; n += blockDim.x) nb[n] = idx[p * NN + n];
+  __syncthreads();
+  for (int e = threadIdx.x; e < NN * kK; e += blockDim.x) {
+    const int n = e / kK, k = e - n * kK;
+    const int64_t j = nb[n];
+    float v = 0.f;
+    if (j >= 0 && j < Ns) {
+      const float dxx = s_pts[3 * j] - qx - T.kp[k][0], dyy = s_pts[3 * j + 1] - qy - T.kp[k][1],
+                  dzz = s_pts[3 * j + 2] - qz - T.kp[k][2];
+      v = fmaxf(0.f, 1.f - sqrtf(dxx * dxx + dyy * dyy + dzz * dzz) * inv_sigma);
+    }
+    w[n][k] = v;
+  }
+  __syncthreads();
+  const float* Gp = dG + p * (int64_t)(kA * kS * kA) * Cin;
+  for (int col = threadIdx.x; col < cols; col += blockDim.x) {
+    const int a = col / Cin, c = col - a * Cin;
+    float f[kK];
+#pragma unroll
+    for (int k = 0; k < kK; k++) f[k] = 0.f;
+#pragma unroll
+    for (int r = 0; r < kA; r++) {
+      int t;
+      if (BUILTIN) {
+        t = 0;
+#pragma unroll
+        for (int aa = 0; aa < kA; aa++) t = a == aa ? kBuiltinRidx[aa][r] : t;
+      } else {
+        t = T.ridx[a][r];
+      }
+      float sv[kS];
+#pragma unroll
+      for (int sl = 0; sl < kS; sl++) sv[sl] = Gp[((int64_t)(r * kS + sl) * kA + t) * Cin + c];
+      if (BUILTIN) {
+#pragma unroll
+        for (int k = 0; k < kK; k++) f[k] += sv[kBuiltinKidx[k][r]];
+      } else {
+#pragma unroll
+        for (int k = 0; k < kK; k++) {
+          float pick = 0.f;
+#pragma unroll
+          for (int sl = 0; sl < kS; sl++) pick = T.kidx[k][r] == sl ? sv[sl] : pick;
+          f[k] += pick;
+        }
+      }
+    }
+    for (int n = 0; n < NN; n++) {
+      const int64_t j = nb[n];
+      if (j < 0 || j >= Ns) continue;               // block-uniform
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < kK; k++) v = fmaf(w[n][k], f[k], v);
+      unsafeAtomicAdd(dx + j * cols + col, v);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int se3_kpconv_so3_gather(const float* q_pts, const float* s_pts, const int64_t* idx, const float* x,
@@ -195,5 +268,47 @@ extern "C" int se3_kpconv_so3_gather_points(const float* q_pts, const float* s_p
   kpconv_gather_kernel<true, true><<<(unsigned)num_queries, threads, 0, (hipStream_t)stream>>>(
       q_pts, s_pts, idx, x, T, 1.0f / sigma, num_queries, num_support, num_neighbors, in_channels, F, P16);
   SE3_CHECK_LAUNCH("kpconv_so3_gather_points");
+  return SE3_OK;
+}
+
+// Backward of the gather + slot-sum stage: dx (num_support, 6, Cin) += transpose of se3_kpconv_so3_gather applied to dG (num_queries * 6,
+// 36 Cin).  dx must be zero-initialised by the caller (accumulated with float atomics).
+extern "C" int se3_kpconv_so3_gather_bwd(const float* q_pts, const float* s_pts, const int64_t* idx, const float* dG,
+                                         const float* kernel_points_host, const int64_t* kidx_host, const int64_t* ridx_host,
+                                         float sigma, int64_t num_queries, int64_t num_support, int num_neighbors, int in_channels,
+                                         float* dx, void* stream) {
+  SE3_REQUIRE(q_pts && s_pts && idx && dG && kernel_points_host && kidx_host && ridx_host && dx, SE3_ERR_INVALID_ARG,
+              "kpconv_so3_gather_bwd: null pointer");
+  SE3_REQUIRE(num_neighbors >= 1 && num_neighbors <= kMaxNN, SE3_ERR_UNSUPPORTED,
+              "kpconv_so3_gather_bwd: %d neighbours (max %d)", num_neighbors, kMaxNN);
+  SE3_REQUIRE(in_channels >= 1 && sigma > 0.f, SE3_ERR_INVALID_ARG, "kpconv_so3_gather_bwd: bad channels/sigma");
+  ConvTables T;
+  bool builtin = true;
+  for (int k = 0; k < kK; k++) {
+    for (int d = 0; d < 3; d++) T.kp[k][d] = kernel_points_host[3 * k + d];
+    for (int r = 0; r < kA; r++) {
+      const int64_t sl = kidx_host[k * kA + r];
+      SE3_REQUIRE(sl >= 0 && sl < kS, SE3_ERR_INVALID_ARG, "kpconv_so3_gather_bwd: kidx out of range");
+      T.kidx[k][r] = (int)sl;
+      builtin = builtin && T.kidx[k][r] == kBuiltinKidx[k][r];
+    }
+  }
+  for (int a = 0; a < kA; a++)
+    for (int r = 0; r < kA; r++) {
+      const int64_t t = ridx_host[a * kA + r];
+      SE3_REQUIRE(t >= 0 && t < kA, SE3_ERR_INVALID_ARG, "kpconv_so3_gather_bwd: ridx out of range");
+      T.ridx[a][r] = (int)t;
+      builtin = builtin && T.ridx[a][r] == kBuiltinRidx[a][r];
+    }
+  if (num_queries == 0) return SE3_OK;
+  const int cols = kA * in_channels;
+  const int threads = cols >= 256 ? 256 : (cols >= 128 ? 128 : 64);
+  if (builtin)
+    kpconv_scatter_kernel<true><<<(unsigned)num_queries, threads, 0, (hipStream_t)stream>>>(
+        q_pts, s_pts, idx, dG, T, 1.0f / sigma, num_queries, num_support, num_neighbors, in_channels, dx);
+  else
+    kpconv_scatter_kernel<false><<<(unsigned)num_queries, threads, 0, (hipStream_t)stream>>>(
+        q_pts, s_pts, idx, dG, T, 1.0f / sigma, num_queries, num_support, num_neighbors, in_channels, dx);
+  SE3_CHECK_LAUNCH("kpconv_so3_gather_bwd");
   return SE3_OK;
 }

@@ -335,6 +335,32 @@ __global__ __launch_bounds__(256) void neighbor_max_kernel(const float* __restri
   }
 }
 
+// Backward of neighbor_max_kernel: the gradient of out[r, c] goes to the neighbour that holds the maximum (the first one in table order on
+// ties, as torch.max(dim) picks a single index; nothing when the maximum is the zero row of a padded entry).  dx is accumulated with
+// hardware float atomics (several rows share a neighbour) and must be zero-initialised by the caller.
+__global__ __launch_bounds__(256) void neighbor_max_bwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
+                                                               const float* __restrict__ dout, int64_t n, int64_t m, int nn,
+                                                               int64_t width, float* __restrict__ dx) {
+  __shared__ int64_t nb[64];
+  const int64_t r = blockIdx.x;
+  for (int j = threadIdx.x; j < nn; j += blockDim.x) nb[j] = idx[r * nn + j];
+  __syncthreads();
+  for (int64_t c = threadIdx.x; c < width; c += blockDim.x) {
+    float best = -INFINITY;
+    int64_t arg = -1;
+    for (int j = 0; j < nn; j++) {
+      const int64_t s = nb[j];
+      if (s < 0) continue;
+      const float v = s < n ? x[s * width + c] : 0.f;
+      if (v > best) {
+        best = v;
+        arg = s;
+      }
+    }
+    if (arg >= 0 && arg < n) unsafeAtomicAdd(dx + arg * width + c, dout[r * width + c]);
+  }
+}
+
 // out[r, c] = max_a x[a * anchor_stride + r * row_stride + c]: the maximum over the anchor axis of (A, R, C) or (R, A, C) features
 // (InvOutBlockEPN, blocks_epn.py:908-926; the 'amax' between equivariant and invariant transformer blocks,
 // conditional_transformer.py:282-283,299-302).  float4 per thread, the A reads of a thread in flight together.
@@ -482,6 +508,16 @@ extern "C" int se3_anchor_max(const float* x, int num_anchors, int64_t rows, int
   anchor_max_kernel<6><<<(unsigned)(blocks > 16384 ? 16384 : blocks), 256, 0, (hipStream_t)stream>>>(x, rows, channels / 4,
                                                                                                   anchor_stride, row_stride, out);
   SE3_CHECK_LAUNCH("anchor_max");
+  return SE3_OK;
+}
+
+extern "C" int se3_neighbor_max_pool_bwd(const float* x, const int64_t* idx, const float* dout, int64_t n, int64_t m, int nn,
+                                         int64_t width, float* dx, void* stream) {
+  SE3_REQUIRE(x && idx && dout && dx && nn >= 1 && nn <= 64, SE3_ERR_INVALID_ARG, "neighbor_max_pool_bwd: bad arguments (nn <= 64)");
+  if (m * width == 0) return SE3_OK;
+  const int threads = width >= 256 ? 256 : (width >= 128 ? 128 : 64);
+  neighbor_max_bwd_kernel<<<(unsigned)m, threads, 0, (hipStream_t)stream>>>(x, idx, dout, n, m, nn, width, dx);
+  SE3_CHECK_LAUNCH("neighbor_max_pool_bwd");
   return SE3_OK;
 }
 

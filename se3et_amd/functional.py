@@ -86,14 +86,21 @@ def anchor_max(x, dim=1):
 def gather_rows_padded(x, idx):
     """x[idx] where idx == x.shape[0] addresses an implicit all-zero row."""
     if AG.needs_grad(x):
-        return AG.differentiable(_ops.gather_rows_padded, AG.gather_rows_padded, 1, x, idx)
+        def bwd(g, needs, x_, idx_):        # rows back onto their sources; the padding row n is dropped (index_add: float atomics)
+            n = x_.shape[0]
+            dx = g.new_zeros((n + 1,) + tuple(x_.shape[1:]))
+            flat = torch.where((idx_ < 0) | (idx_ > n), torch.full_like(idx_, n), idx_).reshape(-1)
+            dx.index_add_(0, flat, g.reshape((-1,) + tuple(x_.shape[1:])))
+            return dx[:n], None
+        return AG.hip_backward(_ops.gather_rows_padded, bwd, 'gather_rows_padded', x, idx)
     return _ops.gather_rows_padded(x, idx)
 
 
 def neighbor_max_pool(x, idx):
     """max over the neighbour rows of x (P_s, ...) for each query (idx (P_q, NN), padding row = zeros)."""
     if AG.needs_grad(x):
-        return AG.differentiable(_ops.neighbor_max_pool, AG.neighbor_max_pool, 1, x, idx)
+        return AG.hip_backward(_ops.neighbor_max_pool, lambda g, needs, x_, idx_: (_ops.neighbor_max_pool_bwd(x_, idx_, g), None),
+                               'neighbor_max_pool', x, idx)
     return _ops.neighbor_max_pool(x, idx)
 
 
@@ -142,9 +149,11 @@ def group_norm_rows(x, weight, bias, groups, eps, leaky_slope=None, residual=Non
 
 def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, sigma):
     if AG.needs_grad(x, weights):
-        return AG.differentiable(lambda x_, w: _ops.kpconv_inter_so3(x_, q_pts, s_pts, idx, kernel_points, w, kidx, ridx, sigma),
-                                 lambda x_, w: AG.kpconv_inter_so3(x_, q_pts, s_pts, idx, kernel_points.detach(), w, kidx, ridx, sigma),
-                                 1, x, weights)
+        # hand-written backward (csrc/kpconv_so3.hip: kpconv_scatter_kernel + two library GEMMs); AG.kpconv_inter_so3 is its torch pin
+        return AG.hip_backward(lambda x_, w: _ops.kpconv_inter_so3(x_, q_pts, s_pts, idx, kernel_points, w, kidx, ridx, sigma),
+                               lambda g, needs, x_, w: _ops.kpconv_inter_so3_bwd(g, x_, q_pts, s_pts, idx, kernel_points, w, kidx, ridx, sigma,
+                                                                                 need_x=needs[0], need_w=needs[1]),
+                               'kpconv_inter_so3', x, weights)
     return _ops.kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, sigma)
 
 

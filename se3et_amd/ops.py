@@ -270,6 +270,19 @@ def neighbor_max_pool(x, idx):
     return out
 
 
+def neighbor_max_pool_bwd(x, idx, grad_out):
+    """HIP (csrc/rowops.hip): gradient of neighbor_max_pool with respect to x (to the arg-max neighbour of every output element)."""
+    x = _req(x.contiguous(), torch.float32, 'x')
+    idx = _req(idx.contiguous(), torch.int64, 'idx', 2)
+    g = _req(grad_out.contiguous(), torch.float32, 'grad_out')
+    n = x.shape[0]
+    width = x.numel() // max(n, 1)
+    dx = torch.zeros_like(x)
+    check(lib().se3_neighbor_max_pool_bwd(x.data_ptr(), idx.data_ptr(), g.data_ptr(), n, idx.shape[0], idx.shape[1], width, dx.data_ptr(),
+                                          _stream()), 'se3_neighbor_max_pool_bwd')
+    return dx
+
+
 _gn_workspace = {}       # (device, stream) -> partial-statistics workspace
 
 
@@ -351,6 +364,46 @@ def _builtin_slot_tables(kt, rt):
             _builtin_checked.clear()
         _builtin_checked[key] = hit
     return hit
+
+
+def kpconv_slot_sums(x, q_pts, s_pts, idx, kernel_points, kidx, ridx, sigma):
+    """HIP (csrc/kpconv_so3.hip): G (P * 6, 36 Cin), the slot-summed neighbourhood features with out = G @ weights.reshape(36 Cin, Cout)."""
+    x = _req(x.contiguous(), torch.float32, 'x', 3)
+    q_pts, s_pts = _req(q_pts.contiguous(), torch.float32, 'q_pts', 2), _req(s_pts.contiguous(), torch.float32, 's_pts', 2)
+    idx = _req(idx.contiguous(), torch.int64, 'neighb_inds', 2)
+    P, NN = idx.shape
+    Ns, A, Cin = x.shape
+    kp, kt, rt = _host_table(kernel_points, torch.float32), _host_table(kidx, torch.int64), _host_table(ridx, torch.int64)
+    G = torch.empty((P * 6, 36 * Cin), dtype=torch.float32, device=x.device)
+    check(lib().se3_kpconv_so3_gather(q_pts.data_ptr(), s_pts.data_ptr(), idx.data_ptr(), x.data_ptr(), kp.data_ptr(),
+                                      kt.data_ptr(), rt.data_ptr(), float(sigma), P, Ns, NN, Cin, G.data_ptr(), _stream()),
+          'se3_kpconv_so3_gather')
+    return G
+
+
+def kpconv_inter_so3_bwd(grad_out, x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, sigma, need_x=True, need_w=True):
+    """Gradients of kpconv_inter_so3 with respect to (x, weights): two library GEMMs on the slot-sum matrix (dW = G^T dout, dG = dout W^T)
+    and the HIP transpose of the gather (csrc/kpconv_so3.hip: kpconv_scatter_kernel)."""
+    x = _req(x.contiguous(), torch.float32, 'x', 3)
+    q_pts, s_pts = _req(q_pts.contiguous(), torch.float32, 'q_pts', 2), _req(s_pts.contiguous(), torch.float32, 's_pts', 2)
+    idx = _req(idx.contiguous(), torch.int64, 'neighb_inds', 2)
+    P, NN = idx.shape
+    Ns, A, Cin = x.shape
+    Cout = weights.shape[-1]
+    d2 = _req(grad_out.contiguous(), torch.float32, 'grad_out').reshape(P * 6, Cout)
+    dx = dw = None
+    if need_w:
+        G = kpconv_slot_sums(x, q_pts, s_pts, idx, kernel_points, kidx, ridx, sigma)
+        dw = mm(G.t(), d2).view(6, 6, Cin, Cout)
+        del G
+    if need_x:
+        kp, kt, rt = _host_table(kernel_points, torch.float32), _host_table(kidx, torch.int64), _host_table(ridx, torch.int64)
+        dG = mm(d2, weights.detach().reshape(36 * Cin, Cout).t())
+        dx = torch.zeros_like(x)
+        check(lib().se3_kpconv_so3_gather_bwd(q_pts.data_ptr(), s_pts.data_ptr(), idx.data_ptr(), dG.data_ptr(), kp.data_ptr(),
+                                              kt.data_ptr(), rt.data_ptr(), float(sigma), P, Ns, NN, Cin, dx.data_ptr(), _stream()),
+              'se3_kpconv_so3_gather_bwd')
+    return dx, dw
 
 
 def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, sigma):

@@ -145,3 +145,55 @@ def test_gradients_of_one_wrapped_op_against_finite_differences():
         fd = ((f(x + eps * dx, w + eps * dw) - f(x - eps * dx, w - eps * dw)) * c).sum() / (2 * eps)
     an = (x.grad * dx).sum() + (w.grad * dw).sum()
     assert abs(float(fd) - float(an)) <= 2e-3 * abs(float(an)), (float(fd), float(an))
+
+
+@pytest.mark.parametrize('P,Ns,NN,Cin,Cout,strided', [(300, 400, 20, 16, 16, True), (257, 257, 33, 32, 64, False), (130, 130, 38, 24, 40, False)])
+def test_hand_written_backward_kernels_match_the_restatement_gradients(P, Ns, NN, Cin, Cout, strided):
+    """KPConv (csrc/kpconv_so3.hip: kpconv_scatter_kernel + two GEMMs), neighbour max-pool and padded row gather: gradients of the
+    hand-written backward against autograd through the PyTorch restatements (se3et_amd/autograd.py), padded neighbour tables included."""
+    from se3et_amd import autograd as AG
+    from se3et_amd import functional as SF
+    from se3et_amd import tables
+    g = torch.Generator().manual_seed(31 + P)
+    dev = 'cuda'
+    rn = lambda *s: torch.randn(*s, generator=g).to(dev)
+    s_pts = (torch.rand(Ns, 3, generator=g) * 0.3).to(dev)
+    q_pts = s_pts[:P].contiguous()
+    d = ((q_pts[:, None] - s_pts[None]) ** 2).sum(-1)
+    idx = d.topk(NN, dim=1, largest=False)[1]
+    idx[d.gather(1, idx) > 0.0625 ** 2] = Ns                       # padded entries
+    kp = torch.from_numpy(tables.kernel_points(0.0625)).to(dev)
+    kidx, ridx = torch.from_numpy(tables.kernel_slot_table()).to(dev), torch.from_numpy(tables.anchor_slot_table()).to(dev)
+    x0, w0 = rn(Ns, 6, Cin), rn(6, 6, Cin, Cout) / (36 * Cin) ** 0.5
+    c = rn(P, 6, Cout)
+    grads = []
+    for fn in (SF.kpconv_inter_so3, AG.kpconv_inter_so3):
+        x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+        (fn(x, q_pts, s_pts, idx, kp, w, kidx, ridx, 0.05) * c).sum().backward()
+        grads.append((x.grad, w.grad))
+    assert_close(grads[0][0], grads[1][0], 2e-5, 'kpconv dL/dx')
+    assert_close(grads[0][1], grads[1][1], 2e-5, 'kpconv dL/dW')
+    # only one of the two gradients requested
+    x = x0.clone().requires_grad_(True)
+    (SF.kpconv_inter_so3(x, q_pts, s_pts, idx, kp, w0, kidx, ridx, 0.05) * c).sum().backward()
+    assert_close(x.grad, grads[1][0], 2e-5, 'kpconv dL/dx alone')
+    w = w0.clone().requires_grad_(True)
+    (SF.kpconv_inter_so3(x0, q_pts, s_pts, idx, kp, w, kidx, ridx, 0.05) * c).sum().backward()
+    assert_close(w.grad, grads[1][1], 2e-5, 'kpconv dL/dW alone')
+    # max-pool and padded gather
+    c2 = rn(P, 6, Cin)
+    for name, hip, ref in (('max pool', SF.neighbor_max_pool, AG.neighbor_max_pool),):
+        got = []
+        for fn in (hip, ref):
+            x = x0.clone().requires_grad_(True)
+            (fn(x, idx) * c2).sum().backward()
+            got.append(x.grad)
+        assert_close(got[0], got[1], 1e-6, name + ' dL/dx')
+    idx1 = idx[:, 0].clone()
+    idx1[::7] = Ns
+    got = []
+    for fn in (SF.gather_rows_padded, AG.gather_rows_padded):
+        x = x0.clone().requires_grad_(True)
+        (fn(x, idx1) * c2).sum().backward()
+        got.append(x.grad)
+    assert_close(got[0], got[1], 1e-6, 'padded gather dL/dx')

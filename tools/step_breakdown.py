@@ -1,0 +1,20 @@
+"""GPU time per bench step by kernel family, from a rocprofv3 kernel_stats CSV of `bench.py --no-cpu-baseline --single-pair-steps 0`
+(25 steps): python tools/step_breakdown.py <kernel_stats.csv> [steps]"""
+import csv, sys
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 25
+fam = [('Cijk_', 'library GEMM'), ('gn_', 'GroupNorm'), ('kpconv_gather', 'KPConv gather'), ('kpconv_contract', 'KPConv contract'),
+       ('kpconv_split', 'KPConv contract'), ('rpe_bias', 'RPE logits'), ('attention_kernel', 'attention'), ('cross_eq', 'cross_eq'),
+       ('geo_', 'geo embedding'), ('embedding_table', 'geo embedding'), ('knn3', 'geo embedding'), ('sinkhorn', 'sinkhorn'),
+       ('radius_', 'radius search'), ('grid_', 'grid subsample'), ('order_kernel', 'grid subsample'), ('neighbor_max', 'neighbor max'),
+       ('add_ln', 'layer norm'), ('elementwise', 'torch elementwise'), ('at::native', 'torch other'), ('rocclr', 'copies / fills')]
+tot = {}
+rows = list(csv.reader(open(sys.argv[1])))[1:]
+for r in rows:
+    name, ns = r[0], float(r[2])
+    if 'MT256x256x16' in name and int(r[1]) < 5: continue       # the clock ramp-up GEMM of bench.py
+    key = next((f for s, f in fam if s in name), 'other HIP kernels')
+    tot[key] = tot.get(key, 0.0) + ns
+s = sum(tot.values())
+for k, v in sorted(tot.items(), key=lambda kv: -kv[1]):
+    print('%-20s %7.2f ms/step  %5.1f %%' % (k, v / steps / 1e6, 100 * v / s))
+print('%-20s %7.2f ms/step' % ('total', s / steps / 1e6))

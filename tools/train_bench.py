@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--variant', default='se3ete')
     ap.add_argument('--pair', default='c2_5k')
+    ap.add_argument('--profile', action='store_true', help='GPU time of the backward of each HIP op (HIP events), one extra step')
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         import bench
@@ -63,7 +64,25 @@ def main():
         print(json.dumps({'metric': 'training step (fwd + bwd + Adam), %s on %s pairs' % (args.variant, args.pair), 's_per_step': round(dt / args.steps, 4),
                           'pairs_per_s': round(world * args.steps / dt, 3), 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                           'loss': float(losses['loss'].detach()), 'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
-                          'backward': 'PyTorch restatements on the GPU (se3et_amd/autograd.py)', 'data': 'synthetic'}), flush=True)
+                          'backward': 'HIP kernels for KPConv / max-pool / row gather, PyTorch restatements on the GPU for the other ops (se3et_amd/autograd.py)', 'data': 'synthetic'}), flush=True)
+    if args.profile and rank == 0:
+        from se3et_amd import autograd as AG
+        AG.BACKWARD_TIMINGS = {}
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        dd = registration_collate_fn_stack_mode([batches[0]], b.num_stages, b.init_voxel_size, b.init_radius, cfg.neighbor_limits, device=dev)
+        opt.zero_grad(set_to_none=True)
+        e0.record()
+        out = net(dd, train=True, rng=rng)
+        loss = loss_fn(out, dd)['loss']
+        e1.record()
+        loss.backward()
+        e2.record()
+        torch.cuda.synchronize()
+        print('forward + loss %.1f ms, backward %.1f ms' % (e0.elapsed_time(e1), e1.elapsed_time(e2)))
+        rows = sorted(((sum(a.elapsed_time(bb) for a, bb in v), len(v), k) for k, v in AG.BACKWARD_TIMINGS.items()), reverse=True)
+        for ms, n, k in rows:
+            print('  backward of %-24s x%-3d %8.1f ms' % (k, n, ms))
+        AG.BACKWARD_TIMINGS = None
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
