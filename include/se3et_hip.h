@@ -108,6 +108,14 @@ int se3_group_norm_segments_fwd(const float* x, const float* x_bias, const float
                                 const float* bias, int64_t rows, int channels, int groups,
                                 const int64_t* segment_row_offsets_host, int num_segments, float eps, int apply_leaky_relu,
                                 float slope, float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* Backward of se3_group_norm_segments_fwd (training step: autograd of GroupNormEPN / F.leaky_relu, blocks_epn.py:684-701): grad_x (rows,
+ * channels); grad_residual (rows, channels) or NULL; grad_params (num_segments, 3, channels) = every segment's contribution to (d weight,
+ * d bias, d x_bias), summed over segments by the caller.  workspace: se3_group_norm_bwd_workspace_bytes(channels) bytes. */
+size_t se3_group_norm_bwd_workspace_bytes(int channels);
+int se3_group_norm_segments_bwd(const float* x, const float* x_bias, const float* residual, const float* weight, const float* bias,
+                                const float* grad_out, int64_t rows, int channels, int groups, const int64_t* segment_row_offsets_host,
+                                int num_segments, float eps, int apply_leaky_relu, float slope, float* grad_x, float* grad_residual,
+                                float* grad_params, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- D6: LayerNorm(hidden + residual) ---------------------------------------------------------------------------
  * Replaces the residual + nn.LayerNorm tails of geotransformer/modules/transformer/rpe_transformer.py:163-164,

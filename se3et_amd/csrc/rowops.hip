@@ -162,7 +162,8 @@ __global__ __launch_bounds__(256) void gn_partial4_kernel(const float* __restric
 // map of every channel, y = x * scale[c] + shift[c] with scale = rstd_g w[c], shift = b[c] + (xb[c] - mean_g) scale.
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ xb,
                                                           const float* __restrict__ gw, const float* __restrict__ gb, int C,
-                                                          int groups, SegTable T, float eps, float* __restrict__ affine) {
+                                                          int groups, SegTable T, float eps, float* __restrict__ affine,
+                                                          float* __restrict__ stats = nullptr) {
   __shared__ WF sh[256];
   __shared__ float mean_s, rstd_s;
   const int g = blockIdx.x, cpg = C / groups, seg = blockIdx.y;
@@ -192,6 +193,10 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     const WF r = sh[0];
     mean_s = r.mean;
     rstd_s = 1.0f / sqrtf(r.m2 / r.n + eps);
+    if (stats) {                               // (mean of x + xb, rstd, element count) of (segment, group): the backward pass reads them
+      float* st = stats + ((size_t)seg * groups + g) * 3;
+      st[0] = mean_s; st[1] = rstd_s; st[2] = r.n;
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < cpg; i += 256) {
@@ -237,6 +242,122 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
       if (has_slope) t = t > 0.f ? t : t * slope;
       y[i] = t;
     }
+  }
+}
+
+// ---- GroupNorm backward (training step) ------------------------------------------------------------------------------------------------
+// y = lrelu(xhat w + b [+ res]),  xhat = (x + xb - mean_g) rstd_g  per (segment, group).  With dz = dy lrelu'(.):
+//   dres = dz,   db[c] = sum_r dz,   dw[c] = sum_r dz xhat,
+//   dx   = rstd (w dz - mean_g(w dz) - xhat mean_g(w dz xhat)) = a[c] dz + e x + f[c],   dxb[c] = sum_r dx.
+// Three passes: the forward statistics again (partial + finalize), per-chunk channel sums (sum dz, sum dz x, sum x), apply.
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                             const float* __restrict__ dout, const float* __restrict__ affine_all,
+                                                             SegTable T, int C, int has_slope, float slope, float* __restrict__ part) {
+  __shared__ float sh[4][64][3];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  long long r0, r1;
+  chunk_rows(T, blockIdx.x, r0, r1);
+  const float* affine = affine_all + (size_t)seg_of_chunk(T, blockIdx.x) * 2 * C;
+  float s1 = 0.f, t2 = 0.f, s4 = 0.f;
+  if (c < C) {
+    const float sc = affine[c], sf = affine[C + c];
+    for (long long r = r0 + rl; r < r1; r += 4) {
+      const float xv = x[r * C + c];
+      float dz = dout[r * C + c];
+      if (has_slope) {
+        const float pre = xv * sc + sf + (res ? res[r * C + c] : 0.f);
+        dz = pre > 0.f ? dz : dz * slope;
+      }
+      s1 += dz;
+      t2 = fmaf(dz, xv, t2);
+      s4 += xv;
+    }
+  }
+  sh[rl][cl][0] = s1; sh[rl][cl][1] = t2; sh[rl][cl][2] = s4;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float* p = part + ((int64_t)blockIdx.x * C + c) * 3;
+#pragma unroll
+    for (int k = 0; k < 3; k++) p[k] = (sh[0][cl][k] + sh[1][cl][k]) + (sh[2][cl][k] + sh[3][cl][k]);
+  }
+}
+
+// per (group, segment): channel sums over the segment's chunks -> the coefficients of the apply pass and the segment's contribution to
+// (dweight, dbias, dxbias): params[seg][0..2][C]
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ xb,
+                                                              const float* __restrict__ gw, const float* __restrict__ stats, int C,
+                                                              int groups, SegTable T, float* __restrict__ coef,
+                                                              float* __restrict__ params) {
+  __shared__ float red[2][256];
+  const int g = blockIdx.x, cpg = C / groups, seg = blockIdx.y;
+  int cb = T.chunk_begin[0], ce = T.chunk_begin[1];
+  long long rb = T.row_begin[0], re = T.row_begin[1];
+#pragma unroll
+  for (int i = 1; i < kGNMaxSegments; i++)
+    if (seg == i) {
+      cb = T.chunk_begin[i]; ce = T.chunk_begin[i + 1];
+      rb = T.row_begin[i]; re = T.row_begin[i + 1];
+    }
+  const float* st = stats + ((size_t)seg * groups + g) * 3;
+  const float mean = st[0], rstd = st[1], n = st[2], nrows = (float)(re - rb);
+  coef += (size_t)seg * 3 * C;
+  params += (size_t)seg * 3 * C;
+  float a1 = 0.f, a2 = 0.f;                     // this thread's share of sum_c w S1, sum_c w S2
+  for (int i = threadIdx.x; i < cpg; i += 256) {
+    const int c = g * cpg + i;
+    float s1 = 0.f, t2 = 0.f, s4 = 0.f;
+    for (int ch = cb; ch < ce; ch++) {
+      const float* p = part + ((int64_t)ch * C + c) * 3;
+      s1 += p[0]; t2 += p[1]; s4 += p[2];
+    }
+    const float shift = (xb ? xb[c] : 0.f) - mean;
+    const float s2 = rstd * (t2 + shift * s1);                 // sum dz xhat
+    params[c] = s2;                                            // dweight
+    params[C + c] = s1;                                        // dbias
+    params[2 * C + c] = s4;                                    // sum x: turned into dxbias below
+    a1 = fmaf(gw[c], s1, a1);
+    a2 = fmaf(gw[c], s2, a2);
+  }
+  red[0][threadIdx.x] = a1; red[1][threadIdx.x] = a2;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + s];
+      red[1][threadIdx.x] += red[1][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  const float m1 = red[0][0] / n, m2 = red[1][0] / n;
+  for (int i = threadIdx.x; i < cpg; i += 256) {
+    const int c = g * cpg + i;
+    const float shift = (xb ? xb[c] : 0.f) - mean;
+    const float a = rstd * gw[c], e = -rstd * rstd * m2, f = -rstd * m1 + e * shift;
+    coef[c] = a; coef[C + c] = e; coef[2 * C + c] = f;
+    params[2 * C + c] = a * params[C + c] + e * params[2 * C + c] + f * nrows;     // dxbias = sum_r dx
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                           const float* __restrict__ dout, const float* __restrict__ affine_all,
+                                                           const float* __restrict__ coef_all, SegTable T, int64_t rows, int C,
+                                                           int has_slope, float slope, float* __restrict__ dx,
+                                                           float* __restrict__ dres) {
+  const int64_t total = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / C;
+    const int c = (int)(i - row * C);
+    const int seg = T.n > 1 ? seg_of_row(T, row) : 0;
+    const float* affine = affine_all + (size_t)seg * 2 * C;
+    const float* coef = coef_all + (size_t)seg * 3 * C;
+    const float xv = x[i];
+    float dz = dout[i];
+    if (has_slope) {
+      const float pre = xv * affine[c] + affine[C + c] + (res ? res[i] : 0.f);
+      dz = pre > 0.f ? dz : dz * slope;
+    }
+    dx[i] = coef[c] * dz + coef[C + c] * xv + coef[2 * C + c];
+    if (dres) dres[i] = dz;
   }
 }
 
@@ -453,6 +574,67 @@ extern "C" int se3_group_norm_segments_fwd(const float* x, const float* x_bias, 
   const int64_t work = (channels % 4 == 0) ? rows * channels / 4 : rows * channels;
   gn_apply_kernel<<<grid_for(work, 256), 256, 0, st>>>(x, residual, affine, T, rows, channels, apply_leaky_relu, slope, out);
   SE3_CHECK_LAUNCH("group_norm");
+  return SE3_OK;
+}
+
+// Backward of se3_group_norm_segments_fwd.  grad_x (rows, C); grad_residual (rows, C) or NULL; grad_params (num_segments, 3, C): every
+// segment's contribution to (d weight, d bias, d x_bias) -- the caller sums over segments.  Workspace: se3_group_norm_bwd_workspace_bytes.
+extern "C" size_t se3_group_norm_bwd_workspace_bytes(int channels) {
+  return se3_group_norm_workspace_bytes(0, channels, 1) + (size_t)((kGNMaxChunks + kGNMaxSegments) * channels * 3 + kGNMaxSegments * 6 * channels) * sizeof(float);
+}
+
+extern "C" int se3_group_norm_segments_bwd(const float* x, const float* x_bias, const float* residual, const float* weight,
+                                           const float* bias, const float* grad_out, int64_t rows, int channels, int groups,
+                                           const int64_t* segment_row_offsets_host, int num_segments, float eps, int apply_leaky_relu,
+                                           float slope, float* grad_x, float* grad_residual, float* grad_params, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+  SE3_REQUIRE(x && weight && bias && grad_out && grad_x && grad_params && workspace, SE3_ERR_INVALID_ARG, "group_norm_bwd: null pointer");
+  SE3_REQUIRE(rows >= 1 && channels >= 1 && groups >= 1 && channels % groups == 0, SE3_ERR_INVALID_ARG,
+              "group_norm_bwd: rows %lld channels %d groups %d", (long long)rows, channels, groups);
+  SE3_REQUIRE(num_segments >= 1 && num_segments <= kGNMaxSegments && (num_segments == 1 || segment_row_offsets_host),
+              SE3_ERR_UNSUPPORTED, "group_norm_bwd: %d segments (1..%d)", num_segments, kGNMaxSegments);
+  SE3_REQUIRE(workspace_bytes >= se3_group_norm_bwd_workspace_bytes(channels), SE3_ERR_WORKSPACE, "group_norm_bwd: workspace too small");
+  SegTable T{};
+  T.n = num_segments;
+  const int cap = kGNMaxChunks / num_segments > 8 ? kGNMaxChunks / num_segments : 8;
+  int chunks = 0;
+  for (int sgm = 0; sgm < num_segments; sgm++) {
+    const int64_t b0 = num_segments == 1 ? 0 : segment_row_offsets_host[sgm];
+    const int64_t b1 = num_segments == 1 ? rows : segment_row_offsets_host[sgm + 1];
+    SE3_REQUIRE(b1 > b0 && b0 >= 0 && b1 <= rows, SE3_ERR_INVALID_ARG, "group_norm_bwd: segment %d rows [%lld, %lld)", sgm,
+                (long long)b0, (long long)b1);
+    T.row_begin[sgm] = b0;
+    T.row_begin[sgm + 1] = b1;
+    T.chunk_begin[sgm] = chunks;
+    chunks += (int)gn_chunks(b1 - b0, channels, cap);
+    T.chunk_begin[sgm + 1] = chunks;
+  }
+  SE3_REQUIRE(T.row_begin[0] == 0 && T.row_begin[num_segments] == rows, SE3_ERR_INVALID_ARG,
+              "group_norm_bwd: the segments must cover all rows");
+  const size_t part_floats = (size_t)(kGNMaxChunks + kGNMaxSegments) * channels * 3;
+  float* part = (float*)workspace;
+  float* affine = part + part_floats;
+  float* stats = affine + (size_t)kGNMaxSegments * 2 * channels;       // (segments, groups, 3): groups <= channels
+  float* bpart = stats + (size_t)kGNMaxSegments * 3 * channels + 64;
+  float* coef = bpart + part_floats;
+  hipStream_t st = (hipStream_t)stream;
+  // 1. the forward statistics
+  if (gn_fast_path(channels) && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    gn_partial4_kernel<<<(unsigned)chunks, 256, 0, st>>>(x, T, channels, part);
+  } else {
+    dim3 g1((unsigned)chunks, (unsigned)se3_cdiv(channels, kGNLanes));
+    gn_partial_kernel<<<g1, kGNLanes * kGNRows, 0, st>>>(x, T, channels, part);
+  }
+  gn_finalize_kernel<<<dim3((unsigned)groups, (unsigned)num_segments), 256, 0, st>>>(part, x_bias, weight, bias, channels, groups, T, eps,
+                                                                                      affine, stats);
+  // 2. channel sums of the incoming gradient, 3. coefficients, 4. apply
+  gn_bwd_partial_kernel<<<dim3((unsigned)chunks, (unsigned)se3_cdiv(channels, 64)), 256, 0, st>>>(x, residual, grad_out, affine, T, channels,
+                                                                                                 apply_leaky_relu, slope, bpart);
+  gn_bwd_finalize_kernel<<<dim3((unsigned)groups, (unsigned)num_segments), 256, 0, st>>>(bpart, x_bias, weight, stats, channels, groups, T,
+                                                                                          coef, grad_params);
+  gn_bwd_apply_kernel<<<grid_for(rows * channels, 256), 256, 0, st>>>(x, residual, grad_out, affine, coef, T, rows, channels,
+                                                                     apply_leaky_relu, slope, grad_x, grad_residual);
+  SE3_CHECK_LAUNCH("group_norm_bwd");
   return SE3_OK;
 }
 

@@ -141,9 +141,12 @@ def group_norm_rows(x, weight, bias, groups, eps, leaky_slope=None, residual=Non
                 mult = x.numel() // x.shape[-1] // x.shape[0]
                 segments = [o * mult for o in offs]
     if AG.needs_grad(x, weight, bias, residual, x_bias):
-        return AG.differentiable(lambda x_, w, b, r, xb: _ops.group_norm_rows(x_, w, b, groups, eps, leaky_slope, r, xb, segments),
-                                 lambda x_, w, b, r, xb: AG.group_norm_rows(x_, w, b, r, xb, groups, eps, leaky_slope, segments),
-                                 1, x, weight, bias, residual, x_bias)
+        # hand-written backward (csrc/rowops.hip: gn_bwd_*); AG.group_norm_rows is its torch pin
+        def bwd(g, needs, x_, w, b, r, xb):
+            dx, dw, db, dr, dxb = _ops.group_norm_rows_bwd(g, x_, w, b, groups, eps, leaky_slope, r, xb, segments)
+            return dx, dw, db, dr, dxb
+        return AG.hip_backward(lambda x_, w, b, r, xb: _ops.group_norm_rows(x_, w, b, groups, eps, leaky_slope, r, xb, segments), bwd,
+                               'group_norm_rows', x, weight, bias, residual, x_bias)
     return _ops.group_norm_rows(x, weight, bias, groups, eps, leaky_slope, residual, x_bias, segments)
 
 

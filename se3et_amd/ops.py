@@ -314,6 +314,35 @@ def group_norm_rows(x, weight, bias, groups, eps, leaky_slope, residual, x_bias=
     return out
 
 
+def group_norm_rows_bwd(grad_out, x, weight, bias, groups, eps, leaky_slope, residual, x_bias=None, segments=None):
+    """HIP (csrc/rowops.hip): gradients of group_norm_rows -> (dx, dweight, dbias, dresidual or None, dx_bias or None)."""
+    x = _req(x.contiguous(), torch.float32, 'x')
+    g = _req(grad_out.contiguous(), torch.float32, 'grad_out')
+    C = x.shape[-1]
+    rows = x.numel() // C
+    if residual is not None:
+        residual = _req(residual.contiguous(), torch.float32, 'residual')
+    ws_bytes = lib().se3_group_norm_bwd_workspace_bytes(C)
+    stream = _stream()
+    key = (x.device, stream.value, 'bwd')
+    ws = _gn_workspace.get(key)
+    if ws is None or ws.numel() < ws_bytes:
+        ws = torch.empty((max(ws_bytes, 1 << 22),), dtype=torch.uint8, device=x.device)
+        _gn_workspace[key] = ws
+    nseg = 1 if segments is None else len(segments) - 1
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if residual is not None else None
+    params = torch.empty((nseg, 3, C), dtype=torch.float32, device=x.device)
+    check(lib().se3_group_norm_segments_bwd(x.data_ptr(), x_bias.data_ptr() if x_bias is not None else None,
+                                            residual.data_ptr() if residual is not None else None, weight.data_ptr(), bias.data_ptr(),
+                                            g.data_ptr(), rows, C, int(groups), _i64_array(segments) if nseg > 1 else None, nseg, float(eps),
+                                            1 if leaky_slope is not None else 0, float(leaky_slope or 0.0), dx.data_ptr(),
+                                            dres.data_ptr() if dres is not None else None, params.data_ptr(), ws.data_ptr(), ws.numel(),
+                                            stream), 'se3_group_norm_segments_bwd')
+    params = params.sum(0) if nseg > 1 else params[0]
+    return dx, params[0], params[1], dres, (params[2] if x_bias is not None else None)
+
+
 _host_table_cache = {}
 
 

@@ -197,3 +197,31 @@ def test_hand_written_backward_kernels_match_the_restatement_gradients(P, Ns, NN
         (fn(x, idx1) * c2).sum().backward()
         got.append(x.grad)
     assert_close(got[0], got[1], 1e-6, 'padded gather dL/dx')
+
+
+@pytest.mark.parametrize('rows,C,groups,slope,with_res,with_xb,segments', [
+    (1800, 32, 4, 0.1, True, True, None), (1501, 64, 32, None, False, False, None), (2400, 48, 8, 0.1, True, False, [0, 700, 1500, 2400]),
+    (600, 16, 8, 0.1, False, True, [0, 10, 600])])
+def test_group_norm_backward_kernels_match_the_restatement_gradients(rows, C, groups, slope, with_res, with_xb, segments):
+    """csrc/rowops.hip gn_bwd_*: all five gradients (x, weight, bias, residual, producing layer's bias) against autograd through the
+    PyTorch restatement, several independently normalised row segments included."""
+    from se3et_amd import autograd as AG
+    from se3et_amd import functional as SF
+    g = torch.Generator().manual_seed(rows)
+    rn = lambda *s: torch.randn(*s, generator=g).cuda()
+    base = [rn(rows // 6, 6, C) if rows % 6 == 0 else rn(rows, C), rn(C), rn(C), rn(rows // 6, 6, C) if rows % 6 == 0 else rn(rows, C), rn(C)]
+    if not with_res: base[3] = None
+    if not with_xb: base[4] = None
+    c = torch.randn(base[0].shape, generator=g).cuda()
+    grads = []
+    for hip in (True, False):
+        t = [b.clone().requires_grad_(True) if b is not None else None for b in base]
+        if hip:
+            y = SF.group_norm_rows(t[0], t[1], t[2], groups, 1e-5, slope, t[3], t[4], segments)
+        else:
+            y = AG.group_norm_rows(t[0], t[1], t[2], t[3], t[4], groups, 1e-5, slope, segments)
+        (y * c).sum().backward()
+        grads.append([b.grad if b is not None else None for b in t])
+    for name, a, b in zip(('x', 'weight', 'bias', 'residual', 'x_bias'), grads[0], grads[1]):
+        if b is not None:
+            assert_close(a, b, 2e-5, 'group norm d/d' + name)
