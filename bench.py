@@ -31,12 +31,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # HBM traffic of one RPE self-attention call relative to its algorithmic bytes, from the rocprofv3 PMC passes committed as
-# profiles/r01_pmc_attention.csv (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of tools/pmc_attention.py on the stack-mode
+# profiles/r02_pmc_attention.csv (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of tools/pmc_attention.py on the stack-mode
 # kernels at the bench shape, 16 clouds per launch; gfx950 correction: FETCH_SIZE x2 for the 16-B/lane streaming reads of
 # rpe_bias_kernel -- its invariant variant then reads 2241 MB for 2223 MB of embedding --, attention_kernel counters raw):
-#   eq  call: (2*1337081.7 + 162945.9 + 203184.0 + 35277.1) KiB = 3149.4 MB  vs 2549.0 MB algorithmic
-#   inv call: (2*1094146.4 +  25740.0 +  33736.0 +  5860.6) KiB = 2307.7 MB  vs 2222.9 MB algorithmic
-PMC_TRAFFIC_RATIO = {'eq': 3149.4 / 2549.0, 'inv': 2307.7 / 2222.9}
+#   eq  call: (2*1336245.8 + 162966.6 + 203184.0 + 35289.5) KiB = 3147.7 MB  vs 2549.0 MB algorithmic
+#   inv call: (2*1094116.0 +  25743.6 +  33736.0 +  5864.4) KiB = 2307.7 MB  vs 2222.9 MB algorithmic
+PMC_TRAFFIC_RATIO = {'eq': 3147.7 / 2549.0, 'inv': 2307.7 / 2222.9}
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s is achievable
 
 
@@ -255,7 +255,7 @@ def main():
         'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None if traffic is None else int(traffic),
         'traffic_source': 'bytes per call; PMC FETCH_SIZE(x2 on the streaming kernel)+WRITE_SIZE per algorithmic byte from '
-                          'profiles/r01_pmc_attention.csv, applied to the calls of this run',
+                          'profiles/r02_pmc_attention.csv, applied to the calls of this run',
         'launches': n_call, 'avg_us': round(us_call / max(n_call, 1), 2),
         'algorithmic_bytes_per_launch': int(bytes_call / max(n_call, 1)),
         'rpe_bias_kernel_avg_us': round(sum(k[2] for k in kinds.values()) / max(n_call, 1), 2),
