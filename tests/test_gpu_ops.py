@@ -384,8 +384,11 @@ def test_cross_attention_eq_matches_oracle(N, M, C, mode):
     assert_close(got.cpu(), want, 1e-4, 'eq cross attention')
 
 
-@pytest.mark.parametrize('N,C,eq', [(59, 32, True), (382, 256, True), (304, 256, False), (100, 128, True)])
+@pytest.mark.parametrize('N,C,eq', [(59, 32, True), (382, 256, True), (304, 256, False), (100, 128, True), (4, 64, True), (5, 256, False),
+                                     (17, 96, True), (65, 256, True), (531, 64, False), (33, 48, True)])
 def test_geometric_embedding_matches_oracle(N, C, eq):
+    """Both forms of the kernel: channel slices with the angle table in LDS (C a multiple of 32: tiny clouds leave most waves without a
+    pair, 531 points give uneven row blocks) and the single-kernel form (C = 48)."""
     from oracle import se3et_oracle as O
     from se3et_amd import functional as SF
     from se3et_amd import tables
