@@ -88,6 +88,13 @@ int se3_grid_subsample(const float* points, const float* normals, int64_t n, con
  * rows, cols <= 143. */
 int se3_log_sinkhorn_fwd(const float* scores, const uint8_t* row_masks, const uint8_t* col_masks, const float* alpha,
                          int batch, int rows, int cols, int iterations, float inf, float* out, void* stream);
+/* Backward of se3_log_sinkhorn_fwd (training step: autograd through learnable_sinkhorn.py:13-66): grad_out (batch, rows+1, cols+1) ->
+ * grad_scores (batch, rows, cols) (0 at masked entries) and grad_alpha_partial (batch): the gradient of the dustbin score per patch pair,
+ * summed by the caller.  One workgroup per patch pair: the forward iterations again with every (u_t, v_t) kept in LDS, then the reverse
+ * sweep.  iterations * (rows + cols + 2) * 4 bytes of LDS (<= 150 KB). */
+int se3_log_sinkhorn_bwd(const float* scores, const uint8_t* row_masks, const uint8_t* col_masks, const float* alpha,
+                         const float* grad_out, int batch, int rows, int cols, int iterations, float inf, float* grad_scores,
+                         float* grad_alpha_partial, void* stream);
 
 /* ---- B2: GroupNorm over stacked points, fused with "+ residual" and LeakyReLU ------------------------------------
  * Replaces GroupNormEPN (geotransformer/modules/e2pn/blocks_epn.py:684-701) and kpconv GroupNorm

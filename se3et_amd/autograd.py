@@ -1,7 +1,7 @@
 """Autograd for the HIP ops (BASELINE.json configs[4]).
 
 Forward = the gfx950 kernel.  Backward: hand-written for the ops that dominated the step (KPConv: csrc/kpconv_so3.hip kpconv_scatter_kernel
-+ two library GEMMs, 474 -> 5 ms per 5k+5k step; GroupNorm: csrc/rowops.hip gn_bwd_*, 20 -> 5 ms; neighbour max-pool; padded row gather --
++ two library GEMMs, 474 -> 5 ms per 5k+5k step; GroupNorm: csrc/rowops.hip gn_bwd_*, 20 -> 5 ms; Sinkhorn: csrc/sinkhorn.hip sinkhorn_bwd_kernel, 18 -> 0.4 ms; neighbour max-pool; padded row gather --
 `hip_backward`), and for the others reverse-mode
 differentiation of a PyTorch restatement of the SAME op, re-evaluated on the GPU inside backward ('until a
 backward kernel exists autograd runs through the PyTorch restatement' -- `differentiable`).  Every

@@ -301,6 +301,11 @@ def superpoint_scores(ref_feats, src_feats, dual_normalization=True):
 
 def log_optimal_transport(scores, row_masks, col_masks, alpha, num_iterations, inf):
     if AG.needs_grad(scores, alpha):
+        # hand-written backward (csrc/sinkhorn.hip: sinkhorn_bwd_kernel) where the dual history fits in LDS; AG.log_optimal_transport is its torch pin
+        if num_iterations * (scores.shape[1] + scores.shape[2] + 2) * 4 <= 150 * 1024 and max(scores.shape[1:]) <= 143:
+            return AG.hip_backward(lambda s_, a_, rm, cm: _ops.log_optimal_transport(s_, rm, cm, a_, num_iterations, inf),
+                                   lambda g, needs, s_, a_, rm, cm: _ops.log_optimal_transport_bwd(g, s_, rm, cm, a_, num_iterations, inf) + (None, None),
+                                   'log_optimal_transport', scores, alpha, row_masks, col_masks)
         return AG.differentiable(lambda s_, a_, rm, cm: _ops.log_optimal_transport(s_, rm, cm, a_, num_iterations, inf),
                                  lambda s_, a_, rm, cm: AG.log_optimal_transport(s_, a_, rm, cm, num_iterations, inf),
                                  1, scores, alpha, row_masks, col_masks)

@@ -216,6 +216,21 @@ def log_optimal_transport(scores, row_masks, col_masks, alpha, num_iterations, i
     return out
 
 
+def log_optimal_transport_bwd(grad_out, scores, row_masks, col_masks, alpha, num_iterations, inf):
+    """HIP (csrc/sinkhorn.hip): gradients of log_optimal_transport with respect to (scores, alpha)."""
+    scores = _req(scores.contiguous(), torch.float32, 'scores', 3)
+    B, R, C = scores.shape
+    g = _req(grad_out.contiguous(), torch.float32, 'grad_out', 3)
+    rm = _req(row_masks.to(torch.uint8).contiguous(), torch.uint8, 'row_masks', 2)
+    cm = _req(col_masks.to(torch.uint8).contiguous(), torch.uint8, 'col_masks', 2)
+    al = _req(alpha.detach().reshape(1).contiguous(), torch.float32, 'alpha')
+    ds = torch.empty_like(scores)
+    da = torch.empty((B,), dtype=torch.float32, device=scores.device)
+    check(lib().se3_log_sinkhorn_bwd(scores.data_ptr(), rm.data_ptr(), cm.data_ptr(), al.data_ptr(), g.data_ptr(), B, R, C,
+                                     int(num_iterations), float(inf), ds.data_ptr(), da.data_ptr(), _stream()), 'se3_log_sinkhorn_bwd')
+    return ds, da.sum().reshape(alpha.shape)
+
+
 def add_layer_norm(hidden, residual, weight, bias, eps, hidden_bias=None):
     """HIP (csrc/rowops.hip): LayerNorm(hidden [+ hidden_bias] + residual); residual may lack leading (anchor) dims of hidden;
     hidden_bias (C,) is the bias of the linear layer that produced hidden (its GEMM then runs bias-free)."""

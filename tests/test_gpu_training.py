@@ -225,3 +225,29 @@ def test_group_norm_backward_kernels_match_the_restatement_gradients(rows, C, gr
     for name, a, b in zip(('x', 'weight', 'bias', 'residual', 'x_bias'), grads[0], grads[1]):
         if b is not None:
             assert_close(a, b, 2e-5, 'group norm d/d' + name)
+
+
+@pytest.mark.parametrize('B,R,C,iters', [(9, 20, 24, 100), (5, 64, 64, 100), (3, 64, 37, 30), (2, 100, 90, 50)])
+def test_sinkhorn_backward_kernel_matches_the_restatement_gradients(B, R, C, iters):
+    """csrc/sinkhorn.hip sinkhorn_bwd_kernel against autograd through the PyTorch restatement of the 2 x iters logsumexp passes: gradients
+    of the scores (valid entries) and of the dustbin score alpha, random masks, a loss that reads the dustbin row / column too."""
+    from se3et_amd import autograd as AG
+    from se3et_amd import functional as SF
+    g = torch.Generator().manual_seed(B * 100 + R)
+    sc0 = torch.randn(B, R, C, generator=g).cuda()
+    rm, cm = (torch.rand(B, R, generator=g) > 0.2).cuda(), (torch.rand(B, C, generator=g) > 0.2).cuda()
+    rm[0], cm[0] = True, True
+    c = torch.randn(B, R + 1, C + 1, generator=g).cuda()
+    valid = torch.ones(B, R + 1, C + 1, dtype=torch.bool, device='cuda')
+    valid[:, :R] &= rm[:, :, None]
+    valid[:, :, :C] &= cm[:, None, :]
+    grads = []
+    for hip in (True, False):
+        sc, al = sc0.clone().requires_grad_(True), torch.tensor(0.7, device='cuda', requires_grad=True)
+        out = SF.log_optimal_transport(sc, rm, cm, al, iters, 1e12) if hip else AG.log_optimal_transport(sc, al, rm, cm, iters, 1e12)
+        (torch.where(valid, out, torch.zeros_like(out)) * c).sum().backward()
+        grads.append((sc.grad, al.grad))
+    m = valid[:, :R, :C]
+    assert float(grads[0][0][~m].abs().max()) == 0.0 if bool((~m).any()) else True
+    assert_close(grads[0][0][m], grads[1][0][m], 1e-4, 'sinkhorn d/dscores')
+    assert abs(float(grads[0][1]) - float(grads[1][1])) <= 1e-4 * max(1.0, abs(float(grads[1][1]))), (float(grads[0][1]), float(grads[1][1]))
