@@ -292,6 +292,13 @@ int se3_geo_embedding_fwd(const float* points, const int64_t* knn, int N, int C,
                           float sigma_d, float sigma_a, const float* w_d, const float* b_d, const float* w_a, const float* b_a,
                           const float* div_term, const float* wigner_d1, int num_anchors, float* emb, float* eq_emb,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* Operands of the embedding's weight gradients (training step: autograd through proj_d / proj_a and the max over the 3 angles,
+ * geotransformer.py:92-121): S (4, N, N, C) = the sinusoid embeddings of the distance index and of the three angle indices; dEk (3, N, N, C)
+ * = grad_emb masked to the channels where angle k holds the maximum.  d proj_d.weight = grad_emb^T S[0], d proj_a.weight = sum_k
+ * dEk[k]^T S[1 + k] (library GEMMs), both bias gradients = sum grad_emb. */
+int se3_geo_embedding_bwd_operands(const float* points, const int64_t* knn, int N, int C, const float* table_a, int a_entries,
+                                   float a_entries_per_unit, float sigma_d, float sigma_a, const float* w_a, const float* b_a,
+                                   const float* div_term, const float* grad_emb, float* S, float* dEk, void* stream);
 /* Builds / validates such a table on the device (replaces the caller-side GEMMs): table (entries, C, 2) float32 = (f, df/dx) of
  * f(x) = weight emb(x) + bias at x = j / entries_per_unit (float64 accumulation), emb = SinusoidalPositionalEmbedding
  * (transformer/positional_embedding.py:8-34) with div_term (C/2,).  state: se3_embedding_table_state_bytes() zero-initialised bytes owned by the caller next to

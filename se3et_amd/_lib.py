@@ -53,6 +53,7 @@ SIGNATURES = {
     'se3_cross_eq_stack_fwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _i64, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'se3_cross_eq_apply': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     'se3_geo_embedding_workspace_bytes': (_sz, [_i32]),
+    'se3_geo_embedding_bwd_operands': (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'se3_geo_embedding_fwd': (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _f32, _vp, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
     'se3_geo_embedding_bf16_fwd': (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _f32, _vp, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
     'se3_embedding_table_state_bytes': (_sz, []),

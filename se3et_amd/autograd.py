@@ -1,7 +1,8 @@
 """Autograd for the HIP ops (BASELINE.json configs[4]).
 
 Forward = the gfx950 kernel.  Backward: hand-written for the ops that dominated the step (KPConv: csrc/kpconv_so3.hip kpconv_scatter_kernel
-+ two library GEMMs, 474 -> 5 ms per 5k+5k step; GroupNorm: csrc/rowops.hip gn_bwd_*, 20 -> 5 ms; Sinkhorn: csrc/sinkhorn.hip sinkhorn_bwd_kernel, 18 -> 0.4 ms; neighbour max-pool; padded row gather --
++ two library GEMMs, 474 -> 5 ms per 5k+5k step; GroupNorm: csrc/rowops.hip gn_bwd_*, 20 -> 5 ms; Sinkhorn: csrc/sinkhorn.hip sinkhorn_bwd_kernel, 18 -> 0.4 ms; geometric embedding: GEMM operands from
+csrc/geo_embedding.hip, 13 -> 3 ms; neighbour max-pool; padded row gather --
 `hip_backward`), and for the others reverse-mode
 differentiation of a PyTorch restatement of the SAME op, re-evaluated on the GPU inside backward ('until a
 backward kernel exists autograd runs through the PyTorch restatement' -- `differentiable`).  Every
@@ -83,10 +84,14 @@ class _HipForwardHipBackward(torch.autograd.Function):
         ctx.bwd_fn, ctx.name = bwd_fn, name
         ctx.save_for_backward(*tensors)
         with torch.no_grad():
-            return hip_fn(*tensors)
+            out = hip_fn(*tensors)
+        if torch.is_tensor(out):
+            return out
+        ctx.mark_non_differentiable(*out[1:])          # further outputs are constants for autograd (e.g. the equivariant embedding)
+        return tuple(out)
 
     @staticmethod
-    def backward(ctx, grad):
+    def backward(ctx, grad, *unused):
         needs = ctx.needs_input_grad[3:]
         if BACKWARD_TIMINGS is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -100,7 +105,7 @@ class _HipForwardHipBackward(torch.autograd.Function):
 
 
 def hip_backward(hip_fn, bwd_fn, name, *tensors):
-    """hip_fn(*tensors) (one output) with the hand-written backward bwd_fn(grad_out, needs_input_grad, *tensors)."""
+    """hip_fn(*tensors) (one differentiable output, the first) with the hand-written backward bwd_fn(grad_out, needs_input_grad, *tensors)."""
     return _HipForwardHipBackward.apply(hip_fn, bwd_fn, name, *tensors)
 
 

@@ -347,6 +347,94 @@ __global__ __launch_bounds__(kSliceThreads) void geo_embedding_slice_kernel(
 #undef SE3_PUBLISH
 }
 
+// ---- backward operands (training step) ---------------------------------------------------------------------------------------------------
+// dL/dW_d = dE^T emb(d),  dL/dW_a = sum_k (dE masked to the channels where angle k holds the maximum)^T emb(angle_k),  dL/db_d = dL/db_a =
+// sum dE: the products are library GEMMs; this kernel writes their operands in one pass over the pairs -- the sinusoid embeddings of the
+// four indices S (4, N N, C) and the masked gradients dEk (3, N N, C).  The arg-max is taken on the same tabulated responses as the
+// forward pass (first index on ties: tied angles of one pair are equal angles, e.g. the n == m diagonal, and then the split is immaterial).
+__global__ void geo_embedding_bwd_operands_kernel(const float* __restrict__ pts, const int64_t* __restrict__ knn, int N, int C,
+                                                  const float2* __restrict__ tab_a, EmbParams P, const float* __restrict__ Wa,
+                                                  const float* __restrict__ ba, const float* __restrict__ div_term,
+                                                  const float* __restrict__ dE, float* __restrict__ S, float* __restrict__ dEk) {
+  __shared__ float idx_s[kMB][4];
+  __shared__ float4 wt_s[kMB][4];
+  __shared__ int j_s[kMB][4];
+  const int n = blockIdx.x;
+  const int m_per = (N + gridDim.y - 1) / gridDim.y;
+  const int m_begin = blockIdx.y * m_per, m_end = min(N, m_begin + m_per);
+  const float px = pts[3 * n], py = pts[3 * n + 1], pz = pts[3 * n + 2];
+  float rx[3], ry[3], rz[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int64_t j = knn[3 * n + k];
+    rx[k] = pts[3 * j] - px; ry[k] = pts[3 * j + 1] - py; rz[k] = pts[3 * j + 2] - pz;
+  }
+  const float nn2 = px * px + py * py + pz * pz;
+  const size_t plane = (size_t)N * N * C;
+  for (int m0 = m_begin; m0 < m_end; m0 += kMB) {
+    __syncthreads();
+    if (threadIdx.x < kMB) {
+      const int m = min(m0 + (int)threadIdx.x, N - 1);
+      const float qx = pts[3 * m], qy = pts[3 * m + 1], qz = pts[3 * m + 2];
+      const float d2 = fmaxf(nn2 - 2.f * (px * qx + py * qy + pz * qz) + (qx * qx + qy * qy + qz * qz), 0.f);
+      float x[4];
+      x[0] = sqrtf(d2) * P.sigma_d_inv;
+      const float vx = qx - px, vy = qy - py, vz = qz - pz;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const float cx = ry[k] * vz - rz[k] * vy, cy = rz[k] * vx - rx[k] * vz, cz = rx[k] * vy - ry[k] * vx;
+        const float sn = sqrtf(cx * cx + cy * cy + cz * cz);
+        float cs = rx[k] * vx + ry[k] * vy + rz[k] * vz;
+        cs = (cs == 0.f) ? 0.f : cs;
+        x[1 + k] = atan2f(sn, cs) * P.factor_a;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        idx_s[threadIdx.x][t] = x[t];
+        if (t > 0) {
+          const float u = x[t] * P.a_inv_h;
+          const int j = (int)floorf(u);
+          const bool ok = (j >= 0) && (j + 1 < P.a_entries);
+          const float tt = u - (float)j, h = 1.0f / P.a_inv_h;
+          const float t2 = tt * tt, t3 = t2 * tt;
+          j_s[threadIdx.x][t] = ok ? j : -1;
+          wt_s[threadIdx.x][t] = make_float4(2.f * t3 - 3.f * t2 + 1.f, -2.f * t3 + 3.f * t2, h * (t3 - 2.f * t2 + tt), h * (t3 - t2));
+        }
+      }
+    }
+    __syncthreads();
+    const int cnt = min(kMB, m_end - m0);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      const float om = div_term[c >> 1];
+      for (int i = 0; i < cnt; i++) {
+        float val[3];
+#pragma unroll
+        for (int t = 1; t < 4; t++) {
+          const int j = j_s[i][t];
+          if (j >= 0) {
+            const float2 p0 = tab_a[(size_t)j * C + c], p1 = tab_a[(size_t)(j + 1) * C + c];
+            const float4 w = wt_s[i][t];
+            val[t - 1] = (w.x * p0.x + w.y * p1.x) + (w.z * p0.y + w.w * p1.y);
+          } else {
+            val[t - 1] = exact_eval(Wa, ba, div_term, C, c, idx_s[i][t]);
+          }
+        }
+        const int kb = val[1] > val[0] ? (val[2] > val[1] ? 2 : 1) : (val[2] > val[0] ? 2 : 0);
+        const size_t o = ((size_t)n * N + (m0 + i)) * C + c;
+        const float g = dE[o];
+#pragma unroll
+        for (int k = 0; k < 3; k++) dEk[k * plane + o] = k == kb ? g : 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          float sn, cs;
+          sincosf(idx_s[i][t] * om, &sn, &cs);
+          S[t * plane + o] = (c & 1) ? cs : sn;
+        }
+      }
+    }
+  }
+}
+
 // ---- table construction on the device -------------------------------------------------------------------------------
 // tab (entries, C, 2) = (f, f') of f(x) = W emb(x) + b at x = j / per_unit, accumulated in float64.  Two launches in front of every
 // embedding call validate the table against the CURRENT weights by content: 64 workgroups hash disjoint slices of (W, b, div_term)
@@ -548,4 +636,28 @@ extern "C" int se3_geo_embedding_bf16_fwd(const float* points, const int64_t* kn
                                           void* workspace, size_t workspace_bytes, void* stream) {
   return geo_embedding(points, knn, N, C, table_d, d_entries, d_entries_per_unit, table_a, a_entries, a_entries_per_unit, sigma_d,
                        sigma_a, w_d, b_d, w_a, b_a, div_term, wigner_d1, num_anchors, emb, 1, eq_emb, workspace, workspace_bytes, stream);
+}
+
+// Operands of the weight gradients of the embedding (training step): S (4, N, N, C) = emb(index_t) for t = distance, angle 0..2 and dEk
+// (3, N, N, C) = grad_emb masked to the channels where angle k is the arg-max.  Then dW_d = grad_emb^T S[0], dW_a = sum_k dEk[k]^T S[1 + k]
+// (library GEMMs), db_d = db_a = sum grad_emb.
+extern "C" int se3_geo_embedding_bwd_operands(const float* points, const int64_t* knn, int N, int C, const float* table_a, int a_entries,
+                                              float a_entries_per_unit, float sigma_d, float sigma_a, const float* w_a, const float* b_a,
+                                              const float* div_term, const float* grad_emb, float* S, float* dEk, void* stream) {
+  SE3_REQUIRE(points && knn && table_a && w_a && b_a && div_term && grad_emb && S && dEk, SE3_ERR_INVALID_ARG,
+              "geo_embedding_bwd_operands: null pointer");
+  SE3_REQUIRE(N >= 1 && C >= 2 && C % 2 == 0 && a_entries >= 2, SE3_ERR_INVALID_ARG, "geo_embedding_bwd_operands: bad sizes");
+  EmbParams P;
+  P.sigma_d_inv = 1.0f / sigma_d;
+  P.factor_a = 180.0f / (sigma_a * 3.14159265358979323846f);
+  P.d_inv_h = 1.f; P.a_inv_h = a_entries_per_unit;
+  P.d_entries = 2; P.a_entries = a_entries;
+  int split = (1024 + N - 1) / N;
+  if (split < 1) split = 1;
+  if (split > (N + kMB - 1) / kMB) split = (N + kMB - 1) / kMB;
+  const int threads = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
+  geo_embedding_bwd_operands_kernel<<<dim3((unsigned)N, (unsigned)split), threads, 0, (hipStream_t)stream>>>(
+      points, knn, N, C, reinterpret_cast<const float2*>(table_a), P, w_a, b_a, div_term, grad_emb, S, dEk);
+  SE3_CHECK_LAUNCH("geo_embedding_bwd_operands");
+  return SE3_OK;
 }

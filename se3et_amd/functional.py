@@ -176,8 +176,14 @@ def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, 
             raise RuntimeError('geometric_embedding: training runs in float32')
         if knn is None:
             knn = _ops.knn3_stack(points.contiguous(), [points.shape[0]])
-        hip = lambda wd, bd, wa, ba: _ops.geometric_embedding(points, div_term, wd, bd, wa, ba, sigma_d, sigma_a, k, wigner_d1, dtype, knn)
+        hip = lambda wd, bd, wa, ba: _ops.geometric_embedding(points, div_term, wd, bd, wa, ba, sigma_d, sigma_a, k, wigner_d1, dtype, knn, tables)
         ref = lambda wd, bd, wa, ba: AG.geometric_embedding(points, div_term, wd, bd, wa, ba, knn, sigma_d, sigma_a)
+        # hand-written backward: the kernel writes the GEMM operands of the four weight gradients (csrc/geo_embedding.hip); `ref` is its torch pin
+        if not AG.needs_grad(points):
+            # (tables validated at forward time stay valid in backward: the weights change in optimizer.step only)
+            bwd = lambda g, needs, wd, bd, wa, ba: _ops.geometric_embedding_bwd(g, points, div_term, wd, bd, wa, ba, sigma_d, sigma_a, knn, tables)
+            out = AG.hip_backward(hip, bwd, 'geometric_embedding', w_d, b_d, w_a, b_a)
+            return out if wigner_d1 is None else (out[0], out[1].detach())
         if wigner_d1 is None:
             return AG.differentiable(hip, ref, 1, w_d, b_d, w_a, b_a)
         # the equivariant embedding has no learned inputs: second output of the kernel, constant for autograd

@@ -914,6 +914,24 @@ def geometric_embedding(points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, 
     return emb if eq is None else (emb, eq)
 
 
+def geometric_embedding_bwd(grad_emb, points, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, knn, tables=None):
+    """Gradients of geometric_embedding with respect to (w_d, b_d, w_a, b_a): the HIP kernel writes the GEMM operands (sinusoid embeddings
+    of the four indices, gradient masked by the arg-max angle), the products are two library GEMMs (csrc/geo_embedding.hip)."""
+    points = _req(points.contiguous(), torch.float32, 'points', 2)
+    g = _req(grad_emb.contiguous(), torch.float32, 'grad_emb', 3)
+    N, C = points.shape[0], w_d.shape[0]
+    knn = _req(knn, torch.int64, 'knn', 2)
+    tab_a = (tables if tables is not None else embedding_tables(div_term, w_d, b_d, w_a, b_a, sigma_a))[1]
+    S = torch.empty((4, N * N, C), dtype=torch.float32, device=points.device)
+    dEk = torch.empty((3 * N * N, C), dtype=torch.float32, device=points.device)
+    check(lib().se3_geo_embedding_bwd_operands(points.data_ptr(), knn.data_ptr(), N, C, tab_a.data_ptr(), tab_a.shape[0], _EMB_A_PER_UNIT,
+                                               float(sigma_d), float(sigma_a), w_a.data_ptr(), b_a.data_ptr(), div_term.data_ptr(),
+                                               g.data_ptr(), S.data_ptr(), dEk.data_ptr(), _stream()), 'se3_geo_embedding_bwd_operands')
+    g2 = g.reshape(N * N, C)
+    db = g2.sum(0)
+    return mm(g2.t(), S[0]), db, mm(dEk.t(), S[1:].reshape(3 * N * N, C)), db.clone()
+
+
 def point_to_node_partition(points, nodes, point_limit):
     """HIP (csrc/partition.hip): (point_to_node (N,) int64, node_masks (M,) bool, node_knn_indices (M, K) int64 padded with N,
     node_knn_masks (M, K) bool) -- nearest node per point, the K nearest own points per node."""

@@ -251,3 +251,38 @@ def test_sinkhorn_backward_kernel_matches_the_restatement_gradients(B, R, C, ite
     assert float(grads[0][0][~m].abs().max()) == 0.0 if bool((~m).any()) else True
     assert_close(grads[0][0][m], grads[1][0][m], 1e-4, 'sinkhorn d/dscores')
     assert abs(float(grads[0][1]) - float(grads[1][1])) <= 1e-4 * max(1.0, abs(float(grads[1][1]))), (float(grads[0][1]), float(grads[1][1]))
+
+
+@pytest.mark.parametrize('N,C,eq', [(61, 32, True), (120, 128, False), (17, 64, True)])
+def test_embedding_backward_kernel_matches_the_restatement_gradients(N, C, eq):
+    """csrc/geo_embedding.hip geo_embedding_bwd_operands_kernel + two GEMMs against autograd through the PyTorch restatement: gradients of
+    proj_d / proj_a weights and biases.  The cotangent is zero on the n == m diagonal (its distance index is the square root of a rounding
+    residue in both implementations: noise of 1e-3 index units); the angle terms are compared in the Frobenius norm, because the two
+    implementations may pick different winners of `max` where two angle responses agree to round-off (a handful of (pair, channel)
+    elements out of millions, each moving single entries of the gradient)."""
+    from se3et_amd import autograd as AG
+    from se3et_amd import functional as SF
+    from se3et_amd import ops, tables
+    g = torch.Generator().manual_seed(N)
+    rn = lambda *s: torch.randn(*s, generator=g).cuda()
+    pts = torch.rand(N, 3, generator=g).cuda()
+    div = torch.exp(torch.arange(0, C, 2).float() * (-np.log(10000.0) / C)).cuda()
+    base = [rn(C, C) / C ** 0.5, rn(C) * 0.1, rn(C, C) / C ** 0.5, rn(C) * 0.1]
+    w1 = torch.from_numpy(tables.wigner_tables()[1]).cuda() if eq else None
+    knn = ops.knn3_stack(pts, [N])
+    c = rn(N, N, C) * (~torch.eye(N, dtype=torch.bool, device='cuda'))[:, :, None]
+    grads = []
+    for hip in (True, False):
+        t = [b.clone().requires_grad_(True) for b in base]
+        if hip:
+            out = SF.geometric_embedding(pts, div, t[0], t[1], t[2], t[3], 0.2, 15.0, 3, wigner_d1=w1, knn=knn)
+            emb = out[0] if eq else out
+        else:
+            emb = AG.geometric_embedding(pts, div, t[0], t[1], t[2], t[3], knn, 0.2, 15.0)
+        (emb * c).sum().backward()
+        grads.append([b.grad for b in t])
+    assert_close(grads[0][0], grads[1][0], 1e-4, 'embedding d/dproj_d.weight')
+    assert_close(grads[0][1], grads[1][1], 1e-5, 'embedding d/dproj_d.bias')
+    assert_close(grads[0][3], grads[1][3], 1e-5, 'embedding d/dproj_a.bias')
+    fro = float((grads[0][2] - grads[1][2]).norm() / grads[1][2].norm())
+    assert fro <= 2e-4, 'embedding d/dproj_a.weight: relative Frobenius error %.2e' % fro
