@@ -13,10 +13,11 @@ def timeit(f, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 P = [80000, 51742, 21411, 7690]
 shapes = [(0, 32), (0, 64), (0, 16), (1, 32), (1, 64), (1, 128), (2, 64), (2, 128), (2, 256), (3, 128), (3, 256), (3, 512)]
-for st, C in shapes:
-    rows = P[st] * 6
-    x = torch.randn(rows, C, device=dev); w = torch.ones(C, device=dev); b = torch.zeros(C, device=dev)
-    seg = [rows * i // 8 for i in range(9)]
-    us = timeit(lambda: ops.group_norm_rows(x, w, b, 32 if C >= 32 else C, 1e-5, 0.1, None, None, seg))
-    mb = rows * C * 4 / 1e6
-    print('rows %7d C %3d  %6.1f MB  %7.1f us  %.2f TB/s (3 passes)' % (rows, C, mb, us, 3 * mb / us))
+for div, nseg in ((1, 8), (8, 1)):          # 8 pairs per forward (8 segments), one pair per forward (one segment)
+    for st, C in shapes:
+        rows = P[st] * 6 // div
+        x = torch.randn(rows, C, device=dev); w = torch.ones(C, device=dev); b = torch.zeros(C, device=dev)
+        seg = [rows * i // nseg for i in range(nseg + 1)] if nseg > 1 else None
+        us = timeit(lambda: ops.group_norm_rows(x, w, b, 32 if C >= 32 else C, 1e-5, 0.1, None, None, seg))
+        mb = rows * C * 4 / 1e6
+        print('segments %d rows %7d C %3d  %6.1f MB  %7.1f us  %.2f TB/s (3 passes)' % (nseg, rows, C, mb, us, 3 * mb / us))
