@@ -427,29 +427,46 @@ __global__ void gather_rows_kernel(const float* __restrict__ x, const int64_t* _
 
 __global__ __launch_bounds__(256) void neighbor_max_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
                                                            int64_t n, int64_t m, int nn, int64_t width, float* __restrict__ out) {
-  __shared__ int64_t nb[64];
+  __shared__ unsigned row_s[64];         // element offset of the neighbour's row; padded entries (row n) and absent columns read row 0
+  __shared__ float fill_s[64];           // and contribute this instead: 0 for a padded entry (the zero row), -inf for an absent column
+  __shared__ unsigned char use_s[64];
   const int64_t r = blockIdx.x;
-  for (int j = threadIdx.x; j < nn; j += blockDim.x) nb[j] = idx[r * nn + j];
+  const int nn8 = (nn + 7) & ~7;
+  for (int j = threadIdx.x; j < nn8; j += blockDim.x) {
+    const int64_t s = j < nn ? idx[r * nn + j] : -1;      // s < 0: column beyond the pair's own table width (several pairs stacked)
+    const bool real = s >= 0 && s < n;
+    row_s[j] = real ? (unsigned)(s * width) : 0u;
+    use_s[j] = real ? 1 : 0;
+    fill_s[j] = s < 0 ? -INFINITY : 0.f;
+  }
   __syncthreads();
+  // 8 gathered rows in flight per thread (the loop was one L2 round trip per neighbour)
   if ((width & 3) == 0) {
     const int64_t w4 = width >> 2;
     for (int64_t c = threadIdx.x; c < w4; c += blockDim.x) {
       float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-      for (int j = 0; j < nn; j++) {
-        const int64_t s = nb[j];
-        if (s < 0) continue;           // column beyond the pair's own table width (several pairs stacked): not a neighbour at all
-        const float4 v = s < n ? reinterpret_cast<const float4*>(x + s * width)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-        best = make_float4(fmaxf(best.x, v.x), fmaxf(best.y, v.y), fmaxf(best.z, v.z), fmaxf(best.w, v.w));
+      for (int j0 = 0; j0 < nn8; j0 += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = reinterpret_cast<const float4*>(x + row_s[j0 + u])[c];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const float f = fill_s[j0 + u];
+          const float4 t = use_s[j0 + u] ? v[u] : make_float4(f, f, f, f);
+          best = make_float4(fmaxf(best.x, t.x), fmaxf(best.y, t.y), fmaxf(best.z, t.z), fmaxf(best.w, t.w));
+        }
       }
       reinterpret_cast<float4*>(out + r * width)[c] = best;
     }
   } else {
     for (int64_t c = threadIdx.x; c < width; c += blockDim.x) {
       float best = -INFINITY;
-      for (int j = 0; j < nn; j++) {
-        const int64_t s = nb[j];
-        if (s < 0) continue;
-        best = fmaxf(best, s < n ? x[s * width + c] : 0.f);
+      for (int j0 = 0; j0 < nn8; j0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = x[row_s[j0 + u] + c];
+#pragma unroll
+        for (int u = 0; u < 8; u++) best = fmaxf(best, use_s[j0 + u] ? v[u] : fill_s[j0 + u]);
       }
       out[r * width + c] = best;
     }
