@@ -108,7 +108,9 @@ struct SlotEntry { unsigned short off[4]; };           // float offsets (k*6 + a
 // shared the G fragments through LDS behind three barriers per K-step: 1.6-1.8x slower).  Every wave reads the K-step's weight fragments
 // (NT x 3 KB, requested one K-step ahead) straight from global memory: the six waves of the three resident workgroups hit the same lines
 // in L1.  (Fetching them once per workgroup into a double-buffered LDS tile behind one barrier per K-step measured 1-15 % SLOWER: the
-// 12 KB per wave and K-step then come out of LDS, which the fragment builder is already loading.)
+// 12 KB per wave and K-step then come out of LDS, which the fragment builder is already loading.  Building the fragments of K-step ks + 1
+// in the shadow of the MFMAs of K-step ks inside one wave -- the K-steps of a chunk unrolled, `sched_group_barrier` groups of one MFMA and
+// four VALU instructions: the interleaving comes out as asked, at 200 VGPRs, and the layer takes 1.63 ms instead of 1.33.)
 __device__ __forceinline__ void build_fragment(const float* frow, const SlotEntry en, bool multi, bf16x8& a1, bf16x8& a2, bf16x8& a3) {
   float v[8];
   {
@@ -131,7 +133,7 @@ __device__ __forceinline__ void build_fragment(const float* frow, const SlotEntr
 }
 
 template <int NT, int RW>       // column tiles (16 output channels each), 1..4; output anchors per wave (1: 6 waves, 2: 3 waves)
-__global__ __launch_bounds__(384 / RW) __attribute__((amdgpu_waves_per_eu(RW == 1 ? 4 : 2, RW == 1 ? 5 : 3))) void kpconv_contract_rows_kernel(
+__global__ __launch_bounds__(384 / RW) __attribute__((amdgpu_waves_per_eu(RW == 1 ? 3 : 2, RW == 1 ? 4 : 3))) void kpconv_contract_rows_kernel(
     const float* __restrict__ F, const uint4* __restrict__ Wf, int64_t P, int64_t P16, int Cin, int Cout, float* __restrict__ out) {
   extern __shared__ __align__(16) float lds[];
   float* ftile = lds;                                                   // [16 points][732]
@@ -167,13 +169,30 @@ __global__ __launch_bounds__(384 / RW) __attribute__((amdgpu_waves_per_eu(RW == 
 #pragma unroll
   for (int f = 0; f < kFr; f++) bn[f] = Wf[f * 64 + lane];
   int64_t g = 0;
+  // The F tile of chunk cc + 1 (46.8 KB) is requested into registers at the top of chunk cc and stored to LDS at the chunk boundary: the
+  // plain copy loop (load, store, load, ...) paid one HBM round trip per float4 and thread -- two thirds of the kernel time.
+  constexpr int kThreads = 384 / RW, kPF = (kTileFloats / 4 + kThreads - 1) / kThreads;
+  f32x4 pf[kPF];                                      // (ext_vector_type: an array of HIP float4 structs ends up in scratch)
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(F + p0 * kRowPad);
+#pragma unroll
+    for (int i = 0; i < kPF; i++) pf[i] = src[min(tid + i * kThreads, kTileFloats / 4 - 1)];
+  }
   for (int cc = 0; cc < chunks; cc++) {
     __syncthreads();                                                    // the previous chunk's F tile is no longer read
+#pragma unroll
+    for (int i = 0; i < kPF; i++)
+      if (tid + i * kThreads < kTileFloats / 4) reinterpret_cast<f32x4*>(ftile)[tid + i * kThreads] = pf[i];
     {
-      const float4* src = reinterpret_cast<const float4*>(F + ((int64_t)cc * P16 + p0) * kRowPad);
-      for (int q = tid; q < kTileFloats / 4; q += 384 / RW) reinterpret_cast<float4*>(ftile)[q] = src[q];
+      const int cn = cc + 1 < chunks ? cc + 1 : cc;                      // unconditional (clamped) so that the compiler can count the requests
+      const f32x4* src = reinterpret_cast<const f32x4*>(F + ((int64_t)cn * P16 + p0) * kRowPad);
+#pragma unroll
+      for (int i = 0; i < kPF; i++) pf[i] = src[min(tid + i * kThreads, kTileFloats / 4 - 1)];
     }
     __syncthreads();
+#define SE3_PRODUCT(a_, pc_)                                                                                        \
+  _Pragma("unroll") for (int q = 0; q < RW; q++) _Pragma("unroll") for (int n = 0; n < NT; n++)                  \
+      acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_[q], b[n][pc_], acc[q][n], 0, 0, 0);
 #pragma unroll 1
     for (int ks = 0; ks < kKS; ks++, g++) {
       bf16x8 a1[RW], a2[RW], a3[RW];
@@ -191,17 +210,14 @@ __global__ __launch_bounds__(384 / RW) __attribute__((amdgpu_waves_per_eu(RW == 
         for (int f = 0; f < kFr; f++) bn[f] = src[f * 64];
       }
       // product-major over the tiles: consecutive MFMAs go to different accumulators; smallest terms first
-#define SE3_PRODUCT(a_, pc_)                                                                                        \
-  _Pragma("unroll") for (int q = 0; q < RW; q++) _Pragma("unroll") for (int n = 0; n < NT; n++)                  \
-      acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_[q], b[n][pc_], acc[q][n], 0, 0, 0);
       SE3_PRODUCT(a3, 0)
       SE3_PRODUCT(a1, 2)
       SE3_PRODUCT(a2, 1)
       SE3_PRODUCT(a2, 0)
       SE3_PRODUCT(a1, 1)
       SE3_PRODUCT(a1, 0)
-#undef SE3_PRODUCT
     }
+#undef SE3_PRODUCT
   }
   // accumulator tile: lane holds column (lane & 15), rows (lane >> 4) * 4 + i = points of the tile
 #pragma unroll
