@@ -132,7 +132,7 @@ __device__ __forceinline__ void build_fragment(const float* frow, const SlotEntr
   a1 = __builtin_bit_cast(bf16x8, p1); a2 = __builtin_bit_cast(bf16x8, p2); a3 = __builtin_bit_cast(bf16x8, p3);
 }
 
-template <int NT, int RW>       // column tiles (16 output channels each), 1..4; output anchors per wave (1: 6 waves, 2: 3 waves)
+template <int NT, int RW, int DBG = 0>       // DBG: ablation bits for tools/micro (1 no weight loads, 2 no builds, 4 no MFMAs, 8 no F tile copies); column tiles (16 output channels each), 1..4; output anchors per wave (1: 6 waves, 2: 3 waves)
 __global__ __launch_bounds__(384 / RW) __attribute__((amdgpu_waves_per_eu(RW == 1 ? 3 : 2, RW == 1 ? 4 : 3))) void kpconv_contract_rows_kernel(
     const float* __restrict__ F, const uint4* __restrict__ Wf, int64_t P, int64_t P16, int Cin, int Cout, float* __restrict__ out) {
   extern __shared__ __align__(16) float lds[];
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(384 / RW) __attribute__((amdgpu_waves_per_eu(RW == 
 #pragma unroll
     for (int i = 0; i < kPF; i++)
       if (tid + i * kThreads < kTileFloats / 4) reinterpret_cast<f32x4*>(ftile)[tid + i * kThreads] = pf[i];
-    {
+    if (!(DBG & 8) || cc == 0) {
       const int cn = cc + 1 < chunks ? cc + 1 : cc;                      // unconditional (clamped) so that the compiler can count the requests
       const f32x4* src = reinterpret_cast<const f32x4*>(F + ((int64_t)cn * P16 + p0) * kRowPad);
 #pragma unroll
@@ -193,29 +193,45 @@ __global__ __launch_bounds__(384 / RW) __attribute__((amdgpu_waves_per_eu(RW == 
 #define SE3_PRODUCT(a_, pc_)                                                                                        \
   _Pragma("unroll") for (int q = 0; q < RW; q++) _Pragma("unroll") for (int n = 0; n < NT; n++)                  \
       acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_[q], b[n][pc_], acc[q][n], 0, 0, 0);
+    bf16x8 a1[RW], a2[RW], a3[RW];
+    if (DBG & 2) {
+#pragma unroll
+      for (int q = 0; q < RW; q++) build_fragment(frow, tab[(r0 + q) * 4 + kb], false, a1[q], a2[q], a3[q]);
+    }
 #pragma unroll 1
     for (int ks = 0; ks < kKS; ks++, g++) {
-      bf16x8 a1[RW], a2[RW], a3[RW];
+      if (!(DBG & 2)) {
 #pragma unroll
-      for (int q = 0; q < RW; q++) build_fragment(frow, tab[(ks * kA + r0 + q) * 4 + kb], ks >= 4, a1[q], a2[q], a3[q]);
+        for (int q = 0; q < RW; q++) build_fragment(frow, tab[(ks * kA + r0 + q) * 4 + kb], ks >= 4, a1[q], a2[q], a3[q]);
+      }
       bf16x8 b[NT][3];
 #pragma unroll
       for (int n = 0; n < NT; n++)
 #pragma unroll
         for (int pc = 0; pc < 3; pc++) b[n][pc] = __builtin_bit_cast(bf16x8, bn[n * 3 + pc]);
-      {                                                                 // request step g + 1 (clamped: unconditional, so the compiler counts it)
+      if (!(DBG & 1)) {                                                 // request step g + 1 (clamped: unconditional, so the compiler counts it)
         const int64_t gq = g + 1 < steps ? g + 1 : steps - 1;
         const uint4* src = Wf + gq * kFr * 64 + lane;
 #pragma unroll
         for (int f = 0; f < kFr; f++) bn[f] = src[f * 64];
       }
       // product-major over the tiles: consecutive MFMAs go to different accumulators; smallest terms first
-      SE3_PRODUCT(a3, 0)
-      SE3_PRODUCT(a1, 2)
-      SE3_PRODUCT(a2, 1)
-      SE3_PRODUCT(a2, 0)
-      SE3_PRODUCT(a1, 1)
-      SE3_PRODUCT(a1, 0)
+      if (!(DBG & 4)) {
+        SE3_PRODUCT(a3, 0)
+        SE3_PRODUCT(a1, 2)
+        SE3_PRODUCT(a2, 1)
+        SE3_PRODUCT(a2, 0)
+        SE3_PRODUCT(a1, 1)
+        SE3_PRODUCT(a1, 0)
+      } else {
+#pragma unroll
+        for (int q = 0; q < RW; q++)
+#pragma unroll
+          for (int n = 0; n < NT; n++) {
+            const bf16x8 t = a1[q] + a2[q] + a3[q] + b[n][0] + b[n][1] + b[n][2];
+            acc[q][n][0] += (float)t[0];
+          }
+      }
     }
 #undef SE3_PRODUCT
   }
@@ -494,6 +510,11 @@ extern "C" int se3_kpconv_so3_contract(const float* F, const void* weight_fragme
     // bench shape) but leave 9 waves per CU, too few to hide the build latency of the cheaper 16/32-column layers (0.92 vs 0.86 ms)
     static const char* rws = getenv("SE3_KPCONV_RW");
     const int rw = rws ? atoi(rws) : (NT == 4 ? 2 : 1);
+    static const char* rdbgs = getenv("SE3_KPCONV_RDBG");
+    const int rdbg = rdbgs ? atoi(rdbgs) : 0;
+#define SE3_ABL(D_) if (rdbg == D_ && NT == 4) { kpconv_contract_rows_kernel<4, 2, D_><<<grid, 192, lds_small, st>>>(F, Wf, num_queries, P16, in_channels, out_channels, out); SE3_CHECK_LAUNCH("kpconv_so3_contract"); return SE3_OK; }
+    SE3_ABL(1) SE3_ABL(2) SE3_ABL(4) SE3_ABL(8) SE3_ABL(3) SE3_ABL(7) SE3_ABL(15) SE3_ABL(11) SE3_ABL(6)
+#undef SE3_ABL
 #define SE3_ROWS(NT_)                                                                                                                \
   if (rw == 2) kpconv_contract_rows_kernel<NT_, 2><<<grid, 192, lds_small, st>>>(F, Wf, num_queries, P16, in_channels, out_channels, out); \
   else kpconv_contract_rows_kernel<NT_, 1><<<grid, 384, lds_small, st>>>(F, Wf, num_queries, P16, in_channels, out_channels, out);
