@@ -304,12 +304,36 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __res
   coef += (size_t)seg * 3 * C;
   params += (size_t)seg * 3 * C;
   float a1 = 0.f, a2 = 0.f;                     // this thread's share of sum_c w S1, sum_c w S2
+  // channel sums over the segment's chunks: with few channels per group the 256 threads split the chunks (fixed order: deterministic)
+  __shared__ float csum[256][3];
+  const bool split = cpg <= 256 && 256 % cpg == 0;
+  if (split) {
+    const int ci = threadIdx.x % cpg, lanes = 256 / cpg, cl = threadIdx.x / cpg;
+    float s1 = 0.f, t2 = 0.f, s4 = 0.f;
+    for (int ch = cb + cl; ch < ce; ch += lanes) {
+      const float* p = part + ((int64_t)ch * C + g * cpg + ci) * 3;
+      s1 += p[0]; t2 += p[1]; s4 += p[2];
+    }
+    csum[threadIdx.x][0] = s1; csum[threadIdx.x][1] = t2; csum[threadIdx.x][2] = s4;
+    __syncthreads();
+    for (int st = lanes >> 1; st > 0; st >>= 1) {          // lanes is a power of two whenever cpg divides 256
+      if (cl < st) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) csum[threadIdx.x][k] += csum[threadIdx.x + st * cpg][k];
+      }
+      __syncthreads();
+    }
+  }
   for (int i = threadIdx.x; i < cpg; i += 256) {
     const int c = g * cpg + i;
     float s1 = 0.f, t2 = 0.f, s4 = 0.f;
-    for (int ch = cb; ch < ce; ch++) {
-      const float* p = part + ((int64_t)ch * C + c) * 3;
-      s1 += p[0]; t2 += p[1]; s4 += p[2];
+    if (split) {
+      s1 = csum[i][0]; t2 = csum[i][1]; s4 = csum[i][2];
+    } else {
+      for (int ch = cb; ch < ce; ch++) {
+        const float* p = part + ((int64_t)ch * C + c) * 3;
+        s1 += p[0]; t2 += p[1]; s4 += p[2];
+      }
     }
     const float shift = (xb ? xb[c] : 0.f) - mean;
     const float s2 = rstd * (t2 + shift * s1);                 // sum dz xhat
