@@ -18,6 +18,7 @@ from ._lib import check, lib
 _HAS_BLAS_SWITCH = hasattr(torch.backends.cuda, 'preferred_blas_library')
 if _HAS_BLAS_SWITCH:
     torch.backends.cuda.preferred_blas_library('cublas')          # 'cublas' = rocBLAS on ROCm
+_BLAS_SWITCH_LOCK = threading.Lock()
 _BIG_GEMM_FLOP = 2.0e9     # above this the hipBLASLt kernels win (KPConv GEMMs: up to 2.7x faster than rocBLAS's choice)
 
 
@@ -28,11 +29,15 @@ def mm(a, b):
     (tools/micro/unary_gemm_backends.py: 1.0-1.4x of the HBM / MFMA bound against 1.1-2.6x)."""
     big = 2.0 * a.shape[0] * a.shape[1] * b.shape[1] > _BIG_GEMM_FLOP
     if _HAS_BLAS_SWITCH and big and (b.stride(-1) == 1 or a.shape[1] <= 32):
-        torch.backends.cuda.preferred_blas_library('cublaslt')
-        try:
+        with _BLAS_SWITCH_LOCK:          # the preference is process-global: host threads of `--inflight 2` must not interleave the flips
+            torch.backends.cuda.preferred_blas_library('cublaslt')
+            try:
+                return torch.mm(a, b)
+            finally:
+                torch.backends.cuda.preferred_blas_library('cublas')
+    if _HAS_BLAS_SWITCH and threading.active_count() > 1:
+        with _BLAS_SWITCH_LOCK:          # (a small product launched while another thread holds the flipped preference would take its path)
             return torch.mm(a, b)
-        finally:
-            torch.backends.cuda.preferred_blas_library('cublas')
     return torch.mm(a, b)
 
 
