@@ -7,15 +7,18 @@
 // is one GEMM with 2.5x fewer flops than the reference's expanded form.  Round 1 wrote G (P*6, 36 Cin) to HBM (1.2 - 2.9 GB per call)
 // and multiplied it with a library GEMM at the f32 MFMA rate.  This kernel never forms G in memory:
 //   * the gather kernel leaves F (2.4x smaller than G) in tile order [channel chunk][point][732] (15 x 6 x 8 values, zero slot, pad);
-//   * a workgroup owns 16 points (= six 16-row MFMA tiles, one per output anchor r) and streams the channel chunks; per K-step of
-//     4 weight slots x 8 channels its waves build the G fragments from the F tile in LDS (1 or 4 adds per element: the C4 orbits of the
-//     kernel points) directly in MFMA operand order;
+//   * a workgroup owns 16 points (= six 16-row MFMA tiles, one per output anchor r) and a block of up to 64 output columns and streams the
+//     channel chunks; per K-step of 4 weight slots x 8 channels every wave builds the G fragment(s) of its output anchor(s) from the F
+//     tile in LDS (1 or 4 adds per element: the C4 orbits of the kernel points) directly in MFMA operand order, in registers;
 //   * the product runs on the bf16 matrix cores at f32 accuracy: every f32 operand is split into three bf16 pieces
 //     (a = a1 + a2 + a3 exactly: 3 x 8 significant bits), the weights once per call (se3_kpconv_split_weights), G on the fly, and the six
 //     products a1 b1, a1 b2, a2 b1, a1 b3, a2 b2, a3 b1 (everything above 2^-24 relative) accumulate in f32:
 //     6 x v_mfma_f32_16x16x32_bf16 = 96 cycles for what 8 x v_mfma_f32_16x16x4_f32 do in 256.
-// Waves split the output columns (each B fragment is used by all six row tiles), the weight fragments are streamed from L2 in lane order
-// (1 KB per fragment, pre-arranged by the split kernel) and each workgroup reads them exactly once.
+// The weight fragments are streamed from L2 / L1 in lane order (1 KB per fragment, pre-arranged by the split kernel).  Layers wider than 64
+// columns run one workgroup per (point tile, block of 64 columns): the fragments are rebuilt per block (a fifth of the time), nothing is
+// shared through LDS and no barrier sits inside a channel chunk.  (The round also built a dedicated wide kernel -- 8 waves in two role
+// groups sharing the G fragments through LDS, LDS-DMA tile copies, raw s_barrier: 1.6-1.76 ms on the 128 / 256-column layers against
+// 1.2-1.3 ms for the column-block form here; DESIGN.md section 4 keeps its measurements.)
 #include "common.h"
 #include <stdlib.h>
 
@@ -32,8 +35,6 @@ constexpr int kRow = kK * kA * kCC;           // 720 floats of F per point and c
 constexpr int kRowPad = 732;
 constexpr int kZeroSlot = kRow;               // float offset of the zero slot inside a row
 constexpr int kTileFloats = kTP * kRowPad;    // 11712 floats = 2928 float4
-constexpr int kTilePieces = (kTileFloats * 4 + 1023) / 1024;      // 46 LDS-DMA pieces of 1 KB (64 lanes x 16 B)
-constexpr int kTileLds = kTilePieces * 256;   // floats per F buffer in LDS of the wide kernel (whole pieces: 256 B beyond the tile)
 
 // slot tables of the SE3ET configuration (se3et_amd/tables.py; identical to csrc/kpconv_so3.hip)
 __device__ constexpr int kKidx[kK][kA] = {{0, 1, 1, 1, 1, 2}, {1, 0, 1, 2, 1, 1}, {1, 1, 0, 1, 2, 1}, {1, 2, 1, 0, 1, 1},
@@ -101,7 +102,7 @@ __global__ void kpconv_split_weights_kernel(const float* __restrict__ W, int Cin
 // ---- contraction -------------------------------------------------------------------------------------------------------------------
 struct SlotEntry { unsigned short off[4]; };           // float offsets (k*6 + a) * 8 of the orbit members inside a point's F row
 
-// ---- narrow layers (<= 64 output channels): one wave per output anchor, fragments in registers ---------------------------------------------
+// ---- one wave per output anchor (or two), fragments in registers ---------------------------------------------
 // With few output columns a K-step holds little matrix work per G fragment (6 MFMAs per column tile) and the kernel is bound by BUILDING
 // the fragments.  So the six row tiles (output anchors) go to six waves: wave r builds its own fragment of the K-step in registers and
 // multiplies it with all NT column tiles -- no fragment buffer in LDS, no barrier inside a channel chunk (the round's first narrow kernel
@@ -166,6 +167,11 @@ __global__ __launch_bounds__(384 / RW) __attribute__((amdgpu_waves_per_eu(RW == 
   const float* frow = ftile + prow * kRowPad;
   constexpr int kFr = 3 * NT;                         // weight fragments of a K-step (a fragment = 64 lanes x 16 B, lane-linear)
   uint4 bn[kFr];                                      // next K-step's fragments, in flight while this step is built and multiplied
+  // blockIdx.y: the workgroup's block of NT column tiles (layers wider than 64 columns run one workgroup per (point tile, column block):
+  // every block rebuilds the fragments -- a fifth of the time -- and nothing is shared through LDS)
+  const int nt0 = blockIdx.y * NT;
+  const int64_t step_frags = (int64_t)(Cout / 16) * 3;                  // fragments of a K-step over the whole layer
+  Wf += (int64_t)nt0 * 3 * 64;
 #pragma unroll
   for (int f = 0; f < kFr; f++) bn[f] = Wf[f * 64 + lane];
   int64_t g = 0;
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(384 / RW) __attribute__((amdgpu_waves_per_eu(RW == 
         for (int pc = 0; pc < 3; pc++) b[n][pc] = __builtin_bit_cast(bf16x8, bn[n * 3 + pc]);
       if (!(DBG & 1)) {                                                 // request step g + 1 (clamped: unconditional, so the compiler counts it)
         const int64_t gq = g + 1 < steps ? g + 1 : steps - 1;
-        const uint4* src = Wf + gq * kFr * 64 + lane;
+        const uint4* src = Wf + gq * step_frags * 64 + lane;
 #pragma unroll
         for (int f = 0; f < kFr; f++) bn[f] = src[f * 64];
       }
@@ -243,220 +249,7 @@ __global__ __launch_bounds__(384 / RW) __attribute__((amdgpu_waves_per_eu(RW == 
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int64_t p = p0 + (lane >> 4) * 4 + i;
-        if (p < P) out[(p * kA + r0 + q) * Cout + n * 16 + (lane & 15)] = acc[q][n][i];
-      }
-}
-
-// ---- wide layers (>= 128 output channels per workgroup): 8 waves in two groups that alternate roles ------------------------------------
-// Waves w and w + 4 share a SIMD.  Every K-step has two halves separated by a barrier: in the first, group X (waves 0..3) multiplies step
-// g while group Y (waves 4..7) builds G-fragment sets 0..2 of step g + 1, requests its own weight fragments and copies a slice of the next
-// channel chunk's F tile; in the second half the roles swap (X builds sets 3..5).  So each SIMD always has one wave on the matrix pipe
-// and one on the VALU / LDS side, instead of both doing the same thing in lockstep behind a common barrier.
-template <int NTW>      // column tiles per wave (8 waves: 8 * NTW column tiles per workgroup)
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void kpconv_contract_wide_kernel(const float* __restrict__ F, const uint4* __restrict__ Wf,
-                                                                       int64_t P, int64_t P16, int Cin, int Cout,
-                                                                       float* __restrict__ out, int dbg) {
-  extern __shared__ __align__(16) float lds[];
-  float* fbuf = lds;                                                    // [2][16 points][732]
-  uint4* abuf = reinterpret_cast<uint4*>(lds + 2 * kTileLds);           // [2][6 r][3 pieces][64 lanes]
-  SlotEntry* tab = reinterpret_cast<SlotEntry*>(abuf + 2 * kA * 3 * 64);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int grp = wave >> 2, wg = wave & 3;                             // role group, wave inside the group
-  const int NT = Cout / 16;
-  const int nt0 = (blockIdx.y * 8 + wave) * NTW;
-  const int64_t p0 = (int64_t)blockIdx.x * kTP;
-  for (int e = tid; e < kKS * kA * 4; e += 512) {
-    const int kb = e & 3, r = (e >> 2) % kA, ks = e / (4 * kA);
-    const int st = slot_at(4 * ks + kb), s = st / kA, t = st % kA;
-    int a = 0;
-    for (int aa = 0; aa < kA; aa++) a = kRidx[aa][r] == t ? aa : a;
-    unsigned long long packed = (unsigned long long)kZeroSlot * 0x0001000100010001ull;   // four 16-bit offsets; absent member = zero slot
-    int cnt = 0;
-    for (int k = 0; k < kK; k++)
-      if (kKidx[k][r] == s && cnt < 4) {
-        const unsigned long long off = (unsigned long long)((k * kA + a) * kCC);
-        packed = (packed & ~(0xffffull << (16 * cnt))) | (off << (16 * cnt));
-        cnt++;
-      }
-    reinterpret_cast<unsigned long long*>(tab)[e] = packed;
-  }
-  const int chunks = Cin / kCC;
-  const int prow = lane & 15, kb = lane >> 4;
-  {   // F tile of chunk 0
-    const float4* src = reinterpret_cast<const float4*>(F + p0 * kRowPad);
-    for (int q = tid; q < kTileFloats / 4; q += 512) reinterpret_cast<float4*>(fbuf)[q] = src[q];
-  }
-  __syncthreads();
-
-  // G fragments of K-step `ks`, output anchor r, built in one go (prologue only)
-  auto build = [&](const float* fb, uint4* ab, int ks, int r) {
-    const float* frow = fb + prow * kRowPad;
-    const SlotEntry en = tab[(ks * kA + r) * 4 + kb];
-    float v[8];
-    {
-      const float4 x0 = *reinterpret_cast<const float4*>(frow + en.off[0]);
-      const float4 x1 = *reinterpret_cast<const float4*>(frow + en.off[0] + 4);
-      v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-    }
-    if (ks >= 4) {                      // block-uniform: K-steps 0..3 hold single-member slots only (absent members: zero slot)
-#pragma unroll
-      for (int j = 1; j < 4; j++) {
-        const float* sp = frow + en.off[j];
-        const float4 x0 = *reinterpret_cast<const float4*>(sp);
-        const float4 x1 = *reinterpret_cast<const float4*>(sp + 4);
-        v[0] += x0.x; v[1] += x0.y; v[2] += x0.z; v[3] += x0.w; v[4] += x1.x; v[5] += x1.y; v[6] += x1.z; v[7] += x1.w;
-      }
-    }
-    uint4 p1, p2, p3;
-    split3(v, p1, p2, p3);
-    uint4* dst = ab + (r * 3) * 64 + lane;
-    dst[0] = p1;
-    dst[64] = p2;
-    dst[128] = p3;
-  };
-  if (wave < kA) build(fbuf, abuf, 0, wave);
-
-  const int64_t steps = (int64_t)chunks * kKS;
-  f32x4 acc[kA][NTW];
-#pragma unroll
-  for (int r = 0; r < kA; r++)
-#pragma unroll
-    for (int n = 0; n < NTW; n++) acc[r][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // weight fragments: b = the step being multiplied, bn = the following step, requested a full K-step (three halves) before its first use:
-  // one half is shorter than an L2 / HBM round trip under load
-  uint4 b[NTW][3], bn[NTW][3];
-  auto load_b = [&](int64_t g) {
-    if (dbg & 16) g = 0;                         // timing experiment: the same fragments every step (no weight stream)
-    const int64_t gc = g < steps ? g : steps - 1;
-#pragma unroll
-    for (int n = 0; n < NTW; n++) {
-      const uint4* src = Wf + ((gc * NT + nt0 + n) * 3) * 64 + lane;
-#pragma unroll
-      for (int pc = 0; pc < 3; pc++) bn[n][pc] = src[pc * 64];
-    }
-  };
-  auto rotate_b = [&]() {
-#pragma unroll
-    for (int n = 0; n < NTW; n++)
-#pragma unroll
-      for (int pc = 0; pc < 3; pc++) b[n][pc] = bn[n][pc];
-  };
-  auto multiply = [&](const uint4* ab) {
-    bf16x8 a1[kA], a2[kA], a3[kA];
-    if (dbg & 4) ab = abuf + (lane & 1) * 64;        // timing experiment: every fragment from two addresses (no LDS bandwidth)
-    // read order = order of first use (a3, a1, a2): the first MFMAs start when a third of the fragments has arrived
-#pragma unroll
-    for (int r = 0; r < kA; r++) a3[r] = __builtin_bit_cast(bf16x8, ab[(r * 3 + 2) * 64 + lane]);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int r = 0; r < kA; r++) a1[r] = __builtin_bit_cast(bf16x8, ab[(r * 3) * 64 + lane]);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int r = 0; r < kA; r++) a2[r] = __builtin_bit_cast(bf16x8, ab[(r * 3 + 1) * 64 + lane]);
-    // all 18 fragment reads are issued before the first MFMA (the compiler otherwise pairs each read with the MFMA that needs it and
-    // exposes one LDS round trip per MFMA); the MFMAs then wait with counted lgkmcnt as the fragments arrive
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int n = 0; n < NTW; n++) {
-      const bf16x8 b1 = __builtin_bit_cast(bf16x8, b[n][0]), b2 = __builtin_bit_cast(bf16x8, b[n][1]),
-                   b3 = __builtin_bit_cast(bf16x8, b[n][2]);
-      // product-major: consecutive MFMAs go to different accumulators (no dependent back-to-back issue); smallest terms first
-#pragma unroll
-      for (int r = 0; r < kA; r++) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[r], b1, acc[r][n], 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < kA; r++) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[r], b3, acc[r][n], 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < kA; r++) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[r], b2, acc[r][n], 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < kA; r++) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[r], b1, acc[r][n], 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < kA; r++) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[r], b2, acc[r][n], 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < kA; r++) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[r], b1, acc[r][n], 0, 0, 0);
-    }
-  };
-
-  // Builder waves: group Y waves 4..6 own output anchors r = 0..2 (first halves), group X waves 0..2 own r = 3..5 (second halves).
-  const bool builder = wg < 3;
-  const int rfix = grp == 1 ? wg : 3 + wg;
-
-  load_b(0);
-  if (grp == 0) {                      // X multiplies step 0 in the first half of the first K-step
-    rotate_b();
-    load_b(1);
-  }
-  __syncthreads();
-
-  int cc = 0, ks = 0;
-#pragma unroll 1
-  for (int64_t g = 0; g < steps; g++) {
-    const int cur = (int)(g & 1);
-    uint4* anext = abuf + (cur ^ 1) * kA * 3 * 64;
-    const uint4* acur = abuf + cur * kA * 3 * 64;
-    const int ks1 = ks + 1 == kKS ? 0 : ks + 1;
-    const int cc1 = ks + 1 == kKS ? cc + 1 : cc;           // chunk of step g + 1: its F tile arrived by LDS-DMA during this chunk
-    // The NEXT channel chunk's F tile goes global -> LDS by LDS-DMA (no registers, no store pass), requested by all eight waves at the
-    // first K-step of a chunk: 46 pieces of 1 KB, lane-linear on both sides (global rows have the LDS row stride).  Its first readers
-    // are the row requests of K-step 7; every wave retires its pieces long before that (the weight-fragment waits of K-step 1 drain
-    // them: requests complete in order), and the barriers in between publish them to the other waves.
-    if (ks == 0 && cc + 1 < chunks && !(dbg & 64)) {
-      const float* gsrc = F + ((int64_t)(cc + 1) * P16 + p0) * kRowPad;
-      float* ldst = fbuf + ((cc + 1) & 1) * kTileLds;
-#pragma unroll
-      for (int i = 0; i < (kTilePieces + 7) / 8; i++) {
-        const int piece = i * 8 + wave;
-        if (piece < kTilePieces)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + piece * 256 + lane * 4),
-                                           (__attribute__((address_space(3))) void*)(ldst + piece * 256), 16, 0, 0);
-      }
-    }
-    // the builder's half: fragments of step g + 1, output anchor rfix, from the F buffer that holds that step (built in one go: a
-    // three-stage register pipeline across halves -- table entry, F rows, add / split / store -- was measured 25 % SLOWER: the extra
-    // live registers and the unconditional four-row reads cost more than the LDS round trips they hide)
-#define SE3_BUILD_HALF()                                                                                  \
-    if (builder && !(dbg & 1) && g + 1 < steps) build(fbuf + (cc1 & 1) * kTileLds, anext, ks1, rfix);
-    // End of a build half: the fragment stores must have landed before the barrier (raw s_barrier + explicit lgkmcnt wait; a plain
-    // __syncthreads() would also drain the VMEM queue, i.e. the weight fragments requested for the NEXT step).
-#define SE3_BUILD_FENCE()                                                                                 \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // ---- first half: X multiplies step g, Y prepares
-    if (grp == 0) {
-      if (!(dbg & 2)) multiply(acur);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    } else {
-      if (!(dbg & 32)) {
-      rotate_b();                                      // Y multiplies step g in the second half
-      load_b(g + 1);
-      }
-      SE3_BUILD_HALF()
-      SE3_BUILD_FENCE()
-    }
-    if (!(dbg & 8)) __builtin_amdgcn_s_barrier();
-    // ---- second half: Y multiplies step g, X prepares
-    if (grp == 1) {
-      if (!(dbg & 2)) multiply(acur);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    } else {
-      if (!(dbg & 32)) {
-      rotate_b();                                      // X multiplies step g + 1 in the next first half
-      load_b(g + 2);
-      }
-      SE3_BUILD_HALF()
-      SE3_BUILD_FENCE()
-    }
-    if (!(dbg & 8)) __builtin_amdgcn_s_barrier();
-    if (++ks == kKS) { ks = 0; cc++; }
-  }
-#undef SE3_BUILD_HALF
-#undef SE3_BUILD_FENCE
-#pragma unroll
-  for (int r = 0; r < kA; r++)
-#pragma unroll
-    for (int n = 0; n < NTW; n++)
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int64_t p = p0 + (lane >> 4) * 4 + i;
-        if (p < P) out[(p * kA + r) * Cout + (nt0 + n) * 16 + (lane & 15)] = acc[r][n][i];
+        if (p < P) out[(p * kA + r0 + q) * Cout + (nt0 + n) * 16 + (lane & 15)] = acc[q][n][i];
       }
 }
 
@@ -495,14 +288,7 @@ extern "C" int se3_kpconv_so3_contract(const float* F, const void* weight_fragme
   // split over the columns as well so that the grid fills the chip (the G fragments are then built once per column split)
   const uint4* Wf = static_cast<const uint4*>(weight_fragments);
   hipStream_t st = (hipStream_t)stream;
-  static bool lds_attr_set = false;      // > 64 KB of dynamic LDS needs the opt-in once per kernel
   const size_t lds_small = (size_t)kTileFloats * 4 + (size_t)kKS * kA * 4 * sizeof(SlotEntry);
-  const size_t lds_wide = (size_t)(2 * kTileLds) * 4 + (size_t)2 * kA * 3 * 64 * 16 + (size_t)kKS * kA * 4 * sizeof(SlotEntry);
-  if (!lds_attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kpconv_contract_wide_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kpconv_contract_wide_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide);
-    lds_attr_set = true;
-  }
   if (NT <= 4) {
     // narrow layers: one wave per output anchor, all column tiles per wave
     const dim3 grid((unsigned)tiles, 1u);
@@ -521,18 +307,10 @@ extern "C" int se3_kpconv_so3_contract(const float* F, const void* weight_fragme
     if (NT == 4) { SE3_ROWS(4) } else if (NT == 3) { SE3_ROWS(3) } else if (NT == 2) { SE3_ROWS(2) } else { SE3_ROWS(1) }
 #undef SE3_ROWS
   } else {
-    SE3_REQUIRE(NT % 8 == 0, SE3_ERR_UNSUPPORTED, "kpconv_so3_contract: %d output channels (need <= 64 or a multiple of 128)",
-                out_channels);
-    // 8 waves x NTW column tiles per workgroup; layers with few row tiles use the narrower workgroup so that the grid fills the chip
-    static const char* force = getenv("SE3_KPCONV_NTW");
-    static const char* dbgs = getenv("SE3_KPCONV_DBG");
-    const int dbg = dbgs ? atoi(dbgs) : 0;
-    const bool two = NT % 16 == 0 && (force ? force[0] == '2' : tiles >= 2 * 256);
-    const dim3 grid((unsigned)tiles, (unsigned)(NT / (two ? 16 : 8)));
-    if (two)
-      kpconv_contract_wide_kernel<2><<<grid, 512, lds_wide, st>>>(F, Wf, num_queries, P16, in_channels, out_channels, out, dbg);
-    else
-      kpconv_contract_wide_kernel<1><<<grid, 512, lds_wide, st>>>(F, Wf, num_queries, P16, in_channels, out_channels, out, dbg);
+    // wider layers: the same kernel, one workgroup per (point tile, block of 64 columns)
+    SE3_REQUIRE(NT % 4 == 0, SE3_ERR_UNSUPPORTED, "kpconv_so3_contract: %d output channels (need <= 64 or a multiple of 64)", out_channels);
+    const dim3 grid((unsigned)tiles, (unsigned)(NT / 4));
+    kpconv_contract_rows_kernel<4, 2><<<grid, 192, lds_small, st>>>(F, Wf, num_queries, P16, in_channels, out_channels, out);
   }
   SE3_CHECK_LAUNCH("kpconv_so3_contract");
   return SE3_OK;

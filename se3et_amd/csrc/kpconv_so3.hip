@@ -44,7 +44,7 @@ template <bool BUILTIN, bool FOUT = false>
 __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restrict__ q_pts, const float* __restrict__ s_pts,
                                                             const int64_t* __restrict__ idx, const float* __restrict__ x,
                                                             ConvTables T, float inv_sigma, int64_t P, int64_t Ns, int NN,
-                                                            int Cin, float* __restrict__ G, int64_t P16 = 0, bool staged = false) {
+                                                            int Cin, float* __restrict__ G, int64_t P16 = 0) {
   __shared__ float w[kMaxNN][kK + 1];
   __shared__ int64_t nb[kMaxNN];
   __shared__ unsigned xrow[kMaxNN];      // element offset of the neighbour's feature row (clamped: invalid rows carry weight 0)
@@ -82,8 +82,12 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
   // entries carry weight, so the loop stops after the last valid one (rounded up to the 8 rows in flight; skipped terms are
   // exact zeros, the sums are unchanged)
   const int NV8 = (last_s + 7) & ~7;
-  for (int col = threadIdx.x; col < cols; col += blockDim.x) {
-    const int a = col / Cin, c = col - a * Cin;
+  // FOUT: channel blocks of up to 128 (the staged rows of a block: 47 KB of LDS); otherwise one pass over all columns
+  const int CBw = FOUT ? min(Cin, 128) : Cin;
+  for (int cb0 = 0; cb0 < Cin; cb0 += CBw) {
+  for (int lc = threadIdx.x; lc < kA * CBw; lc += blockDim.x) {
+    const int a = lc / CBw, c = cb0 + (lc - a * CBw);
+    const int col = a * Cin + c;
     float f[kK];
 #pragma unroll
     for (int k = 0; k < kK; k++) f[k] = 0.f;
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
       }
     }
     if (FOUT) {      // row of (point, channel chunk): 15 x 6 x 8 values, an 8-float zero slot, 4 pad = kFRow floats: staged in LDS, written below
-      float* Fp = (staged ? fstage + (c >> 3) * kFRow : G + ((int64_t)(c >> 3) * P16 + p) * kFRow) + a * 8 + (c & 7);
+      float* Fp = fstage + ((c - cb0) >> 3) * kFRow + a * 8 + (c & 7);
 #pragma unroll
       for (int k = 0; k < kK; k++) Fp[k * kA * 8] = f[k];
       continue;
@@ -125,20 +129,20 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
       for (int sl = 0; sl < kS; sl++) __builtin_nontemporal_store(s[sl], &Gp[((int64_t)(r * kS + sl) * kA + t) * Cin + c]);
     }
   }
-  if (FOUT) {        // zero slot + pad of every row, then the point's rows leave LDS as whole 2928-byte runs (float4 per lane; written as
+  if (FOUT) {        // zero slot + pad of every row, then the block's rows leave LDS as whole 2928-byte runs (float4 per lane; written as
                      // 4-byte scatters straight from the column threads each 192-byte run came from three different store instructions)
-    for (int e = threadIdx.x; e < (Cin >> 3) * (kFRow - kK * kA * 8); e += blockDim.x) {
+    for (int e = threadIdx.x; e < (CBw >> 3) * (kFRow - kK * kA * 8); e += blockDim.x) {
       const int cc = e / (kFRow - kK * kA * 8), w = e - cc * (kFRow - kK * kA * 8);
-      (staged ? fstage + cc * kFRow : G + ((int64_t)cc * P16 + p) * kFRow)[kK * kA * 8 + w] = 0.f;
+      fstage[cc * kFRow + kK * kA * 8 + w] = 0.f;
     }
-    if (staged) {
-      __syncthreads();
-      const int row4 = kFRow / 4;
-      for (int e = threadIdx.x; e < (Cin >> 3) * row4; e += blockDim.x) {
-        const int cc = e / row4, q = e - cc * row4;
-        reinterpret_cast<float4*>(G + ((int64_t)cc * P16 + p) * kFRow)[q] = reinterpret_cast<const float4*>(fstage + cc * kFRow)[q];
-      }
+    __syncthreads();
+    const int row4 = kFRow / 4;
+    for (int e = threadIdx.x; e < (CBw >> 3) * row4; e += blockDim.x) {
+      const int cc = e / row4, q = e - cc * row4;
+      reinterpret_cast<float4*>(G + ((int64_t)((cb0 >> 3) + cc) * P16 + p) * kFRow)[q] = reinterpret_cast<const float4*>(fstage + cc * kFRow)[q];
     }
+    __syncthreads();                                     // the next block overwrites the staging rows
+  }
   }
 }
 
@@ -275,11 +279,10 @@ extern "C" int se3_kpconv_so3_gather_points(const float* q_pts, const float* s_p
   const int cols = kA * in_channels;
   const int threads = cols >= 256 ? 256 : (cols >= 128 ? 128 : 64);
   const int64_t P16 = (num_queries + 15) / 16 * 16;
-  // rows staged in LDS and written as whole runs up to 128 input channels (47 KB: three workgroups per CU); direct 4-byte scatters beyond
-  const bool staged = in_channels <= 128;
-  const size_t stage_bytes = staged ? (size_t)(in_channels / 8) * kFRow * sizeof(float) : 0;
+  // rows staged in LDS in blocks of up to 128 input channels (47 KB: three workgroups per CU) and written as whole runs
+  const size_t stage_bytes = (size_t)((in_channels < 128 ? in_channels : 128) / 8) * kFRow * sizeof(float);
   kpconv_gather_kernel<true, true><<<(unsigned)num_queries, threads, stage_bytes, (hipStream_t)stream>>>(
-      q_pts, s_pts, idx, x, T, 1.0f / sigma, num_queries, num_support, num_neighbors, in_channels, F, P16, staged);
+      q_pts, s_pts, idx, x, T, 1.0f / sigma, num_queries, num_support, num_neighbors, in_channels, F, P16);
   SE3_CHECK_LAUNCH("kpconv_so3_gather_points");
   return SE3_OK;
 }

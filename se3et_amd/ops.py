@@ -383,8 +383,8 @@ def _host_table(t, dtype):
 
 # KPConv contraction path: True = always the matrix-core kernels (csrc/kpconv_contract.hip) where the channel counts allow, False = always
 # the round-1 path (slot sums G in HBM + library f32 GEMM), 'auto' = per layer shape, whichever measured faster on MI355X at the bench
-# shape (tools/micro/kpconv_paths.py, profiles/r02_kpconv_paths.txt): today every layer with <= 64 output channels (32: 0.86 against 1.00 ms,
-# 64: 1.41 against 1.69 ms per call at 8 pairs); the 128 / 256-column layers stay on the library GEMM (1.6-1.8 against 1.2-1.3 ms).
+# shape (tools/micro/kpconv_paths.py, profiles/r02_kpconv_paths.txt): today the hand-written path on every SE3ET layer (32: 0.80 against
+# 0.97 ms, 64: 1.26 against 1.63, 128: 1.68 against 1.91, 256: 1.49 against 1.62 ms per call at 8 pairs).
 # Both paths agree to f32 round-off (tests/test_gpu_ops.py::test_kpconv_matrix_core_path_has_f32_accuracy).
 KPCONV_MATRIX_CORE = os.environ.get('SE3_KPCONV_PATH', 'auto')
 KPCONV_MATRIX_CORE = {'mfma': True, 'gemm': False}.get(KPCONV_MATRIX_CORE, 'auto')
@@ -392,7 +392,7 @@ KPCONV_MATRIX_CORE = {'mfma': True, 'gemm': False}.get(KPCONV_MATRIX_CORE, 'auto
 
 def _kpconv_use_matrix_core(Cin, Cout):
     if KPCONV_MATRIX_CORE == 'auto':
-        return Cout <= 64          # narrow layers: the one-wave-per-anchor kernel beats gather + library GEMM
+        return Cout <= 64 or Cout % 64 == 0          # the shapes the contraction kernel takes
     return bool(KPCONV_MATRIX_CORE)
 
 
@@ -468,7 +468,7 @@ def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, s
         raise RuntimeError('kpconv_inter_so3: inconsistent shapes')
     kp, kt, rt = _host_table(kernel_points, torch.float32), _host_table(kidx, torch.int64), _host_table(ridx, torch.int64)
     nt = Cout // 16
-    if _kpconv_use_matrix_core(Cin, Cout) and Cin % 8 == 0 and Cout % 16 == 0 and (nt <= 4 or nt % 8 == 0) and _builtin_slot_tables(kt, rt):
+    if _kpconv_use_matrix_core(Cin, Cout) and Cin % 8 == 0 and Cout % 16 == 0 and (nt <= 4 or nt % 4 == 0) and _builtin_slot_tables(kt, rt):
         # matrix-core path: F (P16, 90, Cin) in tile order -> slot sums on the fly -> bf16x6 MFMA at f32 accuracy (csrc/kpconv_contract.hip)
         stream = _stream()
         Fk = torch.empty((lib().se3_kpconv_points_floats(P, Cin),), dtype=torch.float32, device=x.device)
