@@ -15,6 +15,7 @@
 // feature columns (a, c) (coalesced reads of the gathered rows), keeps the 15 per-kernel-point sums in registers and
 // writes its 36 slot sums.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -40,7 +41,7 @@ __device__ constexpr int kBuiltinRidx[kA][kA] = {{0, 3, 3, 3, 3, 5}, {1, 0, 4, 5
 
 // FOUT: leave the kernel-point sums F themselves for the matrix-core contraction (csrc/kpconv_contract.hip) in its tile order
 // [channel chunk of 8][point (padded to 16)][k * 6 + a][8 channels] instead of the 2.4x larger slot sums G.
-template <bool BUILTIN, bool FOUT = false>
+template <bool BUILTIN, bool FOUT = false, int FL = 8>      // FL: gathered rows in flight per thread (16 measured 10 % slower)
 __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restrict__ q_pts, const float* __restrict__ s_pts,
                                                             const int64_t* __restrict__ idx, const float* __restrict__ x,
                                                             ConvTables T, float inv_sigma, int64_t P, int64_t Ns, int NN,
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
   const int64_t p = blockIdx.x;
   const int cols = kA * Cin;
   const float qx = q_pts[3 * p], qy = q_pts[3 * p + 1], qz = q_pts[3 * p + 2];
-  const int NN8 = (NN + 7) & ~7;
+  const int NN8 = (NN + FL - 1) & ~(FL - 1);
   __shared__ int last_s;                 // 1 + position of the last valid neighbour
   if (threadIdx.x < 64) {                // NN8 <= 64: the first wave fills the table
     const int n = threadIdx.x;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
   // the tables are padded at the end (sorted by distance, then the padding index / the -1 width marker): only the leading valid
   // entries carry weight, so the loop stops after the last valid one (rounded up to the 8 rows in flight; skipped terms are
   // exact zeros, the sums are unchanged)
-  const int NV8 = (last_s + 7) & ~7;
+  const int NV8 = (last_s + FL - 1) & ~(FL - 1);
   // FOUT: channel blocks of up to 128 (the staged rows of a block: 47 KB of LDS); otherwise one pass over all columns
   const int CBw = FOUT ? min(Cin, 128) : Cin;
   for (int cb0 = 0; cb0 < Cin; cb0 += CBw) {
@@ -93,12 +94,12 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
     for (int k = 0; k < kK; k++) f[k] = 0.f;
     // 8 gathered rows in flight per thread (the loop is otherwise one L2 round trip per neighbour); padded / shadow
     // neighbours read row 0 with weight 0, so the body is branch-free
-    for (int n0 = 0; n0 < NV8; n0 += 8) {
-      float xv[8];
+    for (int n0 = 0; n0 < NV8; n0 += FL) {
+      float xv[FL];
 #pragma unroll
-      for (int u = 0; u < 8; u++) xv[u] = x[xrow[n0 + u] + (unsigned)col];
+      for (int u = 0; u < FL; u++) xv[u] = x[xrow[n0 + u] + (unsigned)col];
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
+      for (int u = 0; u < FL; u++) {
 #pragma unroll
         for (int k = 0; k < kK; k++) f[k] = fmaf(w[n0 + u][k], xv[u], f[k]);
       }
