@@ -132,6 +132,12 @@ int se3_group_norm_segments_bwd(const float* x, const float* x_bias, const float
 int se3_add_layer_norm_fwd(const float* hidden, const float* hidden_bias, const float* residual, const float* weight,
                            const float* bias, int64_t rows, int64_t residual_rows, int channels, float eps, float* out,
                            void* stream);
+/* Backward (training step: autograd through the residual + nn.LayerNorm tails): grad_hidden (rows, channels), which is also the gradient
+ * of the residual before its anchor broadcast is summed; grad_params (3, channels) = (d weight, d bias, d hidden_bias), zero-initialised
+ * by the caller and accumulated with float atomics. */
+int se3_add_layer_norm_bwd(const float* hidden, const float* hidden_bias, const float* residual, const float* weight,
+                           const float* grad_out, int64_t rows, int64_t residual_rows, int channels, float eps, float* grad_hidden,
+                           float* grad_params, void* stream);
 
 /* ---- B2/B3: padded row gather and neighbour max pooling ------------------------------------------------------------
  * Replace nearest_upsample (geotransformer/modules/kpconv/functional.py:6-22), the zero-padded patch gathers of

@@ -31,6 +31,7 @@ SIGNATURES = {
     'se3_group_norm_segments_bwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _f32, _i32, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
     'se3_group_norm_segments_fwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _f32, _i32, _f32, _vp, _vp, _sz, _vp]),
     'se3_add_layer_norm_fwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _f32, _vp, _vp]),
+    'se3_add_layer_norm_bwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _f32, _vp, _vp, _vp]),
     'se3_gather_rows_padded': (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     'se3_neighbor_max_pool': (_i32, [_vp, _vp, _i64, _i64, _i32, _i64, _vp, _vp]),
     'se3_neighbor_max_pool_bwd': (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i64, _vp, _vp]),

@@ -436,6 +436,98 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float* __restrict__ h
   }
 }
 
+// Backward of add_ln_kernel: v = h + hb + res, xhat = (v - mean) rstd, y = xhat w + b.  dv = rstd (dy w - mean(dy w) - xhat mean(dy w xhat));
+// dh = dv (also the residual's gradient; summed over the anchor blocks by the caller when the residual was broadcast); per-channel sums
+// params[0] = sum_rows dy xhat (d weight), params[1] = sum_rows dy (d bias), params[2] = sum_rows dv (d hidden_bias): a wave walks 8 rows with the
+// sums in registers, the four waves of a workgroup meet in LDS, one float atomic per channel, sum and workgroup (params zero-initialised).
+template <int VPL>
+__global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict__ h, const float* __restrict__ hb,
+                                                         const float* __restrict__ res, const float* __restrict__ w,
+                                                         const float* __restrict__ dy, int64_t rows, int64_t res_rows, int C, float eps,
+                                                         float* __restrict__ dh, float* __restrict__ params) {
+  __shared__ float4 red[3][4][64 * VPL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C4 = C >> 2;
+  float4 sw[VPL], sb[VPL], sv[VPL];
+#pragma unroll
+  for (int k = 0; k < VPL; k++) sw[k] = sb[k] = sv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int rr = 0; rr < 8; rr++) {
+    const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * 8 + rr;
+    if (row >= rows) break;                                  // wave-uniform
+    const float4* hp = reinterpret_cast<const float4*>(h + row * C);
+    const float4* rp = reinterpret_cast<const float4*>(res + (row % res_rows) * C);
+    const float4* gp = reinterpret_cast<const float4*>(dy + row * C);
+    float4 v[VPL], g[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPL; k++) {
+      const int i = lane + 64 * k;
+      v[k] = g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < C4) {
+        const float4 a = hp[i], r = rp[i];
+        const float4 c = hb ? reinterpret_cast<const float4*>(hb)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[k] = make_float4((a.x + c.x) + r.x, (a.y + c.y) + r.y, (a.z + c.z) + r.z, (a.w + c.w) + r.w);
+        g[k] = gp[i];
+        s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+      }
+    }
+    const float mean = se3_wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPL; k++) {
+      const int i = lane + 64 * k;
+      if (i < C4) {
+        v[k] = make_float4(v[k].x - mean, v[k].y - mean, v[k].z - mean, v[k].w - mean);
+        q += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
+      }
+    }
+    const float rstd = 1.0f / sqrtf(se3_wave_sum(q) / (float)C + eps);
+    float m1 = 0.f, m2 = 0.f;                               // sum dy w, sum dy w xhat
+    float4 gw[VPL];
+#pragma unroll
+    for (int k = 0; k < VPL; k++) {
+      const int i = lane + 64 * k;
+      gw[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < C4) {
+        const float4 ww = reinterpret_cast<const float4*>(w)[i];
+        v[k] = make_float4(v[k].x * rstd, v[k].y * rstd, v[k].z * rstd, v[k].w * rstd);      // xhat
+        gw[k] = make_float4(g[k].x * ww.x, g[k].y * ww.y, g[k].z * ww.z, g[k].w * ww.w);
+        m1 += (gw[k].x + gw[k].y) + (gw[k].z + gw[k].w);
+        m2 += (gw[k].x * v[k].x + gw[k].y * v[k].y) + (gw[k].z * v[k].z + gw[k].w * v[k].w);
+      }
+    }
+    m1 = se3_wave_sum(m1) / (float)C;
+    m2 = se3_wave_sum(m2) / (float)C;
+    float4* dp = reinterpret_cast<float4*>(dh + row * C);
+#pragma unroll
+    for (int k = 0; k < VPL; k++) {
+      const int i = lane + 64 * k;
+      if (i < C4) {
+        const float4 d = make_float4(rstd * (gw[k].x - m1 - v[k].x * m2), rstd * (gw[k].y - m1 - v[k].y * m2),
+                                     rstd * (gw[k].z - m1 - v[k].z * m2), rstd * (gw[k].w - m1 - v[k].w * m2));
+        dp[i] = d;
+        sw[k] = make_float4(sw[k].x + g[k].x * v[k].x, sw[k].y + g[k].y * v[k].y, sw[k].z + g[k].z * v[k].z, sw[k].w + g[k].w * v[k].w);
+        sb[k] = make_float4(sb[k].x + g[k].x, sb[k].y + g[k].y, sb[k].z + g[k].z, sb[k].w + g[k].w);
+        sv[k] = make_float4(sv[k].x + d.x, sv[k].y + d.y, sv[k].z + d.z, sv[k].w + d.w);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < VPL; k++) {
+    red[0][wave][lane + 64 * k] = sw[k];
+    red[1][wave][lane + 64 * k] = sb[k];
+    red[2][wave][lane + 64 * k] = sv[k];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 3 * C; e += 256) {
+    const int which = e / C, c = e - which * C;
+    float t = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < 4; wv++) t += reinterpret_cast<const float*>(&red[which][wv][0])[c];
+    unsafeAtomicAdd(params + e, t);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // out[i, :] = x[idx[i], :] (zeros when idx[i] == n)   and   out[i, :] = max_j xpad[idx[i, j], :]
 // ---------------------------------------------------------------------------------------------------------------------
@@ -707,6 +799,30 @@ extern "C" int se3_add_layer_norm_fwd(const float* hidden, const float* hidden_b
   else
     add_ln_kernel<8><<<grid, 256, 0, st>>>(hidden, hidden_bias, residual, weight, bias, rows, residual_rows, channels, eps, out);
   SE3_CHECK_LAUNCH("add_layer_norm");
+  return SE3_OK;
+}
+
+// Backward of se3_add_layer_norm_fwd: grad_hidden (rows, channels) (= the gradient of the un-broadcast residual), grad_params (3, channels) =
+// (d weight, d bias, d hidden_bias), zero-initialised by the caller (float atomics).
+extern "C" int se3_add_layer_norm_bwd(const float* hidden, const float* hidden_bias, const float* residual, const float* weight,
+                                      const float* grad_out, int64_t rows, int64_t residual_rows, int channels, float eps,
+                                      float* grad_hidden, float* grad_params, void* stream) {
+  SE3_REQUIRE(hidden && residual && weight && grad_out && grad_hidden && grad_params, SE3_ERR_INVALID_ARG, "add_layer_norm_bwd: null pointer");
+  SE3_REQUIRE(channels >= 4 && channels % 4 == 0 && channels <= 2048 && residual_rows >= 1 && rows % residual_rows == 0, SE3_ERR_UNSUPPORTED,
+              "add_layer_norm_bwd: channels %d (multiple of 4, <= 2048), rows %lld / residual rows %lld", channels, (long long)rows,
+              (long long)residual_rows);
+  if (rows == 0) return SE3_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)se3_cdiv(rows, 32);
+  if (channels <= 256)
+    add_ln_bwd_kernel<1><<<grid, 256, 0, st>>>(hidden, hidden_bias, residual, weight, grad_out, rows, residual_rows, channels, eps, grad_hidden, grad_params);
+  else if (channels <= 512)
+    add_ln_bwd_kernel<2><<<grid, 256, 0, st>>>(hidden, hidden_bias, residual, weight, grad_out, rows, residual_rows, channels, eps, grad_hidden, grad_params);
+  else if (channels <= 1024)
+    add_ln_bwd_kernel<4><<<grid, 256, 0, st>>>(hidden, hidden_bias, residual, weight, grad_out, rows, residual_rows, channels, eps, grad_hidden, grad_params);
+  else
+    add_ln_bwd_kernel<8><<<grid, 256, 0, st>>>(hidden, hidden_bias, residual, weight, grad_out, rows, residual_rows, channels, eps, grad_hidden, grad_params);
+  SE3_CHECK_LAUNCH("add_layer_norm_bwd");
   return SE3_OK;
 }
 

@@ -71,7 +71,14 @@ def project_values_transposed(x, w_v, b_v):
 def add_layer_norm(hidden, residual, weight, bias, eps=1e-5, hidden_bias=None):
     """LayerNorm(hidden [+ hidden_bias] + residual) over the last dim (residual may broadcast over a leading anchor dim)."""
     if AG.needs_grad(hidden, residual, weight, bias, hidden_bias):
-        return AG.differentiable(lambda h, r, w, b, hb: _ops.add_layer_norm(h, r.contiguous() if r.shape == h.shape else r.reshape(r.shape[-2:]), w, b, eps, hb),
+        fix = lambda h, r: r.contiguous() if r.shape == h.shape else r.reshape(r.shape[-2:])
+        if hidden.shape[-1] % 4 == 0:        # hand-written backward (csrc/rowops.hip: add_ln_bwd_kernel); AG.add_layer_norm is its torch pin
+            def bwd(g, needs, h, r, w, b, hb):
+                dh, dr, dw, db, dhb = _ops.add_layer_norm_bwd(g, h, fix(h, r), w, eps, hb)
+                return dh, dr.reshape(r.shape), dw, db, dhb
+            return AG.hip_backward(lambda h, r, w, b, hb: _ops.add_layer_norm(h, fix(h, r), w, b, eps, hb), bwd, 'add_layer_norm',
+                                   hidden, residual, weight, bias, hidden_bias)
+        return AG.differentiable(lambda h, r, w, b, hb: _ops.add_layer_norm(h, fix(h, r), w, b, eps, hb),
                                  lambda h, r, w, b, hb: AG.add_layer_norm(h, r, w, b, hb, eps), 1, hidden, residual, weight, bias, hidden_bias)
     return _ops.add_layer_norm(hidden, residual, weight, bias, eps, hidden_bias)
 

@@ -255,6 +255,22 @@ def add_layer_norm(hidden, residual, weight, bias, eps, hidden_bias=None):
     return out
 
 
+def add_layer_norm_bwd(grad_out, hidden, residual, weight, eps, hidden_bias=None):
+    """HIP (csrc/rowops.hip): gradients of add_layer_norm -> (d hidden, d residual, d weight, d bias, d hidden_bias or None)."""
+    hidden = _req(hidden.contiguous(), torch.float32, 'hidden')
+    g = _req(grad_out.contiguous(), torch.float32, 'grad_out')
+    C = hidden.shape[-1]
+    res = _req(residual.contiguous(), torch.float32, 'residual')
+    rows, res_rows = hidden.numel() // C, res.numel() // C
+    dh = torch.empty_like(hidden)
+    params = torch.zeros((3, C), dtype=torch.float32, device=hidden.device)
+    check(lib().se3_add_layer_norm_bwd(hidden.data_ptr(), hidden_bias.data_ptr() if hidden_bias is not None else None, res.data_ptr(),
+                                       weight.data_ptr(), g.data_ptr(), rows, res_rows, C, float(eps), dh.data_ptr(), params.data_ptr(),
+                                       _stream()), 'se3_add_layer_norm_bwd')
+    dres = dh if res_rows == rows else dh.reshape(rows // res_rows, res_rows, C).sum(0)
+    return dh, dres.reshape(residual.shape), params[0], params[1], (params[2] if hidden_bias is not None else None)
+
+
 def gather_rows_padded(x, idx):
     """HIP: x[idx] with idx == x.shape[0] addressing an all-zero row; idx of any shape."""
     x = _req(x.contiguous(), torch.float32, 'x')

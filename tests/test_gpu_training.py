@@ -286,3 +286,24 @@ def test_embedding_backward_kernel_matches_the_restatement_gradients(N, C, eq):
     assert_close(grads[0][3], grads[1][3], 1e-5, 'embedding d/dproj_a.bias')
     fro = float((grads[0][2] - grads[1][2]).norm() / grads[1][2].norm())
     assert fro <= 2e-4, 'embedding d/dproj_a.weight: relative Frobenius error %.2e' % fro
+
+
+@pytest.mark.parametrize('shape,res_shape,C,with_hb', [((6, 77), (77,), 32, True), ((300,), (300,), 256, False), ((6, 41), (6, 41), 512, True)])
+def test_layer_norm_backward_kernel_matches_the_restatement_gradients(shape, res_shape, C, with_hb):
+    """csrc/rowops.hip add_ln_bwd_kernel: the five gradients of LayerNorm(hidden [+ bias] + residual), the residual broadcast over the
+    anchor axis included, against autograd through the PyTorch restatement."""
+    from se3et_amd import autograd as AG
+    from se3et_amd import functional as SF
+    g = torch.Generator().manual_seed(C + len(shape))
+    rn = lambda *s: torch.randn(*s, generator=g).cuda()
+    base = [rn(*shape, C), rn(*res_shape, C), rn(C), rn(C), rn(C) if with_hb else None]
+    c = rn(*shape, C)
+    grads = []
+    for hip in (True, False):
+        t = [b.clone().requires_grad_(True) if b is not None else None for b in base]
+        y = SF.add_layer_norm(t[0], t[1], t[2], t[3], 1e-5, t[4]) if hip else AG.add_layer_norm(t[0], t[1], t[2], t[3], t[4], 1e-5)
+        (y * c).sum().backward()
+        grads.append([b.grad if b is not None else None for b in t])
+    for name, a, b in zip(('hidden', 'residual', 'weight', 'bias', 'hidden_bias'), grads[0], grads[1]):
+        if b is not None:
+            assert_close(a, b, 2e-5, 'layer norm d/d' + name)

@@ -64,7 +64,7 @@ def main():
         print(json.dumps({'metric': 'training step (fwd + bwd + Adam), %s on %s pairs' % (args.variant, args.pair), 's_per_step': round(dt / args.steps, 4),
                           'pairs_per_s': round(world * args.steps / dt, 3), 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                           'loss': float(losses['loss'].detach()), 'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
-                          'backward': 'HIP kernels for KPConv / GroupNorm / Sinkhorn / embedding / max-pool / row gather, PyTorch restatements on the GPU for the other ops (se3et_amd/autograd.py)', 'data': 'synthetic'}), flush=True)
+                          'backward': 'HIP kernels for KPConv / GroupNorm / LayerNorm / Sinkhorn / embedding / max-pool / row gather, PyTorch restatements on the GPU for the other ops (se3et_amd/autograd.py)', 'data': 'synthetic'}), flush=True)
     if args.profile and rank == 0:
         from se3et_amd import autograd as AG
         AG.BACKWARD_TIMINGS = {}
