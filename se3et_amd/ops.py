@@ -406,9 +406,13 @@ KPCONV_MATRIX_CORE = os.environ.get('SE3_KPCONV_PATH', 'auto')
 KPCONV_MATRIX_CORE = {'mfma': True, 'gemm': False}.get(KPCONV_MATRIX_CORE, 'auto')
 
 
-def _kpconv_use_matrix_core(Cin, Cout):
+def _kpconv_use_matrix_core(Cin, Cout, P):
     if KPCONV_MATRIX_CORE == 'auto':
-        return Cout <= 64 or Cout % 64 == 0          # the shapes the contraction kernel takes
+        if Cout <= 64:
+            return True
+        # wider layers run one workgroup per (16-point tile, block of 64 columns), each walking all K-steps on its own: with few tiles
+        # (one pair per forward: 176-336 workgroups) the library GEMM's split over K fills the chip better (+0.4 ms per single pair)
+        return Cout % 64 == 0 and ((P + 15) // 16) * (Cout // 64) >= 512
     return bool(KPCONV_MATRIX_CORE)
 
 
@@ -484,7 +488,7 @@ def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, s
         raise RuntimeError('kpconv_inter_so3: inconsistent shapes')
     kp, kt, rt = _host_table(kernel_points, torch.float32), _host_table(kidx, torch.int64), _host_table(ridx, torch.int64)
     nt = Cout // 16
-    if _kpconv_use_matrix_core(Cin, Cout) and Cin % 8 == 0 and Cout % 16 == 0 and (nt <= 4 or nt % 4 == 0) and _builtin_slot_tables(kt, rt):
+    if _kpconv_use_matrix_core(Cin, Cout, P) and Cin % 8 == 0 and Cout % 16 == 0 and (nt <= 4 or nt % 4 == 0) and _builtin_slot_tables(kt, rt):
         # matrix-core path: F (P16, 90, Cin) in tile order -> slot sums on the fly -> bf16x6 MFMA at f32 accuracy (csrc/kpconv_contract.hip)
         stream = _stream()
         Fk = torch.empty((lib().se3_kpconv_points_floats(P, Cin),), dtype=torch.float32, device=x.device)
