@@ -175,7 +175,8 @@ int se3_kpconv_so3_gather_bwd(const float* q_pts, const float* s_pts, const int6
                               const float* kernel_points_host, const int64_t* kidx_host, const int64_t* ridx_host, float sigma,
                               int64_t num_queries, int64_t num_support, int num_neighbors, int in_channels, float* dx, void* stream);
 
-/* Matrix-core form of the same convolution (csrc/kpconv_contract.hip), channels multiples of (8, 16): the gather leaves the
+/* Matrix-core form of the same convolution (csrc/kpconv_contract.hip), input channels a multiple of 8, output channels 16, 32, 48 or a
+ * multiple of 64: the gather leaves the
  * kernel-point sums F[p, k, a, c] = sum_n w[p, n, k] x[idx[p, n], a, c] in tile order [Cin / 8][ceil16(P)][732] (se3_kpconv_points_floats
  * floats; a row = 15 * 6 * 8 values + 8 zeros + 4 pad; 2.4x smaller
  * than the slot sums of se3_kpconv_so3_gather; kernel-point / anchor slot tables = the SE3ET configuration, compiled in);
