@@ -1,0 +1,17 @@
+#!/bin/bash
+# SQ counters of one kernel (counters only): tools/pmc_kernel.sh <kernel substring> <script.py> [args...]  ->  average per dispatch
+R=${GRAFT_REPO_ROOT:-$(pwd)}; pat=$1; shift; script=$1; shift
+cd /tmp && export TMPDIR=/tmp
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC"; do
+  rm -rf /tmp/pmck
+  ( cd $R && timeout 300 rocprofv3 --pmc $set --output-format csv -d /tmp/pmck -o p -- python3 $script "$@" > $R/gpurun_out/pmck.log 2>&1 )
+  f=$(find /tmp/pmck -name "*counter_collection.csv" | head -1)
+  python3 - "$f" "$pat" <<'PY'
+import collections, csv, sys
+agg = collections.OrderedDict()
+for r in csv.DictReader(open(sys.argv[1])):
+    if sys.argv[2] in r['Kernel_Name']:
+        v = agg.setdefault(r['Counter_Name'], [0, 0.0]); v[0] += 1; v[1] += float(r['Counter_Value'])
+for c, (n, t) in agg.items(): print('%-28s %16.0f  (%d dispatches)' % (c, t / n, n))
+PY
+done
