@@ -166,34 +166,52 @@ __global__ __launch_bounds__(384 / RW) __attribute__((amdgpu_waves_per_eu(RW == 
   const int prow = lane & 15, kb = lane >> 4;
   const float* frow = ftile + prow * kRowPad;
   constexpr int kFr = 3 * NT;                         // weight fragments of a K-step (a fragment = 64 lanes x 16 B, lane-linear)
-  uint4 bn[kFr];                                      // next K-step's fragments, in flight while this step is built and multiplied
+  // NT <= 4: the next K-step's fragments are in flight while this step is built and multiplied (double buffered in registers); NT = 8
+  // (96 registers of fragments, 64 of accumulators): this step's fragments are requested at the top of the step, behind the build
+  constexpr bool kSingle = NT > 4;
+  uint4 bn[kSingle ? 1 : kFr];
   // blockIdx.y: the workgroup's block of NT column tiles (layers wider than 64 columns run one workgroup per (point tile, column block):
   // every block rebuilds the fragments -- a fifth of the time -- and nothing is shared through LDS)
   const int nt0 = blockIdx.y * NT;
   const int64_t step_frags = (int64_t)(Cout / 16) * 3;                  // fragments of a K-step over the whole layer
   Wf += (int64_t)nt0 * 3 * 64;
+  if (!kSingle) {
 #pragma unroll
-  for (int f = 0; f < kFr; f++) bn[f] = Wf[f * 64 + lane];
+    for (int f = 0; f < kFr; f++) bn[kSingle ? 0 : f] = Wf[f * 64 + lane];
+  }
   int64_t g = 0;
   // The F tile of chunk cc + 1 (46.8 KB) is requested into registers at the top of chunk cc and stored to LDS at the chunk boundary: the
   // plain copy loop (load, store, load, ...) paid one HBM round trip per float4 and thread -- two thirds of the kernel time.
   constexpr int kThreads = 384 / RW, kPF = (kTileFloats / 4 + kThreads - 1) / kThreads;
-  f32x4 pf[kPF];                                      // (ext_vector_type: an array of HIP float4 structs ends up in scratch)
-  {
+  f32x4 pf[kSingle ? 1 : kPF];                        // (ext_vector_type: an array of HIP float4 structs ends up in scratch)
+  if (!kSingle) {
     const f32x4* src = reinterpret_cast<const f32x4*>(F + p0 * kRowPad);
 #pragma unroll
-    for (int i = 0; i < kPF; i++) pf[i] = src[min(tid + i * kThreads, kTileFloats / 4 - 1)];
+    for (int i = 0; i < kPF; i++) pf[kSingle ? 0 : i] = src[min(tid + i * kThreads, kTileFloats / 4 - 1)];
   }
   for (int cc = 0; cc < chunks; cc++) {
     __syncthreads();                                                    // the previous chunk's F tile is no longer read
+    if (!kSingle) {
 #pragma unroll
-    for (int i = 0; i < kPF; i++)
-      if (tid + i * kThreads < kTileFloats / 4) reinterpret_cast<f32x4*>(ftile)[tid + i * kThreads] = pf[i];
-    if (!(DBG & 8) || cc == 0) {
-      const int cn = cc + 1 < chunks ? cc + 1 : cc;                      // unconditional (clamped) so that the compiler can count the requests
-      const f32x4* src = reinterpret_cast<const f32x4*>(F + ((int64_t)cn * P16 + p0) * kRowPad);
+      for (int i = 0; i < kPF; i++)
+        if (tid + i * kThreads < kTileFloats / 4) reinterpret_cast<f32x4*>(ftile)[tid + i * kThreads] = pf[kSingle ? 0 : i];
+      if (!(DBG & 8) || cc == 0) {
+        const int cn = cc + 1 < chunks ? cc + 1 : cc;                    // unconditional (clamped) so that the compiler can count the requests
+        const f32x4* src = reinterpret_cast<const f32x4*>(F + ((int64_t)cn * P16 + p0) * kRowPad);
 #pragma unroll
-      for (int i = 0; i < kPF; i++) pf[i] = src[min(tid + i * kThreads, kTileFloats / 4 - 1)];
+        for (int i = 0; i < kPF; i++) pf[kSingle ? 0 : i] = src[min(tid + i * kThreads, kTileFloats / 4 - 1)];
+      }
+    } else {                                                            // no registers to spare for the tile: plain batched copy
+      const f32x4* src = reinterpret_cast<const f32x4*>(F + ((int64_t)cc * P16 + p0) * kRowPad);
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        f32x4 t[kPF / 2];
+#pragma unroll
+        for (int i = 0; i < kPF / 2; i++) t[i] = src[min(tid + (h * (kPF / 2) + i) * kThreads, kTileFloats / 4 - 1)];
+#pragma unroll
+        for (int i = 0; i < kPF / 2; i++)
+          if (tid + (h * (kPF / 2) + i) * kThreads < kTileFloats / 4) reinterpret_cast<f32x4*>(ftile)[tid + (h * (kPF / 2) + i) * kThreads] = t[i];
+      }
     }
     __syncthreads();
 #define SE3_PRODUCT(a_, pc_)                                                                                        \
@@ -206,20 +224,29 @@ __global__ __launch_bounds__(384 / RW) __attribute__((amdgpu_waves_per_eu(RW == 
     }
 #pragma unroll 1
     for (int ks = 0; ks < kKS; ks++, g++) {
+      bf16x8 b[NT][3];
+      if (kSingle) {
+        const uint4* src = Wf + g * step_frags * 64 + lane;
+#pragma unroll
+        for (int n = 0; n < NT; n++)
+#pragma unroll
+          for (int pc = 0; pc < 3; pc++) b[n][pc] = __builtin_bit_cast(bf16x8, src[(n * 3 + pc) * 64]);
+      }
       if (!(DBG & 2)) {
 #pragma unroll
         for (int q = 0; q < RW; q++) build_fragment(frow, tab[(ks * kA + r0 + q) * 4 + kb], ks >= 4, a1[q], a2[q], a3[q]);
       }
-      bf16x8 b[NT][3];
+      if (!kSingle) {
 #pragma unroll
-      for (int n = 0; n < NT; n++)
+        for (int n = 0; n < NT; n++)
 #pragma unroll
-        for (int pc = 0; pc < 3; pc++) b[n][pc] = __builtin_bit_cast(bf16x8, bn[n * 3 + pc]);
-      if (!(DBG & 1)) {                                                 // request step g + 1 (clamped: unconditional, so the compiler counts it)
-        const int64_t gq = g + 1 < steps ? g + 1 : steps - 1;
-        const uint4* src = Wf + gq * step_frags * 64 + lane;
+          for (int pc = 0; pc < 3; pc++) b[n][pc] = __builtin_bit_cast(bf16x8, bn[kSingle ? 0 : n * 3 + pc]);
+        if (!(DBG & 1)) {                                               // request step g + 1 (clamped: unconditional, so the compiler counts it)
+          const int64_t gq = g + 1 < steps ? g + 1 : steps - 1;
+          const uint4* src = Wf + gq * step_frags * 64 + lane;
 #pragma unroll
-        for (int f = 0; f < kFr; f++) bn[f] = src[f * 64];
+          for (int f = 0; f < kFr; f++) bn[kSingle ? 0 : f] = src[f * 64];
+        }
       }
       // product-major over the tiles: consecutive MFMAs go to different accumulators; smallest terms first
       if (!(DBG & 4)) {
@@ -309,8 +336,16 @@ extern "C" int se3_kpconv_so3_contract(const float* F, const void* weight_fragme
   } else {
     // wider layers: the same kernel, one workgroup per (point tile, block of 64 columns)
     SE3_REQUIRE(NT % 4 == 0, SE3_ERR_UNSUPPORTED, "kpconv_so3_contract: %d output channels (need <= 64 or a multiple of 64)", out_channels);
-    const dim3 grid((unsigned)tiles, (unsigned)(NT / 4));
-    kpconv_contract_rows_kernel<4, 2><<<grid, 192, lds_small, st>>>(F, Wf, num_queries, P16, in_channels, out_channels, out);
+    // 128 columns per workgroup where the layer allows it: a built fragment then feeds 48 MFMAs instead of 24 -- 1.3 instead of 2.6 other
+    // vector instructions per MFMA, which is what fits into the MFMAs' shadow (1.68 -> 1.52 and 1.50 -> 1.31 ms on the 128 / 256-column layers)
+    static const char* w8 = getenv("SE3_KPCONV_NT8");
+    if (NT % 8 == 0 && (w8 ? atoi(w8) != 0 : true)) {
+      const dim3 grid8((unsigned)tiles, (unsigned)(NT / 8));
+      kpconv_contract_rows_kernel<8, 2><<<grid8, 192, lds_small, st>>>(F, Wf, num_queries, P16, in_channels, out_channels, out);
+    } else {
+      const dim3 grid((unsigned)tiles, (unsigned)(NT / 4));
+      kpconv_contract_rows_kernel<4, 2><<<grid, 192, lds_small, st>>>(F, Wf, num_queries, P16, in_channels, out_channels, out);
+    }
   }
   SE3_CHECK_LAUNCH("kpconv_so3_contract");
   return SE3_OK;
