@@ -283,6 +283,17 @@ int se3_cross_eq_stack_fwd(const float* q, const float* k, const float* vt, cons
                            int64_t q_anchor_stride, int64_t k_anchor_stride, int v_row_stride, int64_t v_anchor_stride, int mode,
                            const int64_t* trace_idx, int num_rotations, int sums_given, float* partial_workspace, float* mix,
                            float* weights, float* out, void* stream);
+/* The same on the bf16 matrix cores at f32 accuracy (head dimension 64, A <= 6, key starts and v_row_stride multiples of 16, sums_given
+ * != 0; anything else is forwarded to se3_cross_eq_stack_fwd): q, k and vt are split into three bf16 pieces each in `workspace`
+ * (se3_cross_eq_x6_workspace_bytes bytes, 16-byte aligned; q (A, q_rows, C), k (A, k_rows, C) packed rows) and the six piece products
+ * above 2^-24 are accumulated in f32 -- 2.7x fewer matrix-pipe cycles than the f32 MFMAs. */
+size_t se3_cross_eq_x6_workspace_bytes(int A, int64_t q_rows, int64_t k_rows, int C, int v_row_stride);
+int se3_cross_eq_stack_x6_fwd(const float* q, const float* k, const float* vt, const int64_t* q_starts, const int64_t* q_lengths,
+                              const int64_t* k_starts, const int64_t* k_lengths, int num_pairs, int A, int C, int H, int64_t q_rows,
+                              int64_t k_rows, int64_t q_anchor_stride, int64_t k_anchor_stride, int v_row_stride,
+                              int64_t v_anchor_stride, int mode, const int64_t* trace_idx, int num_rotations, int sums_given,
+                              float* partial_workspace, float* mix, float* weights, float* out, void* workspace,
+                              size_t workspace_bytes, void* stream);
 
 
 /* ---- G1/G2: geometric structure embedding --------------------------------------------------------------------------

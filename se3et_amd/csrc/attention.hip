@@ -888,6 +888,317 @@ __global__ __launch_bounds__(64 * NW) void cross_eq_apply_stack_kernel(CrossEqAr
   }
 }
 
+// ---- bf16x6 form of the equivariant cross attention (stack mode, head dimension 64) ---------------------------------------------------
+// cross_eq_apply_stack_kernel runs at the f32 MFMA rate (75 GF per call in 0.5 ms).  Here q, k and the transposed values are split once
+// per call into three bf16 pieces each (x = x1 + x2 + x3 exactly: 3 x 8 significant bits) and both products of the flash loop run on
+// v_mfma_f32_32x32x16_bf16 with the six piece products above 2^-24 relative (x1 y1, x1 y2, x2 y1, x1 y3, x2 y2, x3 y1) accumulated in f32
+// -- the scheme of csrc/kpconv_contract.hip: 6 x 32 cycles per 16 k instead of 8 x 64.  The softmax weights P are split on the fly from
+// the S^T accumulator registers; their register order fixes the order of the keys inside an MFMA K-step (lane half h holds keys
+// {0..3, 8..11} + 4 h of every 16), so the transposed values are stored with that permutation and a lane's V fragment is one 16-byte load.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned x6_pack(float lo, float hi) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  bf16x2_t v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void x6_split8(const float (&x)[8], uint4& p1, uint4& p2, uint4& p3) {
+  unsigned a[4], b[4], c[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float x0 = x[2 * i], x1 = x[2 * i + 1];
+    a[i] = x6_pack(x0, x1);
+    const float r0 = x0 - __uint_as_float(a[i] << 16), r1 = x1 - __uint_as_float(a[i] & 0xffff0000u);
+    b[i] = x6_pack(r0, r1);
+    const float s0 = r0 - __uint_as_float(b[i] << 16), s1 = r1 - __uint_as_float(b[i] & 0xffff0000u);
+    c[i] = x6_pack(s0, s1);
+  }
+  p1 = make_uint4(a[0], a[1], a[2], a[3]);
+  p2 = make_uint4(b[0], b[1], b[2], b[3]);
+  p3 = make_uint4(c[0], c[1], c[2], c[3]);
+}
+
+// rows (A, R, C) with anchor stride -> pieces [3][A][R][C] bf16; one thread per 8 channels
+__global__ __launch_bounds__(256) void x6_split_rows_kernel(const float* __restrict__ x, int A, int64_t R, int C, int64_t anchor_stride,
+                                                            uint4* __restrict__ out) {
+  const int64_t per = R * (C / 8), total = A * per;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t a = i / per, rem = i - a * per;
+    const float* src = x + a * anchor_stride + rem * 8;
+    const float4 lo = ld4(src), hi = ld4(src + 4);
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    uint4 p1, p2, p3;
+    x6_split8(v, p1, p2, p3);
+    out[i] = p1;
+    out[total + i] = p2;
+    out[2 * total + i] = p3;
+  }
+}
+// transposed values (A, C, v_rs) with anchor stride -> pieces [3][A][C][v_rs] bf16, the keys of every aligned block of 16 in the order
+// 0..3, 8..11, 4..7, 12..15; one thread per 16 keys
+__global__ __launch_bounds__(256) void x6_split_vt_kernel(const float* __restrict__ vt, int A, int C, int v_rs, int64_t anchor_stride,
+                                                          uint4* __restrict__ out) {
+  const int64_t blocks = v_rs / 16, per = (int64_t)C * blocks, total = A * per;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t a = i / per, rem = i - a * per;
+    const float* src = vt + a * anchor_stride + rem * 16;
+    const float4 q0 = ld4(src), q1 = ld4(src + 4), q2 = ld4(src + 8), q3 = ld4(src + 12);
+    const float lo[8] = {q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, q2.z, q2.w};      // keys 0..3, 8..11
+    const float hi[8] = {q1.x, q1.y, q1.z, q1.w, q3.x, q3.y, q3.z, q3.w};      // keys 4..7, 12..15
+    uint4 a1, a2, a3, b1, b2, b3;
+    x6_split8(lo, a1, a2, a3);
+    x6_split8(hi, b1, b2, b3);
+    out[2 * i] = a1; out[2 * i + 1] = b1;
+    out[2 * (total + i)] = a2; out[2 * (total + i) + 1] = b2;
+    out[2 * (2 * total + i)] = a3; out[2 * (2 * total + i) + 1] = b3;
+  }
+}
+
+struct X6Pieces { const uint4 *q[3], *k[3], *v[3]; };       // bf16 pieces, 8 values per uint4
+
+// One wave, one 32-query tile, the 32-key tiles tile_begin, + tile_step, ...: flash_tiles on the bf16 matrix cores at f32 accuracy (D = 64).
+// q / k: element offsets of the (anchor, head) slice into the piece arrays (rows of C bf16); v: element offset of the slice's first row
+// into the transposed-value pieces (rows of v_rs bf16, first key of the pair included).
+__device__ __forceinline__ void flash_tiles_x6(FlashState<64>& st, const X6Pieces& X, int64_t q_off, int64_t k_off, int64_t v_off, int n0,
+                                               int N, int M, int C, int v_rs, float scale, int tile_begin, int tile_step) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, c32 = lane & 31;
+  const int nq = min(n0 + c32, N - 1);
+  bf16x8_t qf[3][4];
+#pragma unroll
+  for (int pc = 0; pc < 3; pc++)
+#pragma unroll
+    for (int u = 0; u < 4; u++) qf[pc][u] = __builtin_bit_cast(bf16x8_t, X.q[pc][(q_off + (int64_t)nq * C + 16 * u + 8 * half) >> 3]);
+  const int tiles = (M + 31) >> 5;
+  for (int tile = tile_begin; tile < tiles; tile += tile_step) {
+    const int m0 = tile << 5;
+    const int64_t krow = k_off + (int64_t)min(m0 + c32, M - 1) * C + 8 * half;
+    bf16x8_t kf[3][4];
+#pragma unroll
+    for (int pc = 0; pc < 3; pc++)
+#pragma unroll
+      for (int u = 0; u < 4; u++) kf[pc][u] = __builtin_bit_cast(bf16x8_t, X.k[pc][(krow + 16 * u) >> 3]);
+    // V^T fragments: row d = 32 dt + c32, K-step j = keys m0 + 16 j .. +15 in the stored (permuted) order, this lane's half of them
+    bf16x8_t vf[3][2][2];
+#pragma unroll
+    for (int pc = 0; pc < 3; pc++)
+#pragma unroll
+      for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+          vf[pc][dt][j] = __builtin_bit_cast(bf16x8_t, X.v[pc][(v_off + (int64_t)(32 * dt + c32) * v_rs + m0 + 16 * j + 8 * half) >> 3]);
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; r++) s[r] = 0.f;
+#define SE3_X6_QK(a_, b_)                                                                                    \
+  _Pragma("unroll") for (int u = 0; u < 4; u++) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[a_][u], qf[b_][u], s, 0, 0, 0);
+    SE3_X6_QK(2, 0) SE3_X6_QK(0, 2) SE3_X6_QK(1, 1) SE3_X6_QK(1, 0) SE3_X6_QK(0, 1) SE3_X6_QK(0, 0)
+#undef SE3_X6_QK
+    // s[r] = S^T[key = (r&3) + 8 (r>>2) + 4 half][query = c32]
+    float mx = -INFINITY;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int key = m0 + 8 * g + 4 * half + j;
+        float val = s[4 * g + j] * scale;
+        val = key < M ? val : -INFINITY;
+        s[4 * g + j] = val;
+        mx = fmaxf(mx, val);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(st.m, mx);
+    const float alpha = __expf(st.m - m_new);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      s[r] = __expf(s[r] - m_new);
+      ps += s[r];
+    }
+    ps += __shfl_xor(ps, 32);
+    st.l = st.l * alpha + ps;
+    st.m = m_new;
+    // P^T as the B operand: K-step j holds s[8 j .. 8 j + 7] = keys {0..3, 8..11} + 4 half + 16 j of the tile
+    bf16x8_t pb[3][2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const float v8[8] = {s[8 * j], s[8 * j + 1], s[8 * j + 2], s[8 * j + 3], s[8 * j + 4], s[8 * j + 5], s[8 * j + 6], s[8 * j + 7]};
+      uint4 p1, p2, p3;
+      x6_split8(v8, p1, p2, p3);
+      pb[0][j] = __builtin_bit_cast(bf16x8_t, p1);
+      pb[1][j] = __builtin_bit_cast(bf16x8_t, p2);
+      pb[2][j] = __builtin_bit_cast(bf16x8_t, p3);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) st.o[dt][r] *= alpha;
+    }
+#define SE3_X6_PV(a_, b_)                                                                                    \
+  _Pragma("unroll") for (int dt = 0; dt < 2; dt++) _Pragma("unroll") for (int j = 0; j < 2; j++)              \
+      st.o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[a_][dt][j], pb[b_][j], st.o[dt], 0, 0, 0);
+    SE3_X6_PV(2, 0) SE3_X6_PV(0, 2) SE3_X6_PV(1, 1) SE3_X6_PV(1, 0) SE3_X6_PV(0, 1) SE3_X6_PV(0, 0)
+#undef SE3_X6_PV
+  }
+}
+
+// grid (ceil(QT / 4), H, A * pairs), 4 waves = 4 consecutive 32-query tiles of one (pair, query anchor a, head).  The workgroup walks
+// the (key anchor e, 32-key tile) sequence once; every K / V^T tile (3 pieces each: 24 KB) goes global -> registers -> LDS one step ahead
+// and is read by the four waves from LDS (rows padded to an odd number of 16-byte units: conflict-free ds_read_b128) -- with every wave
+// fetching its own fragments from L1 (the first form of this kernel: one wave per key anchor) the 512 B per MFMA saturated L1's return
+// path and the kernel ran at the f32 kernel's speed.  out[a, n, h] = sum_e mix[pair, a, e] softmax_m(q_a.k_e * scale) v_e.
+constexpr int kX6KRow = 9, kX6VRow = 5;        // uint4 per K row (64 d = 8 used) / V^T row (32 keys = 4 used)
+__global__ __launch_bounds__(256) void cross_eq_apply_stack_x6_kernel(CrossEqArgs p, X6Pieces X, int64_t q_piece_sa, int64_t k_piece_sa,
+                                                                      int64_t v_piece_sa, const float* __restrict__ mix,
+                                                                      float* __restrict__ out) {
+  constexpr int D = 64;
+  __shared__ uint4 ktile[2][3][32][kX6KRow];
+  __shared__ uint4 vtile[2][3][64][kX6VRow];
+  const int A = p.A, C = p.C;
+  const int pair = blockIdx.z / A, a = blockIdx.z - pair * A;
+  const StackCloud cl = stack_pick(p.S, pair);
+  const int h = blockIdx.y;
+  if (blockIdx.x * 128 >= cl.N) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, c32 = lane & 31;
+  const int n0 = blockIdx.x * 128 + wave * 32;
+  const bool active = n0 < cl.N;                            // (inactive waves still help with the tile copies)
+  const int nq = min(n0 + c32, cl.N - 1);
+  const int64_t q_off = a * q_piece_sa + (int64_t)cl.q_start * C + h * D;
+  bf16x8_t qf[3][4];
+#pragma unroll
+  for (int pc = 0; pc < 3; pc++)
+#pragma unroll
+    for (int u = 0; u < 4; u++) qf[pc][u] = __builtin_bit_cast(bf16x8_t, X.q[pc][(q_off + (int64_t)nq * C + 16 * u + 8 * half) >> 3]);
+  const int tiles = (cl.M + 31) >> 5, steps = A * tiles;
+  // this thread's share of a tile copy: K: 3 pieces x 32 rows x 8 uint4 = 768 -> 3 per thread; V^T: 3 pieces x 64 rows x 4 uint4 = 768 -> 3
+  uint4 rk[3], rv[3];
+  auto request = [&](int step) {
+    const int e = step / tiles, m0 = (step - e * tiles) << 5;
+    const int64_t k_off = e * k_piece_sa + (int64_t)cl.k_start * C + h * D;
+    const int64_t v_off = e * v_piece_sa + (int64_t)h * D * p.v_rs + cl.k_start + m0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int row = tid >> 3, q8 = tid & 7;               // piece i: 32 rows x 8 uint4
+      rk[i] = X.k[i][(k_off + (int64_t)min(m0 + row, cl.M - 1) * C + 8 * q8) >> 3];
+      const int vrow = tid >> 2, q4 = tid & 3;              // piece i: 64 rows x 4 uint4
+      rv[i] = X.v[i][(v_off + (int64_t)vrow * p.v_rs + 8 * q4) >> 3];
+    }
+  };
+  auto publish = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      ktile[buf][i][tid >> 3][tid & 7] = rk[i];
+      vtile[buf][i][tid >> 2][tid & 3] = rv[i];
+    }
+  };
+  request(0);
+  publish(0);
+  __syncthreads();
+  FlashState<D> tot, st;
+  flash_init(tot);
+  flash_init(st);
+  for (int step = 0; step < steps; step++) {
+    const int buf = step & 1;
+    const int e = step / tiles, tile = step - e * tiles, m0 = tile << 5;
+    if (step + 1 < steps) request(step + 1);                 // block-uniform
+    if (active) {
+      // two accumulators, consecutive MFMAs alternate between them (a single one would make all 24 a dependent chain)
+      f32x16 s, s2;
+#pragma unroll
+      for (int r = 0; r < 16; r++) s[r] = s2[r] = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        bf16x8_t kf[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; pc++) kf[pc] = __builtin_bit_cast(bf16x8_t, ktile[buf][pc][c32][2 * u + half]);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2], qf[0][u], s, 0, 0, 0);
+        s2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[2][u], s2, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[1][u], s, 0, 0, 0);
+        s2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[0][u], s2, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[1][u], s, 0, 0, 0);
+        s2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0][u], s2, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) s[r] += s2[r];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int key = m0 + 8 * g + 4 * half + j;
+          float val = s[4 * g + j] * p.scale;
+          val = key < cl.M ? val : -INFINITY;
+          s[4 * g + j] = val;
+          mx = fmaxf(mx, val);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(st.m, mx);
+      const float alpha = __expf(st.m - m_new);
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        s[r] = __expf(s[r] - m_new);
+        ps += s[r];
+      }
+      ps += __shfl_xor(ps, 32);
+      st.l = st.l * alpha + ps;
+      st.m = m_new;
+      bf16x8_t pb[3][2];
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const float v8[8] = {s[8 * j], s[8 * j + 1], s[8 * j + 2], s[8 * j + 3], s[8 * j + 4], s[8 * j + 5], s[8 * j + 6], s[8 * j + 7]};
+        uint4 p1, p2, p3;
+        x6_split8(v8, p1, p2, p3);
+        pb[0][j] = __builtin_bit_cast(bf16x8_t, p1);
+        pb[1][j] = __builtin_bit_cast(bf16x8_t, p2);
+        pb[2][j] = __builtin_bit_cast(bf16x8_t, p3);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) st.o[dt][r] *= alpha;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        bf16x8_t vf[2][3];
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+          for (int pc = 0; pc < 3; pc++) vf[dt][pc] = __builtin_bit_cast(bf16x8_t, vtile[buf][pc][32 * dt + c32][2 * j + half]);
+#define SE3_X6_PV(a_, b_)                                                                                                       \
+  st.o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][a_], pb[b_][j], st.o[0], 0, 0, 0);                                    \
+  st.o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][a_], pb[b_][j], st.o[1], 0, 0, 0);
+        SE3_X6_PV(2, 0) SE3_X6_PV(0, 2) SE3_X6_PV(1, 1) SE3_X6_PV(1, 0) SE3_X6_PV(0, 1) SE3_X6_PV(0, 0)
+#undef SE3_X6_PV
+      }
+      if (tile == tiles - 1) {                                // key anchor e is complete: fold it into the output with its weight
+        const float w = mix[((size_t)pair * A + a) * A + e] / st.l;
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) tot.o[dt][r] += st.o[dt][r] * w;
+        flash_init(st);
+      }
+    }
+    if (step + 1 < steps) publish(buf ^ 1);                   // its readers finished before the barrier that ended the previous step
+    __syncthreads();
+  }
+  if (!active) return;
+  // o[dt][r] = O^T[d = 32 dt + (r & 3) + 8 (r >> 2) + 4 half][query c32]: four consecutive d per (dt, g) -> one float4 per lane
+  const int nrow = n0 + c32;
+  if (nrow < cl.N) {
+    float* op = out + ((size_t)a * p.q_sa) + ((size_t)cl.q_start + nrow) * C + h * D;
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+        *reinterpret_cast<float4*>(op + 32 * dt + 8 * g + 4 * half) =
+            make_float4(tot.o[dt][4 * g], tot.o[dt][4 * g + 1], tot.o[dt][4 * g + 2], tot.o[dt][4 * g + 3]);
+  }
+}
+
 // one workgroup: g[a,e] = sum_i partial[(a*A+e)*P + i] / (N M) -> mixing weights.
 //   mode 0 (a_soft): mix[a,e] = g[a,e] / sum_e g[a,e];  weights = mix (A*A values)
 //   mode 1 (r_soft): w[r] = mean_a g[a, trace[r,a]] normalised over r; mix[a,e] = sum_{r: trace[r,a]=e} w[r]; weights = w (R values)
@@ -1345,6 +1656,71 @@ extern "C" int se3_cross_eq_stack_fwd(const float* q, const float* k, const floa
   }, "cross_eq_stack");
   if (rc != SE3_OK) return rc;
   SE3_CHECK_LAUNCH("cross_eq_stack");
+  return SE3_OK;
+}
+
+// bf16x6 form of se3_cross_eq_stack_fwd (head dimension 64, A <= 6, key starts and the value row stride multiples of 16): q (A, q_rows, C),
+// k (A, k_rows, C) and vt (A, C, v_row_stride) are split into bf16 pieces in `workspace` (se3_cross_eq_x6_workspace_bytes), then the flash
+// loop runs on the bf16 matrix cores at f32 accuracy.  Other shapes take the f32 kernels of se3_cross_eq_stack_fwd.
+extern "C" size_t se3_cross_eq_x6_workspace_bytes(int A, int64_t q_rows, int64_t k_rows, int C, int v_row_stride) {
+  return (size_t)6 * A * ((size_t)q_rows * C + (size_t)k_rows * C + (size_t)C * v_row_stride) + 256;
+}
+
+extern "C" int se3_cross_eq_stack_x6_fwd(const float* q, const float* k, const float* vt, const int64_t* q_starts,
+                                         const int64_t* q_lengths, const int64_t* k_starts, const int64_t* k_lengths, int num_pairs,
+                                         int A, int C, int H, int64_t q_rows, int64_t k_rows, int64_t q_anchor_stride,
+                                         int64_t k_anchor_stride, int v_row_stride, int64_t v_anchor_stride, int mode,
+                                         const int64_t* trace_idx, int num_rotations, int sums_given, float* partial_workspace,
+                                         float* mix, float* weights, float* out, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+  bool ok = workspace != nullptr && H >= 1 && C % H == 0 && C / H == 64 && A >= 1 && A <= 6 && v_row_stride % 16 == 0 && sums_given &&
+            num_pairs >= 1 && num_pairs <= kMaxClouds && k_starts != nullptr && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
+  for (int c = 0; ok && c < num_pairs; c++) ok = k_starts[c] % 16 == 0;
+  if (!ok)
+    return se3_cross_eq_stack_fwd(q, k, vt, q_starts, q_lengths, k_starts, k_lengths, num_pairs, A, C, H, q_anchor_stride, k_anchor_stride,
+                                  v_row_stride, v_anchor_stride, mode, trace_idx, num_rotations, sums_given, partial_workspace, mix,
+                                  weights, out, stream);
+  SE3_REQUIRE(q && k && vt && q_starts && q_lengths && k_lengths && partial_workspace && mix && weights && out, SE3_ERR_INVALID_ARG,
+              "cross_eq_stack_x6: null pointer");
+  SE3_REQUIRE(workspace_bytes >= se3_cross_eq_x6_workspace_bytes(A, q_rows, k_rows, C, v_row_stride), SE3_ERR_WORKSPACE,
+              "cross_eq_stack_x6: workspace too small");
+  SE3_REQUIRE(mode == 0 || (mode == 1 && trace_idx && num_rotations >= 1 && num_rotations <= 64), SE3_ERR_UNSUPPORTED,
+              "cross_eq_stack_x6: mode %d rotations %d", mode, num_rotations);
+  CrossEqArgs p{};
+  p.q = q; p.k = k; p.vt = vt;
+  p.S.n = num_pairs;
+  int qt = 1;
+  for (int c = 0; c < num_pairs; c++) {
+    const int N = (int)q_lengths[c], M = (int)k_lengths[c], Mp = ((M + 31) / 32) * 32;
+    SE3_REQUIRE(N >= 1 && M >= 1 && q_starts[c] >= 0 && k_starts[c] >= 0 && q_starts[c] + N <= q_rows && k_starts[c] + M <= k_rows &&
+                    k_starts[c] + Mp <= v_row_stride,
+                SE3_ERR_INVALID_ARG, "cross_eq_stack_x6: pair %d descriptor", c);
+    p.S.c[c] = StackCloud{nullptr, nullptr, (int)q_starts[c], (int)k_starts[c], N, M, Mp, 0, 0};
+    qt = (N + 31) / 32 > qt ? (N + 31) / 32 : qt;
+  }
+  p.A = A; p.C = C; p.H = H; p.QT = qt;
+  p.q_sa = q_anchor_stride; p.k_sa = k_anchor_stride; p.v_sa = v_anchor_stride; p.v_rs = v_row_stride;
+  p.scale = 1.0f / sqrtf((float)(C / H));
+  hipStream_t st = (hipStream_t)stream;
+  const size_t nq = (size_t)A * q_rows * C / 8, nk = (size_t)A * k_rows * C / 8, nv = (size_t)A * C * v_row_stride / 8;     // uint4 per piece
+  uint4* wq = static_cast<uint4*>(workspace);
+  uint4* wk = wq + 3 * nq;
+  uint4* wv = wk + 3 * nk;
+  x6_split_rows_kernel<<<(unsigned)((nq + 255) / 256 > 4096 ? 4096 : (nq + 255) / 256), 256, 0, st>>>(q, A, q_rows, C, q_anchor_stride, wq);
+  x6_split_rows_kernel<<<(unsigned)((nk + 255) / 256 > 4096 ? 4096 : (nk + 255) / 256), 256, 0, st>>>(k, A, k_rows, C, k_anchor_stride, wk);
+  x6_split_vt_kernel<<<(unsigned)((nv / 2 + 255) / 256 > 4096 ? 4096 : (nv / 2 + 255) / 256), 256, 0, st>>>(vt, A, C, v_row_stride,
+                                                                                                         v_anchor_stride, wv);
+  X6Pieces X;
+  for (int pc = 0; pc < 3; pc++) {
+    X.q[pc] = wq + pc * nq;
+    X.k[pc] = wk + pc * nk;
+    X.v[pc] = wv + pc * nv;
+  }
+  cross_eq_mix_kernel<<<(unsigned)num_pairs, 64, 0, st>>>(partial_workspace, 1, 0.f, A, num_rotations, trace_idx, mode, mix, weights, nullptr,
+                                                       p.S, 1);
+  cross_eq_apply_stack_x6_kernel<<<dim3((unsigned)((qt + 3) / 4), (unsigned)H, (unsigned)(A * num_pairs)), 256, 0, st>>>(
+      p, X, (int64_t)q_rows * C, (int64_t)k_rows * C, (int64_t)C * v_row_stride, mix, out);
+  SE3_CHECK_LAUNCH("cross_eq_stack_x6");
   return SE3_OK;
 }
 

@@ -783,6 +783,8 @@ def cross_attention_eq(q, k, vt, num_heads, mode, trace_idx):
     return out, ret, mix
 
 
+# equivariant cross attention of a batch on the bf16 matrix cores at f32 accuracy (SE3_CROSS_EQ=f32 forces the f32 MFMA kernels)
+CROSS_EQ_BF16X6 = os.environ.get('SE3_CROSS_EQ', 'bf16x6') != 'f32'
 _pair_rows_cache = {}
 
 
@@ -837,6 +839,22 @@ def cross_attention_eq_stack(q, k, vt, q_starts, q_lengths, k_starts, k_lengths,
     partial = torch.bmm(gq.view(A, P, C * C).transpose(0, 1), gk.view(A, P, C * C).permute(1, 2, 0)) * (f * f)      # (P, A, A)
     mix = torch.empty((P, A, A), dtype=torch.float32, device=dev)
     weights = torch.empty((P, A * A if mode == 'a_soft' else R), dtype=torch.float32, device=dev)
+    if CROSS_EQ_BF16X6 and q.stride(1) == C and k.stride(1) == C and q.stride(2) == 1 and k.stride(2) == 1 and vt.stride(2) == 1:
+        # bf16 matrix cores at f32 accuracy (csrc/attention.hip: cross_eq_apply_stack_x6_kernel); shapes it does not take are forwarded
+        # to the f32 kernels by the entry point itself
+        stream = _stream()
+        ws_bytes = lib().se3_cross_eq_x6_workspace_bytes(A, Rq, k.shape[1], C, vt.stride(1))
+        key = (dev, stream.value, 'x6')
+        ws = _gn_workspace.get(key)
+        if ws is None or ws.numel() < ws_bytes:
+            ws = torch.empty((max(ws_bytes, 1 << 24),), dtype=torch.uint8, device=dev)
+            _gn_workspace[key] = ws
+        check(lib().se3_cross_eq_stack_x6_fwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(), _i64_array(q_starts), _i64_array(q_lengths),
+                                              _i64_array(k_starts), _i64_array(k_lengths), P, A, C, int(num_heads), Rq, k.shape[1],
+                                              q.stride(0), k.stride(0), vt.stride(1), vt.stride(0), 0 if mode == 'a_soft' else 1,
+                                              trace_idx.data_ptr(), R, 1, partial.data_ptr(), mix.data_ptr(), weights.data_ptr(),
+                                              out.data_ptr(), ws.data_ptr(), ws.numel(), stream), 'se3_cross_eq_stack_x6_fwd')
+        return mix, weights
     check(lib().se3_cross_eq_stack_fwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(), _i64_array(q_starts), _i64_array(q_lengths),
                                        _i64_array(k_starts), _i64_array(k_lengths), P, A, C, int(num_heads), q.stride(0), k.stride(0),
                                        vt.stride(1), vt.stride(0), 0 if mode == 'a_soft' else 1, trace_idx.data_ptr(), R, 1,

@@ -726,3 +726,40 @@ def test_knn3_matches_oracle(N):
     check(lib().se3_knn3(p.data_ptr(), N, knn.data_ptr(), None), 'se3_knn3')
     torch.cuda.synchronize()
     assert torch.equal(knn.cpu(), want)
+
+
+@pytest.mark.parametrize('lengths,mode', [(((70, 61), (45, 90)), 'a_soft'), (((382, 304),), 'r_soft'), (((33, 40), (64, 64), (17, 100)), 'a_soft')])
+def test_cross_attention_eq_stack_bf16x6_matches_the_single_pair_kernels(lengths, mode):
+    """se3_cross_eq_stack_x6_fwd (bf16 matrix cores, six piece products) against the f32 single-pair kernels (se3_cross_eq_stats / _apply)
+    pair by pair at 2e-5, and against its own f32 stack form (SE3_CROSS_EQ=f32)."""
+    from se3et_amd import functional as SF
+    from se3et_amd import ops, tables
+    g = torch.Generator().manual_seed(len(lengths) * 7 + lengths[0][0])
+    A, C, H = 6, 256, 4
+    trace = torch.from_numpy(tables.trace_indices()[0]).cuda()
+    pad = lambda n: (n + 31) // 32 * 32
+    qs, ks, q_starts, k_starts = [], [], [], []
+    rq = rk = 0
+    for n, m in lengths:
+        q_starts.append(rq); k_starts.append(rk)
+        qs.append(torch.randn(A, n, C, generator=g)); ks.append((torch.randn(A, m, C, generator=g), torch.randn(A, m, C, generator=g)))
+        rq += pad(n); rk += pad(m)
+    q = torch.zeros(A, rq, C); k = torch.zeros(A, rk, C); v = torch.zeros(A, rk, C)
+    for (n, m), s0, t0, qq, (kk, vv) in zip(lengths, q_starts, k_starts, qs, ks):
+        q[:, s0:s0 + n] = qq; k[:, t0:t0 + m] = kk; v[:, t0:t0 + m] = vv
+    q, k, v = q.cuda(), k.cuda(), v.cuda()
+    vt = v.transpose(1, 2).contiguous()                                  # (A, C, rk): key-padded transposed values
+    outs = {}
+    for name, flag in (('bf16x6', True), ('f32', False)):
+        ops.CROSS_EQ_BF16X6 = flag
+        out = torch.zeros(A, rq, C, device='cuda')
+        mix, w = ops.cross_attention_eq_stack(q, k, vt, q_starts, [n for n, _ in lengths], k_starts, [m for _, m in lengths], H, mode, trace, out)
+        outs[name] = (out, mix, w)
+    ops.CROSS_EQ_BF16X6 = True
+    assert_close(outs['bf16x6'][0], outs['f32'][0], 2e-5, 'stack: bf16x6 against f32')
+    eye, zero = torch.eye(C).cuda(), torch.zeros(C).cuda()
+    for p, ((n, m), s0, t0) in enumerate(zip(lengths, q_starts, k_starts)):
+        vt1 = SF.project_values_transposed(v[:, t0:t0 + m].contiguous(), eye, zero)
+        want, want_w, want_mix = SF.cross_attention_eq(q[:, s0:s0 + n].contiguous(), k[:, t0:t0 + m].contiguous(), vt1, H, mode, trace)
+        assert_close(outs['bf16x6'][0][:, s0:s0 + n], want, 2e-5, 'pair %d hidden' % p)
+        assert_close(outs['bf16x6'][1][p], want_mix, 1e-5, 'pair %d mix' % p)
