@@ -82,9 +82,10 @@ def main():
     ap.add_argument('--batch', type=int, default=8, help='registration pairs per forward / step (se3et_amd.batched), 1..8; '
                     '1 = the single-pair forward of the reference API')
     ap.add_argument('--switch-interval', type=float, default=1e-3)
-    ap.add_argument('--prefetch', type=int, default=1, help='build the pyramid of the next batch on a second host thread / HIP '
+    ap.add_argument('--prefetch', type=int, default=None, help='build the pyramid of the next batch on a second host thread / HIP '
                     'stream while the current batch runs through the model (the reference does this in DataLoader workers); every '
-                    'timed step still builds its own pyramid inside the timed region.  0: pyramid and model back to back')
+                    'timed step still builds its own pyramid inside the timed region.  0: pyramid and model back to back.  Default: 1 for '
+                    '--batch > 1, 0 for --batch 1 (560 launches per pair: a second host thread only takes the interpreter away)')
     ap.add_argument('--attention-dtype', default='float32', choices=['float32', 'bfloat16'], help="'bfloat16': geometric embedding "
                     "stored in bf16 (BASELINE.json configs[2] 'bf16 attention'); the headline metric is quoted on float32")
     ap.add_argument('--inflight', type=int, default=1, help='pairs in flight per GPU: host threads, one HIP stream each')
@@ -117,6 +118,8 @@ def main():
     model = load_synthetic_weights(create_model(cfg)).to(dev).eval()
     total_steps = args.steps + args.warmup
     PB = max(1, args.batch)
+    if args.prefetch is None:
+        args.prefetch = 1 if PB > 1 else 0
     # this rank's pairs, uploaded before the timed region (global pair index = (step * world + rank) * batch + j); with
     # --batch B the clouds of B pairs are stacked ref0, src0, ref1, src1, ... and go through ONE forward
     pairs = []
