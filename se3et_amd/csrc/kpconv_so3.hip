@@ -86,8 +86,9 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
   // FOUT: channel blocks of up to 128 (the staged rows of a block: 47 KB of LDS); otherwise one pass over all columns
   const int CBw = FOUT ? min(Cin, 128) : Cin;
   for (int cb0 = 0; cb0 < Cin; cb0 += CBw) {
-  for (int lc = threadIdx.x; lc < kA * CBw; lc += blockDim.x) {
-    const int a = lc / CBw, c = cb0 + (lc - a * CBw);
+  const int cw = min(CBw, Cin - cb0);                  // (the last block of a channel count that is not a multiple of 128 is narrower)
+  for (int lc = threadIdx.x; lc < kA * cw; lc += blockDim.x) {
+    const int a = lc / cw, c = cb0 + (lc - a * cw);
     const int col = a * Cin + c;
     float f[kK];
 #pragma unroll
@@ -132,13 +133,13 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
   }
   if (FOUT) {        // zero slot + pad of every row, then the block's rows leave LDS as whole 2928-byte runs (float4 per lane; written as
                      // 4-byte scatters straight from the column threads each 192-byte run came from three different store instructions)
-    for (int e = threadIdx.x; e < (CBw >> 3) * (kFRow - kK * kA * 8); e += blockDim.x) {
+    for (int e = threadIdx.x; e < (cw >> 3) * (kFRow - kK * kA * 8); e += blockDim.x) {
       const int cc = e / (kFRow - kK * kA * 8), w = e - cc * (kFRow - kK * kA * 8);
       fstage[cc * kFRow + kK * kA * 8 + w] = 0.f;
     }
     __syncthreads();
     const int row4 = kFRow / 4;
-    for (int e = threadIdx.x; e < (CBw >> 3) * row4; e += blockDim.x) {
+    for (int e = threadIdx.x; e < (cw >> 3) * row4; e += blockDim.x) {
       const int cc = e / row4, q = e - cc * row4;
       reinterpret_cast<float4*>(G + ((int64_t)((cb0 >> 3) + cc) * P16 + p) * kFRow)[q] = reinterpret_cast<const float4*>(fstage + cc * kFRow)[q];
     }

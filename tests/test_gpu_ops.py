@@ -166,7 +166,8 @@ def test_kpconv_matches_oracle(P, Ns, NN, Cin, Cout):
         ops.KPCONV_MATRIX_CORE = saved
 
 
-@pytest.mark.parametrize('P,Ns,NN,Cin,Cout', [(500, 500, 35, 32, 32), (2001, 2500, 36, 128, 128), (129, 200, 38, 256, 256)])
+@pytest.mark.parametrize('P,Ns,NN,Cin,Cout', [(500, 500, 35, 32, 32), (2001, 2500, 36, 128, 128), (129, 200, 38, 256, 256), (1, 50, 20, 64, 128),
+                                              (17, 60, 22, 128, 64), (33, 70, 38, 64, 192), (16, 40, 9, 8, 16), (250, 300, 30, 136, 48)])
 def test_kpconv_matrix_core_path_has_f32_accuracy(P, Ns, NN, Cin, Cout):
     """The bf16 matrix-core contraction (three-way operand splits, six products: csrc/kpconv_contract.hip) against the f32 path
     (slot sums + library f32 GEMM) on the same inputs: agreement at f32 round-off level (1e-5 of the max), and both against a float64
