@@ -307,3 +307,32 @@ def test_layer_norm_backward_kernel_matches_the_restatement_gradients(shape, res
     for name, a, b in zip(('hidden', 'residual', 'weight', 'bias', 'hidden_bias'), grads[0], grads[1]):
         if b is not None:
             assert_close(a, b, 2e-5, 'layer norm d/d' + name)
+
+
+def test_kpconv_kernels_with_other_slot_tables_match_the_restatement():
+    """Slot tables that are not the compiled-in SE3ET ones take the table-driven variants of the gather / scatter kernels (kidx / ridx as
+    kernel arguments) and the library-GEMM path: forward and both gradients against the PyTorch restatement."""
+    from se3et_amd import autograd as AG
+    from se3et_amd import functional as SF
+    from se3et_amd import tables
+    g = torch.Generator().manual_seed(77)
+    dev = 'cuda'
+    P, Ns, NN, Cin, Cout = 150, 220, 24, 16, 32
+    s_pts = (torch.rand(Ns, 3, generator=g) * 0.3).to(dev)
+    q_pts = s_pts[:P].contiguous()
+    d = ((q_pts[:, None] - s_pts[None]) ** 2).sum(-1)
+    idx = d.topk(NN, dim=1, largest=False)[1]
+    idx[d.gather(1, idx) > 0.0625 ** 2] = Ns
+    kp = torch.from_numpy(tables.kernel_points(0.0625)).to(dev)
+    kidx = torch.from_numpy(tables.kernel_slot_table()).to(dev)[:, [1, 2, 3, 4, 5, 0]].contiguous()      # a relabelling of the output anchors
+    ridx = torch.from_numpy(tables.anchor_slot_table()).to(dev)[:, [1, 2, 3, 4, 5, 0]].contiguous()
+    x0, w0 = torch.randn(Ns, 6, Cin, generator=g).to(dev), (torch.randn(6, 6, Cin, Cout, generator=g) / (36 * Cin) ** 0.5).to(dev)
+    c = torch.randn(P, 6, Cout, generator=g).to(dev)
+    res = []
+    for fn in (SF.kpconv_inter_so3, AG.kpconv_inter_so3):
+        x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+        y = fn(x, q_pts, s_pts, idx, kp, w, kidx, ridx, 0.05)
+        (y * c).sum().backward()
+        res.append((y.detach(), x.grad, w.grad))
+    for name, a, b in zip(('forward', 'dL/dx', 'dL/dW'), res[0], res[1]):
+        assert_close(a, b, 2e-5, 'kpconv with relabelled tables: ' + name)
