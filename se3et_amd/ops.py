@@ -397,42 +397,59 @@ def _host_table(t, dtype):
     return hit[0]
 
 
-# KPConv contraction path: True = always the matrix-core kernels (csrc/kpconv_contract.hip) where the channel counts allow, False = always
-# the round-1 path (slot sums G in HBM + library f32 GEMM), 'auto' = per layer shape, whichever measured faster on MI355X at the bench
-# shape (tools/micro/kpconv_paths.py, profiles/r02_kpconv_paths.txt): today the hand-written path on every SE3ET layer (32: 0.80 against
-# 0.97 ms, 64: 1.26 against 1.63, 128: 1.68 against 1.91, 256: 1.49 against 1.62 ms per call at 8 pairs).
-# Both paths agree to f32 round-off (tests/test_gpu_ops.py::test_kpconv_matrix_core_path_has_f32_accuracy).
-KPCONV_MATRIX_CORE = os.environ.get('SE3_KPCONV_PATH', 'auto')
-KPCONV_MATRIX_CORE = {'mfma': True, 'gemm': False}.get(KPCONV_MATRIX_CORE, 'auto')
+# KPConv path: True / 'auto' = the fused matrix-core kernel (csrc/kpconv_mfma.hip) where the channel counts allow (Cin % 8, Cout % 32),
+# 'sums' = the same contraction with the orbit sums written to HBM by a separate gather kernel (A/B runs), False = the round-1 path (slot
+# sums G in HBM + library f32 GEMM; also the fallback for other channel counts / slot tables and the operand of the backward pass).
+# All paths agree to f32 round-off (tests/test_gpu_ops.py::test_kpconv_matrix_core_path_has_f32_accuracy).
+KPCONV_MATRIX_CORE = {'mfma': True, 'fused': True, 'sums': 'sums', 'gemm': False}.get(os.environ.get('SE3_KPCONV_PATH', 'auto'), 'auto')
 
 
 def _kpconv_use_matrix_core(Cin, Cout, P):
-    if KPCONV_MATRIX_CORE == 'auto':
-        if Cout <= 64:
-            return True
-        # wider layers run one workgroup per (16-point tile, block of 64 columns), each walking all K-steps on its own: with few tiles
-        # (one pair per forward: 176-336 workgroups) the library GEMM's split over K fills the chip better (+0.4 ms per single pair)
-        return Cout % 64 == 0 and ((P + 15) // 16) * (Cout // 64) >= 512
-    return bool(KPCONV_MATRIX_CORE)
+    return True if KPCONV_MATRIX_CORE == 'auto' else KPCONV_MATRIX_CORE
 
 
 _BUILTIN_KIDX = [[0, 1, 1, 1, 1, 2], [1, 0, 1, 2, 1, 1], [1, 1, 0, 1, 2, 1], [1, 2, 1, 0, 1, 1], [1, 1, 2, 1, 0, 1], [2, 1, 1, 1, 1, 0],
                  [3, 3, 3, 4, 4, 4], [3, 4, 3, 3, 4, 4], [3, 4, 4, 3, 3, 4], [3, 3, 4, 4, 3, 4], [4, 3, 3, 4, 4, 3], [4, 4, 3, 3, 4, 3],
                  [4, 4, 4, 3, 3, 3], [4, 3, 4, 4, 3, 3], [5, 5, 5, 5, 5, 5]]
 _BUILTIN_RIDX = [[0, 3, 3, 3, 3, 5], [1, 0, 4, 5, 2, 1], [2, 2, 0, 4, 5, 4], [3, 5, 2, 0, 4, 3], [4, 4, 5, 2, 0, 2], [5, 1, 1, 1, 1, 0]]
-_builtin_checked = {}
-
-
 def _builtin_slot_tables(kt, rt):
-    """True when the module's (k, r) -> s and (a, r) -> t tables are the SE3ET configuration compiled into the matrix-core kernel."""
-    key = (kt.data_ptr(), rt.data_ptr())
-    hit = _builtin_checked.get(key)
-    if hit is None:
-        hit = kt.tolist() == _BUILTIN_KIDX and rt.tolist() == _BUILTIN_RIDX
-        if len(_builtin_checked) > 64:
-            _builtin_checked.clear()
-        _builtin_checked[key] = hit
-    return hit
+    """True when the module's (k, r) -> s and (a, r) -> t tables are the SE3ET configuration compiled into the matrix-core kernel.  The
+    verdict is an attribute of the host copies `_host_table` returns, so it lives and dies with their cache entries (a verdict keyed by the
+    host tensors' addresses could outlive them and be inherited by other tables placed at the same addresses)."""
+    hit = getattr(kt, '_se3_builtin', None)
+    if hit is None or hit[0] is not rt:
+        hit = (rt, kt.tolist() == _BUILTIN_KIDX and rt.tolist() == _BUILTIN_RIDX)
+        kt._se3_builtin = hit
+    return hit[1]
+
+
+_weight_piece_cache = {}          # (data_ptr, Cin, Cout, device) -> (weakref to the weight tensor, its version counter, pieces)
+
+
+def _kpconv_weight_pieces(weights, Cin, Cout, stream):
+    """f16 hi / lo MFMA fragments of KPConvInterSO3.weights (se3_kpconv_split_weights_f16).  Without autograd (inference) they are kept per
+    weight VERSION: torch bumps `_version` on every in-place update (optimizer steps, load_state_dict, copy_), so a stale entry is never
+    used as long as the weights are not rewritten behind torch's back (`.data` arithmetic, raw pointers) -- call
+    clear_weight_caches() after such an edit.  Under autograd the fragments are rebuilt per call (3 small launches)."""
+    w = _req(weights.detach().contiguous(), torch.float32, 'weights', 4)
+    cacheable = not torch.is_grad_enabled() and w.data_ptr() == weights.data_ptr()
+    key = (w.data_ptr(), Cin, Cout, w.device.index)
+    if cacheable:
+        hit = _weight_piece_cache.get(key)
+        if hit is not None and hit[0]() is not None and hit[1] == weights._version:
+            return hit[2]
+    Wp = torch.empty((lib().se3_kpconv_weight_pieces_bytes(Cin, Cout),), dtype=torch.uint8, device=w.device)
+    check(lib().se3_kpconv_split_weights_f16(w.data_ptr(), Cin, Cout, Wp.data_ptr(), stream), 'se3_kpconv_split_weights_f16')
+    if cacheable:
+        with _TIMING_LOCK:
+            if len(_weight_piece_cache) > 256:
+                _weight_piece_cache.clear()
+            _weight_piece_cache[key] = (weakref.ref(weights), weights._version, Wp)
+    return Wp
+
+
+def clear_weight_caches():
+    _weight_piece_cache.clear()
 
 
 def kpconv_slot_sums(x, q_pts, s_pts, idx, kernel_points, kidx, ridx, sigma):
@@ -487,19 +504,27 @@ def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, s
     if A != 6 or tuple(weights.shape[:3]) != (6, 6, Cin) or Ns != s_pts.shape[0]:
         raise RuntimeError('kpconv_inter_so3: inconsistent shapes')
     kp, kt, rt = _host_table(kernel_points, torch.float32), _host_table(kidx, torch.int64), _host_table(ridx, torch.int64)
-    nt = Cout // 16
-    if _kpconv_use_matrix_core(Cin, Cout, P) and Cin % 8 == 0 and Cout % 16 == 0 and (nt <= 4 or nt % 4 == 0) and _builtin_slot_tables(kt, rt):
-        # matrix-core path: F (P16, 90, Cin) in tile order -> slot sums on the fly -> bf16x6 MFMA at f32 accuracy (csrc/kpconv_contract.hip)
+    path = _kpconv_use_matrix_core(Cin, Cout, P)
+    if path and Cin % 8 == 0 and Cout % 32 == 0 and Ns * 6 * Cin < 2 ** 31 and _builtin_slot_tables(kt, rt):
         stream = _stream()
-        Fk = torch.empty((lib().se3_kpconv_points_floats(P, Cin),), dtype=torch.float32, device=x.device)
-        check(lib().se3_kpconv_so3_gather_points(q_pts.data_ptr(), s_pts.data_ptr(), idx.data_ptr(), x.data_ptr(), kp.data_ptr(),
-                                                 float(sigma), P, Ns, NN, Cin, Fk.data_ptr(), stream), 'se3_kpconv_so3_gather_points')
-        w = _req(weights.detach().contiguous(), torch.float32, 'weights', 4)
-        Wf = torch.empty((lib().se3_kpconv_weight_fragments_bytes(Cin, Cout),), dtype=torch.uint8, device=x.device)
-        check(lib().se3_kpconv_split_weights(w.data_ptr(), Cin, Cout, Wf.data_ptr(), stream), 'se3_kpconv_split_weights')
+        Wp = _kpconv_weight_pieces(weights, Cin, Cout, stream)
         out = torch.empty((P, 6, Cout), dtype=torch.float32, device=x.device)
-        check(lib().se3_kpconv_so3_contract(Fk.data_ptr(), Wf.data_ptr(), P, Cin, Cout, out.data_ptr(), stream),
-              'se3_kpconv_so3_contract')
+        if path == 'sums':
+            # two launches: f16 hi / lo orbit sums (P16, 16, 6, Cin) as tile images in HBM, then the MFMA contraction (kept for A/B runs)
+            Hs = torch.empty((lib().se3_kpconv_sums_bytes(P, Cin),), dtype=torch.uint8, device=x.device)
+            check(lib().se3_kpconv_so3_gather_sums(q_pts.data_ptr(), s_pts.data_ptr(), idx.data_ptr(), x.data_ptr(), kp.data_ptr(),
+                                                   float(sigma), P, Ns, NN, Cin, Hs.data_ptr(), stream), 'se3_kpconv_so3_gather_sums')
+            check(lib().se3_kpconv_so3_contract_f16(Hs.data_ptr(), Wp.data_ptr(), P, Cin, Cout, out.data_ptr(), stream),
+                  'se3_kpconv_so3_contract_f16')
+            return out
+        # fused: neighbour table (valid neighbours + influence weights), then ONE kernel in which producer waves form the f16 hi / lo orbit
+        # sums of a 16-point tile in LDS and consumer waves multiply them on the matrix cores (csrc/kpconv_mfma.hip)
+        kpd = _req(kernel_points.detach().contiguous(), torch.float32, 'kernel_points', 2)
+        nbytes = lib().se3_kpconv_neighbor_table_bytes(P, NN)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+        check(lib().se3_kpconv_so3_fused(q_pts.data_ptr(), s_pts.data_ptr(), idx.data_ptr(), x.data_ptr(), kpd.data_ptr(), float(sigma),
+                                         P, Ns, NN, Cin, Cout, Wp.data_ptr(), out.data_ptr(), ws.data_ptr(), nbytes, stream),
+              'se3_kpconv_so3_fused')
         return out
     G = torch.empty((P * 6, 36 * Cin), dtype=torch.float32, device=x.device)
     check(lib().se3_kpconv_so3_gather(q_pts.data_ptr(), s_pts.data_ptr(), idx.data_ptr(), x.data_ptr(), kp.data_ptr(),

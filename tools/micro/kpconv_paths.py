@@ -1,5 +1,5 @@
 """KPConv per stage at the bench shape (8 pairs per forward): round-1 path (slot sums G + library f32 GEMM) against the matrix-core
-path (F + bf16x6 contraction).  python tools/micro/kpconv_paths.py"""
+path (f16 hi / lo orbit sums + v_mfma_f32_32x32x16_f16 contraction), the latter also per stage.  python tools/micro/kpconv_paths.py"""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from se3et_amd import ops, functional as SF, tables
@@ -23,7 +23,7 @@ def timeit(f, n=10):
 # (query stage, support stage, table, Cin = Cout, sigma scale)
 calls = [(0, 0, 'neighbors', 32), (1, 0, 'subsampling', 32), (1, 1, 'neighbors', 64), (1, 1, 'neighbors', 64), (2, 1, 'subsampling', 64),
          (2, 2, 'neighbors', 128), (2, 2, 'neighbors', 128), (3, 2, 'subsampling', 128), (3, 3, 'neighbors', 256), (3, 3, 'neighbors', 256)]
-tot = {'old': 0.0, 'new': 0.0}
+tot = {'old': 0.0, 'sums': 0.0, 'new': 0.0}
 g = torch.Generator(device='cpu').manual_seed(0)
 for qs, ss, tab, C in calls:
     q, s = dd['points'][qs], dd['points'][ss]
@@ -33,11 +33,24 @@ for qs, ss, tab, C in calls:
     kp = torch.from_numpy(tables.kernel_points(b.init_radius * 2 ** ss)).to(dev)
     sig = b.init_sigma * 2 ** ss
     res = {}
-    for name, flag in (('old', False), ('new', True)):
+    for name, flag in (('old', False), ('sums', 'sums'), ('new', True)):
         ops.KPCONV_MATRIX_CORE = flag
         res[name] = timeit(lambda: SF.kpconv_inter_so3(x, q, s, idx, kp, w, kidx, ridx, sig))
         tot[name] += res[name]
     ops.KPCONV_MATRIX_CORE = 'auto'
+    # the two stages of the matrix-core path by themselves
+    from se3et_amd._lib import lib, check
+    P, NN = idx.shape; st = ops._stream()
+    Hs = torch.empty((lib().se3_kpconv_sums_bytes(P, C),), dtype=torch.uint8, device=dev)
+    kph = kp.cpu().contiguous()
+    Wp = ops._kpconv_weight_pieces(w, C, C, st)
+    out = torch.empty((P, 6, C), device=dev)
+    t_g = timeit(lambda: check(lib().se3_kpconv_so3_gather_sums(q.data_ptr(), s.data_ptr(), idx.data_ptr(), x.data_ptr(), kph.data_ptr(), float(sig), P, s.shape[0], NN, C, Hs.data_ptr(), st), 'g'))
+    t_c = timeit(lambda: check(lib().se3_kpconv_so3_contract_f16(Hs.data_ptr(), Wp.data_ptr(), P, C, C, out.data_ptr(), st), 'c'))
+    err = float((out - torch.mm(ops.kpconv_slot_sums(x, q, s, idx, kp, kidx, ridx, sig), w.reshape(36 * C, C)).view(P, 6, C)).abs().max() / out.abs().max())
     gf = 2.0 * 6 * q.shape[0] * 36 * C * C / 1e9
-    print('P %6d NN %2d C %3d  old %.3f ms  new %.3f ms  (%.0f GF: new = %.0f TF/s f32-equivalent)' % (q.shape[0], idx.shape[1], C, res['old'], res['new'], gf, gf / res['new']))
-print('total old %.2f ms  new %.2f ms per 8 pairs' % (tot['old'], tot['new']))
+    ops.KPCONV_MATRIX_CORE = True; outf = SF.kpconv_inter_so3(x, q, s, idx, kp, w, kidx, ridx, sig); ops.KPCONV_MATRIX_CORE = 'auto'
+    errf = float((outf - torch.mm(ops.kpconv_slot_sums(x, q, s, idx, kp, kidx, ridx, sig), w.reshape(36 * C, C)).view(P, 6, C)).abs().max() / outf.abs().max())
+    print('P %6d NN %2d C %3d  gemm %.3f ms  sums %.3f ms (gather %.3f + contract %.3f)  fused %.3f ms (%.0f GF: %.0f TF/s f32-equivalent, %.2f PF/s f16)  err %.1e / %.1e'
+          % (q.shape[0], idx.shape[1], C, res['old'], res['sums'], t_g, t_c, res['new'], gf, gf / res['new'], 3 * gf / res['new'] / 1e3, err, errf))
+print('total gemm %.2f ms  sums %.2f ms  fused %.2f ms per 8 pairs' % (tot['old'], tot['sums'], tot['new']))
