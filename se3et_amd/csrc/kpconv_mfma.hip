@@ -24,6 +24,16 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;      // (an array of HIP uint4 structs ends up in scratch)
 
+#ifdef SE3_KPCONV_STAMPS      // diagnostic build of tools/micro/kpconv_stamps.hip only: wave time stamps of the first workgroups
+__device__ long long* g_stamps = nullptr;
+constexpr int kStampBlocks = 64, kStampSteps = 40, kStampSlots = 6;
+#define SE3_STAMP(step_, slot_)                                                                                            \
+  if (g_stamps && blockIdx.x < kStampBlocks && blockIdx.y == 0 && (step_) < kStampSteps && lane == 0)                      \
+    g_stamps[(((int64_t)blockIdx.x * 16 + wave) * kStampSteps + (step_)) * kStampSlots + (slot_)] = __builtin_amdgcn_s_memtime();
+#else
+#define SE3_STAMP(step_, slot_)
+#endif
+
 constexpr int kTile4 = kTileB / 16;          // uint4 per tile image (3104)
 constexpr int kHeaderB = 256;                // weight-fragment buffer: [header: 1 / scale, max |W| bits][fragments]
 
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(64 * NCW * KS) void kpconv_mfma_kernel(const u32x4*
 // The matrix pipe (consumers) and the vector ALUs (producers) of a SIMD are fed by different waves and overlap.
 
 // neighbour table of a layer: per query point the VALID neighbours compacted to the front (invalid ones carry weight 0 in the reference:
-// blocks_epn.py:471,377 shadow point / zero feature row), padded with (index 0, weights 0) up to a multiple of 8
+// blocks_epn.py:471,377 shadow point / zero feature row), padded with (index 0, weights 0) up to a multiple of 24 (NNp)
 //   nbr  [P][NNp] int32     support row of the j-th valid neighbour
 //   wts  [P][NNp][16] f32   w[k] = max(0, 1 - |s - q - kp_k| / sigma), k < 15; [15] = 0
 //   cnt  [P] int32          valid neighbours
@@ -211,36 +221,37 @@ __global__ __launch_bounds__(64) void kpconv_neighbor_table_kernel(const float* 
   if (valid) order[__popcll(m & ((1ull << n) - 1ull))] = n;
   __syncthreads();
   if (n == 0) cnt[p] = nv;
-  if (n >= NNp) return;
-  float w[16];
+  for (int e = n; e < NNp; e += 64) {
+    float w[16];
 #pragma unroll
-  for (int k = 0; k < 16; k++) w[k] = 0.f;
-  int row = 0;
-  if (n < nv) {
-    const int64_t js = idx[p * NN + order[n]];
-    row = (int)js;
-    const float qx = q_pts[3 * p], qy = q_pts[3 * p + 1], qz = q_pts[3 * p + 2];
-    const float sx = s_pts[3 * js], sy = s_pts[3 * js + 1], sz = s_pts[3 * js + 2];
+    for (int k = 0; k < 16; k++) w[k] = 0.f;
+    int row = 0;
+    if (e < nv) {
+      const int64_t js = idx[p * NN + order[e]];
+      row = (int)js;
+      const float qx = q_pts[3 * p], qy = q_pts[3 * p + 1], qz = q_pts[3 * p + 2];
+      const float sx = s_pts[3 * js], sy = s_pts[3 * js + 1], sz = s_pts[3 * js + 2];
 #pragma unroll
-    for (int k = 0; k < kK; k++) {
-      const float dx = sx - qx - kp[3 * k], dy = sy - qy - kp[3 * k + 1], dz = sz - qz - kp[3 * k + 2];
-      w[k] = fmaxf(0.f, 1.f - sqrtf(dx * dx + dy * dy + dz * dz) * inv_sigma);
+      for (int k = 0; k < kK; k++) {
+        const float dx = sx - qx - kp[3 * k], dy = sy - qy - kp[3 * k + 1], dz = sz - qz - kp[3 * k + 2];
+        w[k] = fmaxf(0.f, 1.f - sqrtf(dx * dx + dy * dy + dz * dz) * inv_sigma);
+      }
     }
-  }
-  nbr[p * NNp + n] = row;
-  float4* dst = reinterpret_cast<float4*>(wts + (p * NNp + n) * 16);
+    nbr[p * NNp + e] = row;
+    float4* dst = reinterpret_cast<float4*>(wts + (p * NNp + e) * 16);
 #pragma unroll
-  for (int q = 0; q < 4; q++) dst[q] = make_float4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    for (int q = 0; q < 4; q++) dst[q] = make_float4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+  }
 }
 
-template <int NCW, int KS>
+template <int NCW, int KS, int CT>      // consumer waves: NCW column groups x KS K-split groups; CT column tiles (32 columns) per wave
 __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
     const float* __restrict__ x, const int* __restrict__ nbr, const float* __restrict__ wts, const int* __restrict__ cnt, int NNp,
     const u32x4* __restrict__ Wf, const float* __restrict__ hdr, int64_t P, int Cin, int Cout, float* __restrict__ out) {
   constexpr int NC = NCW * KS;                                         // consumer waves
   constexpr int NPW = 8;                                               // producer waves: two points of the tile each
   constexpr int kSPW = kSteps / KS;                                    // K16-steps per consumer wave and chunk
-  static_assert(kSteps % KS == 0 && kSPW % 3 == 0, "K split must leave a multiple of 3 K16-steps per wave");
+  static_assert(kSteps % KS == 0 && kSPW % 2 == 0, "K split must leave an even number of K16-steps per wave");
   extern __shared__ __align__(16) unsigned char lds[];                 // [3 images][table]
   unsigned* tab = reinterpret_cast<unsigned*>(lds + 3 * kTileB);       // [K16-step][rsel][h]: three 8-bit run numbers (anchor pairs 0..2)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -265,6 +276,8 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
   const int steps_total = chunks + 2;
   if (wave >= NC) {
     // ---------------- producer ----------------
+    // The gather is bound by the bytes in flight per compute unit (random 64-byte sectors out of L2 / Infinity Cache): 24 neighbour rows
+    // are requested per wave before the first is used (8 waves x 24 x 384 B = 72 KB in flight).
     const int pw = wave - NC;
     const int a = lane < 48 ? lane >> 3 : 5, cp = lane & 7, half = cp >> 2;    // channel pair cp of the 16: chunk half, channels 2 (cp & 3) + {0, 1}
     const unsigned col0 = (unsigned)(a * Cin + 2 * cp);                  // + pair * 16
@@ -274,6 +287,7 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
 #pragma unroll
     for (int o = 0; o < 2 * kOrbits; o++) held[o] = 0u;
     for (int u = 0; u < steps_total; u++) {
+      SE3_STAMP(u, 0)
       if (u < 2 * pairs) {
         const int T = u >> 1, second = u & 1;
         const int i = pw + NPW * second;                                  // point of the tile, uniform over the wave
@@ -298,21 +312,36 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
           const int* nb = nbr + p * NNp;
           const float* wr = wts + p * NNp * 16;
           const float* xc = x + T * 16 + (active ? col0 : 0u);
-          for (int n0 = 0; n0 < nv; n0 += 8) {
-            float2 xv[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) xv[q] = *reinterpret_cast<const float2*>(xc + (unsigned)nb[n0 + q] * rowlen);
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-#pragma unroll
-              for (int k = 0; k < kK; k++) {
-                const float w = wr[(n0 + q) * 16 + k];
-                f0[k] = fmaf(w, xv[q].x, f0[k]);
-                f1[k] = fmaf(w, xv[q].y, f1[k]);
-              }
-            }
+          // rotating prefetch, three batches of 8 neighbour rows deep: the requests of batch b + 3 leave right behind the FMAs of batch b.
+          // All requests are unconditional (batch numbers clamped into the table row, whose tail is index 0 / weight 0) and at the top
+          // level of the loop body: hipcc sinks a load into the branch that uses it, which would serialise request and use.
+          const int nbat = (nv + 7) >> 3, lastb = NNp / 8 - 1;
+          SE3_STAMP(u, 1)
+          float2 xa[8], xb[8], xc8[8];
+#define SE3_REQ(dst_, b_)                                                                                     \
+  {                                                                                                           \
+    const int bb_ = (b_) < lastb ? (b_) : lastb;                                                              \
+    _Pragma("unroll") for (int q = 0; q < 8; q++) dst_[q] = *reinterpret_cast<const float2*>(xc + (unsigned)nb[bb_ * 8 + q] * rowlen); \
+  }
+#define SE3_FMA(src_, b_)                                                                                     \
+  _Pragma("unroll") for (int q = 0; q < 8; q++) _Pragma("unroll") for (int k = 0; k < kK; k++) {              \
+    const float w = wr[((b_) * 8 + q) * 16 + k];                                                              \
+    f0[k] = fmaf(w, src_[q].x, f0[k]);                                                                        \
+    f1[k] = fmaf(w, src_[q].y, f1[k]);                                                                        \
+  }
+          SE3_REQ(xa, 0) SE3_REQ(xb, 1) SE3_REQ(xc8, 2)
+          for (int b = 0; b < nbat; b += 3) {
+            SE3_FMA(xa, b)
+            SE3_REQ(xa, b + 3)
+            if (b + 1 < nbat) { SE3_FMA(xb, b + 1) }
+            SE3_REQ(xb, b + 4)
+            if (b + 2 < nbat) { SE3_FMA(xc8, b + 2) }
+            SE3_REQ(xc8, b + 5)
           }
+#undef SE3_REQ
+#undef SE3_FMA
         }
+        SE3_STAMP(u, 2)
         unsigned char* dst = (half ? img_hi : img_lo) + i * kRowB + dst0;
         const bool store_now = active && (half == 0 || second);
 #pragma unroll
@@ -336,7 +365,9 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
           held[2 * o + 1] = lo;
         }
       }
+      SE3_STAMP(u, 3)
       if (u + 1 < steps_total) __syncthreads();
+      SE3_STAMP(u, 4)
     }
     if (KS > 1) {
       __syncthreads();
@@ -346,89 +377,130 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
   }
   // ---------------- consumer ----------------
   const int cw = wave % NCW, ksp = wave / NCW;
-  const int NCT = Cout / 32, ct = blockIdx.y * NCW + cw;
+  const int NCT = Cout / 32, ct0 = (blockIdx.y * NCW + cw) * CT;
   const int i32 = lane & 31, h = lane >> 5;
   const int a_base = row_point(i32) * kRowB;                           // + piece * kTP * kRowB + run * 16
   const int tab_lane = row_rsel(i32) * 2 + h;
-  f32x16 acc[3];
+  f32x16 acc[CT][3];
 #pragma unroll
-  for (int rt = 0; rt < 3; rt++)
+  for (int n = 0; n < CT; n++)
 #pragma unroll
-    for (int v = 0; v < 16; v++) acc[rt][v] = 0.f;
-  // weight fragments (hi, lo) of this wave's next three K16-steps: a ring of three register pairs, refilled behind the step's MFMAs
-  const u32x4* wbase = Wf + (int64_t)ct * 2 * 64 + lane;
+    for (int rt = 0; rt < 3; rt++)
+#pragma unroll
+      for (int v = 0; v < 16; v++) acc[n][rt][v] = 0.f;
+  // weight fragments (hi, lo) of this wave's next two K16-steps: two register sets, each refilled behind the MFMAs that read it
+  const u32x4* wbase = Wf + (int64_t)ct0 * 2 * 64 + lane;
   const int64_t wstep = (int64_t)NCT * 2 * 64;                          // uint4 per K16-step over the whole layer
   const int64_t last_step = (int64_t)chunks * kSteps - KS + ksp;
-  u32x4 bq[3][2];
+  u32x4 bq[2][CT][2];
 #pragma unroll
-  for (int j = 0; j < 3; j++) {
+  for (int j = 0; j < 2; j++) {
     int64_t g = ksp + j * KS;
     g = g < last_step ? g : last_step;
-    bq[j][0] = wbase[g * wstep];
-    bq[j][1] = wbase[g * wstep + 64];
+#pragma unroll
+    for (int n = 0; n < CT; n++) {
+      bq[j][n][0] = wbase[g * wstep + n * 128];
+      bq[j][n][1] = wbase[g * wstep + n * 128 + 64];
+    }
   }
   __syncthreads();                                                      // steps 0 and 1: nothing to multiply yet
   __syncthreads();
   for (int cc = 0; cc < chunks; cc++) {
     const unsigned char* img = lds + (cc % 3) * kTileB;
+    SE3_STAMP(cc + 2, 0)
+    // A fragments of the step after the one being multiplied are read while its MFMAs run (two register sets)
+    f16x8 av[2][3][2];
+    {
+      const unsigned runs = tab[ksp * 4 + tab_lane];
+#pragma unroll
+      for (int rt = 0; rt < 3; rt++) {
+        const int off = a_base + (int)((runs >> (8 * rt)) & 0xff) * 16;
+        av[0][rt][0] = *reinterpret_cast<const f16x8*>(img + off);
+        av[0][rt][1] = *reinterpret_cast<const f16x8*>(img + off + kTP * kRowB);
+      }
+    }
 #pragma unroll 1
-    for (int q3 = 0; q3 < kSPW; q3 += 3) {
+    for (int q2 = 0; q2 < kSPW; q2 += 2) {
 #pragma unroll
-      for (int j = 0; j < 3; j++) {
-        const int st = ksp + (q3 + j) * KS;
-        const unsigned runs = tab[st * 4 + tab_lane];
-        f16x8 av[3][2];
+      for (int j = 0; j < 2; j++) {
+        const int st = ksp + (q2 + j) * KS;
+        {
+          const int sn = st + KS < kSteps ? st + KS : st;                // next step of this chunk (clamped: the last one re-reads itself)
+          const unsigned runs = tab[sn * 4 + tab_lane];
 #pragma unroll
-        for (int rt = 0; rt < 3; rt++) {
-          const int off = a_base + (int)((runs >> (8 * rt)) & 0xff) * 16;
-          av[rt][0] = *reinterpret_cast<const f16x8*>(img + off);
-          av[rt][1] = *reinterpret_cast<const f16x8*>(img + off + kTP * kRowB);
+          for (int rt = 0; rt < 3; rt++) {
+            const int off = a_base + (int)((runs >> (8 * rt)) & 0xff) * 16;
+            av[j ^ 1][rt][0] = *reinterpret_cast<const f16x8*>(img + off);
+            av[j ^ 1][rt][1] = *reinterpret_cast<const f16x8*>(img + off + kTP * kRowB);
+          }
         }
-        const f16x8 b0 = __builtin_bit_cast(f16x8, bq[j][0]), b1 = __builtin_bit_cast(f16x8, bq[j][1]);
         // smallest terms first; consecutive MFMAs go to different accumulators
 #pragma unroll
-        for (int rt = 0; rt < 3; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[rt][1], b0, acc[rt], 0, 0, 0);
+        for (int n = 0; n < CT; n++) {
+          const f16x8 b0 = __builtin_bit_cast(f16x8, bq[j][n][0]);
 #pragma unroll
-        for (int rt = 0; rt < 3; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[rt][0], b1, acc[rt], 0, 0, 0);
+          for (int rt = 0; rt < 3; rt++) acc[n][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[j][rt][1], b0, acc[n][rt], 0, 0, 0);
+        }
 #pragma unroll
-        for (int rt = 0; rt < 3; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[rt][0], b0, acc[rt], 0, 0, 0);
+        for (int n = 0; n < CT; n++) {
+          const f16x8 b1 = __builtin_bit_cast(f16x8, bq[j][n][1]);
+#pragma unroll
+          for (int rt = 0; rt < 3; rt++) acc[n][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[j][rt][0], b1, acc[n][rt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int n = 0; n < CT; n++) {
+          const f16x8 b0 = __builtin_bit_cast(f16x8, bq[j][n][0]);
+#pragma unroll
+          for (int rt = 0; rt < 3; rt++) acc[n][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[j][rt][0], b0, acc[n][rt], 0, 0, 0);
+        }
         {
-          int64_t g = (int64_t)cc * kSteps + st + 3 * KS;                // unconditional (clamped) so that the compiler can count the requests
+          int64_t g = (int64_t)cc * kSteps + st + 2 * KS;                // unconditional (clamped) so that the compiler can count the requests
           g = g < last_step ? g : last_step;
-          bq[j][0] = wbase[g * wstep];
-          bq[j][1] = wbase[g * wstep + 64];
+#pragma unroll
+          for (int n = 0; n < CT; n++) {
+            bq[j][n][0] = wbase[g * wstep + n * 128];
+            bq[j][n][1] = wbase[g * wstep + n * 128 + 64];
+          }
         }
       }
     }
+    SE3_STAMP(cc + 2, 3)
     if (cc + 1 < chunks) __syncthreads();
+    SE3_STAMP(cc + 2, 4)
   }
   if (KS > 1) {                                                          // merge the K split through LDS (the images are no longer needed)
     __syncthreads();
     float* red = reinterpret_cast<float*>(lds);
     if (ksp > 0) {
 #pragma unroll
-      for (int rt = 0; rt < 3; rt++)
+      for (int n = 0; n < CT; n++)
 #pragma unroll
-        for (int v = 0; v < 16; v++) red[(((ksp - 1) * NCW + cw) * 48 + rt * 16 + v) * 64 + lane] = acc[rt][v];
+        for (int rt = 0; rt < 3; rt++)
+#pragma unroll
+          for (int v = 0; v < 16; v++) red[((((ksp - 1) * NCW + cw) * CT + n) * 48 + rt * 16 + v) * 64 + lane] = acc[n][rt][v];
     }
     __syncthreads();
     if (ksp > 0) return;
 #pragma unroll 1
     for (int k = 1; k < KS; k++)
 #pragma unroll
-      for (int rt = 0; rt < 3; rt++)
+      for (int n = 0; n < CT; n++)
 #pragma unroll
-        for (int v = 0; v < 16; v++) acc[rt][v] += red[(((k - 1) * NCW + cw) * 48 + rt * 16 + v) * 64 + lane];
+        for (int rt = 0; rt < 3; rt++)
+#pragma unroll
+          for (int v = 0; v < 16; v++) acc[n][rt][v] += red[((((k - 1) * NCW + cw) * CT + n) * 48 + rt * 16 + v) * 64 + lane];
   }
   const float inv_scale = hdr[0];
 #pragma unroll
-  for (int rt = 0; rt < 3; rt++)
+  for (int n = 0; n < CT; n++)
 #pragma unroll
-    for (int v = 0; v < 16; v++) {
-      const int64_t p = p0 + v;
-      const int r = 2 * rt + ((0x96 >> (2 * (v >> 2) + h)) & 1);
-      if (p < P) out[(p * kA + r) * Cout + ct * 32 + i32] = acc[rt][v] * inv_scale;
-    }
+    for (int rt = 0; rt < 3; rt++)
+#pragma unroll
+      for (int v = 0; v < 16; v++) {
+        const int64_t p = p0 + v;
+        const int r = 2 * rt + ((0x96 >> (2 * (v >> 2) + h)) & 1);
+        if (p < P) out[(p * kA + r) * Cout + (ct0 + n) * 32 + i32] = acc[n][rt][v] * inv_scale;
+      }
 }
 
 }  // namespace
@@ -491,7 +563,7 @@ extern "C" int se3_kpconv_so3_contract_f16(const void* sums, const void* weight_
 
 extern "C" size_t se3_kpconv_neighbor_table_bytes(int64_t num_queries, int num_neighbors) {
   if (num_queries < 0 || num_neighbors < 1 || num_neighbors > 64) return 0;
-  const size_t nnp = (size_t)(num_neighbors + 7) / 8 * 8;
+  const size_t nnp = (size_t)(num_neighbors + 23) / 24 * 24;
   return (size_t)num_queries * nnp * (16 * sizeof(float) + sizeof(int)) + (size_t)num_queries * sizeof(int) + 256;
 }
 
@@ -511,7 +583,7 @@ extern "C" int se3_kpconv_so3_fused(const float* q_pts, const float* s_pts, cons
               "kpconv_so3_fused: workspace too small");
   if (num_queries == 0) return SE3_OK;
   hipStream_t st = (hipStream_t)stream;
-  const int NNp = (num_neighbors + 7) / 8 * 8;
+  const int NNp = (num_neighbors + 23) / 24 * 24;
   float* wts = static_cast<float*>(workspace);
   int* nbr = reinterpret_cast<int*>(wts + (size_t)num_queries * NNp * 16);
   int* cnt = nbr + (size_t)num_queries * NNp;
@@ -522,20 +594,22 @@ extern "C" int se3_kpconv_so3_fused(const float* q_pts, const float* s_pts, cons
   const float* hdr = static_cast<const float*>(weight_pieces);
   const u32x4* Wf = reinterpret_cast<const u32x4*>(static_cast<const unsigned char*>(weight_pieces) + kHeaderB);
   const size_t lds = (size_t)3 * kTileB + kSteps * 4 * sizeof(unsigned);
-#define SE3_FUSED(NCW_, KS_)                                                                                               \
-  {                                                                                                                              \
-    static bool attr_set = false;                                                                                                \
-    if (!attr_set) {                                                                                                             \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kpconv_fused_kernel<NCW_, KS_>),                            \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                           \
-      attr_set = true;                                                                                                           \
-    }                                                                                                                            \
-    kpconv_fused_kernel<NCW_, KS_><<<dim3((unsigned)tiles, (unsigned)(NCT / NCW_)), 64 * (NCW_ * KS_ + 8), lds, st>>>(  \
-        x, nbr, wts, cnt, NNp, Wf, hdr, num_queries, in_channels, out_channels, out);                                            \
+#define SE3_FUSED(NCW_, KS_, CT_)                                                                                                   \
+  {                                                                                                                                 \
+    static bool attr_set = false;                                                                                                   \
+    if (!attr_set) {                                                                                                                \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kpconv_fused_kernel<NCW_, KS_, CT_>),                                \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                              \
+      attr_set = true;                                                                                                              \
+    }                                                                                                                               \
+    kpconv_fused_kernel<NCW_, KS_, CT_><<<dim3((unsigned)tiles, (unsigned)(NCT / (NCW_ * CT_))), 64 * (NCW_ * KS_ + 8), lds, st>>>( \
+        x, nbr, wts, cnt, NNp, Wf, hdr, num_queries, in_channels, out_channels, out);                                               \
   }
-  if (NCT % 4 == 0) SE3_FUSED(4, 2)
-  else if (NCT % 2 == 0) SE3_FUSED(2, 3)
-  else SE3_FUSED(1, 6)
+  // 12 waves per compute unit (3 per SIMD: 168 registers): 8 producers + 3 or 4 consumers
+  if (NCT % 8 == 0) SE3_FUSED(4, 1, 2)
+  else if (NCT % 4 == 0) SE3_FUSED(4, 1, 1)
+  else if (NCT % 2 == 0) SE3_FUSED(1, 3, 2)
+  else SE3_FUSED(1, 3, 1)
 #undef SE3_FUSED
   SE3_CHECK_LAUNCH("kpconv_so3_fused");
   return SE3_OK;
