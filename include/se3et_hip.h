@@ -194,34 +194,34 @@ int se3_kpconv_split_weights(const float* weights, int in_channels, int out_chan
 int se3_kpconv_so3_contract(const float* F, const void* weight_fragments, int64_t num_queries, int in_channels, int out_channels,
                             float* out, void* stream);
 
-/* Round 3 form of the matrix-core convolution (csrc/kpconv_sums.h, kpconv_so3.hip, kpconv_mfma.hip; input channels a multiple of 8,
- * output channels a multiple of 32, SE3ET slot tables compiled in).  Over all (weight slot s, output anchor r) only 16 distinct
- * kernel-point sums occur (6 vertices, centre, 3 equators, 6 face quadruples); se3_kpconv_so3_gather_sums leaves those "orbit sums"
- * H[p, orbit, a, c] = sum_{k in orbit} sum_n w[p, n, k] x[idx[p, n], a, c], split once into f16 hi + lo pieces, as tile images
- * [Cin / 8][ceil(P / 16)][piece][point][97 x 16 B] (se3_kpconv_sums_bytes bytes); se3_kpconv_split_weights_f16 re-arranges weights
- * (36 Cin, Cout) -- KPConvInterSO3.weights (6, 6, Cin, Cout) flattened, blocks_epn.py:105-106 -- into f16 hi / lo MFMA fragments scaled by
- * a power of two (`pieces`: se3_kpconv_weight_pieces_bytes bytes incl. a 256-byte header holding 1 / scale); se3_kpconv_so3_contract_f16
- * multiplies with v_mfma_f32_32x32x16_f16 (hi hi + hi lo + lo hi in f32: 2^-22 per term) reading the slot sums of blocks_epn.py:503-546 in
- * place from the image: out (P, 6, Cout).  Range: |H| < 65504 (f16 hi piece); values below 2^-3 keep an absolute error of 2^-25. */
-size_t se3_kpconv_sums_bytes(int64_t num_queries, int in_channels);
-int se3_kpconv_so3_gather_sums(const float* q_pts, const float* s_pts, const int64_t* idx, const float* x,
-                               const float* kernel_points_host, float sigma, int64_t num_queries, int64_t num_support,
-                               int num_neighbors, int in_channels, void* sums, void* stream);
+/* Round 3 form of the matrix-core convolution (csrc/kpconv_sums.h, csrc/kpconv_mfma.hip; input channels a multiple of 8, output channels a
+ * multiple of 32, SE3ET slot tables compiled in; num_support * 6 * in_channels < 2^31).  Over all (weight slot s, output anchor r) only 16
+ * distinct kernel-point sums occur (6 vertices, centre, 3 equators, 6 face quadruples): the "orbits".
+ *   se3_kpconv_neighbor_table: per query point its valid neighbours (compacted; shadow / padded entries carry weight 0 in the reference,
+ *     blocks_epn.py:471,377) and their 16 orbit weights hw[o] = sum_{k in o} max(0, 1 - |s - q - kp_k| / sigma) (blocks_epn.py:520-533);
+ *     kernel_points_dev (15, 3) DEVICE; table: se3_kpconv_neighbor_table_bytes bytes.  Depends on the geometry only: layers that share
+ *     (q_pts, s_pts, idx, kernel points, sigma) may share it.
+ *   se3_kpconv_split_weights_f16: weights (36 Cin, Cout) -- KPConvInterSO3.weights (6, 6, Cin, Cout) flattened, blocks_epn.py:105-106 -- as f16
+ *     hi / lo MFMA fragments scaled by a power of two (`pieces`: se3_kpconv_weight_pieces_bytes bytes incl. a 256-byte header with 1 / scale).
+ *   se3_kpconv_so3_fused: KPConvInterSO3.forward (blocks_epn.py:454-546) in ONE kernel: producer waves form the orbit sums
+ *     H[p, o, a, c] = sum_n hw[p, n, o] x[idx[p, n], a, c] of a 16-point tile on the f32 matrix cores and leave them, split into f16 hi + lo
+ *     pieces, in LDS; consumer waves multiply them with v_mfma_f32_32x32x16_f16 (hi hi + hi lo + lo hi in f32: 2^-22 per term), reading the
+ *     slot sums of blocks_epn.py:503-546 in place: out (P, 6, Cout).  The operand never exists in HBM.
+ *   se3_kpconv_so3_gather_sums + se3_kpconv_so3_contract_f16: the same two stages as two launches, H as tile images
+ *     [Cin / 8][ceil(P / 16)][piece][point][97 x 16 B] in HBM (se3_kpconv_sums_bytes bytes).
+ * Range: |H| < 65504 (f16 hi piece); values below 2^-3 keep an absolute error of 2^-25. */
+size_t se3_kpconv_neighbor_table_bytes(int64_t num_queries, int num_neighbors);
+int se3_kpconv_neighbor_table(const float* q_pts, const float* s_pts, const int64_t* idx, const float* kernel_points_dev, float sigma,
+                              int64_t num_queries, int64_t num_support, int num_neighbors, void* table, size_t table_bytes, void* stream);
 size_t se3_kpconv_weight_pieces_bytes(int in_channels, int out_channels);
 int se3_kpconv_split_weights_f16(const float* weights, int in_channels, int out_channels, void* pieces, void* stream);
+int se3_kpconv_so3_fused(const float* x, const void* table, int64_t num_queries, int64_t num_support, int num_neighbors, int in_channels,
+                         int out_channels, const void* weight_pieces, float* out, void* stream);
+size_t se3_kpconv_sums_bytes(int64_t num_queries, int in_channels);
+int se3_kpconv_so3_gather_sums(const float* x, const void* table, int64_t num_queries, int64_t num_support, int num_neighbors,
+                               int in_channels, void* sums, void* stream);
 int se3_kpconv_so3_contract_f16(const void* sums, const void* weight_pieces, int64_t num_queries, int in_channels, int out_channels,
                                 float* out, void* stream);
-
-/* Fused form (the default): KPConvInterSO3.forward (blocks_epn.py:454-546) as a neighbour-table launch + ONE kernel.  The table holds per
- * query point its valid neighbours (compacted; shadow / padded entries carry weight 0 in the reference, blocks_epn.py:471,377) and their 15
- * influence weights max(0, 1 - |s - q - kp_k| / sigma) (blocks_epn.py:520-533).  In the main kernel producer waves form the f16 hi / lo
- * orbit sums of a 16-point tile and channel chunk in LDS (neighbour list and weights through scalar loads) while consumer waves multiply
- * the previous chunk on the matrix cores: the operand never exists in HBM.  kernel_points_dev (15, 3) DEVICE; workspace:
- * se3_kpconv_neighbor_table_bytes bytes; weight_pieces from se3_kpconv_split_weights_f16; num_support * 6 * in_channels < 2^31. */
-size_t se3_kpconv_neighbor_table_bytes(int64_t num_queries, int num_neighbors);
-int se3_kpconv_so3_fused(const float* q_pts, const float* s_pts, const int64_t* idx, const float* x, const float* kernel_points_dev,
-                         float sigma, int64_t num_queries, int64_t num_support, int num_neighbors, int in_channels, int out_channels,
-                         const void* weight_pieces, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- D1/D2: RPE self attention (RPEMultiHeadAttention.forward) ------------------------------------------------------
  * Replaces geotransformer/modules/transformer/rpe_transformer.py:39-131 in two launches.

@@ -1,19 +1,22 @@
-// B1: E2PN anchor-group kernel-point convolution (KPConvInterSO3), contraction stage on the f16 matrix cores at f32 accuracy.
+// B1: E2PN anchor-group kernel-point convolution (KPConvInterSO3) on the matrix cores at f32 accuracy -- gather AND contraction.
 //
-// Reference: geotransformer/modules/e2pn/blocks_epn.py:454-546 (forward) with the weight permutation tables of :228-332:
+// Reference: geotransformer/modules/e2pn/blocks_epn.py:334-390 (feat_gather_by_perm), :454-546 (forward), weight tables :228-332:
 //   out[p, r, d] = sum_{(s, t), c} G[p, r, (s, t), c] W[s, t, c, d],      G[p, r, (s, t), c] = H[p, orbit(s, r), anchor(t, r), c]
-// with the orbit sums H of csrc/kpconv_sums.h (16 kernel-point sums x 6 anchors per point and channel, formed and split by the producer:
-// csrc/kpconv_so3.hip).  Round 2's contraction rebuilt every G fragment per output anchor inside the K loop (1 or 4 LDS row reads, adds,
-// a three-way bf16 split: 2.6 vector instructions per MFMA, matrix pipe 34 % busy).  Here the K loop holds NO arithmetic besides the MFMAs:
-//   * operands are two f16 pieces each (x = hi + lo, 22 significant bits; the weights are scaled by a power of two so that their lo pieces
-//     stay normal numbers) and the three products hi hi + hi lo + lo hi accumulate in f32: error 2^-22 per term, below the f32 GEMM's own
-//     accumulation error (tests/test_gpu_ops.py::test_kpconv_matrix_core_path_has_f32_accuracy) -- 3 MFMAs where the bf16 form took 6;
-//   * a workgroup owns a 16-point tile = 96 output rows = three 32-row tiles (anchor pairs) of v_mfma_f32_32x32x16_f16 and, per wave, one
-//     32-column tile: a wave's K16-step (2 weight slots x 8 channels) is 6 ds_read_b128 (A: the H tile image in LDS, read in place through
-//     a 72-entry offset table), 2 global loads (B: weight fragments in lane order, requested a step ahead, L1 / L2 resident) and 9 MFMAs;
-//   * the row order inside a 32-row tile is chosen so that every 16-lane group of a ds_read_b128 reads ONE run of 16 different points:
-//     conflict-free with the odd row stride of the image.
-// Layers with fewer than 4 column tiles split the K16-steps of a chunk over the waves instead (sums merged through LDS at the end).
+//   H[p, o, a, c] = sum_n hw[p, n, o] x[idx[p, n], a, c],                  hw[p, n, o] = sum_{k in orbit o} max(0, 1 - |s_n - q_p - kp_k| / sigma)
+// with the 16 kernel-point orbits of csrc/kpconv_sums.h.  Three stages, all MFMA:
+//   1. kpconv_neighbor_table_kernel: per query point its VALID neighbours (compacted) and their 16 orbit weights hw (64 B per neighbour).
+//   2. gather: per point and 16 input channels H = hw^T x is a (16 orbits x n) . (n x 96 columns) product: v_mfma_f32_16x16x4_f32 (exact f32
+//      FMA chains) with the orbit weights as A and the gathered rows as B operand -- vector loads only (the round's first forms, 15 FMAs per
+//      gathered element on the vector ALUs with the weights in LDS or, wave-uniform, in SGPRs through scalar loads, were bound by LDS reads
+//      and by the scalar-load round trip per 6 rows that the SGPR file allows).  The result is split ONCE into f16 hi + lo pieces.
+//   3. contraction: v_mfma_f32_32x32x16_f16, three products hi hi + hi lo + lo hi accumulated in f32 (2^-22 per term, below the f32 GEMM's own
+//      accumulation error; the weights are scaled by a power of two so that their lo pieces stay normal numbers).  The K loop holds nothing
+//      but ds_read_b128 (A: the tile image in LDS, read in place through a 72-entry offset table), weight-fragment loads (B: lane order, L1 /
+//      L2 resident, requested ahead) and MFMAs.  A workgroup owns a 16-point tile = 96 output rows = three 32-row tiles (anchor pairs); the
+//      row order inside a 32-row tile is chosen so that every 16-lane group of a ds_read_b128 reads ONE run of 16 different points:
+//      conflict-free with the odd row stride of the image.
+// Fused form (default): stages 2 and 3 in ONE kernel, producer waves filling the image of chunk t + 1 in LDS while consumer waves multiply
+// chunk t: H never exists in HBM.  Two-launch form (se3_kpconv_so3_gather_sums + se3_kpconv_so3_contract_f16): the images go through HBM.
 #include "common.h"
 #include "kpconv_sums.h"
 
@@ -23,6 +26,7 @@ using namespace kpsum;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;      // (an array of HIP uint4 structs ends up in scratch)
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 #ifdef SE3_KPCONV_STAMPS      // diagnostic build of tools/micro/kpconv_stamps.hip only: wave time stamps of the first workgroups
 __device__ long long* g_stamps = nullptr;
@@ -34,7 +38,7 @@ constexpr int kStampBlocks = 64, kStampSteps = 40, kStampSlots = 6;
 #define SE3_STAMP(step_, slot_)
 #endif
 
-constexpr int kTile4 = kTileB / 16;          // uint4 per tile image (3104)
+constexpr int kTile4 = kTileB / 16;          // uint4 per tile image (3109)
 constexpr int kHeaderB = 256;                // weight-fragment buffer: [header: 1 / scale, max |W| bits][fragments]
 
 // ---- weights: (36 Cin, Cout) f32 -> f16 hi / lo fragments [chunk][K16-step][column tile][piece][lane] x 16 B, scaled by a power of two ----
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(64 * NCW * KS) void kpconv_mfma_kernel(const u32x4*
     tab[e] = v;
   }
   const int i32 = lane & 31, h = lane >> 5;
-  const int a_base = row_point(i32) * kRowB;                           // + piece * kTP * kRowB + run * 16
+  const int a_base = row_point(i32) * kRowB;                           // + piece * kPieceB + run * 16
   const int tab_lane = row_rsel(i32) * 2 + h;
   f32x16 acc[3];
 #pragma unroll
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(64 * NCW * KS) void kpconv_mfma_kernel(const u32x4*
       for (int rt = 0; rt < 3; rt++) {
         const int off = a_base + (int)((runs >> (8 * rt)) & 0xff) * 16;
         a[rt][0] = *reinterpret_cast<const f16x8*>(lds + off);
-        a[rt][1] = *reinterpret_cast<const f16x8*>(lds + off + kTP * kRowB);
+        a[rt][1] = *reinterpret_cast<const f16x8*>(lds + off + kPieceB);
       }
       const f16x8 b0 = __builtin_bit_cast(f16x8, bn0), b1 = __builtin_bit_cast(f16x8, bn1);
       {
@@ -191,26 +195,16 @@ __global__ __launch_bounds__(64 * NCW * KS) void kpconv_mfma_kernel(const u32x4*
 }
 
 
-// ======== fused form: the orbit sums never leave the compute unit ========================================================================
-// One 16-wave workgroup per compute unit and 16-point tile; the tile image exists twice in LDS (2 x 48.5 KB).  In phase t the PRODUCER
-// waves form the image of channel chunk t while the CONSUMER waves multiply chunk t - 1 out of the other buffer; one barrier per chunk.
-//   consumer waves (NCW x KS): the K loop -- ds_read_b128 of the image, weight fragments from L1 / L2 (a ring of three K16-steps in
-//     registers), MFMAs; no other arithmetic;
-//   producer waves (NPW): one POINT of the tile at a time, lane = (anchor a, channel c of the chunk) (48 of 64 lanes); the point's neighbour
-//     list and its 15 influence weights per neighbour come from a per-layer table (kpconv_neighbor_table_kernel) through SCALAR loads --
-//     they are uniform over the wave, so the inner loop is 1 vector load + 8 packed FMAs with SGPR-pair operands per neighbour, no LDS;
-//     then the 16 orbit sums, the f16 hi / lo split and a DPP exchange inside channel pairs so that every lane stores one dword per orbit.
-// The matrix pipe (consumers) and the vector ALUs (producers) of a SIMD are fed by different waves and overlap.
-
-// neighbour table of a layer: per query point the VALID neighbours compacted to the front (invalid ones carry weight 0 in the reference:
-// blocks_epn.py:471,377 shadow point / zero feature row), padded with (index 0, weights 0) up to a multiple of 24 (NNp)
+// ---- stage 1: neighbour table ------------------------------------------------------------------------------------------------------------
+// Per query point the VALID neighbours compacted to the front (invalid ones carry weight 0 in the reference: blocks_epn.py:471,377 shadow
+// point / zero feature row), padded with (index 0, weights 0) up to a multiple of 24 entries (NNp):
+//   hwt  [P][NNp][16] f32   orbit weights hw[o] = sum_{k in orbit o} max(0, 1 - |s - q - kp_k| / sigma)   (blocks_epn.py:520-533)
 //   nbr  [P][NNp] int32     support row of the j-th valid neighbour
-//   wts  [P][NNp][16] f32   w[k] = max(0, 1 - |s - q - kp_k| / sigma), k < 15; [15] = 0
 //   cnt  [P] int32          valid neighbours
 __global__ __launch_bounds__(64) void kpconv_neighbor_table_kernel(const float* __restrict__ q_pts, const float* __restrict__ s_pts,
                                                                    const int64_t* __restrict__ idx, int64_t Ns, int NN, int NNp,
-                                                                   const float* __restrict__ kp, float inv_sigma, int* __restrict__ nbr,
-                                                                   float* __restrict__ wts, int* __restrict__ cnt) {
+                                                                   const float* __restrict__ kp, float inv_sigma, float* __restrict__ hwt,
+                                                                   int* __restrict__ nbr, int* __restrict__ cnt) {
   __shared__ int order[64];
   const int64_t p = blockIdx.x;
   const int n = threadIdx.x;
@@ -222,31 +216,138 @@ __global__ __launch_bounds__(64) void kpconv_neighbor_table_kernel(const float* 
   __syncthreads();
   if (n == 0) cnt[p] = nv;
   for (int e = n; e < NNp; e += 64) {
-    float w[16];
+    float hw[kOrbits];
 #pragma unroll
-    for (int k = 0; k < 16; k++) w[k] = 0.f;
+    for (int o = 0; o < kOrbits; o++) hw[o] = 0.f;
     int row = 0;
     if (e < nv) {
       const int64_t js = idx[p * NN + order[e]];
       row = (int)js;
       const float qx = q_pts[3 * p], qy = q_pts[3 * p + 1], qz = q_pts[3 * p + 2];
       const float sx = s_pts[3 * js], sy = s_pts[3 * js + 1], sz = s_pts[3 * js + 2];
+      float w[kK];
 #pragma unroll
       for (int k = 0; k < kK; k++) {
         const float dx = sx - qx - kp[3 * k], dy = sy - qy - kp[3 * k + 1], dz = sz - qz - kp[3 * k + 2];
         w[k] = fmaxf(0.f, 1.f - sqrtf(dx * dx + dy * dy + dz * dz) * inv_sigma);
       }
+#pragma unroll
+      for (int o = 0; o < kOrbits; o++)
+#pragma unroll
+        for (int k = 0; k < kK; k++)
+          if ((kOrb.mask[o] >> k) & 1) hw[o] += w[k];
     }
     nbr[p * NNp + e] = row;
-    float4* dst = reinterpret_cast<float4*>(wts + (p * NNp + e) * 16);
+    float4* dst = reinterpret_cast<float4*>(hwt + (p * NNp + e) * 16);
 #pragma unroll
-    for (int q = 0; q < 4; q++) dst[q] = make_float4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    for (int q = 0; q < 4; q++) dst[q] = make_float4(hw[4 * q], hw[4 * q + 1], hw[4 * q + 2], hw[4 * q + 3]);
   }
 }
 
+// ---- stage 2: gather on the f32 matrix cores (one wave = one point x 16 channels) ---------------------------------------------------------
+// v_mfma_f32_16x16x4_f32: A[row = orbit l & 15][k = l >> 4] = hw[neighbour 4 j + (l >> 4)][orbit], B[k][col = l & 15] = x[that neighbour][a][c0 + col],
+// D[orbit 4 (l >> 4) + reg][col]: six column tiles (anchors) per point, one MFMA per 4 neighbours and anchor.
+constexpr int kGJ = 6;                       // groups of 4 neighbours per request round (24 neighbours)
+
+struct GatherOps {                            // operands of one request round of one wave
+  float aw[kGJ];                              // orbit weights (A)
+  float xb[kA][kGJ];                          // gathered feature values (B)
+};
+
+// neighbour numbers of round j0 (groups j0 .. j0 + 5) for this lane's k index g = lane >> 4
+__device__ __forceinline__ void gather_request_rows(const int* __restrict__ nbrow, int j0, int g, int (&nbv)[kGJ]) {
+#pragma unroll
+  for (int j = 0; j < kGJ; j++) nbv[j] = nbrow[4 * (j0 + j) + g];
+}
+__device__ __forceinline__ void gather_request_ops(const float* __restrict__ x, const float* __restrict__ hwrow, int j0, int g, int c16,
+                                                   const int (&nbv)[kGJ], unsigned rowlen, unsigned col, int Cin, GatherOps& q) {
+#pragma unroll
+  for (int j = 0; j < kGJ; j++) q.aw[j] = hwrow[(4 * (j0 + j) + g) * 16 + c16];
+#pragma unroll
+  for (int j = 0; j < kGJ; j++)
+#pragma unroll
+    for (int a = 0; a < kA; a++) q.xb[a][j] = x[(unsigned)nbv[j] * rowlen + (unsigned)(a * Cin) + col];
+}
+__device__ __forceinline__ void gather_multiply(const GatherOps& q, int jcount, f32x4 (&acc)[kA]) {      // jcount: groups of 4 with a valid neighbour (uniform)
+#pragma unroll
+  for (int j = 0; j < kGJ; j++) {
+    if (j < jcount) {
+#pragma unroll
+      for (int a = 0; a < kA; a++) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.aw[j], q.xb[a][j], acc[a], 0, 0, 0);
+    }
+  }
+}
+// f16 hi / lo split of the wave's 24 values per lane, channel pairs exchanged inside lane pairs: even lanes end up with the hi dword of
+// channels (c, c + 1), odd lanes with the lo dword of (c - 1, c); word[a][reg] belongs to run (a, orbit 4 g + reg)
+__device__ __forceinline__ void gather_split(const f32x4 (&acc)[kA], int odd, unsigned (&word)[kA][4]) {
+#pragma unroll
+  for (int a = 0; a < kA; a++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const float v = acc[a][r];
+      const _Float16 hi = (_Float16)v;
+      const _Float16 lo = (_Float16)(v - (float)hi);
+      const unsigned u = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+      const unsigned w2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0xB1, 0xf, 0xf, false);      // quad_perm [1, 0, 3, 2]: the pair's other lane
+      word[a][r] = odd ? ((w2 >> 16) | (u & 0xffff0000u)) : ((u & 0xffffu) | (w2 << 16));
+    }
+}
+
+// two-launch form: the images go to HBM.  One workgroup = one point x up to four channel pairs (one wave each); the rows are staged in
+// wave-private LDS and leave as 16-byte stores.
+constexpr int kStageRow[4] = {0, 392, 836, 1228};      // dword offsets of the (half, piece) rows of a wave's staging block: 4 banks apart
+constexpr int kStageDw = 1228 + 384;
+__global__ __launch_bounds__(256) void kpconv_orbit_gather_kernel(const float* __restrict__ x, const float* __restrict__ hwt,
+                                                                   const int* __restrict__ nbr, const int* __restrict__ cnt, int NNp,
+                                                                   int64_t tiles, int Cin, unsigned char* __restrict__ Hs) {
+  __shared__ __align__(16) unsigned stage[4][kStageDw];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15, odd = c16 & 1, half = c16 >> 3;
+  const int64_t p = blockIdx.x;
+  const int T = blockIdx.y * 4 + wave, chunks = Cin / kCC;
+  if (2 * T >= chunks) return;
+  const bool has2 = 2 * T + 1 < chunks;
+  const unsigned rowlen = (unsigned)(kA * Cin), col = (unsigned)(T * 16 + (has2 || half == 0 ? c16 : c16 - 8));
+  const int nv = cnt[p];
+  const int* nbrow = nbr + p * NNp;
+  const float* hwrow = hwt + p * NNp * 16;
+  f32x4 acc[kA];
+#pragma unroll
+  for (int a = 0; a < kA; a++) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int j0 = 0; 4 * j0 < nv; j0 += kGJ) {
+    int nbv[kGJ];
+    GatherOps q;
+    gather_request_rows(nbrow, j0, g, nbv);
+    gather_request_ops(x, hwrow, j0, g, c16, nbv, rowlen, col, Cin, q);
+    gather_multiply(q, (nv + 3) / 4 - j0, acc);
+  }
+  unsigned word[kA][4];
+  gather_split(acc, odd, word);
+  unsigned* st = stage[wave];
+  const int cpair = (c16 & 7) >> 1;
+#pragma unroll
+  for (int a = 0; a < kA; a++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) st[kStageRow[half * 2 + odd] + (a * 16 + 4 * g + r) * 4 + cpair] = word[a][r];
+  // (wave-private staging block: the LDS operations of a wave complete in order, no barrier)
+  for (int e = lane; e < 4 * 96; e += 64) {
+    const int row = e / 96, q4 = e - row * 96, hf = row >> 1, piece = row & 1;
+    if (hf == 1 && !has2) continue;
+    unsigned char* dst = Hs + ((int64_t)(2 * T + hf) * tiles + (p >> 4)) * kTileB + (size_t)piece * kPieceB + (size_t)(p & 15) * kRowB;
+    reinterpret_cast<u32x4*>(dst)[q4] = *reinterpret_cast<const u32x4*>(st + kStageRow[row] + q4 * 4);
+  }
+}
+
+// ---- fused form: stages 2 and 3 in one kernel ------------------------------------------------------------------------------------------
+// One 11- or 12-wave workgroup per compute unit and 16-point tile; three tile images in LDS (3 x 48.6 KB).
+// Schedule: step u = 0 .. chunks + 1, one barrier between steps.  CONSUMER waves multiply chunk u - 2 (image (u - 2) % 3) in step u >= 2.
+// A PRODUCER wave (8 of them) handles ONE point per step over a PAIR of chunks (16 channels): in step u = 2T its first point, in step 2T + 1 its
+// second, for chunks (2T, 2T + 1).  Only one image besides the one being filled is free for writing while three exist, so rows of chunk 2T go
+// to image (2T) % 3 at once, while rows of chunk 2T + 1 computed in step 2T wait in registers for one step (image (2T + 1) % 3 is still being
+// read during step 2T).  All operands of step u + 1 (neighbour numbers, orbit weights, 36 gathered values per lane) are requested during step
+// u: the producers' memory latency (two dependent round trips, 1-3 us each under load) is off the critical path.
 template <int NCW, int KS, int CT>      // consumer waves: NCW column groups x KS K-split groups; CT column tiles (32 columns) per wave
 __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
-    const float* __restrict__ x, const int* __restrict__ nbr, const float* __restrict__ wts, const int* __restrict__ cnt, int NNp,
+    const float* __restrict__ x, const float* __restrict__ hwt, const int* __restrict__ nbr, const int* __restrict__ cnt, int NNp,
     const u32x4* __restrict__ Wf, const float* __restrict__ hdr, int64_t P, int Cin, int Cout, float* __restrict__ out) {
   constexpr int NC = NCW * KS;                                         // consumer waves
   constexpr int NPW = 8;                                               // producer waves: two points of the tile each
@@ -268,102 +369,87 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
     }
     tab[e] = v;
   }
-  // Schedule: step u = 0 .. chunks + 1, one barrier between steps.  Consumers multiply chunk u - 2 (image (u - 2) % 3) in step u >= 2.
-  // A producer wave handles ONE point per step over a PAIR of chunks (16 channels: lane = anchor x channel pair, 8-byte loads, whole
-  // 64-byte sectors): in step u = 2T its first point, in step 2T + 1 its second, for chunks (2T, 2T + 1).  Only one image is free for
-  // writing besides the one being filled while three exist, so rows of chunk 2T go to image (2T) % 3 at once, while rows of chunk 2T + 1
-  // computed in step 2T wait in registers for one step (image (2T + 1) % 3 is still being read during step 2T).
   const int steps_total = chunks + 2;
   if (wave >= NC) {
     // ---------------- producer ----------------
-    // The gather is bound by the bytes in flight per compute unit (random 64-byte sectors out of L2 / Infinity Cache): 24 neighbour rows
-    // are requested per wave before the first is used (8 waves x 24 x 384 B = 72 KB in flight).
     const int pw = wave - NC;
-    const int a = lane < 48 ? lane >> 3 : 5, cp = lane & 7, half = cp >> 2;    // channel pair cp of the 16: chunk half, channels 2 (cp & 3) + {0, 1}
-    const unsigned col0 = (unsigned)(a * Cin + 2 * cp);                  // + pair * 16
+    const int g = lane >> 4, c16 = lane & 15, odd = c16 & 1, half = c16 >> 3, cpair = (c16 & 7) >> 1;
     const unsigned rowlen = (unsigned)(kA * Cin);
-    const int dst0 = a * 16 + (cp & 3) * 4;                               // byte offset of the lane's hi dword inside a point's row (+ o * 96; lo: + kTP * kRowB)
-    unsigned held[2 * kOrbits];
+    // byte offset of this lane's dword of (anchor 0, orbit 4 g) inside its image (+ point * kRowB + (a * 16 + reg) * 16)
+    const int dst0 = odd * kPieceB + g * 64 + cpair * 4;
+    unsigned held[kA][4];
 #pragma unroll
-    for (int o = 0; o < 2 * kOrbits; o++) held[o] = 0u;
+    for (int a = 0; a < kA; a++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) held[a][r] = 0u;
+    // operands of the step about to run, requested one step ahead
+    GatherOps ops;
+    int nv_cur = 0;
+    const int64_t plast = P - 1;
+    auto point_of = [&](int u) { return p0 + pw + NPW * (u & 1); };
+    auto col_of = [&](int u) {                                          // first of this lane's columns in step u (odd chunk count: the upper half re-reads the lower one)
+      const int T = u >> 1;
+      return (unsigned)(T * 16 + ((2 * T + 1 < chunks || half == 0) ? c16 : c16 - 8));
+    };
+    {
+      const int64_t p = point_of(0), pc = p < P ? p : plast;
+      int nbv[kGJ];
+      gather_request_rows(nbr + pc * NNp, 0, g, nbv);
+      nv_cur = p < P ? cnt[pc] : 0;
+      gather_request_ops(x, hwt + pc * NNp * 16, 0, g, c16, nbv, rowlen, col_of(0), Cin, ops);
+    }
     for (int u = 0; u < steps_total; u++) {
       SE3_STAMP(u, 0)
       if (u < 2 * pairs) {
         const int T = u >> 1, second = u & 1;
         const int i = pw + NPW * second;                                  // point of the tile, uniform over the wave
-        const int64_t p = p0 + i;
+        const int64_t p = p0 + i, pc = p < P ? p : plast;
         const bool has2 = 2 * T + 1 < chunks;                             // (odd chunk count: the last pair is a single chunk)
-        unsigned char* img_lo = lds + ((2 * T) % 3) * kTileB;
-        unsigned char* img_hi = lds + ((2 * T + 1) % 3) * kTileB;
-        const bool active = lane < 48 && (half == 0 || has2);
-        if (second && half == 1 && active) {                              // the first point's rows of chunk 2T + 1, held since the last step
-          unsigned char* dst = img_hi + pw * kRowB + dst0;
+        unsigned char* img_a = lds + ((2 * T) % 3) * kTileB;
+        unsigned char* img_b = lds + ((2 * T + 1) % 3) * kTileB;
+        if (second && half == 1 && has2) {                                // the first point's rows of chunk 2T + 1, held since the last step
+          unsigned char* dst = img_b + pw * kRowB + dst0;
 #pragma unroll
-          for (int o = 0; o < kOrbits; o++) {
-            *reinterpret_cast<unsigned*>(dst + o * (kA * 16)) = held[2 * o];
-            *reinterpret_cast<unsigned*>(dst + o * (kA * 16) + kTP * kRowB) = held[2 * o + 1];
-          }
-        }
-        float f0[kK], f1[kK];
+          for (int a = 0; a < kA; a++)
 #pragma unroll
-        for (int k = 0; k < kK; k++) f0[k] = f1[k] = 0.f;
-        if (p < P) {
-          const int nv = cnt[p];
-          const int* nb = nbr + p * NNp;
-          const float* wr = wts + p * NNp * 16;
-          const float* xc = x + T * 16 + (active ? col0 : 0u);
-          // rotating prefetch, three batches of 8 neighbour rows deep: the requests of batch b + 3 leave right behind the FMAs of batch b.
-          // All requests are unconditional (batch numbers clamped into the table row, whose tail is index 0 / weight 0) and at the top
-          // level of the loop body: hipcc sinks a load into the branch that uses it, which would serialise request and use.
-          const int nbat = (nv + 7) >> 3, lastb = NNp / 8 - 1;
-          SE3_STAMP(u, 1)
-          float2 xa[8], xb[8], xc8[8];
-#define SE3_REQ(dst_, b_)                                                                                     \
-  {                                                                                                           \
-    const int bb_ = (b_) < lastb ? (b_) : lastb;                                                              \
-    _Pragma("unroll") for (int q = 0; q < 8; q++) dst_[q] = *reinterpret_cast<const float2*>(xc + (unsigned)nb[bb_ * 8 + q] * rowlen); \
-  }
-#define SE3_FMA(src_, b_)                                                                                     \
-  _Pragma("unroll") for (int q = 0; q < 8; q++) _Pragma("unroll") for (int k = 0; k < kK; k++) {              \
-    const float w = wr[((b_) * 8 + q) * 16 + k];                                                              \
-    f0[k] = fmaf(w, src_[q].x, f0[k]);                                                                        \
-    f1[k] = fmaf(w, src_[q].y, f1[k]);                                                                        \
-  }
-          SE3_REQ(xa, 0) SE3_REQ(xb, 1) SE3_REQ(xc8, 2)
-          for (int b = 0; b < nbat; b += 3) {
-            SE3_FMA(xa, b)
-            SE3_REQ(xa, b + 3)
-            if (b + 1 < nbat) { SE3_FMA(xb, b + 1) }
-            SE3_REQ(xb, b + 4)
-            if (b + 2 < nbat) { SE3_FMA(xc8, b + 2) }
-            SE3_REQ(xc8, b + 5)
-          }
-#undef SE3_REQ
-#undef SE3_FMA
+            for (int r = 0; r < 4; r++) *reinterpret_cast<unsigned*>(dst + (a * 16 + r) * 16) = held[a][r];
         }
+        // neighbour numbers and count of the NEXT step's point: in flight while this step multiplies
+        const bool more = u + 1 < 2 * pairs;
+        const int64_t pn = point_of(u + 1), pnc = pn < P ? pn : plast;
+        int nbn[kGJ];
+        gather_request_rows(nbr + pnc * NNp, 0, g, nbn);
+        const int nv_next = (more && pn < P) ? cnt[pnc] : 0;
+        SE3_STAMP(u, 1)
+        f32x4 acc[kA];
+#pragma unroll
+        for (int a = 0; a < kA; a++) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nv = __builtin_amdgcn_readfirstlane(nv_cur);
+        gather_multiply(ops, (nv + 3) / 4, acc);
+        for (int j0 = kGJ; 4 * j0 < nv; j0 += kGJ) {                      // more than 24 valid neighbours: further rounds, requested on the spot
+          int nbv[kGJ];
+          GatherOps q;
+          gather_request_rows(nbr + pc * NNp, j0, g, nbv);
+          gather_request_ops(x, hwt + pc * NNp * 16, j0, g, c16, nbv, rowlen, col_of(u), Cin, q);
+          gather_multiply(q, (nv + 3) / 4 - j0, acc);
+        }
+        // the next step's operands leave now (their neighbour numbers have arrived behind the MFMAs)
+        gather_request_ops(x, hwt + pnc * NNp * 16, 0, g, c16, nbn, rowlen, col_of(more ? u + 1 : u), Cin, ops);
+        nv_cur = nv_next;
         SE3_STAMP(u, 2)
-        unsigned char* dst = (half ? img_hi : img_lo) + i * kRowB + dst0;
-        const bool store_now = active && (half == 0 || second);
+        unsigned word[kA][4];
+        gather_split(acc, odd, word);
+        unsigned char* dst = (half ? img_b : img_a) + i * kRowB + dst0;
+        if (half == 0 || (second && has2)) {
 #pragma unroll
-        for (int o = 0; o < kOrbits; o++) {
-          float v0 = 0.f, v1 = 0.f;
+          for (int a = 0; a < kA; a++)
 #pragma unroll
-          for (int k = 0; k < kK; k++)
-            if ((kOrb.mask[o] >> k) & 1) {
-              v0 += f0[k];
-              v1 += f1[k];
-            }
-          const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
-          const _Float16 l0 = (_Float16)(v0 - (float)h0), l1 = (_Float16)(v1 - (float)h1);
-          const unsigned hi = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-          const unsigned lo = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
-          if (store_now) {
-            *reinterpret_cast<unsigned*>(dst + o * (kA * 16)) = hi;
-            *reinterpret_cast<unsigned*>(dst + o * (kA * 16) + kTP * kRowB) = lo;
-          }
-          held[2 * o] = hi;
-          held[2 * o + 1] = lo;
+            for (int r = 0; r < 4; r++) *reinterpret_cast<unsigned*>(dst + (a * 16 + r) * 16) = word[a][r];
         }
+#pragma unroll
+        for (int a = 0; a < kA; a++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) held[a][r] = word[a][r];
       }
       SE3_STAMP(u, 3)
       if (u + 1 < steps_total) __syncthreads();
@@ -379,7 +465,7 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
   const int cw = wave % NCW, ksp = wave / NCW;
   const int NCT = Cout / 32, ct0 = (blockIdx.y * NCW + cw) * CT;
   const int i32 = lane & 31, h = lane >> 5;
-  const int a_base = row_point(i32) * kRowB;                           // + piece * kTP * kRowB + run * 16
+  const int a_base = row_point(i32) * kRowB;                           // + piece * kPieceB + run * 16
   const int tab_lane = row_rsel(i32) * 2 + h;
   f32x16 acc[CT][3];
 #pragma unroll
@@ -395,12 +481,12 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
   u32x4 bq[2][CT][2];
 #pragma unroll
   for (int j = 0; j < 2; j++) {
-    int64_t g = ksp + j * KS;
-    g = g < last_step ? g : last_step;
+    int64_t gs = ksp + j * KS;
+    gs = gs < last_step ? gs : last_step;
 #pragma unroll
     for (int n = 0; n < CT; n++) {
-      bq[j][n][0] = wbase[g * wstep + n * 128];
-      bq[j][n][1] = wbase[g * wstep + n * 128 + 64];
+      bq[j][n][0] = wbase[gs * wstep + n * 128];
+      bq[j][n][1] = wbase[gs * wstep + n * 128 + 64];
     }
   }
   __syncthreads();                                                      // steps 0 and 1: nothing to multiply yet
@@ -416,7 +502,7 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
       for (int rt = 0; rt < 3; rt++) {
         const int off = a_base + (int)((runs >> (8 * rt)) & 0xff) * 16;
         av[0][rt][0] = *reinterpret_cast<const f16x8*>(img + off);
-        av[0][rt][1] = *reinterpret_cast<const f16x8*>(img + off + kTP * kRowB);
+        av[0][rt][1] = *reinterpret_cast<const f16x8*>(img + off + kPieceB);
       }
     }
 #pragma unroll 1
@@ -431,7 +517,7 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
           for (int rt = 0; rt < 3; rt++) {
             const int off = a_base + (int)((runs >> (8 * rt)) & 0xff) * 16;
             av[j ^ 1][rt][0] = *reinterpret_cast<const f16x8*>(img + off);
-            av[j ^ 1][rt][1] = *reinterpret_cast<const f16x8*>(img + off + kTP * kRowB);
+            av[j ^ 1][rt][1] = *reinterpret_cast<const f16x8*>(img + off + kPieceB);
           }
         }
         // smallest terms first; consecutive MFMAs go to different accumulators
@@ -454,12 +540,12 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
           for (int rt = 0; rt < 3; rt++) acc[n][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[j][rt][0], b0, acc[n][rt], 0, 0, 0);
         }
         {
-          int64_t g = (int64_t)cc * kSteps + st + 2 * KS;                // unconditional (clamped) so that the compiler can count the requests
-          g = g < last_step ? g : last_step;
+          int64_t gs = (int64_t)cc * kSteps + st + 2 * KS;               // unconditional (clamped) so that the compiler can count the requests
+          gs = gs < last_step ? gs : last_step;
 #pragma unroll
           for (int n = 0; n < CT; n++) {
-            bq[j][n][0] = wbase[g * wstep + n * 128];
-            bq[j][n][1] = wbase[g * wstep + n * 128 + 64];
+            bq[j][n][0] = wbase[gs * wstep + n * 128];
+            bq[j][n][1] = wbase[gs * wstep + n * 128 + 64];
           }
         }
       }
@@ -567,28 +653,66 @@ extern "C" size_t se3_kpconv_neighbor_table_bytes(int64_t num_queries, int num_n
   return (size_t)num_queries * nnp * (16 * sizeof(float) + sizeof(int)) + (size_t)num_queries * sizeof(int) + 256;
 }
 
-// One call = KPConvInterSO3.forward (blocks_epn.py:454-546): neighbour table, then the fused gather + contraction.  `workspace`:
-// se3_kpconv_neighbor_table_bytes bytes; weight_pieces from se3_kpconv_split_weights_f16.
-extern "C" int se3_kpconv_so3_fused(const float* q_pts, const float* s_pts, const int64_t* idx, const float* x,
-                                    const float* kernel_points_dev, float sigma, int64_t num_queries, int64_t num_support,
-                                    int num_neighbors, int in_channels, int out_channels, const void* weight_pieces, float* out,
-                                    void* workspace, size_t workspace_bytes, void* stream) {
-  SE3_REQUIRE(q_pts && s_pts && idx && x && kernel_points_dev && weight_pieces && out && workspace, SE3_ERR_INVALID_ARG,
-              "kpconv_so3_fused: null pointer");
+namespace {
+struct NeighborTable {
+  const float* hwt;
+  const int *nbr, *cnt;
+  int NNp;
+};
+NeighborTable table_views(const void* table, int64_t P, int NN) {
+  NeighborTable t;
+  t.NNp = (NN + 23) / 24 * 24;
+  t.hwt = static_cast<const float*>(table);
+  t.nbr = reinterpret_cast<const int*>(t.hwt + (size_t)P * t.NNp * 16);
+  t.cnt = t.nbr + (size_t)P * t.NNp;
+  return t;
+}
+}  // namespace
+
+extern "C" int se3_kpconv_neighbor_table(const float* q_pts, const float* s_pts, const int64_t* idx, const float* kernel_points_dev,
+                                         float sigma, int64_t num_queries, int64_t num_support, int num_neighbors, void* table,
+                                         size_t table_bytes, void* stream) {
+  SE3_REQUIRE(q_pts && s_pts && idx && kernel_points_dev && table, SE3_ERR_INVALID_ARG, "kpconv_neighbor_table: null pointer");
+  SE3_REQUIRE(num_neighbors >= 1 && num_neighbors <= 64 && sigma > 0.f, SE3_ERR_UNSUPPORTED, "kpconv_neighbor_table: %d neighbours (max 64)",
+              num_neighbors);
+  SE3_REQUIRE(num_support < (1ll << 31), SE3_ERR_UNSUPPORTED, "kpconv_neighbor_table: more than 2^31 support points");
+  SE3_REQUIRE(table_bytes >= se3_kpconv_neighbor_table_bytes(num_queries, num_neighbors), SE3_ERR_INVALID_ARG,
+              "kpconv_neighbor_table: table buffer too small");
+  if (num_queries == 0) return SE3_OK;
+  const NeighborTable t = table_views(table, num_queries, num_neighbors);
+  kpconv_neighbor_table_kernel<<<(unsigned)num_queries, 64, 0, (hipStream_t)stream>>>(
+      q_pts, s_pts, idx, num_support, num_neighbors, t.NNp, kernel_points_dev, 1.0f / sigma, const_cast<float*>(t.hwt),
+      const_cast<int*>(t.nbr), const_cast<int*>(t.cnt));
+  SE3_CHECK_LAUNCH("kpconv_neighbor_table");
+  return SE3_OK;
+}
+
+extern "C" int se3_kpconv_so3_gather_sums(const float* x, const void* table, int64_t num_queries, int64_t num_support, int num_neighbors,
+                                          int in_channels, void* sums, void* stream) {
+  SE3_REQUIRE(x && table && sums, SE3_ERR_INVALID_ARG, "kpconv_so3_gather_sums: null pointer");
+  SE3_REQUIRE(num_neighbors >= 1 && num_neighbors <= 64, SE3_ERR_UNSUPPORTED, "kpconv_so3_gather_sums: %d neighbours (max 64)", num_neighbors);
+  SE3_REQUIRE(in_channels >= 8 && in_channels % 8 == 0, SE3_ERR_UNSUPPORTED, "kpconv_so3_gather_sums: channels must be a multiple of 8");
+  SE3_REQUIRE((int64_t)num_support * kA * in_channels < (1ll << 31), SE3_ERR_UNSUPPORTED, "kpconv_so3_gather_sums: support features exceed 2^31 elements");
+  if (num_queries == 0) return SE3_OK;
+  const NeighborTable t = table_views(table, num_queries, num_neighbors);
+  const int pairs = (in_channels / kCC + 1) / 2, waves = pairs < 4 ? pairs : 4;
+  kpconv_orbit_gather_kernel<<<dim3((unsigned)num_queries, (unsigned)((pairs + 3) / 4)), 64 * waves, 0, (hipStream_t)stream>>>(
+      x, t.hwt, t.nbr, t.cnt, t.NNp, se3_cdiv(num_queries, kTP), in_channels, static_cast<unsigned char*>(sums));
+  SE3_CHECK_LAUNCH("kpconv_so3_gather_sums");
+  return SE3_OK;
+}
+
+// KPConvInterSO3.forward (blocks_epn.py:454-546) after se3_kpconv_neighbor_table: gather + contraction in one kernel.
+extern "C" int se3_kpconv_so3_fused(const float* x, const void* table, int64_t num_queries, int64_t num_support, int num_neighbors,
+                                    int in_channels, int out_channels, const void* weight_pieces, float* out, void* stream) {
+  SE3_REQUIRE(x && table && weight_pieces && out, SE3_ERR_INVALID_ARG, "kpconv_so3_fused: null pointer");
   SE3_REQUIRE(num_neighbors >= 1 && num_neighbors <= 64, SE3_ERR_UNSUPPORTED, "kpconv_so3_fused: %d neighbours (max 64)", num_neighbors);
-  SE3_REQUIRE(in_channels > 0 && in_channels % kCC == 0 && out_channels >= 32 && out_channels % 32 == 0 && sigma > 0.f, SE3_ERR_UNSUPPORTED,
+  SE3_REQUIRE(in_channels > 0 && in_channels % kCC == 0 && out_channels >= 32 && out_channels % 32 == 0, SE3_ERR_UNSUPPORTED,
               "kpconv_so3_fused: channels (%d, %d) must be multiples of (8, 32)", in_channels, out_channels);
   SE3_REQUIRE((int64_t)num_support * kA * in_channels < (1ll << 31), SE3_ERR_UNSUPPORTED, "kpconv_so3_fused: support features exceed 2^31 elements");
-  SE3_REQUIRE(workspace_bytes >= se3_kpconv_neighbor_table_bytes(num_queries, num_neighbors), SE3_ERR_INVALID_ARG,
-              "kpconv_so3_fused: workspace too small");
   if (num_queries == 0) return SE3_OK;
   hipStream_t st = (hipStream_t)stream;
-  const int NNp = (num_neighbors + 23) / 24 * 24;
-  float* wts = static_cast<float*>(workspace);
-  int* nbr = reinterpret_cast<int*>(wts + (size_t)num_queries * NNp * 16);
-  int* cnt = nbr + (size_t)num_queries * NNp;
-  kpconv_neighbor_table_kernel<<<(unsigned)num_queries, 64, 0, st>>>(q_pts, s_pts, idx, num_support, num_neighbors, NNp, kernel_points_dev,
-                                                                    1.0f / sigma, nbr, wts, cnt);
+  const NeighborTable t = table_views(table, num_queries, num_neighbors);
   const int NCT = out_channels / 32;
   const int64_t tiles = se3_cdiv(num_queries, kTP);
   const float* hdr = static_cast<const float*>(weight_pieces);
@@ -603,9 +727,9 @@ extern "C" int se3_kpconv_so3_fused(const float* q_pts, const float* s_pts, cons
       attr_set = true;                                                                                                              \
     }                                                                                                                               \
     kpconv_fused_kernel<NCW_, KS_, CT_><<<dim3((unsigned)tiles, (unsigned)(NCT / (NCW_ * CT_))), 64 * (NCW_ * KS_ + 8), lds, st>>>( \
-        x, nbr, wts, cnt, NNp, Wf, hdr, num_queries, in_channels, out_channels, out);                                               \
+        x, t.hwt, t.nbr, t.cnt, t.NNp, Wf, hdr, num_queries, in_channels, out_channels, out);                                       \
   }
-  // 12 waves per compute unit (3 per SIMD: 168 registers): 8 producers + 3 or 4 consumers
+  // 11 or 12 waves per compute unit (3 per SIMD: 168 registers): 8 producers + 3 or 4 consumers
   if (NCT % 8 == 0) SE3_FUSED(4, 1, 2)
   else if (NCT % 4 == 0) SE3_FUSED(4, 1, 1)
   else if (NCT % 2 == 0) SE3_FUSED(1, 3, 2)

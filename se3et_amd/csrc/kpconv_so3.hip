@@ -15,7 +15,6 @@
 // feature columns (a, c) (coalesced reads of the gathered rows), keeps the 15 per-kernel-point sums in registers and
 // writes its 36 slot sums.
 #include "common.h"
-#include "kpconv_sums.h"
 #include <stdlib.h>
 
 namespace {
@@ -42,8 +41,6 @@ __device__ constexpr int kBuiltinRidx[kA][kA] = {{0, 3, 3, 3, 3, 5}, {1, 0, 4, 5
 
 // MODE 1: leave the kernel-point sums F themselves for the round-2 matrix-core contraction (csrc/kpconv_contract.hip) in its tile order
 // [channel chunk of 8][point (padded to 16)][k * 6 + a][8 channels] instead of the 2.4x larger slot sums G.
-// MODE 2: leave the 16 orbit sums H (csrc/kpconv_sums.h), split into f16 hi / lo pieces, as the tile images csrc/kpconv_mfma.hip reads in place:
-// [channel chunk of 8][tile of 16 points][piece][point][(orbit, anchor) run of 8 channels x f16].
 template <bool BUILTIN, int MODE = 0, int FL = 8>      // FL: gathered rows in flight per thread (16 measured 10 % slower)
 __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restrict__ q_pts, const float* __restrict__ s_pts,
                                                             const int64_t* __restrict__ idx, const float* __restrict__ x,
@@ -52,7 +49,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
   __shared__ float w[kMaxNN][kK + 1];
   __shared__ int64_t nb[kMaxNN];
   __shared__ unsigned xrow[kMaxNN];      // element offset of the neighbour's feature row (clamped: invalid rows carry weight 0)
-  extern __shared__ __align__(16) float fstage[];      // MODE 1: the point's (Cin / 8) rows of kFRow floats; MODE 2: [chunk][piece][96 runs x 16 B]
+  extern __shared__ __align__(16) float fstage[];      // MODE 1: the point's (Cin / 8) rows of kFRow floats
   constexpr bool FOUT = MODE != 0;
   const int64_t p = blockIdx.x;
   const int cols = kA * Cin;
@@ -109,27 +106,6 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
         for (int k = 0; k < kK; k++) f[k] = fmaf(w[n0 + u][k], xv[u], f[k]);
       }
     }
-    if (MODE == 2) {
-      // the 16 orbit sums of this column, each split into f16 hi + lo; lane pairs (c, c + 1) exchange halves so that every lane
-      // stores one dword: even lanes the hi pieces of both channels, odd lanes the lo pieces
-      unsigned char* hrow = reinterpret_cast<unsigned char*>(fstage) + (size_t)((c - cb0) >> 3) * (2 * kpsum::kOrbits * kA * 16);
-      const int odd = c & 1;
-      unsigned char* dst = hrow + odd * (kpsum::kOrbits * kA * 16) + a * 16 + ((c & 7) - odd) * 2;
-#pragma unroll
-      for (int o = 0; o < kpsum::kOrbits; o++) {
-        float v = 0.f;
-#pragma unroll
-        for (int k = 0; k < kK; k++)
-          if ((kpsum::kOrb.mask[o] >> k) & 1) v += f[k];
-        const _Float16 hi = (_Float16)v;
-        const _Float16 lo = (_Float16)(v - (float)hi);
-        const unsigned u = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
-        const unsigned w2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0xB1, 0xf, 0xf, false);      // quad_perm [1, 0, 3, 2]: the pair's other lane
-        const unsigned word = odd ? ((w2 >> 16) | (u & 0xffff0000u)) : ((u & 0xffffu) | (w2 << 16));
-        *reinterpret_cast<unsigned*>(dst + o * (kA * 16)) = word;
-      }
-      continue;
-    }
     if (MODE == 1) {      // row of (point, channel chunk): 15 x 6 x 8 values, an 8-float zero slot, 4 pad = kFRow floats: staged in LDS, written below
       float* Fp = fstage + ((c - cb0) >> 3) * kFRow + a * 8 + (c & 7);
 #pragma unroll
@@ -155,19 +131,6 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
 #pragma unroll
       for (int sl = 0; sl < kS; sl++) __builtin_nontemporal_store(s[sl], &Gp[((int64_t)(r * kS + sl) * kA + t) * Cin + c]);
     }
-  }
-  if (MODE == 2) {   // the block's rows leave LDS as 1536-byte runs into the tile images
-    __syncthreads();
-    const int row4 = kpsum::kOrbits * kA;                // uint4 per (chunk, piece) row
-    unsigned char* Hb = reinterpret_cast<unsigned char*>(G);
-    const int64_t tiles = P16 / kpsum::kTP;
-    for (int e = threadIdx.x; e < (cw >> 3) * 2 * row4; e += blockDim.x) {
-      const int q = e % row4, piece = (e / row4) & 1, cc = e / (2 * row4);
-      uint4* drow = reinterpret_cast<uint4*>(Hb + ((int64_t)((cb0 >> 3) + cc) * tiles + (p >> 4)) * kpsum::kTileB +
-                                             (size_t)(piece * kpsum::kTP + (int)(p & 15)) * kpsum::kRowB);
-      drow[q] = reinterpret_cast<const uint4*>(fstage)[e];
-    }
-    __syncthreads();                                     // the next block overwrites the staging rows
   }
   if (MODE == 1) {   // zero slot + pad of every row, then the block's rows leave LDS as whole 2928-byte runs (float4 per lane; written as
                      // 4-byte scatters straight from the column threads each 192-byte run came from three different store instructions)
@@ -324,29 +287,6 @@ extern "C" int se3_kpconv_so3_gather_points(const float* q_pts, const float* s_p
   kpconv_gather_kernel<true, 1><<<(unsigned)num_queries, threads, stage_bytes, (hipStream_t)stream>>>(
       q_pts, s_pts, idx, x, T, 1.0f / sigma, num_queries, num_support, num_neighbors, in_channels, F, P16);
   SE3_CHECK_LAUNCH("kpconv_so3_gather_points");
-  return SE3_OK;
-}
-
-// Same gather, output = the f16 hi / lo orbit sums for se3_kpconv_so3_contract_f16 (tile images, csrc/kpconv_sums.h).
-extern "C" int se3_kpconv_so3_gather_sums(const float* q_pts, const float* s_pts, const int64_t* idx, const float* x,
-                                          const float* kernel_points_host, float sigma, int64_t num_queries, int64_t num_support,
-                                          int num_neighbors, int in_channels, void* sums, void* stream) {
-  SE3_REQUIRE(q_pts && s_pts && idx && x && kernel_points_host && sums, SE3_ERR_INVALID_ARG, "kpconv_so3_gather_sums: null pointer");
-  SE3_REQUIRE(num_neighbors >= 1 && num_neighbors <= kMaxNN, SE3_ERR_UNSUPPORTED,
-              "kpconv_so3_gather_sums: %d neighbours (max %d)", num_neighbors, kMaxNN);
-  SE3_REQUIRE(in_channels >= 8 && in_channels % 8 == 0 && sigma > 0.f, SE3_ERR_INVALID_ARG,
-              "kpconv_so3_gather_sums: channels must be a multiple of 8");
-  if (num_queries == 0) return SE3_OK;
-  ConvTables T = {};
-  for (int k = 0; k < kK; k++)
-    for (int d = 0; d < 3; d++) T.kp[k][d] = kernel_points_host[3 * k + d];
-  const int cols = kA * in_channels;
-  const int threads = cols >= 256 ? 256 : (cols >= 128 ? 128 : 64);
-  const int64_t P16 = (num_queries + 15) / 16 * 16;
-  const size_t stage_bytes = (size_t)((in_channels < 128 ? in_channels : 128) / 8) * 2 * kpsum::kOrbits * kA * 16;
-  kpconv_gather_kernel<true, 2><<<(unsigned)num_queries, threads, stage_bytes, (hipStream_t)stream>>>(
-      q_pts, s_pts, idx, x, T, 1.0f / sigma, num_queries, num_support, num_neighbors, in_channels, static_cast<float*>(sums), P16);
-  SE3_CHECK_LAUNCH("kpconv_so3_gather_sums");
   return SE3_OK;
 }
 

@@ -18,7 +18,9 @@ constexpr int kCC = 8;                         // channels per chunk (one 16-byt
 constexpr int kTP = 16;                        // points per tile
 constexpr int kRowB = (kOrbits * kA + 1) * 16; // bytes per (piece, point) row of a tile: 96 runs of 16 B + 16 B pad (odd number of 16-B
                                                // units: the 16 points of a b128 read fall into different bank quads)
-constexpr int kTileB = 2 * kTP * kRowB;        // one (channel chunk, point tile) image: [piece][point][row] = 49 664 B, the same in HBM and LDS
+constexpr int kPieceB = kTP * kRowB + 32;      // hi piece, 32 B, lo piece, 48 B: the lo piece sits 8 banks and the next image 4 banks further, so
+constexpr int kTileB = 2 * kPieceB + 16;       // that the producers' dword stores (hi / lo pieces of two images per instruction) spread over all banks
+                                               // one (channel chunk, point tile) image: [piece][point][row] = 49 744 B, the same in HBM and LDS
 constexpr int kSteps = kS * kA / 2;            // K16-steps per channel chunk: 2 weight slots x 8 channels
 
 // slot tables of the SE3ET configuration (se3et_amd/tables.py kernel_slot_table / anchor_slot_table)
@@ -65,7 +67,7 @@ constexpr OrbitTable make_orbits() {
 __device__ constexpr OrbitTable kOrb = make_orbits();
 static_assert(make_orbits().count == kOrbits, "the SE3ET slot tables have 16 distinct kernel-point orbits");
 
-// 16-byte run of (orbit, anchor) inside a point's row
-__host__ __device__ constexpr int run_of(int orbit, int a) { return orbit * kA + a; }
+// 16-byte run of (orbit, anchor) inside a point's row: anchor-major, so that the 16 orbits a producer wave holds for one anchor are contiguous
+__host__ __device__ constexpr int run_of(int orbit, int a) { return a * kOrbits + orbit; }
 
 }  // namespace kpsum

@@ -509,21 +509,22 @@ def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, s
         stream = _stream()
         Wp = _kpconv_weight_pieces(weights, Cin, Cout, stream)
         out = torch.empty((P, 6, Cout), dtype=torch.float32, device=x.device)
+        # neighbour table (valid neighbours + 16 orbit weights each), then ONE kernel in which producer waves form the f16 hi / lo orbit sums
+        # of a 16-point tile on the f32 matrix cores into LDS and consumer waves multiply them on the f16 matrix cores (csrc/kpconv_mfma.hip)
+        kpd = _req(kernel_points.detach().contiguous(), torch.float32, 'kernel_points', 2)
+        nbytes = lib().se3_kpconv_neighbor_table_bytes(P, NN)
+        tab = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+        check(lib().se3_kpconv_neighbor_table(q_pts.data_ptr(), s_pts.data_ptr(), idx.data_ptr(), kpd.data_ptr(), float(sigma), P, Ns, NN,
+                                              tab.data_ptr(), nbytes, stream), 'se3_kpconv_neighbor_table')
         if path == 'sums':
-            # two launches: f16 hi / lo orbit sums (P16, 16, 6, Cin) as tile images in HBM, then the MFMA contraction (kept for A/B runs)
+            # two launches: the orbit sums as tile images in HBM, then the contraction (kept for A/B runs)
             Hs = torch.empty((lib().se3_kpconv_sums_bytes(P, Cin),), dtype=torch.uint8, device=x.device)
-            check(lib().se3_kpconv_so3_gather_sums(q_pts.data_ptr(), s_pts.data_ptr(), idx.data_ptr(), x.data_ptr(), kp.data_ptr(),
-                                                   float(sigma), P, Ns, NN, Cin, Hs.data_ptr(), stream), 'se3_kpconv_so3_gather_sums')
+            check(lib().se3_kpconv_so3_gather_sums(x.data_ptr(), tab.data_ptr(), P, Ns, NN, Cin, Hs.data_ptr(), stream),
+                  'se3_kpconv_so3_gather_sums')
             check(lib().se3_kpconv_so3_contract_f16(Hs.data_ptr(), Wp.data_ptr(), P, Cin, Cout, out.data_ptr(), stream),
                   'se3_kpconv_so3_contract_f16')
             return out
-        # fused: neighbour table (valid neighbours + influence weights), then ONE kernel in which producer waves form the f16 hi / lo orbit
-        # sums of a 16-point tile in LDS and consumer waves multiply them on the matrix cores (csrc/kpconv_mfma.hip)
-        kpd = _req(kernel_points.detach().contiguous(), torch.float32, 'kernel_points', 2)
-        nbytes = lib().se3_kpconv_neighbor_table_bytes(P, NN)
-        ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
-        check(lib().se3_kpconv_so3_fused(q_pts.data_ptr(), s_pts.data_ptr(), idx.data_ptr(), x.data_ptr(), kpd.data_ptr(), float(sigma),
-                                         P, Ns, NN, Cin, Cout, Wp.data_ptr(), out.data_ptr(), ws.data_ptr(), nbytes, stream),
+        check(lib().se3_kpconv_so3_fused(x.data_ptr(), tab.data_ptr(), P, Ns, NN, Cin, Cout, Wp.data_ptr(), out.data_ptr(), stream),
               'se3_kpconv_so3_fused')
         return out
     G = torch.empty((P * 6, 36 * Cin), dtype=torch.float32, device=x.device)

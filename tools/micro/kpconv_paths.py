@@ -42,15 +42,17 @@ for qs, ss, tab, C in calls:
     from se3et_amd._lib import lib, check
     P, NN = idx.shape; st = ops._stream()
     Hs = torch.empty((lib().se3_kpconv_sums_bytes(P, C),), dtype=torch.uint8, device=dev)
-    kph = kp.cpu().contiguous()
     Wp = ops._kpconv_weight_pieces(w, C, C, st)
     out = torch.empty((P, 6, C), device=dev)
-    t_g = timeit(lambda: check(lib().se3_kpconv_so3_gather_sums(q.data_ptr(), s.data_ptr(), idx.data_ptr(), x.data_ptr(), kph.data_ptr(), float(sig), P, s.shape[0], NN, C, Hs.data_ptr(), st), 'g'))
+    nb = lib().se3_kpconv_neighbor_table_bytes(P, NN); tabl = torch.empty((nb,), dtype=torch.uint8, device=dev)
+    t_t = timeit(lambda: check(lib().se3_kpconv_neighbor_table(q.data_ptr(), s.data_ptr(), idx.data_ptr(), kp.data_ptr(), float(sig), P, s.shape[0], NN, tabl.data_ptr(), nb, st), 't'))
+    t_g = timeit(lambda: check(lib().se3_kpconv_so3_gather_sums(x.data_ptr(), tabl.data_ptr(), P, s.shape[0], NN, C, Hs.data_ptr(), st), 'g'))
     t_c = timeit(lambda: check(lib().se3_kpconv_so3_contract_f16(Hs.data_ptr(), Wp.data_ptr(), P, C, C, out.data_ptr(), st), 'c'))
+    t_f = timeit(lambda: check(lib().se3_kpconv_so3_fused(x.data_ptr(), tabl.data_ptr(), P, s.shape[0], NN, C, C, Wp.data_ptr(), out.data_ptr(), st), 'f'))
     err = float((out - torch.mm(ops.kpconv_slot_sums(x, q, s, idx, kp, kidx, ridx, sig), w.reshape(36 * C, C)).view(P, 6, C)).abs().max() / out.abs().max())
     gf = 2.0 * 6 * q.shape[0] * 36 * C * C / 1e9
     ops.KPCONV_MATRIX_CORE = True; outf = SF.kpconv_inter_so3(x, q, s, idx, kp, w, kidx, ridx, sig); ops.KPCONV_MATRIX_CORE = 'auto'
     errf = float((outf - torch.mm(ops.kpconv_slot_sums(x, q, s, idx, kp, kidx, ridx, sig), w.reshape(36 * C, C)).view(P, 6, C)).abs().max() / outf.abs().max())
-    print('P %6d NN %2d C %3d  gemm %.3f ms  sums %.3f ms (gather %.3f + contract %.3f)  fused %.3f ms (%.0f GF: %.0f TF/s f32-equivalent, %.2f PF/s f16)  err %.1e / %.1e'
-          % (q.shape[0], idx.shape[1], C, res['old'], res['sums'], t_g, t_c, res['new'], gf, gf / res['new'], 3 * gf / res['new'] / 1e3, err, errf))
+    print('P %6d NN %2d C %3d  gemm %.3f ms  sums %.3f ms (table %.3f + gather %.3f + contract %.3f)  fused %.3f ms (kernel %.3f) (%.0f GF: %.0f TF/s f32-equivalent, %.2f PF/s f16)  err %.1e / %.1e'
+          % (q.shape[0], idx.shape[1], C, res['old'], res['sums'], t_t, t_g, t_c, res['new'], t_f, gf, gf / res['new'], 3 * gf / res['new'] / 1e3, err, errf))
 print('total gemm %.2f ms  sums %.2f ms  fused %.2f ms per 8 pairs' % (tot['old'], tot['sums'], tot['new']))

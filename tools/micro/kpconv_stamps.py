@@ -1,5 +1,5 @@
 """Where the waves of the fused KPConv kernel spend a step (diagnostic build with s_memtime stamps): python tools/micro/kpconv_stamps.py <layer 0..9>
-Producer slots: 0 step start, 1 neighbour count known, 2 neighbour loop done, 3 rows stored, 4 barrier left.  Consumer: 0 chunk start, 3 MFMAs issued, 4 barrier left."""
+Producer slots: 0 step start, 1 next point's rows requested, 2 MFMAs + next operands requested, 3 rows split and stored, 4 barrier left.  Consumer: 0 chunk start, 3 MFMAs issued, 4 barrier left."""
 import ctypes, os, sys; R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R)
 import numpy as np, torch
 from se3et_amd import ops, tables, _lib
@@ -28,12 +28,14 @@ Wp = ops._kpconv_weight_pieces(w, C, C, ops._stream())
 out = torch.empty((P, 6, C), device=dev)
 nbytes = _lib.lib().se3_kpconv_neighbor_table_bytes(P, NN)
 ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+_lib.check(_lib.lib().se3_kpconv_neighbor_table(q.data_ptr(), s.data_ptr(), idx.data_ptr(), kp.data_ptr(), float(sig), P, s.shape[0], NN, ws.data_ptr(), nbytes, None), 'table')
 stamps = torch.zeros((64, 16, 40, 6), dtype=torch.int64, device=dev)
-L.se3_kpconv_so3_fused.argtypes = [vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_size_t, vp]
+L.se3_kpconv_so3_fused.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]
 L.se3_debug_kpconv_set_stamps.argtypes = [vp]
 assert L.se3_debug_kpconv_set_stamps(stamps.data_ptr()) == 0
+torch.cuda.synchronize()
 for _ in range(3):
-    rc = L.se3_kpconv_so3_fused(q.data_ptr(), s.data_ptr(), idx.data_ptr(), x.data_ptr(), kp.data_ptr(), float(sig), P, s.shape[0], NN, C, C, Wp.data_ptr(), out.data_ptr(), ws.data_ptr(), nbytes, None)
+    rc = L.se3_kpconv_so3_fused(x.data_ptr(), ws.data_ptr(), P, s.shape[0], NN, C, C, Wp.data_ptr(), out.data_ptr(), None)
     assert rc == 0
 torch.cuda.synchronize()
 st = stamps.cpu().numpy().astype(np.float64)
@@ -45,7 +47,7 @@ ok = prod[..., 0] > 0
 def seg(a, i, j, m): d = (a[..., j] - a[..., i])[m]; return d.mean(), np.percentile(d, 90)
 act = ok & (prod[..., 2] > 0) & (prod[..., 1] > 0)
 print('layer %d: P %d C %d, %d chunks; ticks of s_memtime (100 MHz realtime? -> treat as cycles of the shader clock)' % (layer, P, C, chunks))
-for name, i, j in (('count known', 0, 1), ('neighbour loop', 1, 2), ('orbit sums + split + stores', 2, 3), ('barrier wait', 3, 4)):
+for name, i, j in (('held rows + next requests', 0, 1), ('gather MFMAs', 1, 2), ('split + stores', 2, 3), ('barrier wait', 3, 4)):
     m, p90 = seg(prod, i, j, act & (prod[..., j] > 0)); print('  producer %-30s mean %8.0f  p90 %8.0f' % (name, m, p90))
 m, p90 = seg(prod, 0, 4, act & (prod[..., 4] > 0)); print('  producer %-30s mean %8.0f  p90 %8.0f' % ('whole step', m, p90))
 cons = blk[:, :nc, 2:min(steps, 40)]
