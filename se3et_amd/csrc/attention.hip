@@ -27,6 +27,8 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float f4get(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
@@ -82,6 +84,16 @@ __device__ __forceinline__ void split_bf16x4(const float4& v, uint2& hi, uint2& 
   lo = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
 }
 
+// f16 hi + lo pieces of four floats (x = hi + lo to 2^-22 |x|; lo pieces of |x| < 2^-3 are subnormal f16: absolute error 2^-25)
+__device__ __forceinline__ void split_f16x4(const float4& v, uint2& hi, uint2& lo) {
+  f16x4 h, l;
+  h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+  l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
+  l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
+  hi = __builtin_bit_cast(uint2, h);
+  lo = __builtin_bit_cast(uint2, l);
+}
+
 constexpr int kStageStride = 36;     // floats per staged logits row (32 keys + 4: the 4 lane groups of a store hit disjoint banks)
 
 // One 16-key tile of the relative-position logits: 4 RT MFMAs per 16-channel chunk against the LDS-resident folded queries;
@@ -94,7 +106,12 @@ constexpr int kStageStride = 36;     // floats per staged logits row (32 keys + 
 // BF: the embedding is stored in bf16.  In 4-byte words the address pattern is the f32 one with half the row stride and half
 // the chunks (a lane's 16-byte load = 8 consecutive channels = its B operand of v_mfma_f32_16x16x32_bf16); the folded queries
 // are split into bf16 hi + lo fragments (two MFMAs per chunk and row tile: the query side stays exact to 2^-16).
-template <int CT, int RT, bool NEXT, bool EQ, bool UA, bool BF>
+// HS (round 3, the default for the f32 embedding): the f32 MFMAs (1/16 of the f16 rate: 225 us of matrix time per equivariant call at the
+// bench shape, as much as the HBM stream itself) are replaced by v_mfma_f32_16x16x32_f16 on f16 hi + lo pieces of BOTH operands -- the folded
+// queries split once when they are staged in LDS, the embedding values in registers right behind their load -- three products
+// hi hi + hi lo + lo hi in f32 (2^-22 per term: 1e-6 on logits of magnitude 4).  A lane's two float4 of a 32-channel step are not
+// consecutive channels; the A fragments are staged with the same permutation of the K index.
+template <int CT, int RT, bool NEXT, bool EQ, bool UA, bool BF, bool HS = false>
 __device__ __forceinline__ void bias_tile(float4 (&b)[BF ? CT / 2 : CT], const float4* afrag, const float4* qe_s, float* stage,
                                           int col0, const float* Erow, const float* eq_row, unsigned eq_anchor_stride, int tile,
                                           int next_tile, int M, int AH, int H) {
@@ -116,6 +133,35 @@ __device__ __forceinline__ void bias_tile(float4 (&b)[BF ? CT / 2 : CT], const f
   f32x4 acc[RT], acc_lo[RT];
 #pragma unroll
   for (int rt = 0; rt < RT; rt++) acc[rt] = acc_lo[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (HS) {
+    constexpr int KT = CT / 2;              // 32-channel steps; fragments: hi at (rt * KT + j) * 64, lo RT * KT * 64 further
+#pragma unroll
+    for (int j = 0; j < KT; j++) {
+      float4 ah[RT], al[RT];              // (not read ahead: the three waves of a SIMD cover the LDS latency, and 16 more registers spill)
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++) {
+        ah[rt] = afrag[(rt * KT + j) * 64 + lane];
+        al[rt] = afrag[((RT + rt) * KT + j) * 64 + lane];
+      }
+      const float4 b0 = b[2 * j], b1 = b[2 * j + 1];
+      uint2 h0, l0, h1, l1;
+      split_f16x4(b0, h0, l0);
+      split_f16x4(b1, h1, l1);
+      const f16x8 bh = __builtin_bit_cast(f16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+      const f16x8 bl = __builtin_bit_cast(f16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al[rt]), bh, acc[rt], 0, 0, 0);
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[rt]), bl, acc[rt], 0, 0, 0);
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[rt]), bh, acc[rt], 0, 0, 0);
+      if (NEXT) {
+        b[2 * j] = ld4(Enext + 16 * (2 * j));
+        b[2 * j + 1] = ld4(Enext + 16 * (2 * j + 1));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
   float4 a[NF];
 #pragma unroll
   for (int f = 0; f < NF; f++) a[f] = afrag[(f * CTB) * 64 + lane];
@@ -152,6 +198,7 @@ __device__ __forceinline__ void bias_tile(float4 (&b)[BF ? CT / 2 : CT], const f
       for (int f = 0; f < NF; f++) a[f] = an[f];
     }
   }
+  }
 #pragma unroll
   for (int rt = 0; rt < RT; rt++) {
 #pragma unroll
@@ -173,7 +220,7 @@ __device__ __forceinline__ void bias_tile(float4 (&b)[BF ? CT / 2 : CT], const f
 // range [w U / G, (w+1) U / G) and walks it row segment by row segment (the folded queries of the segment's row are staged
 // in LDS in MFMA-fragment order); inside a segment the 4 waves stride over the units.  A unit = two 16-key tiles whose
 // logits are collected in a wave-private LDS block and written out as full 128-byte row segments (float4 per lane).
-template <int CT, int RT, int MINW, bool EQ, bool UA, bool BF = false>
+template <int CT, int RT, int MINW, bool EQ, bool UA, bool BF = false, bool HS = false>
 __global__ __launch_bounds__(256, MINW) void rpe_bias_kernel(const float* __restrict__ qp, const float* __restrict__ qe,
                                                              int qp_rs, long long qp_sa, Stack S, int AH, int H,
                                                              float* __restrict__ bias) {
@@ -243,6 +290,18 @@ __global__ __launch_bounds__(256, MINW) void rpe_bias_kernel(const float* __rest
           af2[slot] = hi;
           af2[slot + RT * CTB * 64 * 2] = lo;
         }
+      } else if (HS) {
+        // f16 fragment (rt, j)[kk * 16 + r] = channels 32 j + 4 kk .. +3 and 32 j + 16 + 4 kk .. +3 of row 16 rt + r (the K order of a
+        // lane's two embedding float4 of that step): this float4 is one 8-byte half
+        const int t = c4 >> 2, kk = c4 & 3, j = t >> 1, hf = t & 1;
+        uint2 hi, lo;
+        split_f16x4(qv[u], hi, lo);
+        uint2* af2 = reinterpret_cast<uint2*>(afrag);
+        const int slot = ((((row >> 4) * (CT / 2) + j) * 64 + kk * 16 + (row & 15)) << 1) + hf;
+        if (i < QTOT) {
+          af2[slot] = hi;
+          af2[slot + RT * (CT / 2) * 64 * 2] = lo;
+        }
       } else {
         const int t = c4 >> 2, kk = c4 & 3;
         if (i < QTOT) afrag[((row >> 4) * CT + t) * 64 + kk * 16 + (row & 15)] = qv[u];
@@ -257,11 +316,11 @@ __global__ __launch_bounds__(256, MINW) void rpe_bias_kernel(const float* __rest
     const unsigned bias_ah = (unsigned)cl.N * cl.Mp;
     for (; unit < u_hi; unit += 4) {
       const int t0 = unit << 1;
-      bias_tile<CT, RT, true, EQ, UA, BF>(b, afrag, qe_s, stage, 0, Erow, eq_row, eq_sa, t0, t0 + 1, cl.M, AH, H);
+      bias_tile<CT, RT, true, EQ, UA, BF, HS>(b, afrag, qe_s, stage, 0, Erow, eq_row, eq_sa, t0, t0 + 1, cl.M, AH, H);
       if (unit + 4 < u_hi)
-        bias_tile<CT, RT, true, EQ, UA, BF>(b, afrag, qe_s, stage, 16, Erow, eq_row, eq_sa, t0 + 1, t0 + 8, cl.M, AH, H);
+        bias_tile<CT, RT, true, EQ, UA, BF, HS>(b, afrag, qe_s, stage, 16, Erow, eq_row, eq_sa, t0 + 1, t0 + 8, cl.M, AH, H);
       else
-        bias_tile<CT, RT, false, EQ, UA, BF>(b, afrag, qe_s, stage, 16, Erow, eq_row, eq_sa, t0 + 1, t0 + 1, cl.M, AH, H);
+        bias_tile<CT, RT, false, EQ, UA, BF, HS>(b, afrag, qe_s, stage, 16, Erow, eq_row, eq_sa, t0 + 1, t0 + 1, cl.M, AH, H);
       // the unit's (rows, 32 keys) block: 8 lanes cover one row's 128 bytes
       const int r8 = lane >> 3, m4 = (lane & 7) * 4;
 #pragma unroll
@@ -513,6 +572,135 @@ __device__ __forceinline__ void flash_tiles_qlds(FlashState<D>& st, const float4
   }
 }
 
+// f16-split form of flash_tiles_qlds (round 3; head dimensions that are multiples of 16): both products on v_mfma_f32_32x32x16_f16 with every
+// operand as f16 hi + lo pieces and three products hi hi + hi lo + lo hi accumulated in f32 (2^-22 per term) -- 24 MFMAs of 32 cycles per
+// (32 query, 32 key) tile where the f32 form issues 64 of 64 cycles (93 us of matrix time per equivariant call at the bench shape).  The
+// query tile is split once into LDS (q_h / q_l[(2 j + half) * 32 + c32] = 8 f16: channels 16 j + 4 half .. +3 and 16 j + 8 + 4 half .. +3, the
+// order in which a lane's two K float4 of MFMA j arrive); K, V^T and the softmax weights are split in registers.  The S^T accumulator
+// registers of a lane are keys {8 g + 4 half + j}: registers 0..7 / 8..15 are directly the B operand of the two K16 steps of P V, and the V^T
+// registers are loaded in the same key order.
+__device__ __forceinline__ void split_f16x8(const float (&v)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    hi[i] = (_Float16)v[i];
+    lo[i] = (_Float16)(v[i] - (float)hi[i]);
+  }
+}
+template <int D, bool HAS_BIAS>
+__device__ __forceinline__ void flash_tiles_f16(FlashState<D>& st, const uint4* q_h, const uint4* q_l, const float* __restrict__ k,
+                                                const float* __restrict__ v, const float* __restrict__ bias, int n0, int N, int M,
+                                                int k_rs, int v_rs, int Mp, float scale, int tile_begin, int tile_step) {
+  constexpr int DT = FlashState<D>::DT, KU = FlashState<D>::KU, KJ = D / 16;
+  static_assert(D % 16 == 0, "f16 flash tiles need a head dimension that is a multiple of 16");
+  const int lane = threadIdx.x & 63, half = lane >> 5, c32 = lane & 31;
+  const int nq = min(n0 + c32, N - 1);
+  const float* bias_row = HAS_BIAS ? bias + (size_t)nq * Mp : nullptr;
+  const int tiles = (M + 31) >> 5;
+  if (tile_begin >= tiles) return;
+  float4 kf[KU], b4[4];
+  {
+    const float* kr = k + (size_t)min((tile_begin << 5) + c32, M - 1) * k_rs + 4 * half;
+#pragma unroll
+    for (int u = 0; u < KU; u++) kf[u] = ld4(kr + 8 * u);
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+      b4[g] = HAS_BIAS ? ld4(bias_row + (tile_begin << 5) + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int tile = tile_begin; tile < tiles; tile += tile_step) {
+    const int m0 = tile << 5;
+    const int tn = min(tile + tile_step, tiles - 1);      // the last iteration re-requests its own tile: branch-free
+    float vv[DT * 16];
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; r++) s[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < KJ; j++) {
+      const f16x8 qh = __builtin_bit_cast(f16x8, q_h[(2 * j + half) * 32 + c32]);
+      const f16x8 ql = __builtin_bit_cast(f16x8, q_l[(2 * j + half) * 32 + c32]);
+      const float kv[8] = {kf[2 * j].x, kf[2 * j].y, kf[2 * j].z, kf[2 * j].w, kf[2 * j + 1].x, kf[2 * j + 1].y, kf[2 * j + 1].z, kf[2 * j + 1].w};
+      f16x8 kh, kl;
+      split_f16x8(kv, kh, kl);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh, s, 0, 0, 0);
+    }
+    // (1) V^T of this tile, (2) K fragment of the next tile -- into the registers the S phase just read (see flash_tiles_qlds)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) {
+      const int dd = 32 * dt + c32;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {          // keys m0 + 8 g + 4 half .. +3 are contiguous in the transposed values
+        const float4 t = dd < D ? ld4(v + (size_t)dd * v_rs + m0 + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+        vv[dt * 16 + 4 * g + 0] = t.x;
+        vv[dt * 16 + 4 * g + 1] = t.y;
+        vv[dt * 16 + 4 * g + 2] = t.z;
+        vv[dt * 16 + 4 * g + 3] = t.w;
+      }
+    }
+    {
+      const float* kr = k + (size_t)min((tn << 5) + c32, M - 1) * k_rs + 4 * half;
+#pragma unroll
+      for (int u = 0; u < KU; u++) kf[u] = ld4(kr + 8 * u);
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int key = m0 + 8 * g + 4 * half + j;
+        float val = (s[4 * g + j] + f4get(b4[g], j)) * scale;
+        val = key < M ? val : -INFINITY;
+        s[4 * g + j] = val;
+        mx = fmaxf(mx, val);
+      }
+    }
+    // (3) the logits of the next tile, into the registers just consumed, requested last (in-order VMEM counter)
+    __builtin_amdgcn_sched_barrier(0);
+    if (HAS_BIAS) {
+#pragma unroll
+      for (int g = 0; g < 4; g++) b4[g] = ld4(bias_row + (tn << 5) + 8 * g + 4 * half);
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(st.m, mx);
+    const float alpha = __expf(st.m - m_new);        // st.m = -inf on the first tile -> 0
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      s[r] = __expf(s[r] - m_new);
+      ps += s[r];
+    }
+    ps += __shfl_xor(ps, 32);
+    st.l = st.l * alpha + ps;
+    st.m = m_new;
+    f16x8 ph[2], pl[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const float pv[8] = {s[8 * i], s[8 * i + 1], s[8 * i + 2], s[8 * i + 3], s[8 * i + 4], s[8 * i + 5], s[8 * i + 6], s[8 * i + 7]};
+      split_f16x8(pv, ph[i], pl[i]);
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) st.o[dt][r] *= alpha;
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const float vs[8] = {vv[dt * 16 + 8 * i], vv[dt * 16 + 8 * i + 1], vv[dt * 16 + 8 * i + 2], vv[dt * 16 + 8 * i + 3],
+                             vv[dt * 16 + 8 * i + 4], vv[dt * 16 + 8 * i + 5], vv[dt * 16 + 8 * i + 6], vv[dt * 16 + 8 * i + 7]};
+        f16x8 vh, vl;
+        split_f16x8(vs, vh, vl);
+        st.o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[i], st.o[dt], 0, 0, 0);
+        st.o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[i], st.o[dt], 0, 0, 0);
+        st.o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[i], st.o[dt], 0, 0, 0);
+      }
+    }
+  }
+}
+
 template <int D>
 __device__ __forceinline__ void flash_init(FlashState<D>& st) {
   st.m = -INFINITY;
@@ -670,7 +858,30 @@ __global__ __launch_bounds__(64 * NW, MINW) void attention_kernel(AttnArgs p) {
     prof = p.prof + ((size_t)blockIdx.x * NW + wave) * 32;
     if ((threadIdx.x & 63) == 0) prof[0] = clock64();
   }
-  if (MODE >= 2) {
+  if (MODE == 4) {
+    // the query tile as f16 hi / lo pieces: fragment (j, half)[c32] = channels 16 j + 4 half .. +3 | 16 j + 8 + 4 half .. +3; thread i stages
+    // one float4 = one 8-byte half of a fragment
+    if constexpr (D % 16 == 0) {
+      uint2* qh2 = reinterpret_cast<uint2*>(q_s);
+      uint2* ql2 = qh2 + (D / 16) * 2 * 32 * 2;
+      for (int i = threadIdx.x; i < (D / 8) * 2 * 32; i += 64 * NW) {
+        const int c32 = i & 31, uh = i >> 5, u = uh >> 1, hf = uh & 1;
+        const float4 qv = ld4(q + (size_t)min(n0 + c32, cl.N - 1) * p.q_rs + 8 * u + 4 * hf);
+        uint2 hi, lo;
+        split_f16x4(qv, hi, lo);
+        const int slot = ((((u >> 1) * 2 + hf) * 32 + c32) << 1) + (u & 1);
+        qh2[slot] = hi;
+        ql2[slot] = lo;
+      }
+      __syncthreads();
+      const uint4* q_h = reinterpret_cast<const uint4*>(q_s);
+      const uint4* q_l = q_h + (D / 16) * 2 * 32;
+      if (p.bias != nullptr)
+        flash_tiles_f16<D, true>(st, q_h, q_l, k, v, bias, n0, cl.N, cl.M, p.k_rs, p.v_rs, cl.Mp, p.scale, wave, NW);
+      else
+        flash_tiles_f16<D, false>(st, q_h, q_l, k, v, bias, n0, cl.N, cl.M, p.k_rs, p.v_rs, cl.Mp, p.scale, wave, NW);
+    }
+  } else if (MODE >= 2) {
     for (int i = threadIdx.x; i < (D / 8) * 2 * 32; i += 64 * NW) {
       const int c32 = i & 31, uh = i >> 5;
       q_s[i] = ld4(q + (size_t)min(n0 + c32, cl.N - 1) * p.q_rs + 8 * (uh >> 1) + 4 * (uh & 1));
@@ -1358,8 +1569,10 @@ static int launch_rpe_bias(const float* qp, const float* qe, int row_stride, int
   }
   SE3_REQUIRE(total < (1ll << 31), SE3_ERR_UNSUPPORTED, "rpe_bias: too many (row, key tile) units");
   S.total_units = (int)total;
-  // one resident round: 3 workgroups of 4 waves per CU (LDS: fragments + staging), each with a balanced range of units
-  int wgs = 3 * device_cu_count();
+  // one resident round, each workgroup with a balanced range of units: 3 workgroups of 4 waves per CU (LDS: fragments + staging) for the
+  // f32 / bf16-embedding kernels, 2 for the f16-split kernel (the splits need ~190 registers; 8 waves x 16 KB stay in flight per CU)
+  const bool half_split = !emb_bf16 && g_bias_variant != 2 && g_bias_variant != 3 && (qe == nullptr || H % 4 == 0);
+  int wgs = (half_split ? 2 : 3) * device_cu_count();
   if (g_bias_split > 0) wgs = g_bias_split * device_cu_count();
   if (wgs > (total + 3) / 4) wgs = (int)((total + 3) / 4);
   if (wgs < 1) wgs = 1;
@@ -1372,10 +1585,12 @@ static int launch_rpe_bias(const float* qp, const float* qe, int row_stride, int
     else launch_kernel(1, rpe_bias_kernel<CT, RT, 2, true, false, true>, grid, dim3(256), st, SE3_BIAS_ARGS);                         \
   } else if (qe == nullptr) {                                                                                               \
     if (g_bias_variant == 2) launch_kernel(1, rpe_bias_kernel<CT, RT, 2, false, true>, grid, dim3(256), st, SE3_BIAS_ARGS);           \
-    else launch_kernel(1, rpe_bias_kernel<CT, RT, 3, false, true>, grid, dim3(256), st, SE3_BIAS_ARGS);                               \
+    else if (g_bias_variant == 3) launch_kernel(1, rpe_bias_kernel<CT, RT, 3, false, true>, grid, dim3(256), st, SE3_BIAS_ARGS);      \
+    else launch_kernel(1, rpe_bias_kernel<CT, RT, 2, false, true, false, true>, grid, dim3(256), st, SE3_BIAS_ARGS);                  \
   } else if (H % 4 == 0) {                                                                                           \
     if (g_bias_variant == 2) launch_kernel(1, rpe_bias_kernel<CT, RT, 2, true, true>, grid, dim3(256), st, SE3_BIAS_ARGS);            \
-    else launch_kernel(1, rpe_bias_kernel<CT, RT, 3, true, true>, grid, dim3(256), st, SE3_BIAS_ARGS);                                \
+    else if (g_bias_variant == 3) launch_kernel(1, rpe_bias_kernel<CT, RT, 3, true, true>, grid, dim3(256), st, SE3_BIAS_ARGS);       \
+    else launch_kernel(1, rpe_bias_kernel<CT, RT, 2, true, true, false, true>, grid, dim3(256), st, SE3_BIAS_ARGS);                   \
   } else {                                                                                                           \
     launch_kernel(1, rpe_bias_kernel<CT, RT, 2, true, false>, grid, dim3(256), st, SE3_BIAS_ARGS);                                    \
   }
@@ -1474,6 +1689,20 @@ static int launch_attention(AttnArgs& p, hipStream_t st) {
       case 2: launch_kernel(2, attention_kernel<D, 4, 3, 0>, grid, dim3(256), st, p); break;
       case 3: launch_kernel(2, attention_kernel<D, 6, 2, 2>, grid, dim3(384), st, p); break;
       case 9: p.prof = g_attn_prof; launch_kernel(2, attention_kernel<D, 4, 3, 3>, grid, dim3(256), st, p); break;
+      case 5:                                                                                     // f16 hi / lo split MFMAs (flash_tiles_f16)
+        if constexpr (D % 16 == 0) launch_kernel(2, attention_kernel<D, 4, 3, 4>, grid, dim3(256), st, p);
+        else launch_kernel(2, attention_kernel<D, 4, 3, 2>, grid, dim3(256), st, p);
+        break;
+      case 6: launch_kernel(2, attention_kernel<D, 2, 3, 2>, grid, dim3(128), st, p); break;
+      case 7:
+        if constexpr (D % 16 == 0) launch_kernel(2, attention_kernel<D, 2, 3, 4>, grid, dim3(128), st, p);
+        else launch_kernel(2, attention_kernel<D, 2, 3, 2>, grid, dim3(128), st, p);
+        break;
+      case 8: launch_kernel(2, attention_kernel<D, 1, 3, 2>, grid, dim3(64), st, p); break;
+      case 10:
+        if constexpr (D % 16 == 0) launch_kernel(2, attention_kernel<D, 1, 3, 4>, grid, dim3(64), st, p);
+        else launch_kernel(2, attention_kernel<D, 1, 3, 2>, grid, dim3(64), st, p);
+        break;
       default: launch_kernel(2, attention_kernel<D, 4, 3, 2>, grid, dim3(256), st, p); break;
     }
   }, "attention");
