@@ -37,36 +37,74 @@ sys.path.insert(0, ROOT)
 #   eq  call: (2*1336245.8 + 162966.6 + 203184.0 + 35289.5) KiB = 3147.7 MB  vs 2549.0 MB algorithmic
 #   inv call: (2*1094116.0 +  25743.6 +  33736.0 +  5864.4) KiB = 2307.7 MB  vs 2222.9 MB algorithmic
 PMC_TRAFFIC_RATIO = {'eq': 3147.7 / 2549.0, 'inv': 2307.7 / 2222.9}
+PMC_TRAFFIC_FILE = 'profiles/r02_pmc_attention.csv'
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s is achievable
 
 
-def launch_ranks(n, argv, script=None):
-    """Parent of a self-launched multi-GPU run: N children `python bench.py <argv>`, one rank each.  Never initialises a GPU."""
+def visible_gpus():
+    """GPUs this process may use WITHOUT touching the HIP runtime (the launcher parent must never initialise a GPU: its children do):
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES if set, else the KFD topology (nodes with SIMDs).  None when neither is readable."""
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(',') if t.strip() != ''])
+    root = '/sys/class/kfd/kfd/topology/nodes'
+    try:
+        count = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, 'properties')) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            count += int(props.get('simd_count', '0')) > 0
+        return count
+    except (OSError, ValueError):
+        return None
+
+
+def launch_ranks(n, argv, script=None, python=None, poll=0.2, timeout=3600.0):
+    """Parent of a self-launched multi-GPU run: N children `python bench.py <argv>`, one rank each.  Never initialises a GPU.  All
+    children are watched: the first non-zero exit ends the others (which this launcher started), so a rank that dies before the
+    rendezvous does not leave the rest waiting for the collective timeout."""
     import socket
     import subprocess
+    import tempfile
     sock = socket.socket()
     sock.bind(('127.0.0.1', 0))
     port = sock.getsockname()[1]
     sock.close()
     procs = []
+    out0 = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port))
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC (RCCL across processes on this driver)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script or __file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode]
-    for p in procs[1:]:
-        try:
-            codes.append(p.wait(timeout=600))
-        except subprocess.TimeoutExpired:
-            p.kill()                                                # exactly the child started above
-            codes.append(-9)
-    for line in out.decode().splitlines():           # stdout carries the ONE JSON line; library chatter goes to stderr
+        procs.append(subprocess.Popen([python or sys.executable, os.path.abspath(script or __file__)] + list(argv), env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    t_end = time.monotonic() + timeout
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs) and time.monotonic() < t_end:
+        for p in procs:
+            if p.poll() not in (None, 0):
+                failed = p.returncode
+        time.sleep(poll)
+    if failed is not None or time.monotonic() >= t_end:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()                                       # exactly the children started above
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    codes = [p.wait() for p in procs]
+    out0.seek(0)
+    for line in out0.read().decode().splitlines():   # stdout carries the ONE JSON line; library chatter goes to stderr
         print(line, file=sys.stdout if line.lstrip().startswith('{') else sys.stderr, flush=True)
+    if failed is None and time.monotonic() >= t_end and any(c != 0 for c in codes):
+        return 124
     bad = [c for c in codes if c != 0]
+    if failed is not None:
+        return failed if failed > 0 else 1
     return 0 if not bad else (bad[0] if bad[0] > 0 else 1)
 
 
@@ -91,12 +129,17 @@ def main():
     ap.add_argument('--inflight', type=int, default=1, help='pairs in flight per GPU: host threads, one HIP stream each')
     ap.add_argument('--single-pair-steps', type=int, default=16, help='pairs of the one-pair-per-forward measurement reported as '
                     '`single_pair` (rank 0 at --gpus 1 only; 0 = skip)')
+    ap.add_argument('--train-steps', type=int, default=5, help='training steps (fwd + bwd + Adam, one pair each) of the `train_step` object '
+                    '(rank 0 at --gpus 1 only; 0 = skip)')
+    ap.add_argument('--roofline-quiet-steps', type=int, default=3, help='extra steps after the timed region without the pyramid prefetch '
+                    'stream, for `roofline.quiet` (0 = skip)')
     ap.add_argument('--fake-device', action='store_true', help='launcher self-test: gloo rendezvous, sharding, barriers and the '
                     'MAX-over-ranks clock run for real, the step is a host sleep (no GPU needed; tests/test_bench_launch.py)')
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        if not args.fake_device and torch.cuda.device_count() < args.gpus:      # device_count() does not initialise the GPU
-            raise SystemExit('bench.py: --gpus %d but only %d device(s) visible' % (args.gpus, torch.cuda.device_count()))
+        seen = None if args.fake_device else visible_gpus()         # (no HIP call in the launcher: torch.cuda.device_count() is one on ROCm)
+        if seen is not None and seen < args.gpus:
+            raise SystemExit('bench.py: --gpus %d but only %d device(s) visible' % (args.gpus, seen))
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     if args.fake_device:
         return run_fake(args)
@@ -224,9 +267,58 @@ def main():
     elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
     timings, se3_ops.KERNEL_TIMINGS = se3_ops.KERNEL_TIMINGS, None
 
-    # One RPE self-attention call = rpe_bias_kernel (streams the embeddings) + attention_kernel (softmax.V), launched back to
-    # back by one C-ABI call for both clouds of the pair.  Each launch carries its own start / stop HIP event pair on the
-    # launch stream (hipExtLaunchKernelGGL: the dispatch's begin / end timestamps); the call's time is the sum of the two.
+    roofline = collect_roofline(se3_lib, timings, args)
+    # The same kernels with nothing else on the GPU: by default the pyramid of the next batch is built on a second stream BESIDE the timed
+    # kernels (--prefetch 1), which lengthens them; a few extra steps without it (after the timed region) give the kernels' own rate.
+    if args.prefetch and args.roofline_quiet_steps > 0:
+        se3_ops.KERNEL_TIMINGS = {}
+        se3_lib.lib().se3_debug_kernel_timing(1)
+        for i in range(args.warmup, min(total_steps, args.warmup + args.roofline_quiet_steps)):
+            step(i)
+        torch.cuda.synchronize()
+        quiet_timings, se3_ops.KERNEL_TIMINGS = se3_ops.KERNEL_TIMINGS, None
+        quiet = collect_roofline(se3_lib, quiet_timings, args)
+        roofline['quiet'] = {k: quiet[k] for k in ('achieved', 'frac', 'launches', 'avg_us', 'rpe_bias_kernel_avg_us', 'attention_kernel_avg_us',
+                                                   'eq_call_avg_us', 'inv_call_avg_us')}
+        roofline['quiet']['note'] = 'same kernels, same shapes, %d extra step(s) after the timed region with the pyramid prefetch stream idle' % args.roofline_quiet_steps
+
+    single_pair = None
+    if rank == 0 and args.gpus == 1 and args.single_pair_steps > 0:
+        single_pair = run_single_pair(model, cfg, args, dev, feats)
+    train = None
+    if rank == 0 and args.gpus == 1 and args.train_steps > 0 and args.variant == 'se3ete':
+        train = run_train_step(args.variant, args, dev)
+    cpu_baseline = None
+    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(model, cfg, args)
+    ranks_seen = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+
+    if rank == 0:
+        n, dims, _ = PAIR_PRESETS[args.pair]
+        line = {
+            'metric': 'point-cloud pairs/sec (fwd), SE3ET-E 5k-pt pairs', 'value': round(world * args.steps * PB / elapsed, 3),
+            'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32' if args.attention_dtype == 'float32' else 'f32 (geometric embedding stored in bf16)',
+            'data': 'synthetic',
+            'config': {'workload': 'SE3ET-E forward (pyramid + backbone + transformer + matching + Sinkhorn + LGR) on '
+                                   'synthetic %d+%d-point pairs, %d pair(s) per rank per step' % (n, n, PB) +
+                                   (' = BASELINE.json configs[3]: 64 independent pairs per step over 8 GPUs' if world == 8 and PB == 8 else ''),
+                       'ranks_seen': ranks_seen,
+                       'variant': args.variant, 'pair_preset': args.pair, 'sharding': 'pairs round-robin over ranks, no collective',
+                       'pairs_per_forward': PB, 'pairs_in_flight_per_gpu': max(1, args.inflight), 'pyramid_prefetch': bool(args.prefetch),
+                       'attention_dtype': args.attention_dtype},
+            'roofline': roofline, 'cpu_baseline': cpu_baseline, 'single_pair': single_pair, 'train_step': train,
+        }
+        print(json.dumps(line), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+def collect_roofline(se3_lib, timings, args):
+    """One RPE self-attention call = rpe_bias_kernel (streams the embeddings) + attention_kernel (softmax.V), launched back to back by one
+    C-ABI call for all clouds of the batch.  Each launch carries its own start / stop HIP event pair on the launch stream
+    (hipExtLaunchKernelGGL: the dispatch's begin / end timestamps); the call's time is the sum of the two."""
     import ctypes
     calls = timings.get('rpe_self_attention_calls', [])
     cap = 4 * len(calls) + 64 * args.steps
@@ -254,12 +346,12 @@ def main():
     traffic = sum(PMC_TRAFFIC_RATIO[name] * k[1] for name, k in kinds.items()) / max(n_call, 1)
     if args.attention_dtype != 'float32':
         traffic = None                 # the PMC passes were taken on the f32 kernels
-    roofline = {
-        'kernel': 'RPE self-attention call = rpe_bias_kernel + attention_kernel (both clouds of a pair per launch)',
+    return {
+        'kernel': 'RPE self-attention call = rpe_bias_kernel + attention_kernel (all clouds of the batch per launch)',
         'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None if traffic is None else int(traffic),
         'traffic_source': 'bytes per call; PMC FETCH_SIZE(x2 on the streaming kernel)+WRITE_SIZE per algorithmic byte from '
-                          'profiles/r02_pmc_attention.csv, applied to the calls of this run',
+                          '%s, applied to the calls of this run' % PMC_TRAFFIC_FILE,
         'launches': n_call, 'avg_us': round(us_call / max(n_call, 1), 2),
         'algorithmic_bytes_per_launch': int(bytes_call / max(n_call, 1)),
         'rpe_bias_kernel_avg_us': round(sum(k[2] for k in kinds.values()) / max(n_call, 1), 2),
@@ -268,34 +360,57 @@ def main():
         'inv_call_avg_us': round((kinds['inv'][2] + kinds['inv'][3]) / max(kinds['inv'][0], 1), 2),
     }
 
-    single_pair = None
-    if rank == 0 and args.gpus == 1 and args.single_pair_steps > 0:
-        single_pair = run_single_pair(model, cfg, args, dev, feats)
-    cpu_baseline = None
-    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(model, cfg, args)
-    ranks_seen = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
 
-    if rank == 0:
-        n, dims, _ = PAIR_PRESETS[args.pair]
-        line = {
-            'metric': 'point-cloud pairs/sec (fwd), SE3ET-E 5k-pt pairs', 'value': round(world * args.steps * PB / elapsed, 3),
-            'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32' if args.attention_dtype == 'float32' else 'f32 (geometric embedding stored in bf16)',
-            'data': 'synthetic',
-            'config': {'workload': 'SE3ET-E forward (pyramid + backbone + transformer + matching + Sinkhorn + LGR) on '
-                                   'synthetic %d+%d-point pairs, %d pair(s) per rank per step' % (n, n, PB) +
-                                   (' = BASELINE.json configs[3]: 64 independent pairs per step over 8 GPUs' if world == 8 and PB == 8 else ''),
-                       'ranks_seen': ranks_seen,
-                       'variant': args.variant, 'pair_preset': args.pair, 'sharding': 'pairs round-robin over ranks, no collective',
-                       'pairs_per_forward': PB, 'pairs_in_flight_per_gpu': max(1, args.inflight), 'pyramid_prefetch': bool(args.prefetch),
-                       'attention_dtype': args.attention_dtype},
-            'roofline': roofline, 'cpu_baseline': cpu_baseline, 'single_pair': single_pair,
-        }
-        print(json.dumps(line), flush=True)
-    if torch.distributed.is_initialized():
-        torch.distributed.destroy_process_group()
+def run_train_step(cfg_variant, args, dev):
+    """BASELINE.json configs[4] on one GPU: SE3ET-E forward (training mode, ground-truth targets) + OverallLoss + backward + Adam on
+    synthetic 5k+5k pairs, one pair per step (experiments/se3ete.3dmatch/loss.py:15-76, engine/base_trainer.py:181-196); pyramid on
+    the GPU inside the step.  Seconds per step over `--train-steps` steps after 2 warm-up steps, the forward / backward / optimizer
+    split of one more step by HIP events, peak memory."""
+    from se3et_amd.data import registration_collate_fn_stack_mode
+    from se3et_amd.model import create_model, load_synthetic_weights, make_cfg
+    from se3et_amd.synthetic import make_pair
+    from se3et_amd.training import OverallLoss, make_optimizer, train_step
+    cfg = make_cfg(cfg_variant)
+    model = load_synthetic_weights(create_model(cfg)).to(dev).train()
+    loss_fn, opt = OverallLoss(cfg), make_optimizer(model, cfg)
+    b = cfg.backbone
+    rng = np.random.RandomState(0)
+    n = args.train_steps + 3
+    batches = []
+    for i in range(n):
+        ref, src, T = make_pair(args.pair, index=2000 + i)
+        batches.append(dict(ref_points=ref, src_points=src, ref_feats=np.ones((len(ref), 1), np.float32),
+                            src_feats=np.ones((len(src), 1), np.float32), transform=T))
+
+    def collate(i):
+        return registration_collate_fn_stack_mode([batches[i]], b.num_stages, b.init_voxel_size, b.init_radius, cfg.neighbor_limits, device=dev)
+
+    for i in range(2):
+        train_step(model, collate(i), loss_fn, opt, rng=rng)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    t0 = time.perf_counter()
+    for i in range(2, 2 + args.train_steps):
+        losses, _ = train_step(model, collate(i), loss_fn, opt, rng=rng)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.train_steps
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    dd = collate(n - 1)
+    opt.zero_grad(set_to_none=True)
+    ev[0].record()
+    loss = loss_fn(model(dd, train=True, rng=rng), dd)['loss']
+    ev[1].record()
+    loss.backward()
+    ev[2].record()
+    opt.step()
+    ev[3].record()
+    torch.cuda.synchronize()
+    return {'s_per_step': round(dt, 4), 'pairs_per_s': round(1.0 / dt, 2), 'steps': args.train_steps,
+            'forward_loss_ms': round(ev[0].elapsed_time(ev[1]), 2), 'backward_ms': round(ev[1].elapsed_time(ev[2]), 2),
+            'adam_ms': round(ev[2].elapsed_time(ev[3]), 2), 'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            'loss': round(float(losses['loss'].detach()), 4),
+            'note': 'BASELINE.json configs[4] on one GPU: forward (training mode) + OverallLoss + backward + Adam, one synthetic 5k+5k pair per '
+                    'step incl. the on-GPU pyramid; pinned against the reference by tests/test_gpu_training.py::test_fullsize_training_step_matches_reference'}
 
 
 def run_fake(args):

@@ -295,7 +295,7 @@ def gen_precompute_cap():
     np.savez_compressed(os.path.join(HERE, 'precompute_cap.npz'), **res)
 
 
-def gen_train(variant, fname, micro=True, pair='micro'):
+def gen_train(variant, fname, micro=True, pair='micro', synth_seed=None, full_grads=None):
     """BASELINE.json configs[4] pieces through the genuine reference in TRAINING mode: forward with ground-truth superpoint
     targets, OverallLoss (weighted circle loss + fine NLL), backward, one Adam step.  Stored: the loss values, the ground-truth
     correspondences, the gradient norm of every parameter and a few complete gradients, the total norm, and a parameter checksum
@@ -308,6 +308,12 @@ def gen_train(variant, fname, micro=True, pair='micro'):
         cfg.geotransformer.input_dim, cfg.geotransformer.hidden_dim, cfg.geotransformer.output_dim = 128, 32, 32
     torch.manual_seed(0)
     model = create_model(cfg).train()
+    if synth_seed is not None:      # full-size models: name-keyed synthetic weights (regenerated on the other side, not stored)
+        sd = model.state_dict()
+        for k in sd:
+            if k.rsplit('.', 1)[-1] in LEARNED_LEAVES and sd[k].dtype == torch.float32 and 'anchors' not in k:
+                sd[k] = torch.from_numpy(np.asarray(synth_tensor(k, sd[k].shape, synth_seed)))
+        model.load_state_dict(sd)
     loss_fn = loss_mod.OverallLoss(cfg)
     ref, src, T = make_pair(pair)
     dd = collate(ref, src, T, cfg.backbone.num_stages, cfg.backbone.init_voxel_size, cfg.backbone.init_radius,
@@ -338,10 +344,10 @@ def gen_train(variant, fname, micro=True, pair='micro'):
         norms.append(float(g.norm()))
         total += float((g * g).sum())
     res['grad/names'], res['grad/norms'], res['grad/total_norm'] = np.array(names), np.array(norms), np.float64(total ** 0.5)
-    for n in ('backbone.encoder1_1.interso3.conv.weights', 'backbone.encoder4_3.unary2.mlp.weight',
-              'transformer.embedding.proj_d.weight', 'transformer.transformer.layers.0.attention.attention.proj_eq.weight',
-              'transformer.transformer.layers.3.attention.attention.proj_q.weight', 'transformer.out_proj.weight',
-              'optimal_transport.alpha', 'transformer.transformer.rotcompress.expand.weight'):
+    for n in full_grads or ('backbone.encoder1_1.interso3.conv.weights', 'backbone.encoder4_3.unary2.mlp.weight',
+                            'transformer.embedding.proj_d.weight', 'transformer.transformer.layers.0.attention.attention.proj_eq.weight',
+                            'transformer.transformer.layers.3.attention.attention.proj_q.weight', 'transformer.out_proj.weight',
+                            'optimal_transport.alpha', 'transformer.transformer.rotcompress.expand.weight'):
         if n in dict(model.named_parameters()) and dict(model.named_parameters())[n].grad is not None:
             res['grad/full/' + n] = _np(dict(model.named_parameters())[n].grad)
     opt.step()
@@ -393,6 +399,13 @@ if __name__ == '__main__':
     if 'train' in which:
         gen_train('se3ete.3dmatch', 'train_micro_se3ete.npz')
         gen_train('se3eti.3dmatch', 'train_micro_se3eti.npz')
+    if 'train_fullsize' in which:
+        # BASELINE.json configs[4] at its own size: SE3ET-E, the 5k+5k pair 0 of the bench workload, synthetic weights (seed 7)
+        gen_train('se3ete.3dmatch', 'train_c2_se3ete_5k.npz', micro=False, pair='c2_5k', synth_seed=7,
+                  full_grads=('backbone.encoder1_1.interso3.conv.weights', 'backbone.encoder2_2.interso3.conv.weights',
+                              'transformer.embedding.proj_d.weight', 'transformer.transformer.layers.0.attention.attention.proj_eq.weight',
+                              'transformer.transformer.layers.3.attention.attention.proj_q.weight', 'transformer.out_proj.weight',
+                              'optimal_transport.alpha'))
     if 'cap' in which:
         gen_precompute_cap()
     if 'fullsize' in which:

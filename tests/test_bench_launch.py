@@ -36,3 +36,43 @@ def test_bench_single_rank_and_torchrun_environment():
     # under an external launcher (RANK / WORLD_SIZE set) the process is a rank, not a launcher: a mismatching --gpus is refused
     rc, out, err = _run(['--gpus', '2'], {'RANK': '0', 'LOCAL_RANK': '0', 'WORLD_SIZE': '1'})
     assert rc != 0 and 'WORLD_SIZE' in err
+
+
+def _stub(tmp_path, body):
+    path = tmp_path / 'stub_rank.py'
+    path.write_text('import json, os, sys, time\nrank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])\n' + body)
+    return str(path)
+
+
+def test_real_launcher_branch_with_stub_ranks(tmp_path, monkeypatch):
+    """The launcher itself (not --fake-device): N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* on 127.0.0.1, rank 0's JSON line
+    forwarded, the device count taken from the environment / sysfs -- the parent never calls into HIP."""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,1,2')
+    assert bench.visible_gpus() == 3
+    monkeypatch.delenv('HIP_VISIBLE_DEVICES')
+    assert 'torch.cuda' not in open(os.path.join(ROOT, 'bench.py')).read().split('def main():')[0].split('def launch_ranks')[1]
+    script = _stub(tmp_path, 'assert os.environ["MASTER_ADDR"] == "127.0.0.1" and os.environ["LOCAL_RANK"] == str(rank)\n'
+                             'time.sleep(0.2 * rank)\n'
+                             'if rank == 0: print(json.dumps({"ranks_seen": world, "argv": sys.argv[1:]}))\n')
+    import contextlib, io
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        rc = bench.launch_ranks(3, ['--steps', '2'], script=script)
+    assert rc == 0
+    line = json.loads(buf.getvalue().strip())
+    assert line == {'ranks_seen': 3, 'argv': ['--steps', '2']}
+
+
+def test_launcher_ends_the_other_ranks_when_one_dies(tmp_path):
+    """A rank that dies before the rendezvous must not leave the launcher waiting: the first non-zero exit ends the remaining children
+    and becomes the launcher's status."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    script = _stub(tmp_path, 'if rank == 1: sys.exit(7)\ntime.sleep(120)\n')
+    t0 = time.monotonic()
+    rc = bench.launch_ranks(3, [], script=script)
+    assert rc == 7
+    assert time.monotonic() - t0 < 30

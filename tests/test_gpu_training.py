@@ -26,10 +26,8 @@ def _setup(variant, fixture, golden_dir):
     return g, cfg, model, dd
 
 
-@pytest.mark.parametrize('variant,fixture', [('micro_e', 'train_micro_se3ete.npz'), ('micro_i', 'train_micro_se3eti.npz')])
-def test_training_step_matches_reference(golden_dir, variant, fixture):
+def _check_training_step(g, cfg, model, dd, grad_tol=1e-3, full_tol=2e-3):
     from se3et_amd.training import OverallLoss, make_optimizer
-    g, cfg, model, dd = _setup(variant, fixture, golden_dir)
     targets = (torch.from_numpy(g['target/ref']).long(), torch.from_numpy(g['target/src']).long())
     out = model(dd, train=True, targets=targets)
     # ground-truth superpoint correspondences: same pairs, same overlaps
@@ -53,15 +51,83 @@ def test_training_step_matches_reference(golden_dir, variant, fixture):
         gn = float(params[n].grad.double().norm())
         total += gn * gn
         # 1e-3 relative for every parameter whose gradient matters, absolute floor for the tiny ones
-        assert abs(gn - want_norm) <= 1e-3 * want_norm + 1e-5 * big, (n, gn, float(want_norm))
-    assert abs(total ** 0.5 - float(g['grad/total_norm'])) <= 1e-3 * float(g['grad/total_norm'])
+        assert abs(gn - want_norm) <= grad_tol * want_norm + 1e-5 * big, (n, gn, float(want_norm))
+    assert abs(total ** 0.5 - float(g['grad/total_norm'])) <= grad_tol * float(g['grad/total_norm'])
     for key in g.files:
         if key.startswith('grad/full/'):
-            assert_close(params[key[len('grad/full/'):]].grad.cpu(), g[key], 2e-3, key)
+            assert_close(params[key[len('grad/full/'):]].grad.cpu(), g[key], full_tol, key)
     opt.step()
     assert_close(model.transformer.out_proj.weight.detach().cpu(), g['after_step/out_proj_weight'], 1e-4, 'out_proj.weight after Adam')
     psum = sum(float(p.detach().double().sum()) for p in model.parameters())
     assert abs(psum - float(g['after_step/param_sum'])) <= 1e-4 * abs(float(g['after_step/param_sum'])) + 1e-2
+
+
+@pytest.mark.parametrize('variant,fixture', [('micro_e', 'train_micro_se3ete.npz'), ('micro_i', 'train_micro_se3eti.npz')])
+def test_training_step_matches_reference(golden_dir, variant, fixture):
+    g, cfg, model, dd = _setup(variant, fixture, golden_dir)
+    _check_training_step(g, cfg, model, dd)
+
+
+def _setup_fullsize(golden_dir):
+    """BASELINE.json configs[4] at its own size: SE3ET-E (17.1 M parameters), pair 0 of the bench workload (5000 + 5000 points), name-keyed
+    synthetic weights (seed 7) -- tests/golden/train_c2_se3ete_5k.npz holds the genuine reference's forward + OverallLoss + backward + Adam
+    step on exactly that (generate_golden.py train_fullsize)."""
+    from se3et_amd.data import registration_collate_fn_stack_mode
+    from se3et_amd.model import create_model, load_synthetic_weights, make_cfg
+    g = np.load(golden_dir + '/train_c2_se3ete_5k.npz')
+    cfg = make_cfg('se3ete')
+    model = load_synthetic_weights(create_model(cfg), seed=7).cuda().train()
+    d = dict(ref_points=g['ref'], src_points=g['src'], ref_feats=np.ones((len(g['ref']), 1), np.float32),
+             src_feats=np.ones((len(g['src']), 1), np.float32), transform=g['transform'])
+    b = cfg.backbone
+    dd = registration_collate_fn_stack_mode([d], b.num_stages, b.init_voxel_size, b.init_radius, cfg.neighbor_limits)
+    return g, cfg, model, dd
+
+
+def test_fullsize_training_step_matches_reference(golden_dir):
+    """Losses 1e-4, the gradient norm of every one of the 346 parameters 1e-3, seven complete gradients 2e-3, parameters after the Adam step:
+    the hand-written backward kernels (KPConv at 80 000 / 51 742 / 21 411 / 5 506 points up to 256 channels, GroupNorm, embedding at 382
+    superpoints, Sinkhorn, LayerNorm) against the reference's autograd at the size they run at."""
+    g, cfg, model, dd = _setup_fullsize(golden_dir)
+    _check_training_step(g, cfg, model, dd)
+
+
+def test_ddp_wrapped_model_gives_the_unwrapped_gradients(golden_dir):
+    """The real SE3ET-E in DistributedDataParallel (backend nccl = RCCL, world size 1, this process): custom autograd Functions,
+    find_unused_parameters, float-atomic scatter -- gradients, reduced by DDP's bucketed all-reduce, equal the unwrapped step's."""
+    import torch.distributed as dist
+    from se3et_amd.training import OverallLoss, distributed_model
+    g, cfg, model, dd = _setup_fullsize(golden_dir)
+    targets = (torch.from_numpy(g['target/ref']).long(), torch.from_numpy(g['target/src']).long())
+    loss_fn = OverallLoss(cfg)
+
+    def grads(net):
+        for p in model.parameters():
+            p.grad = None
+        out = net(dd, train=True, targets=targets)
+        loss = loss_fn(out, dd)['loss']
+        loss.backward()
+        return float(loss.detach()), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    loss0, g0 = grads(model)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29541', rank=0, world_size=1)
+    try:
+        assert dist.get_backend() == 'nccl' and dist.get_world_size() == 1
+        net = distributed_model(model, torch.device('cuda', torch.cuda.current_device()))
+        loss1, g1 = grads(net)
+        loss2, g2 = grads(net)              # a second step through the same wrapper (bucket rebuild after the first)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert abs(loss1 - loss0) <= 1e-5 * abs(loss0) and abs(loss2 - loss0) <= 1e-5 * abs(loss0)
+    assert set(g0) == set(g1) == set(g2)
+    big = max(float(v.norm()) for v in g0.values())
+    for n in g0:
+        # float atomics in the KPConv scatter: arrival-order round-off between two runs, nothing more
+        for other in (g1[n], g2[n]):
+            assert float((other - g0[n]).norm()) <= 2e-4 * float(g0[n].norm()) + 1e-6 * big, n
 
 
 def test_restatements_match_the_kernels():

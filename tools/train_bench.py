@@ -65,14 +65,16 @@ def main():
                           'pairs_per_s': round(world * args.steps / dt, 3), 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                           'loss': float(losses['loss'].detach()), 'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
                           'backward': 'HIP kernels for KPConv / GroupNorm / LayerNorm / Sinkhorn / embedding / max-pool / row gather, PyTorch restatements on the GPU for the other ops (se3et_amd/autograd.py)', 'data': 'synthetic'}), flush=True)
-    if args.profile and rank == 0:
+    if args.profile and world > 1 and rank == 0:
+        print('--profile is a single-GPU option (a forward / backward through the DDP wrapper on one rank would wait for its peers): skipped')
+    if args.profile and world == 1:
         from se3et_amd import autograd as AG
         AG.BACKWARD_TIMINGS = {}
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         dd = registration_collate_fn_stack_mode([batches[0]], b.num_stages, b.init_voxel_size, b.init_radius, cfg.neighbor_limits, device=dev)
         opt.zero_grad(set_to_none=True)
         e0.record()
-        out = net(dd, train=True, rng=rng)
+        out = model(dd, train=True, rng=rng)
         loss = loss_fn(out, dd)['loss']
         e1.record()
         loss.backward()
