@@ -175,26 +175,7 @@ int se3_kpconv_so3_gather_bwd(const float* q_pts, const float* s_pts, const int6
                               const float* kernel_points_host, const int64_t* kidx_host, const int64_t* ridx_host, float sigma,
                               int64_t num_queries, int64_t num_support, int num_neighbors, int in_channels, float* dx, void* stream);
 
-/* Matrix-core form of the same convolution (csrc/kpconv_contract.hip), input channels a multiple of 8, output channels 16, 32, 48 or a
- * multiple of 64: the gather leaves the
- * kernel-point sums F[p, k, a, c] = sum_n w[p, n, k] x[idx[p, n], a, c] in tile order [Cin / 8][ceil16(P)][732] (se3_kpconv_points_floats
- * floats; a row = 15 * 6 * 8 values + 8 zeros + 4 pad; 2.4x smaller
- * than the slot sums of se3_kpconv_so3_gather; kernel-point / anchor slot tables = the SE3ET configuration, compiled in);
- * se3_kpconv_split_weights re-arranges weights (36 Cin, Cout) -- KPConvInterSO3.weights (6, 6, Cin, Cout) flattened -- into
- * three-piece bf16 MFMA fragments (`fragments`: se3_kpconv_weight_fragments_bytes bytes, rebuilt per call: no stale copies);
- * se3_kpconv_so3_contract builds the slot sums on the fly and multiplies on the bf16 matrix cores at f32 accuracy (six
- * products of the three-way splits): out (P, 6, Cout).  Replaces blocks_epn.py:454-546 without materialising neighb_x, the
- * expanded weights or the (6P, 36 Cin) operand. */
-int se3_kpconv_so3_gather_points(const float* q_pts, const float* s_pts, const int64_t* idx, const float* x,
-                                 const float* kernel_points_host, float sigma, int64_t num_queries, int64_t num_support,
-                                 int num_neighbors, int in_channels, float* F, void* stream);
-size_t se3_kpconv_points_floats(int64_t num_queries, int in_channels);
-size_t se3_kpconv_weight_fragments_bytes(int in_channels, int out_channels);
-int se3_kpconv_split_weights(const float* weights, int in_channels, int out_channels, void* fragments, void* stream);
-int se3_kpconv_so3_contract(const float* F, const void* weight_fragments, int64_t num_queries, int in_channels, int out_channels,
-                            float* out, void* stream);
-
-/* Round 3 form of the matrix-core convolution (csrc/kpconv_sums.h, csrc/kpconv_mfma.hip; input channels a multiple of 8, output channels a
+/* Matrix-core form of the same convolution (csrc/kpconv_sums.h, csrc/kpconv_mfma.hip; input channels a multiple of 8, output channels a
  * multiple of 32, SE3ET slot tables compiled in; num_support * 6 * in_channels < 2^31).  Over all (weight slot s, output anchor r) only 16
  * distinct kernel-point sums occur (6 vertices, centre, 3 equators, 6 face quadruples): the "orbits".
  *   se3_kpconv_neighbor_table: per query point its valid neighbours (compacted; shadow / padded entries carry weight 0 in the reference,
@@ -350,7 +331,8 @@ int se3_geo_embedding_bwd_operands(const float* points, const int64_t* knn, int 
  * f(x) = weight emb(x) + bias at x = j / entries_per_unit (float64 accumulation), emb = SinusoidalPositionalEmbedding
  * (transformer/positional_embedding.py:8-34) with div_term (C/2,).  state: se3_embedding_table_state_bytes() zero-initialised bytes owned by the caller next to
  * the table; the kernel keeps a content hash of (weight, bias, div_term, sizes) there and returns immediately when the table
- * already belongs to the current values -- call it in front of every se3_geo_embedding_*_fwd; no host synchronisation. */
+ * already belongs to the current values -- call it in front of every se3_geo_embedding_*_fwd; no host synchronisation.  A (table, state)
+ * pair has ONE writer: calls for it must be ordered (one stream); concurrent streams keep their own pair. */
 size_t se3_embedding_table_state_bytes(void);
 int se3_embedding_table_refresh(const float* weight, const float* bias, const float* div_term, int C, int entries,
                                 float entries_per_unit, float* table, void* state, void* stream);

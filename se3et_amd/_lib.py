@@ -37,11 +37,6 @@ SIGNATURES = {
     'se3_neighbor_max_pool_bwd': (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i64, _vp, _vp]),
     'se3_kpconv_so3_gather': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _i32, _vp, _vp]),
     'se3_kpconv_so3_gather_bwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _i32, _vp, _vp]),
-    'se3_kpconv_so3_gather_points': (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _i32, _vp, _vp]),
-    'se3_kpconv_points_floats': (_sz, [_i64, _i32]),
-    'se3_kpconv_weight_fragments_bytes': (_sz, [_i32, _i32]),
-    'se3_kpconv_split_weights': (_i32, [_vp, _i32, _i32, _vp, _vp]),
-    'se3_kpconv_so3_contract': (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     'se3_kpconv_sums_bytes': (_sz, [_i64, _i32]),
     'se3_kpconv_so3_gather_sums': (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp]),
     'se3_kpconv_weight_pieces_bytes': (_sz, [_i32, _i32]),

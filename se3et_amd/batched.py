@@ -217,12 +217,10 @@ def forward_pairs(model, data_dict, with_registration=True):
         raise RuntimeError('forward_pairs: an even number of stacked clouds is required (ref0, src0, ref1, src1, ...)')
     B = nc // 2
     # GroupNorm statistics per pair, at every pyramid stage
-    seg = {}
-    for pts, ln in zip(data_dict['points'], lengths):
+    seg = []
+    for ln in lengths:
         o = _offsets(ln.tolist())
-        cuts = [o[2 * p] for p in range(B)] + [o[-1]]
-        if seg.setdefault(pts.shape[0], cuts) != cuts:
-            raise RuntimeError('forward_pairs: two pyramid stages with the same point count but different pair boundaries')
+        seg.append([o[2 * p] for p in range(B)] + [o[-1]])
     with SF.norm_segments(seg):
         feats_list = model.backbone(data_dict['features'], data_dict)
     feats_c, feats_f = feats_list[-1], feats_list[0]

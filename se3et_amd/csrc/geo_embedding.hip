@@ -525,7 +525,8 @@ __global__ void __launch_bounds__(256) embedding_table_refresh_kernel(const floa
     for (int e = 0; e < kTabE; e++)
       if (e0 + e < entries) tab[(size_t)(e0 + e) * C + o] = make_float2((float)(f[e] + bo), (float)df[e]);
   }
-  // 3. the last workgroup to finish publishes the hash (modulo: concurrent rebuilds of the same table stay consistent)
+  // 3. the last workgroup to finish publishes the hash.  ONE writer per (table, state): the callers keep a table per launch stream
+  //    (se3et_amd/ops.py _embedding_table) -- two streams rebuilding one table at once would mix their completion counts
   __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -571,11 +572,10 @@ static int geo_embedding(const float* points, const int64_t* knn, int N, int C, 
   P.factor_a = 180.0f / (sigma_a * 3.14159265358979323846f);
   P.d_inv_h = d_entries_per_unit; P.a_inv_h = a_entries_per_unit;
   P.d_entries = d_entries; P.a_entries = a_entries;
-  // channel-slice form when the angle table slice fits in LDS (SE3ET: 418 entries x 256 B) and the caller brought the record workspace;
-  // SE3_GEO_EMB=rows forces the form above
+  // channel-slice form when the angle table slice fits in LDS (SE3ET: 418 entries x 256 B) and the caller brought the record workspace
+  // (workspace = NULL selects the single-kernel form above)
   const size_t slice_lds = (size_t)a_entries * 16 * sizeof(float4) + (size_t)(kSliceThreads / 64) * 2 * kRecBytes;
-  static const char* form = getenv("SE3_GEO_EMB");
-  if (C % kCS == 0 && slice_lds <= 150 * 1024 && workspace != nullptr && !(form && form[0] == 'r')) {
+  if (C % kCS == 0 && slice_lds <= 150 * 1024 && workspace != nullptr) {
     SE3_REQUIRE(workspace_bytes >= se3_geo_embedding_workspace_bytes(N), SE3_ERR_WORKSPACE, "geo_embedding: workspace too small");
     SE3_REQUIRE((long long)N * N < (1ll << 31) / 4, SE3_ERR_UNSUPPORTED, "geo_embedding: N = %d too large for the record index", N);
     static bool attr_set = false;

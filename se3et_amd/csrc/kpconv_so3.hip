@@ -20,7 +20,6 @@
 namespace {
 
 constexpr int kK = 15, kA = 6, kS = 6, kMaxNN = 64;
-constexpr int kFRow = 732;            // floats per (point, 8-channel chunk) row of the F layout (csrc/kpconv_contract.hip: kRowPad)
 
 struct ConvTables {
   float kp[kK][3];
@@ -39,18 +38,14 @@ __device__ constexpr int kBuiltinKidx[kK][kA] = {{0, 1, 1, 1, 1, 2}, {1, 0, 1, 2
 __device__ constexpr int kBuiltinRidx[kA][kA] = {{0, 3, 3, 3, 3, 5}, {1, 0, 4, 5, 2, 1}, {2, 2, 0, 4, 5, 4},
                                                  {3, 5, 2, 0, 4, 3}, {4, 4, 5, 2, 0, 2}, {5, 1, 1, 1, 1, 0}};
 
-// MODE 1: leave the kernel-point sums F themselves for the round-2 matrix-core contraction (csrc/kpconv_contract.hip) in its tile order
-// [channel chunk of 8][point (padded to 16)][k * 6 + a][8 channels] instead of the 2.4x larger slot sums G.
-template <bool BUILTIN, int MODE = 0, int FL = 8>      // FL: gathered rows in flight per thread (16 measured 10 % slower)
+template <bool BUILTIN, int FL = 8>      // FL: gathered rows in flight per thread (16 measured 10 % slower)
 __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restrict__ q_pts, const float* __restrict__ s_pts,
                                                             const int64_t* __restrict__ idx, const float* __restrict__ x,
                                                             ConvTables T, float inv_sigma, int64_t P, int64_t Ns, int NN,
-                                                            int Cin, float* __restrict__ G, int64_t P16 = 0) {
+                                                            int Cin, float* __restrict__ G) {
   __shared__ float w[kMaxNN][kK + 1];
   __shared__ int64_t nb[kMaxNN];
   __shared__ unsigned xrow[kMaxNN];      // element offset of the neighbour's feature row (clamped: invalid rows carry weight 0)
-  extern __shared__ __align__(16) float fstage[];      // MODE 1: the point's (Cin / 8) rows of kFRow floats
-  constexpr bool FOUT = MODE != 0;
   const int64_t p = blockIdx.x;
   const int cols = kA * Cin;
   const float qx = q_pts[3 * p], qy = q_pts[3 * p + 1], qz = q_pts[3 * p + 2];
@@ -84,13 +79,8 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
   // entries carry weight, so the loop stops after the last valid one (rounded up to the 8 rows in flight; skipped terms are
   // exact zeros, the sums are unchanged)
   const int NV8 = (last_s + FL - 1) & ~(FL - 1);
-  // FOUT: channel blocks of up to 128 (the staged rows of a block: 47 KB of LDS); otherwise one pass over all columns
-  const int CBw = FOUT ? min(Cin, 128) : Cin;
-  for (int cb0 = 0; cb0 < Cin; cb0 += CBw) {
-  const int cw = min(CBw, Cin - cb0);                  // (the last block of a channel count that is not a multiple of 128 is narrower)
-  for (int lc = threadIdx.x; lc < kA * cw; lc += blockDim.x) {
-    const int a = lc / cw, c = cb0 + (lc - a * cw);
-    const int col = a * Cin + c;
+  for (int col = threadIdx.x; col < cols; col += blockDim.x) {
+    const int a = col / Cin, c = col - a * Cin;
     float f[kK];
 #pragma unroll
     for (int k = 0; k < kK; k++) f[k] = 0.f;
@@ -105,12 +95,6 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
 #pragma unroll
         for (int k = 0; k < kK; k++) f[k] = fmaf(w[n0 + u][k], xv[u], f[k]);
       }
-    }
-    if (MODE == 1) {      // row of (point, channel chunk): 15 x 6 x 8 values, an 8-float zero slot, 4 pad = kFRow floats: staged in LDS, written below
-      float* Fp = fstage + ((c - cb0) >> 3) * kFRow + a * 8 + (c & 7);
-#pragma unroll
-      for (int k = 0; k < kK; k++) Fp[k * kA * 8] = f[k];
-      continue;
     }
     float* Gp = G + p * (int64_t)(kA * kS * kA) * Cin;
 #pragma unroll
@@ -131,21 +115,6 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
 #pragma unroll
       for (int sl = 0; sl < kS; sl++) __builtin_nontemporal_store(s[sl], &Gp[((int64_t)(r * kS + sl) * kA + t) * Cin + c]);
     }
-  }
-  if (MODE == 1) {   // zero slot + pad of every row, then the block's rows leave LDS as whole 2928-byte runs (float4 per lane; written as
-                     // 4-byte scatters straight from the column threads each 192-byte run came from three different store instructions)
-    for (int e = threadIdx.x; e < (cw >> 3) * (kFRow - kK * kA * 8); e += blockDim.x) {
-      const int cc = e / (kFRow - kK * kA * 8), w = e - cc * (kFRow - kK * kA * 8);
-      fstage[cc * kFRow + kK * kA * 8 + w] = 0.f;
-    }
-    __syncthreads();
-    const int row4 = kFRow / 4;
-    for (int e = threadIdx.x; e < (cw >> 3) * row4; e += blockDim.x) {
-      const int cc = e / row4, q = e - cc * row4;
-      reinterpret_cast<float4*>(G + ((int64_t)((cb0 >> 3) + cc) * P16 + p) * kFRow)[q] = reinterpret_cast<const float4*>(fstage + cc * kFRow)[q];
-    }
-    __syncthreads();                                     // the next block overwrites the staging rows
-  }
   }
 }
 
@@ -263,30 +232,6 @@ extern "C" int se3_kpconv_so3_gather(const float* q_pts, const float* s_pts, con
     kpconv_gather_kernel<false><<<(unsigned)num_queries, threads, 0, (hipStream_t)stream>>>(
         q_pts, s_pts, idx, x, T, 1.0f / sigma, num_queries, num_support, num_neighbors, in_channels, G);
   SE3_CHECK_LAUNCH("kpconv_so3_gather");
-  return SE3_OK;
-}
-
-// Same gather, output F for se3_kpconv_so3_contract: layout [Cin / 8][ceil16(P)][732] (732 = 15 * 6 * 8 values + 8 zeros + 4 pad).
-extern "C" int se3_kpconv_so3_gather_points(const float* q_pts, const float* s_pts, const int64_t* idx, const float* x,
-                                            const float* kernel_points_host, float sigma, int64_t num_queries, int64_t num_support,
-                                            int num_neighbors, int in_channels, float* F, void* stream) {
-  SE3_REQUIRE(q_pts && s_pts && idx && x && kernel_points_host && F, SE3_ERR_INVALID_ARG, "kpconv_so3_gather_points: null pointer");
-  SE3_REQUIRE(num_neighbors >= 1 && num_neighbors <= kMaxNN, SE3_ERR_UNSUPPORTED,
-              "kpconv_so3_gather_points: %d neighbours (max %d)", num_neighbors, kMaxNN);
-  SE3_REQUIRE(in_channels >= 8 && in_channels % 8 == 0 && sigma > 0.f, SE3_ERR_INVALID_ARG,
-              "kpconv_so3_gather_points: channels must be a multiple of 8");
-  if (num_queries == 0) return SE3_OK;
-  ConvTables T = {};
-  for (int k = 0; k < kK; k++)
-    for (int d = 0; d < 3; d++) T.kp[k][d] = kernel_points_host[3 * k + d];
-  const int cols = kA * in_channels;
-  const int threads = cols >= 256 ? 256 : (cols >= 128 ? 128 : 64);
-  const int64_t P16 = (num_queries + 15) / 16 * 16;
-  // rows staged in LDS in blocks of up to 128 input channels (47 KB: three workgroups per CU) and written as whole runs
-  const size_t stage_bytes = (size_t)((in_channels < 128 ? in_channels : 128) / 8) * kFRow * sizeof(float);
-  kpconv_gather_kernel<true, 1><<<(unsigned)num_queries, threads, stage_bytes, (hipStream_t)stream>>>(
-      q_pts, s_pts, idx, x, T, 1.0f / sigma, num_queries, num_support, num_neighbors, in_channels, F, P16);
-  SE3_CHECK_LAUNCH("kpconv_so3_gather_points");
   return SE3_OK;
 }
 

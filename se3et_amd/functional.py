@@ -119,32 +119,43 @@ def apply_transform(points, T):
 # B: backbone ops
 # ---------------------------------------------------------------------------------------------------------------------
 class norm_segments:
-    """Context: while active, GroupNorm over a stacked tensor whose first dim is one of `point_offsets` keys (the stacked point
-    count of a pyramid stage) normalises every pair separately: {points_in_stage: [0, end of pair 0, end of pair 1, ...]}.
-    Thread-local (pairs may be processed by several host threads)."""
+    """Context: while active, GroupNorm inside the backbone normalises every pair of a stacked batch separately.  `stage_offsets[i]` =
+    [0, end of pair 0, end of pair 1, ...] in stacked points of pyramid stage i; the backbone announces the stage each block runs at
+    (`norm_segments.at_stage(i)`), so two stages that happen to hold the same number of points cannot be confused.  Thread-local (batches
+    may be processed by several host threads)."""
     _tls = threading.local()
 
-    def __init__(self, point_offsets):
-        self.point_offsets = point_offsets
+    def __init__(self, stage_offsets):
+        self.stage_offsets = [list(o) for o in stage_offsets]
 
     def __enter__(self):
-        self.prev = getattr(norm_segments._tls, 'current', None)
-        norm_segments._tls.current = self.point_offsets
+        self.prev = (getattr(norm_segments._tls, 'current', None), getattr(norm_segments._tls, 'stage', None))
+        norm_segments._tls.current, norm_segments._tls.stage = self.stage_offsets, None
         return self
 
     def __exit__(self, *exc):
-        norm_segments._tls.current = self.prev
+        norm_segments._tls.current, norm_segments._tls.stage = self.prev
         return False
+
+    @staticmethod
+    def at_stage(i, support=None):
+        """Called by the backbone in front of the blocks of pyramid stage i (a no-op outside a norm_segments context).  A strided block
+        also normalises its INPUT rows, which live at the finer stage `support`; a tensor belongs to the one of the two stages whose point
+        count it has (grid subsampling only removes points per cloud: equal totals mean equal pair boundaries)."""
+        norm_segments._tls.stage = None if i is None else ((i,) if support is None else (i, support))
 
 
 def group_norm_rows(x, weight, bias, groups, eps, leaky_slope=None, residual=None, x_bias=None, segments=None):
     """GroupNorm over (rows x channels-in-group) for x (..., C) with ALL leading dims pooled into the statistics
     (GroupNormEPN / kpconv GroupNorm), optionally `+ residual` then LeakyReLU, fused in one pass."""
     if segments is None:
-        ctx = getattr(norm_segments._tls, 'current', None)
-        if ctx is not None:
-            offs = ctx.get(x.shape[0])
-            if offs is not None and len(offs) > 2:
+        ctx, stage = getattr(norm_segments._tls, 'current', None), getattr(norm_segments._tls, 'stage', None)
+        if ctx is not None and stage is not None:
+            offs = next((ctx[i] for i in stage if ctx[i][-1] == x.shape[0]), None)
+            if offs is None:
+                raise RuntimeError('group_norm_rows: %d rows inside a block of pyramid stage(s) %s holding %s stacked points'
+                                   % (x.shape[0], stage, [ctx[i][-1] for i in stage]))
+            if len(offs) > 2:
                 mult = x.numel() // x.shape[-1] // x.shape[0]
                 segments = [o * mult for o in offs]
     if AG.needs_grad(x, weight, bias, residual, x_bias):

@@ -98,21 +98,27 @@ class E2PN(nn.Module):
     def forward(self, feats, data_dict):
         pts, nb = data_dict['points'], data_dict['neighbors']
         sub, up = data_dict['subsampling'], data_dict['upsampling']
+        at_stage = SF.norm_segments.at_stage          # per-pair GroupNorm statistics of a stacked batch need the stage a block runs at
+        at_stage(0)
         x = self.preprocess(feats)
         x = self.encoder1_1(x, pts[0], pts[0], nb[0])
         x = self.encoder1_2(x, pts[0], pts[0], nb[0])
         inv = {}
         for s in range(2, self.num_stages + 1):
+            at_stage(s - 1, support=s - 2)
             x = getattr(self, 'encoder%d_1' % s)(x, pts[s - 1], pts[s - 2], sub[s - 2])
+            at_stage(s - 1)
             x = getattr(self, 'encoder%d_2' % s)(x, pts[s - 1], pts[s - 1], nb[s - 1])
             x = getattr(self, 'encoder%d_3' % s)(x, pts[s - 1], pts[s - 1], nb[s - 1])
             inv[s] = getattr(self, 'equ2inv%d' % s)(x)
         feats_list = [x]
         latent = inv[self.num_stages]
         for s in range(self.num_stages - 1, 1, -1):
+            at_stage(s - 1)
             latent = torch.cat((nearest_upsample(latent, up[s - 1]), inv[s]), 1)
             latent = getattr(self, 'decoder%d' % s)(latent)
             feats_list.append(latent)
+        at_stage(None)
         feats_list.reverse()
         return feats_list
 

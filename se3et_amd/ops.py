@@ -899,23 +899,26 @@ def _embedding_table(weight, bias, div_term, x_max, per_unit):
     DEVICE by se3_embedding_table_refresh in front of every use: the kernel hashes the current weight values and rebuilds the
     table when they differ from the ones it was built from.  The host cache below only holds the buffers (keyed by the
     storage addresses): identity / version bookkeeping of the Parameters plays no role, so `p.data.copy_()`, `module.to()`,
-    `load_state_dict` and optimizer steps can never leave a stale table behind."""
+    `load_state_dict` and optimizer steps can never leave a stale table behind.  One table + validation state PER LAUNCH STREAM: the
+    refresh kernels count their completed workgroups in the state block, which two streams rebuilding the same table at the same time
+    (first use under `bench.py --inflight 2`) would mix -- calls on one stream are ordered, so a per-stream table has one writer."""
     weight, bias, div_term = weight.detach(), bias.detach(), div_term.detach()
     for t, name in ((weight, 'weight'), (bias, 'bias'), (div_term, 'div_term')):
         _req(t, torch.float32, 'embedding ' + name)
     C = weight.shape[0]
     n = int(math.ceil(x_max * per_unit)) + 2
-    key = (str(weight.device), weight.data_ptr(), bias.data_ptr(), div_term.data_ptr(), C, n, float(per_unit))
+    stream = _stream()
+    key = (str(weight.device), stream.value, weight.data_ptr(), bias.data_ptr(), div_term.data_ptr(), C, n, float(per_unit))
     hit = _emb_table_cache.get(key)
     if hit is None:
         hit = (torch.empty((n, C, 2), dtype=torch.float32, device=weight.device),
                torch.zeros((lib().se3_embedding_table_state_bytes(),), dtype=torch.uint8, device=weight.device))
-        if len(_emb_table_cache) > 16:
+        if len(_emb_table_cache) > 32:
             _emb_table_cache.clear()
         _emb_table_cache[key] = hit
     tab, state = hit
     check(lib().se3_embedding_table_refresh(weight.data_ptr(), bias.data_ptr(), div_term.data_ptr(), C, n, float(per_unit),
-                                            tab.data_ptr(), state.data_ptr(), _stream()), 'se3_embedding_table_refresh')
+                                            tab.data_ptr(), state.data_ptr(), stream), 'se3_embedding_table_refresh')
     return tab
 
 
