@@ -413,6 +413,18 @@ int se3_mutual_topk_mask(const float* scores, const uint8_t* row_masks, const ui
 
 
 
+/* grouping.anchor_query (grouping_cuda_kernel.cu:166-233, grouping_cuda.cpp:88-108): anchor_weights (b, np, na, ks, nn) =
+ * (kw_k - r)^2 + ((kh_k - theta) r)^2 for the local neighbour coordinates grouped_xyz (b, 3, np, nn), r = |x| + 1e-6,
+ * theta = acos(x . anchors[a] / r), kernel_points (ks, 2) = (radial, angular) positions.  (sample_idx, grouped_indices and nq of the
+ * reference's signature are not read by its kernel.) */
+int se3_vgtk_anchor_query(const float* grouped_xyz, const float* anchors, const float* kernel_points, int batch, int num_points,
+                          int num_neighbors, int num_anchors, int kernel_size, float* anchor_weights, void* stream);
+/* grouping.initial_anchor_query (grouping_cuda_kernel.cu:102-152, grouping_cuda.cpp:138-158): centers (b, 3, nc), xyz (m, 3) shared by the
+ * batch, kernel_points (ks, na, 3): anchor_weights / anchor_counts (b, ks, nc, na) = sum / number over the points within `radius` of the
+ * centre of the positive part of 1 - |kernel point + centre - point|^2 / sigma.  Summed in point order (the reference: atomicAdd). */
+int se3_vgtk_initial_anchor_query(const float* centers, const float* xyz, const float* kernel_points, int batch, int num_centers,
+                                  int num_points, int num_anchors, int kernel_size, float radius, float sigma, float* anchor_weights,
+                                  float* anchor_counts, void* stream);
 /* ---- EPN toolkit (vgtk) equivalents: SURVEY section 8f row 4 -------------------------------------------------------------------------
  * Replace the CUDA extensions vgtk.cuda.{gathering, grouping, zpconv} (geotransformer/modules/e2pn/vgtk/vgtk/cuda: gathering_cuda.cpp,
  * grouping_cuda.cpp, zpconv_cuda.cpp and their *_kernel.cu) entry for entry: same tensor layouts (channel-first, int32 indices), same

@@ -3,7 +3,7 @@
 Only tests/ may import this.  numpy loops, small cases only.  The kernels that DO have an importable twin
 (vgtk/spconv/functional.py:373-399 inter_zpconv_grouping_naive; gather = torch.gather) are pinned by fixtures generated from the
 genuine reference (tests/golden/vgtk_ops.npz); the three below restate the .cu sources -- the reference holds no test for them:
-'parity unpinned' beyond the sources for ball_query, furthest_point_sampling and the intra convolution."""
+'parity unpinned' beyond the sources for ball_query, furthest_point_sampling, the intra convolution and the two anchor queries."""
 import math
 
 import numpy as np
@@ -59,3 +59,41 @@ def intra_zpconv(nbr, w, feats):
     """zpconv_cuda_kernel.cu:119-156: out[b, c, k, p, a] = sum_n w[a, k, n] feats[b, c, p, nbr[a, n]]."""
     g = feats[:, :, :, nbr]                                     # (b, c, p, a, n)
     return np.einsum('bcpan,akn->bckpa', g, w)
+
+
+def anchor_query(grouped_xyz, anchors, kernel_points):
+    """grouping_cuda_kernel.cu:166-233: grouped_xyz (b, 3, p, nn) -> (b, p, na, ks, nn), float32 arithmetic."""
+    g = grouped_xyz.astype(np.float32)
+    x, y, z = g[:, 0], g[:, 1], g[:, 2]                                    # (b, p, nn)
+    norm = (np.sqrt(x * x + y * y + z * z) + np.float32(1e-6)).astype(np.float32)
+    a = anchors.astype(np.float32)
+    dot = x[:, :, None, :] * a[None, None, :, 0, None] + y[:, :, None, :] * a[None, None, :, 1, None] + z[:, :, None, :] * a[None, None, :, 2, None]
+    with np.errstate(invalid='ignore'):
+        theta = np.arccos((dot / norm[:, :, None, :]).astype(np.float32)).astype(np.float32)      # (b, p, na, nn)
+    kw, kh = kernel_points[:, 0].astype(np.float32), kernel_points[:, 1].astype(np.float32)
+    dr = kw[None, None, None, :, None] - norm[:, :, None, None, :]
+    da = (kh[None, None, None, :, None] - theta[:, :, :, None, :]) * norm[:, :, None, None, :]
+    return (dr * dr + da * da).astype(np.float32)
+
+
+def initial_anchor_query(centers, xyz, kernel_points, radius, sigma):
+    """grouping_cuda_kernel.cu:102-152: centers (b, 3, nc), xyz (m, 3), kernel_points (ks, na, 3) -> weights, counts (b, ks, nc, na);
+    sums in point order, float32."""
+    b, _, nc = centers.shape
+    ks, na, _ = kernel_points.shape
+    w = np.zeros((b, ks, nc, na), np.float32)
+    n = np.zeros((b, ks, nc, na), np.float32)
+    x = xyz.astype(np.float32)
+    for bi in range(b):
+        c = centers[bi].astype(np.float32).T                              # (nc, 3)
+        for pm in range(x.shape[0]):
+            d = c - x[pm]
+            near = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]) <= np.float32(radius)
+            for pn in np.nonzero(near)[0]:
+                kp = kernel_points.astype(np.float32) + c[pn]                # (ks, na, 3)
+                e = kp - x[pm]
+                d2k = np.sqrt((e[..., 0] * e[..., 0] + e[..., 1] * e[..., 1]) + e[..., 2] * e[..., 2]).astype(np.float32)
+                wt = (np.float32(1) - d2k * d2k / np.float32(sigma)).astype(np.float32)
+                w[bi, :, pn, :] += np.where(wt > 0, wt, np.float32(0))
+                n[bi, :, pn, :] += np.float32(1)
+    return w, n

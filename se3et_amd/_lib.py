@@ -78,6 +78,8 @@ SIGNATURES = {
     'se3_weighted_procrustes_segments': (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _f32, _f32, _vp, _vp]),
     'se3_vgtk_gather_points_fwd': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     'se3_vgtk_gather_points_bwd': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    'se3_vgtk_anchor_query': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    'se3_vgtk_initial_anchor_query': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp]),
     'se3_vgtk_ball_query': (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
     'se3_vgtk_furthest_point_sampling': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     'se3_vgtk_inter_zpconv_fwd': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),

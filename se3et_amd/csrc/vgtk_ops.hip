@@ -24,17 +24,92 @@ __global__ void gather_points_fwd_kernel(const float* __restrict__ points, const
   out[((int64_t)b * c + ci) * m + j] = points[((int64_t)b * c + ci) * n + idx[(int64_t)b * m + j]];
 }
 
-// grad_points[b, c, i] = sum_{j: idx[b, j] = i} grad_out[b, c, j], summed in ascending j (one thread per (b, c) row walks the indices)
-__global__ void gather_points_bwd_kernel(const float* __restrict__ grad_out, const int* __restrict__ idx, int batch, int c, int n, int m,
-                                         float* __restrict__ grad_points) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;                   // b * c + ci
-  if (row >= batch * c) return;
-  const int b = row / c;
-  float* gp = grad_points + (int64_t)row * n;
-  for (int i = 0; i < n; i++) gp[i] = 0.f;
-  const float* go = grad_out + (int64_t)row * m;
+// grad_points[b, c, i] = sum_{j: idx[b, j] = i} grad_out[b, c, j], summed in ascending j (the reference scatters with atomicAdd: arrival order).
+// Gather form, no atomics, no workspace: a workgroup owns 64 target points of one batch element; every thread (target, channel group) scans
+// the index list -- staged through LDS in chunks, read as broadcasts -- and adds the matching columns of its channels as it meets them.
+constexpr int kGatherChunk = 2048;
+__global__ __launch_bounds__(256) void gather_points_bwd_kernel(const float* __restrict__ grad_out, const int* __restrict__ idx, int c, int n,
+                                                                int m, float* __restrict__ grad_points) {
+  __shared__ int sidx[kGatherChunk];
+  const int b = blockIdx.y, i = blockIdx.x * 64 + (threadIdx.x & 63), cg = threadIdx.x >> 6;       // 4 channel groups
   const int* ib = idx + (int64_t)b * m;
-  for (int j = 0; j < m; j++) gp[ib[j]] += go[j];
+  const float* go = grad_out + (int64_t)b * c * m;
+  // channels cg, cg + 4, ...: up to 8 running sums in registers per pass over the indices
+  for (int c0 = cg; c0 < c; c0 += 32) {
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc[u] = 0.f;
+    for (int j0 = 0; j0 < m; j0 += kGatherChunk) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < kGatherChunk && j0 + t < m; t += 256) sidx[t] = ib[j0 + t];
+      __syncthreads();
+      const int cnt = min(kGatherChunk, m - j0);
+      for (int t = 0; t < cnt; t++) {
+        if (sidx[t] == i) {
+#pragma unroll
+          for (int u = 0; u < 8; u++)
+            if (c0 + 4 * u < c) acc[u] += go[(int64_t)(c0 + 4 * u) * m + j0 + t];
+        }
+      }
+    }
+    if (i < n) {
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (c0 + 4 * u < c) grad_points[((int64_t)b * c + c0 + 4 * u) * n + i] = acc[u];
+    }
+  }
+}
+
+// ---- anchor queries (grouping_cuda_kernel.cu:102-233) ---------------------------------------------------------------------------------------
+// anchor_query: w[b, p, a, k, n] = (kw_k - r)^2 + ((kh_k - theta) r)^2 with r = |x| + 1e-6, theta = acos(x . anchor_a / r) for the local
+// neighbour coordinates x = grouped_xyz[b, :, p, n] and kernel points (kw, kh) = (radial, angular) positions.
+__global__ void anchor_query_kernel(const float* __restrict__ grouped_xyz, const float* __restrict__ anchors, const float* __restrict__ kernel_points,
+                                    int np, int nn, int na, int ks, float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;        // (point, neighbour) of batch blockIdx.y
+  const int b = blockIdx.y;
+  const int64_t pn = (int64_t)np * nn;
+  if (e >= pn) return;
+  const float* g = grouped_xyz + (int64_t)b * 3 * pn;
+  const float x = g[e], y = g[pn + e], z = g[2 * pn + e];
+  const float norm = sqrtf(x * x + y * y + z * z) + 1e-6f;
+  const int64_t pi = e / nn, ni = e - pi * nn;
+  float* o = out + (int64_t)b * np * na * ks * nn;
+  for (int ai = 0; ai < na; ai++) {
+    const float theta = acosf((x * anchors[3 * ai] + y * anchors[3 * ai + 1] + z * anchors[3 * ai + 2]) / norm);
+    for (int ki = 0; ki < ks; ki++) {
+      const float dr = kernel_points[2 * ki] - norm, da = (kernel_points[2 * ki + 1] - theta) * norm;
+      o[(((pi * na) + ai) * ks + ki) * nn + ni] = dr * dr + da * da;
+    }
+  }
+}
+
+// initial_anchor_query: for every centre within `radius` of a point of xyz (m, 3; shared by the batch) and every kernel point kp[k, a] placed at
+// the centre: weights[b, k, c, a] += max-gated 1 - |kp + centre - point|^2 / sigma (only positive terms), count[b, k, c, a] += 1.  The reference
+// adds with atomicAdd from one thread per (point, k); here one thread per output walks the points in index order (deterministic).
+__global__ void initial_anchor_query_kernel(const float* __restrict__ centers, const float* __restrict__ xyz, const float* __restrict__ kernel_points,
+                                            int nc, int m, int na, int ks, float radius, float sigma, float* __restrict__ weights,
+                                            float* __restrict__ counts) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;        // ((k, centre), anchor) of batch blockIdx.y
+  const int b = blockIdx.y;
+  if (e >= (int64_t)ks * nc * na) return;
+  const int an = (int)(e % na), pn = (int)((e / na) % nc), kn = (int)(e / ((int64_t)na * nc));
+  const float* cb = centers + (int64_t)b * 3 * nc;
+  const float cx = cb[pn], cy = cb[nc + pn], cz = cb[2 * nc + pn];
+  const float kx = kernel_points[(kn * na + an) * 3] + cx, ky = kernel_points[(kn * na + an) * 3 + 1] + cy,
+              kz = kernel_points[(kn * na + an) * 3 + 2] + cz;
+  float w = 0.f, cnt = 0.f;
+  for (int pm = 0; pm < m; pm++) {
+    const float x = xyz[3 * pm], y = xyz[3 * pm + 1], z = xyz[3 * pm + 2];
+    const float d2c = sqrtf((cx - x) * (cx - x) + (cy - y) * (cy - y) + (cz - z) * (cz - z));
+    if (d2c <= radius) {
+      const float d2k = sqrtf((kx - x) * (kx - x) + (ky - y) * (ky - y) + (kz - z) * (kz - z));
+      const float wt = 1.f - (d2k * d2k / sigma);
+      if (wt > 0.f) w += wt;
+      cnt += 1.f;
+    }
+  }
+  weights[(int64_t)b * ks * nc * na + e] = w;
+  counts[(int64_t)b * ks * nc * na + e] = cnt;
 }
 
 // ---- ball_query: the first `nsample` support points (ascending index) with d^2 < r^2; short lists repeat cyclically ---------------------
@@ -276,9 +351,34 @@ extern "C" int se3_vgtk_gather_points_bwd(const float* grad_out, const int32_t* 
                                           int num_indices, float* grad_points, void* stream) {
   SE3_REQUIRE(grad_out && idx && grad_points, SE3_ERR_INVALID_ARG, "vgtk_gather_points_bwd: null pointer");
   SE3_REQUIRE(batch >= 1 && channels >= 1 && num_points >= 1 && num_indices >= 0, SE3_ERR_INVALID_ARG, "vgtk_gather_points_bwd: bad sizes");
-  gather_points_bwd_kernel<<<(unsigned)se3_cdiv((int64_t)batch * channels, 64), 64, 0, (hipStream_t)stream>>>(
-      grad_out, idx, batch, channels, num_points, num_indices, grad_points);
+  gather_points_bwd_kernel<<<dim3((unsigned)se3_cdiv(num_points, 64), (unsigned)batch), 256, 0, (hipStream_t)stream>>>(
+      grad_out, idx, channels, num_points, num_indices, grad_points);
   SE3_CHECK_LAUNCH("vgtk_gather_points_bwd");
+  return SE3_OK;
+}
+
+extern "C" int se3_vgtk_anchor_query(const float* grouped_xyz, const float* anchors, const float* kernel_points, int batch, int num_points,
+                                     int num_neighbors, int num_anchors, int kernel_size, float* anchor_weights, void* stream) {
+  SE3_REQUIRE(grouped_xyz && anchors && kernel_points && anchor_weights, SE3_ERR_INVALID_ARG, "vgtk_anchor_query: null pointer");
+  SE3_REQUIRE(batch >= 1 && num_points >= 1 && num_neighbors >= 1 && num_anchors >= 1 && kernel_size >= 1, SE3_ERR_INVALID_ARG,
+              "vgtk_anchor_query: bad sizes");
+  const dim3 grid((unsigned)se3_cdiv((int64_t)num_points * num_neighbors, 256), (unsigned)batch);
+  anchor_query_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(grouped_xyz, anchors, kernel_points, num_points, num_neighbors, num_anchors,
+                                                            kernel_size, anchor_weights);
+  SE3_CHECK_LAUNCH("vgtk_anchor_query");
+  return SE3_OK;
+}
+
+extern "C" int se3_vgtk_initial_anchor_query(const float* centers, const float* xyz, const float* kernel_points, int batch, int num_centers,
+                                             int num_points, int num_anchors, int kernel_size, float radius, float sigma,
+                                             float* anchor_weights, float* anchor_counts, void* stream) {
+  SE3_REQUIRE(centers && xyz && kernel_points && anchor_weights && anchor_counts, SE3_ERR_INVALID_ARG, "vgtk_initial_anchor_query: null pointer");
+  SE3_REQUIRE(batch >= 1 && num_centers >= 1 && num_points >= 0 && num_anchors >= 1 && kernel_size >= 1, SE3_ERR_INVALID_ARG,
+              "vgtk_initial_anchor_query: bad sizes");
+  const dim3 grid((unsigned)se3_cdiv((int64_t)kernel_size * num_centers * num_anchors, 256), (unsigned)batch);
+  initial_anchor_query_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(centers, xyz, kernel_points, num_centers, num_points, num_anchors,
+                                                                    kernel_size, radius, sigma, anchor_weights, anchor_counts);
+  SE3_CHECK_LAUNCH("vgtk_initial_anchor_query");
   return SE3_OK;
 }
 

@@ -4,6 +4,8 @@ Mirror of the call sites of vgtk.cuda.{gathering, grouping, zpconv} in the refer
     vgtk/spconv/functional.py:102-129  Gathering (autograd)            -> Gathering, gather_points
     vgtk/pc/sample.py:54-60            ball_query_index                -> ball_query_index
     vgtk/pc/sample.py:62-80            furthest_sample_index           -> furthest_sample_index
+    vgtk/so3conv/functional.py:108-109 initial_anchor_query            -> initial_anchor_query
+    vgtk/spconv/functional.py:512      cuda_nn.anchor_query            -> anchor_query
     vgtk/spconv/functional.py:314-335  InterZPConvGrouping (autograd)  -> InterZPConvGrouping, inter_zpconv_grouping
     vgtk/spconv/functional.py:211-238  IntraZPConvGrouping (autograd)  -> IntraZPConvGrouping, intra_zpconv_grouping
 Same tensor layouts (channel-first float32, int32 indices), CUDA tensors only (on ROCm 'cuda' is the HIP device).  No SE3ET model
@@ -53,6 +55,36 @@ def ball_query_index(query_points, support_points, radius, n_sample):
     idx = torch.empty((b, m, int(n_sample)), dtype=torch.int32, device=q.device)
     check(lib().se3_vgtk_ball_query(q.data_ptr(), s.data_ptr(), b, n, m, float(radius), int(n_sample), idx.data_ptr(), _stream()), 'se3_vgtk_ball_query')
     return idx
+
+
+def anchor_query(sample_idx, grouped_indices, grouped_xyz, anchors, kernel_points, nq=0):
+    """grouping.anchor_query (grouping_cuda.cpp:88-108): grouped_xyz (b, 3, p, nn) local coordinates, anchors (na, 3), kernel_points (ks, 2)
+    -> [anchor_weights (b, p, na, ks, nn)].  sample_idx / grouped_indices / nq are accepted for signature compatibility (the reference's
+    kernel does not read them)."""
+    g = _req(grouped_xyz.contiguous(), torch.float32, 'grouped_xyz', 4)
+    a, k = _req(anchors.contiguous(), torch.float32, 'anchors', 2), _req(kernel_points.contiguous(), torch.float32, 'kernel_points', 2)
+    b, three, p, nn_ = g.shape
+    if three != 3 or a.shape[1] != 3 or k.shape[1] != 2:
+        raise RuntimeError('anchor_query: grouped_xyz (b, 3, p, nn), anchors (na, 3), kernel_points (ks, 2)')
+    out = torch.empty((b, p, a.shape[0], k.shape[0], nn_), dtype=torch.float32, device=g.device)
+    check(lib().se3_vgtk_anchor_query(g.data_ptr(), a.data_ptr(), k.data_ptr(), b, p, nn_, a.shape[0], k.shape[0], out.data_ptr(), _stream()),
+          'se3_vgtk_anchor_query')
+    return [out]
+
+
+def initial_anchor_query(frag, centers, kernels, r, sigma):
+    """vgtk/so3conv/functional.py:108-109: frag (m, 3) points, centers (b, 3, nc), kernels (ks, na, 3) -> [weights, counts] (b, ks, nc, na)."""
+    c, x = _req(centers.contiguous(), torch.float32, 'centers', 3), _req(frag.contiguous(), torch.float32, 'frag', 2)
+    k = _req(kernels.contiguous(), torch.float32, 'kernels', 3)
+    b, three, nc = c.shape
+    if three != 3 or x.shape[1] != 3 or k.shape[2] != 3:
+        raise RuntimeError('initial_anchor_query: centers (b, 3, nc), frag (m, 3), kernels (ks, na, 3)')
+    ks, na = k.shape[0], k.shape[1]
+    w = torch.empty((b, ks, nc, na), dtype=torch.float32, device=c.device)
+    n = torch.empty_like(w)
+    check(lib().se3_vgtk_initial_anchor_query(c.data_ptr(), x.data_ptr(), k.data_ptr(), b, nc, x.shape[0], na, ks, float(r), float(sigma),
+                                              w.data_ptr(), n.data_ptr(), _stream()), 'se3_vgtk_initial_anchor_query')
+    return [w, n]
 
 
 def furthest_sample_index(pc, n_sample, lazy_sample=False):

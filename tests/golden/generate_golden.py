@@ -209,7 +209,7 @@ def gen_micro(variant, fname):
     np.savez_compressed(os.path.join(HERE, fname), **res)
 
 
-def gen_synthw(variant, fname, pair='micro'):
+def gen_synthw(variant, fname, pair='micro', keep_ops=True):
     cfg, model, (ref, src, T), dd, ops, feats, out = run_model(variant, micro=False, synth_seed=7, pair=pair)
     res = {'blocks': np.array(cfg.geotransformer.blocks), 'pair': np.array(pair), 'synth_seed': np.int64(7)}
     names, shapes, dtypes = [], [], []
@@ -219,11 +219,11 @@ def gen_synthw(variant, fname, pair='micro'):
         dtypes.append(str(v.dtype).replace('torch.', ''))
     res['sd_names'], res['sd_shapes'], res['sd_dtypes'] = np.array(names), np.array(shapes), np.array(dtypes)
     res['lengths'] = np.stack([_np(l) for l in dd['lengths']])
-    for i in (0, 3):
+    for i in (0, 3) if keep_ops else ():
         rec = ops.get('attn_%d' % i, {})
         if 'out0' in rec:
             res['op/attn_%d/out0' % i] = rec['out0']
-    for name in ops:
+    for name in ops if keep_ops else ():
         if name.startswith('layer_'):
             res['op/%s/out0' % name] = ops[name]['out0']
     pack_outputs(out, feats, res, full=False)
@@ -392,6 +392,9 @@ if __name__ == '__main__':
         gen_synthw('se3ete2.3dmatch', 'synthw_se3ete2.npz')
         gen_synthw('se3eti2.3dmatch', 'synthw_se3eti2.npz')
         gen_synthw('se3ete.3dmatch', 'synthw_se3ete.npz')
+    if 'c1' in which or 'synthw' in which:
+        # BASELINE.json configs[0]: SE3ET-I2 on the 2k+2k pair (outputs only)
+        gen_synthw('se3eti2.3dmatch', 'synthw_se3eti2_c1.npz', pair='c1_2k', keep_ops=False)
     if 'kitti' in which or 'synthw' in which:
         gen_synthw('se3eti.kitti', 'synthw_se3eti_kitti.npz', pair='c3_4k')
     if 'vgtk' in which:

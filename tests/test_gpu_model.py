@@ -74,7 +74,8 @@ def test_micro_model_matches_reference(golden_dir, variant, fixture):
 
 
 @pytest.mark.parametrize('variant,fixture', [('se3ete2', 'synthw_se3ete2.npz'), ('se3eti2', 'synthw_se3eti2.npz'),
-                                             ('se3ete', 'synthw_se3ete.npz'), ('se3eti_kitti', 'synthw_se3eti_kitti.npz')])
+                                             ('se3ete', 'synthw_se3ete.npz'), ('se3eti_kitti', 'synthw_se3eti_kitti.npz'),
+                                             ('se3eti2', 'synthw_se3eti2_c1.npz')])      # the last one = BASELINE.json configs[0]: SE3ET-I2, 2k+2k pair
 def test_real_width_model_matches_reference(golden_dir, variant, fixture):
     g = np.load(golden_dir + '/' + fixture)
     model, dd, out = _run(variant, str(g['pair']), synth_seed=int(g['synth_seed']))

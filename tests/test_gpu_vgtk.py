@@ -99,3 +99,48 @@ def test_intra_zpconv_grouping_matches_source_restatement():
     ref = feats.detach().clone().requires_grad_(True)
     (torch.einsum('bcpan,akn->bckpa', ref[:, :, :, torch.from_numpy(nbr).long().cuda()], torch.from_numpy(w).cuda()) * cot).sum().backward()
     assert_close(feats.grad.cpu(), ref.grad.cpu(), 1e-5, 'intra zpconv backward')
+
+
+def test_anchor_queries_match_the_source_restatements():
+    """grouping.anchor_query / initial_anchor_query (no PyTorch twin in the reference: restated from the .cu sources in oracle/vgtk_oracle.py)."""
+    from oracle import vgtk_oracle as VO
+    from se3et_amd import vgtk
+    rng = np.random.default_rng(3)
+    g = (rng.standard_normal((2, 3, 37, 9)) * 0.3).astype(np.float32)
+    anchors = rng.standard_normal((12, 3)).astype(np.float32)
+    anchors /= np.linalg.norm(anchors, axis=1, keepdims=True)
+    kp = np.stack([rng.uniform(0.1, 0.6, 5), rng.uniform(0.0, 1.2, 5)], 1).astype(np.float32)
+    got, = vgtk.anchor_query(None, None, torch.from_numpy(g).cuda(), torch.from_numpy(anchors).cuda(), torch.from_numpy(kp).cuda(), 0)
+    want = VO.anchor_query(g, anchors, kp)
+    ok = np.isfinite(want)
+    assert ok.mean() > 0.99
+    assert_close(torch.from_numpy(np.where(ok, got.cpu().numpy(), 0)), np.where(ok, want, 0), 1e-4, 'anchor_query')
+    centers = (rng.uniform(-0.5, 0.5, (2, 3, 11))).astype(np.float32)
+    xyz = rng.uniform(-0.6, 0.6, (300, 3)).astype(np.float32)
+    kpts = (rng.standard_normal((4, 6, 3)) * 0.1).astype(np.float32)
+    w, n = vgtk.initial_anchor_query(torch.from_numpy(xyz).cuda(), torch.from_numpy(centers).cuda(), torch.from_numpy(kpts).cuda(), 0.35, 0.06)
+    ww, wn = VO.initial_anchor_query(centers, xyz, kpts, 0.35, 0.06)
+    assert float(wn.sum()) > 100
+    assert torch.equal(n.cpu(), torch.from_numpy(wn))
+    assert_close(w.cpu(), ww, 1e-5, 'initial_anchor_query weights')
+    w2, n2 = vgtk.initial_anchor_query(torch.from_numpy(xyz).cuda(), torch.from_numpy(centers).cuda(), torch.from_numpy(kpts).cuda(), 0.35, 0.06)
+    assert torch.equal(w2, w) and torch.equal(n2, n)          # deterministic (the reference adds with atomicAdd)
+
+
+def test_gather_points_backward_is_parallel_and_deterministic():
+    """Many sources per target, several channel groups and index chunks: the gradient equals index_add in float64 and repeats bit for bit."""
+    from se3et_amd import vgtk
+    g = torch.Generator().manual_seed(2)
+    b, c, n, m = 3, 37, 500, 5000
+    pts = torch.randn(b, c, n, generator=g).cuda().requires_grad_(True)
+    idx = torch.randint(0, n, (b, m), generator=g, dtype=torch.int32).cuda()
+    cot = torch.randn(b, c, m, generator=g).cuda()
+    (vgtk.Gathering.apply(pts, idx) * cot).sum().backward()
+    want = torch.zeros(b, c, n, dtype=torch.float64, device='cuda')
+    for bi in range(b):
+        want[bi].index_add_(1, idx[bi].long(), cot[bi].double())
+    assert_close(pts.grad.cpu(), want.float().cpu(), 1e-5, 'gather_points backward')
+    first = pts.grad.clone()
+    pts.grad = None
+    (vgtk.Gathering.apply(pts, idx) * cot).sum().backward()
+    assert torch.equal(pts.grad, first)

@@ -123,7 +123,8 @@ def test_per_op_fixtures(golden_dir):
 
 
 @pytest.mark.parametrize('variant,fixture', [('se3ete2', 'synthw_se3ete2.npz'), ('se3eti2', 'synthw_se3eti2.npz'),
-                                             ('se3eti_kitti', 'synthw_se3eti_kitti.npz')])
+                                             ('se3eti_kitti', 'synthw_se3eti_kitti.npz'),
+                                             ('se3eti2', 'synthw_se3eti2_c1.npz')])      # BASELINE.json configs[0]: SE3ET-I2 on the 2k+2k pair
 def test_real_width_forward_matches_reference(golden_dir, variant, fixture):
     """Oracle + the product's own state-dict construction (tables, names, shapes) + name-keyed synthetic weights."""
     from oracle import se3et_oracle as O
