@@ -139,6 +139,18 @@ int se3_add_layer_norm_bwd(const float* hidden, const float* hidden_bias, const 
                            const float* grad_out, int64_t rows, int64_t residual_rows, int channels, float eps, float* grad_hidden,
                            float* grad_params, void* stream);
 
+/* ---- B2 / D: dense layers on the f16 matrix cores at f32 accuracy (csrc/linear_f16.hip) ------------------------------------------------------
+ * y = x W^T [+ bias] [ReLU]: UnaryBlockEPN.mlp / LastUnaryBlockEPN.mlp (blocks_epn.py:639-665,798-852), the kpconv UnaryBlock
+ * (modules/kpconv/modules.py:54-93) and the transformer's nn.Linear layers (rpe_transformer.py:56-73, vanilla_transformer.py:22-37,
+ * output_layer.py).  weight (out_features, in_features) row-major f32, in_features a multiple of 32; se3_linear_split_weights_f16 turns it
+ * into f16 hi / lo MFMA fragments scaled by a power of two (`pieces`: se3_linear_weight_pieces_bytes bytes, once per weight version);
+ * se3_linear_f16: x (rows, in_features) with row stride x_row_stride floats (16-byte aligned rows), out (rows, out_features) with row
+ * stride out_row_stride; three products hi hi + hi lo + lo hi in f32 (2^-22 per term).  Range |x| < 65504. */
+size_t se3_linear_weight_pieces_bytes(int out_features, int in_features);
+int se3_linear_split_weights_f16(const float* weight, int out_features, int in_features, void* pieces, void* stream);
+int se3_linear_f16(const float* x, int64_t rows, int in_features, int64_t x_row_stride, const void* weight_pieces, const float* bias,
+                   int out_features, int apply_relu, float* out, int64_t out_row_stride, void* stream);
+
 /* ---- B2/B3: padded row gather and neighbour max pooling ------------------------------------------------------------
  * Replace nearest_upsample (geotransformer/modules/kpconv/functional.py:6-22), the zero-padded patch gathers of
  * experiments/se3ete.3dmatch/model.py:108-111,190-193 and max_pool (geotransformer/modules/e2pn/blocks.py:93-110).

@@ -31,10 +31,13 @@ to_device = _ops.to_device
 
 
 def linear(x, weight, bias=None, relu=False):
-    """Library GEMM x W^T [+ b]; with relu=True the activation rides in the GEMM epilogue (one launch)."""
-    if AG.needs_grad(x, weight, bias):                      # training: the same library GEMM through torch's own autograd
+    """x W^T [+ b] [ReLU]: the f16 hi / lo split kernel (csrc/linear_f16.hip, f32 accuracy) for the large inference GEMMs, a library GEMM
+    otherwise (with relu=True the activation rides in the GEMM epilogue either way)."""
+    if AG.needs_grad(x, weight, bias):                      # training: the library GEMM through torch's own autograd
         y = F.linear(x, weight, bias)
         return F.relu(y) if relu else y
+    if _ops.linear_f16_ok(x, weight):
+        return _ops.linear_f16(x, weight, bias, relu)
     if bias is None and not relu:
         if x.dim() == 2:
             return mm(x, weight.t())
@@ -50,6 +53,8 @@ def project_qk(x, w_q, b_q, w_k, b_k):
     """q and k projections of the same tensor as ONE library GEMM with stacked weights -> (q, k)."""
     if AG.needs_grad(x, w_q, b_q, w_k, b_k):
         return F.linear(x, w_q, b_q), F.linear(x, w_k, b_k)
+    if _ops.linear_f16_ok(x, w_q):           # (the split weights are cached per parameter: no stacked copy)
+        return _ops.linear_f16(x, w_q, b_q), _ops.linear_f16(x, w_k, b_k)
     qk = F.linear(x, torch.cat((w_q, w_k), 0), torch.cat((b_q, b_k), 0))
     C = w_q.shape[0]
     return qk[..., :C].contiguous(), qk[..., C:].contiguous()
@@ -285,7 +290,7 @@ def rpe_self_attention_packed(x, starts, lengths, embs, eq_embs, w_stack, b_stac
     H = num_heads
     C = x.shape[-1]
     x3 = x if x.dim() == 3 else x.unsqueeze(0)
-    proj = F.linear(x3, w_stack, b_stack)                                  # (A, R, 2C + HC [+ 4H])
+    proj = linear(x3, w_stack, b_stack)                                    # (A, R, 2C + HC [+ 4H])
     A_, R_ = x3.shape[0], x3.shape[1]
     vt = torch.baddbmm(b_v[None, :, None].expand(A_, C, R_), w_v[None].expand(A_, C, C), x3.transpose(1, 2))   # (A, C, R)
     hidden = torch.zeros_like(x3)

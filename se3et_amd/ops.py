@@ -41,6 +41,58 @@ def mm(a, b):
     return torch.mm(a, b)
 
 
+# ---- dense layers on the f16 matrix cores (csrc/linear_f16.hip) --------------------------------------------------------------
+# 'auto': the hand-written f16 hi / lo split kernel for the inference GEMMs it wins on MI355X (tools/micro/linear_shapes.py, gpurun_out ->
+# profiles/r03_linear_shapes.txt: in_features >= 256 and >= 20 000 rows: 1.1-1.55x the library's f32-MFMA-bound kernels; the short-K layers
+# are HBM bound and stay on the library, which streams them better), the library otherwise; SE3_LINEAR=library forces the library everywhere.
+LINEAR_F16 = os.environ.get('SE3_LINEAR', 'auto') != 'library'
+LINEAR_F16_MIN_ROWS, LINEAR_F16_MIN_K = 20000, 256
+_linear_piece_cache = {}          # (data_ptr, N, K, device) -> (weakref to the weight tensor, its version counter, pieces)
+
+
+def _linear_weight_pieces(weight, stream):
+    """f16 hi / lo MFMA fragments of an (N, K) weight, kept per weight VERSION (torch bumps `_version` on every in-place update: optimizer
+    steps, load_state_dict, copy_; call clear_weight_caches() after rewriting weights behind torch's back)."""
+    N, K = weight.shape
+    key = (weight.data_ptr(), N, K, weight.device.index)
+    hit = _linear_piece_cache.get(key)
+    if hit is not None and hit[0]() is not None and hit[1] == weight._version:
+        return hit[2]
+    Wp = torch.empty((lib().se3_linear_weight_pieces_bytes(N, K),), dtype=torch.uint8, device=weight.device)
+    check(lib().se3_linear_split_weights_f16(weight.data_ptr(), N, K, Wp.data_ptr(), stream), 'se3_linear_split_weights_f16')
+    with _TIMING_LOCK:
+        if len(_linear_piece_cache) > 512:
+            _linear_piece_cache.clear()
+        _linear_piece_cache[key] = (weakref.ref(weight), weight._version, Wp)
+    return Wp
+
+
+def linear_f16_ok(x, weight):
+    """True when linear_f16 applies: inference, f32 GPU tensors, unit-stride rows aligned to 16 bytes, enough rows to fill the chip."""
+    if not LINEAR_F16 or torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+        return False
+    if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 2 and weight.is_contiguous()):
+        return False
+    K = weight.shape[1]
+    rows = x.numel() // max(x.shape[-1], 1)
+    return (x.shape[-1] == K and K % 32 == 0 and K >= LINEAR_F16_MIN_K and rows >= LINEAR_F16_MIN_ROWS and x.is_contiguous()
+            and x.data_ptr() % 16 == 0)
+
+
+def linear_f16(x, weight, bias=None, relu=False):
+    """y = x W^T [+ bias] [ReLU] for x (..., K) contiguous, weight (N, K): csrc/linear_f16.hip."""
+    stream = _stream()
+    w = weight.detach()
+    N, K = w.shape
+    rows = x.numel() // K
+    Wp = _linear_weight_pieces(w, stream)
+    out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+    b = None if bias is None else _req(bias.detach().contiguous(), torch.float32, 'bias', 1)
+    check(lib().se3_linear_f16(x.data_ptr(), rows, K, K, Wp.data_ptr(), None if b is None else b.data_ptr(), N, 1 if relu else 0,
+                               out.data_ptr(), N, stream), 'se3_linear_f16')
+    return out
+
+
 # ---- optional per-kernel timing with HIP events on the launch stream (enabled by bench.py) -----------------------------
 TIMING_TAG = None             # optional tag (e.g. 'self') set by callers that want a separate bucket
 KERNEL_TIMINGS = None          # dict name -> list of (start_event, end_event, algorithmic_bytes) while enabled
@@ -450,6 +502,7 @@ def _kpconv_weight_pieces(weights, Cin, Cout, stream):
 
 def clear_weight_caches():
     _weight_piece_cache.clear()
+    _linear_piece_cache.clear()
 
 
 def kpconv_slot_sums(x, q_pts, s_pts, idx, kernel_points, kidx, ridx, sigma):

@@ -764,3 +764,31 @@ def test_cross_attention_eq_stack_bf16x6_matches_the_single_pair_kernels(lengths
         want, want_w, want_mix = SF.cross_attention_eq(q[:, s0:s0 + n].contiguous(), k[:, t0:t0 + m].contiguous(), vt1, H, mode, trace)
         assert_close(outs['bf16x6'][0][:, s0:s0 + n], want, 2e-5, 'pair %d hidden' % p)
         assert_close(outs['bf16x6'][1][p], want_mix, 1e-5, 'pair %d mix' % p)
+
+
+@pytest.mark.parametrize('rows,K,N,bias,relu', [(4096, 256, 256, True, False), (5000, 32, 64, False, False), (2049, 1024, 256, True, True),
+                                                (3000, 256, 1552, True, False), (2500, 64, 96, False, True), (7777, 512, 128, False, False),
+                                                (2048, 1536, 512, True, False)])
+def test_linear_f16_split_has_f32_accuracy(rows, K, N, bias, relu):
+    """csrc/linear_f16.hip (f16 hi / lo pieces of both operands, three products in f32) against a float64 evaluation: not worse than twice
+    the library f32 GEMM's own error, and within 2e-6 of the largest output; column counts that are not multiples of 64, a row count that
+    is not a multiple of the 128-row tile, bias and ReLU epilogues."""
+    from se3et_amd import ops
+    g = torch.Generator().manual_seed(rows + K + N)
+    x = (torch.randn(rows, K, generator=g) * torch.rand(rows, 1, generator=g) * 3).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda() if bias else None
+    got = ops.linear_f16(x, w, b, relu)
+    ref = torch.nn.functional.linear(x.double(), w.double(), None if b is None else b.double())
+    lib32 = torch.nn.functional.linear(x, w, b)
+    if relu:
+        ref, lib32 = ref.clamp_min(0), lib32.clamp_min(0)
+    e_new, e_lib = float((got.double() - ref).abs().max()), float((lib32.double() - ref).abs().max())
+    assert e_new <= max(2 * e_lib, 2e-6 * float(ref.abs().max())), (e_new, e_lib)
+    # a changed weight (in-place update bumps the version counter) is picked up
+    w.mul_(0.5)
+    got2 = ops.linear_f16(x, w, b, relu)
+    ref2 = torch.nn.functional.linear(x.double(), w.double(), None if b is None else b.double())
+    if relu:
+        ref2 = ref2.clamp_min(0)
+    assert float((got2.double() - ref2).abs().max()) <= 2e-6 * float(ref2.abs().max()) + 2 * e_lib
