@@ -2,8 +2,8 @@
 (25 steps): python tools/step_breakdown.py <kernel_stats.csv> [steps]"""
 import csv, sys
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 25
-fam = [('Cijk_', 'library GEMM'), ('gn_', 'GroupNorm'), ('kpconv_gather', 'KPConv gather'), ('kpconv_contract', 'KPConv contract'),
-       ('kpconv_split', 'KPConv contract'), ('rpe_bias', 'RPE logits'), ('attention_kernel', 'attention'), ('cross_eq', 'cross_eq'),
+fam = [('Cijk_', 'library GEMM'), ('linear_', 'dense f16-split GEMM'), ('gn_', 'GroupNorm'), ('kpconv_gather', 'KPConv gather (G form)'),
+       ('kpconv_fused', 'KPConv fused'), ('kpconv_neighbor_table', 'KPConv neighbour table'), ('kpconv_', 'KPConv other'), ('rpe_bias', 'RPE logits'), ('attention_kernel', 'attention'), ('cross_eq', 'cross_eq'),
        ('geo_', 'geo embedding'), ('embedding_table', 'geo embedding'), ('knn3', 'geo embedding'), ('sinkhorn', 'sinkhorn'),
        ('radius_', 'radius search'), ('grid_', 'grid subsample'), ('order_kernel', 'grid subsample'), ('neighbor_max', 'neighbor max'),
        ('add_ln', 'layer norm'), ('elementwise', 'torch elementwise'), ('at::native', 'torch other'), ('rocclr', 'copies / fills')]
