@@ -9,6 +9,14 @@
  *   - return value: 0 = ok, otherwise an SE3_ERR_* code (the Python host raises RuntimeError, mirroring the
  *     TORCH_CHECK failures of the reference extension, geotransformer/extensions/common/torch_helper.h:6-35).
  *
+ * Hard limits (requests beyond them return SE3_ERR_UNSUPPORTED, nothing is truncated silently):
+ *   - stacked calls take at most SE3_MAX_BATCH = 16 clouds (8 registration pairs per forward);
+ *   - radius search keeps at most SE3_MAX_NEIGHBOR_LIMIT = 64 neighbours per query (the reference's limits are 36 / 38);
+ *   - point_to_node_partition: point_limit <= 128 (the KITTI configuration's patch size);
+ *   - attention: anchors * heads <= 32, head dimension in {8, 16, 32, 64}, channels of the relative-position kernel in {32, 64, 128, 256};
+ *   - KPConv matrix-core path: input channels a multiple of 8, output channels a multiple of 32, num_support * 6 * in_channels < 2^31, the
+ *     SE3ET slot tables (kanchor 6, 15 kernel points), |orbit sums| < 65504; se3_linear_f16: in_features a multiple of 32, |x| < 65504.
+ *
  * Each entry point names the reference interface it replaces (paths under the reference repository).
  */
 #ifndef SE3ET_HIP_H_
@@ -33,8 +41,9 @@ extern "C" {
 /* Library / build identification. */
 const char* se3_version(void);
 const char* se3_last_error(void);   /* text of the last failure on the calling thread */
-/* Benchmark tuning / profiling hooks (process-global, defaults 0): kernel variant + workgroups per CU of the relative-position
- * kernel; variant of the attention kernel; variant 9 of the attention kernel writes 32 clock64() stamps per wave to `stamps`. */
+/* Benchmark tuning / profiling hooks (process-global, defaults 0; every variant computes the same result): kernel variant + workgroups per
+ * CU of the relative-position kernel (3 = exact f32 MFMAs instead of the f16 hi / lo split); variant of the attention kernel (5 = f16-split
+ * flash loop, 6 / 7 two waves per workgroup, 8 / 10 one wave); variant 9 writes 32 clock64() stamps per wave to `stamps`. */
 void se3_debug_set_bias_variant(int variant, int split);
 void se3_debug_set_attention_variant(int variant);
 void se3_debug_set_attention_profile(long long* stamps);
