@@ -31,13 +31,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # HBM traffic of one RPE self-attention call relative to its algorithmic bytes, from the rocprofv3 PMC passes committed as
-# profiles/r02_pmc_attention.csv (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of tools/pmc_attention.py on the stack-mode
+# profiles/r03_pmc_attention.csv (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of tools/pmc_attention.py on the stack-mode
 # kernels at the bench shape, 16 clouds per launch; gfx950 correction: FETCH_SIZE x2 for the 16-B/lane streaming reads of
-# rpe_bias_kernel -- its invariant variant then reads 2241 MB for 2223 MB of embedding --, attention_kernel counters raw):
-#   eq  call: (2*1336245.8 + 162966.6 + 203184.0 + 35289.5) KiB = 3147.7 MB  vs 2549.0 MB algorithmic
-#   inv call: (2*1094116.0 +  25743.6 +  33736.0 +  5864.4) KiB = 2307.7 MB  vs 2222.9 MB algorithmic
-PMC_TRAFFIC_RATIO = {'eq': 3147.7 / 2549.0, 'inv': 2307.7 / 2222.9}
-PMC_TRAFFIC_FILE = 'profiles/r02_pmc_attention.csv'
+# rpe_bias_kernel, attention_kernel counters raw).  Counters cannot be read inside this process, so the ratio of that run is applied:
+#   eq  call: (2*1311893.3 + 162943.5 + 202416.0 + 35277.9) KiB = 3097.0 MB  vs 2549.0 MB algorithmic
+#   inv call: (2*1088452.0 +  25734.1 +  33736.0 +  5861.9) KiB = 2296.0 MB  vs 2222.9 MB algorithmic
+PMC_TRAFFIC_RATIO = {'eq': 3097.0 / 2549.0, 'inv': 2296.0 / 2222.9}
+PMC_TRAFFIC_FILE = 'profiles/r03_pmc_attention.csv'
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s is achievable
 
 
