@@ -120,11 +120,12 @@ def main():
     ap.add_argument('--batch', type=int, default=8, help='registration pairs per forward / step (se3et_amd.batched), 1..8; '
                     '1 = the single-pair forward of the reference API')
     ap.add_argument('--switch-interval', type=float, default=1e-3)
-    ap.add_argument('--prefetch', type=int, default=0, help='build the pyramid of the next batch on a second host thread / HIP '
+    ap.add_argument('--prefetch', type=int, default=None, help='build the pyramid of the next batch on a second host thread / HIP '
                     'stream while the current batch runs through the model (the reference does this in DataLoader workers); every '
-                    'timed step still builds its own pyramid inside the timed region.  0 (default since round 3): pyramid and model back to back -- '
-                    'with the round-3 kernels the overlap no longer pays on the measured boxes (283.9 against 286.5 pairs/s) and the second '
-                    'stream lengthened the timed attention kernels')
+                    'timed step still builds its own pyramid inside the timed region.  0: pyramid and model back to back.  Default: 1 for '
+                    '--batch > 1 (+4 %: 297-303 against 285-292 pairs/s in a same-box A/B of the round-3 build; `roofline.quiet` reports the '
+                    'attention kernels without the second stream), 0 for --batch 1 (550 launches per pair: a second host thread only takes '
+                    'the interpreter away)')
     ap.add_argument('--attention-dtype', default='float32', choices=['float32', 'bfloat16'], help="'bfloat16': geometric embedding "
                     "stored in bf16 (BASELINE.json configs[2] 'bf16 attention'); the headline metric is quoted on float32")
     ap.add_argument('--inflight', type=int, default=1, help='pairs in flight per GPU: host threads, one HIP stream each')

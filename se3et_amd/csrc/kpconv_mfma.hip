@@ -197,8 +197,9 @@ __global__ __launch_bounds__(64 * NCW * KS) void kpconv_mfma_kernel(const u32x4*
 
 // ---- stage 1: neighbour table ------------------------------------------------------------------------------------------------------------
 // Per query point the VALID neighbours compacted to the front (invalid ones carry weight 0 in the reference: blocks_epn.py:471,377 shadow
-// point / zero feature row), padded with (index 0, weights 0) up to a multiple of 24 entries (NNp):
-//   hwt  [P][NNp][16] f32   orbit weights hw[o] = sum_{k in orbit o} max(0, 1 - |s - q - kp_k| / sigma)   (blocks_epn.py:520-533)
+// point / zero feature row), padded with (index 0, weights 0) up to a multiple of 32 entries (NNp):
+//   hwt  [P][16][NNp] f32   orbit weights hw[o][n] = sum_{k in orbit o} max(0, 1 - |s_n - q - kp_k| / sigma)   (blocks_epn.py:520-533), orbit-major:
+//                           a lane's 8 neighbours of one orbit are one 32-byte run
 //   nbr  [P][NNp] int32     support row of the j-th valid neighbour
 //   cnt  [P] int32          valid neighbours
 __global__ __launch_bounds__(64) void kpconv_neighbor_table_kernel(const float* __restrict__ q_pts, const float* __restrict__ s_pts,
@@ -238,43 +239,56 @@ __global__ __launch_bounds__(64) void kpconv_neighbor_table_kernel(const float* 
           if ((kOrb.mask[o] >> k) & 1) hw[o] += w[k];
     }
     nbr[p * NNp + e] = row;
-    float4* dst = reinterpret_cast<float4*>(hwt + (p * NNp + e) * 16);
 #pragma unroll
-    for (int q = 0; q < 4; q++) dst[q] = make_float4(hw[4 * q], hw[4 * q + 1], hw[4 * q + 2], hw[4 * q + 3]);
+    for (int o = 0; o < kOrbits; o++) hwt[(p * kOrbits + o) * NNp + e] = hw[o];
   }
 }
 
-// ---- stage 2: gather on the f32 matrix cores (one wave = one point x 16 channels) ---------------------------------------------------------
-// v_mfma_f32_16x16x4_f32: A[row = orbit l & 15][k = l >> 4] = hw[neighbour 4 j + (l >> 4)][orbit], B[k][col = l & 15] = x[that neighbour][a][c0 + col],
-// D[orbit 4 (l >> 4) + reg][col]: six column tiles (anchors) per point, one MFMA per 4 neighbours and anchor.
-constexpr int kGJ = 6;                       // groups of 4 neighbours per request round (24 neighbours)
+// ---- stage 2: gather on the f16 matrix cores (one wave = one point x 16 channels) ---------------------------------------------------------
+// v_mfma_f32_16x16x32_f16: A[row = orbit l & 15][k = 8 (l >> 4) + j] = hw[orbit][neighbour 8 g + j], B[k][col = l & 15] = x[that neighbour][a][c0 + col],
+// D[orbit 4 (l >> 4) + reg][col]: six column tiles (anchors) per point, 32 neighbours per MFMA; both operands as f16 hi + lo pieces, three
+// products in f32 (2^-22 per term).  (The round's first MFMA gather used v_mfma_f32_16x16x4_f32 -- exact f32 -- at 1/16 of this rate: 36 MFMAs of
+// 32 cycles per point and channel pair, as much matrix-pipe time as the contraction itself on the 64-wide layers; now 18 of 16 cycles plus
+// ~300 vector instructions for the splits on otherwise idle ALUs.)
+constexpr int kGN = 8;                       // neighbours per lane and request round (4 k-groups: 32 neighbours per round)
 
 struct GatherOps {                            // operands of one request round of one wave
-  float aw[kGJ];                              // orbit weights (A)
-  float xb[kA][kGJ];                          // gathered feature values (B)
+  float aw[kGN];                              // orbit weights (A): orbit l & 15, neighbours 8 g ..
+  float xb[kA][kGN];                          // gathered feature values (B): column l & 15 of anchor a, neighbours 8 g ..
 };
 
-// neighbour numbers of round j0 (groups j0 .. j0 + 5) for this lane's k index g = lane >> 4
-__device__ __forceinline__ void gather_request_rows(const int* __restrict__ nbrow, int j0, int g, int (&nbv)[kGJ]) {
-#pragma unroll
-  for (int j = 0; j < kGJ; j++) nbv[j] = nbrow[4 * (j0 + j) + g];
+// neighbour numbers of round `rd` (neighbours 32 rd .. + 31) for this lane's k-group g = lane >> 4
+__device__ __forceinline__ void gather_request_rows(const int* __restrict__ nbrow, int rd, int g, int (&nbv)[kGN]) {
+  const int4 lo = *reinterpret_cast<const int4*>(nbrow + 32 * rd + 8 * g), hi = *reinterpret_cast<const int4*>(nbrow + 32 * rd + 8 * g + 4);
+  nbv[0] = lo.x; nbv[1] = lo.y; nbv[2] = lo.z; nbv[3] = lo.w; nbv[4] = hi.x; nbv[5] = hi.y; nbv[6] = hi.z; nbv[7] = hi.w;
 }
-__device__ __forceinline__ void gather_request_ops(const float* __restrict__ x, const float* __restrict__ hwrow, int j0, int g, int c16,
-                                                   const int (&nbv)[kGJ], unsigned rowlen, unsigned col, int Cin, GatherOps& q) {
+__device__ __forceinline__ void gather_request_ops(const float* __restrict__ x, const float* __restrict__ hwrow, int NNp, int rd, int g, int c16,
+                                                   const int (&nbv)[kGN], unsigned rowlen, unsigned col, int Cin, GatherOps& q) {
+  const float* wr = hwrow + c16 * NNp + 32 * rd + 8 * g;
+  const float4 w0 = *reinterpret_cast<const float4*>(wr), w1 = *reinterpret_cast<const float4*>(wr + 4);
+  q.aw[0] = w0.x; q.aw[1] = w0.y; q.aw[2] = w0.z; q.aw[3] = w0.w; q.aw[4] = w1.x; q.aw[5] = w1.y; q.aw[6] = w1.z; q.aw[7] = w1.w;
 #pragma unroll
-  for (int j = 0; j < kGJ; j++) q.aw[j] = hwrow[(4 * (j0 + j) + g) * 16 + c16];
-#pragma unroll
-  for (int j = 0; j < kGJ; j++)
+  for (int j = 0; j < kGN; j++)
 #pragma unroll
     for (int a = 0; a < kA; a++) q.xb[a][j] = x[(unsigned)nbv[j] * rowlen + (unsigned)(a * Cin) + col];
 }
-__device__ __forceinline__ void gather_multiply(const GatherOps& q, int jcount, f32x4 (&acc)[kA]) {      // jcount: groups of 4 with a valid neighbour (uniform)
+__device__ __forceinline__ void split8(const float (&v)[kGN], f16x8& hi, f16x8& lo) {
 #pragma unroll
-  for (int j = 0; j < kGJ; j++) {
-    if (j < jcount) {
+  for (int i = 0; i < kGN; i++) {
+    hi[i] = (_Float16)v[i];
+    lo[i] = (_Float16)(v[i] - (float)hi[i]);
+  }
+}
+__device__ __forceinline__ void gather_multiply(const GatherOps& q, f32x4 (&acc)[kA]) {
+  f16x8 ah, al;
+  split8(q.aw, ah, al);
 #pragma unroll
-      for (int a = 0; a < kA; a++) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.aw[j], q.xb[a][j], acc[a], 0, 0, 0);
-    }
+  for (int a = 0; a < kA; a++) {
+    f16x8 bh, bl;
+    split8(q.xb[a], bh, bl);
+    acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[a], 0, 0, 0);
+    acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[a], 0, 0, 0);
+    acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[a], 0, 0, 0);
   }
 }
 // f16 hi / lo split of the wave's 24 values per lane, channel pairs exchanged inside lane pairs: even lanes end up with the hi dword of
@@ -313,12 +327,12 @@ __global__ __launch_bounds__(256) void kpconv_orbit_gather_kernel(const float* _
   f32x4 acc[kA];
 #pragma unroll
   for (int a = 0; a < kA; a++) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int j0 = 0; 4 * j0 < nv; j0 += kGJ) {
-    int nbv[kGJ];
+  for (int rd = 0; 32 * rd < nv; rd++) {
+    int nbv[kGN];
     GatherOps q;
-    gather_request_rows(nbrow, j0, g, nbv);
-    gather_request_ops(x, hwrow, j0, g, c16, nbv, rowlen, col, Cin, q);
-    gather_multiply(q, (nv + 3) / 4 - j0, acc);
+    gather_request_rows(nbrow, rd, g, nbv);
+    gather_request_ops(x, hwrow, NNp, rd, g, c16, nbv, rowlen, col, Cin, q);
+    gather_multiply(q, acc);
   }
   unsigned word[kA][4];
   gather_split(acc, odd, word);
@@ -352,7 +366,7 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
   constexpr int NC = NCW * KS;                                         // consumer waves
   constexpr int NPW = 8;                                               // producer waves: two points of the tile each
   constexpr int kSPW = kSteps / KS;                                    // K16-steps per consumer wave and chunk
-  static_assert(kSteps % KS == 0 && kSPW % 2 == 0, "K split must leave an even number of K16-steps per wave");
+  static_assert(kSteps % KS == 0, "K split must divide the 18 K16-steps of a chunk");
   extern __shared__ __align__(16) unsigned char lds[];                 // [3 images][table]
   unsigned* tab = reinterpret_cast<unsigned*>(lds + 3 * kTileB);       // [K16-step][rsel][h]: three 8-bit run numbers (anchor pairs 0..2)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -393,10 +407,10 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
     };
     {
       const int64_t p = point_of(0), pc = p < P ? p : plast;
-      int nbv[kGJ];
+      int nbv[kGN];
       gather_request_rows(nbr + pc * NNp, 0, g, nbv);
       nv_cur = p < P ? cnt[pc] : 0;
-      gather_request_ops(x, hwt + pc * NNp * 16, 0, g, c16, nbv, rowlen, col_of(0), Cin, ops);
+      gather_request_ops(x, hwt + pc * NNp * 16, NNp, 0, g, c16, nbv, rowlen, col_of(0), Cin, ops);
     }
     for (int u = 0; u < steps_total; u++) {
       SE3_STAMP(u, 0)
@@ -417,7 +431,7 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
         // neighbour numbers and count of the NEXT step's point: in flight while this step multiplies
         const bool more = u + 1 < 2 * pairs;
         const int64_t pn = point_of(u + 1), pnc = pn < P ? pn : plast;
-        int nbn[kGJ];
+        int nbn[kGN];
         gather_request_rows(nbr + pnc * NNp, 0, g, nbn);
         const int nv_next = (more && pn < P) ? cnt[pnc] : 0;
         SE3_STAMP(u, 1)
@@ -425,16 +439,16 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
 #pragma unroll
         for (int a = 0; a < kA; a++) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int nv = __builtin_amdgcn_readfirstlane(nv_cur);
-        gather_multiply(ops, (nv + 3) / 4, acc);
-        for (int j0 = kGJ; 4 * j0 < nv; j0 += kGJ) {                      // more than 24 valid neighbours: further rounds, requested on the spot
-          int nbv[kGJ];
+        if (nv > 0) gather_multiply(ops, acc);
+        for (int rd = 1; 32 * rd < nv; rd++) {                            // more than 32 valid neighbours: further rounds, requested on the spot
+          int nbv[kGN];
           GatherOps q;
-          gather_request_rows(nbr + pc * NNp, j0, g, nbv);
-          gather_request_ops(x, hwt + pc * NNp * 16, j0, g, c16, nbv, rowlen, col_of(u), Cin, q);
-          gather_multiply(q, (nv + 3) / 4 - j0, acc);
+          gather_request_rows(nbr + pc * NNp, rd, g, nbv);
+          gather_request_ops(x, hwt + pc * NNp * 16, NNp, rd, g, c16, nbv, rowlen, col_of(u), Cin, q);
+          gather_multiply(q, acc);
         }
         // the next step's operands leave now (their neighbour numbers have arrived behind the MFMAs)
-        gather_request_ops(x, hwt + pnc * NNp * 16, 0, g, c16, nbn, rowlen, col_of(more ? u + 1 : u), Cin, ops);
+        gather_request_ops(x, hwt + pnc * NNp * 16, NNp, 0, g, c16, nbn, rowlen, col_of(more ? u + 1 : u), Cin, ops);
         nv_cur = nv_next;
         SE3_STAMP(u, 2)
         unsigned word[kA][4];
@@ -474,13 +488,18 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
     for (int rt = 0; rt < 3; rt++)
 #pragma unroll
       for (int v = 0; v < 16; v++) acc[n][rt][v] = 0.f;
-  // weight fragments (hi, lo) of this wave's next two K16-steps: two register sets, each refilled behind the MFMAs that read it
+  // weight fragments (hi, lo) of this wave's next BD K16-steps: a ring of BD register sets, each refilled behind the MFMAs that read it
+  // (with the fragments always L1-resident a chunk of the 256-wide layer takes 13.4 K cycles instead of 19.7 K: the L2 round trip of the
+  // weight stream is the consumers' main stall, tools/micro/kpconv_stamps.py with -DSE3_DIAG_FIXED_B)
+  constexpr int BD = (CT == 2 && KS > 1) ? 2 : 3;                       // ring depth (the K-split two-tile form has no registers for a third set)
+  constexpr int U = BD == 3 ? 6 : 2;                                    // unroll = lcm(2 A buffers, BD)
+  static_assert(kSPW % U == 0, "K16-steps per wave and chunk must be a multiple of the unroll");
   const u32x4* wbase = Wf + (int64_t)ct0 * 2 * 64 + lane;
   const int64_t wstep = (int64_t)NCT * 2 * 64;                          // uint4 per K16-step over the whole layer
   const int64_t last_step = (int64_t)chunks * kSteps - KS + ksp;
-  u32x4 bq[2][CT][2];
+  u32x4 bq[BD][CT][2];
 #pragma unroll
-  for (int j = 0; j < 2; j++) {
+  for (int j = 0; j < BD; j++) {
     int64_t gs = ksp + j * KS;
     gs = gs < last_step ? gs : last_step;
 #pragma unroll
@@ -506,48 +525,54 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
       }
     }
 #pragma unroll 1
-    for (int q2 = 0; q2 < kSPW; q2 += 2) {
+    for (int q0 = 0; q0 < kSPW; q0 += U) {
 #pragma unroll
-      for (int j = 0; j < 2; j++) {
-        const int st = ksp + (q2 + j) * KS;
+      for (int j = 0; j < U; j++) {
+        constexpr int kDummy = 0;
+        const int ja = j & 1, jb = j % BD;
+        const int st = ksp + (q0 + j) * KS;
         {
           const int sn = st + KS < kSteps ? st + KS : st;                // next step of this chunk (clamped: the last one re-reads itself)
           const unsigned runs = tab[sn * 4 + tab_lane];
 #pragma unroll
           for (int rt = 0; rt < 3; rt++) {
             const int off = a_base + (int)((runs >> (8 * rt)) & 0xff) * 16;
-            av[j ^ 1][rt][0] = *reinterpret_cast<const f16x8*>(img + off);
-            av[j ^ 1][rt][1] = *reinterpret_cast<const f16x8*>(img + off + kPieceB);
+            av[ja ^ 1][rt][0] = *reinterpret_cast<const f16x8*>(img + off);
+            av[ja ^ 1][rt][1] = *reinterpret_cast<const f16x8*>(img + off + kPieceB);
           }
         }
         // smallest terms first; consecutive MFMAs go to different accumulators
 #pragma unroll
         for (int n = 0; n < CT; n++) {
-          const f16x8 b0 = __builtin_bit_cast(f16x8, bq[j][n][0]);
+          const f16x8 b0 = __builtin_bit_cast(f16x8, bq[jb][n][0]);
 #pragma unroll
-          for (int rt = 0; rt < 3; rt++) acc[n][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[j][rt][1], b0, acc[n][rt], 0, 0, 0);
+          for (int rt = 0; rt < 3; rt++) acc[n][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[ja][rt][1], b0, acc[n][rt], 0, 0, 0);
         }
 #pragma unroll
         for (int n = 0; n < CT; n++) {
-          const f16x8 b1 = __builtin_bit_cast(f16x8, bq[j][n][1]);
+          const f16x8 b1 = __builtin_bit_cast(f16x8, bq[jb][n][1]);
 #pragma unroll
-          for (int rt = 0; rt < 3; rt++) acc[n][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[j][rt][0], b1, acc[n][rt], 0, 0, 0);
+          for (int rt = 0; rt < 3; rt++) acc[n][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[ja][rt][0], b1, acc[n][rt], 0, 0, 0);
         }
 #pragma unroll
         for (int n = 0; n < CT; n++) {
-          const f16x8 b0 = __builtin_bit_cast(f16x8, bq[j][n][0]);
+          const f16x8 b0 = __builtin_bit_cast(f16x8, bq[jb][n][0]);
 #pragma unroll
-          for (int rt = 0; rt < 3; rt++) acc[n][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[j][rt][0], b0, acc[n][rt], 0, 0, 0);
+          for (int rt = 0; rt < 3; rt++) acc[n][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[ja][rt][0], b0, acc[n][rt], 0, 0, 0);
         }
         {
-          int64_t gs = (int64_t)cc * kSteps + st + 2 * KS;               // unconditional (clamped) so that the compiler can count the requests
+          int64_t gs = (int64_t)cc * kSteps + st + BD * KS;              // unconditional (clamped) so that the compiler can count the requests
           gs = gs < last_step ? gs : last_step;
+#ifdef SE3_DIAG_FIXED_B                                                  // (diagnostic build only: the same fragments every step -- L1 hits)
+          gs = ksp;
+#endif
 #pragma unroll
           for (int n = 0; n < CT; n++) {
-            bq[j][n][0] = wbase[gs * wstep + n * 128];
-            bq[j][n][1] = wbase[gs * wstep + n * 128 + 64];
+            bq[jb][n][0] = wbase[gs * wstep + n * 128];
+            bq[jb][n][1] = wbase[gs * wstep + n * 128 + 64];
           }
         }
+        (void)kDummy;
       }
     }
     SE3_STAMP(cc + 2, 3)
@@ -649,7 +674,7 @@ extern "C" int se3_kpconv_so3_contract_f16(const void* sums, const void* weight_
 
 extern "C" size_t se3_kpconv_neighbor_table_bytes(int64_t num_queries, int num_neighbors) {
   if (num_queries < 0 || num_neighbors < 1 || num_neighbors > 64) return 0;
-  const size_t nnp = (size_t)(num_neighbors + 23) / 24 * 24;
+  const size_t nnp = (size_t)(num_neighbors + 31) / 32 * 32;
   return (size_t)num_queries * nnp * (16 * sizeof(float) + sizeof(int)) + (size_t)num_queries * sizeof(int) + 256;
 }
 
@@ -661,7 +686,7 @@ struct NeighborTable {
 };
 NeighborTable table_views(const void* table, int64_t P, int NN) {
   NeighborTable t;
-  t.NNp = (NN + 23) / 24 * 24;
+  t.NNp = (NN + 31) / 32 * 32;
   t.hwt = static_cast<const float*>(table);
   t.nbr = reinterpret_cast<const int*>(t.hwt + (size_t)P * t.NNp * 16);
   t.cnt = t.nbr + (size_t)P * t.NNp;

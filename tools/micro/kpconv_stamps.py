@@ -6,7 +6,7 @@ from se3et_amd import ops, tables, _lib
 from se3et_amd.data import precompute_data_stack_mode
 from se3et_amd.model import make_cfg
 from se3et_amd.synthetic import make_pair
-L = ctypes.CDLL(os.path.join(R, 'tools/micro/libkpconv_stamps.so'))
+L = ctypes.CDLL(os.path.join(R, 'tools/micro/' + os.environ.get('KPCONV_STAMPS_LIB', 'libkpconv_stamps.so')))
 layer = int(sys.argv[1]); dev = torch.device('cuda'); cfg = make_cfg('se3ete'); b = cfg.backbone
 clouds = []
 for j in range(8):
