@@ -792,3 +792,46 @@ def test_linear_f16_split_has_f32_accuracy(rows, K, N, bias, relu):
     if relu:
         ref2 = ref2.clamp_min(0)
     assert float((got2.double() - ref2).abs().max()) <= 2e-6 * float(ref2.abs().max()) + 2 * e_lib
+
+
+@pytest.mark.parametrize('P,Ns,NN,Cin,Cout,box', [(77, 90, 38, 24, 32, 0.05), (130, 130, 40, 40, 96, 0.04), (33, 64, 36, 8, 64, 0.05),
+                                                  (200, 260, 48, 72, 160, 0.06), (16, 16, 16, 16, 32, 0.03), (95, 400, 64, 64, 256, 0.08)])
+def test_fused_kpconv_edge_shapes(P, Ns, NN, Cin, Cout, box):
+    """The fused matrix-core kernel where its schedule has corners: more than 32 VALID neighbours per point (a second gather round), odd numbers
+    of 8-channel chunks (the last producer pair is a single chunk), 3 / 5 column tiles (K-split consumers), point counts that are not
+    multiples of the 16-point tile, 64 neighbours -- against the float64 formula and the f32 path."""
+    from se3et_amd import functional as SF
+    from se3et_amd import ops
+    g = torch.Generator().manual_seed(P + Cin)
+    radius, sigma = 0.0625, 0.05
+    s_pts = torch.rand(Ns, 3, generator=g) * box                      # a small box: most of the NN nearest points are inside the radius
+    q_pts = s_pts[torch.randperm(Ns, generator=g)[:P]].contiguous()
+    d = ((q_pts[:, None] - s_pts[None]) ** 2).sum(-1)
+    idx = d.topk(min(NN, Ns), dim=1, largest=False)[1]
+    if idx.shape[1] < NN:
+        idx = torch.cat((idx, torch.full((P, NN - idx.shape[1]), Ns, dtype=idx.dtype)), 1)
+    idx[torch.cat((d, torch.full((P, 1), 1e9)), 1).gather(1, idx) > radius ** 2] = Ns
+    assert int(((idx < Ns).sum(1)).max()) > min(32, Ns - 1) or NN <= 32 or Ns <= 32
+    x = torch.randn(Ns, 6, Cin, generator=g)
+    st = _conv_state(Cin, Cout, radius)
+    args = (x.cuda(), q_pts.cuda(), s_pts.cuda(), idx.cuda(), st['kernel_points'].cuda(), st['weights'].cuda(),
+            st['kidx_rot'][:, 0, :].cuda(), st['ridx_rot'][0].cuda(), sigma)
+    saved = ops.KPCONV_MATRIX_CORE
+    try:
+        outs = {}
+        for path in (True, 'sums', False):
+            ops.KPCONV_MATRIX_CORE = path
+            outs[path] = SF.kpconv_inter_so3(*args).cpu()
+    finally:
+        ops.KPCONV_MATRIX_CORE = saved
+    xs = torch.cat((x, torch.zeros(1, 6, Cin))).double()
+    sp = torch.cat((s_pts, torch.full((1, 3), 1e6))).double()
+    nb = sp[idx] - q_pts.double()[:, None]
+    w = (1 - (nb[:, :, None] - st['kernel_points'].double()[None, None]).norm(dim=-1) / sigma).clamp(min=0)
+    Fk = torch.einsum('pnk,pnac->pkac', w, xs[idx])
+    W = st['weights'].double()[st['kidx_rot'][:, 0, :][:, None, :], st['ridx_rot'][0][None, :, :]]
+    ref = torch.einsum('pkac,karcd->prd', Fk, W)
+    e_old = float((outs[False].double() - ref).abs().max())
+    for path in (True, 'sums'):
+        e_new = float((outs[path].double() - ref).abs().max())
+        assert e_new <= max(2 * e_old, 2e-6 * float(ref.abs().max())), (path, e_new, e_old)
