@@ -1099,39 +1099,28 @@ __global__ __launch_bounds__(64 * NW) void cross_eq_apply_stack_kernel(CrossEqAr
   }
 }
 
-// ---- bf16x6 form of the equivariant cross attention (stack mode, head dimension 64) ---------------------------------------------------
+// ---- split-f16 form of the equivariant cross attention (stack mode, head dimension 64) -------------------------------------------------
 // cross_eq_apply_stack_kernel runs at the f32 MFMA rate (75 GF per call in 0.5 ms).  Here q, k and the transposed values are split once
-// per call into three bf16 pieces each (x = x1 + x2 + x3 exactly: 3 x 8 significant bits) and both products of the flash loop run on
-// v_mfma_f32_32x32x16_bf16 with the six piece products above 2^-24 relative (x1 y1, x1 y2, x2 y1, x1 y3, x2 y2, x3 y1) accumulated in f32
-// -- the scheme of csrc/kpconv_contract.hip: 6 x 32 cycles per 16 k instead of 8 x 64.  The softmax weights P are split on the fly from
-// the S^T accumulator registers; their register order fixes the order of the keys inside an MFMA K-step (lane half h holds keys
-// {0..3, 8..11} + 4 h of every 16), so the transposed values are stored with that permutation and a lane's V fragment is one 16-byte load.
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+// per call into f16 hi + lo pieces (x = hi + lo to 2^-22 |x|) and both products of the flash loop run on v_mfma_f32_32x32x16_f16 with the
+// three piece products hi hi + hi lo + lo hi accumulated in f32 -- the scheme of csrc/kpconv_mfma.hip: 3 x 32 cycles per 16 k instead of
+// 8 x 64 (round 2 used three bf16 pieces and six products: twice the matrix work and 1.5x the piece bytes for two more bits).  The softmax
+// weights P are split on the fly from the S^T accumulator registers; their register order fixes the order of the keys inside an MFMA
+// K-step (lane half h holds keys {0..3, 8..11} + 4 h of every 16), so the transposed values are stored with that permutation and a lane's
+// V fragment is one 16-byte load.  (Entry point and kernel keep their round-2 names, "x6".)
+typedef _Float16 h2x8_t __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ unsigned x6_pack(float lo, float hi) {
-  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-  bf16x2_t v;
-  v[0] = (__bf16)lo;
-  v[1] = (__bf16)hi;
-  return __builtin_bit_cast(unsigned, v);
-}
-__device__ __forceinline__ void x6_split8(const float (&x)[8], uint4& p1, uint4& p2, uint4& p3) {
-  unsigned a[4], b[4], c[4];
+__device__ __forceinline__ void h2_split8(const float (&x)[8], uint4& hi, uint4& lo) {
+  h2x8_t h, l;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const float x0 = x[2 * i], x1 = x[2 * i + 1];
-    a[i] = x6_pack(x0, x1);
-    const float r0 = x0 - __uint_as_float(a[i] << 16), r1 = x1 - __uint_as_float(a[i] & 0xffff0000u);
-    b[i] = x6_pack(r0, r1);
-    const float s0 = r0 - __uint_as_float(b[i] << 16), s1 = r1 - __uint_as_float(b[i] & 0xffff0000u);
-    c[i] = x6_pack(s0, s1);
+  for (int i = 0; i < 8; i++) {
+    h[i] = (_Float16)x[i];
+    l[i] = (_Float16)(x[i] - (float)h[i]);
   }
-  p1 = make_uint4(a[0], a[1], a[2], a[3]);
-  p2 = make_uint4(b[0], b[1], b[2], b[3]);
-  p3 = make_uint4(c[0], c[1], c[2], c[3]);
+  hi = __builtin_bit_cast(uint4, h);
+  lo = __builtin_bit_cast(uint4, l);
 }
 
-// rows (A, R, C) with anchor stride -> pieces [3][A][R][C] bf16; one thread per 8 channels
+// rows (A, R, C) with anchor stride -> pieces [2][A][R][C] f16; one thread per 8 channels
 __global__ __launch_bounds__(256) void x6_split_rows_kernel(const float* __restrict__ x, int A, int64_t R, int C, int64_t anchor_stride,
                                                             uint4* __restrict__ out) {
   const int64_t per = R * (C / 8), total = A * per;
@@ -1140,14 +1129,13 @@ __global__ __launch_bounds__(256) void x6_split_rows_kernel(const float* __restr
     const float* src = x + a * anchor_stride + rem * 8;
     const float4 lo = ld4(src), hi = ld4(src + 4);
     const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    uint4 p1, p2, p3;
-    x6_split8(v, p1, p2, p3);
+    uint4 p1, p2;
+    h2_split8(v, p1, p2);
     out[i] = p1;
     out[total + i] = p2;
-    out[2 * total + i] = p3;
   }
 }
-// transposed values (A, C, v_rs) with anchor stride -> pieces [3][A][C][v_rs] bf16, the keys of every aligned block of 16 in the order
+// transposed values (A, C, v_rs) with anchor stride -> pieces [2][A][C][v_rs] f16, the keys of every aligned block of 16 in the order
 // 0..3, 8..11, 4..7, 12..15; one thread per 16 keys
 __global__ __launch_bounds__(256) void x6_split_vt_kernel(const float* __restrict__ vt, int A, int C, int v_rs, int64_t anchor_stride,
                                                           uint4* __restrict__ out) {
@@ -1158,102 +1146,15 @@ __global__ __launch_bounds__(256) void x6_split_vt_kernel(const float* __restric
     const float4 q0 = ld4(src), q1 = ld4(src + 4), q2 = ld4(src + 8), q3 = ld4(src + 12);
     const float lo[8] = {q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, q2.z, q2.w};      // keys 0..3, 8..11
     const float hi[8] = {q1.x, q1.y, q1.z, q1.w, q3.x, q3.y, q3.z, q3.w};      // keys 4..7, 12..15
-    uint4 a1, a2, a3, b1, b2, b3;
-    x6_split8(lo, a1, a2, a3);
-    x6_split8(hi, b1, b2, b3);
+    uint4 a1, a2, b1, b2;
+    h2_split8(lo, a1, a2);
+    h2_split8(hi, b1, b2);
     out[2 * i] = a1; out[2 * i + 1] = b1;
     out[2 * (total + i)] = a2; out[2 * (total + i) + 1] = b2;
-    out[2 * (2 * total + i)] = a3; out[2 * (2 * total + i) + 1] = b3;
   }
 }
 
-struct X6Pieces { const uint4 *q[3], *k[3], *v[3]; };       // bf16 pieces, 8 values per uint4
-
-// One wave, one 32-query tile, the 32-key tiles tile_begin, + tile_step, ...: flash_tiles on the bf16 matrix cores at f32 accuracy (D = 64).
-// q / k: element offsets of the (anchor, head) slice into the piece arrays (rows of C bf16); v: element offset of the slice's first row
-// into the transposed-value pieces (rows of v_rs bf16, first key of the pair included).
-__device__ __forceinline__ void flash_tiles_x6(FlashState<64>& st, const X6Pieces& X, int64_t q_off, int64_t k_off, int64_t v_off, int n0,
-                                               int N, int M, int C, int v_rs, float scale, int tile_begin, int tile_step) {
-  const int lane = threadIdx.x & 63, half = lane >> 5, c32 = lane & 31;
-  const int nq = min(n0 + c32, N - 1);
-  bf16x8_t qf[3][4];
-#pragma unroll
-  for (int pc = 0; pc < 3; pc++)
-#pragma unroll
-    for (int u = 0; u < 4; u++) qf[pc][u] = __builtin_bit_cast(bf16x8_t, X.q[pc][(q_off + (int64_t)nq * C + 16 * u + 8 * half) >> 3]);
-  const int tiles = (M + 31) >> 5;
-  for (int tile = tile_begin; tile < tiles; tile += tile_step) {
-    const int m0 = tile << 5;
-    const int64_t krow = k_off + (int64_t)min(m0 + c32, M - 1) * C + 8 * half;
-    bf16x8_t kf[3][4];
-#pragma unroll
-    for (int pc = 0; pc < 3; pc++)
-#pragma unroll
-      for (int u = 0; u < 4; u++) kf[pc][u] = __builtin_bit_cast(bf16x8_t, X.k[pc][(krow + 16 * u) >> 3]);
-    // V^T fragments: row d = 32 dt + c32, K-step j = keys m0 + 16 j .. +15 in the stored (permuted) order, this lane's half of them
-    bf16x8_t vf[3][2][2];
-#pragma unroll
-    for (int pc = 0; pc < 3; pc++)
-#pragma unroll
-      for (int dt = 0; dt < 2; dt++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-          vf[pc][dt][j] = __builtin_bit_cast(bf16x8_t, X.v[pc][(v_off + (int64_t)(32 * dt + c32) * v_rs + m0 + 16 * j + 8 * half) >> 3]);
-    f32x16 s;
-#pragma unroll
-    for (int r = 0; r < 16; r++) s[r] = 0.f;
-#define SE3_X6_QK(a_, b_)                                                                                    \
-  _Pragma("unroll") for (int u = 0; u < 4; u++) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[a_][u], qf[b_][u], s, 0, 0, 0);
-    SE3_X6_QK(2, 0) SE3_X6_QK(0, 2) SE3_X6_QK(1, 1) SE3_X6_QK(1, 0) SE3_X6_QK(0, 1) SE3_X6_QK(0, 0)
-#undef SE3_X6_QK
-    // s[r] = S^T[key = (r&3) + 8 (r>>2) + 4 half][query = c32]
-    float mx = -INFINITY;
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int key = m0 + 8 * g + 4 * half + j;
-        float val = s[4 * g + j] * scale;
-        val = key < M ? val : -INFINITY;
-        s[4 * g + j] = val;
-        mx = fmaxf(mx, val);
-      }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(st.m, mx);
-    const float alpha = __expf(st.m - m_new);
-    float ps = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      s[r] = __expf(s[r] - m_new);
-      ps += s[r];
-    }
-    ps += __shfl_xor(ps, 32);
-    st.l = st.l * alpha + ps;
-    st.m = m_new;
-    // P^T as the B operand: K-step j holds s[8 j .. 8 j + 7] = keys {0..3, 8..11} + 4 half + 16 j of the tile
-    bf16x8_t pb[3][2];
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const float v8[8] = {s[8 * j], s[8 * j + 1], s[8 * j + 2], s[8 * j + 3], s[8 * j + 4], s[8 * j + 5], s[8 * j + 6], s[8 * j + 7]};
-      uint4 p1, p2, p3;
-      x6_split8(v8, p1, p2, p3);
-      pb[0][j] = __builtin_bit_cast(bf16x8_t, p1);
-      pb[1][j] = __builtin_bit_cast(bf16x8_t, p2);
-      pb[2][j] = __builtin_bit_cast(bf16x8_t, p3);
-    }
-#pragma unroll
-    for (int dt = 0; dt < 2; dt++) {
-#pragma unroll
-      for (int r = 0; r < 16; r++) st.o[dt][r] *= alpha;
-    }
-#define SE3_X6_PV(a_, b_)                                                                                    \
-  _Pragma("unroll") for (int dt = 0; dt < 2; dt++) _Pragma("unroll") for (int j = 0; j < 2; j++)              \
-      st.o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[a_][dt][j], pb[b_][j], st.o[dt], 0, 0, 0);
-    SE3_X6_PV(2, 0) SE3_X6_PV(0, 2) SE3_X6_PV(1, 1) SE3_X6_PV(1, 0) SE3_X6_PV(0, 1) SE3_X6_PV(0, 0)
-#undef SE3_X6_PV
-  }
-}
+struct X6Pieces { const uint4 *q[2], *k[2], *v[2]; };       // f16 hi / lo pieces, 8 values per uint4
 
 // grid (ceil(QT / 4), H, A * pairs), 4 waves = 4 consecutive 32-query tiles of one (pair, query anchor a, head).  The workgroup walks
 // the (key anchor e, 32-key tile) sequence once; every K / V^T tile (3 pieces each: 24 KB) goes global -> registers -> LDS one step ahead
@@ -1265,8 +1166,8 @@ __global__ __launch_bounds__(256) void cross_eq_apply_stack_x6_kernel(CrossEqArg
                                                                       int64_t v_piece_sa, const float* __restrict__ mix,
                                                                       float* __restrict__ out) {
   constexpr int D = 64;
-  __shared__ uint4 ktile[2][3][32][kX6KRow];
-  __shared__ uint4 vtile[2][3][64][kX6VRow];
+  __shared__ uint4 ktile[2][2][32][kX6KRow];
+  __shared__ uint4 vtile[2][2][64][kX6VRow];
   const int A = p.A, C = p.C;
   const int pair = blockIdx.z / A, a = blockIdx.z - pair * A;
   const StackCloud cl = stack_pick(p.S, pair);
@@ -1277,20 +1178,20 @@ __global__ __launch_bounds__(256) void cross_eq_apply_stack_x6_kernel(CrossEqArg
   const bool active = n0 < cl.N;                            // (inactive waves still help with the tile copies)
   const int nq = min(n0 + c32, cl.N - 1);
   const int64_t q_off = a * q_piece_sa + (int64_t)cl.q_start * C + h * D;
-  bf16x8_t qf[3][4];
+  h2x8_t qf[2][4];
 #pragma unroll
-  for (int pc = 0; pc < 3; pc++)
+  for (int pc = 0; pc < 2; pc++)
 #pragma unroll
-    for (int u = 0; u < 4; u++) qf[pc][u] = __builtin_bit_cast(bf16x8_t, X.q[pc][(q_off + (int64_t)nq * C + 16 * u + 8 * half) >> 3]);
+    for (int u = 0; u < 4; u++) qf[pc][u] = __builtin_bit_cast(h2x8_t, X.q[pc][(q_off + (int64_t)nq * C + 16 * u + 8 * half) >> 3]);
   const int tiles = (cl.M + 31) >> 5, steps = A * tiles;
-  // this thread's share of a tile copy: K: 3 pieces x 32 rows x 8 uint4 = 768 -> 3 per thread; V^T: 3 pieces x 64 rows x 4 uint4 = 768 -> 3
-  uint4 rk[3], rv[3];
+  // this thread's share of a tile copy: K: 2 pieces x 32 rows x 8 uint4 = 512 -> 2 per thread; V^T: 2 pieces x 64 rows x 4 uint4 = 512 -> 2
+  uint4 rk[2], rv[2];
   auto request = [&](int step) {
     const int e = step / tiles, m0 = (step - e * tiles) << 5;
     const int64_t k_off = e * k_piece_sa + (int64_t)cl.k_start * C + h * D;
     const int64_t v_off = e * v_piece_sa + (int64_t)h * D * p.v_rs + cl.k_start + m0;
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < 2; i++) {
       const int row = tid >> 3, q8 = tid & 7;               // piece i: 32 rows x 8 uint4
       rk[i] = X.k[i][(k_off + (int64_t)min(m0 + row, cl.M - 1) * C + 8 * q8) >> 3];
       const int vrow = tid >> 2, q4 = tid & 3;              // piece i: 64 rows x 4 uint4
@@ -1299,7 +1200,7 @@ __global__ __launch_bounds__(256) void cross_eq_apply_stack_x6_kernel(CrossEqArg
   };
   auto publish = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < 2; i++) {
       ktile[buf][i][tid >> 3][tid & 7] = rk[i];
       vtile[buf][i][tid >> 2][tid & 3] = rv[i];
     }
@@ -1315,21 +1216,18 @@ __global__ __launch_bounds__(256) void cross_eq_apply_stack_x6_kernel(CrossEqArg
     const int e = step / tiles, tile = step - e * tiles, m0 = tile << 5;
     if (step + 1 < steps) request(step + 1);                 // block-uniform
     if (active) {
-      // two accumulators, consecutive MFMAs alternate between them (a single one would make all 24 a dependent chain)
+      // two accumulators, consecutive MFMAs alternate between them
       f32x16 s, s2;
 #pragma unroll
       for (int r = 0; r < 16; r++) s[r] = s2[r] = 0.f;
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        bf16x8_t kf[3];
+        h2x8_t kf[2];
 #pragma unroll
-        for (int pc = 0; pc < 3; pc++) kf[pc] = __builtin_bit_cast(bf16x8_t, ktile[buf][pc][c32][2 * u + half]);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2], qf[0][u], s, 0, 0, 0);
-        s2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[2][u], s2, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[1][u], s, 0, 0, 0);
-        s2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[0][u], s2, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[1][u], s, 0, 0, 0);
-        s2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0][u], s2, 0, 0, 0);
+        for (int pc = 0; pc < 2; pc++) kf[pc] = __builtin_bit_cast(h2x8_t, ktile[buf][pc][c32][2 * u + half]);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], qf[0][u], s, 0, 0, 0);
+        s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[1][u], s2, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[0][u], s, 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < 16; r++) s[r] += s2[r];
@@ -1357,15 +1255,14 @@ __global__ __launch_bounds__(256) void cross_eq_apply_stack_x6_kernel(CrossEqArg
       ps += __shfl_xor(ps, 32);
       st.l = st.l * alpha + ps;
       st.m = m_new;
-      bf16x8_t pb[3][2];
+      h2x8_t pb[2][2];
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         const float v8[8] = {s[8 * j], s[8 * j + 1], s[8 * j + 2], s[8 * j + 3], s[8 * j + 4], s[8 * j + 5], s[8 * j + 6], s[8 * j + 7]};
-        uint4 p1, p2, p3;
-        x6_split8(v8, p1, p2, p3);
-        pb[0][j] = __builtin_bit_cast(bf16x8_t, p1);
-        pb[1][j] = __builtin_bit_cast(bf16x8_t, p2);
-        pb[2][j] = __builtin_bit_cast(bf16x8_t, p3);
+        uint4 p1, p2;
+        h2_split8(v8, p1, p2);
+        pb[0][j] = __builtin_bit_cast(h2x8_t, p1);
+        pb[1][j] = __builtin_bit_cast(h2x8_t, p2);
       }
 #pragma unroll
       for (int dt = 0; dt < 2; dt++)
@@ -1373,15 +1270,15 @@ __global__ __launch_bounds__(256) void cross_eq_apply_stack_x6_kernel(CrossEqArg
         for (int r = 0; r < 16; r++) st.o[dt][r] *= alpha;
 #pragma unroll
       for (int j = 0; j < 2; j++) {
-        bf16x8_t vf[2][3];
+        h2x8_t vf[2][2];
 #pragma unroll
         for (int dt = 0; dt < 2; dt++)
 #pragma unroll
-          for (int pc = 0; pc < 3; pc++) vf[dt][pc] = __builtin_bit_cast(bf16x8_t, vtile[buf][pc][32 * dt + c32][2 * j + half]);
+          for (int pc = 0; pc < 2; pc++) vf[dt][pc] = __builtin_bit_cast(h2x8_t, vtile[buf][pc][32 * dt + c32][2 * j + half]);
 #define SE3_X6_PV(a_, b_)                                                                                                       \
-  st.o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][a_], pb[b_][j], st.o[0], 0, 0, 0);                                    \
-  st.o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][a_], pb[b_][j], st.o[1], 0, 0, 0);
-        SE3_X6_PV(2, 0) SE3_X6_PV(0, 2) SE3_X6_PV(1, 1) SE3_X6_PV(1, 0) SE3_X6_PV(0, 1) SE3_X6_PV(0, 0)
+  st.o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][a_], pb[b_][j], st.o[0], 0, 0, 0);                                     \
+  st.o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][a_], pb[b_][j], st.o[1], 0, 0, 0);
+        SE3_X6_PV(1, 0) SE3_X6_PV(0, 1) SE3_X6_PV(0, 0)
 #undef SE3_X6_PV
       }
       if (tile == tiles - 1) {                                // key anchor e is complete: fold it into the output with its weight
@@ -1889,10 +1786,10 @@ extern "C" int se3_cross_eq_stack_fwd(const float* q, const float* k, const floa
 }
 
 // bf16x6 form of se3_cross_eq_stack_fwd (head dimension 64, A <= 6, key starts and the value row stride multiples of 16): q (A, q_rows, C),
-// k (A, k_rows, C) and vt (A, C, v_row_stride) are split into bf16 pieces in `workspace` (se3_cross_eq_x6_workspace_bytes), then the flash
+// k (A, k_rows, C) and vt (A, C, v_row_stride) are split into f16 hi / lo pieces in `workspace` (se3_cross_eq_x6_workspace_bytes), then the flash
 // loop runs on the bf16 matrix cores at f32 accuracy.  Other shapes take the f32 kernels of se3_cross_eq_stack_fwd.
 extern "C" size_t se3_cross_eq_x6_workspace_bytes(int A, int64_t q_rows, int64_t k_rows, int C, int v_row_stride) {
-  return (size_t)6 * A * ((size_t)q_rows * C + (size_t)k_rows * C + (size_t)C * v_row_stride) + 256;
+  return (size_t)4 * A * ((size_t)q_rows * C + (size_t)k_rows * C + (size_t)C * v_row_stride) + 256;      // two f16 pieces per value
 }
 
 extern "C" int se3_cross_eq_stack_x6_fwd(const float* q, const float* k, const float* vt, const int64_t* q_starts,
@@ -1933,14 +1830,14 @@ extern "C" int se3_cross_eq_stack_x6_fwd(const float* q, const float* k, const f
   hipStream_t st = (hipStream_t)stream;
   const size_t nq = (size_t)A * q_rows * C / 8, nk = (size_t)A * k_rows * C / 8, nv = (size_t)A * C * v_row_stride / 8;     // uint4 per piece
   uint4* wq = static_cast<uint4*>(workspace);
-  uint4* wk = wq + 3 * nq;
-  uint4* wv = wk + 3 * nk;
+  uint4* wk = wq + 2 * nq;
+  uint4* wv = wk + 2 * nk;
   x6_split_rows_kernel<<<(unsigned)((nq + 255) / 256 > 4096 ? 4096 : (nq + 255) / 256), 256, 0, st>>>(q, A, q_rows, C, q_anchor_stride, wq);
   x6_split_rows_kernel<<<(unsigned)((nk + 255) / 256 > 4096 ? 4096 : (nk + 255) / 256), 256, 0, st>>>(k, A, k_rows, C, k_anchor_stride, wk);
   x6_split_vt_kernel<<<(unsigned)((nv / 2 + 255) / 256 > 4096 ? 4096 : (nv / 2 + 255) / 256), 256, 0, st>>>(vt, A, C, v_row_stride,
                                                                                                          v_anchor_stride, wv);
   X6Pieces X;
-  for (int pc = 0; pc < 3; pc++) {
+  for (int pc = 0; pc < 2; pc++) {
     X.q[pc] = wq + pc * nq;
     X.k[pc] = wk + pc * nk;
     X.v[pc] = wv + pc * nv;
