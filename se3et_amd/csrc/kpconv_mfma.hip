@@ -30,7 +30,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 #ifdef SE3_KPCONV_STAMPS      // diagnostic build of tools/micro/kpconv_stamps.hip only: wave time stamps of the first workgroups
 __device__ long long* g_stamps = nullptr;
-constexpr int kStampBlocks = 64, kStampSteps = 40, kStampSlots = 6;
+constexpr int kStampBlocks = 64, kStampSteps = 40, kStampSlots = 8;
 #define SE3_STAMP(step_, slot_)                                                                                            \
   if (g_stamps && blockIdx.x < kStampBlocks && blockIdx.y == 0 && (step_) < kStampSteps && lane == 0)                      \
     g_stamps[(((int64_t)blockIdx.x * 16 + wave) * kStampSteps + (step_)) * kStampSlots + (slot_)] = __builtin_amdgcn_s_memtime();
@@ -250,6 +250,9 @@ __global__ __launch_bounds__(64) void kpconv_neighbor_table_kernel(const float* 
 // products in f32 (2^-22 per term).  (The round's first MFMA gather used v_mfma_f32_16x16x4_f32 -- exact f32 -- at 1/16 of this rate: 36 MFMAs of
 // 32 cycles per point and channel pair, as much matrix-pipe time as the contraction itself on the 64-wide layers; now 18 of 16 cycles plus
 // ~300 vector instructions for the splits on otherwise idle ALUs.)
+// The producers are bound by the number of vector-memory instructions, not by bytes: 8 waves x 58 requests per step take ~9.4 K cycles (one
+// dword request per ~20 cycles and CU, the price of a 16-byte one), 2.8 K for splits + MFMAs, 2.4 K for the result split + stores (stamps of
+// tools/micro/kpconv_stamps.py, layer 5); masking the lanes of k-groups without valid neighbours changed nothing.
 constexpr int kGN = 8;                       // neighbours per lane and request round (4 k-groups: 32 neighbours per round)
 
 struct GatherOps {                            // operands of one request round of one wave
@@ -439,7 +442,9 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
 #pragma unroll
         for (int a = 0; a < kA; a++) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int nv = __builtin_amdgcn_readfirstlane(nv_cur);
+        SE3_STAMP(u, 5)
         if (nv > 0) gather_multiply(ops, acc);
+        SE3_STAMP(u, 6)
         for (int rd = 1; 32 * rd < nv; rd++) {                            // more than 32 valid neighbours: further rounds, requested on the spot
           int nbv[kGN];
           GatherOps q;

@@ -5,7 +5,7 @@
 // -DSE3_DIAG_FIXED_B: every K16-step multiplies with the first step's weight fragments (wrong results; shows what the weight stream costs)
 #include "../../se3et_amd/csrc/kpconv_mfma.hip"
 
-extern "C" int se3_debug_kpconv_set_stamps(void* device_buffer) {      // 64 blocks x 16 waves x 40 steps x 6 slots x int64
+extern "C" int se3_debug_kpconv_set_stamps(void* device_buffer) {      // 64 blocks x 16 waves x 40 steps x 8 slots x int64
   long long* p = static_cast<long long*>(device_buffer);
   return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)) == hipSuccess ? 0 : 1;
 }

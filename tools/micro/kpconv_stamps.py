@@ -29,7 +29,7 @@ out = torch.empty((P, 6, C), device=dev)
 nbytes = _lib.lib().se3_kpconv_neighbor_table_bytes(P, NN)
 ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
 _lib.check(_lib.lib().se3_kpconv_neighbor_table(q.data_ptr(), s.data_ptr(), idx.data_ptr(), kp.data_ptr(), float(sig), P, s.shape[0], NN, ws.data_ptr(), nbytes, None), 'table')
-stamps = torch.zeros((64, 16, 40, 6), dtype=torch.int64, device=dev)
+stamps = torch.zeros((64, 16, 40, 8), dtype=torch.int64, device=dev)
 L.se3_kpconv_so3_fused.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]
 L.se3_debug_kpconv_set_stamps.argtypes = [vp]
 assert L.se3_debug_kpconv_set_stamps(stamps.data_ptr()) == 0
@@ -47,7 +47,7 @@ ok = prod[..., 0] > 0
 def seg(a, i, j, m): d = (a[..., j] - a[..., i])[m]; return d.mean(), np.percentile(d, 90)
 act = ok & (prod[..., 2] > 0) & (prod[..., 1] > 0)
 print('layer %d: P %d C %d, %d chunks; ticks of s_memtime (100 MHz realtime? -> treat as cycles of the shader clock)' % (layer, P, C, chunks))
-for name, i, j in (('held rows + next requests', 0, 1), ('gather MFMAs', 1, 2), ('split + stores', 2, 3), ('barrier wait', 3, 4)):
+for name, i, j in (('held rows + next requests', 0, 1), ('  (acc init, count)', 1, 5), ('  split operands + 18 MFMAs', 5, 6), ('  extra rounds + next operand requests', 6, 2), ('split result + stores', 2, 3), ('barrier wait', 3, 4)):
     m, p90 = seg(prod, i, j, act & (prod[..., j] > 0)); print('  producer %-30s mean %8.0f  p90 %8.0f' % (name, m, p90))
 m, p90 = seg(prod, 0, 4, act & (prod[..., 4] > 0)); print('  producer %-30s mean %8.0f  p90 %8.0f' % ('whole step', m, p90))
 cons = blk[:, :nc, 2:min(steps, 40)]
