@@ -253,27 +253,54 @@ __global__ __launch_bounds__(64) void kpconv_neighbor_table_kernel(const float* 
 // The producers are bound by the number of vector-memory instructions, not by bytes: 8 waves x 58 requests per step take ~9.4 K cycles (one
 // dword request per ~20 cycles and CU, the price of a 16-byte one), 2.8 K for splits + MFMAs, 2.4 K for the result split + stores (stamps of
 // tools/micro/kpconv_stamps.py, layer 5); masking the lanes of k-groups without valid neighbours changed nothing.
-constexpr int kGN = 8;                       // neighbours per lane and request round (4 k-groups: 32 neighbours per round)
+// Neighbour slots per request round: 32 (one MFMA K-step: lane k-group g holds slots 8 g .. 8 g + 7) or, for tables wider than 32 (EXT), 40:
+// slots 32 + 2 g, 32 + 2 g + 1 ride in a second K-step whose other six values per lane are zero.  At the bench shape the stage-2 / stage-3
+// tables are 36 / 38 wide and 55-60 % of their points have more than 32 valid neighbours (tools/micro/neighbor_counts.py): a second,
+// un-prefetched 32-slot round cost those points 6.8 K cycles per step (stamps), the two tail slots cost 12 more requests, and only for
+// points that need them.
+constexpr int kGN = 8, kGX = 2;
 
+template <bool EXT>
 struct GatherOps {                            // operands of one request round of one wave
-  float aw[kGN];                              // orbit weights (A): orbit l & 15, neighbours 8 g ..
-  float xb[kA][kGN];                          // gathered feature values (B): column l & 15 of anchor a, neighbours 8 g ..
+  float aw[kGN + (EXT ? kGX : 0)];            // orbit weights (A): orbit l & 15, slots 8 g .. 8 g + 7 (, 32 + 2 g, 32 + 2 g + 1)
+  float xb[kA][kGN + (EXT ? kGX : 0)];        // gathered feature values (B): column l & 15 of anchor a, the same slots
 };
 
-// neighbour numbers of round `rd` (neighbours 32 rd .. + 31) for this lane's k-group g = lane >> 4
-__device__ __forceinline__ void gather_request_rows(const int* __restrict__ nbrow, int rd, int g, int (&nbv)[kGN]) {
-  const int4 lo = *reinterpret_cast<const int4*>(nbrow + 32 * rd + 8 * g), hi = *reinterpret_cast<const int4*>(nbrow + 32 * rd + 8 * g + 4);
+template <bool EXT>
+__device__ __forceinline__ void gather_request_rows(const int* __restrict__ nbrow, int rd, int g, int (&nbv)[kGN + (EXT ? kGX : 0)]) {
+  constexpr int S = EXT ? 40 : 32;
+  const int4 lo = *reinterpret_cast<const int4*>(nbrow + S * rd + 8 * g), hi = *reinterpret_cast<const int4*>(nbrow + S * rd + 8 * g + 4);
   nbv[0] = lo.x; nbv[1] = lo.y; nbv[2] = lo.z; nbv[3] = lo.w; nbv[4] = hi.x; nbv[5] = hi.y; nbv[6] = hi.z; nbv[7] = hi.w;
+  if constexpr (EXT) {
+    const int2 t = *reinterpret_cast<const int2*>(nbrow + S * rd + 32 + 2 * g);
+    nbv[8] = t.x;
+    nbv[9] = t.y;
+  }
 }
+// nv: valid neighbours of the point (uniform): the tail slots are requested only when the round has more than 32
+template <bool EXT>
 __device__ __forceinline__ void gather_request_ops(const float* __restrict__ x, const float* __restrict__ hwrow, int NNp, int rd, int g, int c16,
-                                                   const int (&nbv)[kGN], unsigned rowlen, unsigned col, int Cin, GatherOps& q) {
-  const float* wr = hwrow + c16 * NNp + 32 * rd + 8 * g;
+                                                   const int (&nbv)[kGN + (EXT ? kGX : 0)], unsigned rowlen, unsigned col, int Cin, int nv,
+                                                   GatherOps<EXT>& q) {
+  constexpr int S = EXT ? 40 : 32;
+  const float* wr = hwrow + c16 * NNp + S * rd + 8 * g;
   const float4 w0 = *reinterpret_cast<const float4*>(wr), w1 = *reinterpret_cast<const float4*>(wr + 4);
   q.aw[0] = w0.x; q.aw[1] = w0.y; q.aw[2] = w0.z; q.aw[3] = w0.w; q.aw[4] = w1.x; q.aw[5] = w1.y; q.aw[6] = w1.z; q.aw[7] = w1.w;
 #pragma unroll
   for (int j = 0; j < kGN; j++)
 #pragma unroll
     for (int a = 0; a < kA; a++) q.xb[a][j] = x[(unsigned)nbv[j] * rowlen + (unsigned)(a * Cin) + col];
+  if constexpr (EXT) {
+    if (nv > S * rd + 32) {
+      const float2 wt = *reinterpret_cast<const float2*>(hwrow + c16 * NNp + S * rd + 32 + 2 * g);
+      q.aw[8] = wt.x;
+      q.aw[9] = wt.y;
+#pragma unroll
+      for (int j = kGN; j < kGN + kGX; j++)
+#pragma unroll
+        for (int a = 0; a < kA; a++) q.xb[a][j] = x[(unsigned)nbv[j] * rowlen + (unsigned)(a * Cin) + col];
+    }
+  }
 }
 __device__ __forceinline__ void split8(const float (&v)[kGN], f16x8& hi, f16x8& lo) {
 #pragma unroll
@@ -282,16 +309,41 @@ __device__ __forceinline__ void split8(const float (&v)[kGN], f16x8& hi, f16x8& 
     lo[i] = (_Float16)(v[i] - (float)hi[i]);
   }
 }
-__device__ __forceinline__ void gather_multiply(const GatherOps& q, f32x4 (&acc)[kA]) {
+__device__ __forceinline__ void split2(float v0, float v1, f16x8& hi, f16x8& lo) {      // two values, six zeros
+#pragma unroll
+  for (int i = 0; i < 8; i++) hi[i] = lo[i] = (_Float16)0.f;
+  hi[0] = (_Float16)v0; lo[0] = (_Float16)(v0 - (float)hi[0]);
+  hi[1] = (_Float16)v1; lo[1] = (_Float16)(v1 - (float)hi[1]);
+}
+// tail: the round has more than 32 valid neighbours (uniform)
+template <bool EXT>
+__device__ __forceinline__ void gather_multiply(const GatherOps<EXT>& q, bool tail, f32x4 (&acc)[kA]) {
   f16x8 ah, al;
-  split8(q.aw, ah, al);
+  {
+    const float w8[kGN] = {q.aw[0], q.aw[1], q.aw[2], q.aw[3], q.aw[4], q.aw[5], q.aw[6], q.aw[7]};
+    split8(w8, ah, al);
+  }
 #pragma unroll
   for (int a = 0; a < kA; a++) {
+    const float v8[kGN] = {q.xb[a][0], q.xb[a][1], q.xb[a][2], q.xb[a][3], q.xb[a][4], q.xb[a][5], q.xb[a][6], q.xb[a][7]};
     f16x8 bh, bl;
-    split8(q.xb[a], bh, bl);
+    split8(v8, bh, bl);
     acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[a], 0, 0, 0);
     acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[a], 0, 0, 0);
     acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[a], 0, 0, 0);
+  }
+  if constexpr (EXT) {
+    if (tail) {
+      split2(q.aw[8], q.aw[9], ah, al);
+#pragma unroll
+      for (int a = 0; a < kA; a++) {
+        f16x8 bh, bl;
+        split2(q.xb[a][8], q.xb[a][9], bh, bl);
+        acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[a], 0, 0, 0);
+        acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[a], 0, 0, 0);
+        acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[a], 0, 0, 0);
+      }
+    }
   }
 }
 // f16 hi / lo split of the wave's 24 values per lane, channel pairs exchanged inside lane pairs: even lanes end up with the hi dword of
@@ -314,6 +366,7 @@ __device__ __forceinline__ void gather_split(const f32x4 (&acc)[kA], int odd, un
 // wave-private LDS and leave as 16-byte stores.
 constexpr int kStageRow[4] = {0, 392, 836, 1228};      // dword offsets of the (half, piece) rows of a wave's staging block: 4 banks apart
 constexpr int kStageDw = 1228 + 384;
+template <bool EXT>
 __global__ __launch_bounds__(256) void kpconv_orbit_gather_kernel(const float* __restrict__ x, const float* __restrict__ hwt,
                                                                    const int* __restrict__ nbr, const int* __restrict__ cnt, int NNp,
                                                                    int64_t tiles, int Cin, unsigned char* __restrict__ Hs) {
@@ -330,12 +383,13 @@ __global__ __launch_bounds__(256) void kpconv_orbit_gather_kernel(const float* _
   f32x4 acc[kA];
 #pragma unroll
   for (int a = 0; a < kA; a++) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int rd = 0; 32 * rd < nv; rd++) {
-    int nbv[kGN];
-    GatherOps q;
-    gather_request_rows(nbrow, rd, g, nbv);
-    gather_request_ops(x, hwrow, NNp, rd, g, c16, nbv, rowlen, col, Cin, q);
-    gather_multiply(q, acc);
+  constexpr int S = EXT ? 40 : 32;
+  for (int rd = 0; S * rd < nv; rd++) {
+    int nbv[kGN + (EXT ? kGX : 0)];
+    GatherOps<EXT> q;
+    gather_request_rows<EXT>(nbrow, rd, g, nbv);
+    gather_request_ops<EXT>(x, hwrow, NNp, rd, g, c16, nbv, rowlen, col, Cin, nv, q);
+    gather_multiply<EXT>(q, nv > S * rd + 32, acc);
   }
   unsigned word[kA][4];
   gather_split(acc, odd, word);
@@ -362,7 +416,7 @@ __global__ __launch_bounds__(256) void kpconv_orbit_gather_kernel(const float* _
 // to image (2T) % 3 at once, while rows of chunk 2T + 1 computed in step 2T wait in registers for one step (image (2T + 1) % 3 is still being
 // read during step 2T).  All operands of step u + 1 (neighbour numbers, orbit weights, 36 gathered values per lane) are requested during step
 // u: the producers' memory latency (two dependent round trips, 1-3 us each under load) is off the critical path.
-template <int NCW, int KS, int CT>      // consumer waves: NCW column groups x KS K-split groups; CT column tiles (32 columns) per wave
+template <int NCW, int KS, int CT, bool EXT>      // consumer waves: NCW column groups x KS K-split groups; CT column tiles (32 columns) per wave; EXT: neighbour tables wider than 32
 __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
     const float* __restrict__ x, const float* __restrict__ hwt, const int* __restrict__ nbr, const int* __restrict__ cnt, int NNp,
     const u32x4* __restrict__ Wf, const float* __restrict__ hdr, int64_t P, int Cin, int Cout, float* __restrict__ out) {
@@ -400,7 +454,8 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
 #pragma unroll
       for (int r = 0; r < 4; r++) held[a][r] = 0u;
     // operands of the step about to run, requested one step ahead
-    GatherOps ops;
+    constexpr int S = EXT ? 40 : 32;
+    GatherOps<EXT> ops;
     int nv_cur = 0;
     const int64_t plast = P - 1;
     auto point_of = [&](int u) { return p0 + pw + NPW * (u & 1); };
@@ -410,10 +465,10 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
     };
     {
       const int64_t p = point_of(0), pc = p < P ? p : plast;
-      int nbv[kGN];
-      gather_request_rows(nbr + pc * NNp, 0, g, nbv);
+      int nbv[kGN + (EXT ? kGX : 0)];
+      gather_request_rows<EXT>(nbr + pc * NNp, 0, g, nbv);
       nv_cur = p < P ? cnt[pc] : 0;
-      gather_request_ops(x, hwt + pc * NNp * 16, NNp, 0, g, c16, nbv, rowlen, col_of(0), Cin, ops);
+      gather_request_ops<EXT>(x, hwt + pc * NNp * 16, NNp, 0, g, c16, nbv, rowlen, col_of(0), Cin, __builtin_amdgcn_readfirstlane(nv_cur), ops);
     }
     for (int u = 0; u < steps_total; u++) {
       SE3_STAMP(u, 0)
@@ -434,8 +489,8 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
         // neighbour numbers and count of the NEXT step's point: in flight while this step multiplies
         const bool more = u + 1 < 2 * pairs;
         const int64_t pn = point_of(u + 1), pnc = pn < P ? pn : plast;
-        int nbn[kGN];
-        gather_request_rows(nbr + pnc * NNp, 0, g, nbn);
+        int nbn[kGN + (EXT ? kGX : 0)];
+        gather_request_rows<EXT>(nbr + pnc * NNp, 0, g, nbn);
         const int nv_next = (more && pn < P) ? cnt[pnc] : 0;
         SE3_STAMP(u, 1)
         f32x4 acc[kA];
@@ -443,17 +498,19 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
         for (int a = 0; a < kA; a++) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int nv = __builtin_amdgcn_readfirstlane(nv_cur);
         SE3_STAMP(u, 5)
-        if (nv > 0) gather_multiply(ops, acc);
+        if (nv > 0) gather_multiply<EXT>(ops, nv > 32, acc);
         SE3_STAMP(u, 6)
-        for (int rd = 1; 32 * rd < nv; rd++) {                            // more than 32 valid neighbours: further rounds, requested on the spot
-          int nbv[kGN];
-          GatherOps q;
-          gather_request_rows(nbr + pc * NNp, rd, g, nbv);
-          gather_request_ops(x, hwt + pc * NNp * 16, NNp, rd, g, c16, nbv, rowlen, col_of(u), Cin, q);
-          gather_multiply(q, acc);
+        for (int rd = 1; S * rd < nv; rd++) {                             // more valid neighbours than a round holds: further rounds, requested on the spot
+          int nbv[kGN + (EXT ? kGX : 0)];
+          GatherOps<EXT> q;
+          gather_request_rows<EXT>(nbr + pc * NNp, rd, g, nbv);
+          gather_request_ops<EXT>(x, hwt + pc * NNp * 16, NNp, rd, g, c16, nbv, rowlen, col_of(u), Cin, nv, q);
+          gather_multiply<EXT>(q, nv > S * rd + 32, acc);
         }
+        SE3_STAMP(u, 7)
         // the next step's operands leave now (their neighbour numbers have arrived behind the MFMAs)
-        gather_request_ops(x, hwt + pnc * NNp * 16, NNp, 0, g, c16, nbn, rowlen, col_of(more ? u + 1 : u), Cin, ops);
+        gather_request_ops<EXT>(x, hwt + pnc * NNp * 16, NNp, 0, g, c16, nbn, rowlen, col_of(more ? u + 1 : u), Cin,
+                                __builtin_amdgcn_readfirstlane(nv_next), ops);
         nv_cur = nv_next;
         SE3_STAMP(u, 2)
         unsigned word[kA][4];
@@ -679,7 +736,7 @@ extern "C" int se3_kpconv_so3_contract_f16(const void* sums, const void* weight_
 
 extern "C" size_t se3_kpconv_neighbor_table_bytes(int64_t num_queries, int num_neighbors) {
   if (num_queries < 0 || num_neighbors < 1 || num_neighbors > 64) return 0;
-  const size_t nnp = (size_t)(num_neighbors + 31) / 32 * 32;
+  const size_t nnp = num_neighbors <= 32 ? 32 : (size_t)(num_neighbors + 39) / 40 * 40;
   return (size_t)num_queries * nnp * (16 * sizeof(float) + sizeof(int)) + (size_t)num_queries * sizeof(int) + 256;
 }
 
@@ -691,7 +748,7 @@ struct NeighborTable {
 };
 NeighborTable table_views(const void* table, int64_t P, int NN) {
   NeighborTable t;
-  t.NNp = (NN + 31) / 32 * 32;
+  t.NNp = NN <= 32 ? 32 : (NN + 39) / 40 * 40;      // rounds of 32 slots, or of 40 for tables wider than 32 (csrc: GatherOps<EXT>)
   t.hwt = static_cast<const float*>(table);
   t.nbr = reinterpret_cast<const int*>(t.hwt + (size_t)P * t.NNp * 16);
   t.cnt = t.nbr + (size_t)P * t.NNp;
@@ -726,8 +783,13 @@ extern "C" int se3_kpconv_so3_gather_sums(const float* x, const void* table, int
   if (num_queries == 0) return SE3_OK;
   const NeighborTable t = table_views(table, num_queries, num_neighbors);
   const int pairs = (in_channels / kCC + 1) / 2, waves = pairs < 4 ? pairs : 4;
-  kpconv_orbit_gather_kernel<<<dim3((unsigned)num_queries, (unsigned)((pairs + 3) / 4)), 64 * waves, 0, (hipStream_t)stream>>>(
-      x, t.hwt, t.nbr, t.cnt, t.NNp, se3_cdiv(num_queries, kTP), in_channels, static_cast<unsigned char*>(sums));
+  const dim3 grid((unsigned)num_queries, (unsigned)((pairs + 3) / 4));
+  if (t.NNp > 32)
+    kpconv_orbit_gather_kernel<true><<<grid, 64 * waves, 0, (hipStream_t)stream>>>(x, t.hwt, t.nbr, t.cnt, t.NNp, se3_cdiv(num_queries, kTP),
+                                                                                  in_channels, static_cast<unsigned char*>(sums));
+  else
+    kpconv_orbit_gather_kernel<false><<<grid, 64 * waves, 0, (hipStream_t)stream>>>(x, t.hwt, t.nbr, t.cnt, t.NNp, se3_cdiv(num_queries, kTP),
+                                                                                   in_channels, static_cast<unsigned char*>(sums));
   SE3_CHECK_LAUNCH("kpconv_so3_gather_sums");
   return SE3_OK;
 }
@@ -748,22 +810,28 @@ extern "C" int se3_kpconv_so3_fused(const float* x, const void* table, int64_t n
   const float* hdr = static_cast<const float*>(weight_pieces);
   const u32x4* Wf = reinterpret_cast<const u32x4*>(static_cast<const unsigned char*>(weight_pieces) + kHeaderB);
   const size_t lds = (size_t)3 * kTileB + kSteps * 4 * sizeof(unsigned);
-#define SE3_FUSED(NCW_, KS_, CT_)                                                                                                   \
-  {                                                                                                                                 \
-    static bool attr_set = false;                                                                                                   \
-    if (!attr_set) {                                                                                                                \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kpconv_fused_kernel<NCW_, KS_, CT_>),                                \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                              \
-      attr_set = true;                                                                                                              \
-    }                                                                                                                               \
-    kpconv_fused_kernel<NCW_, KS_, CT_><<<dim3((unsigned)tiles, (unsigned)(NCT / (NCW_ * CT_))), 64 * (NCW_ * KS_ + 8), lds, st>>>( \
-        x, t.hwt, t.nbr, t.cnt, t.NNp, Wf, hdr, num_queries, in_channels, out_channels, out);                                       \
+#define SE3_FUSED_X(NCW_, KS_, CT_, EXT_)                                                                                                 \
+  {                                                                                                                                       \
+    static bool attr_set = false;                                                                                                         \
+    if (!attr_set) {                                                                                                                      \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kpconv_fused_kernel<NCW_, KS_, CT_, EXT_>),                                \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                                    \
+      attr_set = true;                                                                                                                    \
+    }                                                                                                                                     \
+    kpconv_fused_kernel<NCW_, KS_, CT_, EXT_><<<dim3((unsigned)tiles, (unsigned)(NCT / (NCW_ * CT_))), 64 * (NCW_ * KS_ + 8), lds, st>>>( \
+        x, t.hwt, t.nbr, t.cnt, t.NNp, Wf, hdr, num_queries, in_channels, out_channels, out);                                             \
+  }
+#define SE3_FUSED(NCW_, KS_, CT_)                       \
+  {                                                     \
+    if (t.NNp > 32) SE3_FUSED_X(NCW_, KS_, CT_, true)   \
+    else SE3_FUSED_X(NCW_, KS_, CT_, false)             \
   }
   // 11 or 12 waves per compute unit (3 per SIMD: 168 registers): 8 producers + 3 or 4 consumers
   if (NCT % 8 == 0) SE3_FUSED(4, 1, 2)
   else if (NCT % 4 == 0) SE3_FUSED(4, 1, 1)
   else if (NCT % 2 == 0) SE3_FUSED(1, 3, 2)
   else SE3_FUSED(1, 3, 1)
+#undef SE3_FUSED_X
 #undef SE3_FUSED
   SE3_CHECK_LAUNCH("kpconv_so3_fused");
   return SE3_OK;
