@@ -133,6 +133,33 @@ int se3_group_norm_segments_bwd(const float* x, const float* x_bias, const float
                                 int num_segments, float eps, int apply_leaky_relu, float slope, float* grad_x, float* grad_residual,
                                 float* grad_params, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Pending forms (inference path of the bottleneck blocks, blocks_epn.py:798-852): a GroupNorm [+ LeakyReLU] that has been reduced to its
+ * affine table [segment][2][channels] (scale, shift: norm(x + x_bias) * weight + bias == x * scale + shift) but not applied -- the consumer
+ * applies it while it loads x, so the normalised activation never makes a round trip through HBM.
+ *   se3_group_norm_stats   the table of GroupNorm over T(x), T = a pending stage on x itself (in_affine NULL: T = identity).  Workspace:
+ *                          se3_group_norm_workspace_bytes.
+ *   se3_group_norm_apply   out = lrelu_f( Tb(Ta(x)) + R ),  T.(v) = lrelu_slope(v * scale + shift);  R = residual * scale_r + shift_r
+ *                          (residual_affine: the shortcut branch's own pending GroupNorm), the plain residual, or nothing.  A slope of 1
+ *                          is "no LeakyReLU".  channels % 4 == 0.
+ *   se3_dense_norm_fwd     UnaryBlockEPN (blocks_epn.py:639-665) = mlp + GroupNormEPN with both of the above folded into the GEMM
+ *                          (csrc/dense_norm.hip): out = T_b(T_a(x)) W^T WITHOUT the bias (raw), affine_out = the table of
+ *                          GroupNorm(out + linear_bias) computed from the accumulators.  weight_pieces: se3_linear_split_weights_f16.
+ *                          in_features a power of two 32..1024; out_features 32, 64, 128 or a multiple of 256; f16 hi/lo split arithmetic
+ *                          (f32 accuracy, |T(x)| < 65504).  Workspace: se3_dense_norm_workspace_bytes(out_features). */
+int se3_group_norm_stats(const float* x, const float* in_affine, float in_slope, const float* x_bias, const float* weight, const float* bias,
+                         int64_t rows, int channels, int groups, const int64_t* segment_row_offsets_host, int num_segments, float eps,
+                         float* affine_out, void* workspace, size_t workspace_bytes, void* stream);
+int se3_group_norm_apply(const float* x, const float* affine_a, float slope_a, const float* affine_b, float slope_b, const float* residual,
+                         const float* residual_affine, float final_slope, int64_t rows, int channels,
+                         const int64_t* segment_row_offsets_host, int num_segments, float* out, void* stream);
+size_t se3_dense_norm_workspace_bytes(int out_features);
+int se3_dense_norm_fwd(const float* x, int64_t rows, int in_features, const float* in_affine_a, float in_slope_a, const float* in_affine_b,
+                       float in_slope_b, const void* weight_pieces, int out_features, const float* linear_bias, const float* norm_weight,
+                       const float* norm_bias, int groups, float eps, const int64_t* segment_row_offsets_host, int num_segments, float* out,
+                       float* affine_out, void* workspace, size_t workspace_bytes, void* stream);
+/* Tuning hook (tools/micro): workgroups se3_dense_norm_fwd aims at (default 768 = 3 per compute unit, all resident at once). */
+void se3_dense_norm_set_target_chunks(int workgroups);
+
 /* ---- D6: LayerNorm(hidden + residual) ---------------------------------------------------------------------------
  * Replaces the residual + nn.LayerNorm tails of geotransformer/modules/transformer/rpe_transformer.py:163-164,
  * vanilla_transformer.py:910-911 and output_layer.py:21,46.  hidden (rows, channels); residual (residual_rows,

@@ -1,0 +1,332 @@
+// B2: the dense layer of a unary block fused with the GroupNorm on either side of it (inference path of UnaryBlockEPN,
+// geotransformer/modules/e2pn/blocks_epn.py:639-665 mlp + 684-701 GroupNormEPN, as composed by ResnetBottleneckBlockEPN, :798-852).
+//
+//   y = T(x) W^T            T: the pending GroupNorm(s) + LeakyReLU of the producer, applied to x on its way into LDS (0, 1 or 2 stages of
+//                           v -> lrelu(v scale[seg][k] + shift[seg][k])): the normalised activation is never written to HBM
+//   statistics of y         Welford partials (count, mean, M2) per (row chunk, output channel) from the accumulators, merged over the
+//                           chunk's row tiles in registers: the GroupNorm that follows needs no pass over y (rowops.hip: gn_partial4_kernel);
+//                           the layer's bias is not added to y: it shifts the means (gn_finalize_kernel) and nothing else
+//
+// Arithmetic as csrc/linear_f16.hip: f16 hi + lo pieces of both operands, three products on v_mfma_f32_32x32x16_f16, f32 accumulation
+// (error 2^-22 per term).  One workgroup (4 waves) owns one row chunk of one segment (the chunks of the GroupNorm statistics: a chunk
+// never straddles two pairs of the stacked batch) and walks its row tiles with the loads two K-steps ahead of the multiplies, across tile
+// boundaries: these layers are short (K 32 .. 256 for most of the rows), their time is HBM time, and a tile-at-a-time kernel leaves the
+// memory system idle during every prologue and epilogue (linear_f16_kernel: 2.4 TB/s at K = 64).
+#include "common.h"
+#include "group_norm.h"
+
+namespace {
+
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+constexpr int kHeaderB = 256;                 // weight pieces: se3_linear_split_weights_f16 (csrc/linear_f16.hip)
+constexpr int kRowB = 80;                     // bytes per (piece, row) of the A image of one K-step: 32 f16 + 16 B pad
+
+struct DenseArgs {
+  const float* x;            // (rows, K)
+  const float* in_affine[2]; // per stage: [segment][2][K] (scale, shift), or null
+  float in_slope[2];
+  int K, N, NCT;
+  const u32x4* Wf;
+  const float* hdr;
+  float* out;                // (rows, N): x W^T, no bias
+  float* part;               // [chunk][N][3]
+  SegTable T;
+};
+
+// WM x WN waves, each RT x CT MFMA tiles of 32 x 32: rows per tile TR = 32 RT WM, columns per workgroup BN = 32 CT WN
+template <int WM, int WN, int RT, int CT>
+__global__ __launch_bounds__(256, 3) void dense_norm_kernel(const DenseArgs a) {
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int TR = 32 * RT * WM, BN = 32 * CT * WN, U = TR / 32;      // U: float4 units per thread and K-step
+  constexpr int kPieceB = TR * kRowB, kBufB = 2 * kPieceB;
+  __shared__ __align__(16) unsigned char lds[2 * kBufB];
+  extern __shared__ __align__(16) float aff[];                           // [stage][2][K] of this workgroup's segment
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int K = a.K, N = a.N;
+  long long r0, r1;
+  chunk_rows(a.T, blockIdx.x, r0, r1);
+  if (r0 >= r1) {                                                        // (a chunk emptied by the row quantum: its partials count nothing)
+    for (int i = tid; i < BN; i += 256) {
+      float* p = a.part + ((int64_t)blockIdx.x * N + blockIdx.y * BN + i) * 3;
+      p[0] = p[1] = p[2] = 0.f;
+    }
+    return;
+  }
+  const int seg = seg_of_chunk(a.T, blockIdx.x);
+  const int stages = (a.in_affine[0] != nullptr) + (a.in_affine[1] != nullptr);
+  for (int st = 0; st < stages; st++)
+    for (int i = tid; i < 2 * K; i += 256) aff[st * 2 * K + i] = a.in_affine[st][(size_t)seg * 2 * K + i];
+  const int nk = K >> 5, lognk = 31 - __builtin_clz(nk);
+  const int ntiles = (int)((r1 - r0 + TR - 1) / TR);
+  const int total = ntiles * nk;
+  // A staging: unit j of a thread = 4 consecutive floats of row (tid >> 3) + 32 j, floats 4 (tid & 7) .. + 3 of the K-step
+  // Buffer addressing (uniform base and step offset, 32-bit lane offsets): rows past the end of the chunk read as zeros.
+  const int q = tid & 7, urow = tid >> 3;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + r0 * K), 0, (int)((r1 - r0) * K * 4), 0x00020000);
+  const int xoff = (urow * K + 4 * q) * 4;
+  auto request = [&](int s, f32x4 (&v)[U]) {
+    const int tile = s >> lognk, kk = s & (nk - 1);
+    const int soff = (tile * TR * K + kk * 32) * 4;
+#pragma unroll
+    for (int j = 0; j < U; j++) v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff + j * 32 * K * 4, soff, 0));
+  };
+  auto stage = [&](int buf, int s, const f32x4 (&v)[U]) {               // T(v) -> f16 hi / lo -> LDS image `buf`
+    const int k = (s & (nk - 1)) * 32 + 4 * q;
+    f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sh0 = {0.f, 0.f, 0.f, 0.f}, sc1 = sc0, sh1 = sh0;
+    if (stages > 0) {
+      sc0 = *reinterpret_cast<const f32x4*>(aff + k);
+      sh0 = *reinterpret_cast<const f32x4*>(aff + K + k);
+    }
+    if (stages > 1) {
+      sc1 = *reinterpret_cast<const f32x4*>(aff + 2 * K + k);
+      sh1 = *reinterpret_cast<const f32x4*>(aff + 3 * K + k);
+    }
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+      f32x4 t = v[j];
+      if (stages > 0) {
+        t = t * sc0 + sh0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) t[e] = t[e] > 0.f ? t[e] : t[e] * a.in_slope[0];
+      }
+      if (stages > 1) {
+        t = t * sc1 + sh1;
+#pragma unroll
+        for (int e = 0; e < 4; e++) t[e] = t[e] > 0.f ? t[e] : t[e] * a.in_slope[1];
+      }
+      f16x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        hi[e] = (_Float16)t[e];
+        lo[e] = (_Float16)(t[e] - (float)hi[e]);
+      }
+      unsigned char* dst = lds + buf * kBufB + (urow + 32 * j) * kRowB + q * 8;
+      *reinterpret_cast<f16x4*>(dst) = hi;
+      *reinterpret_cast<f16x4*>(dst + kPieceB) = lo;
+    }
+  };
+  const int a_read = (wm * (RT * 32) + i32) * kRowB + h * 16;           // + rt * 32 * kRowB + ks * 32 + piece * kPieceB
+  const int ct0 = blockIdx.y * (BN / 32) + wn * CT;
+  const u32x4* wbase = a.Wf + (int64_t)ct0 * 2 * 64 + lane;
+  const int64_t wstep = (int64_t)a.NCT * 2 * 64;                        // u32x4 per K16-step
+  const int nk16 = 2 * nk;
+  const float inv_scale = a.hdr[0];
+  f32x16 acc[RT][CT];
+#pragma unroll
+  for (int r = 0; r < RT; r++)
+#pragma unroll
+    for (int c = 0; c < CT; c++)
+#pragma unroll
+      for (int v = 0; v < 16; v++) acc[r][c][v] = 0.f;
+  WF run[CT];
+#pragma unroll
+  for (int c = 0; c < CT; c++) run[c] = {0.f, 0.f, 0.f};
+  u32x4 bq[2][CT][2];                                                   // weight fragments of the next two K16 sub-steps
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+#pragma unroll
+    for (int c = 0; c < CT; c++) {
+      const int g = j & (nk16 - 1);
+      bq[j][c][0] = wbase[g * wstep + c * 128];
+      bq[j][c][1] = wbase[g * wstep + c * 128 + 64];
+    }
+
+  auto multiply = [&](int buf, int s) {
+    const unsigned char* img = lds + buf * kBufB + a_read;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      f16x8 av[RT][2];
+#pragma unroll
+      for (int r = 0; r < RT; r++) {
+        av[r][0] = *reinterpret_cast<const f16x8*>(img + r * 32 * kRowB + ks * 32);
+        av[r][1] = *reinterpret_cast<const f16x8*>(img + r * 32 * kRowB + ks * 32 + kPieceB);
+      }
+#pragma unroll
+      for (int c = 0; c < CT; c++) {
+        const f16x8 b0 = __builtin_bit_cast(f16x8, bq[ks][c][0]);
+#pragma unroll
+        for (int r = 0; r < RT; r++) acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[r][1], b0, acc[r][c], 0, 0, 0);
+      }
+#pragma unroll
+      for (int c = 0; c < CT; c++) {
+        const f16x8 b1 = __builtin_bit_cast(f16x8, bq[ks][c][1]);
+#pragma unroll
+        for (int r = 0; r < RT; r++) acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[r][0], b1, acc[r][c], 0, 0, 0);
+      }
+#pragma unroll
+      for (int c = 0; c < CT; c++) {
+        const f16x8 b0 = __builtin_bit_cast(f16x8, bq[ks][c][0]);
+#pragma unroll
+        for (int r = 0; r < RT; r++) acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[r][0], b0, acc[r][c], 0, 0, 0);
+      }
+      {
+        const int g = (2 * ((s + 1) & (nk - 1)) + ks) & (nk16 - 1);    // the same sub-step of the next K-step (the sequence wraps at a tile end)
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+          bq[ks][c][0] = wbase[g * wstep + c * 128];
+          bq[ks][c][1] = wbase[g * wstep + c * 128 + 64];
+        }
+      }
+    }
+    if ((s & (nk - 1)) != nk - 1) return;
+    // ---- end of a row tile: store y, fold the tile into the running statistics of this wave's columns, clear the accumulators
+    const int tile = s >> lognk;
+    const long long trow0 = r0 + (long long)tile * TR + wm * (RT * 32);            // uniform
+    const int rows_here = (int)(r1 - trow0 < RT * 32 ? (r1 - trow0 > 0 ? r1 - trow0 : 0) : RT * 32);
+    const int left = rows_here - 4 * h;                                            // rows of this lane's column slice that exist
+    // the rows of this wave's block as a buffer of rows_here rows: stores to rows past the chunk fall outside and are dropped
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(a.out + trow0 * N, 0, rows_here * N * 4, 0x00020000);
+#pragma unroll
+    for (int c = 0; c < CT; c++) {
+      const int lane_off = (4 * h * N + (ct0 + c) * 32 + i32) * 4;
+      float cnt = 0.f, sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < RT; r++)
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+          const int rr = r * 32 + (v & 3) + 8 * (v >> 2);
+          const float val = acc[r][c][v] * inv_scale;
+          acc[r][c][v] = val;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ors, lane_off, rr * N * 4, 0);
+          if (rr < left) {
+            cnt += 1.f;
+            sum += val;
+          }
+        }
+      cnt += __shfl_xor(cnt, 32);
+      sum += __shfl_xor(sum, 32);
+      const float mean = sum / fmaxf(cnt, 1.f);
+      float m2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < RT; r++)
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+          const int rr = r * 32 + (v & 3) + 8 * (v >> 2);
+          const float d = acc[r][c][v] - mean;
+          if (rr < left) m2 += d * d;
+          acc[r][c][v] = 0.f;
+        }
+      m2 += __shfl_xor(m2, 32);
+      run[c] = wf_merge(run[c], WF{cnt, mean, m2});
+    }
+  };
+
+  f32x4 ra[U], rb[U];                                                   // the operands of steps s + 1 and s + 2
+  request(0, ra);
+  request(1, rb);
+  __syncthreads();                                                       // the affine table
+  stage(0, 0, ra);
+#pragma unroll
+  for (int j = 0; j < U; j++) ra[j] = rb[j];
+  request(2, rb);
+  __syncthreads();
+#pragma unroll 1
+  for (int s = 0; s < total; s++) {
+    multiply(s & 1, s);
+    stage((s + 1) & 1, s + 1, ra);
+#pragma unroll
+    for (int j = 0; j < U; j++) ra[j] = rb[j];
+    request(s + 3, rb);
+    __syncthreads();
+  }
+  // the waves that share columns merge their statistics through LDS; wave row 0 writes the chunk's partials
+  __syncthreads();
+  WF* sh = reinterpret_cast<WF*>(lds);                                   // [wave][CT][32]
+  if (h == 0)
+#pragma unroll
+    for (int c = 0; c < CT; c++) sh[(wave * CT + c) * 32 + i32] = run[c];
+  __syncthreads();
+  if (wm == 0 && h == 0)
+#pragma unroll
+    for (int c = 0; c < CT; c++) {
+      WF w = run[c];
+      for (int m = 1; m < WM; m++) w = wf_merge(w, sh[((m * WN + wn) * CT + c) * 32 + i32]);
+      float* p = a.part + ((int64_t)blockIdx.x * N + (ct0 + c) * 32 + i32) * 3;
+      p[0] = w.n; p[1] = w.mean; p[2] = w.m2;
+    }
+}
+
+int g_target_chunks = 768;                   // workgroups (row chunks x column blocks) aimed at: 3 per compute unit, all resident at once
+
+}  // namespace
+
+extern "C" void se3_dense_norm_set_target_chunks(int workgroups) { g_target_chunks = workgroups > 0 ? workgroups : 768; }
+
+extern "C" size_t se3_dense_norm_workspace_bytes(int out_features) {
+  return (size_t)(kGNMaxChunks + kGNMaxSegments) * out_features * 3 * sizeof(float) + 256;
+}
+
+extern "C" int se3_dense_norm_fwd(const float* x, int64_t rows, int in_features, const float* in_affine_a, float in_slope_a,
+                                  const float* in_affine_b, float in_slope_b, const void* weight_pieces, int out_features,
+                                  const float* linear_bias, const float* norm_weight, const float* norm_bias, int groups, float eps,
+                                  const int64_t* segment_row_offsets_host, int num_segments, float* out, float* affine_out, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  SE3_REQUIRE(x && weight_pieces && norm_weight && norm_bias && out && affine_out && workspace, SE3_ERR_INVALID_ARG, "dense_norm: null pointer");
+  const int K = in_features, N = out_features;
+  SE3_REQUIRE(K >= 32 && K <= 1024 && (K & (K - 1)) == 0 && N >= 32 && N % 32 == 0 && (N < 256 ? (N & (N - 1)) == 0 : N % 256 == 0),
+              SE3_ERR_UNSUPPORTED, "dense_norm: %d -> %d features (in: a power of two 32..1024; out: 32, 64, 128 or a multiple of 256)", K, N);
+  SE3_REQUIRE(rows >= 1 && groups >= 1 && N % groups == 0, SE3_ERR_INVALID_ARG, "dense_norm: rows %lld groups %d", (long long)rows, groups);
+  SE3_REQUIRE(num_segments >= 1 && num_segments <= kGNMaxSegments && (num_segments == 1 || segment_row_offsets_host), SE3_ERR_UNSUPPORTED,
+              "dense_norm: %d segments (1..%d)", num_segments, kGNMaxSegments);
+  SE3_REQUIRE(((uintptr_t)x & 15) == 0 && (in_affine_a || !in_affine_b), SE3_ERR_INVALID_ARG, "dense_norm: x must be 16-byte aligned; stage b needs stage a");
+  SE3_REQUIRE(workspace_bytes >= se3_dense_norm_workspace_bytes(N), SE3_ERR_WORKSPACE, "dense_norm: workspace too small");
+  const int TR = N >= 256 ? 64 : 128, BN = N >= 256 ? 256 : N;
+  const int ncb = N / BN;
+  // row chunks: whole row tiles, about g_target_chunks workgroups in all, never across a segment boundary
+  SegTable T{};
+  T.n = num_segments;
+  T.quantum = TR;
+  int64_t tiles = 0;
+  for (int s = 0; s < num_segments; s++) {
+    const int64_t b0 = num_segments == 1 ? 0 : segment_row_offsets_host[s], b1 = num_segments == 1 ? rows : segment_row_offsets_host[s + 1];
+    SE3_REQUIRE(b1 > b0 && b0 >= 0 && b1 <= rows, SE3_ERR_INVALID_ARG, "dense_norm: segment %d rows [%lld, %lld)", s, (long long)b0, (long long)b1);
+    tiles += se3_cdiv(b1 - b0, TR);
+  }
+  int64_t want = g_target_chunks / ncb;
+  if (want > kGNMaxChunks - num_segments) want = kGNMaxChunks - num_segments;
+  if (want < 1) want = 1;
+  const int64_t tiles_per_chunk = se3_cdiv(tiles, want);
+  int chunks = 0;
+  for (int s = 0; s < num_segments; s++) {
+    const int64_t b0 = num_segments == 1 ? 0 : segment_row_offsets_host[s], b1 = num_segments == 1 ? rows : segment_row_offsets_host[s + 1];
+    T.row_begin[s] = b0;
+    T.row_begin[s + 1] = b1;
+    T.chunk_begin[s] = chunks;
+    chunks += (int)se3_cdiv(se3_cdiv(b1 - b0, TR), tiles_per_chunk);
+    T.chunk_begin[s + 1] = chunks;
+  }
+  SE3_REQUIRE(T.row_begin[0] == 0 && T.row_begin[num_segments] == rows && chunks <= kGNMaxChunks + kGNMaxSegments, SE3_ERR_INVALID_ARG,
+              "dense_norm: the segments must cover all rows");
+  DenseArgs a{};
+  a.x = x;
+  a.in_affine[0] = in_affine_a;
+  a.in_affine[1] = in_affine_b;
+  a.in_slope[0] = in_slope_a;
+  a.in_slope[1] = in_slope_b;
+  a.K = K;
+  a.N = N;
+  a.NCT = (N + 63) / 64 * 2;
+  a.hdr = static_cast<const float*>(weight_pieces);
+  a.Wf = reinterpret_cast<const u32x4*>(static_cast<const unsigned char*>(weight_pieces) + kHeaderB);
+  a.out = out;
+  a.part = static_cast<float*>(workspace);
+  a.T = T;
+  const size_t dyn = (size_t)((in_affine_a != nullptr) + (in_affine_b != nullptr)) * 2 * K * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)chunks, (unsigned)ncb);
+  if (N >= 256) dense_norm_kernel<1, 4, 2, 2><<<grid, 256, dyn, st>>>(a);
+  else if (N == 128) dense_norm_kernel<2, 2, 2, 2><<<grid, 256, dyn, st>>>(a);
+  else if (N == 64) dense_norm_kernel<4, 1, 1, 2><<<grid, 256, dyn, st>>>(a);
+  else dense_norm_kernel<4, 1, 1, 1><<<grid, 256, dyn, st>>>(a);
+  gn_finalize_kernel<<<dim3((unsigned)groups, (unsigned)num_segments), 256, 0, st>>>(a.part, linear_bias, norm_weight, norm_bias, N, groups, T, eps,
+                                                                                      affine_out);
+  SE3_CHECK_LAUNCH("dense_norm");
+  return SE3_OK;
+}

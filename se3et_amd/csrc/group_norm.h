@@ -1,0 +1,151 @@
+// GroupNorm over stacked points: the pieces shared by the row-wise kernels (rowops.hip) and the dense layer that produces GroupNorm
+// statistics in its epilogue (dense_norm.hip).  geotransformer/modules/e2pn/blocks_epn.py:684-701 (GroupNormEPN).
+#pragma once
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GroupNorm: per-(row chunk, channel) Welford partials -> per-group finalize (Chan merge) -> normalize.
+// Deterministic (no atomics) and cancellation-free (M2 form).
+// ---------------------------------------------------------------------------------------------------------------------
+struct WF {
+  float n, mean, m2;
+};
+__device__ __forceinline__ WF wf_merge(WF a, WF b) {
+  if (b.n == 0.f) return a;
+  if (a.n == 0.f) return b;
+  WF r;
+  r.n = a.n + b.n;
+  const float d = b.mean - a.mean;
+  const float f = b.n / r.n;
+  r.mean = a.mean + d * f;
+  r.m2 = a.m2 + b.m2 + d * d * a.n * f;
+  return r;
+}
+
+// Segments: independent row ranges of one stacked tensor, each with its own statistics (one registration pair each when
+// several pairs share a launch; the reference normalises per pair because it runs one pair per forward).
+constexpr int kGNMaxSegments = 16;
+constexpr int kGNMaxChunks = 1024;
+struct SegTable {
+  int n;
+  int quantum;                             // rows per chunk are a multiple of this (0 / 1: any); the dense layer's chunks hold whole row tiles
+  long long row_begin[kGNMaxSegments + 1];
+  int chunk_begin[kGNMaxSegments + 1];
+};
+__device__ __forceinline__ int seg_of_chunk(const SegTable& T, int chunk) {
+  int s = 0;
+#pragma unroll
+  for (int i = 1; i < kGNMaxSegments; i++)
+    if (i < T.n && chunk >= T.chunk_begin[i]) s = i;
+  return s;
+}
+__device__ __forceinline__ int seg_of_row(const SegTable& T, long long row) {
+  int s = 0;
+#pragma unroll
+  for (int i = 1; i < kGNMaxSegments; i++)
+    if (i < T.n && row >= T.row_begin[i]) s = i;
+  return s;
+}
+// the rows [r0, r1) of global chunk `chunk`
+__device__ __forceinline__ void chunk_rows(const SegTable& T, int chunk, long long& r0, long long& r1) {
+  const int s = seg_of_chunk(T, chunk);
+  long long b0 = T.row_begin[0], b1 = T.row_begin[1];
+  int c0 = T.chunk_begin[0], c1 = T.chunk_begin[1];
+#pragma unroll
+  for (int i = 1; i < kGNMaxSegments; i++)
+    if (s == i) {
+      b0 = T.row_begin[i];
+      b1 = T.row_begin[i + 1];
+      c0 = T.chunk_begin[i];
+      c1 = T.chunk_begin[i + 1];
+    }
+  long long per = (b1 - b0 + (c1 - c0) - 1) / (c1 - c0);
+  if (T.quantum > 1) per = (per + T.quantum - 1) / T.quantum * T.quantum;
+  r0 = b0 + (long long)(chunk - c0) * per;
+  r1 = min(b1, r0 + per);
+}
+
+__device__ __forceinline__ void wf_push(WF& w, float v) {
+  w.n += 1.f;
+  const float d = v - w.mean;
+  w.mean += d * __frcp_rn(w.n);
+  w.m2 += d * (v - w.mean);
+}
+
+
+// xb (may be null): per-channel constant added to x before the normalisation (the bias of the linear layer that produced x);
+// it shifts the per-channel partial means and leaves the M2 terms unchanged, so only this pass sees it.  Output: the affine
+// map of every channel, y = x * scale[c] + shift[c] with scale = rstd_g w[c], shift = b[c] + (xb[c] - mean_g) scale.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ xb,
+                                                          const float* __restrict__ gw, const float* __restrict__ gb, int C,
+                                                          int groups, SegTable T, float eps, float* __restrict__ affine,
+                                                          float* __restrict__ stats = nullptr) {
+  __shared__ WF sh[256];
+  __shared__ float mean_s, rstd_s;
+  const int g = blockIdx.x, cpg = C / groups, seg = blockIdx.y;
+  int cb = T.chunk_begin[0], ce = T.chunk_begin[1];
+#pragma unroll
+  for (int i = 1; i < kGNMaxSegments; i++)
+    if (seg == i) {
+      cb = T.chunk_begin[i];
+      ce = T.chunk_begin[i + 1];
+    }
+  affine += (size_t)seg * 2 * C;
+  const int total = (ce - cb) * cpg;
+  WF w = {0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int chunk = cb + i / cpg, c = g * cpg + (i % cpg);
+    const float* p = part + ((int64_t)chunk * C + c) * 3;
+    WF o = {p[0], p[1] + (xb ? xb[c] : 0.f), p[2]};
+    w = wf_merge(w, o);
+  }
+  sh[threadIdx.x] = w;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sh[threadIdx.x] = wf_merge(sh[threadIdx.x], sh[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const WF r = sh[0];
+    mean_s = r.mean;
+    rstd_s = 1.0f / sqrtf(r.m2 / r.n + eps);
+    if (stats) {                               // (mean of x + xb, rstd, element count) of (segment, group): the backward pass reads them
+      float* st = stats + ((size_t)seg * groups + g) * 3;
+      st[0] = mean_s; st[1] = rstd_s; st[2] = r.n;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < cpg; i += 256) {
+    const int c = g * cpg + i;
+    const float scale = rstd_s * gw[c];
+    affine[c] = scale;
+    affine[C + c] = gb[c] + ((xb ? xb[c] : 0.f) - mean_s) * scale;
+  }
+}
+
+}  // namespace
+
+static bool gn_fast_path(int channels) { return channels >= 16 && channels <= 1024 && (channels & (channels - 1)) == 0; }
+
+// chunks per segment: up to 256 (more only move time into the finalize pass: 1024 chunks of a one-pair tensor cost it 11 us instead of 6)
+static int gn_chunk_cap(int num_segments) {
+  int cap = kGNMaxChunks / num_segments;
+  if (cap > 256) cap = 256;
+  return cap > 8 ? cap : 8;
+}
+
+// row chunks of the partial pass: a pure function of the problem size (the statistics must not depend on scheduling)
+static int64_t gn_chunks(int64_t rows, int channels, int cap) {
+  int64_t n;
+  if (gn_fast_path(channels)) {
+    const int64_t row_lanes = 256 / (channels / 4);
+    n = rows / (8 * row_lanes) + 1;           // >= 8 rows per row lane = one batch of loads in flight (32 rows: 20-30 % slower on the
+                                              // one-pair-per-forward tensors, where the partial pass is one latency chain per thread)
+  } else {
+    n = rows / 64 + 1;
+  }
+  return n > cap ? cap : n;
+}
+

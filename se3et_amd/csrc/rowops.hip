@@ -7,69 +7,10 @@
 //   add+LN        rpe_transformer.py:163-164, vanilla_transformer.py:910-911, output_layer.py:21, 46
 //   gather / max  kpconv/functional.py:6-22 (nearest_upsample), e2pn/blocks.py:93-110 (max_pool)
 #include "common.h"
+#include "group_norm.h"
 #include <stdlib.h>
 
 namespace {
-
-// ---------------------------------------------------------------------------------------------------------------------
-// GroupNorm: per-(row chunk, channel) Welford partials -> per-group finalize (Chan merge) -> normalize.
-// Deterministic (no atomics) and cancellation-free (M2 form).
-// ---------------------------------------------------------------------------------------------------------------------
-struct WF {
-  float n, mean, m2;
-};
-__device__ __forceinline__ WF wf_merge(WF a, WF b) {
-  if (b.n == 0.f) return a;
-  if (a.n == 0.f) return b;
-  WF r;
-  r.n = a.n + b.n;
-  const float d = b.mean - a.mean;
-  const float f = b.n / r.n;
-  r.mean = a.mean + d * f;
-  r.m2 = a.m2 + b.m2 + d * d * a.n * f;
-  return r;
-}
-
-// Segments: independent row ranges of one stacked tensor, each with its own statistics (one registration pair each when
-// several pairs share a launch; the reference normalises per pair because it runs one pair per forward).
-constexpr int kGNMaxSegments = 16;
-constexpr int kGNMaxChunks = 1024;
-struct SegTable {
-  int n;
-  long long row_begin[kGNMaxSegments + 1];
-  int chunk_begin[kGNMaxSegments + 1];
-};
-__device__ __forceinline__ int seg_of_chunk(const SegTable& T, int chunk) {
-  int s = 0;
-#pragma unroll
-  for (int i = 1; i < kGNMaxSegments; i++)
-    if (i < T.n && chunk >= T.chunk_begin[i]) s = i;
-  return s;
-}
-__device__ __forceinline__ int seg_of_row(const SegTable& T, long long row) {
-  int s = 0;
-#pragma unroll
-  for (int i = 1; i < kGNMaxSegments; i++)
-    if (i < T.n && row >= T.row_begin[i]) s = i;
-  return s;
-}
-// the rows [r0, r1) of global chunk `chunk`
-__device__ __forceinline__ void chunk_rows(const SegTable& T, int chunk, long long& r0, long long& r1) {
-  const int s = seg_of_chunk(T, chunk);
-  long long b0 = T.row_begin[0], b1 = T.row_begin[1];
-  int c0 = T.chunk_begin[0], c1 = T.chunk_begin[1];
-#pragma unroll
-  for (int i = 1; i < kGNMaxSegments; i++)
-    if (s == i) {
-      b0 = T.row_begin[i];
-      b1 = T.row_begin[i + 1];
-      c0 = T.chunk_begin[i];
-      c1 = T.chunk_begin[i + 1];
-    }
-  const long long per = (b1 - b0 + (c1 - c0) - 1) / (c1 - c0);
-  r0 = b0 + (long long)(chunk - c0) * per;
-  r1 = min(b1, r0 + per);
-}
 
 constexpr int kGNLanes = 64;   // channels per block
 constexpr int kGNRows = 4;     // row lanes per block
@@ -102,18 +43,30 @@ __global__ __launch_bounds__(kGNLanes* kGNRows) void gn_partial_kernel(const flo
 // Throughput version of the partial pass for power-of-two channel counts (16 .. 1024): float4 loads, Q = C / 4 channel quads
 // across the block and 256 / Q row lanes, 8 rows in flight per thread, tree merge over the row lanes.  The chunking is a
 // pure function of (rows, C), so the result does not depend on scheduling.
-__device__ __forceinline__ void wf_push(WF& w, float v) {
-  w.n += 1.f;
-  const float d = v - w.mean;
-  w.mean += d * __frcp_rn(w.n);
-  w.m2 += d * (v - w.mean);
-}
-
+// PRE: the statistics are those of lrelu(x scale + shift) -- a GroupNorm + LeakyReLU still pending on x (affine table [segment][2][C]).
+template <bool PRE>
 __global__ __launch_bounds__(256) void gn_partial4_kernel(const float* __restrict__ x, SegTable T, int C,
-                                                          float* __restrict__ part) {
+                                                          float* __restrict__ part, const float* __restrict__ pre_affine = nullptr,
+                                                          float pre_slope = 1.f) {
   __shared__ WF sh[256][4];
   const int Q = C >> 2, RL = 256 / Q;
   const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
+  float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (PRE) {
+    const float* pa = pre_affine + (size_t)seg_of_chunk(T, blockIdx.x) * 2 * C;
+    psc = reinterpret_cast<const float4*>(pa)[q];
+    psh = reinterpret_cast<const float4*>(pa + C)[q];
+  }
+  auto pre = [&](float4 v) {
+    if (PRE) {
+      v = make_float4(v.x * psc.x + psh.x, v.y * psc.y + psh.y, v.z * psc.z + psh.z, v.w * psc.w + psh.w);
+      v.x = v.x > 0.f ? v.x : v.x * pre_slope;
+      v.y = v.y > 0.f ? v.y : v.y * pre_slope;
+      v.z = v.z > 0.f ? v.z : v.z * pre_slope;
+      v.w = v.w > 0.f ? v.w : v.w * pre_slope;
+    }
+    return v;
+  };
   long long r0, r1;
   chunk_rows(T, blockIdx.x, r0, r1);
   WF w[4] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
@@ -122,7 +75,7 @@ __global__ __launch_bounds__(256) void gn_partial4_kernel(const float* __restric
   for (; r + 7 * RL < r1; r += 8 * RL) {
     float4 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) v[u] = xq[(r + u * RL) * Q];
+    for (int u = 0; u < 8; u++) v[u] = pre(xq[(r + u * RL) * Q]);
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       wf_push(w[0], v[u].x);
@@ -132,7 +85,7 @@ __global__ __launch_bounds__(256) void gn_partial4_kernel(const float* __restric
     }
   }
   for (; r < r1; r += RL) {
-    const float4 v = xq[r * Q];
+    const float4 v = pre(xq[r * Q]);
     wf_push(w[0], v.x);
     wf_push(w[1], v.y);
     wf_push(w[2], v.z);
@@ -155,56 +108,6 @@ __global__ __launch_bounds__(256) void gn_partial4_kernel(const float* __restric
       float* p = part + ((int64_t)blockIdx.x * C + 4 * q + k) * 3;
       p[0] = o.n; p[1] = o.mean; p[2] = o.m2;
     }
-  }
-}
-
-// xb (may be null): per-channel constant added to x before the normalisation (the bias of the linear layer that produced x);
-// it shifts the per-channel partial means and leaves the M2 terms unchanged, so only this pass sees it.  Output: the affine
-// map of every channel, y = x * scale[c] + shift[c] with scale = rstd_g w[c], shift = b[c] + (xb[c] - mean_g) scale.
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ xb,
-                                                          const float* __restrict__ gw, const float* __restrict__ gb, int C,
-                                                          int groups, SegTable T, float eps, float* __restrict__ affine,
-                                                          float* __restrict__ stats = nullptr) {
-  __shared__ WF sh[256];
-  __shared__ float mean_s, rstd_s;
-  const int g = blockIdx.x, cpg = C / groups, seg = blockIdx.y;
-  int cb = T.chunk_begin[0], ce = T.chunk_begin[1];
-#pragma unroll
-  for (int i = 1; i < kGNMaxSegments; i++)
-    if (seg == i) {
-      cb = T.chunk_begin[i];
-      ce = T.chunk_begin[i + 1];
-    }
-  affine += (size_t)seg * 2 * C;
-  const int total = (ce - cb) * cpg;
-  WF w = {0.f, 0.f, 0.f};
-  for (int i = threadIdx.x; i < total; i += 256) {
-    const int chunk = cb + i / cpg, c = g * cpg + (i % cpg);
-    const float* p = part + ((int64_t)chunk * C + c) * 3;
-    WF o = {p[0], p[1] + (xb ? xb[c] : 0.f), p[2]};
-    w = wf_merge(w, o);
-  }
-  sh[threadIdx.x] = w;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (threadIdx.x < s) sh[threadIdx.x] = wf_merge(sh[threadIdx.x], sh[threadIdx.x + s]);
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    const WF r = sh[0];
-    mean_s = r.mean;
-    rstd_s = 1.0f / sqrtf(r.m2 / r.n + eps);
-    if (stats) {                               // (mean of x + xb, rstd, element count) of (segment, group): the backward pass reads them
-      float* st = stats + ((size_t)seg * groups + g) * 3;
-      st[0] = mean_s; st[1] = rstd_s; st[2] = r.n;
-    }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < cpg; i += 256) {
-    const int c = g * cpg + i;
-    const float scale = rstd_s * gw[c];
-    affine[c] = scale;
-    affine[C + c] = gb[c] + ((xb ? xb[c] : 0.f) - mean_s) * scale;
   }
 }
 
@@ -243,6 +146,52 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
       if (has_slope) t = t > 0.f ? t : t * slope;
       y[i] = t;
     }
+  }
+}
+
+// The pending forms of the fused dense layers made concrete: y = lrelu_f( Tb(Ta(x)) + R ), T.(v) = lrelu(v scale + shift) per (segment,
+// channel), R = residual scale_r + shift_r (a second raw tensor with its own pending GroupNorm: the shortcut of a bottleneck block) or the
+// plain residual.  C % 4 == 0.
+struct ChainArgs {
+  const float* x;
+  const float* affine_a;
+  const float* affine_b;
+  const float* res;
+  const float* affine_r;
+  float slope_a, slope_b, slope_f;
+  int64_t rows;
+  int C;
+  float* y;
+};
+__device__ __forceinline__ float4 affine_lrelu(float4 v, const float* aff, int C, int c0, float slope) {
+  const float4 sc = *reinterpret_cast<const float4*>(aff + c0), sf = *reinterpret_cast<const float4*>(aff + C + c0);
+  float4 o = make_float4(v.x * sc.x + sf.x, v.y * sc.y + sf.y, v.z * sc.z + sf.z, v.w * sc.w + sf.w);
+  o.x = o.x > 0.f ? o.x : o.x * slope;
+  o.y = o.y > 0.f ? o.y : o.y * slope;
+  o.z = o.z > 0.f ? o.z : o.z * slope;
+  o.w = o.w > 0.f ? o.w : o.w * slope;
+  return o;
+}
+__global__ __launch_bounds__(256) void gn_chain_apply_kernel(ChainArgs p, SegTable T) {
+  const int64_t total4 = p.rows * p.C >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int C = p.C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+    const int64_t row = (i << 2) / C;
+    const int c0 = (int)((i << 2) - row * C);
+    const size_t so = (size_t)(T.n > 1 ? seg_of_row(T, row) : 0) * 2 * C;
+    float4 o = affine_lrelu(reinterpret_cast<const float4*>(p.x)[i], p.affine_a + so, C, c0, p.slope_a);
+    if (p.affine_b) o = affine_lrelu(o, p.affine_b + so, C, c0, p.slope_b);
+    if (p.res) {
+      float4 t = reinterpret_cast<const float4*>(p.res)[i];
+      if (p.affine_r) t = affine_lrelu(t, p.affine_r + so, C, c0, 1.f);
+      o = make_float4(o.x + t.x, o.y + t.y, o.z + t.z, o.w + t.w);
+    }
+    o.x = o.x > 0.f ? o.x : o.x * p.slope_f;
+    o.y = o.y > 0.f ? o.y : o.y * p.slope_f;
+    o.z = o.z > 0.f ? o.z : o.z * p.slope_f;
+    o.w = o.w > 0.f ? o.w : o.w * p.slope_f;
+    reinterpret_cast<float4*>(p.y)[i] = o;
   }
 }
 
@@ -644,28 +593,6 @@ inline unsigned grid_for(int64_t work, int tpb) {
 
 }  // namespace
 
-static bool gn_fast_path(int channels) { return channels >= 16 && channels <= 1024 && (channels & (channels - 1)) == 0; }
-
-// chunks per segment: up to 256 (more only move time into the finalize pass: 1024 chunks of a one-pair tensor cost it 11 us instead of 6)
-static int gn_chunk_cap(int num_segments) {
-  int cap = kGNMaxChunks / num_segments;
-  if (cap > 256) cap = 256;
-  return cap > 8 ? cap : 8;
-}
-
-// row chunks of the partial pass: a pure function of the problem size (the statistics must not depend on scheduling)
-static int64_t gn_chunks(int64_t rows, int channels, int cap) {
-  int64_t n;
-  if (gn_fast_path(channels)) {
-    const int64_t row_lanes = 256 / (channels / 4);
-    n = rows / (8 * row_lanes) + 1;           // >= 8 rows per row lane = one batch of loads in flight (32 rows: 20-30 % slower on the
-                                              // one-pair-per-forward tensors, where the partial pass is one latency chain per thread)
-  } else {
-    n = rows / 64 + 1;
-  }
-  return n > cap ? cap : n;
-}
-
 extern "C" size_t se3_group_norm_workspace_bytes(int64_t rows, int channels, int groups) {
   (void)rows;
   (void)groups;   // upper bound over any segmentation: <= kGNMaxChunks + 16 chunk partials, 16 affine tables
@@ -706,7 +633,7 @@ extern "C" int se3_group_norm_segments_fwd(const float* x, const float* x_bias, 
   float* affine = part + (size_t)(kGNMaxChunks + kGNMaxSegments) * channels * 3;
   hipStream_t st = (hipStream_t)stream;
   if (gn_fast_path(channels) && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
-    gn_partial4_kernel<<<(unsigned)chunks, 256, 0, st>>>(x, T, channels, part);
+    gn_partial4_kernel<false><<<(unsigned)chunks, 256, 0, st>>>(x, T, channels, part);
   } else {
     dim3 g1((unsigned)chunks, (unsigned)se3_cdiv(channels, kGNLanes));
     gn_partial_kernel<<<g1, kGNLanes * kGNRows, 0, st>>>(x, T, channels, part);
@@ -716,6 +643,72 @@ extern "C" int se3_group_norm_segments_fwd(const float* x, const float* x_bias, 
   const int64_t work = (channels % 4 == 0) ? rows * channels / 4 : rows * channels;
   gn_apply_kernel<<<grid_for(work, 256), 256, 0, st>>>(x, residual, affine, T, rows, channels, apply_leaky_relu, slope, out);
   SE3_CHECK_LAUNCH("group_norm");
+  return SE3_OK;
+}
+
+// The two halves of se3_group_norm_segments_fwd on their own, for activations that stay in their pending form (dense_norm.hip):
+// statistics -> affine table [segment][2][channels] (scale, shift) without a pass that applies it ...
+static int gn_segment_table(const char* who, int64_t rows, int channels, const int64_t* segment_row_offsets_host, int num_segments, bool chunked,
+                            SegTable& T, int& chunks) {
+  SE3_REQUIRE(num_segments >= 1 && num_segments <= kGNMaxSegments && (num_segments == 1 || segment_row_offsets_host), SE3_ERR_UNSUPPORTED,
+              "%s: %d segments (1..%d)", who, num_segments, kGNMaxSegments);
+  T = SegTable{};
+  T.n = num_segments;
+  const int cap = gn_chunk_cap(num_segments);
+  chunks = 0;
+  for (int sgm = 0; sgm < num_segments; sgm++) {
+    const int64_t b0 = num_segments == 1 ? 0 : segment_row_offsets_host[sgm];
+    const int64_t b1 = num_segments == 1 ? rows : segment_row_offsets_host[sgm + 1];
+    SE3_REQUIRE(b1 > b0 && b0 >= 0 && b1 <= rows, SE3_ERR_INVALID_ARG, "%s: segment %d rows [%lld, %lld)", who, sgm, (long long)b0, (long long)b1);
+    T.row_begin[sgm] = b0;
+    T.row_begin[sgm + 1] = b1;
+    T.chunk_begin[sgm] = chunks;
+    if (chunked) chunks += (int)gn_chunks(b1 - b0, channels, cap);
+    T.chunk_begin[sgm + 1] = chunks;
+  }
+  SE3_REQUIRE(T.row_begin[0] == 0 && T.row_begin[num_segments] == rows, SE3_ERR_INVALID_ARG, "%s: the segments must cover all rows", who);
+  return SE3_OK;
+}
+
+extern "C" int se3_group_norm_stats(const float* x, const float* in_affine, float in_slope, const float* x_bias, const float* weight,
+                                    const float* bias, int64_t rows, int channels, int groups, const int64_t* segment_row_offsets_host,
+                                    int num_segments, float eps, float* affine_out, void* workspace, size_t workspace_bytes, void* stream) {
+  SE3_REQUIRE(x && weight && bias && affine_out && workspace, SE3_ERR_INVALID_ARG, "group_norm_stats: null pointer");
+  SE3_REQUIRE(rows >= 1 && channels >= 1 && groups >= 1 && channels % groups == 0, SE3_ERR_INVALID_ARG,
+              "group_norm_stats: rows %lld channels %d groups %d", (long long)rows, channels, groups);
+  SE3_REQUIRE(workspace_bytes >= se3_group_norm_workspace_bytes(rows, channels, groups), SE3_ERR_WORKSPACE, "group_norm_stats: workspace too small");
+  const bool fast = gn_fast_path(channels) && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  SE3_REQUIRE(fast || !in_affine, SE3_ERR_UNSUPPORTED, "group_norm_stats: a pending input form needs a power-of-two channel count (16..1024), got %d",
+              channels);
+  SegTable T;
+  int chunks;
+  const int rc = gn_segment_table("group_norm_stats", rows, channels, segment_row_offsets_host, num_segments, true, T, chunks);
+  if (rc != SE3_OK) return rc;
+  float* part = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  if (fast && in_affine) gn_partial4_kernel<true><<<(unsigned)chunks, 256, 0, st>>>(x, T, channels, part, in_affine, in_slope);
+  else if (fast) gn_partial4_kernel<false><<<(unsigned)chunks, 256, 0, st>>>(x, T, channels, part);
+  else gn_partial_kernel<<<dim3((unsigned)chunks, (unsigned)se3_cdiv(channels, kGNLanes)), kGNLanes * kGNRows, 0, st>>>(x, T, channels, part);
+  gn_finalize_kernel<<<dim3((unsigned)groups, (unsigned)num_segments), 256, 0, st>>>(part, x_bias, weight, bias, channels, groups, T, eps, affine_out);
+  SE3_CHECK_LAUNCH("group_norm_stats");
+  return SE3_OK;
+}
+
+// ... and the pass that makes a pending form concrete: out = lrelu_f( Tb(Ta(x)) + R ) (gn_chain_apply_kernel); slopes of 1 = no LeakyReLU.
+extern "C" int se3_group_norm_apply(const float* x, const float* affine_a, float slope_a, const float* affine_b, float slope_b,
+                                    const float* residual, const float* residual_affine, float final_slope, int64_t rows, int channels,
+                                    const int64_t* segment_row_offsets_host, int num_segments, float* out, void* stream) {
+  SE3_REQUIRE(x && affine_a && out, SE3_ERR_INVALID_ARG, "group_norm_apply: null pointer");
+  SE3_REQUIRE(rows >= 1 && channels >= 4 && channels % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, SE3_ERR_UNSUPPORTED,
+              "group_norm_apply: rows %lld channels %d (a multiple of 4)", (long long)rows, channels);
+  SE3_REQUIRE(residual || !residual_affine, SE3_ERR_INVALID_ARG, "group_norm_apply: residual_affine without a residual");
+  SegTable T;
+  int chunks;
+  const int rc = gn_segment_table("group_norm_apply", rows, channels, segment_row_offsets_host, num_segments, false, T, chunks);
+  if (rc != SE3_OK) return rc;
+  ChainArgs p{x, affine_a, affine_b, residual, residual_affine, slope_a, slope_b, final_slope, rows, channels, out};
+  gn_chain_apply_kernel<<<grid_for(rows * channels / 4, 256), 256, 0, (hipStream_t)stream>>>(p, T);
+  SE3_CHECK_LAUNCH("group_norm_apply");
   return SE3_OK;
 }
 
@@ -762,7 +755,7 @@ extern "C" int se3_group_norm_segments_bwd(const float* x, const float* x_bias, 
   hipStream_t st = (hipStream_t)stream;
   // 1. the forward statistics
   if (gn_fast_path(channels) && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
-    gn_partial4_kernel<<<(unsigned)chunks, 256, 0, st>>>(x, T, channels, part);
+    gn_partial4_kernel<false><<<(unsigned)chunks, 256, 0, st>>>(x, T, channels, part);
   } else {
     dim3 g1((unsigned)chunks, (unsigned)se3_cdiv(channels, kGNLanes));
     gn_partial_kernel<<<g1, kGNLanes * kGNRows, 0, st>>>(x, T, channels, part);

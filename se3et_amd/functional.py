@@ -150,19 +150,59 @@ class norm_segments:
         norm_segments._tls.stage = None if i is None else ((i,) if support is None else (i, support))
 
 
+def row_segments(x):
+    """Row offsets [0, end of pair 0, ...] of the independently normalised row ranges of x (points x anchors flattened), or None for a
+    single range: from the active norm_segments context and the stage the backbone announced."""
+    ctx, stage = getattr(norm_segments._tls, 'current', None), getattr(norm_segments._tls, 'stage', None)
+    if ctx is None or stage is None:
+        return None
+    offs = next((ctx[i] for i in stage if ctx[i][-1] == x.shape[0]), None)
+    if offs is None:
+        raise RuntimeError('group_norm_rows: %d rows inside a block of pyramid stage(s) %s holding %s stacked points'
+                           % (x.shape[0], stage, [ctx[i][-1] for i in stage]))
+    if len(offs) <= 2:
+        return None
+    mult = x.numel() // x.shape[-1] // x.shape[0]
+    return [o * mult for o in offs]
+
+
+# Pending forms (inference): a GroupNorm [+ LeakyReLU] reduced to its affine table and applied by whoever loads the tensor next
+# (se3et_amd.ops.Pending; csrc/dense_norm.hip, csrc/rowops.hip: gn_chain_apply_kernel).
+Pending = _ops.Pending
+PENDING_NORM = True           # False: every GroupNorm as its own three launches (A/B runs, tools/micro)
+
+
+def dense_norm_ok(x, weight, groups):
+    raw = x.raw if isinstance(x, Pending) else x
+    return PENDING_NORM and not AG.needs_grad(raw, weight) and _ops.dense_norm_ok(x, weight, groups)
+
+
+@_hip
+def dense_norm(x, weight, linear_bias, norm_weight, norm_bias, groups, eps):
+    """Dense layer + the statistics of the GroupNorm that follows it -> Pending(raw = T(x) W^T, [affine table]) (slope 1: the caller sets
+    the LeakyReLU slope of its block).  x: a tensor or a Pending."""
+    segments = x.segments if isinstance(x, Pending) else row_segments(x)
+    return _ops.dense_norm(x, weight, linear_bias, norm_weight, norm_bias, groups, eps, segments)
+
+
+@_hip
+def norm_stats(x, norm_weight, norm_bias, groups, eps, slope, x_bias=None):
+    """x (tensor, or Pending with one stage) -> x with one more pending GroupNorm + LeakyReLU(slope) stage."""
+    pend = x if isinstance(x, Pending) else Pending(x, [], [], row_segments(x))
+    return pend.then(_ops.group_norm_stats(pend, norm_weight, norm_bias, groups, eps, x_bias), slope)
+
+
+@_hip
+def norm_apply(x, residual=None, final_slope=1.0):
+    """A Pending made concrete, optionally + residual (tensor or one-stage Pending) and a final LeakyReLU."""
+    return _ops.group_norm_apply(x, residual, final_slope)
+
+
 def group_norm_rows(x, weight, bias, groups, eps, leaky_slope=None, residual=None, x_bias=None, segments=None):
     """GroupNorm over (rows x channels-in-group) for x (..., C) with ALL leading dims pooled into the statistics
     (GroupNormEPN / kpconv GroupNorm), optionally `+ residual` then LeakyReLU, fused in one pass."""
     if segments is None:
-        ctx, stage = getattr(norm_segments._tls, 'current', None), getattr(norm_segments._tls, 'stage', None)
-        if ctx is not None and stage is not None:
-            offs = next((ctx[i] for i in stage if ctx[i][-1] == x.shape[0]), None)
-            if offs is None:
-                raise RuntimeError('group_norm_rows: %d rows inside a block of pyramid stage(s) %s holding %s stacked points'
-                                   % (x.shape[0], stage, [ctx[i][-1] for i in stage]))
-            if len(offs) > 2:
-                mult = x.numel() // x.shape[-1] // x.shape[0]
-                segments = [o * mult for o in offs]
+        segments = row_segments(x)
     if AG.needs_grad(x, weight, bias, residual, x_bias):
         # hand-written backward (csrc/rowops.hip: gn_bwd_*); AG.group_norm_rows is its torch pin
         def bwd(g, needs, x_, w, b, r, xb):

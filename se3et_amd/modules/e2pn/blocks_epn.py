@@ -75,6 +75,10 @@ class GroupNormEPN(nn.Module):
         return SF.group_norm_rows(x, self.norm.weight, self.norm.bias, self.num_groups, self.norm.eps, leaky_slope,
                                   residual, x_bias)
 
+    def pending(self, x, leaky_slope=None):
+        """Inference: the statistics only -- x (a tensor, or a Pending with one stage) with this norm [+ LeakyReLU] pending on it."""
+        return SF.norm_stats(x, self.norm.weight, self.norm.bias, self.num_groups, self.norm.eps, 1.0 if leaky_slope is None else leaky_slope)
+
 
 class UnaryBlockEPN(nn.Module):
     def __init__(self, in_dim, out_dim, group_norm, bn_momentum, no_relu=False):
@@ -89,6 +93,16 @@ class UnaryBlockEPN(nn.Module):
         if residual is not None or final_slope is not None:
             return self.norm(x, leaky_slope=final_slope, residual=residual, x_bias=self.mlp.bias)
         return self.norm(x, leaky_slope=None if self.no_relu else 0.1, x_bias=self.mlp.bias)
+
+    def pending_ok(self, x):
+        return SF.dense_norm_ok(x, self.mlp.weight, self.norm.num_groups)
+
+    def pending(self, x):
+        """Inference: mlp with the norm's statistics from the GEMM epilogue (csrc/dense_norm.hip); x may itself be pending.  -> Pending."""
+        n = self.norm
+        p = SF.dense_norm(x, self.mlp.weight, self.mlp.bias, n.norm.weight, n.norm.bias, n.num_groups, n.norm.eps)
+        p.slopes[-1] = 1.0 if self.no_relu else 0.1
+        return p
 
 
 class LastUnaryBlockEPN(nn.Module):
@@ -126,6 +140,11 @@ class SimpleBlockEPN(nn.Module):
         self.norm = GroupNormEPN(group_norm, out_dim)
 
     def forward(self, x, q_pts, s_pts, neighb_inds):
+        if (SF.PENDING_NORM and not SF.AG.needs_grad(x, self.interso3.conv.weights, self.norm.norm.weight) and x.is_cuda
+                and self.out_dim in (16, 32, 64, 128, 256, 512, 1024)):
+            # inference: both norms as statistics passes over the convolution's output, applied together in one pass
+            y = self.interso3.norm.pending(self.interso3.conv(q_pts, s_pts, neighb_inds, x), 0.1)
+            return SF.norm_apply(self.norm.pending(y, 0.1))
         return self.norm(self.interso3(x, q_pts, s_pts, neighb_inds), leaky_slope=0.1)
 
 
@@ -141,7 +160,26 @@ class ResnetBottleneckBlockEPN(nn.Module):
         self.unary2 = UnaryBlockEPN(mid, out_dim, group_norm, bn, no_relu=True)
         self.skip_conv = UnaryBlockEPN(in_dim, out_dim, group_norm, bn, no_relu=True) if in_dim != out_dim else nn.Identity()
 
+    def _forward_pending(self, x, q_pts, s_pts, neighb_inds):
+        """Inference (blocks_epn.py:798-852 with the norms in pending form): every dense layer takes the statistics of the norm behind it
+        from its accumulators and applies the norm in front of it while loading; activations are written once, raw, and only the
+        convolution's input and the block's output are made concrete."""
+        skip = x
+        if not isinstance(self.unary1, nn.Identity):
+            x = SF.norm_apply(self.unary1.pending(x))                         # the convolution gathers rows: concrete
+        y = self.interso3.norm.pending(self.interso3.conv(q_pts, s_pts, neighb_inds, x), 0.1)
+        y = self.norm.pending(y, 0.1)                                         # norm of the activated norm: a second statistics pass
+        if 'strided' in self.block_name:
+            skip = SF.neighbor_max_pool(skip, neighb_inds)
+        if not isinstance(self.skip_conv, nn.Identity):
+            skip = self.skip_conv.pending(skip)
+        return SF.norm_apply(self.unary2.pending(y), residual=skip, final_slope=0.1)
+
     def forward(self, x, q_pts, s_pts, neighb_inds):
+        if (SF.PENDING_NORM and not SF.AG.needs_grad(x, self.interso3.conv.weights, self.norm.norm.weight) and self.unary2.pending_ok(x.new_empty((0, self.unary2.in_dim)))
+                and all(isinstance(u, nn.Identity) or u.pending_ok(x) for u in (self.unary1, self.skip_conv))
+                and self.unary2.in_dim in (16, 32, 64, 128, 256, 512, 1024)):
+            return self._forward_pending(x, q_pts, s_pts, neighb_inds)
         skip = x
         x = self.unary1(x)
         x = self.interso3(x, q_pts, s_pts, neighb_inds)

@@ -431,6 +431,115 @@ def group_norm_rows_bwd(grad_out, x, weight, bias, groups, eps, leaky_slope, res
     return dx, params[0], params[1], dres, (params[2] if x_bias is not None else None)
 
 
+def _norm_workspace(device, stream, nbytes):
+    key = (device, stream.value)
+    ws = _gn_workspace.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty((max(nbytes, 1 << 22),), dtype=torch.uint8, device=device)
+        _gn_workspace[key] = ws
+    return ws
+
+
+class Pending:
+    """An activation in its pending form: `raw` (rows.., C) float32 plus up to two stages v -> lrelu(v * scale + shift, slope) that its
+    consumer applies while loading it (the GroupNorm [+ LeakyReLU] of the producer, reduced to per-(segment, channel) affine tables by
+    group_norm_stats / dense_norm).  `affines`: list of (nseg, 2, C) tensors; `slopes`: list of floats (1.0 = no LeakyReLU)."""
+    __slots__ = ('raw', 'affines', 'slopes', 'segments')
+
+    def __init__(self, raw, affines, slopes, segments):
+        self.raw, self.affines, self.slopes, self.segments = raw, list(affines), list(slopes), segments
+
+    def then(self, affine, slope):
+        return Pending(self.raw, self.affines + [affine], self.slopes + [slope], self.segments)
+
+
+def dense_norm_ok(x, weight, groups):
+    """True when the fused dense layer + GroupNorm statistics kernel (csrc/dense_norm.hip) takes this layer."""
+    raw = x.raw if isinstance(x, Pending) else x
+    if torch.is_grad_enabled() and (raw.requires_grad or weight.requires_grad):
+        return False
+    N, K = weight.shape
+    return (raw.is_cuda and raw.dtype == torch.float32 and weight.dtype == torch.float32 and weight.is_contiguous() and raw.is_contiguous()
+            and raw.shape[-1] == K and 32 <= K <= 1024 and K & (K - 1) == 0 and (N in (32, 64, 128) or N % 256 == 0) and N % groups == 0
+            and raw.data_ptr() % 16 == 0)
+
+
+def dense_norm(x, weight, linear_bias, norm_weight, norm_bias, groups, eps, segments=None):
+    """HIP (csrc/dense_norm.hip): the dense layer of a unary block with the GroupNorm statistics of its output taken from the accumulators.
+    x: a tensor or a Pending (its stages are applied on load).  -> Pending(raw = T(x) W^T without the bias, [affine of GroupNorm(raw + bias)],
+    slope left to the caller via .slopes[-1])."""
+    pend = x if isinstance(x, Pending) else Pending(x, [], [], segments)
+    raw = _req(pend.raw, torch.float32, 'x')
+    if len(pend.affines) > 2:
+        raise RuntimeError('dense_norm: at most two pending stages')
+    segments = pend.segments if segments is None else segments
+    N, K = weight.shape
+    rows = raw.numel() // K
+    stream = _stream()
+    Wp = _linear_weight_pieces(weight.detach(), stream)
+    nseg = 1 if segments is None else len(segments) - 1
+    out = torch.empty(raw.shape[:-1] + (N,), dtype=torch.float32, device=raw.device)
+    affine = torch.empty((nseg, 2, N), dtype=torch.float32, device=raw.device)
+    ws = _norm_workspace(raw.device, stream, lib().se3_dense_norm_workspace_bytes(N))
+    aa = pend.affines + [None, None]
+    sl = pend.slopes + [1.0, 1.0]
+    check(lib().se3_dense_norm_fwd(raw.data_ptr(), rows, K, aa[0].data_ptr() if aa[0] is not None else None, float(sl[0]),
+                                   aa[1].data_ptr() if aa[1] is not None else None, float(sl[1]), Wp.data_ptr(), N,
+                                   linear_bias.data_ptr() if linear_bias is not None else None, norm_weight.data_ptr(), norm_bias.data_ptr(),
+                                   int(groups), float(eps), _i64_array(segments) if nseg > 1 else None, nseg, out.data_ptr(),
+                                   affine.data_ptr(), ws.data_ptr(), ws.numel(), stream), 'se3_dense_norm_fwd')
+    return Pending(out, [affine], [1.0], segments)
+
+
+def group_norm_stats(x, weight, bias, groups, eps, x_bias=None, segments=None):
+    """HIP (csrc/rowops.hip): the affine table (nseg, 2, C) of GroupNorm over T(x) (x: tensor, or Pending with ONE stage)."""
+    pend = x if isinstance(x, Pending) else Pending(x, [], [], segments)
+    raw = _req(pend.raw.contiguous(), torch.float32, 'x')
+    if len(pend.affines) > 1:
+        raise RuntimeError('group_norm_stats: at most one pending stage')
+    segments = pend.segments if segments is None else segments
+    C = raw.shape[-1]
+    rows = raw.numel() // C
+    stream = _stream()
+    nseg = 1 if segments is None else len(segments) - 1
+    affine = torch.empty((nseg, 2, C), dtype=torch.float32, device=raw.device)
+    ws = _norm_workspace(raw.device, stream, lib().se3_group_norm_workspace_bytes(rows, C, groups))
+    pa = pend.affines[0] if pend.affines else None
+    check(lib().se3_group_norm_stats(raw.data_ptr(), pa.data_ptr() if pa is not None else None, float(pend.slopes[0]) if pa is not None else 1.0,
+                                     x_bias.data_ptr() if x_bias is not None else None, weight.data_ptr(), bias.data_ptr(), rows, C,
+                                     int(groups), _i64_array(segments) if nseg > 1 else None, nseg, float(eps), affine.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), stream), 'se3_group_norm_stats')
+    return affine
+
+
+def group_norm_apply(x, residual=None, final_slope=1.0):
+    """HIP (csrc/rowops.hip): a Pending made concrete: lrelu_f(T_b(T_a(raw)) + R), R = a tensor, a Pending with one stage (slope 1), or None."""
+    if not x.affines or len(x.affines) > 2:
+        raise RuntimeError('group_norm_apply: one or two pending stages')
+    raw = _req(x.raw, torch.float32, 'x')
+    C = raw.shape[-1]
+    rows = raw.numel() // C
+    res, res_aff = None, None
+    if isinstance(residual, Pending):
+        if len(residual.affines) != 1 or residual.slopes[0] != 1.0:
+            raise RuntimeError('group_norm_apply: the residual may carry one stage without LeakyReLU')
+        res, res_aff = _req(residual.raw, torch.float32, 'residual'), residual.affines[0]
+    elif residual is not None:
+        res = _req(residual.contiguous(), torch.float32, 'residual')
+    if res is not None and res.shape != raw.shape:
+        raise RuntimeError('group_norm_apply: residual shape mismatch')
+    segments = x.segments
+    nseg = 1 if segments is None else len(segments) - 1
+    out = torch.empty_like(raw)
+    aa = x.affines + [None]
+    sl = x.slopes + [1.0]
+    check(lib().se3_group_norm_apply(raw.data_ptr(), aa[0].data_ptr(), float(sl[0]), aa[1].data_ptr() if aa[1] is not None else None, float(sl[1]),
+                                     res.data_ptr() if res is not None else None, res_aff.data_ptr() if res_aff is not None else None,
+                                     float(final_slope), rows, C, _i64_array(segments) if nseg > 1 else None, nseg, out.data_ptr(), _stream()),
+          'se3_group_norm_apply')
+    return out
+
+
 _host_table_cache = {}
 
 

@@ -794,6 +794,68 @@ def test_linear_f16_split_has_f32_accuracy(rows, K, N, bias, relu):
     assert float((got2.double() - ref2).abs().max()) <= 2e-6 * float(ref2.abs().max()) + 2 * e_lib
 
 
+def _pending_reference(x, stages, seg):
+    """float64: the stages v -> lrelu(v * scale + shift, slope) applied per segment."""
+    x = x.double().clone()
+    for aff, slope in stages:
+        for s in range(len(seg) - 1):
+            v = x[seg[s]:seg[s + 1]] * aff[s, 0].double() + aff[s, 1].double()
+            x[seg[s]:seg[s + 1]] = torch.where(v > 0, v, v * slope)
+    return x
+
+
+@pytest.mark.parametrize('rows,K,N,groups,nstage,seg', [
+    (6000, 64, 128, 32, 0, None), (5001, 128, 32, 32, 1, [0, 1999, 5001]), (4100, 32, 128, 32, 2, [0, 130, 2000, 4100]),
+    (7000, 64, 256, 32, 2, [0, 3500, 7000]), (3000, 256, 64, 32, 1, None), (2500, 128, 512, 32, 0, [0, 700, 2500]),
+    (1300, 1024, 256, 32, 1, [0, 64, 1300]), (900, 256, 1024, 32, 0, None)])
+def test_dense_norm_matches_linear_then_group_norm(rows, K, N, groups, nstage, seg):
+    """csrc/dense_norm.hip: y = T(x) W^T with the pending stages T applied on load and the GroupNorm statistics of y + bias taken from the
+    accumulators, then group_norm_apply -- against the float64 composition T -> linear -> GroupNorm (per segment) -> LeakyReLU, with row
+    counts that are not multiples of the row tile, segments shorter than a tile, 0 / 1 / 2 pending stages, every tile shape."""
+    from se3et_amd import ops
+    g = torch.Generator().manual_seed(rows + K + N)
+    x = (torch.randn(rows, K, generator=g) * (1 + torch.rand(1, K, generator=g) * 2) + torch.randn(1, K, generator=g)).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    gw, gb = (torch.rand(N, generator=g) + 0.5).cuda(), torch.randn(N, generator=g).cuda()
+    segs = seg or [0, rows]
+    nseg = len(segs) - 1
+    stages = [((torch.randn(nseg, 2, K, generator=g) * 0.5 + torch.tensor([1.0, 0.0])[None, :, None]).cuda(), sl) for sl in (0.1, 0.2)[:nstage]]
+    pend = ops.Pending(x, [a for a, _ in stages], [sl for _, sl in stages], seg)
+    assert ops.dense_norm_ok(pend, w, groups)
+    out = ops.dense_norm(pend, w, b, gw, gb, groups, 1e-5, seg)
+    xt = _pending_reference(x, stages, segs)
+    y = xt @ w.double().t()
+    assert float((out.raw.double() - y).abs().max()) <= 3e-6 * float(y.abs().max())
+    yb = y + b.double()
+    ref = torch.empty_like(yb)
+    for s in range(nseg):
+        v = yb[segs[s]:segs[s + 1]].reshape(-1, groups, N // groups)
+        m, var = v.mean((0, 2), keepdim=True), v.var((0, 2), unbiased=False, keepdim=True)
+        ref[segs[s]:segs[s + 1]] = ((v - m) / (var + 1e-5).sqrt()).reshape(-1, N) * gw.double() + gb.double()
+    ref = torch.where(ref > 0, ref, ref * 0.1)
+    out.slopes[-1] = 0.1
+    got = ops.group_norm_apply(out)
+    assert float((got.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    # the statistics alone, from a pass over the raw tensor with one pending stage, agree with the epilogue's
+    aff2 = ops.group_norm_stats(ops.Pending(out.raw, [], [], seg), gw, gb, groups, 1e-5, x_bias=b)
+    assert torch.allclose(aff2, out.affines[0], rtol=2e-4, atol=2e-5)
+    # GroupNorm of the activated tensor (the second norm of a bottleneck block), pending on a pending
+    gw2, gb2 = (torch.rand(N, generator=g) + 0.5).cuda(), torch.randn(N, generator=g).cuda()
+    aff3 = ops.group_norm_stats(out, gw2, gb2, groups, 1e-5)
+    ref3 = ops.group_norm_rows(got, gw2, gb2, groups, 1e-5, 0.1, None, None, seg)
+    got3 = ops.group_norm_apply(out.then(aff3, 0.1))
+    assert float((got3 - ref3).abs().max()) <= 2e-5 * max(1.0, float(ref3.abs().max()))
+    # shortcut branch in its pending form + final LeakyReLU: lrelu(norm(y) + norm_s(y_s))
+    ys = torch.randn(rows, N, generator=g).cuda()
+    affs = ops.group_norm_stats(ops.Pending(ys, [], [], seg), gw2, gb2, groups, 1e-5)
+    short = ops.group_norm_rows(ys, gw2, gb2, groups, 1e-5, None, None, None, seg)
+    plain = ops.Pending(out.raw, out.affines, [1.0], seg)
+    ref4 = ops.group_norm_rows(out.raw, gw, gb, groups, 1e-5, 0.1, short, b, seg)
+    got4 = ops.group_norm_apply(plain, ops.Pending(ys, [affs], [1.0], seg), 0.1)
+    assert float((got4 - ref4).abs().max()) <= 2e-5 * max(1.0, float(ref4.abs().max()))
+
+
 @pytest.mark.parametrize('P,Ns,NN,Cin,Cout,box', [(77, 90, 38, 24, 32, 0.05), (130, 130, 40, 40, 96, 0.04), (33, 64, 36, 8, 64, 0.05),
                                                   (200, 260, 48, 72, 160, 0.06), (16, 16, 16, 16, 32, 0.03), (95, 400, 64, 64, 256, 0.08)])
 def test_fused_kpconv_edge_shapes(P, Ns, NN, Cin, Cout, box):
