@@ -137,7 +137,8 @@ int se3_group_norm_segments_bwd(const float* x, const float* x_bias, const float
  * affine table [segment][2][channels] (scale, shift: norm(x + x_bias) * weight + bias == x * scale + shift) but not applied -- the consumer
  * applies it while it loads x, so the normalised activation never makes a round trip through HBM.
  *   se3_group_norm_stats   the table of GroupNorm over T(x), T = a pending stage on x itself (in_affine NULL: T = identity).  Workspace:
- *                          se3_group_norm_workspace_bytes.
+ *                          se3_group_norm_stats_workspace_bytes(channels) bytes, ZERO before the first call (arrival counters of the
+ *                          in-kernel finalize at its start; every call leaves them zero), one per stream.
  *   se3_group_norm_apply   out = lrelu_f( Tb(Ta(x)) + R ),  T.(v) = lrelu_slope(v * scale + shift);  R = residual * scale_r + shift_r
  *                          (residual_affine: the shortcut branch's own pending GroupNorm), the plain residual, or nothing.  A slope of 1
  *                          is "no LeakyReLU".  channels % 4 == 0.
@@ -145,14 +146,17 @@ int se3_group_norm_segments_bwd(const float* x, const float* x_bias, const float
  *                          (csrc/dense_norm.hip): out = T_b(T_a(x)) W^T WITHOUT the bias (raw), affine_out = the table of
  *                          GroupNorm(out + linear_bias) computed from the accumulators.  weight_pieces: se3_linear_split_weights_f16.
  *                          in_features a power of two 32..1024; out_features 32, 64, 128 or a multiple of 256; f16 hi/lo split arithmetic
- *                          (f32 accuracy, |T(x)| < 65504).  Workspace: se3_dense_norm_workspace_bytes(out_features). */
+ *                          (f32 accuracy, |T(x)| < 65504); out_features / groups a power of two <= 32.  Workspace:
+ *                          se3_dense_norm_workspace_bytes(groups) bytes, ZERO before the first call (it starts with the arrival counters
+ *                          of the in-kernel finalize; every call leaves them zero), one per stream. */
+size_t se3_group_norm_stats_workspace_bytes(int channels);
 int se3_group_norm_stats(const float* x, const float* in_affine, float in_slope, const float* x_bias, const float* weight, const float* bias,
                          int64_t rows, int channels, int groups, const int64_t* segment_row_offsets_host, int num_segments, float eps,
                          float* affine_out, void* workspace, size_t workspace_bytes, void* stream);
 int se3_group_norm_apply(const float* x, const float* affine_a, float slope_a, const float* affine_b, float slope_b, const float* residual,
                          const float* residual_affine, float final_slope, int64_t rows, int channels,
                          const int64_t* segment_row_offsets_host, int num_segments, float* out, void* stream);
-size_t se3_dense_norm_workspace_bytes(int out_features);
+size_t se3_dense_norm_workspace_bytes(int groups);
 int se3_dense_norm_fwd(const float* x, int64_t rows, int in_features, const float* in_affine_a, float in_slope_a, const float* in_affine_b,
                        float in_slope_b, const void* weight_pieces, int out_features, const float* linear_bias, const float* norm_weight,
                        const float* norm_bias, int groups, float eps, const int64_t* segment_row_offsets_host, int num_segments, float* out,

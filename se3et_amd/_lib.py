@@ -32,6 +32,7 @@ SIGNATURES = {
     'se3_group_norm_segments_fwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _f32, _i32, _f32, _vp, _vp, _sz, _vp]),
     'se3_add_layer_norm_fwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _f32, _vp, _vp]),
     'se3_add_layer_norm_bwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _f32, _vp, _vp, _vp]),
+    'se3_group_norm_stats_workspace_bytes': (_sz, [_i32]),
     'se3_group_norm_stats': (_i32, [_vp, _vp, _f32, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _f32, _vp, _vp, _sz, _vp]),
     'se3_group_norm_apply': (_i32, [_vp, _vp, _f32, _vp, _f32, _vp, _vp, _f32, _i64, _i32, _vp, _i32, _vp, _vp]),
     'se3_dense_norm_workspace_bytes': (_sz, [_i32]),

@@ -34,9 +34,17 @@ struct DenseArgs {
   const u32x4* Wf;
   const float* hdr;
   float* out;                // (rows, N): x W^T, no bias
-  float* part;               // [chunk][N][3]
+  float* part;               // [chunk][groups][3]: (count, mean, M2) of (out + bias) over the chunk's rows and the group's channels
+  int* counters;             // [segment][column block]: chunks of the segment that have delivered their partials (zero between launches)
+  const float* xb;           // (N) bias of the layer (shifts the means only), or null
+  const float* gw;           // (N) GroupNorm weight, bias
+  const float* gb;
+  float* affine;             // out: [segment][2][N]
+  int groups;
+  float eps;
   SegTable T;
 };
+
 
 // WM x WN waves, each RT x CT MFMA tiles of 32 x 32: rows per tile TR = 32 RT WM, columns per workgroup BN = 32 CT WN
 template <int WM, int WN, int RT, int CT>
@@ -52,14 +60,17 @@ __global__ __launch_bounds__(256, 3) void dense_norm_kernel(const DenseArgs a) {
   const int K = a.K, N = a.N;
   long long r0, r1;
   chunk_rows(a.T, blockIdx.x, r0, r1);
-  if (r0 >= r1) {                                                        // (a chunk emptied by the row quantum: its partials count nothing)
-    for (int i = tid; i < BN; i += 256) {
-      float* p = a.part + ((int64_t)blockIdx.x * N + blockIdx.y * BN + i) * 3;
-      p[0] = p[1] = p[2] = 0.f;
-    }
-    return;
-  }
+  if (r1 < r0) r1 = r0;                                                  // (a chunk emptied by the row quantum: no tiles, partials that count nothing)
   const int seg = seg_of_chunk(a.T, blockIdx.x);
+  int cb0 = a.T.chunk_begin[0], cb1 = a.T.chunk_begin[1];
+#pragma unroll
+  for (int i = 1; i < kGNMaxSegments; i++)
+    if (seg == i) {
+      cb0 = a.T.chunk_begin[i];
+      cb1 = a.T.chunk_begin[i + 1];
+    }
+  cb0 = __builtin_amdgcn_readfirstlane(cb0);
+  cb1 = __builtin_amdgcn_readfirstlane(cb1);
   const int stages = (a.in_affine[0] != nullptr) + (a.in_affine[1] != nullptr);
   for (int st = 0; st < stages; st++)
     for (int i = tid; i < 2 * K; i += 256) aff[st * 2 * K + i] = a.in_affine[st][(size_t)seg * 2 * K + i];
@@ -69,7 +80,7 @@ __global__ __launch_bounds__(256, 3) void dense_norm_kernel(const DenseArgs a) {
   // A staging: unit j of a thread = 4 consecutive floats of row (tid >> 3) + 32 j, floats 4 (tid & 7) .. + 3 of the K-step
   // Buffer addressing (uniform base and step offset, 32-bit lane offsets): rows past the end of the chunk read as zeros.
   const int q = tid & 7, urow = tid >> 3;
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + r0 * K), 0, (int)((r1 - r0) * K * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (r1 > r0 ? r0 : 0) * K), 0, (int)((r1 - r0) * K * 4), 0x00020000);
   const int xoff = (urow * K + 4 * q) * 4;
   auto request = [&](int s, f32x4 (&v)[U]) {
     const int tile = s >> lognk, kk = s & (nk - 1);
@@ -236,21 +247,33 @@ __global__ __launch_bounds__(256, 3) void dense_norm_kernel(const DenseArgs a) {
     request(s + 3, rb);
     __syncthreads();
   }
-  // the waves that share columns merge their statistics through LDS; wave row 0 writes the chunk's partials
+  // ---- the chunk's statistics: + bias, waves that share columns merged through LDS, channels merged into their groups across lanes
   __syncthreads();
+  const int cpg = N / a.groups;                                          // channels per group: a power of two <= 32 (host-checked)
   WF* sh = reinterpret_cast<WF*>(lds);                                   // [wave][CT][32]
+  if (a.xb)
+#pragma unroll
+    for (int c = 0; c < CT; c++) run[c].mean += a.xb[(ct0 + c) * 32 + i32];
   if (h == 0)
 #pragma unroll
     for (int c = 0; c < CT; c++) sh[(wave * CT + c) * 32 + i32] = run[c];
   __syncthreads();
-  if (wm == 0 && h == 0)
+  if (wm == 0)
 #pragma unroll
     for (int c = 0; c < CT; c++) {
       WF w = run[c];
       for (int m = 1; m < WM; m++) w = wf_merge(w, sh[((m * WN + wn) * CT + c) * 32 + i32]);
-      float* p = a.part + ((int64_t)blockIdx.x * N + (ct0 + c) * 32 + i32) * 3;
-      p[0] = w.n; p[1] = w.mean; p[2] = w.m2;
+      for (int d = 1; d < cpg; d <<= 1) {
+        const WF o = {__shfl_xor(w.n, d), __shfl_xor(w.mean, d), __shfl_xor(w.m2, d)};
+        w = wf_merge(w, o);
+      }
+      const int col = (ct0 + c) * 32 + i32;
+      if (h == 0 && (col & (cpg - 1)) == 0) gn_store_partial(a.part + ((int64_t)blockIdx.x * a.groups + col / cpg) * 3, w);
     }
+  // ---- the last chunk of a segment to arrive turns the segment's partials into the affine table
+  if (!gn_last_arrival(a.counters + seg * kGNMaxColumnBlocks + blockIdx.y, cb1 - cb0)) return;
+  const int gpb = BN / cpg;                                              // groups of this column block
+  gn_finalize_groups(a.part, a.groups, cb0, cb1, blockIdx.y * gpb, gpb, cpg, a.xb, a.gw, a.gb, a.eps, a.affine + (size_t)seg * 2 * N, N);
 }
 
 int g_target_chunks = 768;                   // workgroups (row chunks x column blocks) aimed at: 3 per compute unit, all resident at once
@@ -259,8 +282,11 @@ int g_target_chunks = 768;                   // workgroups (row chunks x column 
 
 extern "C" void se3_dense_norm_set_target_chunks(int workgroups) { g_target_chunks = workgroups > 0 ? workgroups : 768; }
 
-extern "C" size_t se3_dense_norm_workspace_bytes(int out_features) {
-  return (size_t)(kGNMaxChunks + kGNMaxSegments) * out_features * 3 * sizeof(float) + 256;
+constexpr size_t kCounterB = kGNCounterB;
+
+// [arrival counters: zero before the first call, left zero by every call][partials: (chunk, group) x 3 floats]
+extern "C" size_t se3_dense_norm_workspace_bytes(int groups) {
+  return kCounterB + (size_t)(kGNMaxChunks + kGNMaxSegments) * (groups > 0 ? groups : 1) * 3 * sizeof(float);
 }
 
 extern "C" int se3_dense_norm_fwd(const float* x, int64_t rows, int in_features, const float* in_affine_a, float in_slope_a,
@@ -273,10 +299,15 @@ extern "C" int se3_dense_norm_fwd(const float* x, int64_t rows, int in_features,
   SE3_REQUIRE(K >= 32 && K <= 1024 && (K & (K - 1)) == 0 && N >= 32 && N % 32 == 0 && (N < 256 ? (N & (N - 1)) == 0 : N % 256 == 0),
               SE3_ERR_UNSUPPORTED, "dense_norm: %d -> %d features (in: a power of two 32..1024; out: 32, 64, 128 or a multiple of 256)", K, N);
   SE3_REQUIRE(rows >= 1 && groups >= 1 && N % groups == 0, SE3_ERR_INVALID_ARG, "dense_norm: rows %lld groups %d", (long long)rows, groups);
+  {
+    const int cpg = N / groups;
+    SE3_REQUIRE(cpg <= 32 && (cpg & (cpg - 1)) == 0 && N / (N >= 256 ? 256 : N) <= kGNMaxColumnBlocks, SE3_ERR_UNSUPPORTED,
+                "dense_norm: %d channels per group (a power of two <= 32), %d output features (<= %d)", cpg, N, 256 * kGNMaxColumnBlocks);
+  }
   SE3_REQUIRE(num_segments >= 1 && num_segments <= kGNMaxSegments && (num_segments == 1 || segment_row_offsets_host), SE3_ERR_UNSUPPORTED,
               "dense_norm: %d segments (1..%d)", num_segments, kGNMaxSegments);
   SE3_REQUIRE(((uintptr_t)x & 15) == 0 && (in_affine_a || !in_affine_b), SE3_ERR_INVALID_ARG, "dense_norm: x must be 16-byte aligned; stage b needs stage a");
-  SE3_REQUIRE(workspace_bytes >= se3_dense_norm_workspace_bytes(N), SE3_ERR_WORKSPACE, "dense_norm: workspace too small");
+  SE3_REQUIRE(workspace_bytes >= se3_dense_norm_workspace_bytes(groups), SE3_ERR_WORKSPACE, "dense_norm: workspace too small");
   const int TR = N >= 256 ? 64 : 128, BN = N >= 256 ? 256 : N;
   const int ncb = N / BN;
   // row chunks: whole row tiles, about g_target_chunks workgroups in all, never across a segment boundary
@@ -316,7 +347,14 @@ extern "C" int se3_dense_norm_fwd(const float* x, int64_t rows, int in_features,
   a.hdr = static_cast<const float*>(weight_pieces);
   a.Wf = reinterpret_cast<const u32x4*>(static_cast<const unsigned char*>(weight_pieces) + kHeaderB);
   a.out = out;
-  a.part = static_cast<float*>(workspace);
+  a.counters = static_cast<int*>(workspace);
+  a.part = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + kCounterB);
+  a.xb = linear_bias;
+  a.gw = norm_weight;
+  a.gb = norm_bias;
+  a.affine = affine_out;
+  a.groups = groups;
+  a.eps = eps;
   a.T = T;
   const size_t dyn = (size_t)((in_affine_a != nullptr) + (in_affine_b != nullptr)) * 2 * K * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
@@ -325,8 +363,6 @@ extern "C" int se3_dense_norm_fwd(const float* x, int64_t rows, int in_features,
   else if (N == 128) dense_norm_kernel<2, 2, 2, 2><<<grid, 256, dyn, st>>>(a);
   else if (N == 64) dense_norm_kernel<4, 1, 1, 2><<<grid, 256, dyn, st>>>(a);
   else dense_norm_kernel<4, 1, 1, 1><<<grid, 256, dyn, st>>>(a);
-  gn_finalize_kernel<<<dim3((unsigned)groups, (unsigned)num_segments), 256, 0, st>>>(a.part, linear_bias, norm_weight, norm_bias, N, groups, T, eps,
-                                                                                      affine_out);
   SE3_CHECK_LAUNCH("dense_norm");
   return SE3_OK;
 }

@@ -125,6 +125,57 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   }
 }
 
+// In-kernel finalize of the producers that deliver GROUP partials [chunk][groups][3] (the bias already inside the means): the workgroup
+// that finds itself last of its segment (arrival counter) calls this with all of its 4 waves.  One wave per group: lanes merge the
+// segment's chunks [cb0, cb1), a butterfly merges the lanes, lanes < channels-per-group write the affine map of their channel.
+constexpr int kGNMaxColumnBlocks = 16;
+constexpr size_t kGNCounterB = kGNMaxSegments * kGNMaxColumnBlocks * sizeof(int);
+__device__ __forceinline__ void gn_store_partial(float* p, const WF& w) {          // read back by another compute unit in the same launch
+  __hip_atomic_store(p + 0, w.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(p + 1, w.mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(p + 2, w.m2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// true in every thread of the workgroup that arrives last of `expected`; resets the counter for the next launch.  No agent-scope fence:
+// on this chip that is a write-back and an invalidate of the whole L2 of the XCD (every workgroup of a streaming kernel doing one halves
+// the kernel's rate); the partials are agent-scope atomic stores and loads (they go through to the memory side on their own), so all that
+// is needed is that this workgroup's stores have completed before its ticket is drawn.
+__device__ __forceinline__ bool gn_last_arrival(int* counter, int expected) {
+  __shared__ int ticket;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (a workgroup-scope release fence compiles to nothing here)
+  __syncthreads();
+  if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (ticket != expected - 1) return false;
+  if (threadIdx.x == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+__device__ __forceinline__ void gn_finalize_groups(const float* part, int groups, int cb0, int cb1, int g_begin, int g_count, int cpg,
+                                                   const float* xb, const float* gw, const float* gb, float eps, float* affine, int C) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int gi = wave; gi < g_count; gi += 4) {
+    const int g = g_begin + gi;
+    WF w = {0.f, 0.f, 0.f};
+    for (int i = cb0 + lane; i < cb1; i += 64) {
+      const float* p = part + ((int64_t)i * groups + g) * 3;
+      const WF o = {__hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                    __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                    __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+      w = wf_merge(w, o);
+    }
+    for (int d = 1; d < 64; d <<= 1) {
+      const WF o = {__shfl_xor(w.n, d), __shfl_xor(w.mean, d), __shfl_xor(w.m2, d)};
+      w = wf_merge(w, o);
+    }
+    const float mean = __shfl(w.mean, 0), rstd = 1.0f / sqrtf(__shfl(w.m2, 0) / fmaxf(__shfl(w.n, 0), 1.f) + eps);
+    for (int j = lane; j < cpg; j += 64) {
+      const int c = g * cpg + j;
+      const float scale = rstd * gw[c];
+      affine[c] = scale;
+      affine[C + c] = gb[c] + ((xb ? xb[c] : 0.f) - mean) * scale;
+    }
+  }
+}
+
 }  // namespace
 
 static bool gn_fast_path(int channels) { return channels >= 16 && channels <= 1024 && (channels & (channels - 1)) == 0; }

@@ -44,10 +44,21 @@ __global__ __launch_bounds__(kGNLanes* kGNRows) void gn_partial_kernel(const flo
 // across the block and 256 / Q row lanes, 8 rows in flight per thread, tree merge over the row lanes.  The chunking is a
 // pure function of (rows, C), so the result does not depend on scheduling.
 // PRE: the statistics are those of lrelu(x scale + shift) -- a GroupNorm + LeakyReLU still pending on x (affine table [segment][2][C]).
-template <bool PRE>
+// FIN: group partials [chunk][groups][3] (+ bias) instead of channel partials, and the last chunk of a segment to arrive writes the affine
+// table itself (group_norm.h: gn_finalize_groups): no finalize launch.
+struct GnFinArgs {
+  const float* xb;
+  const float* gw;
+  const float* gb;
+  float* affine;      // [segment][2][C]
+  int* counters;      // [segment][kGNMaxColumnBlocks], zero between launches
+  int groups;
+  float eps;
+};
+template <bool PRE, bool FIN = false>
 __global__ __launch_bounds__(256) void gn_partial4_kernel(const float* __restrict__ x, SegTable T, int C,
                                                           float* __restrict__ part, const float* __restrict__ pre_affine = nullptr,
-                                                          float pre_slope = 1.f) {
+                                                          float pre_slope = 1.f, GnFinArgs fin = GnFinArgs{}) {
   __shared__ WF sh[256][4];
   const int Q = C >> 2, RL = 256 / Q;
   const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
@@ -100,6 +111,29 @@ __global__ __launch_bounds__(256) void gn_partial4_kernel(const float* __restric
       for (int k = 0; k < 4; k++) sh[threadIdx.x][k] = wf_merge(sh[threadIdx.x][k], sh[threadIdx.x + s * Q][k]);
     }
     __syncthreads();
+  }
+  if (FIN) {
+    WF* shc = &sh[0][0];                                                  // the chunk's channel partials, channel-major (thread q: 4 q .. 4 q + 3)
+    if (fin.xb)
+      for (int c = threadIdx.x; c < C; c += 256) shc[c].mean += fin.xb[c];
+    __syncthreads();
+    const int cpg = C / fin.groups;
+    for (int g = threadIdx.x; g < fin.groups; g += 256) {
+      WF w = shc[g * cpg];
+      for (int j = 1; j < cpg; j++) w = wf_merge(w, shc[g * cpg + j]);
+      gn_store_partial(part + ((int64_t)blockIdx.x * fin.groups + g) * 3, w);
+    }
+    const int seg = seg_of_chunk(T, blockIdx.x);
+    int cb0 = T.chunk_begin[0], cb1 = T.chunk_begin[1];
+#pragma unroll
+    for (int i = 1; i < kGNMaxSegments; i++)
+      if (seg == i) {
+        cb0 = T.chunk_begin[i];
+        cb1 = T.chunk_begin[i + 1];
+      }
+    if (!gn_last_arrival(fin.counters + seg * kGNMaxColumnBlocks, cb1 - cb0)) return;
+    gn_finalize_groups(part, fin.groups, cb0, cb1, 0, fin.groups, cpg, fin.xb, fin.gw, fin.gb, fin.eps, fin.affine + (size_t)seg * 2 * C, C);
+    return;
   }
   if (rl == 0) {
 #pragma unroll
@@ -670,13 +704,17 @@ static int gn_segment_table(const char* who, int64_t rows, int channels, const i
   return SE3_OK;
 }
 
+extern "C" size_t se3_group_norm_stats_workspace_bytes(int channels) {
+  return kGNCounterB + se3_group_norm_workspace_bytes(0, channels, 1);
+}
+
 extern "C" int se3_group_norm_stats(const float* x, const float* in_affine, float in_slope, const float* x_bias, const float* weight,
                                     const float* bias, int64_t rows, int channels, int groups, const int64_t* segment_row_offsets_host,
                                     int num_segments, float eps, float* affine_out, void* workspace, size_t workspace_bytes, void* stream) {
   SE3_REQUIRE(x && weight && bias && affine_out && workspace, SE3_ERR_INVALID_ARG, "group_norm_stats: null pointer");
   SE3_REQUIRE(rows >= 1 && channels >= 1 && groups >= 1 && channels % groups == 0, SE3_ERR_INVALID_ARG,
               "group_norm_stats: rows %lld channels %d groups %d", (long long)rows, channels, groups);
-  SE3_REQUIRE(workspace_bytes >= se3_group_norm_workspace_bytes(rows, channels, groups), SE3_ERR_WORKSPACE, "group_norm_stats: workspace too small");
+  SE3_REQUIRE(workspace_bytes >= se3_group_norm_stats_workspace_bytes(channels), SE3_ERR_WORKSPACE, "group_norm_stats: workspace too small");
   const bool fast = gn_fast_path(channels) && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
   SE3_REQUIRE(fast || !in_affine, SE3_ERR_UNSUPPORTED, "group_norm_stats: a pending input form needs a power-of-two channel count (16..1024), got %d",
               channels);
@@ -684,12 +722,17 @@ extern "C" int se3_group_norm_stats(const float* x, const float* in_affine, floa
   int chunks;
   const int rc = gn_segment_table("group_norm_stats", rows, channels, segment_row_offsets_host, num_segments, true, T, chunks);
   if (rc != SE3_OK) return rc;
-  float* part = (float*)workspace;
+  // [arrival counters (zero before the first call, left zero by every call)][partials]
+  float* part = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + kGNCounterB);
   hipStream_t st = (hipStream_t)stream;
-  if (fast && in_affine) gn_partial4_kernel<true><<<(unsigned)chunks, 256, 0, st>>>(x, T, channels, part, in_affine, in_slope);
-  else if (fast) gn_partial4_kernel<false><<<(unsigned)chunks, 256, 0, st>>>(x, T, channels, part);
-  else gn_partial_kernel<<<dim3((unsigned)chunks, (unsigned)se3_cdiv(channels, kGNLanes)), kGNLanes * kGNRows, 0, st>>>(x, T, channels, part);
-  gn_finalize_kernel<<<dim3((unsigned)groups, (unsigned)num_segments), 256, 0, st>>>(part, x_bias, weight, bias, channels, groups, T, eps, affine_out);
+  if (fast) {
+    const GnFinArgs fin{x_bias, weight, bias, affine_out, static_cast<int*>(workspace), groups, eps};
+    if (in_affine) gn_partial4_kernel<true, true><<<(unsigned)chunks, 256, 0, st>>>(x, T, channels, part, in_affine, in_slope, fin);
+    else gn_partial4_kernel<false, true><<<(unsigned)chunks, 256, 0, st>>>(x, T, channels, part, nullptr, 1.f, fin);
+  } else {
+    gn_partial_kernel<<<dim3((unsigned)chunks, (unsigned)se3_cdiv(channels, kGNLanes)), kGNLanes * kGNRows, 0, st>>>(x, T, channels, part);
+    gn_finalize_kernel<<<dim3((unsigned)groups, (unsigned)num_segments), 256, 0, st>>>(part, x_bias, weight, bias, channels, groups, T, eps, affine_out);
+  }
   SE3_CHECK_LAUNCH("group_norm_stats");
   return SE3_OK;
 }

@@ -82,10 +82,9 @@ def linear_f16_ok(x, weight):
 def linear_f16(x, weight, bias=None, relu=False):
     """y = x W^T [+ bias] [ReLU] for x (..., K) contiguous, weight (N, K): csrc/linear_f16.hip."""
     stream = _stream()
-    w = weight.detach()
-    N, K = w.shape
+    N, K = weight.shape
     rows = x.numel() // K
-    Wp = _linear_weight_pieces(w, stream)
+    Wp = _linear_weight_pieces(weight, stream)      # (the tensor object itself: the cache entry lives as long as it does)
     out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
     b = None if bias is None else _req(bias.detach().contiguous(), torch.float32, 'bias', 1)
     check(lib().se3_linear_f16(x.data_ptr(), rows, K, K, Wp.data_ptr(), None if b is None else b.data_ptr(), N, 1 if relu else 0,
@@ -431,12 +430,17 @@ def group_norm_rows_bwd(grad_out, x, weight, bias, groups, eps, leaky_slope, res
     return dx, params[0], params[1], dres, (params[2] if x_bias is not None else None)
 
 
-def _norm_workspace(device, stream, nbytes):
+_dense_ws = {}
+
+
+def _dense_workspace(device, stream, nbytes):
+    """Workspace of dense_norm, one per stream: it begins with the arrival counters of the in-kernel finalize, which must start at zero
+    (every call leaves them zero)."""
     key = (device, stream.value)
-    ws = _gn_workspace.get(key)
+    ws = _dense_ws.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty((max(nbytes, 1 << 22),), dtype=torch.uint8, device=device)
-        _gn_workspace[key] = ws
+        ws = torch.zeros((max(nbytes, 1 << 20),), dtype=torch.uint8, device=device)
+        _dense_ws[key] = ws
     return ws
 
 
@@ -461,6 +465,7 @@ def dense_norm_ok(x, weight, groups):
     N, K = weight.shape
     return (raw.is_cuda and raw.dtype == torch.float32 and weight.dtype == torch.float32 and weight.is_contiguous() and raw.is_contiguous()
             and raw.shape[-1] == K and 32 <= K <= 1024 and K & (K - 1) == 0 and (N in (32, 64, 128) or N % 256 == 0) and N % groups == 0
+            and N // groups in (1, 2, 4, 8, 16, 32) and N <= 4096
             and raw.data_ptr() % 16 == 0)
 
 
@@ -476,11 +481,11 @@ def dense_norm(x, weight, linear_bias, norm_weight, norm_bias, groups, eps, segm
     N, K = weight.shape
     rows = raw.numel() // K
     stream = _stream()
-    Wp = _linear_weight_pieces(weight.detach(), stream)
+    Wp = _linear_weight_pieces(weight, stream)
     nseg = 1 if segments is None else len(segments) - 1
     out = torch.empty(raw.shape[:-1] + (N,), dtype=torch.float32, device=raw.device)
     affine = torch.empty((nseg, 2, N), dtype=torch.float32, device=raw.device)
-    ws = _norm_workspace(raw.device, stream, lib().se3_dense_norm_workspace_bytes(N))
+    ws = _dense_workspace(raw.device, stream, lib().se3_dense_norm_workspace_bytes(int(groups)))
     aa = pend.affines + [None, None]
     sl = pend.slopes + [1.0, 1.0]
     check(lib().se3_dense_norm_fwd(raw.data_ptr(), rows, K, aa[0].data_ptr() if aa[0] is not None else None, float(sl[0]),
@@ -503,7 +508,7 @@ def group_norm_stats(x, weight, bias, groups, eps, x_bias=None, segments=None):
     stream = _stream()
     nseg = 1 if segments is None else len(segments) - 1
     affine = torch.empty((nseg, 2, C), dtype=torch.float32, device=raw.device)
-    ws = _norm_workspace(raw.device, stream, lib().se3_group_norm_workspace_bytes(rows, C, groups))
+    ws = _dense_workspace(raw.device, stream, lib().se3_group_norm_stats_workspace_bytes(C))
     pa = pend.affines[0] if pend.affines else None
     check(lib().se3_group_norm_stats(raw.data_ptr(), pa.data_ptr() if pa is not None else None, float(pend.slopes[0]) if pa is not None else 1.0,
                                      x_bias.data_ptr() if x_bias is not None else None, weight.data_ptr(), bias.data_ptr(), rows, C,

@@ -1,18 +1,19 @@
-"""Which call sites of the 8-pair forward spend GPU time in torch's own small kernels (copies, cats, fills, element-wise)?  Wraps the
-dispatcher with torch.profiler (with_stack) and groups self-CUDA time of aten ops by the innermost se3et_amd frame.
-python tools/torch_ops_sites.py"""
+"""Which call sites of the 8-pair forward launch torch's own small kernels (copies, cats, fills, element-wise)?  A TorchDispatchMode records
+every aten op with the innermost se3et_amd frame that issued it; GPU time per op from a second, profiled run (self device time by op name and
+input sizes, spread over the sites by call count).  python tools/torch_ops_sites.py [pairs]"""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import collections
 import numpy as np, torch
-from torch.profiler import profile, ProfilerActivity
+from torch.utils._python_dispatch import TorchDispatchMode
 from se3et_amd.batched import forward_pairs
 from se3et_amd.data import precompute_data_stack_mode
 from se3et_amd.model import create_model, load_synthetic_weights, make_cfg
 from se3et_amd.synthetic import make_pair
+pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = torch.device('cuda'); cfg = make_cfg('se3ete'); b = cfg.backbone
 model = load_synthetic_weights(create_model(cfg)).to(dev).eval()
 clouds = []
-for j in range(8):
+for j in range(pairs):
     ref, src, _ = make_pair('c2_5k', index=j); clouds += [ref, src]
 pts = torch.from_numpy(np.concatenate(clouds, 0)).to(dev); lens = torch.tensor([len(c) for c in clouds])
 feats = torch.ones((pts.shape[0], 1), device=dev)
@@ -20,20 +21,41 @@ def step():
     d = precompute_data_stack_mode(pts, lens, b.num_stages, b.init_voxel_size, b.init_radius, cfg.neighbor_limits)
     d['features'] = feats
     return forward_pairs(model, d)
+
+SKIP = ('aten::view', 'aten::_unsafe_view', 'aten::reshape', 'aten::t', 'aten::transpose', 'aten::permute', 'aten::expand', 'aten::slice',
+        'aten::select', 'aten::unsqueeze', 'aten::squeeze', 'aten::detach', 'aten::alias', 'aten::as_strided', 'aten::empty', 'aten::split',
+        'aten::unbind', 'aten::_local_scalar_dense', 'aten::empty_like', 'aten::empty_strided', 'aten::new_empty', 'aten::unfold', 'aten::chunk',
+        'aten::narrow', 'aten::lift_fresh', 'aten::is_nonzero', 'aten::item')
+
+class Sites(TorchDispatchMode):
+    def __init__(self):
+        super().__init__(); self.count = collections.Counter(); self.numel = collections.Counter()
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        out = func(*args, **(kwargs or {}))
+        name = 'aten::' + func.__name__.split('.')[0]
+        if name not in SKIP:
+            f, site = sys._getframe(1), '?'
+            while f is not None:
+                fn = f.f_code.co_filename
+                if 'se3et_amd' in fn and 'torch' not in fn.split('se3et_amd')[-1]:
+                    site = '%s:%d' % (fn.split('se3et_amd/')[-1], f.f_lineno); break
+                f = f.f_back
+            t = out if torch.is_tensor(out) else (out[0] if isinstance(out, (tuple, list)) and out and torch.is_tensor(out[0]) else None)
+            on_gpu = any(torch.is_tensor(a) and a.is_cuda for a in list(args) + ([t] if t is not None else []))
+            if on_gpu:
+                self.count[(name, site)] += 1
+                self.numel[(name, site)] += t.numel() if t is not None else 0
+        return out
+
 with torch.no_grad():
-    for _ in range(3): step()
+    for _ in range(2): step()
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-        step(); torch.cuda.synchronize()
-agg = collections.defaultdict(lambda: [0, 0.0])
-for e in prof.events():
-    t = getattr(e, 'self_device_time_total', None)
-    if t is None: t = getattr(e, 'self_cuda_time_total', 0)
-    if not t or not e.name.startswith('aten::') or any(k in e.name for k in ('mm', 'linear', 'matmul', 'einsum', 'bmm')): continue
-    site = next((s for s in (e.stack or []) if 'se3et_amd' in s), '?')
-    site = site.split('se3et_amd/')[-1][:70]
-    k = (e.name, site); agg[k][0] += 1; agg[k][1] += t
-tot = sum(v[1] for v in agg.values())
-for (name, site), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
-    print('%8.1f us x%-3d %-28s %s' % (us, n, name, site))
-print('total %.2f ms' % (tot / 1e3))
+    with Sites() as S:
+        step()
+    torch.cuda.synchronize()
+per_site = collections.defaultdict(lambda: [0, 0])
+for (name, site), n in S.count.items():
+    per_site[site][0] += n; per_site[site][1] += S.numel[(name, site)]
+print('aten ops on GPU tensors in one forward of %d pairs: %d at %d sites (views / allocations not counted)' % (pairs, sum(S.count.values()), len(per_site)))
+for (name, site), n in sorted(S.count.items(), key=lambda kv: -S.numel[kv[0]])[:60]:
+    print('x%-3d %-26s %12d elements  %s' % (n, name, S.numel[(name, site)], site))
