@@ -239,7 +239,10 @@ int se3_kpconv_so3_gather_bwd(const float* q_pts, const float* s_pts, const int6
  *   se3_kpconv_so3_fused: KPConvInterSO3.forward (blocks_epn.py:454-546) in ONE kernel: producer waves form the orbit sums
  *     H[p, o, a, c] = sum_n hw[p, n, o] x[idx[p, n], a, c] of a 16-point tile on the f32 matrix cores and leave them, split into f16 hi + lo
  *     pieces, in LDS; consumer waves multiply them with v_mfma_f32_32x32x16_f16 (hi hi + hi lo + lo hi in f32: 2^-22 per term), reading the
- *     slot sums of blocks_epn.py:503-546 in place: out (P, 6, Cout).  The operand never exists in HBM.
+ *     slot sums of blocks_epn.py:503-546 in place: out (P, 6, Cout).  The operand never exists in HBM.  With few tiles (one pair per
+ *     forward, the coarse stages) the input channels of a tile are split over several workgroups whose partial outputs the last one to
+ *     arrive adds in a fixed order: split_workspace = se3_kpconv_fused_split_workspace_bytes bytes (0: this shape does not split), ZERO
+ *     before the first call (arrival counters at its start; every call leaves them zero), one per stream; NULL = never split.
  *   se3_kpconv_so3_gather_sums + se3_kpconv_so3_contract_f16: the same two stages as two launches, H as tile images
  *     [Cin / 8][ceil(P / 16)][piece][point][97 x 16 B] in HBM (se3_kpconv_sums_bytes bytes).
  * Range: |H| < 65504 (f16 hi piece); values below 2^-3 keep an absolute error of 2^-25. */
@@ -248,8 +251,10 @@ int se3_kpconv_neighbor_table(const float* q_pts, const float* s_pts, const int6
                               int64_t num_queries, int64_t num_support, int num_neighbors, void* table, size_t table_bytes, void* stream);
 size_t se3_kpconv_weight_pieces_bytes(int in_channels, int out_channels);
 int se3_kpconv_split_weights_f16(const float* weights, int in_channels, int out_channels, void* pieces, void* stream);
+size_t se3_kpconv_fused_split_workspace_bytes(int64_t num_queries, int in_channels, int out_channels);
 int se3_kpconv_so3_fused(const float* x, const void* table, int64_t num_queries, int64_t num_support, int num_neighbors, int in_channels,
-                         int out_channels, const void* weight_pieces, float* out, void* stream);
+                         int out_channels, const void* weight_pieces, float* out, void* split_workspace, size_t split_workspace_bytes,
+                         void* stream);
 size_t se3_kpconv_sums_bytes(int64_t num_queries, int in_channels);
 int se3_kpconv_so3_gather_sums(const float* x, const void* table, int64_t num_queries, int64_t num_support, int num_neighbors,
                                int in_channels, void* sums, void* stream);

@@ -323,7 +323,12 @@ extern "C" int se3_dense_norm_fwd(const float* x, int64_t rows, int in_features,
   int64_t want = g_target_chunks / ncb;
   if (want > kGNMaxChunks - num_segments) want = kGNMaxChunks - num_segments;
   if (want < 1) want = 1;
-  const int64_t tiles_per_chunk = se3_cdiv(tiles, want);
+  int64_t tiles_per_chunk = se3_cdiv(tiles, want);
+  for (int s = 0; s < num_segments; s++) {                                // at most 256 chunks per segment: the in-kernel finalize reads them all
+    const int64_t b0 = num_segments == 1 ? 0 : segment_row_offsets_host[s], b1 = num_segments == 1 ? rows : segment_row_offsets_host[s + 1];
+    const int64_t need = se3_cdiv(se3_cdiv(b1 - b0, TR), 256);
+    if (need > tiles_per_chunk) tiles_per_chunk = need;
+  }
   int chunks = 0;
   for (int s = 0; s < num_segments; s++) {
     const int64_t b0 = num_segments == 1 ? 0 : segment_row_offsets_host[s], b1 = num_segments == 1 ? rows : segment_row_offsets_host[s + 1];

@@ -149,29 +149,48 @@ __device__ __forceinline__ bool gn_last_arrival(int* counter, int expected) {
   if (threadIdx.x == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return true;
 }
+// All 256 threads: T = 256 / (groups rounded up to a power of two) threads per group (at most 64, at least 1), each merging every T-th
+// chunk of the segment with its loads issued 16 at a time (the partials were written by other compute units: every load is a trip to the
+// memory side, and a chain of dependent ones is what made a one-wave-per-group version cost 25 us on a one-pair tensor), then a
+// butterfly over the T lanes.
+__device__ __forceinline__ WF gn_load_partial(const float* p) {
+  return WF{__hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+            __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+}
 __device__ __forceinline__ void gn_finalize_groups(const float* part, int groups, int cb0, int cb1, int g_begin, int g_count, int cpg,
                                                    const float* xb, const float* gw, const float* gb, float eps, float* affine, int C) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int gi = wave; gi < g_count; gi += 4) {
-    const int g = g_begin + gi;
+  int gp2 = 1;
+  while (gp2 < g_count) gp2 <<= 1;
+  const int T = gp2 >= 256 ? 1 : (256 / gp2 > 64 ? 64 : 256 / gp2);        // threads per group (a power of two: lanes of one wave)
+  const int per_pass = 256 / T;                                            // groups handled at once
+  const int sub = threadIdx.x % T;
+  for (int gi = threadIdx.x / T; gi < gp2; gi += per_pass) {
+    const bool live = gi < g_count;
+    const int g = g_begin + (live ? gi : 0);
     WF w = {0.f, 0.f, 0.f};
-    for (int i = cb0 + lane; i < cb1; i += 64) {
-      const float* p = part + ((int64_t)i * groups + g) * 3;
-      const WF o = {__hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                    __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                    __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
-      w = wf_merge(w, o);
+    for (int i0 = cb0 + sub; i0 < cb1; i0 += 16 * T) {
+      WF o[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const int i = i0 + j * T;
+        o[j] = (live && i < cb1) ? gn_load_partial(part + ((int64_t)i * groups + g) * 3) : WF{0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < 16; j++) w = wf_merge(w, o[j]);
     }
-    for (int d = 1; d < 64; d <<= 1) {
+    for (int d = 1; d < T; d <<= 1) {
       const WF o = {__shfl_xor(w.n, d), __shfl_xor(w.mean, d), __shfl_xor(w.m2, d)};
       w = wf_merge(w, o);
     }
-    const float mean = __shfl(w.mean, 0), rstd = 1.0f / sqrtf(__shfl(w.m2, 0) / fmaxf(__shfl(w.n, 0), 1.f) + eps);
-    for (int j = lane; j < cpg; j += 64) {
+    if (!live) continue;
+    // the lanes of a group merged in different orders (round-off): lane 0 of the group decides, the others take its values
+    const float mean = w.mean, rstd = 1.0f / sqrtf(w.m2 / fmaxf(w.n, 1.f) + eps);
+    const float mean0 = __shfl(mean, (threadIdx.x & 63) - sub), rstd0 = __shfl(rstd, (threadIdx.x & 63) - sub);
+    for (int j = sub; j < cpg; j += T) {
       const int c = g * cpg + j;
-      const float scale = rstd * gw[c];
+      const float scale = rstd0 * gw[c];
       affine[c] = scale;
-      affine[C + c] = gb[c] + ((xb ? xb[c] : 0.f) - mean) * scale;
+      affine[C + c] = gb[c] + ((xb ? xb[c] : 0.f) - mean0) * scale;
     }
   }
 }

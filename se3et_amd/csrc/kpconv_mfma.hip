@@ -419,7 +419,8 @@ __global__ __launch_bounds__(256) void kpconv_orbit_gather_kernel(const float* _
 template <int NCW, int KS, int CT, bool EXT>      // consumer waves: NCW column groups x KS K-split groups; CT column tiles (32 columns) per wave; EXT: neighbour tables wider than 32
 __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
     const float* __restrict__ x, const float* __restrict__ hwt, const int* __restrict__ nbr, const int* __restrict__ cnt, int NNp,
-    const u32x4* __restrict__ Wf, const float* __restrict__ hdr, int64_t P, int Cin, int Cout, float* __restrict__ out) {
+    const u32x4* __restrict__ Wf, const float* __restrict__ hdr, int64_t P, int Cin, int Cout, float* __restrict__ out,
+    float* __restrict__ split_part, int* __restrict__ split_count) {
   constexpr int NC = NCW * KS;                                         // consumer waves
   constexpr int NPW = 8;                                               // producer waves: two points of the tile each
   constexpr int kSPW = kSteps / KS;                                    // K16-steps per consumer wave and chunk
@@ -429,7 +430,9 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t tile = blockIdx.x, p0 = tile * kTP;
-  const int chunks = Cin / kCC, pairs = (chunks + 1) / 2;
+  // gridDim.z > 1 (few tiles: one pair per forward): the input-channel chunks are split over gridDim.z workgroups, whose partial outputs
+  // the last one to arrive adds up in a fixed order (see the epilogue)
+  const int chunks = Cin / kCC / (int)gridDim.z, chunk0 = blockIdx.z * chunks, pairs = (chunks + 1) / 2;
   for (int e = tid; e < kSteps * 4; e += 64 * (NC + NPW)) {
     const int h = e & 1, rsel = (e >> 1) & 1, st = e >> 2;
     const int u = 2 * st + h, s = u / kA, t = u % kA;
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
     auto point_of = [&](int u) { return p0 + pw + NPW * (u & 1); };
     auto col_of = [&](int u) {                                          // first of this lane's columns in step u (odd chunk count: the upper half re-reads the lower one)
       const int T = u >> 1;
-      return (unsigned)(T * 16 + ((2 * T + 1 < chunks || half == 0) ? c16 : c16 - 8));
+      return (unsigned)(chunk0 * kCC + T * 16 + ((2 * T + 1 < chunks || half == 0) ? c16 : c16 - 8));
     };
     {
       const int64_t p = point_of(0), pc = p < P ? p : plast;
@@ -556,8 +559,8 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
   constexpr int BD = (CT == 2 && KS > 1) ? 2 : 3;                       // ring depth (the K-split two-tile form has no registers for a third set)
   constexpr int U = BD == 3 ? 6 : 2;                                    // unroll = lcm(2 A buffers, BD)
   static_assert(kSPW % U == 0, "K16-steps per wave and chunk must be a multiple of the unroll");
-  const u32x4* wbase = Wf + (int64_t)ct0 * 2 * 64 + lane;
   const int64_t wstep = (int64_t)NCT * 2 * 64;                          // uint4 per K16-step over the whole layer
+  const u32x4* wbase = Wf + (int64_t)chunk0 * kSteps * wstep + (int64_t)ct0 * 2 * 64 + lane;
   const int64_t last_step = (int64_t)chunks * kSteps - KS + ksp;
   u32x4 bq[BD][CT][2];
 #pragma unroll
@@ -664,18 +667,80 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
           for (int v = 0; v < 16; v++) acc[n][rt][v] += red[((((k - 1) * NCW + cw) * CT + n) * 48 + rt * 16 + v) * 64 + lane];
   }
   const float inv_scale = hdr[0];
+  // Output addressing: row (point v, rotation r = 2 rt + (h ^ s[v >> 2])), s = 0, 1, 1, 0 -- the accumulator's row order; buffer stores with
+  // the tile as the buffer (rows past the last point fall outside and are dropped), lane part in two offsets, the rest uniform.
+  const int row_b = Cout * 4;
+  const int rows_here = (int)(P - p0 < kTP ? P - p0 : kTP);
+  int voff[CT][2];
+#pragma unroll
+  for (int n = 0; n < CT; n++) {
+    voff[n][0] = ((ct0 + n) * 32 + i32) * 4 + h * row_b;
+    voff[n][1] = ((ct0 + n) * 32 + i32) * 4 + (1 - h) * row_b;
+  }
+  constexpr int kAgent = 16;                                              // sc1: agent scope (the access goes through to the memory side)
+#pragma unroll
+  for (int n = 0; n < CT; n++)
+#pragma unroll
+    for (int rt = 0; rt < 3; rt++) acc[n][rt] *= inv_scale;
+  if (gridDim.z > 1) {
+    // Split input channels: this wave's slice of the tile goes to the partial buffer of its split; the wave that finds itself last of the
+    // gridDim.z that own the slice (arrival counter, reset for the next launch) adds the partials in split order and writes the output:
+    // no atomics on the output, the same sum whatever the arrival order.  (Agent-scope stores / loads; no fence: see group_norm.h.)
+    const int64_t rows_all = (int64_t)gridDim.x * kTP * kA;
+    {
+      const __amdgpu_buffer_rsrc_t prs =
+          __builtin_amdgcn_make_buffer_rsrc(split_part + (blockIdx.z * rows_all + p0 * kA) * Cout, 0, kTP * kA * row_b, 0x00020000);
+#pragma unroll
+      for (int n = 0; n < CT; n++)
+#pragma unroll
+        for (int rt = 0; rt < 3; rt++)
+#pragma unroll
+          for (int v = 0; v < 16; v++) {
+            const float val = acc[n][rt][v];          // (a scalar copy: __builtin_bit_cast of a vector ELEMENT reads element 0, hipcc 7.2)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), prs, voff[n][(0x6 >> (v >> 2)) & 1],
+                                                  (v * kA + 2 * rt) * row_b, kAgent);
+          }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int* counter = split_count + (int64_t)tile * (NCT / CT) + ct0 / CT;
+    int ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket != (int)gridDim.z - 1) return;
+    if (lane == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int n = 0; n < CT; n++)
+#pragma unroll
+      for (int rt = 0; rt < 3; rt++)
+#pragma unroll
+        for (int v = 0; v < 16; v++) acc[n][rt][v] = 0.f;
+#pragma unroll 1
+    for (int z = 0; z < (int)gridDim.z; z++) {
+      const __amdgpu_buffer_rsrc_t prs =
+          __builtin_amdgcn_make_buffer_rsrc(split_part + (z * rows_all + p0 * kA) * Cout, 0, kTP * kA * row_b, 0x00020000);
+#pragma unroll
+      for (int n = 0; n < CT; n++)
+#pragma unroll
+        for (int rt = 0; rt < 3; rt++)
+#pragma unroll
+          for (int v = 0; v < 16; v++)
+            acc[n][rt][v] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, voff[n][(0x6 >> (v >> 2)) & 1],
+                                                                                            (v * kA + 2 * rt) * row_b, kAgent));
+    }
+  }
+  const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(out + p0 * kA * Cout, 0, rows_here * kA * row_b, 0x00020000);
 #pragma unroll
   for (int n = 0; n < CT; n++)
 #pragma unroll
     for (int rt = 0; rt < 3; rt++)
 #pragma unroll
       for (int v = 0; v < 16; v++) {
-        const int64_t p = p0 + v;
-        const int r = 2 * rt + ((0x96 >> (2 * (v >> 2) + h)) & 1);
-        if (p < P) out[(p * kA + r) * Cout + (ct0 + n) * 32 + i32] = acc[n][rt][v] * inv_scale;
+        const float val = acc[n][rt][v];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ors, voff[n][(0x6 >> (v >> 2)) & 1], (v * kA + 2 * rt) * row_b, 0);
       }
 }
 
+// KPConvInterSO3.forward (blocks_epn.py:454-546) after se3_kpconv_neighbor_table: gather + contraction in one kernel.
 }  // namespace
 
 extern "C" size_t se3_kpconv_sums_bytes(int64_t num_queries, int in_channels) {
@@ -795,8 +860,31 @@ extern "C" int se3_kpconv_so3_gather_sums(const float* x, const void* table, int
 }
 
 // KPConvInterSO3.forward (blocks_epn.py:454-546) after se3_kpconv_neighbor_table: gather + contraction in one kernel.
+// Few tiles (one pair per forward, the coarse stages): the input-channel chunks of a tile are split over `splits` workgroups.
+static int fused_splits(int64_t tiles, int colblocks, int chunks) {
+  int z = 1;
+  while (tiles * colblocks * z < 256 && chunks % (4 * z) == 0 && chunks / (2 * z) >= 4) z *= 2;
+  return z;
+}
+static int64_t fused_tiles(int64_t num_queries) { return se3_cdiv(num_queries, kTP); }
+static int fused_colblocks(int out_channels) {
+  const int NCT = out_channels / 32;
+  return NCT % 8 == 0 ? NCT / 8 : NCT % 4 == 0 ? NCT / 4 : NCT % 2 == 0 ? NCT / 2 : NCT;
+}
+
+// Workspace of the split form: [arrival counters: ZERO before the first call, left zero by every call][partial outputs]; 0 = this shape
+// does not split (the workspace may then be NULL).
+extern "C" size_t se3_kpconv_fused_split_workspace_bytes(int64_t num_queries, int in_channels, int out_channels) {
+  if (num_queries <= 0 || in_channels % kCC || out_channels % 32) return 0;
+  const int64_t tiles = fused_tiles(num_queries);
+  const int z = fused_splits(tiles, fused_colblocks(out_channels), in_channels / kCC);
+  if (z == 1) return 0;
+  return (size_t)tiles * (out_channels / 32) * sizeof(int) + 256 + (size_t)z * tiles * kTP * kA * out_channels * sizeof(float);
+}
+
 extern "C" int se3_kpconv_so3_fused(const float* x, const void* table, int64_t num_queries, int64_t num_support, int num_neighbors,
-                                    int in_channels, int out_channels, const void* weight_pieces, float* out, void* stream) {
+                                    int in_channels, int out_channels, const void* weight_pieces, float* out, void* split_workspace,
+                                    size_t split_workspace_bytes, void* stream) {
   SE3_REQUIRE(x && table && weight_pieces && out, SE3_ERR_INVALID_ARG, "kpconv_so3_fused: null pointer");
   SE3_REQUIRE(num_neighbors >= 1 && num_neighbors <= 64, SE3_ERR_UNSUPPORTED, "kpconv_so3_fused: %d neighbours (max 64)", num_neighbors);
   SE3_REQUIRE(in_channels > 0 && in_channels % kCC == 0 && out_channels >= 32 && out_channels % 32 == 0, SE3_ERR_UNSUPPORTED,
@@ -810,6 +898,18 @@ extern "C" int se3_kpconv_so3_fused(const float* x, const void* table, int64_t n
   const float* hdr = static_cast<const float*>(weight_pieces);
   const u32x4* Wf = reinterpret_cast<const u32x4*>(static_cast<const unsigned char*>(weight_pieces) + kHeaderB);
   const size_t lds = (size_t)3 * kTileB + kSteps * 4 * sizeof(unsigned);
+  int splits = 1;
+  int* split_count = nullptr;
+  float* split_part = nullptr;
+  if (split_workspace != nullptr) {
+    const size_t need = se3_kpconv_fused_split_workspace_bytes(num_queries, in_channels, out_channels);
+    if (need != 0) {
+      SE3_REQUIRE(split_workspace_bytes >= need, SE3_ERR_WORKSPACE, "kpconv_so3_fused: split workspace too small");
+      splits = fused_splits(tiles, fused_colblocks(out_channels), in_channels / kCC);
+      split_count = static_cast<int*>(split_workspace);
+      split_part = reinterpret_cast<float*>(static_cast<unsigned char*>(split_workspace) + ((size_t)tiles * NCT * sizeof(int) + 255) / 256 * 256);
+    }
+  }
 #define SE3_FUSED_X(NCW_, KS_, CT_, EXT_)                                                                                                 \
   {                                                                                                                                       \
     static bool attr_set = false;                                                                                                         \
@@ -818,8 +918,9 @@ extern "C" int se3_kpconv_so3_fused(const float* x, const void* table, int64_t n
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                                    \
       attr_set = true;                                                                                                                    \
     }                                                                                                                                     \
-    kpconv_fused_kernel<NCW_, KS_, CT_, EXT_><<<dim3((unsigned)tiles, (unsigned)(NCT / (NCW_ * CT_))), 64 * (NCW_ * KS_ + 8), lds, st>>>( \
-        x, t.hwt, t.nbr, t.cnt, t.NNp, Wf, hdr, num_queries, in_channels, out_channels, out);                                             \
+    kpconv_fused_kernel<NCW_, KS_, CT_, EXT_>                                                                                             \
+        <<<dim3((unsigned)tiles, (unsigned)(NCT / (NCW_ * CT_)), (unsigned)splits), 64 * (NCW_ * KS_ + 8), lds, st>>>(                    \
+            x, t.hwt, t.nbr, t.cnt, t.NNp, Wf, hdr, num_queries, in_channels, out_channels, out, split_part, split_count);                \
   }
 #define SE3_FUSED(NCW_, KS_, CT_)                       \
   {                                                     \

@@ -431,17 +431,23 @@ def group_norm_rows_bwd(grad_out, x, weight, bias, groups, eps, leaky_slope, res
 
 
 _dense_ws = {}
+_kpconv_split_ws = {}
+KPCONV_SPLIT = True           # few-tile layers split their input channels over workgroups (False: A/B runs)
+
+
+def _zeroed_workspace(cache, device, stream, nbytes):
+    """A workspace that begins with arrival counters (in-kernel finalize / split reduction): one per stream, zero when first used; every
+    call leaves the counters zero."""
+    key = (device, stream.value)
+    ws = cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.zeros((max(nbytes, 1 << 20),), dtype=torch.uint8, device=device)
+        cache[key] = ws
+    return ws
 
 
 def _dense_workspace(device, stream, nbytes):
-    """Workspace of dense_norm, one per stream: it begins with the arrival counters of the in-kernel finalize, which must start at zero
-    (every call leaves them zero)."""
-    key = (device, stream.value)
-    ws = _dense_ws.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.zeros((max(nbytes, 1 << 20),), dtype=torch.uint8, device=device)
-        _dense_ws[key] = ws
-    return ws
+    return _zeroed_workspace(_dense_ws, device, stream, nbytes)
 
 
 class Pending:
@@ -691,7 +697,10 @@ def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, s
             check(lib().se3_kpconv_so3_contract_f16(Hs.data_ptr(), Wp.data_ptr(), P, Cin, Cout, out.data_ptr(), stream),
                   'se3_kpconv_so3_contract_f16')
             return out
-        check(lib().se3_kpconv_so3_fused(x.data_ptr(), tab.data_ptr(), P, Ns, NN, Cin, Cout, Wp.data_ptr(), out.data_ptr(), stream),
+        sbytes = lib().se3_kpconv_fused_split_workspace_bytes(P, Cin, Cout) if KPCONV_SPLIT else 0
+        sws = _zeroed_workspace(_kpconv_split_ws, x.device, stream, sbytes) if sbytes else None
+        check(lib().se3_kpconv_so3_fused(x.data_ptr(), tab.data_ptr(), P, Ns, NN, Cin, Cout, Wp.data_ptr(), out.data_ptr(),
+                                         sws.data_ptr() if sws is not None else None, sws.numel() if sws is not None else 0, stream),
               'se3_kpconv_so3_fused')
         return out
     G = torch.empty((P * 6, 36 * Cin), dtype=torch.float32, device=x.device)

@@ -857,7 +857,8 @@ def test_dense_norm_matches_linear_then_group_norm(rows, K, N, groups, nstage, s
 
 
 @pytest.mark.parametrize('P,Ns,NN,Cin,Cout,box', [(77, 90, 38, 24, 32, 0.05), (130, 130, 40, 40, 96, 0.04), (33, 64, 36, 8, 64, 0.05),
-                                                  (200, 260, 48, 72, 160, 0.06), (16, 16, 16, 16, 32, 0.03), (95, 400, 64, 64, 256, 0.08)])
+                                                  (200, 260, 48, 72, 160, 0.06), (16, 16, 16, 16, 32, 0.03), (95, 400, 64, 64, 256, 0.08),
+                                                  (100, 150, 36, 128, 128, 0.05), (50, 90, 38, 256, 256, 0.05), (700, 900, 38, 256, 256, 0.12)])
 def test_fused_kpconv_edge_shapes(P, Ns, NN, Cin, Cout, box):
     """The fused matrix-core kernel where its schedule has corners: more than 32 VALID neighbours per point (a second gather round), odd numbers
     of 8-channel chunks (the last producer pair is a single chunk), 3 / 5 column tiles (K-split consumers), point counts that are not
@@ -897,3 +898,14 @@ def test_fused_kpconv_edge_shapes(P, Ns, NN, Cin, Cout, box):
     for path in (True, 'sums'):
         e_new = float((outs[path].double() - ref).abs().max())
         assert e_new <= max(2 * e_old, 2e-6 * float(ref.abs().max())), (path, e_new, e_old)
+    # few tiles: the input channels are split over workgroups; the partial sums are added in a fixed order (bit-identical runs), the arrival
+    # counters are back at zero for the next call, and the split form agrees with the unsplit one to round-off
+    if ops.lib().se3_kpconv_fused_split_workspace_bytes(P, Cin, Cout):
+        again = SF.kpconv_inter_so3(*args).cpu()
+        assert torch.equal(again, outs[True])
+        ops.KPCONV_SPLIT = False
+        try:
+            whole = SF.kpconv_inter_so3(*args).cpu()
+        finally:
+            ops.KPCONV_SPLIT = True
+        assert float((whole - again).abs().max()) <= 5e-6 * float(ref.abs().max())

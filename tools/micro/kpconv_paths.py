@@ -48,7 +48,7 @@ for qs, ss, tab, C in calls:
     t_t = timeit(lambda: check(lib().se3_kpconv_neighbor_table(q.data_ptr(), s.data_ptr(), idx.data_ptr(), kp.data_ptr(), float(sig), P, s.shape[0], NN, tabl.data_ptr(), nb, st), 't'))
     t_g = timeit(lambda: check(lib().se3_kpconv_so3_gather_sums(x.data_ptr(), tabl.data_ptr(), P, s.shape[0], NN, C, Hs.data_ptr(), st), 'g'))
     t_c = timeit(lambda: check(lib().se3_kpconv_so3_contract_f16(Hs.data_ptr(), Wp.data_ptr(), P, C, C, out.data_ptr(), st), 'c'))
-    t_f = timeit(lambda: check(lib().se3_kpconv_so3_fused(x.data_ptr(), tabl.data_ptr(), P, s.shape[0], NN, C, C, Wp.data_ptr(), out.data_ptr(), st), 'f'))
+    t_f = timeit(lambda: check(lib().se3_kpconv_so3_fused(x.data_ptr(), tabl.data_ptr(), P, s.shape[0], NN, C, C, Wp.data_ptr(), out.data_ptr(), None, 0, st), 'f'))
     err = float((out - torch.mm(ops.kpconv_slot_sums(x, q, s, idx, kp, kidx, ridx, sig), w.reshape(36 * C, C)).view(P, 6, C)).abs().max() / out.abs().max())
     gf = 2.0 * 6 * q.shape[0] * 36 * C * C / 1e9
     ops.KPCONV_MATRIX_CORE = True; outf = SF.kpconv_inter_so3(x, q, s, idx, kp, w, kidx, ridx, sig); ops.KPCONV_MATRIX_CORE = 'auto'
