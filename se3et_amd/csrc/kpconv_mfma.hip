@@ -872,14 +872,16 @@ static int fused_colblocks(int out_channels) {
   return NCT % 8 == 0 ? NCT / 8 : NCT % 4 == 0 ? NCT / 4 : NCT % 2 == 0 ? NCT / 2 : NCT;
 }
 
-// Workspace of the split form: [arrival counters: ZERO before the first call, left zero by every call][partial outputs]; 0 = this shape
+// Workspace of the split form: [arrival counters: a region of FIXED size, so that layers of different shapes sharing one workspace never
+// write partial sums over each other's counters; ZERO before the first call, left zero by every call][partial outputs]; 0 = this shape
 // does not split (the workspace may then be NULL).
+constexpr size_t kSplitCounterB = 64 * 1024;
 extern "C" size_t se3_kpconv_fused_split_workspace_bytes(int64_t num_queries, int in_channels, int out_channels) {
   if (num_queries <= 0 || in_channels % kCC || out_channels % 32) return 0;
   const int64_t tiles = fused_tiles(num_queries);
   const int z = fused_splits(tiles, fused_colblocks(out_channels), in_channels / kCC);
-  if (z == 1) return 0;
-  return (size_t)tiles * (out_channels / 32) * sizeof(int) + 256 + (size_t)z * tiles * kTP * kA * out_channels * sizeof(float);
+  if (z == 1 || (size_t)tiles * (out_channels / 32) * sizeof(int) > kSplitCounterB) return 0;
+  return kSplitCounterB + (size_t)z * tiles * kTP * kA * out_channels * sizeof(float);
 }
 
 extern "C" int se3_kpconv_so3_fused(const float* x, const void* table, int64_t num_queries, int64_t num_support, int num_neighbors,
@@ -907,7 +909,7 @@ extern "C" int se3_kpconv_so3_fused(const float* x, const void* table, int64_t n
       SE3_REQUIRE(split_workspace_bytes >= need, SE3_ERR_WORKSPACE, "kpconv_so3_fused: split workspace too small");
       splits = fused_splits(tiles, fused_colblocks(out_channels), in_channels / kCC);
       split_count = static_cast<int*>(split_workspace);
-      split_part = reinterpret_cast<float*>(static_cast<unsigned char*>(split_workspace) + ((size_t)tiles * NCT * sizeof(int) + 255) / 256 * 256);
+      split_part = reinterpret_cast<float*>(static_cast<unsigned char*>(split_workspace) + kSplitCounterB);
     }
   }
 #define SE3_FUSED_X(NCW_, KS_, CT_, EXT_)                                                                                                 \

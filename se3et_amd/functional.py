@@ -12,9 +12,11 @@ import threading
 import torch
 import torch.nn.functional as F
 
+from . import attention_bwd as ABW
 from . import autograd as AG
 from . import ops as _ops
 
+ATTENTION_BACKWARD = 'explicit'      # 'autograd': reverse-mode differentiation of the PyTorch restatements (the pin of the explicit form)
 HIP_OPS = set()          # filled below as kernels are bound; tests assert the hot ops are in here
 
 
@@ -264,9 +266,14 @@ def rpe_attention(q, k, vt, emb, w_p, eq_emb, w_eq, num_heads, return_scores=Fal
     the query side (q.(W e + b) = (W^T q).e + q.b; the q.b term is constant along m and cancels in the softmax).
     Convenience form (the layers use `rpe_self_attention_packed`, which gets q, k and the folded queries from ONE GEMM)."""
     if AG.needs_grad(q, k, vt, emb, w_p, w_eq):
-        hidden = AG.differentiable(lambda q_, k_, v_, e_, wp, ee, we: rpe_attention(q_, k_, v_, e_, wp, ee, we, num_heads)[0],
-                                   lambda q_, k_, v_, e_, wp, ee, we: AG.rpe_attention(q_, k_, v_, e_, wp, ee, we, num_heads),
-                                   1, q, k, vt, emb, w_p, eq_emb, w_eq)
+        fwd = lambda q_, k_, v_, e_, wp, ee, we: rpe_attention(q_, k_, v_, e_, wp, ee, we, num_heads)[0]
+        if ATTENTION_BACKWARD == 'explicit' and emb.dtype == torch.float32 and (q.dim() == 2 or q.shape[0] * num_heads <= 32):
+            # hand-derived backward (se3et_amd/attention_bwd.py): logits recomputed by the forward's HIP kernel, batched library GEMMs
+            hidden = AG.hip_backward(fwd, lambda g, needs, *t: ABW.rpe_attention_bwd(g, needs, *t, num_heads), 'rpe_attention',
+                                     q, k, vt, emb, w_p, eq_emb, w_eq)
+        else:
+            hidden = AG.differentiable(fwd, lambda q_, k_, v_, e_, wp, ee, we: AG.rpe_attention(q_, k_, v_, e_, wp, ee, we, num_heads),
+                                       1, q, k, vt, emb, w_p, eq_emb, w_eq)
         return hidden, None
     anchored = q.dim() == 3
     q3 = q if anchored else q.unsqueeze(0)
@@ -341,6 +348,9 @@ def rpe_self_attention_packed(x, starts, lengths, embs, eq_embs, w_stack, b_stac
 def cross_attention(q, k, vt, num_heads):
     """q (N, C), k (M, C), vt (C, Mp) or (A, C, Mp) -> (N, C) or (A, N, C)."""
     if AG.needs_grad(q, k, vt):
+        if ATTENTION_BACKWARD == 'explicit':
+            return AG.hip_backward(lambda q_, k_, v_: _ops.cross_attention(q_, k_, v_, num_heads),
+                                   lambda g, needs, *t: ABW.cross_attention_bwd(g, needs, *t, num_heads), 'cross_attention', q, k, vt)
         return AG.differentiable(lambda q_, k_, v_: _ops.cross_attention(q_, k_, v_, num_heads),
                                  lambda q_, k_, v_: AG.cross_attention(q_, k_, v_, num_heads), 1, q, k, vt)
     return _ops.cross_attention(q, k, vt, num_heads)

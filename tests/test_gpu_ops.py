@@ -909,3 +909,8 @@ def test_fused_kpconv_edge_shapes(P, Ns, NN, Cin, Cout, box):
         finally:
             ops.KPCONV_SPLIT = True
         assert float((whole - again).abs().max()) <= 5e-6 * float(ref.abs().max())
+        # another split shape through the same workspace (its partial sums must not land on this shape's counters), then this one again
+        other = _conv_state(64, 64, radius)
+        SF.kpconv_inter_so3(torch.randn(Ns, 6, 64).cuda(), *args[1:4], other['kernel_points'].cuda(), other['weights'].cuda(),
+                            other['kidx_rot'][:, 0, :].cuda(), other['ridx_rot'][0].cuda(), sigma)
+        assert torch.equal(SF.kpconv_inter_so3(*args).cpu(), again)

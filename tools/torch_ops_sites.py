@@ -20,8 +20,9 @@ feats = torch.ones((pts.shape[0], 1), device=dev)
 def step():
     d = precompute_data_stack_mode(pts, lens, b.num_stages, b.init_voxel_size, b.init_radius, cfg.neighbor_limits)
     d['features'] = feats
-    return forward_pairs(model, d)
+    return forward_pairs(model, d) if pairs > 1 else model(d)
 
+FILLS = ('aten::zeros', 'aten::zeros_like', 'aten::fill_', 'aten::zero_', 'aten::ones', 'aten::ones_like', 'aten::full', 'aten::new_zeros', 'aten::copy_', 'aten::_to_copy', 'aten::clone', 'aten::cat', 'aten::contiguous')
 SKIP = ('aten::view', 'aten::_unsafe_view', 'aten::reshape', 'aten::t', 'aten::transpose', 'aten::permute', 'aten::expand', 'aten::slice',
         'aten::select', 'aten::unsqueeze', 'aten::squeeze', 'aten::detach', 'aten::alias', 'aten::as_strided', 'aten::empty', 'aten::split',
         'aten::unbind', 'aten::_local_scalar_dense', 'aten::empty_like', 'aten::empty_strided', 'aten::new_empty', 'aten::unfold', 'aten::chunk',
@@ -59,3 +60,9 @@ for (name, site), n in S.count.items():
 print('aten ops on GPU tensors in one forward of %d pairs: %d at %d sites (views / allocations not counted)' % (pairs, sum(S.count.values()), len(per_site)))
 for (name, site), n in sorted(S.count.items(), key=lambda kv: -S.numel[kv[0]])[:60]:
     print('x%-3d %-26s %12d elements  %s' % (n, name, S.numel[(name, site)], site))
+print('--- fills / copies by site')
+for (name, site), n in sorted(((k, v) for k, v in S.count.items() if k[0] in FILLS), key=lambda kv: -kv[1])[:50]:
+    print('x%-3d %-26s %12d elements  %s' % (n, name, S.numel[(name, site)], site))
+print('--- launches by site (all ops)')
+for site, (n, el) in sorted(per_site.items(), key=lambda kv: -kv[1][0])[:40]:
+    print('x%-3d %12d elements  %s' % (n, el, site))
