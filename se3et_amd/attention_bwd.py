@@ -117,3 +117,96 @@ def cross_attention_bwd(grad, needs, q, k, vt, num_heads):
         dvt[..., :M] = torch.matmul(gh.transpose(2, 3), P).reshape(A, C, M)
         dvt = dvt if per_anchor else dvt[0]
     return dq, dk, dvt
+
+
+class _CrossAttentionEq(torch.autograd.Function):
+    """functional.cross_attention_eq (vanilla_transformer.py:247-641, 751-870; 'a_soft' / 'r_soft') with all three outputs differentiable:
+    hidden (A, N, C), the weights ((A, A) or (R,)) and the anchor-pair mixing matrix (eq2inv_soft consumes it).
+
+        S[a,e] = q_a k_e^T / sqrt(d),  g[a,e] = mean_{n,m} (mean_h S)^2,  mix = normalised g (per row / over rotations),
+        out[a] = sum_e mix[a,e] softmax_m(S[a,e]) v_e
+        dS = mix o P o (G - rowsum(P o G)) + 2 dg mean_h S / (N M H),   G[a,e] = dO_a v_e^T,   dmix[a,e] = <P[a,e], G[a,e]> + g_mix
+    """
+
+    @staticmethod
+    def forward(ctx, q, k, vt, trace_idx, num_heads, mode):
+        with torch.no_grad():
+            out, w, mix = _ops.cross_attention_eq(q, k, vt, num_heads, mode, trace_idx)
+        ctx.save_for_backward(q, k, vt, trace_idx)
+        ctx.num_heads, ctx.mode = num_heads, mode
+        return out, w, mix
+
+    @staticmethod
+    def backward(ctx, g_out, g_w, g_mix):
+        from . import autograd as AG
+        if AG.BACKWARD_TIMINGS is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        with torch.no_grad():
+            got = _cross_attention_eq_bwd(ctx, g_out, g_w, g_mix)
+        if AG.BACKWARD_TIMINGS is not None:
+            e1.record()
+            AG.BACKWARD_TIMINGS.setdefault('cross_attention_eq (HIP)', []).append((e0, e1))
+        return got + (None, None, None)
+
+
+def _cross_attention_eq_bwd(ctx, g_out, g_w, g_mix):
+    q, k, vt, trace_idx = ctx.saved_tensors
+    H, mode = ctx.num_heads, ctx.mode
+    A, N, C = q.shape
+    M = k.shape[1]
+    d = C // H
+    scale = 1.0 / math.sqrt(d)
+    qh = q.reshape(A, N, H, d).permute(0, 2, 1, 3)                        # (A, H, N, d)
+    kh = k.reshape(A, M, H, d).permute(0, 2, 1, 3)                        # (A, H, M, d)
+    vhT = vt[..., :M].reshape(A, H, d, M)                                 # (A, H, d, M)
+    S = torch.matmul(qh[:, None], kh[None].transpose(-1, -2)) * scale     # (A, A, H, N, M)
+    P = torch.softmax(S, -1)
+    Sbar = S.mean(2)                                                      # (A, A, N, M)
+    g = (Sbar * Sbar).mean((-1, -2))                                      # (A, A)
+    ar = torch.arange(A, device=q.device)
+    if mode == 'a_soft':
+        Gs = g.sum(1, keepdim=True)
+        mix = g / Gs
+    else:
+        R = trace_idx.shape[0]
+        wr = g[ar[None, :], trace_idx].mean(1)                            # (R,)
+        W = wr.sum()
+        w = wr / W
+        mix = torch.zeros((A, A), dtype=q.dtype, device=q.device).index_put_(
+            (ar[None, :].expand(R, A).reshape(-1), trace_idx.reshape(-1)), w[:, None].expand(R, A).reshape(-1), accumulate=True)
+    dmix = torch.zeros_like(mix) if g_mix is None else g_mix.reshape(A, A).clone()
+    dS = None
+    dq = torch.zeros_like(qh)
+    dk = torch.zeros_like(kh)
+    dvt = torch.zeros_like(vt) if ctx.needs_input_grad[2] else None
+    if g_out is not None:
+        gh = g_out.reshape(A, N, H, d).permute(0, 2, 1, 3)                # (A, H, N, d)
+        G = torch.matmul(gh[:, None], vhT[None])                          # (A, A, H, N, M): dO_a v_e^T
+        PG = P * G
+        dmix = dmix + PG.sum((-1, -2, -3))
+        dS = (PG - P * PG.sum(-1, keepdim=True)) * mix[:, :, None, None, None]
+        if dvt is not None:
+            # dv_e = sum_a mix[a, e] P[a, e]^T dO_a, stored transposed (A, C, Mp)
+            Pw = P * mix[:, :, None, None, None]
+            dvt[..., :M] = torch.matmul(gh[:, None].transpose(-1, -2), Pw).sum(0).reshape(A, C, M)
+    # through the normalised anchor-pair statistics
+    if mode == 'a_soft':
+        dw = dmix if g_w is None else dmix + g_w.reshape(A, A)
+        dg = dw / Gs - (dw * g).sum(1, keepdim=True) / (Gs * Gs)
+    else:
+        dw = dmix[ar[None, :], trace_idx].sum(1)                          # (R,)
+        if g_w is not None:
+            dw = dw + g_w.reshape(-1)
+        dwr = dw / W - (dw * wr).sum() / (W * W)
+        dg = torch.zeros_like(g).index_put_((ar[None, :].expand_as(trace_idx).reshape(-1), trace_idx.reshape(-1)),
+                                            (dwr[:, None] / A).expand_as(trace_idx).reshape(-1), accumulate=True)
+    dSg = (dg[:, :, None, None] * Sbar) * (2.0 / (N * M * H))             # (A, A, N, M), the same for every head
+    dS = dSg[:, :, None] + dS if dS is not None else dSg[:, :, None].expand(A, A, H, N, M)
+    dq = torch.matmul(dS, kh[None]).sum(1) * scale                        # (A, H, N, d)
+    dk = torch.matmul(dS.transpose(-1, -2), qh[:, None]).sum(0) * scale   # (A, H, M, d)
+    return (dq.permute(0, 2, 1, 3).reshape(A, N, C), dk.permute(0, 2, 1, 3).reshape(A, M, C), dvt)
+
+
+def cross_attention_eq(q, k, vt, num_heads, mode, trace_idx):
+    return _CrossAttentionEq.apply(q, k, vt, trace_idx, num_heads, mode)

@@ -2,9 +2,9 @@
 
 Forward = the gfx950 kernel.  Backward: hand-written for the ops that dominated the step (KPConv: csrc/kpconv_so3.hip kpconv_scatter_kernel
 + two library GEMMs, 474 -> 5 ms per 5k+5k step; GroupNorm: csrc/rowops.hip gn_bwd_*, 20 -> 5 ms; Sinkhorn: csrc/sinkhorn.hip sinkhorn_bwd_kernel, 18 -> 0.4 ms; geometric embedding: GEMM operands from
-csrc/geo_embedding.hip, 13 -> 3 ms; neighbour max-pool; padded row gather; RPE self attention and plain cross attention:
-se3et_amd/attention_bwd.py, logits recomputed by the forward's kernel + batched GEMMs, 8.9 -> 5.0 ms --
-`hip_backward`), and for the others (equivariant cross attention) reverse-mode
+csrc/geo_embedding.hip, 13 -> 3 ms; neighbour max-pool; padded row gather; the three attention ops: se3et_amd/attention_bwd.py,
+logits recomputed by the forward's kernel + batched GEMMs, 12.9 -> 8.1 ms --
+`hip_backward`), and for anything else (and as the pin of the hand-derived forms: functional.ATTENTION_BACKWARD = 'autograd') reverse-mode
 differentiation of a PyTorch restatement of the SAME op, re-evaluated on the GPU inside backward ('until a
 backward kernel exists autograd runs through the PyTorch restatement' -- `differentiable`).  Every
 restatement below is plain torch on GPU tensors -- nothing here runs on the CPU and nothing imports oracle/.  `differentiable(hip_fn,

@@ -361,6 +361,8 @@ def cross_attention_eq(q, k, vt, num_heads, mode, trace_idx):
     'a_soft', w (R,) for 'r_soft'; mix (A, A) = the anchor-pair weights actually applied (for r_soft the 24 rotation weights
     collapsed onto anchor pairs, mix[a, e] = sum_{r: trace[r, a] = e} w[r])."""
     if AG.needs_grad(q, k, vt):
+        if ATTENTION_BACKWARD == 'explicit':
+            return ABW.cross_attention_eq(q, k, vt, num_heads, mode, trace_idx)
         return AG.differentiable(lambda q_, k_, v_, t_: _ops.cross_attention_eq(q_, k_, v_, num_heads, mode, t_),
                                  lambda q_, k_, v_, t_: AG.cross_attention_eq(q_, k_, v_, t_, num_heads, mode), 3, q, k, vt, trace_idx)
     return _ops.cross_attention_eq(q, k, vt, num_heads, mode, trace_idx)

@@ -438,3 +438,27 @@ def test_attention_backward_matches_autograd(anchors, use_eq):
         want = torch.autograd.grad(AG.cross_attention(q2, k2, vt2, H), (q2, k2, vt2), go2)
         for name, a, b in zip(('q', 'k', 'vt'), got, want):
             assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()), 'cross ' + name
+
+
+@pytest.mark.parametrize('mode', ['a_soft', 'r_soft'])
+def test_equivariant_cross_attention_backward_matches_autograd(mode):
+    """se3et_amd/attention_bwd.py::_CrossAttentionEq (all three outputs differentiable) against reverse-mode differentiation of the
+    restatement, with gradients arriving on the hidden states, the weights and the mixing matrix."""
+    from se3et_amd import autograd as AG
+    from se3et_amd import functional as SF
+    from se3et_amd import tables
+    g = torch.Generator().manual_seed(9)
+    A, N, M, C, H = 6, 382, 350, 256, 4
+    Mp = (M + 31) // 32 * 32
+    mk = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).cuda().requires_grad_(True)
+    q, k, vt = mk(A, N, C, scale=0.7), mk(A, M, C, scale=0.7), mk(A, C, Mp)
+    trace = torch.from_numpy(tables.trace_indices()[0]).long().cuda()
+    outs_a = SF.cross_attention_eq(q, k, vt, H, mode, trace)
+    outs_b = AG.cross_attention_eq(q, k, vt, trace, H, mode)
+    gos = [torch.randn(o.shape, generator=g).cuda() for o in outs_b]
+    for o_a, o_b in zip(outs_a, outs_b):
+        assert float((o_a - o_b).abs().max()) <= 1e-4 * float(o_b.abs().max())
+    got = torch.autograd.grad([o.reshape(b.shape) for o, b in zip(outs_a, outs_b)], (q, k, vt), gos)
+    want = torch.autograd.grad(outs_b, (q, k, vt), gos)
+    for name, a, b in zip(('q', 'k', 'vt'), got, want):
+        assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()), name

@@ -64,7 +64,7 @@ def main():
         print(json.dumps({'metric': 'training step (fwd + bwd + Adam), %s on %s pairs' % (args.variant, args.pair), 's_per_step': round(dt / args.steps, 4),
                           'pairs_per_s': round(world * args.steps / dt, 3), 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                           'loss': float(losses['loss'].detach()), 'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
-                          'backward': 'HIP kernels for KPConv / GroupNorm / LayerNorm / Sinkhorn / embedding / max-pool / row gather; RPE self attention and plain cross attention: hand-derived backward on the HIP logits kernel + batched GEMMs (se3et_amd/attention_bwd.py); equivariant cross attention: reverse mode through its PyTorch restatement (se3et_amd/autograd.py)', 'data': 'synthetic'}), flush=True)
+                          'backward': 'HIP kernels for KPConv / GroupNorm / LayerNorm / Sinkhorn / embedding / max-pool / row gather; attention (RPE self, plain cross, equivariant cross): hand-derived backward, logits recomputed by the HIP kernel, batched GEMMs (se3et_amd/attention_bwd.py)', 'data': 'synthetic'}), flush=True)
     if args.profile and world > 1 and rank == 0:
         print('--profile is a single-GPU option (a forward / backward through the DDP wrapper on one rank would wait for its peers): skipped')
     if args.profile and world == 1:
