@@ -141,7 +141,9 @@ int se3_group_norm_segments_bwd(const float* x, const float* x_bias, const float
  *                          in-kernel finalize at its start; every call leaves them zero), one per stream.
  *   se3_group_norm_apply   out = lrelu_f( Tb(Ta(x)) + R ),  T.(v) = lrelu_slope(v * scale + shift);  R = residual * scale_r + shift_r
  *                          (residual_affine: the shortcut branch's own pending GroupNorm), the plain residual, or nothing.  A slope of 1
- *                          is "no LeakyReLU".  channels % 4 == 0.
+ *                          is "no LeakyReLU".  channels % 4 == 0.  blocked_layout = 1: x is (points, 6, channels) and out is written as
+ *                          [point][channels / 16][anchor pair][16][2], the layout se3_kpconv_so3_fused gathers whole cache lines from
+ *                          (x_blocked = 1; channels % 16 == 0).
  *   se3_dense_norm_fwd     UnaryBlockEPN (blocks_epn.py:639-665) = mlp + GroupNormEPN with both of the above folded into the GEMM
  *                          (csrc/dense_norm.hip): out = T_b(T_a(x)) W^T WITHOUT the bias (raw), affine_out = the table of
  *                          GroupNorm(out + linear_bias) computed from the accumulators.  weight_pieces: se3_linear_split_weights_f16.
@@ -155,7 +157,7 @@ int se3_group_norm_stats(const float* x, const float* in_affine, float in_slope,
                          float* affine_out, void* workspace, size_t workspace_bytes, void* stream);
 int se3_group_norm_apply(const float* x, const float* affine_a, float slope_a, const float* affine_b, float slope_b, const float* residual,
                          const float* residual_affine, float final_slope, int64_t rows, int channels,
-                         const int64_t* segment_row_offsets_host, int num_segments, float* out, void* stream);
+                         const int64_t* segment_row_offsets_host, int num_segments, int blocked_layout, float* out, void* stream);
 size_t se3_dense_norm_workspace_bytes(int groups);
 int se3_dense_norm_fwd(const float* x, int64_t rows, int in_features, const float* in_affine_a, float in_slope_a, const float* in_affine_b,
                        float in_slope_b, const void* weight_pieces, int out_features, const float* linear_bias, const float* norm_weight,
@@ -243,6 +245,7 @@ int se3_kpconv_so3_gather_bwd(const float* q_pts, const float* s_pts, const int6
  *     forward, the coarse stages) the input channels of a tile are split over several workgroups whose partial outputs the last one to
  *     arrive adds in a fixed order: split_workspace = se3_kpconv_fused_split_workspace_bytes bytes (0: this shape does not split), ZERO
  *     before the first call (arrival counters at its start; every call leaves them zero), one per stream; NULL = never split.
+ *     x_blocked = 1: x in the blocked layout written by se3_group_norm_apply(blocked_layout = 1) (in_channels % 16 == 0).
  *   se3_kpconv_so3_gather_sums + se3_kpconv_so3_contract_f16: the same two stages as two launches, H as tile images
  *     [Cin / 8][ceil(P / 16)][piece][point][97 x 16 B] in HBM (se3_kpconv_sums_bytes bytes).
  * Range: |H| < 65504 (f16 hi piece); values below 2^-3 keep an absolute error of 2^-25. */
@@ -254,7 +257,7 @@ int se3_kpconv_split_weights_f16(const float* weights, int in_channels, int out_
 size_t se3_kpconv_fused_split_workspace_bytes(int64_t num_queries, int in_channels, int out_channels);
 int se3_kpconv_so3_fused(const float* x, const void* table, int64_t num_queries, int64_t num_support, int num_neighbors, int in_channels,
                          int out_channels, const void* weight_pieces, float* out, void* split_workspace, size_t split_workspace_bytes,
-                         void* stream);
+                         int x_blocked, void* stream);
 size_t se3_kpconv_sums_bytes(int64_t num_queries, int in_channels);
 int se3_kpconv_so3_gather_sums(const float* x, const void* table, int64_t num_queries, int64_t num_support, int num_neighbors,
                                int in_channels, void* sums, void* stream);

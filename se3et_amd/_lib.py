@@ -34,7 +34,7 @@ SIGNATURES = {
     'se3_add_layer_norm_bwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _f32, _vp, _vp, _vp]),
     'se3_group_norm_stats_workspace_bytes': (_sz, [_i32]),
     'se3_group_norm_stats': (_i32, [_vp, _vp, _f32, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _f32, _vp, _vp, _sz, _vp]),
-    'se3_group_norm_apply': (_i32, [_vp, _vp, _f32, _vp, _f32, _vp, _vp, _f32, _i64, _i32, _vp, _i32, _vp, _vp]),
+    'se3_group_norm_apply': (_i32, [_vp, _vp, _f32, _vp, _f32, _vp, _vp, _f32, _i64, _i32, _vp, _i32, _i32, _vp, _vp]),
     'se3_dense_norm_workspace_bytes': (_sz, [_i32]),
     'se3_dense_norm_fwd': (_i32, [_vp, _i64, _i32, _vp, _f32, _vp, _f32, _vp, _i32, _vp, _vp, _vp, _i32, _f32, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
     'se3_dense_norm_set_target_chunks': (None, [_i32]),
@@ -54,7 +54,7 @@ SIGNATURES = {
     'se3_kpconv_neighbor_table_bytes': (_sz, [_i64, _i32]),
     'se3_kpconv_neighbor_table': (_i32, [_vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _vp, _sz, _vp]),
     'se3_kpconv_fused_split_workspace_bytes': (_sz, [_i64, _i32, _i32]),
-    'se3_kpconv_so3_fused': (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    'se3_kpconv_so3_fused': (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _i32, _vp]),
     'se3_rpe_bias_fwd': (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     'se3_attention_fwd': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _f32, _vp, _vp]),
     'se3_rpe_bias_stack_fwd': (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),

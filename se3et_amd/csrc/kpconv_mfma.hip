@@ -277,8 +277,12 @@ __device__ __forceinline__ void gather_request_rows(const int* __restrict__ nbro
     nbv[9] = t.y;
   }
 }
-// nv: valid neighbours of the point (uniform): the tail slots are requested only when the round has more than 32
-template <bool EXT>
+// nv: valid neighbours of the point (uniform): the tail slots are requested only when the round has more than 32.
+// BLK: x in the blocked layout [point][Cin / 16][anchor pair][16 channels][2 anchors] (rowops.hip: gn_chain_apply_blocked_kernel writes it):
+// the six anchors of a lane's channel are three 8-byte loads, and one wave-instruction reads four neighbours x 128 contiguous bytes --
+// whole cache lines.  In the plain layout (point, anchor, channel) an instruction reads four 64-byte half lines whose other halves the next
+// step fetches again: twice the lines through the compute unit's L1, the producers' limit (tools/micro/kpconv_stamps.py).
+template <bool EXT, bool BLK>
 __device__ __forceinline__ void gather_request_ops(const float* __restrict__ x, const float* __restrict__ hwrow, int NNp, int rd, int g, int c16,
                                                    const int (&nbv)[kGN + (EXT ? kGX : 0)], unsigned rowlen, unsigned col, int Cin, int nv,
                                                    GatherOps<EXT>& q) {
@@ -286,19 +290,29 @@ __device__ __forceinline__ void gather_request_ops(const float* __restrict__ x, 
   const float* wr = hwrow + c16 * NNp + S * rd + 8 * g;
   const float4 w0 = *reinterpret_cast<const float4*>(wr), w1 = *reinterpret_cast<const float4*>(wr + 4);
   q.aw[0] = w0.x; q.aw[1] = w0.y; q.aw[2] = w0.z; q.aw[3] = w0.w; q.aw[4] = w1.x; q.aw[5] = w1.y; q.aw[6] = w1.z; q.aw[7] = w1.w;
+  const unsigned blk = (col >> 4) * 96 + (col & 15) * 2;                 // (BLK) floats from the point's row to this lane's anchor pair 0
+  auto fetch = [&](int j) {
+    if constexpr (BLK) {
 #pragma unroll
-  for (int j = 0; j < kGN; j++)
+      for (int ap = 0; ap < kA / 2; ap++) {
+        const float2 v = *reinterpret_cast<const float2*>(x + (unsigned)nbv[j] * rowlen + blk + ap * 32);
+        q.xb[2 * ap][j] = v.x;
+        q.xb[2 * ap + 1][j] = v.y;
+      }
+    } else {
 #pragma unroll
-    for (int a = 0; a < kA; a++) q.xb[a][j] = x[(unsigned)nbv[j] * rowlen + (unsigned)(a * Cin) + col];
+      for (int a = 0; a < kA; a++) q.xb[a][j] = x[(unsigned)nbv[j] * rowlen + (unsigned)(a * Cin) + col];
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < kGN; j++) fetch(j);
   if constexpr (EXT) {
     if (nv > S * rd + 32) {
       const float2 wt = *reinterpret_cast<const float2*>(hwrow + c16 * NNp + S * rd + 32 + 2 * g);
       q.aw[8] = wt.x;
       q.aw[9] = wt.y;
 #pragma unroll
-      for (int j = kGN; j < kGN + kGX; j++)
-#pragma unroll
-        for (int a = 0; a < kA; a++) q.xb[a][j] = x[(unsigned)nbv[j] * rowlen + (unsigned)(a * Cin) + col];
+      for (int j = kGN; j < kGN + kGX; j++) fetch(j);
     }
   }
 }
@@ -388,7 +402,7 @@ __global__ __launch_bounds__(256) void kpconv_orbit_gather_kernel(const float* _
     int nbv[kGN + (EXT ? kGX : 0)];
     GatherOps<EXT> q;
     gather_request_rows<EXT>(nbrow, rd, g, nbv);
-    gather_request_ops<EXT>(x, hwrow, NNp, rd, g, c16, nbv, rowlen, col, Cin, nv, q);
+    gather_request_ops<EXT, false>(x, hwrow, NNp, rd, g, c16, nbv, rowlen, col, Cin, nv, q);
     gather_multiply<EXT>(q, nv > S * rd + 32, acc);
   }
   unsigned word[kA][4];
@@ -416,7 +430,7 @@ __global__ __launch_bounds__(256) void kpconv_orbit_gather_kernel(const float* _
 // to image (2T) % 3 at once, while rows of chunk 2T + 1 computed in step 2T wait in registers for one step (image (2T + 1) % 3 is still being
 // read during step 2T).  All operands of step u + 1 (neighbour numbers, orbit weights, 36 gathered values per lane) are requested during step
 // u: the producers' memory latency (two dependent round trips, 1-3 us each under load) is off the critical path.
-template <int NCW, int KS, int CT, bool EXT>      // consumer waves: NCW column groups x KS K-split groups; CT column tiles (32 columns) per wave; EXT: neighbour tables wider than 32
+template <int NCW, int KS, int CT, bool EXT, bool BLK>      // consumer waves: NCW column groups x KS K-split groups; CT column tiles (32 columns) per wave; EXT: neighbour tables wider than 32; BLK: x in the blocked layout
 __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
     const float* __restrict__ x, const float* __restrict__ hwt, const int* __restrict__ nbr, const int* __restrict__ cnt, int NNp,
     const u32x4* __restrict__ Wf, const float* __restrict__ hdr, int64_t P, int Cin, int Cout, float* __restrict__ out,
@@ -471,7 +485,7 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
       int nbv[kGN + (EXT ? kGX : 0)];
       gather_request_rows<EXT>(nbr + pc * NNp, 0, g, nbv);
       nv_cur = p < P ? cnt[pc] : 0;
-      gather_request_ops<EXT>(x, hwt + pc * NNp * 16, NNp, 0, g, c16, nbv, rowlen, col_of(0), Cin, __builtin_amdgcn_readfirstlane(nv_cur), ops);
+      gather_request_ops<EXT, BLK>(x, hwt + pc * NNp * 16, NNp, 0, g, c16, nbv, rowlen, col_of(0), Cin, __builtin_amdgcn_readfirstlane(nv_cur), ops);
     }
     for (int u = 0; u < steps_total; u++) {
       SE3_STAMP(u, 0)
@@ -507,12 +521,12 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
           int nbv[kGN + (EXT ? kGX : 0)];
           GatherOps<EXT> q;
           gather_request_rows<EXT>(nbr + pc * NNp, rd, g, nbv);
-          gather_request_ops<EXT>(x, hwt + pc * NNp * 16, NNp, rd, g, c16, nbv, rowlen, col_of(u), Cin, nv, q);
+          gather_request_ops<EXT, BLK>(x, hwt + pc * NNp * 16, NNp, rd, g, c16, nbv, rowlen, col_of(u), Cin, nv, q);
           gather_multiply<EXT>(q, nv > S * rd + 32, acc);
         }
         SE3_STAMP(u, 7)
         // the next step's operands leave now (their neighbour numbers have arrived behind the MFMAs)
-        gather_request_ops<EXT>(x, hwt + pnc * NNp * 16, NNp, 0, g, c16, nbn, rowlen, col_of(more ? u + 1 : u), Cin,
+        gather_request_ops<EXT, BLK>(x, hwt + pnc * NNp * 16, NNp, 0, g, c16, nbn, rowlen, col_of(more ? u + 1 : u), Cin,
                                 __builtin_amdgcn_readfirstlane(nv_next), ops);
         nv_cur = nv_next;
         SE3_STAMP(u, 2)
@@ -886,12 +900,14 @@ extern "C" size_t se3_kpconv_fused_split_workspace_bytes(int64_t num_queries, in
 
 extern "C" int se3_kpconv_so3_fused(const float* x, const void* table, int64_t num_queries, int64_t num_support, int num_neighbors,
                                     int in_channels, int out_channels, const void* weight_pieces, float* out, void* split_workspace,
-                                    size_t split_workspace_bytes, void* stream) {
+                                    size_t split_workspace_bytes, int x_blocked, void* stream) {
   SE3_REQUIRE(x && table && weight_pieces && out, SE3_ERR_INVALID_ARG, "kpconv_so3_fused: null pointer");
   SE3_REQUIRE(num_neighbors >= 1 && num_neighbors <= 64, SE3_ERR_UNSUPPORTED, "kpconv_so3_fused: %d neighbours (max 64)", num_neighbors);
   SE3_REQUIRE(in_channels > 0 && in_channels % kCC == 0 && out_channels >= 32 && out_channels % 32 == 0, SE3_ERR_UNSUPPORTED,
               "kpconv_so3_fused: channels (%d, %d) must be multiples of (8, 32)", in_channels, out_channels);
   SE3_REQUIRE((int64_t)num_support * kA * in_channels < (1ll << 31), SE3_ERR_UNSUPPORTED, "kpconv_so3_fused: support features exceed 2^31 elements");
+  SE3_REQUIRE(!x_blocked || in_channels % 16 == 0, SE3_ERR_UNSUPPORTED, "kpconv_so3_fused: the blocked feature layout needs in_channels %% 16 == 0 (%d)",
+              in_channels);
   if (num_queries == 0) return SE3_OK;
   hipStream_t st = (hipStream_t)stream;
   const NeighborTable t = table_views(table, num_queries, num_neighbors);
@@ -912,22 +928,27 @@ extern "C" int se3_kpconv_so3_fused(const float* x, const void* table, int64_t n
       split_part = reinterpret_cast<float*>(static_cast<unsigned char*>(split_workspace) + kSplitCounterB);
     }
   }
-#define SE3_FUSED_X(NCW_, KS_, CT_, EXT_)                                                                                                 \
+#define SE3_FUSED_X(NCW_, KS_, CT_, EXT_, BLK_)                                                                                           \
   {                                                                                                                                       \
     static bool attr_set = false;                                                                                                         \
     if (!attr_set) {                                                                                                                      \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kpconv_fused_kernel<NCW_, KS_, CT_, EXT_>),                                \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kpconv_fused_kernel<NCW_, KS_, CT_, EXT_, BLK_>),                          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                                    \
       attr_set = true;                                                                                                                    \
     }                                                                                                                                     \
-    kpconv_fused_kernel<NCW_, KS_, CT_, EXT_>                                                                                             \
+    kpconv_fused_kernel<NCW_, KS_, CT_, EXT_, BLK_>                                                                                       \
         <<<dim3((unsigned)tiles, (unsigned)(NCT / (NCW_ * CT_)), (unsigned)splits), 64 * (NCW_ * KS_ + 8), lds, st>>>(                    \
             x, t.hwt, t.nbr, t.cnt, t.NNp, Wf, hdr, num_queries, in_channels, out_channels, out, split_part, split_count);                \
   }
-#define SE3_FUSED(NCW_, KS_, CT_)                       \
-  {                                                     \
-    if (t.NNp > 32) SE3_FUSED_X(NCW_, KS_, CT_, true)   \
-    else SE3_FUSED_X(NCW_, KS_, CT_, false)             \
+#define SE3_FUSED(NCW_, KS_, CT_)                                  \
+  {                                                                \
+    if (t.NNp > 32) {                                              \
+      if (x_blocked) SE3_FUSED_X(NCW_, KS_, CT_, true, true)       \
+      else SE3_FUSED_X(NCW_, KS_, CT_, true, false)                \
+    } else {                                                       \
+      if (x_blocked) SE3_FUSED_X(NCW_, KS_, CT_, false, true)      \
+      else SE3_FUSED_X(NCW_, KS_, CT_, false, false)               \
+    }                                                              \
   }
   // 11 or 12 waves per compute unit (3 per SIMD: 168 registers): 8 producers + 3 or 4 consumers
   if (NCT % 8 == 0) SE3_FUSED(4, 1, 2)

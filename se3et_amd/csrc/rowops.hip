@@ -229,6 +229,41 @@ __global__ __launch_bounds__(256) void gn_chain_apply_kernel(ChainArgs p, SegTab
   }
 }
 
+// The same, written in the layout the fused KPConv gathers from (csrc/kpconv_mfma.hip, BLK): x (points, 6 anchors, C) ->
+// [point][C / 16][anchor pair][16 channels][2 anchors].  A thread owns two anchor rows x 4 channels: two 16-byte reads, 32 contiguous bytes out.
+__global__ __launch_bounds__(256) void gn_chain_apply_blocked_kernel(ChainArgs p, SegTable T) {
+  const int C = p.C, Q = C >> 2;
+  const int64_t total = (p.rows >> 1) * Q;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t pr = i / Q;                              // anchor-pair row: point n = pr / 3, pair ap = pr % 3
+    const int c0 = (int)(i - pr * Q) << 2;
+    const int64_t n = pr / 3;
+    const int ap = (int)(pr - n * 3);
+    const int64_t r0 = n * 6 + 2 * ap;
+    const size_t so = (size_t)(T.n > 1 ? seg_of_row(T, r0) : 0) * 2 * C;
+    float4 o[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      const int64_t at = ((r0 + e) * C + c0) >> 2;
+      o[e] = affine_lrelu(reinterpret_cast<const float4*>(p.x)[at], p.affine_a + so, C, c0, p.slope_a);
+      if (p.affine_b) o[e] = affine_lrelu(o[e], p.affine_b + so, C, c0, p.slope_b);
+      if (p.res) {
+        float4 t = reinterpret_cast<const float4*>(p.res)[at];
+        if (p.affine_r) t = affine_lrelu(t, p.affine_r + so, C, c0, 1.f);
+        o[e] = make_float4(o[e].x + t.x, o[e].y + t.y, o[e].z + t.z, o[e].w + t.w);
+      }
+      o[e].x = o[e].x > 0.f ? o[e].x : o[e].x * p.slope_f;
+      o[e].y = o[e].y > 0.f ? o[e].y : o[e].y * p.slope_f;
+      o[e].z = o[e].z > 0.f ? o[e].z : o[e].z * p.slope_f;
+      o[e].w = o[e].w > 0.f ? o[e].w : o[e].w * p.slope_f;
+    }
+    float4* dst = reinterpret_cast<float4*>(p.y + n * 6 * C + (c0 >> 4) * 96 + ap * 32 + (c0 & 15) * 2);
+    dst[0] = make_float4(o[0].x, o[1].x, o[0].y, o[1].y);
+    dst[1] = make_float4(o[0].z, o[1].z, o[0].w, o[1].w);
+  }
+}
+
 // ---- GroupNorm backward (training step) ------------------------------------------------------------------------------------------------
 // y = lrelu(xhat w + b [+ res]),  xhat = (x + xb - mean_g) rstd_g  per (segment, group).  With dz = dy lrelu'(.):
 //   dres = dz,   db[c] = sum_r dz,   dw[c] = sum_r dz xhat,
@@ -740,7 +775,7 @@ extern "C" int se3_group_norm_stats(const float* x, const float* in_affine, floa
 // ... and the pass that makes a pending form concrete: out = lrelu_f( Tb(Ta(x)) + R ) (gn_chain_apply_kernel); slopes of 1 = no LeakyReLU.
 extern "C" int se3_group_norm_apply(const float* x, const float* affine_a, float slope_a, const float* affine_b, float slope_b,
                                     const float* residual, const float* residual_affine, float final_slope, int64_t rows, int channels,
-                                    const int64_t* segment_row_offsets_host, int num_segments, float* out, void* stream) {
+                                    const int64_t* segment_row_offsets_host, int num_segments, int blocked_layout, float* out, void* stream) {
   SE3_REQUIRE(x && affine_a && out, SE3_ERR_INVALID_ARG, "group_norm_apply: null pointer");
   SE3_REQUIRE(rows >= 1 && channels >= 4 && channels % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, SE3_ERR_UNSUPPORTED,
               "group_norm_apply: rows %lld channels %d (a multiple of 4)", (long long)rows, channels);
@@ -749,8 +784,12 @@ extern "C" int se3_group_norm_apply(const float* x, const float* affine_a, float
   int chunks;
   const int rc = gn_segment_table("group_norm_apply", rows, channels, segment_row_offsets_host, num_segments, false, T, chunks);
   if (rc != SE3_OK) return rc;
+  SE3_REQUIRE(!blocked_layout || (channels % 16 == 0 && rows % 6 == 0), SE3_ERR_UNSUPPORTED,
+              "group_norm_apply: the blocked layout is for (points, 6, channels) with channels %% 16 == 0 (rows %lld, channels %d)", (long long)rows,
+              channels);
   ChainArgs p{x, affine_a, affine_b, residual, residual_affine, slope_a, slope_b, final_slope, rows, channels, out};
-  gn_chain_apply_kernel<<<grid_for(rows * channels / 4, 256), 256, 0, (hipStream_t)stream>>>(p, T);
+  if (blocked_layout) gn_chain_apply_blocked_kernel<<<grid_for(rows * channels / 8, 256), 256, 0, (hipStream_t)stream>>>(p, T);
+  else gn_chain_apply_kernel<<<grid_for(rows * channels / 4, 256), 256, 0, (hipStream_t)stream>>>(p, T);
   SE3_CHECK_LAUNCH("group_norm_apply");
   return SE3_OK;
 }

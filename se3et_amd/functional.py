@@ -195,9 +195,11 @@ def norm_stats(x, norm_weight, norm_bias, groups, eps, slope, x_bias=None):
 
 
 @_hip
-def norm_apply(x, residual=None, final_slope=1.0):
-    """A Pending made concrete, optionally + residual (tensor or one-stage Pending) and a final LeakyReLU."""
-    return _ops.group_norm_apply(x, residual, final_slope)
+def norm_apply(x, residual=None, final_slope=1.0, blocked=False):
+    """A Pending made concrete, optionally + residual (tensor or one-stage Pending) and a final LeakyReLU.  blocked=True: as the fused
+    KPConv's gather layout (ops.BlockedFeatures; only kpconv_inter_so3 takes it)."""
+    return _ops.group_norm_apply(x, residual, final_slope, blocked and _ops.KPCONV_BLOCKED and x.raw.dim() == 3 and x.raw.shape[1] == 6
+                                 and x.raw.shape[2] % 16 == 0)
 
 
 def group_norm_rows(x, weight, bias, groups, eps, leaky_slope=None, residual=None, x_bias=None, segments=None):

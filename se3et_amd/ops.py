@@ -463,6 +463,22 @@ class Pending:
         return Pending(self.raw, self.affines + [affine], self.slopes + [slope], self.segments)
 
 
+class BlockedFeatures:
+    """(points, 6, C) features stored as [point][C / 16][anchor pair][16 channels][2 anchors] -- the layout the fused KPConv gathers whole
+    cache lines from (group_norm_apply(blocked=True) writes it, kpconv_inter_so3 reads it); `plain()` is the ordinary tensor."""
+    __slots__ = ('data', 'shape')
+
+    def __init__(self, data, shape):
+        self.data, self.shape = data, tuple(shape)
+
+    def plain(self):
+        n, a, c = self.shape
+        return self.data.view(n, c // 16, a // 2, 16, 2).permute(0, 2, 4, 1, 3).reshape(n, a, c)
+
+
+KPCONV_BLOCKED = True          # False: the KPConv input in the plain layout (A/B runs)
+
+
 def dense_norm_ok(x, weight, groups):
     """True when the fused dense layer + GroupNorm statistics kernel (csrc/dense_norm.hip) takes this layer."""
     raw = x.raw if isinstance(x, Pending) else x
@@ -523,8 +539,9 @@ def group_norm_stats(x, weight, bias, groups, eps, x_bias=None, segments=None):
     return affine
 
 
-def group_norm_apply(x, residual=None, final_slope=1.0):
-    """HIP (csrc/rowops.hip): a Pending made concrete: lrelu_f(T_b(T_a(raw)) + R), R = a tensor, a Pending with one stage (slope 1), or None."""
+def group_norm_apply(x, residual=None, final_slope=1.0, blocked=False):
+    """HIP (csrc/rowops.hip): a Pending made concrete: lrelu_f(T_b(T_a(raw)) + R), R = a tensor, a Pending with one stage (slope 1), or None.
+    blocked=True (raw (points, 6, C), C % 16 == 0): the result in the fused KPConv's gather layout, as BlockedFeatures."""
     if not x.affines or len(x.affines) > 2:
         raise RuntimeError('group_norm_apply: one or two pending stages')
     raw = _req(x.raw, torch.float32, 'x')
@@ -546,9 +563,10 @@ def group_norm_apply(x, residual=None, final_slope=1.0):
     sl = x.slopes + [1.0]
     check(lib().se3_group_norm_apply(raw.data_ptr(), aa[0].data_ptr(), float(sl[0]), aa[1].data_ptr() if aa[1] is not None else None, float(sl[1]),
                                      res.data_ptr() if res is not None else None, res_aff.data_ptr() if res_aff is not None else None,
-                                     float(final_slope), rows, C, _i64_array(segments) if nseg > 1 else None, nseg, out.data_ptr(), _stream()),
+                                     float(final_slope), rows, C, _i64_array(segments) if nseg > 1 else None, nseg, 1 if blocked else 0,
+                                     out.data_ptr(), _stream()),
           'se3_group_norm_apply')
-    return out
+    return BlockedFeatures(out, raw.shape) if blocked else out
 
 
 _host_table_cache = {}
@@ -666,19 +684,30 @@ def kpconv_inter_so3_bwd(grad_out, x, q_pts, s_pts, idx, kernel_points, weights,
 
 
 def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, sigma):
-    """Matrix-core path (csrc/kpconv_contract.hip) for channel counts that are multiples of (8, 16); otherwise the HIP gather of
-    the slot-summed neighbourhood features (csrc/kpconv_so3.hip) + one library GEMM with the (36 Cin, Cout) weight matrix."""
-    x = _req(x.contiguous(), torch.float32, 'x', 3)
+    """Fused matrix-core kernel (csrc/kpconv_mfma.hip) for channel counts that are multiples of (8, 32); otherwise the HIP gather of
+    the slot-summed neighbourhood features (csrc/kpconv_so3.hip) + one library GEMM with the (36 Cin, Cout) weight matrix.
+    x: (Ns, 6, Cin) tensor or BlockedFeatures (inference: written by group_norm_apply(blocked=True))."""
+    blocked = isinstance(x, BlockedFeatures)
+    xb = x.data if blocked else None
+    if blocked:
+        Ns, A, Cin = x.shape
+    else:
+        x = _req(x.contiguous(), torch.float32, 'x', 3)
+        Ns, A, Cin = x.shape
     q_pts, s_pts = _req(q_pts.contiguous(), torch.float32, 'q_pts', 2), _req(s_pts.contiguous(), torch.float32, 's_pts', 2)
     idx = _req(idx.contiguous(), torch.int64, 'neighb_inds', 2)
     P, NN = idx.shape
-    Ns, A, Cin = x.shape
     Cout = weights.shape[-1]
     if A != 6 or tuple(weights.shape[:3]) != (6, 6, Cin) or Ns != s_pts.shape[0]:
         raise RuntimeError('kpconv_inter_so3: inconsistent shapes')
     kp, kt, rt = _host_table(kernel_points, torch.float32), _host_table(kidx, torch.int64), _host_table(ridx, torch.int64)
     path = _kpconv_use_matrix_core(Cin, Cout, P)
-    if path and Cin % 8 == 0 and Cout % 32 == 0 and Ns * 6 * Cin < 2 ** 31 and _builtin_slot_tables(kt, rt):
+    fused_ok = bool(path) and Cin % 8 == 0 and Cout % 32 == 0 and Ns * 6 * Cin < 2 ** 31 and _builtin_slot_tables(kt, rt)
+    if blocked and not (fused_ok and path != 'sums' and Cin % 16 == 0):
+        x, blocked = x.plain().contiguous(), False              # (only the fused kernel reads the blocked layout)
+    if fused_ok:
+        if blocked:
+            x = xb
         stream = _stream()
         Wp = _kpconv_weight_pieces(weights, Cin, Cout, stream)
         out = torch.empty((P, 6, Cout), dtype=torch.float32, device=x.device)
@@ -700,7 +729,8 @@ def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, s
         sbytes = lib().se3_kpconv_fused_split_workspace_bytes(P, Cin, Cout) if KPCONV_SPLIT else 0
         sws = _zeroed_workspace(_kpconv_split_ws, x.device, stream, sbytes) if sbytes else None
         check(lib().se3_kpconv_so3_fused(x.data_ptr(), tab.data_ptr(), P, Ns, NN, Cin, Cout, Wp.data_ptr(), out.data_ptr(),
-                                         sws.data_ptr() if sws is not None else None, sws.numel() if sws is not None else 0, stream),
+                                         sws.data_ptr() if sws is not None else None, sws.numel() if sws is not None else 0,
+                                         1 if blocked else 0, stream),
               'se3_kpconv_so3_fused')
         return out
     G = torch.empty((P * 6, 36 * Cin), dtype=torch.float32, device=x.device)

@@ -837,6 +837,10 @@ def test_dense_norm_matches_linear_then_group_norm(rows, K, N, groups, nstage, s
     out.slopes[-1] = 0.1
     got = ops.group_norm_apply(out)
     assert float((got.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    if rows % 6 == 0 and N % 16 == 0 and seg is None:
+        # the same pass writing the fused KPConv's gather layout
+        p3 = ops.Pending(out.raw.view(rows // 6, 6, N), out.affines, out.slopes, None)
+        assert torch.equal(ops.group_norm_apply(p3, blocked=True).plain().reshape(rows, N), got)
     # the statistics alone, from a pass over the raw tensor with one pending stage, agree with the epilogue's
     aff2 = ops.group_norm_stats(ops.Pending(out.raw, [], [], seg), gw, gb, groups, 1e-5, x_bias=b)
     assert torch.allclose(aff2, out.affines[0], rtol=2e-4, atol=2e-5)
@@ -898,6 +902,11 @@ def test_fused_kpconv_edge_shapes(P, Ns, NN, Cin, Cout, box):
     for path in (True, 'sums'):
         e_new = float((outs[path].double() - ref).abs().max())
         assert e_new <= max(2 * e_old, 2e-6 * float(ref.abs().max())), (path, e_new, e_old)
+    if Cin % 16 == 0:
+        # the blocked feature layout [point][Cin / 16][anchor pair][16][2] (whole cache lines per gather instruction): the same arithmetic
+        xb = ops.BlockedFeatures(x.view(Ns, 3, 2, Cin // 16, 16).permute(0, 3, 1, 4, 2).contiguous().cuda(), (Ns, 6, Cin))
+        assert torch.equal(xb.plain().cpu(), x)
+        assert torch.equal(SF.kpconv_inter_so3(xb, *args[1:]).cpu(), outs[True])
     # few tiles: the input channels are split over workgroups; the partial sums are added in a fixed order (bit-identical runs), the arrival
     # counters are back at zero for the next call, and the split form agrees with the unsplit one to round-off
     if ops.lib().se3_kpconv_fused_split_workspace_bytes(P, Cin, Cout):

@@ -48,11 +48,18 @@ for qs, ss, tab, C in calls:
     t_t = timeit(lambda: check(lib().se3_kpconv_neighbor_table(q.data_ptr(), s.data_ptr(), idx.data_ptr(), kp.data_ptr(), float(sig), P, s.shape[0], NN, tabl.data_ptr(), nb, st), 't'))
     t_g = timeit(lambda: check(lib().se3_kpconv_so3_gather_sums(x.data_ptr(), tabl.data_ptr(), P, s.shape[0], NN, C, Hs.data_ptr(), st), 'g'))
     t_c = timeit(lambda: check(lib().se3_kpconv_so3_contract_f16(Hs.data_ptr(), Wp.data_ptr(), P, C, C, out.data_ptr(), st), 'c'))
-    t_f = timeit(lambda: check(lib().se3_kpconv_so3_fused(x.data_ptr(), tabl.data_ptr(), P, s.shape[0], NN, C, C, Wp.data_ptr(), out.data_ptr(), None, 0, st), 'f'))
+    t_f = timeit(lambda: check(lib().se3_kpconv_so3_fused(x.data_ptr(), tabl.data_ptr(), P, s.shape[0], NN, C, C, Wp.data_ptr(), out.data_ptr(), None, 0, 0, st), 'f'))
+    t_b = float('nan')
+    if C % 16 == 0:      # the same kernel reading the blocked feature layout (whole cache lines per gather instruction)
+        Ns = s.shape[0]
+        xb = x.view(Ns, 3, 2, C // 16, 16).permute(0, 3, 1, 4, 2).contiguous()
+        t_b = timeit(lambda: check(lib().se3_kpconv_so3_fused(xb.data_ptr(), tabl.data_ptr(), P, Ns, NN, C, C, Wp.data_ptr(), out.data_ptr(), None, 0, 1, st), 'f'))
+        tot['blocked'] = tot.get('blocked', 0.0) + t_b
+        check(lib().se3_kpconv_so3_fused(x.data_ptr(), tabl.data_ptr(), P, Ns, NN, C, C, Wp.data_ptr(), out.data_ptr(), None, 0, 0, st), 'f')
     err = float((out - torch.mm(ops.kpconv_slot_sums(x, q, s, idx, kp, kidx, ridx, sig), w.reshape(36 * C, C)).view(P, 6, C)).abs().max() / out.abs().max())
     gf = 2.0 * 6 * q.shape[0] * 36 * C * C / 1e9
     ops.KPCONV_MATRIX_CORE = True; outf = SF.kpconv_inter_so3(x, q, s, idx, kp, w, kidx, ridx, sig); ops.KPCONV_MATRIX_CORE = 'auto'
     errf = float((outf - torch.mm(ops.kpconv_slot_sums(x, q, s, idx, kp, kidx, ridx, sig), w.reshape(36 * C, C)).view(P, 6, C)).abs().max() / outf.abs().max())
-    print('P %6d NN %2d C %3d  gemm %.3f ms  sums %.3f ms (table %.3f + gather %.3f + contract %.3f)  fused %.3f ms (kernel %.3f) (%.0f GF: %.0f TF/s f32-equivalent, %.2f PF/s f16)  err %.1e / %.1e'
-          % (q.shape[0], idx.shape[1], C, res['old'], res['sums'], t_t, t_g, t_c, res['new'], t_f, gf, gf / res['new'], 3 * gf / res['new'] / 1e3, err, errf))
-print('total gemm %.2f ms  sums %.2f ms  fused %.2f ms per 8 pairs' % (tot['old'], tot['sums'], tot['new']))
+    print('P %6d NN %2d C %3d  gemm %.3f ms  sums %.3f ms (table %.3f + gather %.3f + contract %.3f)  fused %.3f ms (kernel %.3f, blocked x %.3f) (%.0f GF: %.0f TF/s f32-equivalent, %.2f PF/s f16)  err %.1e / %.1e'
+          % (q.shape[0], idx.shape[1], C, res['old'], res['sums'], t_t, t_g, t_c, res['new'], t_f, t_b, gf, gf / res['new'], 3 * gf / res['new'] / 1e3, err, errf))
+print('total gemm %.2f ms  sums %.2f ms  fused %.2f ms (kernels with blocked x: %.2f ms) per 8 pairs' % (tot['old'], tot['sums'], tot['new'], tot.get('blocked', float('nan'))))

@@ -30,12 +30,12 @@ nbytes = _lib.lib().se3_kpconv_neighbor_table_bytes(P, NN)
 ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
 _lib.check(_lib.lib().se3_kpconv_neighbor_table(q.data_ptr(), s.data_ptr(), idx.data_ptr(), kp.data_ptr(), float(sig), P, s.shape[0], NN, ws.data_ptr(), nbytes, None), 'table')
 stamps = torch.zeros((64, 16, 40, 8), dtype=torch.int64, device=dev)
-L.se3_kpconv_so3_fused.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_size_t, vp]
+L.se3_kpconv_so3_fused.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_size_t, ctypes.c_int, vp]
 L.se3_debug_kpconv_set_stamps.argtypes = [vp]
 assert L.se3_debug_kpconv_set_stamps(stamps.data_ptr()) == 0
 torch.cuda.synchronize()
 for _ in range(3):
-    rc = L.se3_kpconv_so3_fused(x.data_ptr(), ws.data_ptr(), P, s.shape[0], NN, C, C, Wp.data_ptr(), out.data_ptr(), None, 0, None)
+    rc = L.se3_kpconv_so3_fused(x.data_ptr(), ws.data_ptr(), P, s.shape[0], NN, C, C, Wp.data_ptr(), out.data_ptr(), None, 0, 0, None)
     assert rc == 0
 torch.cuda.synchronize()
 st = stamps.cpu().numpy().astype(np.float64)
