@@ -204,34 +204,53 @@ def main():
         import queue
         q = queue.Queue(maxsize=2)
         side = streams[-1]
+        stop, failed = threading.Event(), []
+
+        def put(item):                       # never blocks for good: a consumer that died must not leave this thread (and the process) waiting
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.2)
+                    return
+                except queue.Full:
+                    pass
 
         def producer():
-            with torch.cuda.stream(side):
-                for i in indices:
-                    pts, lens = pairs[i]
-                    data = precompute_data_stack_mode(pts, lens, b.num_stages, b.init_voxel_size, b.init_radius,
-                                                      cfg.neighbor_limits)
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                    q.put((data, ev))
-            q.put(None)
+            try:
+                with torch.cuda.stream(side):
+                    for i in indices:
+                        if stop.is_set():
+                            break
+                        pts, lens = pairs[i]
+                        data = precompute_data_stack_mode(pts, lens, b.num_stages, b.init_voxel_size, b.init_radius,
+                                                          cfg.neighbor_limits)
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        put((data, ev))
+            except BaseException as e:       # handed to the main thread below
+                failed.append(e)
+            put(None)
 
-        th = threading.Thread(target=producer)
+        th = threading.Thread(target=producer, daemon=True)
         th.start()
         main = torch.cuda.current_stream()
         keep = []
-        while True:
-            item = q.get()
-            if item is None:
-                break
-            data, ev = item
-            main.wait_event(ev)
-            for key in ('points', 'neighbors', 'subsampling', 'upsampling'):
-                for t in data[key]:
-                    t.record_stream(main)          # allocated on the side stream, consumed on the main stream
-            forward(data)
-            keep = [data] + keep[:1]
-        th.join()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                data, ev = item
+                main.wait_event(ev)
+                for key in ('points', 'neighbors', 'subsampling', 'upsampling'):
+                    for t in data[key]:
+                        t.record_stream(main)          # allocated on the side stream, consumed on the main stream
+                forward(data)
+                keep = [data] + keep[:1]
+        finally:
+            stop.set()
+            th.join(timeout=30)
+        if failed:
+            raise failed[0]
 
     def run_all(indices):
         P = max(1, args.inflight)
@@ -242,11 +261,21 @@ def main():
             for i in indices:
                 step(i)
             return
-        threads = [threading.Thread(target=run, args=(indices[t::P], streams[t])) for t in range(P)]
+        failed = []
+
+        def guarded(idx, stream):
+            try:
+                run(idx, stream)
+            except BaseException as e:
+                failed.append(e)
+
+        threads = [threading.Thread(target=guarded, args=(indices[t::P], streams[t]), daemon=True) for t in range(P)]
         for t in threads:
             t.start()
         for t in threads:
             t.join()
+        if failed:
+            raise failed[0]
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.inflight) + 1)]
     if args.inflight > 1 or args.prefetch:

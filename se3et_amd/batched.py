@@ -115,7 +115,7 @@ def transformer_pairs(gt, points_c, lengths_c, feats_c, packed=False):
     P1 = _Packed([lengths_c[2 * i + 1] for i in range(B)])
     PA = _Packed([lengths_c[c] for c in order])             # P0 followed by P1 (both row counts are multiples of 32)
     R0 = P0.rows
-    x = SF.linear(feats_c.transpose(0, 1), gt.in_proj.weight, gt.in_proj.bias)                      # (A, P, C)
+    x = SF.linear(feats_c, gt.in_proj.weight, gt.in_proj.bias).transpose(0, 1)                      # (A, P, C): a view, packed (copied) below
     X = PA.pack([x[:, offs[c]:offs[c + 1]] for c in order])                                          # (A, R, C)
     embs_o, eqs_o = [embs[c] for c in order], [eqs[c] for c in order]
 

@@ -40,6 +40,11 @@ def linear(x, weight, bias=None, relu=False):
         return F.relu(y) if relu else y
     if _ops.linear_f16_ok(x, weight):
         return _ops.linear_f16(x, weight, bias, relu)
+    if x.dim() == 3 and not x.is_contiguous() and x.stride(2) == 1 and not relu:
+        # a row range of packed (A, R, C) features: one batched GEMM over the anchors on the strided view (F.linear would copy it first)
+        A, R, N = x.shape[0], x.shape[1], weight.shape[0]
+        wt = weight.t()[None].expand(A, weight.shape[1], N)
+        return torch.bmm(x, wt) if bias is None else torch.baddbmm(bias[None, None, :].expand(A, R, N), x, wt)
     if bias is None and not relu:
         if x.dim() == 2:
             return mm(x, weight.t())

@@ -115,8 +115,11 @@ class E2PN(nn.Module):
         latent = inv[self.num_stages]
         for s in range(self.num_stages - 1, 1, -1):
             at_stage(s - 1)
-            latent = torch.cat((nearest_upsample(latent, up[s - 1]), inv[s]), 1)
-            latent = getattr(self, 'decoder%d' % s)(latent)
+            dec = getattr(self, 'decoder%d' % s)
+            if SF.AG.needs_grad(latent, inv[s], dec.mlp.weight):
+                latent = dec(torch.cat((nearest_upsample(latent, up[s - 1]), inv[s]), 1))
+            else:                     # inference: the dense layer's coarse half runs before the upsampling, nothing is concatenated
+                latent = dec.forward_upsampled(latent, up[s - 1], inv[s])
             feats_list.append(latent)
         at_stage(None)
         feats_list.reverse()

@@ -2,7 +2,8 @@
 (25 steps): python tools/step_breakdown.py <kernel_stats.csv> [steps]"""
 import csv, sys
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 25
-fam = [('Cijk_', 'library GEMM'), ('linear_', 'dense f16-split GEMM'), ('gn_', 'GroupNorm'), ('kpconv_gather', 'KPConv gather (G form)'),
+fam = [('Cijk_', 'library GEMM'), ('linear_', 'dense f16-split GEMM'), ('dense_norm', 'dense + GroupNorm fused'), ('gn_chain_apply', 'GroupNorm apply (pending forms)'),
+       ('gn_', 'GroupNorm'), ('kpconv_gather', 'KPConv gather (G form)'),
        ('kpconv_fused', 'KPConv fused'), ('kpconv_neighbor_table', 'KPConv neighbour table'), ('kpconv_', 'KPConv other'), ('rpe_bias', 'RPE logits'), ('attention_kernel', 'attention'), ('cross_eq', 'cross_eq'),
        ('geo_', 'geo embedding'), ('embedding_table', 'geo embedding'), ('knn3', 'geo embedding'), ('sinkhorn', 'sinkhorn'),
        ('radius_', 'radius search'), ('grid_', 'grid subsample'), ('order_kernel', 'grid subsample'), ('neighbor_max', 'neighbor max'),
@@ -16,5 +17,5 @@ for r in rows:
     tot[key] = tot.get(key, 0.0) + ns
 s = sum(tot.values())
 for k, v in sorted(tot.items(), key=lambda kv: -kv[1]):
-    print('%-20s %7.2f ms/step  %5.1f %%' % (k, v / steps / 1e6, 100 * v / s))
-print('%-20s %7.2f ms/step' % ('total', s / steps / 1e6))
+    print('%-32s %7.2f ms/step  %5.1f %%' % (k, v / steps / 1e6, 100 * v / s))
+print('%-32s %7.2f ms/step' % ('total', s / steps / 1e6))

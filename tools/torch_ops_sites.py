@@ -35,12 +35,13 @@ class Sites(TorchDispatchMode):
         out = func(*args, **(kwargs or {}))
         name = 'aten::' + func.__name__.split('.')[0]
         if name not in SKIP:
-            f, site = sys._getframe(1), '?'
-            while f is not None:
+            f, chain = sys._getframe(1), []
+            while f is not None and len(chain) < 3:
                 fn = f.f_code.co_filename
                 if 'se3et_amd' in fn and 'torch' not in fn.split('se3et_amd')[-1]:
-                    site = '%s:%d' % (fn.split('se3et_amd/')[-1], f.f_lineno); break
+                    chain.append('%s:%d' % (fn.split('se3et_amd/')[-1], f.f_lineno))
                 f = f.f_back
+            site = ' < '.join(chain) if chain else '?' 
             t = out if torch.is_tensor(out) else (out[0] if isinstance(out, (tuple, list)) and out and torch.is_tensor(out[0]) else None)
             on_gpu = any(torch.is_tensor(a) and a.is_cuda for a in list(args) + ([t] if t is not None else []))
             if on_gpu:
