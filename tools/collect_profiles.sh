@@ -1,17 +1,18 @@
 #!/bin/bash
 # Everything under profiles/rNN_* in one GPU call: tools/collect_profiles.sh r03   (writes gpurun_out/profiles_r03/; copy what is to be kept)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; tag=${1:-rXX}; O=$R/gpurun_out/profiles_$tag; mkdir -p $O; cd $R
-python bench.py > $O/${tag}_bench.json 2> $O/bench.err
-python bench.py --batch 1 --no-cpu-baseline --single-pair-steps 0 --train-steps 0 > $O/${tag}_bench_batch1.json 2>> $O/bench.err
-python bench.py --prefetch 0 --no-cpu-baseline --single-pair-steps 0 --train-steps 0 > $O/${tag}_bench_noprefetch.json 2>> $O/bench.err
-python bench.py --variant se3eti_kitti --pair c3_20k --attention-dtype bfloat16 --batch 4 --steps 10 --warmup 3 --no-cpu-baseline --single-pair-steps 0 --train-steps 0 > $O/${tag}_bench_c3_bf16.json 2>> $O/bench.err
-python bench.py --variant se3eti_kitti --pair c3_20k --batch 4 --steps 10 --warmup 3 --no-cpu-baseline --single-pair-steps 0 --train-steps 0 > $O/${tag}_bench_c3_f32.json 2>> $O/bench.err
+timeout 900 python bench.py > $O/${tag}_bench.json 2> $O/bench.err
+timeout 900 python bench.py --batch 1 --no-cpu-baseline --single-pair-steps 0 --train-steps 0 > $O/${tag}_bench_batch1.json 2>> $O/bench.err
+timeout 900 python bench.py --prefetch 0 --no-cpu-baseline --single-pair-steps 0 --train-steps 0 > $O/${tag}_bench_noprefetch.json 2>> $O/bench.err
+timeout 900 python bench.py --variant se3eti_kitti --pair c3_20k --attention-dtype bfloat16 --batch 4 --steps 10 --warmup 3 --no-cpu-baseline --single-pair-steps 0 --train-steps 0 > $O/${tag}_bench_c3_bf16.json 2>> $O/bench.err
+timeout 900 python bench.py --variant se3eti_kitti --pair c3_20k --batch 4 --steps 10 --warmup 3 --no-cpu-baseline --single-pair-steps 0 --train-steps 0 > $O/${tag}_bench_c3_f32.json 2>> $O/bench.err
 tools/prof.sh ${tag} bench.py --no-cpu-baseline --single-pair-steps 0 --train-steps 0 --roofline-quiet-steps 0 > $O/prof.txt 2>&1; cp gpurun_out/${tag}_kernel_stats.csv $O/${tag}_kernel_stats.csv
 tools/prof.sh ${tag}b1 bench.py --batch 1 --no-cpu-baseline --single-pair-steps 0 --train-steps 0 >> $O/prof.txt 2>&1; cp gpurun_out/${tag}b1_kernel_stats.csv $O/${tag}_kernel_stats_batch1.csv
 python tools/step_breakdown.py $O/${tag}_kernel_stats.csv 25 > $O/${tag}_step_breakdown.txt 2>&1
-python tools/micro/kpconv_paths.py 2>&1 | grep -v "amdgpu.ids\|Warning" > $O/${tag}_kpconv_paths.txt
+timeout 300 python tools/micro/kpconv_paths.py 2>&1 | grep -v "amdgpu.ids\|Warning" > $O/${tag}_kpconv_paths.txt
+timeout 300 python tools/micro/dense_norm_shapes.py 2>&1 | grep -v "amdgpu.ids\|Warning" > $O/${tag}_dense_norm_shapes.txt
 for L in 2 5 8; do echo "== KPConv layer $L (tools/micro/kpconv_layer.py $L fused): counters of kpconv_fused_kernel, average per dispatch"; tools/pmc_kernel.sh kpconv_fused_kernel tools/micro/kpconv_layer.py $L fused 3; tail -1 gpurun_out/pmck.log | grep layer; done > $O/${tag}_pmc_kpconv.txt 2>&1
 tools/pmc_passes.sh > $O/${tag}_pmc_attention_raw.txt 2>&1
 for K in rpe_bias_kernel attention_kernel; do echo "== $K (tools/pmc_attention.py: 16 clouds per launch; equivariant and invariant dispatches averaged together)"; tools/pmc_kernel.sh $K tools/pmc_attention.py; done > $O/${tag}_pmc_attention_sq.txt 2>&1
-python tools/train_bench.py --steps 5 --warmup 2 --profile > $O/${tag}_train_bench.txt 2>&1
+timeout 600 python tools/train_bench.py --steps 5 --warmup 2 --profile > $O/${tag}_train_bench.txt 2>&1
 ls -la $O
