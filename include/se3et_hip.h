@@ -67,6 +67,12 @@ int se3_radius_neighbors(const float* q_points, int64_t nq, const float* s_point
                          const int64_t* q_lengths_host, const int64_t* s_lengths_host, int batch, float radius,
                          int limit, int64_t* neighbors, int32_t* max_count, void* stream);
 
+/* Several pairs stacked in one table (se3et_amd/data.py): out (rows, width) = the first `width` columns of full (rows, full_width), with the
+ * columns at and beyond a PAIR's own width set to -1 (pair p = rows [pair_row_ends[p-1], pair_row_ends[p]); a pair run alone keeps
+ * min(limit, its largest neighbour count) columns -- the reference's collate, geotransformer/utils/data.py precompute_data_stack_mode).
+ * HOST arrays, at most 64 pairs. */
+int se3_neighbor_table_trim(const int64_t* full, int64_t rows, int full_width, int width, const int64_t* pair_row_ends_host,
+                            const int* pair_widths_host, int num_pairs, int64_t* out, void* stream);
 /* Uniform-grid variant of se3_radius_neighbors for large supports (identical results).  se3_radius_grid_build bins the
  * support cloud (cells of edge >= radius) into a caller-owned workspace; se3_radius_neighbors_grid then searches any query
  * set against it with the SAME radius.  One grid serves every search sharing support and radius (a stage's neighbour and

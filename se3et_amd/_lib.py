@@ -98,6 +98,7 @@ SIGNATURES = {
     'se3_vgtk_intra_zpconv_fwd': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     'se3_vgtk_intra_zpconv_bwd': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     'se3_grid_subsample_host': (_i32, [_vp, _vp, _i64, _vp, _i32, _f32, _vp, _vp, _vp]),
+    'se3_neighbor_table_trim': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
     'se3_radius_neighbors_host': (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _f32, _i64, _vp, _vp]),
     'se3_log_sinkhorn_fwd': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     'se3_log_sinkhorn_bwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),

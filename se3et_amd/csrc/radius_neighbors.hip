@@ -488,3 +488,50 @@ extern "C" int se3_radius_neighbors_grid(const float* q_points, int64_t nq, cons
   SE3_CHECK_LAUNCH("radius_neighbors_grid");
   return SE3_OK;
 }
+
+// ---- stacked pairs: the neighbour table cut to the width a batch needs, columns past a PAIR's own width marked -1 ----------------------
+// The reference runs one pair per forward and keeps min(limit, that pair's largest count) columns (data.py:96-99 of the reference's
+// collate); with several pairs stacked the table is as wide as the widest pair needs and the surplus columns of the narrower pairs are
+// marked -1 (every consumer skips them; the padding index Ns would select the zero row instead).  One launch per table instead of a
+// column copy and a strided fill per pair.
+namespace {
+constexpr int kTrimMaxPairs = 64;
+struct TrimPairs {
+  int n;
+  long long row_end[kTrimMaxPairs];
+  int width[kTrimMaxPairs];
+};
+__global__ __launch_bounds__(256) void neighbor_table_trim_kernel(const int64_t* __restrict__ full, int64_t rows, int full_width, int width,
+                                                                  TrimPairs P, int64_t* __restrict__ out) {
+  const int64_t total = rows * width;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / width;
+    const int col = (int)(i - row * width);
+    int w = width;
+    for (int p = 0; p < P.n; p++)
+      if (row < P.row_end[p]) {
+        w = P.width[p];
+        break;
+      }
+    out[i] = col < w ? full[row * full_width + col] : -1;
+  }
+}
+}  // namespace
+
+extern "C" int se3_neighbor_table_trim(const int64_t* full, int64_t rows, int full_width, int width, const int64_t* pair_row_ends_host,
+                                       const int* pair_widths_host, int num_pairs, int64_t* out, void* stream) {
+  SE3_REQUIRE(full && out && pair_row_ends_host && pair_widths_host, SE3_ERR_INVALID_ARG, "neighbor_table_trim: null pointer");
+  SE3_REQUIRE(rows >= 0 && width >= 1 && width <= full_width && num_pairs >= 1 && num_pairs <= kTrimMaxPairs, SE3_ERR_UNSUPPORTED,
+              "neighbor_table_trim: rows %lld width %d of %d, %d pairs (max %d)", (long long)rows, width, full_width, num_pairs, kTrimMaxPairs);
+  if (rows == 0) return SE3_OK;
+  TrimPairs P{};
+  P.n = num_pairs;
+  for (int p = 0; p < num_pairs; p++) {
+    P.row_end[p] = pair_row_ends_host[p];
+    P.width[p] = pair_widths_host[p] < width ? pair_widths_host[p] : width;
+  }
+  neighbor_table_trim_kernel<<<(unsigned)(se3_cdiv(rows * width, 256) < 65536 ? se3_cdiv(rows * width, 256) : 65536), 256, 0, (hipStream_t)stream>>>(full, rows, full_width, width, P, out);
+  SE3_CHECK_LAUNCH("neighbor_table_trim");
+  return SE3_OK;
+}
+

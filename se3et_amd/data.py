@@ -63,19 +63,27 @@ def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, 
     stage_of = {'neighbors': lambda k: k, 'subsampling': lambda k: k + 1, 'upsampling': lambda k: k}
     for j, (kind, (full, _)) in enumerate(jobs):
         width = min(full.shape[1], int(counts[j].max()))
-        table = full if width == full.shape[1] else full[:, :width].contiguous()
-        if pair_counts is not None and num_pairs > 1 and min(pair_counts[j]) < width:
+        if pair_counts is not None and 1 < num_pairs <= 64 and min(pair_counts[j]) < width and full.is_cuda:
             # several pairs stacked: a pair processed alone would have kept only min(limit, ITS max count) columns; columns
-            # beyond that are marked -1 (ignored by every consumer, unlike the padding index Ns which selects the zero row)
+            # beyond that are marked -1 (ignored by every consumer, unlike the padding index Ns which selects the zero row): one launch
             q_lengths = lengths_list[stage_of[kind](len(out[kind]))]
-            row = 0
+            ends, row = [], 0
             for p in range(num_pairs):
-                rows_p = int(q_lengths[2 * p] + q_lengths[2 * p + 1])
-                if pair_counts[j][p] < width:
-                    if table is full:
-                        table = full.clone()
-                    table[row:row + rows_p, pair_counts[j][p]:] = -1
-                row += rows_p
+                row += int(q_lengths[2 * p] + q_lengths[2 * p + 1])
+                ends.append(row)
+            table = _ops.neighbor_table_trim(full, width, ends, pair_counts[j])
+        else:
+            table = full if width == full.shape[1] else full[:, :width].contiguous()
+            if pair_counts is not None and num_pairs > 1 and min(pair_counts[j]) < width:
+                q_lengths = lengths_list[stage_of[kind](len(out[kind]))]
+                row = 0
+                for p in range(num_pairs):
+                    rows_p = int(q_lengths[2 * p] + q_lengths[2 * p + 1])
+                    if pair_counts[j][p] < width:
+                        if table is full:
+                            table = full.clone()
+                        table[row:row + rows_p, pair_counts[j][p]:] = -1
+                    row += rows_p
         out[kind].append(table)
     return out
 

@@ -822,6 +822,17 @@ def rpe_bias(qp, qe, emb, eq_emb, num_heads):
     return bias
 
 
+def neighbor_table_trim(full, width, pair_row_ends, pair_widths):
+    """HIP (csrc/radius_neighbors.hip): full (rows, W) int64 -> (rows, width) with the columns past each pair's own width marked -1."""
+    full = _req(full, torch.int64, 'full', 2)
+    rows, W = full.shape
+    out = torch.empty((rows, width), dtype=torch.int64, device=full.device)
+    n = len(pair_row_ends)
+    check(lib().se3_neighbor_table_trim(full.data_ptr(), rows, W, int(width), _i64_array(pair_row_ends), (ctypes.c_int * n)(*[int(w) for w in pair_widths]),
+                                        n, out.data_ptr(), _stream()), 'se3_neighbor_table_trim')
+    return out
+
+
 def to_device(values, dtype, device):
     """Small host list -> device tensor through pinned memory and an asynchronous copy.  `torch.tensor(values, device=...)`
     copies from pageable memory, which makes the host wait for everything queued on the stream (a full synchronisation per

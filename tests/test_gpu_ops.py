@@ -923,3 +923,22 @@ def test_fused_kpconv_edge_shapes(P, Ns, NN, Cin, Cout, box):
         SF.kpconv_inter_so3(torch.randn(Ns, 6, 64).cuda(), *args[1:4], other['kernel_points'].cuda(), other['weights'].cuda(),
                             other['kidx_rot'][:, 0, :].cuda(), other['ridx_rot'][0].cuda(), sigma)
         assert torch.equal(SF.kpconv_inter_so3(*args).cpu(), again)
+
+
+def test_neighbor_table_trim_marks_each_pairs_surplus_columns():
+    """csrc/radius_neighbors.hip: the stacked neighbour table cut to the batch's width with the columns past every PAIR's own width set to
+    -1 -- against the column copy + per-pair strided fill it replaces."""
+    from se3et_amd import ops
+    g = torch.Generator().manual_seed(3)
+    rows_per_pair, W, width = [700, 13, 1200, 1], 38, 31
+    widths = [31, 20, 36, 7]
+    full = torch.randint(0, 5000, (sum(rows_per_pair), W), generator=g).cuda()
+    ends = list(np.cumsum(rows_per_pair))
+    got = ops.neighbor_table_trim(full, width, ends, widths)
+    want = full[:, :width].clone()
+    row = 0
+    for n, w in zip(rows_per_pair, widths):
+        if w < width:
+            want[row:row + n, w:] = -1
+        row += n
+    assert torch.equal(got, want)
