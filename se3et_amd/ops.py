@@ -683,6 +683,28 @@ def kpconv_inter_so3_bwd(grad_out, x, q_pts, s_pts, idx, kernel_points, weights,
     return dx, dw
 
 
+_neighbor_table_cache = {}
+
+
+def _kpconv_neighbor_table(q_pts, s_pts, idx, kernel_points, sigma, P, Ns, NN, stream):
+    """The neighbour table of the fused KPConv (valid neighbours compacted + 16 orbit weights each): a function of the geometry only, so the
+    layers of a pyramid stage (same query / support points, neighbour indices, kernel points and extent) share it.  Kept per stream for the
+    LAST geometry seen -- identified by the tensor objects themselves (weak references: a freed tensor's address can be reused) and their
+    version counters (in-place changes)."""
+    kpd = _req(kernel_points.detach().contiguous(), torch.float32, 'kernel_points', 2)
+    key = (q_pts.data_ptr(), q_pts._version, s_pts.data_ptr(), s_pts._version, idx.data_ptr(), idx._version, kernel_points.data_ptr(),
+           kernel_points._version, float(sigma), P, Ns, NN)
+    hit = _neighbor_table_cache.get(stream.value)
+    if hit is not None and hit[0] == key and all(r() is t for r, t in zip(hit[1], (q_pts, s_pts, idx))):
+        return hit[2]
+    nbytes = lib().se3_kpconv_neighbor_table_bytes(P, NN)
+    tab = torch.empty((nbytes,), dtype=torch.uint8, device=q_pts.device)
+    check(lib().se3_kpconv_neighbor_table(q_pts.data_ptr(), s_pts.data_ptr(), idx.data_ptr(), kpd.data_ptr(), float(sigma), P, Ns, NN,
+                                          tab.data_ptr(), nbytes, stream), 'se3_kpconv_neighbor_table')
+    _neighbor_table_cache[stream.value] = (key, tuple(weakref.ref(t) for t in (q_pts, s_pts, idx)), tab)
+    return tab
+
+
 def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, sigma):
     """Fused matrix-core kernel (csrc/kpconv_mfma.hip) for channel counts that are multiples of (8, 32); otherwise the HIP gather of
     the slot-summed neighbourhood features (csrc/kpconv_so3.hip) + one library GEMM with the (36 Cin, Cout) weight matrix.
@@ -713,11 +735,7 @@ def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, s
         out = torch.empty((P, 6, Cout), dtype=torch.float32, device=x.device)
         # neighbour table (valid neighbours + 16 orbit weights each), then ONE kernel in which producer waves form the f16 hi / lo orbit sums
         # of a 16-point tile on the f32 matrix cores into LDS and consumer waves multiply them on the f16 matrix cores (csrc/kpconv_mfma.hip)
-        kpd = _req(kernel_points.detach().contiguous(), torch.float32, 'kernel_points', 2)
-        nbytes = lib().se3_kpconv_neighbor_table_bytes(P, NN)
-        tab = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
-        check(lib().se3_kpconv_neighbor_table(q_pts.data_ptr(), s_pts.data_ptr(), idx.data_ptr(), kpd.data_ptr(), float(sigma), P, Ns, NN,
-                                              tab.data_ptr(), nbytes, stream), 'se3_kpconv_neighbor_table')
+        tab = _kpconv_neighbor_table(q_pts, s_pts, idx, kernel_points, sigma, P, Ns, NN, stream)
         if path == 'sums':
             # two launches: the orbit sums as tile images in HBM, then the contraction (kept for A/B runs)
             Hs = torch.empty((lib().se3_kpconv_sums_bytes(P, Cin),), dtype=torch.uint8, device=x.device)

@@ -942,3 +942,23 @@ def test_neighbor_table_trim_marks_each_pairs_surplus_columns():
             want[row:row + n, w:] = -1
         row += n
     assert torch.equal(got, want)
+
+
+def test_kpconv_neighbor_table_is_shared_only_for_the_same_geometry():
+    """ops._kpconv_neighbor_table: the layers of a stage reuse the table; other points, an in-place change or another extent rebuild it."""
+    from se3et_amd import ops
+    g = torch.Generator().manual_seed(4)
+    s = torch.rand(300, 3, generator=g).cuda() * 0.2
+    q = s[:120].contiguous()
+    idx = ((q[:, None] - s[None]) ** 2).sum(-1).topk(24, largest=False)[1].contiguous()
+    kp = _conv_state(16, 32, 0.0625)['kernel_points'].cuda()
+    st = ops._stream()
+    t0 = ops._kpconv_neighbor_table(q, s, idx, kp, 0.05, 120, 300, 24, st)
+    assert ops._kpconv_neighbor_table(q, s, idx, kp, 0.05, 120, 300, 24, st) is t0
+    assert ops._kpconv_neighbor_table(q, s, idx, kp, 0.06, 120, 300, 24, st) is not t0
+    t1 = ops._kpconv_neighbor_table(q, s, idx, kp, 0.05, 120, 300, 24, st)
+    q.mul_(1.0001)                                                   # same tensor, new values
+    t2 = ops._kpconv_neighbor_table(q, s, idx, kp, 0.05, 120, 300, 24, st)
+    assert t2 is not t1 and not torch.equal(t2, t1)
+    q2 = q.clone()
+    assert ops._kpconv_neighbor_table(q2, s, idx, kp, 0.05, 120, 300, 24, st) is not t2
