@@ -29,6 +29,7 @@ def _hip(fn):
 # dense layers (library GEMMs) and small glue
 # ---------------------------------------------------------------------------------------------------------------------
 mm = _ops.mm
+shared_tensors = _ops._Shared          # device tensors cached across host threads / streams (see ops._Shared)
 to_device = _ops.to_device
 
 

@@ -117,9 +117,10 @@ class RPEMultiHeadAttention(nn.Module):
             w, b, offs = SF.compose_self_attention_weights(self.proj_q.weight, self.proj_q.bias, self.proj_k.weight,
                                                            self.proj_k.bias, self.proj_p.weight,
                                                            self.proj_eq.weight if use_eq else None, self.num_heads)
-            cache = (key, w, b, offs)
+            cache = (key, SF.shared_tensors(w, b), offs)          # composed on this thread's stream; other streams wait for it on the GPU
             self._stack_cache = cache
-        return cache[1], cache[2], cache[3]
+        w, b = cache[1].get()
+        return w, b, cache[2]
 
     def forward_packed(self, x, starts, lengths, embs, eq_embs):
         """Self attention of several clouds packed row-wise in x ([A,] R, C) (see functional.pack_rows)."""

@@ -50,6 +50,29 @@ LINEAR_F16_MIN_ROWS, LINEAR_F16_MIN_K = 20000, 256
 _linear_piece_cache = {}          # (data_ptr, N, K, device) -> (weakref to the weight tensor, its version counter, pieces)
 
 
+class _Shared:
+    """Device tensors built asynchronously on one stream and read from others (weight pieces, index tables: caches shared by the host
+    threads of `--inflight N`, one HIP stream each).  A reader on another stream waits -- on the GPU, not the host -- for the event recorded
+    behind the kernels that fill them, and tells the caching allocator that its stream uses the memory too.  (Without this the second
+    thread's first GEMM could read weight pieces the first thread's split kernel had not written yet.)"""
+    __slots__ = ('tensors', 'stream', 'event')
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+        self.stream = torch.cuda.current_stream()
+        self.event = torch.cuda.Event()
+        self.event.record(self.stream)
+
+    def get(self):
+        cur = torch.cuda.current_stream()
+        if cur != self.stream:
+            if not self.event.query():
+                cur.wait_event(self.event)
+            for t in self.tensors:
+                t.record_stream(cur)
+        return self.tensors
+
+
 def _linear_weight_pieces(weight, stream):
     """f16 hi / lo MFMA fragments of an (N, K) weight, kept per weight VERSION (torch bumps `_version` on every in-place update: optimizer
     steps, load_state_dict, copy_; call clear_weight_caches() after rewriting weights behind torch's back)."""
@@ -57,13 +80,13 @@ def _linear_weight_pieces(weight, stream):
     key = (weight.data_ptr(), N, K, weight.device.index)
     hit = _linear_piece_cache.get(key)
     if hit is not None and hit[0]() is not None and hit[1] == weight._version:
-        return hit[2]
+        return hit[2].get()[0]
     Wp = torch.empty((lib().se3_linear_weight_pieces_bytes(N, K),), dtype=torch.uint8, device=weight.device)
     check(lib().se3_linear_split_weights_f16(weight.data_ptr(), N, K, Wp.data_ptr(), stream), 'se3_linear_split_weights_f16')
     with _TIMING_LOCK:
         if len(_linear_piece_cache) > 512:
             _linear_piece_cache.clear()
-        _linear_piece_cache[key] = (weakref.ref(weight), weight._version, Wp)
+        _linear_piece_cache[key] = (weakref.ref(weight), weight._version, _Shared(Wp))
     return Wp
 
 
@@ -627,14 +650,14 @@ def _kpconv_weight_pieces(weights, Cin, Cout, stream):
     if cacheable:
         hit = _weight_piece_cache.get(key)
         if hit is not None and hit[0]() is not None and hit[1] == weights._version:
-            return hit[2]
+            return hit[2].get()[0]
     Wp = torch.empty((lib().se3_kpconv_weight_pieces_bytes(Cin, Cout),), dtype=torch.uint8, device=w.device)
     check(lib().se3_kpconv_split_weights_f16(w.data_ptr(), Cin, Cout, Wp.data_ptr(), stream), 'se3_kpconv_split_weights_f16')
     if cacheable:
         with _TIMING_LOCK:
             if len(_weight_piece_cache) > 256:
                 _weight_piece_cache.clear()
-            _weight_piece_cache[key] = (weakref.ref(weights), weights._version, Wp)
+            _weight_piece_cache[key] = (weakref.ref(weights), weights._version, _Shared(Wp))
     return Wp
 
 
@@ -1057,11 +1080,12 @@ def _pair_rows(starts, lengths, device):
         W = max(key[1])
         idx = to_device([s + min(j, n - 1) for s, n in zip(key[0], key[1]) for j in range(W)], torch.int64, device)
         mask = to_device([1.0 if j < n else 0.0 for n in key[1] for j in range(W)], torch.float32, device)
-        hit = (idx, mask.view(1, len(key[1]), W, 1), W)
+        hit = (_Shared(idx, mask), W)
         if len(_pair_rows_cache) > 64:
             _pair_rows_cache.clear()
         _pair_rows_cache[key] = hit
-    return hit
+    idx, mask = hit[0].get()
+    return idx, mask.view(1, len(key[1]), hit[1], 1), hit[1]
 
 
 def _gram_per_pair(x, starts, lengths):

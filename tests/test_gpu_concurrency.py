@@ -1,0 +1,69 @@
+"""Several batches in flight (`bench.py --inflight N`: one host thread + one HIP stream each) against the same batches run one after the
+other.  The model is FRESH (cold weight-piece, index-table and composed-projection caches): the first use is where a cache shared by the
+streams can be read on one stream before the kernels that fill it have run on another (se3et_amd/ops.py: _Shared)."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(cfg, first_pair, pairs):
+    from se3et_amd.data import precompute_data_stack_mode
+    from se3et_amd.synthetic import make_pair
+    b = cfg.backbone
+    clouds = []
+    for j in range(pairs):
+        ref, src, _ = make_pair('c2_5k', index=first_pair + j)
+        clouds += [ref, src]
+    pts = torch.from_numpy(np.concatenate(clouds, 0)).cuda()
+    lens = torch.tensor([len(c) for c in clouds])
+
+    def run():
+        data = precompute_data_stack_mode(pts, lens, b.num_stages, b.init_voxel_size, b.init_radius, cfg.neighbor_limits)
+        data['features'] = torch.ones((pts.shape[0], 1), device='cuda')
+        return data
+    return run
+
+
+@pytest.mark.parametrize('threads', [2, 3])
+def test_batches_in_flight_give_the_sequential_results(threads):
+    from se3et_amd import ops
+    from se3et_amd.batched import forward_pairs
+    from se3et_amd.model import create_model, load_synthetic_weights, make_cfg
+    cfg = make_cfg('se3ete')
+    model = load_synthetic_weights(create_model(cfg)).cuda().eval()
+    ops.clear_weight_caches()
+    builders = [_batch(cfg, 2 * t, 2) for t in range(threads)]
+    streams = [torch.cuda.Stream() for _ in range(threads)]
+    got, failed = [None] * threads, []
+    gate = threading.Barrier(threads)
+
+    def work(t):
+        try:
+            with torch.cuda.stream(streams[t]), torch.no_grad():
+                gate.wait()
+                outs = forward_pairs(model, builders[t]())
+                got[t] = [{k: v.detach().clone() for k, v in o.items() if torch.is_tensor(v)} for o in outs]
+                streams[t].synchronize()
+        except BaseException as e:       # (a thread's exception would otherwise only be printed)
+            failed.append(e)
+
+    pool = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+    for th in pool:
+        th.start()
+    for th in pool:
+        th.join()
+    if failed:
+        raise failed[0]
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        for t in range(threads):
+            want = forward_pairs(model, builders[t]())
+            for p, (g, w) in enumerate(zip(got[t], want)):
+                assert g['ref_corr_points'].shape == w['ref_corr_points'].shape, (t, p)
+                assert torch.equal(g['ref_node_corr_indices'], w['ref_node_corr_indices']), (t, p)
+                for key in ('ref_feats_c', 'src_feats_c', 'estimated_transform'):
+                    assert float((g[key] - w[key]).abs().max()) <= 1e-5 * max(1.0, float(w[key].abs().max())), (t, p, key)
