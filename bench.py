@@ -5,12 +5,13 @@ Workload (BASELINE.json configs[1]): SE3ET-E forward on synthetic 5k+5k point-cl
 name-keyed synthetic weights.  A step = one batch of `--batch` (default 8) registration pairs per rank through ONE forward
 (se3et_amd.batched: clouds stacked ref0, src0, ref1, ...; per pair the results of the single-pair forward): on-GPU stage
 pyramid (grid subsampling + 10 radius searches) -> E2PN backbone -> geometric transformer -> superpoint matching ->
-Sinkhorn -> local-to-global registration.  `--batch 1` runs the reference-shaped single-pair forward.  The raw pairs are
-resident in HBM before the timed region.  Pairs are sharded over ranks with no collective on the data path (weak scaling);
+Sinkhorn -> local-to-global registration.  `--batch 1` runs the reference-shaped single-pair forward.  By default three such
+batches are in flight per GPU (`--inflight`: one host thread + HIP stream each; a batch's host synchronisations and under-filled
+kernels are covered by the other batches).  The raw pairs are resident in HBM before the timed region.  Pairs are sharded over ranks with no collective on the data path (weak scaling);
 the job time is the MAX over ranks; value = pairs / second over all ranks.
 
 Prints ONE JSON line: pairs/s plus a `roofline` object for the RPE self-attention kernels (per-launch HIP events on the
-launch stream, live over the timed region), a `cpu_baseline` object (the CPU oracle timed on this box's host cores) and a
+launch stream, live over the timed region; `roofline.quiet`: the same kernels with one batch in flight), a `cpu_baseline` object (the CPU oracle timed on this box's host cores) and a
 `single_pair` object (the reference-shaped one-pair-per-forward path: pairs/s, kernel launches, host synchronisations).
 
 Multi-GPU: one process per GPU.  Under `torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE in the environment) every process
@@ -111,8 +112,8 @@ def launch_ranks(n, argv, script=None, python=None, poll=0.2, timeout=3600.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=6)
     ap.add_argument('--variant', default='se3ete')
     ap.add_argument('--pair', default='c2_5k')
     ap.add_argument('--cpu-baseline-pairs', type=int, default=2)
@@ -128,13 +129,19 @@ def main():
                     'the interpreter away)')
     ap.add_argument('--attention-dtype', default='float32', choices=['float32', 'bfloat16'], help="'bfloat16': geometric embedding "
                     "stored in bf16 (BASELINE.json configs[2] 'bf16 attention'); the headline metric is quoted on float32")
-    ap.add_argument('--inflight', type=int, default=1, help='pairs in flight per GPU: host threads, one HIP stream each')
+    ap.add_argument('--inflight', type=int, default=None, help='batches in flight per GPU: host threads, one HIP stream each, every one '
+                    'building the pyramid of its batch and running it through the model.  Default 3 for --batch > 1: the forward of a batch has '
+                    'host synchronisations (data-dependent sizes) and under-filled kernels (coarse stages, the transformer) during which '
+                    'another batch keeps the GPU busy: 409-419 against 326-334 pairs/s with one batch in flight + pyramid prefetch (same-box '
+                    'A/B; 2: 380-394, 4: 399-402).  Concurrent kernels share the GPU, so the durations of the timed attention kernels '
+                    'grow: `roofline` reports them as measured in the timed region and `roofline.quiet` with one batch in flight.  Default 1 '
+                    'for --batch 1')
     ap.add_argument('--single-pair-steps', type=int, default=16, help='pairs of the one-pair-per-forward measurement reported as '
                     '`single_pair` (rank 0 at --gpus 1 only; 0 = skip)')
     ap.add_argument('--train-steps', type=int, default=5, help='training steps (fwd + bwd + Adam, one pair each) of the `train_step` object '
                     '(rank 0 at --gpus 1 only; 0 = skip)')
-    ap.add_argument('--roofline-quiet-steps', type=int, default=3, help='extra steps after the timed region without the pyramid prefetch '
-                    'stream, for `roofline.quiet` (0 = skip)')
+    ap.add_argument('--roofline-quiet-steps', type=int, default=3, help='extra steps after the timed region with one batch in flight and no '
+                    'other stream, for `roofline.quiet` (0 = skip)')
     ap.add_argument('--fake-device', action='store_true', help='launcher self-test: gloo rendezvous, sharding, barriers and the '
                     'MAX-over-ranks clock run for real, the step is a host sleep (no GPU needed; tests/test_bench_launch.py)')
     args = ap.parse_args()
@@ -163,6 +170,10 @@ def main():
     model = load_synthetic_weights(create_model(cfg)).to(dev).eval()
     total_steps = args.steps + args.warmup
     PB = max(1, args.batch)
+    if args.inflight is None:
+        args.inflight = 3 if PB > 1 else 1
+    if args.inflight > 1:
+        args.prefetch = 0                 # every in-flight thread builds its own pyramid
     if args.prefetch is None:
         args.prefetch = 1 if PB > 1 else 0
     # this rank's pairs, uploaded before the timed region (global pair index = (step * world + rank) * batch + j); with
@@ -299,9 +310,10 @@ def main():
     timings, se3_ops.KERNEL_TIMINGS = se3_ops.KERNEL_TIMINGS, None
 
     roofline = collect_roofline(se3_lib, timings, args)
-    # The same kernels with nothing else on the GPU: by default the pyramid of the next batch is built on a second stream BESIDE the timed
-    # kernels (--prefetch 1), which lengthens them; a few extra steps without it (after the timed region) give the kernels' own rate.
-    if args.prefetch and args.roofline_quiet_steps > 0:
+    # The same kernels with nothing else on the GPU: by default other batches (--inflight) or the next batch's pyramid (--prefetch 1) run on
+    # other streams BESIDE the timed kernels, which lengthens them; a few extra steps with one batch in flight (after the timed region)
+    # give the kernels' own rate.
+    if (args.prefetch or args.inflight > 1) and args.roofline_quiet_steps > 0:
         se3_ops.KERNEL_TIMINGS = {}
         se3_lib.lib().se3_debug_kernel_timing(1)
         for i in range(args.warmup, min(total_steps, args.warmup + args.roofline_quiet_steps)):
@@ -311,7 +323,11 @@ def main():
         quiet = collect_roofline(se3_lib, quiet_timings, args)
         roofline['quiet'] = {k: quiet[k] for k in ('achieved', 'frac', 'launches', 'avg_us', 'rpe_bias_kernel_avg_us', 'attention_kernel_avg_us',
                                                    'eq_call_avg_us', 'inv_call_avg_us')}
-        roofline['quiet']['note'] = 'same kernels, same shapes, %d extra step(s) after the timed region with the pyramid prefetch stream idle' % args.roofline_quiet_steps
+        roofline['quiet']['note'] = ('same kernels, same shapes, %d extra step(s) after the timed region with ONE batch in flight and no other '
+                                     'stream active: the rate of the kernels themselves' % args.roofline_quiet_steps)
+        roofline['note'] = ('measured in the timed region, where %s share the GPU with the timed kernels (their durations include the '
+                            'time slices of the other streams); `quiet` = the same kernels alone on the GPU'
+                            % ('%d batches in flight' % args.inflight if args.inflight > 1 else "the next batch's pyramid kernels"))
 
     single_pair = None
     if rank == 0 and args.gpus == 1 and args.single_pair_steps > 0:
@@ -337,7 +353,7 @@ def main():
                                    (' = BASELINE.json configs[3]: 64 independent pairs per step over 8 GPUs' if world == 8 and PB == 8 else ''),
                        'ranks_seen': ranks_seen,
                        'variant': args.variant, 'pair_preset': args.pair, 'sharding': 'pairs round-robin over ranks, no collective',
-                       'pairs_per_forward': PB, 'pairs_in_flight_per_gpu': max(1, args.inflight), 'pyramid_prefetch': bool(args.prefetch),
+                       'pairs_per_forward': PB, 'batches_in_flight_per_gpu': max(1, args.inflight), 'pyramid_prefetch': bool(args.prefetch),
                        'attention_dtype': args.attention_dtype},
             'roofline': roofline, 'cpu_baseline': cpu_baseline, 'single_pair': single_pair, 'train_step': train,
         }
