@@ -1108,6 +1108,7 @@ __global__ __launch_bounds__(64 * NW) void cross_eq_apply_stack_kernel(CrossEqAr
 // K-step (lane half h holds keys {0..3, 8..11} + 4 h of every 16), so the transposed values are stored with that permutation and a lane's
 // V fragment is one 16-byte load.  (Entry point and kernel keep their round-2 names, "x6".)
 typedef _Float16 h2x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4r __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void h2_split8(const float (&x)[8], uint4& hi, uint4& lo) {
   h2x8_t h, l;
@@ -1185,36 +1186,44 @@ __global__ __launch_bounds__(256) void cross_eq_apply_stack_x6_kernel(CrossEqArg
     for (int u = 0; u < 4; u++) qf[pc][u] = __builtin_bit_cast(h2x8_t, X.q[pc][(q_off + (int64_t)nq * C + 16 * u + 8 * half) >> 3]);
   const int tiles = (cl.M + 31) >> 5, steps = A * tiles;
   // this thread's share of a tile copy: K: 2 pieces x 32 rows x 8 uint4 = 512 -> 2 per thread; V^T: 2 pieces x 64 rows x 4 uint4 = 512 -> 2
-  uint4 rk[2], rv[2];
-  auto request = [&](int step) {
+  // Three register sets: the tile of step s + 3 is requested at the start of step s and published (written to LDS) at the end of step
+  // s + 2 -- two full steps for the L2 round trip.  With one set (distance 1) a step lasted as long as that round trip (~5 000 cycles for
+  // 24 MFMAs + a 32-key softmax), the kernel was latency bound at 2.25 waves per SIMD.  Requests are unconditional (clamped) so that the
+  // compiler counts them: an `if` around a load turns every later wait into vmcnt(0).
+  u32x4r rk[3][2], rv[3][2];                               // (ext_vector_type: arrays of the HIP uint4 struct end up in scratch)
+  auto request = [&](int step, u32x4r (&rk)[2], u32x4r (&rv)[2]) {
+    step = step < steps ? step : steps - 1;
     const int e = step / tiles, m0 = (step - e * tiles) << 5;
     const int64_t k_off = e * k_piece_sa + (int64_t)cl.k_start * C + h * D;
     const int64_t v_off = e * v_piece_sa + (int64_t)h * D * p.v_rs + cl.k_start + m0;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int row = tid >> 3, q8 = tid & 7;               // piece i: 32 rows x 8 uint4
-      rk[i] = X.k[i][(k_off + (int64_t)min(m0 + row, cl.M - 1) * C + 8 * q8) >> 3];
+      rk[i] = __builtin_bit_cast(u32x4r, X.k[i][(k_off + (int64_t)min(m0 + row, cl.M - 1) * C + 8 * q8) >> 3]);
       const int vrow = tid >> 2, q4 = tid & 3;              // piece i: 64 rows x 4 uint4
-      rv[i] = X.v[i][(v_off + (int64_t)vrow * p.v_rs + 8 * q4) >> 3];
+      rv[i] = __builtin_bit_cast(u32x4r, X.v[i][(v_off + (int64_t)vrow * p.v_rs + 8 * q4) >> 3]);
     }
   };
-  auto publish = [&](int buf) {
+  auto publish = [&](int buf, const u32x4r (&rk)[2], const u32x4r (&rv)[2]) {
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-      ktile[buf][i][tid >> 3][tid & 7] = rk[i];
-      vtile[buf][i][tid >> 2][tid & 3] = rv[i];
+      ktile[buf][i][tid >> 3][tid & 7] = __builtin_bit_cast(uint4, rk[i]);
+      vtile[buf][i][tid >> 2][tid & 3] = __builtin_bit_cast(uint4, rv[i]);
     }
   };
-  request(0);
-  publish(0);
+  request(0, rk[0], rv[0]);
+  publish(0, rk[0], rv[0]);
+  request(1, rk[1], rv[1]);
+  request(2, rk[2], rv[2]);
   __syncthreads();
   FlashState<D> tot, st;
   flash_init(tot);
   flash_init(st);
-  for (int step = 0; step < steps; step++) {
+  // one step; RS: the register set that is free now (tile step + 3 goes there), PS: the set holding tile step + 1
+  auto one_step = [&](int step, u32x4r (&rk_req)[2], u32x4r (&rv_req)[2], const u32x4r (&rk_pub)[2], const u32x4r (&rv_pub)[2]) {
     const int buf = step & 1;
     const int e = step / tiles, tile = step - e * tiles, m0 = tile << 5;
-    if (step + 1 < steps) request(step + 1);                 // block-uniform
+    request(step + 3, rk_req, rv_req);
     if (active) {
       // two accumulators, consecutive MFMAs alternate between them
       f32x16 s, s2;
@@ -1290,8 +1299,13 @@ __global__ __launch_bounds__(256) void cross_eq_apply_stack_x6_kernel(CrossEqArg
         flash_init(st);
       }
     }
-    if (step + 1 < steps) publish(buf ^ 1);                   // its readers finished before the barrier that ended the previous step
+    publish(buf ^ 1, rk_pub, rv_pub);                          // its readers finished before the barrier that ended the previous step
     __syncthreads();
+  };
+  for (int step = 0; step < steps; step += 3) {                // set of tile t = t % 3 (tile 0 went through set 0 above)
+    one_step(step, rk[0], rv[0], rk[1], rv[1]);
+    if (step + 1 < steps) one_step(step + 1, rk[1], rv[1], rk[2], rv[2]);
+    if (step + 2 < steps) one_step(step + 2, rk[2], rv[2], rk[0], rv[0]);
   }
   if (!active) return;
   // o[dt][r] = O^T[d = 32 dt + (r & 3) + 8 (r >> 2) + 4 half][query c32]: four consecutive d per (dt, g) -> one float4 per lane
