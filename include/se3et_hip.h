@@ -354,6 +354,9 @@ int se3_cross_eq_apply(const float* q, const float* k, const float* vt, const fl
  * (pair, a, e) and the statistics launch is skipped (mean_h S = (scale/H) q_a[n].k_e[m] over all C channels, so the caller can
  * get the sums from two Gram matrices per pair: (scale/H)^2 <Q_a^T Q_a, K_e^T K_e>_F -- 3.5x fewer flops, library GEMMs); mix (num_pairs, A, A); weights (num_pairs, A*A) for mode 0 / (num_pairs, num_rotations) for mode 1; out (A, Rq, C) in
  * the packing of q.  num_pairs <= 16. */
+/* The sums_given statistics of the stack mode from per-pair Gram matrices: out (num_pairs, A, A) = factor * <gq[a, p], gk[e, p]>_F, gq / gk
+ * (A, num_pairs, elements) contiguous (elements = C * C, a multiple of 4). */
+int se3_gram_frobenius(const float* gq, const float* gk, int A, int num_pairs, int64_t elements, float factor, float* out, void* stream);
 int se3_cross_eq_stack_fwd(const float* q, const float* k, const float* vt, const int64_t* q_starts, const int64_t* q_lengths,
                            const int64_t* k_starts, const int64_t* k_lengths, int num_pairs, int A, int C, int H,
                            int64_t q_anchor_stride, int64_t k_anchor_stride, int v_row_stride, int64_t v_anchor_stride, int mode,

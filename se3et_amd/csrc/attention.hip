@@ -1754,6 +1754,40 @@ extern "C" int se3_cross_eq_mix(const float* partial, int num_partials_per_pair,
   return SE3_OK;
 }
 
+// <Gq[a, p], Gk[e, p]>_F for every (pair p, query anchor a, key anchor e): the anchor-pair statistics of the equivariant cross attention from
+// the per-pair Gram matrices (se3_cross_eq_stack_fwd, sums_given).  gq, gk (A, P, n) contiguous; out (P, A, A) = factor * the inner products.
+// One workgroup per (p, a, e): 2 n floats from L2 (each Gram matrix is read by A workgroups).  The library's batched GEMM took 51 us for
+// this (A x n) . (n x A) shape with n = 65 536.
+namespace {
+__global__ __launch_bounds__(256) void gram_frobenius_kernel(const float* __restrict__ gq, const float* __restrict__ gk, int A, int P, int64_t n,
+                                                             float factor, float* __restrict__ out) {
+  __shared__ float red[4];
+  const int e = blockIdx.x % A, a = (blockIdx.x / A) % A, p = blockIdx.x / (A * A);
+  const float4* x = reinterpret_cast<const float4*>(gq + ((size_t)a * P + p) * n);
+  const float4* y = reinterpret_cast<const float4*>(gk + ((size_t)e * P + p) * n);
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < (n >> 2); i += 256) {
+    const float4 u = x[i], v = y[i];
+    acc += u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
+  }
+  acc = se3_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1] + red[2] + red[3]) * factor;
+}
+}  // namespace
+
+extern "C" int se3_gram_frobenius(const float* gq, const float* gk, int A, int num_pairs, int64_t elements, float factor, float* out,
+                                  void* stream) {
+  SE3_REQUIRE(gq && gk && out, SE3_ERR_INVALID_ARG, "gram_frobenius: null pointer");
+  SE3_REQUIRE(A >= 1 && num_pairs >= 1 && elements >= 4 && elements % 4 == 0 && ((uintptr_t)gq & 15) == 0 && ((uintptr_t)gk & 15) == 0,
+              SE3_ERR_UNSUPPORTED, "gram_frobenius: A %d pairs %d elements %lld (a multiple of 4, 16-byte aligned)", A, num_pairs,
+              (long long)elements);
+  gram_frobenius_kernel<<<(unsigned)(num_pairs * A * A), 256, 0, (hipStream_t)stream>>>(gq, gk, A, num_pairs, elements, factor, out);
+  SE3_CHECK_LAUNCH("gram_frobenius");
+  return SE3_OK;
+}
+
 extern "C" int se3_cross_eq_stack_fwd(const float* q, const float* k, const float* vt, const int64_t* q_starts,
                                       const int64_t* q_lengths, const int64_t* k_starts, const int64_t* k_lengths, int num_pairs,
                                       int A, int C, int H, int64_t q_anchor_stride, int64_t k_anchor_stride, int v_row_stride,

@@ -1092,8 +1092,10 @@ def _gram_per_pair(x, starts, lengths):
     """x (A, R, C) packed rows -> (A, P, C, C): X_p^T X_p over the rows of every pair (library GEMM)."""
     idx, mask, W = _pair_rows(starts, lengths, x.device)
     A, P, C = x.shape[0], len(starts), x.shape[2]
-    win = x.index_select(1, idx).view(A * P, W, C)
-    return torch.bmm((win * mask.view(1, P, W, 1).expand(A, P, W, 1).reshape(A * P, W, 1)).transpose(1, 2), win).view(A, P, C, C)
+    win = x.index_select(1, idx).view(A, P, W, C)
+    win.mul_(mask)                                   # rows past a cloud's length -> 0 (the mask is 0 / 1: masking both operands is masking one)
+    win = win.view(A * P, W, C)
+    return torch.bmm(win.transpose(1, 2), win).view(A, P, C, C)
 
 
 def cross_attention_eq_stack(q, k, vt, q_starts, q_lengths, k_starts, k_lengths, num_heads, mode, trace_idx, out):
@@ -1121,7 +1123,8 @@ def cross_attention_eq_stack(q, k, vt, q_starts, q_lengths, k_starts, k_lengths,
     # (A*A, N, M) score pass of se3_cross_eq_stats (vanilla_transformer.py:380-389,425-426 computes the scores themselves)
     f = 1.0 / (math.sqrt(C // int(num_heads)) * int(num_heads))
     gq, gk = _gram_per_pair(q, q_starts, q_lengths), _gram_per_pair(k, k_starts, k_lengths)
-    partial = torch.bmm(gq.view(A, P, C * C).transpose(0, 1), gk.view(A, P, C * C).permute(1, 2, 0)) * (f * f)      # (P, A, A)
+    partial = torch.empty((P, A, A), dtype=torch.float32, device=dev)
+    check(lib().se3_gram_frobenius(gq.data_ptr(), gk.data_ptr(), A, P, C * C, f * f, partial.data_ptr(), _stream()), 'se3_gram_frobenius')
     mix = torch.empty((P, A, A), dtype=torch.float32, device=dev)
     weights = torch.empty((P, A * A if mode == 'a_soft' else R), dtype=torch.float32, device=dev)
     if CROSS_EQ_BF16X6 and q.stride(1) == C and k.stride(1) == C and q.stride(2) == 1 and k.stride(2) == 1 and vt.stride(2) == 1:
