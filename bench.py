@@ -374,10 +374,13 @@ def collect_roofline(se3_lib, timings, args):
     se3_lib.lib().se3_debug_kernel_timing(0)
     n_ev = se3_lib.lib().se3_debug_kernel_timing_collect(us, tags, cap)
     per_call, i = [], 0
-    while i < n_ev:                                   # tag 1 (logits kernel) is always followed by its tag-2 attention launch
-        if tags[i] == 1 and i + 1 < n_ev and tags[i + 1] == 2:
-            per_call.append((us[i], us[i + 1]))
-            i += 2
+    while i < n_ev:                                   # tag 1 (logits kernel) is always followed by its attention launch: tag 2, with the
+        j, pre = i + 1, 0.0                           # K / V^T split in front of it (tag 3) when the f16 form runs -- counted with it
+        if tags[i] == 1 and j < n_ev and tags[j] == 3:
+            pre, j = us[j], j + 1
+        if tags[i] == 1 and j < n_ev and tags[j] == 2:
+            per_call.append((us[i], pre + us[j]))
+            i = j + 1
         else:
             i += 1                                    # attention launches of the cross-attention layers
     if len(per_call) != len(calls):
@@ -394,7 +397,7 @@ def collect_roofline(se3_lib, timings, args):
     if args.attention_dtype != 'float32':
         traffic = None                 # the PMC passes were taken on the f32 kernels
     return {
-        'kernel': 'RPE self-attention call = rpe_bias_kernel + attention_kernel (all clouds of the batch per launch)',
+        'kernel': 'RPE self-attention call = rpe_bias_kernel + attention kernel incl. its K / V^T split (all clouds of the batch per launch)',
         'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None if traffic is None else int(traffic),
         'traffic_source': 'bytes per call; PMC FETCH_SIZE(x2 on the streaming kernel)+WRITE_SIZE per algorithmic byte from '

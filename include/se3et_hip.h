@@ -306,7 +306,13 @@ int se3_attention_stack_fwd(const float* q, const float* k, const float* vt, con
                             const int64_t* q_lengths, const int64_t* k_starts, const int64_t* k_lengths,
                             const int64_t* bias_offsets, int num_clouds, int num_anchors, int C, int H, int q_row_stride,
                             int k_row_stride, int v_row_stride, int64_t q_anchor_stride, int64_t k_anchor_stride,
-                            int64_t v_anchor_stride, int64_t out_anchor_stride, float scale, float* out, void* stream);
+                            int64_t v_anchor_stride, int64_t out_anchor_stride, float scale, float* out, void* kv_pieces_workspace,
+                            size_t kv_pieces_bytes, void* stream);
+/* kv_pieces_workspace (may be NULL): se3_attention_kv_pieces_bytes(anchors, max_c(k_starts[c] + k_lengths[c]), C, v_row_stride) bytes, 16-byte
+ * aligned, one per stream.  With it (head dimension 64, k_starts multiples of 16, v_row_stride a multiple of 16) k and vt are split once
+ * into f16 hi / lo pieces and both products run on the f16 matrix cores (three products, f32 accumulation: the error of an f32 product);
+ * without it, or for other shapes, on the f32 matrix cores. */
+size_t se3_attention_kv_pieces_bytes(int num_anchors, int64_t key_rows, int C, int v_row_stride);
 
 /* The whole stack-mode RPE self-attention call (the reference's RPEMultiHeadAttention.forward up to the output projection,
  * rpe_transformer.py:39-131, for all clouds of the pair): se3_rpe_bias_stack_fwd into `logits_workspace` followed by
@@ -317,7 +323,8 @@ int se3_rpe_self_attention_stack_fwd(const float* q, const float* k, const float
                                      int row_stride, int64_t anchor_stride, int v_row_stride, int64_t v_anchor_stride,
                                      const float* const* emb_ptrs, const float* const* eq_ptrs, const int64_t* starts,
                                      const int64_t* lengths, int num_clouds, int num_anchors, int C, int H,
-                                     float* logits_workspace, int64_t out_anchor_stride, float* out, void* stream);
+                                     float* logits_workspace, int64_t out_anchor_stride, float* out, void* kv_pieces_workspace,
+                                     size_t kv_pieces_bytes, void* stream);
 
 /* bf16 geometric embedding (BASELINE.json configs[2]: "bf16 attention"): the same two calls with emb_ptrs[c] -> (N_c, M_c, C)
  * bfloat16 (16-byte aligned, C a multiple of 32), which halves the N*M*C term of the call's HBM bytes.  Queries, keys, values,
@@ -331,7 +338,8 @@ int se3_rpe_self_attention_stack_bf16_fwd(const float* q, const float* k, const 
                                           int row_stride, int64_t anchor_stride, int v_row_stride, int64_t v_anchor_stride,
                                           const uint16_t* const* emb_ptrs, const float* const* eq_ptrs, const int64_t* starts,
                                           const int64_t* lengths, int num_clouds, int num_anchors, int C, int H,
-                                          float* logits_workspace, int64_t out_anchor_stride, float* out, void* stream);
+                                          float* logits_workspace, int64_t out_anchor_stride, float* out, void* kv_pieces_workspace,
+                                          size_t kv_pieces_bytes, void* stream);
 
 /* ---- D4/D5: anchor-equivariant cross attention (MultiHeadAttentionEQ, 'a_soft' / 'r_soft') ----------------------------
  * Replaces geotransformer/modules/transformer/vanilla_transformer.py:247-476,506-577,751-870.  q (A, N, C), k/v (A, M, C).

@@ -59,9 +59,10 @@ SIGNATURES = {
     'se3_attention_fwd': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _f32, _vp, _vp]),
     'se3_rpe_bias_stack_fwd': (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     'se3_rpe_bias_stack_bf16_fwd': (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
-    'se3_attention_stack_fwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f32, _vp, _vp]),
-    'se3_rpe_self_attention_stack_fwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp]),
-    'se3_rpe_self_attention_stack_bf16_fwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp]),
+    'se3_attention_kv_pieces_bytes': (_sz, [_i32, _i64, _i32, _i32]),
+    'se3_attention_stack_fwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _sz, _vp]),
+    'se3_rpe_self_attention_stack_fwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
+    'se3_rpe_self_attention_stack_bf16_fwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
     'se3_cross_eq_stats': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     'se3_cross_eq_mix': (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     'se3_cross_eq_x6_workspace_bytes': (_sz, [_i32, _i64, _i64, _i32, _i32]),

@@ -1224,7 +1224,7 @@ __global__ __launch_bounds__(256) void cross_eq_apply_stack_x6_kernel(CrossEqArg
     const int buf = step & 1;
     const int e = step / tiles, tile = step - e * tiles, m0 = tile << 5;
     request(step + 3, rk_req, rv_req);
-    if (active) {
+    if (active && step < steps) {
       // two accumulators, consecutive MFMAs alternate between them
       f32x16 s, s2;
 #pragma unroll
@@ -1302,10 +1302,11 @@ __global__ __launch_bounds__(256) void cross_eq_apply_stack_x6_kernel(CrossEqArg
     publish(buf ^ 1, rk_pub, rv_pub);                          // its readers finished before the barrier that ended the previous step
     __syncthreads();
   };
+  // (unconditional three-step body: see attention_x6_kernel; steps = A * tiles, padded steps fall on key anchor e >= A and are skipped whole)
   for (int step = 0; step < steps; step += 3) {                // set of tile t = t % 3 (tile 0 went through set 0 above)
     one_step(step, rk[0], rv[0], rk[1], rv[1]);
-    if (step + 1 < steps) one_step(step + 1, rk[1], rv[1], rk[2], rv[2]);
-    if (step + 2 < steps) one_step(step + 2, rk[2], rv[2], rk[0], rv[0]);
+    one_step(step + 1, rk[1], rv[1], rk[2], rv[2]);
+    one_step(step + 2, rk[2], rv[2], rk[0], rv[0]);
   }
   if (!active) return;
   // o[dt][r] = O^T[d = 32 dt + (r & 3) + 8 (r >> 2) + 4 half][query c32]: four consecutive d per (dt, g) -> one float4 per lane
@@ -1587,6 +1588,242 @@ extern "C" int se3_rpe_bias_stack_bf16_fwd(const float* qp, const float* qe, int
                         q_lengths, k_lengths, bias_offsets, num_clouds, C, AH, H, bias, stream, true);
 }
 
+// ---- RPE / plain attention of a stack of clouds on the f16 matrix cores (head dimension 64) ---------------------------------------------
+// attention_kernel above multiplies on the f32 matrix cores (57 % of their peak at A = 6: 160 us per call) and its f16-split form
+// (MODE 4) splits every K and V^T tile again in every workgroup that reads it -- vector-ALU bound, no gain.  Here K and V^T are split ONCE
+// per call (attn_split_kv_kernel: the pieces have the byte size of the f32 tensors) and the kernel has the structure of
+// cross_eq_apply_stack_x6_kernel: 4 waves = 4 consecutive 32-query tiles of one (cloud, anchor, head), every 32-key K / V^T tile goes
+// global -> registers -> LDS THREE steps ahead and is read by the four waves from LDS, the logits tile of a wave (16 floats per lane, written
+// by rpe_bias_kernel on other XCDs: a trip to the memory side) is requested three steps ahead as well.  No merge over waves: a wave owns
+// its queries.  S = (q.k [+ bias]) * scale, online softmax, P split into f16 hi / lo in registers, three products each for q.k and P.v.
+__global__ __launch_bounds__(256) void attn_split_kv_kernel(const float* __restrict__ k, int k_rs, int64_t k_sa, const float* __restrict__ vt, int v_rs,
+                                                            int64_t v_sa, int A, int64_t R, int C, uint4* __restrict__ outk, uint4* __restrict__ outv) {
+  const int64_t kper = R * (C / 8), ktot = A * kper, vblocks = v_rs / 16, vper = (int64_t)C * vblocks, vtot = A * vper;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ktot + vtot; i += (int64_t)gridDim.x * 256) {
+    if (i < ktot) {
+      const int64_t a = i / kper, rem = i - a * kper, row = rem / (C / 8), c8 = rem - row * (C / 8);
+      const float* src = k + a * k_sa + row * k_rs + c8 * 8;
+      const float4 lo = ld4(src), hi = ld4(src + 4);
+      const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      uint4 p1, p2;
+      h2_split8(v, p1, p2);
+      outk[i] = p1;
+      outk[ktot + i] = p2;
+    } else {
+      const int64_t j = i - ktot, a = j / vper, rem = j - a * vper, row = rem / vblocks, blk = rem - row * vblocks;
+      const float* src = vt + a * v_sa + row * v_rs + blk * 16;
+      const float4 q0 = ld4(src), q1 = ld4(src + 4), q2 = ld4(src + 8), q3 = ld4(src + 12);
+      const float lo[8] = {q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, q2.z, q2.w};      // keys 0..3, 8..11
+      const float hi[8] = {q1.x, q1.y, q1.z, q1.w, q3.x, q3.y, q3.z, q3.w};      // keys 4..7, 12..15
+      uint4 a1, a2, b1, b2;
+      h2_split8(lo, a1, a2);
+      h2_split8(hi, b1, b2);
+      outv[2 * j] = a1; outv[2 * j + 1] = b1;
+      outv[2 * (vtot + j)] = a2; outv[2 * (vtot + j) + 1] = b2;
+    }
+  }
+}
+
+struct AttnPieces { const uint4 *k[2], *v[2]; };
+
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(256) void attention_x6_kernel(AttnArgs p, AttnPieces X, int64_t k_piece_sa, int64_t v_piece_sa) {
+  constexpr int D = 64;
+  __shared__ uint4 ktile[2][2][32][kX6KRow];
+  __shared__ uint4 vtile[2][2][64][kX6VRow];
+  const int A = p.A, C = p.C;
+  const int ci = blockIdx.z / A, a = blockIdx.z - ci * A;
+  const StackCloud cl = stack_pick(p.S, ci);
+  const int h = blockIdx.y;
+  if (blockIdx.x * 128 >= cl.N) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, c32 = lane & 31;
+  const int n0 = blockIdx.x * 128 + wave * 32;
+  const bool active = n0 < cl.N;                            // (inactive waves still help with the tile copies)
+  const int nq = min(n0 + c32, cl.N - 1);
+  h2x8_t qf[2][4];
+  {
+    const float* qr = p.q + a * p.q_sa + ((size_t)cl.q_start + nq) * p.q_rs + h * D + 8 * half;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const float4 lo = ld4(qr + 16 * u), hi = ld4(qr + 16 * u + 4);
+      const float v8[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      uint4 p1, p2;
+      h2_split8(v8, p1, p2);
+      qf[0][u] = __builtin_bit_cast(h2x8_t, p1);
+      qf[1][u] = __builtin_bit_cast(h2x8_t, p2);
+    }
+  }
+  const int steps = (cl.M + 31) >> 5;
+  const int64_t k_off = a * k_piece_sa + (int64_t)cl.k_start * C + h * D;
+  const int64_t v_off0 = a * v_piece_sa + (int64_t)h * D * p.v_rs + cl.k_start;
+  const float* bias_row = HAS_BIAS ? p.bias + cl.bias_off + ((size_t)(a * p.H + h) * cl.N + nq) * cl.Mp + 4 * half : nullptr;
+  u32x4r rk[3][2], rv[3][2];
+  f32x4 rb[3][4];
+  auto request = [&](int step, u32x4r (&rk)[2], u32x4r (&rv)[2], f32x4 (&rb)[4]) {
+    step = step < steps ? step : steps - 1;
+    const int m0 = step << 5;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int row = tid >> 3, q8 = tid & 7;               // piece i: 32 rows x 8 uint4
+      rk[i] = __builtin_bit_cast(u32x4r, X.k[i][(k_off + (int64_t)min(m0 + row, cl.M - 1) * C + 8 * q8) >> 3]);
+      const int vrow = tid >> 2, q4 = tid & 3;              // piece i: 64 rows x 4 uint4
+      rv[i] = __builtin_bit_cast(u32x4r, X.v[i][(v_off0 + m0 + (int64_t)vrow * p.v_rs + 8 * q4) >> 3]);
+    }
+    if (HAS_BIAS) {
+#pragma unroll
+      for (int g = 0; g < 4; g++) rb[g] = *reinterpret_cast<const f32x4*>(bias_row + m0 + 8 * g);
+    }
+  };
+  auto publish = [&](int buf, const u32x4r (&rk)[2], const u32x4r (&rv)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      ktile[buf][i][tid >> 3][tid & 7] = __builtin_bit_cast(uint4, rk[i]);
+      vtile[buf][i][tid >> 2][tid & 3] = __builtin_bit_cast(uint4, rv[i]);
+    }
+  };
+  request(0, rk[0], rv[0], rb[0]);
+  publish(0, rk[0], rv[0]);
+  request(1, rk[1], rv[1], rb[1]);
+  request(2, rk[2], rv[2], rb[2]);
+  __syncthreads();
+  FlashState<D> st;
+  flash_init(st);
+  // one step; *_req: the register set that is free now (tile step + 3 goes there), *_pub: the set holding tile step + 1; bias: this step's
+  auto one_step = [&](int step, u32x4r (&rk_req)[2], u32x4r (&rv_req)[2], f32x4 (&rb_req)[4], const u32x4r (&rk_pub)[2],
+                      const u32x4r (&rv_pub)[2]) {
+    const int buf = step & 1, m0 = step << 5;
+    f32x4 b4[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) b4[g] = HAS_BIAS ? rb_req[g] : f32x4{0.f, 0.f, 0.f, 0.f};   // (this step's logits sit in the set about to be refilled)
+    request(step + 3, rk_req, rv_req, rb_req);
+    if (active) {
+      f32x16 s, s2;
+#pragma unroll
+      for (int r = 0; r < 16; r++) s[r] = s2[r] = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        h2x8_t kf[2];
+#pragma unroll
+        for (int pc = 0; pc < 2; pc++) kf[pc] = __builtin_bit_cast(h2x8_t, ktile[buf][pc][c32][2 * u + half]);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], qf[0][u], s, 0, 0, 0);
+        s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[1][u], s2, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[0][u], s, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) s[r] += s2[r];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int key = m0 + 8 * g + 4 * half + j;
+          float val = (s[4 * g + j] + b4[g][j]) * p.scale;
+          val = key < cl.M ? val : -INFINITY;
+          s[4 * g + j] = val;
+          mx = fmaxf(mx, val);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(st.m, mx);
+      const float alpha = __expf(st.m - m_new);
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        s[r] = __expf(s[r] - m_new);
+        ps += s[r];
+      }
+      ps += __shfl_xor(ps, 32);
+      st.l = st.l * alpha + ps;
+      st.m = m_new;
+      h2x8_t pb[2][2];
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const float v8[8] = {s[8 * j], s[8 * j + 1], s[8 * j + 2], s[8 * j + 3], s[8 * j + 4], s[8 * j + 5], s[8 * j + 6], s[8 * j + 7]};
+        uint4 p1, p2;
+        h2_split8(v8, p1, p2);
+        pb[0][j] = __builtin_bit_cast(h2x8_t, p1);
+        pb[1][j] = __builtin_bit_cast(h2x8_t, p2);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) st.o[dt][r] *= alpha;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        h2x8_t vf[2][2];
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+          for (int pc = 0; pc < 2; pc++) vf[dt][pc] = __builtin_bit_cast(h2x8_t, vtile[buf][pc][32 * dt + c32][2 * j + half]);
+#define SE3_X6_PV(a_, b_)                                                                                                       \
+  st.o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][a_], pb[b_][j], st.o[0], 0, 0, 0);                                     \
+  st.o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][a_], pb[b_][j], st.o[1], 0, 0, 0);
+        SE3_X6_PV(1, 0) SE3_X6_PV(0, 1) SE3_X6_PV(0, 0)
+#undef SE3_X6_PV
+      }
+    }
+    publish(buf ^ 1, rk_pub, rv_pub);
+    __syncthreads();
+  };
+  // The step count is padded to a multiple of 3 (the padding steps see only masked keys: exp(-inf) = 0, the running maximum is finite after
+  // the first real tile): with `if (step + 1 < steps)` around the second and third step the paths into the loop's back edge carry different
+  // numbers of outstanding loads and the compiler waits vmcnt(0) there -- the full latency of the tile just requested, every third step.
+  for (int step = 0; step < steps; step += 3) {                // set of tile t = t % 3
+    one_step(step, rk[0], rv[0], rb[0], rk[1], rv[1]);
+    one_step(step + 1, rk[1], rv[1], rb[1], rk[2], rv[2]);
+    one_step(step + 2, rk[2], rv[2], rb[2], rk[0], rv[0]);
+  }
+  if (!active) return;
+  const int nrow = n0 + c32;
+  if (nrow < cl.N) {
+    const float inv_l = 1.0f / st.l;
+    float* op = p.out + a * p.o_sa + ((size_t)cl.q_start + nrow) * C + h * D;
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+        *reinterpret_cast<float4*>(op + 32 * dt + 8 * g + 4 * half) =
+            make_float4(st.o[dt][4 * g] * inv_l, st.o[dt][4 * g + 1] * inv_l, st.o[dt][4 * g + 2] * inv_l, st.o[dt][4 * g + 3] * inv_l);
+  }
+}
+
+// K / V^T pieces + the f16 kernel; false = this shape stays on attention_kernel (head dimension other than 64, unaligned rows, no workspace)
+extern "C" size_t se3_attention_kv_pieces_bytes(int num_anchors, int64_t key_rows, int C, int v_row_stride) {
+  if (num_anchors < 1 || key_rows < 1 || C < 8 || v_row_stride < 16) return 0;
+  return (size_t)2 * num_anchors * ((size_t)key_rows * C + (size_t)C * v_row_stride) * sizeof(_Float16) + 256;
+}
+static bool launch_attention_x6(AttnArgs& p, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (ws == nullptr || g_attn_variant == 11 || p.C / p.H != 64 || p.C % 8 || p.v_rs % 16 || p.q_rs % 4 || p.k_rs % 4 ||
+      (reinterpret_cast<uintptr_t>(ws) & 15) || (reinterpret_cast<uintptr_t>(p.q) & 15) || (reinterpret_cast<uintptr_t>(p.k) & 15) ||
+      (reinterpret_cast<uintptr_t>(p.v) & 15) || (p.A > 1 && (p.k_sa == 0 || p.v_sa == 0)))
+    return false;
+  int64_t R = 0;
+  int nmax = 1;
+  for (int c = 0; c < p.S.n; c++) {
+    const StackCloud& cl = p.S.c[c];
+    if (cl.k_start % 16) return false;
+    R = cl.k_start + cl.M > R ? cl.k_start + cl.M : R;
+    nmax = cl.N > nmax ? cl.N : nmax;
+  }
+  if (ws_bytes < se3_attention_kv_pieces_bytes(p.A, R, p.C, p.v_rs)) return false;
+  const int64_t nk = (int64_t)p.A * R * (p.C / 8), nv = (int64_t)p.A * p.C * (p.v_rs / 8);      // uint4 per piece
+  uint4* wk = static_cast<uint4*>(ws);
+  uint4* wv = wk + 2 * nk;
+  const int64_t work = nk + nv / 2;
+  // (tag 3: the prologue of the attention launch that follows -- bench.py adds its time to that launch)
+  launch_kernel(3, attn_split_kv_kernel, dim3((unsigned)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256)), dim3(256), st, p.k, p.k_rs, p.k_sa,
+                p.v, p.v_rs, p.v_sa, p.A, R, p.C, wk, wv);
+  AttnPieces X;
+  for (int pc = 0; pc < 2; pc++) {
+    X.k[pc] = wk + pc * nk;
+    X.v[pc] = wv + pc * nv;
+  }
+  const dim3 grid((unsigned)((nmax + 127) / 128), (unsigned)p.H, (unsigned)(p.S.n * p.A));
+  if (p.bias != nullptr) launch_kernel(2, attention_x6_kernel<true>, grid, dim3(256), st, p, X, (int64_t)R * p.C, (int64_t)p.C * p.v_rs);
+  else launch_kernel(2, attention_x6_kernel<false>, grid, dim3(256), st, p, X, (int64_t)R * p.C, (int64_t)p.C * p.v_rs);
+  return true;
+}
+
 static int launch_attention(AttnArgs& p, hipStream_t st) {
   int qt = 1;
   for (int c = 0; c < p.S.n; c++) qt = (p.S.c[c].N + 31) / 32 > qt ? (p.S.c[c].N + 31) / 32 : qt;
@@ -1650,7 +1887,8 @@ extern "C" int se3_attention_stack_fwd(const float* q, const float* k, const flo
                                        const int64_t* k_lengths, const int64_t* bias_offsets, int num_clouds, int num_anchors,
                                        int C, int H, int q_row_stride, int k_row_stride, int v_row_stride,
                                        int64_t q_anchor_stride, int64_t k_anchor_stride, int64_t v_anchor_stride,
-                                       int64_t out_anchor_stride, float scale, float* out, void* stream) {
+                                       int64_t out_anchor_stride, float scale, float* out, void* kv_pieces_workspace,
+                                       size_t kv_pieces_bytes, void* stream) {
   SE3_REQUIRE(q && k && vt && out && q_starts && q_lengths && k_starts && k_lengths, SE3_ERR_INVALID_ARG,
               "attention_stack: null pointer");
   SE3_REQUIRE((bias == nullptr) == (bias_offsets == nullptr), SE3_ERR_INVALID_ARG,
@@ -1675,6 +1913,14 @@ extern "C" int se3_attention_stack_fwd(const float* q, const float* k, const flo
   p.q_rs = q_row_stride; p.k_rs = k_row_stride; p.v_rs = v_row_stride;
   p.q_sa = q_anchor_stride; p.k_sa = k_anchor_stride; p.v_sa = v_anchor_stride; p.o_sa = out_anchor_stride;
   p.scale = scale;
+  if (launch_attention_x6(p, kv_pieces_workspace, kv_pieces_bytes, (hipStream_t)stream)) {
+    SE3_CHECK_LAUNCH("attention (f16 pieces)");
+    return SE3_OK;
+  }
+  if (launch_attention_x6(p, kv_pieces_workspace, kv_pieces_bytes, (hipStream_t)stream)) {
+    SE3_CHECK_LAUNCH("attention (f16 pieces)");
+    return SE3_OK;
+  }
   return launch_attention(p, (hipStream_t)stream);
 }
 
@@ -1682,8 +1928,8 @@ static int rpe_self_attention_stack(const float* q, const float* k, const float*
                                     int row_stride, int64_t anchor_stride, int v_row_stride, int64_t v_anchor_stride,
                                     const void* const* emb_ptrs, const float* const* eq_ptrs, const int64_t* starts,
                                     const int64_t* lengths, int num_clouds, int num_anchors, int C, int H,
-                                    float* logits_workspace, int64_t out_anchor_stride, float* out, void* stream,
-                                    bool emb_bf16) {
+                                    float* logits_workspace, int64_t out_anchor_stride, float* out, void* kv_pieces_workspace,
+                                    size_t kv_pieces_bytes, void* stream, bool emb_bf16) {
   SE3_REQUIRE(starts && lengths && logits_workspace, SE3_ERR_INVALID_ARG, "rpe_self_attention_stack: null pointer");
   SE3_REQUIRE(num_clouds >= 1 && num_clouds <= kMaxClouds, SE3_ERR_UNSUPPORTED, "rpe_self_attention_stack: %d clouds (1..%d)",
               num_clouds, kMaxClouds);
@@ -1701,7 +1947,7 @@ static int rpe_self_attention_stack(const float* q, const float* k, const float*
   if (rc != SE3_OK) return rc;
   return se3_attention_stack_fwd(q, k, vt, logits_workspace, starts, lengths, starts, lengths, offsets, num_clouds, num_anchors,
                                  C, H, row_stride, row_stride, v_row_stride, anchor_stride, anchor_stride, v_anchor_stride,
-                                 out_anchor_stride, 1.0f / sqrtf((float)(C / H)), out, stream);
+                                 out_anchor_stride, 1.0f / sqrtf((float)(C / H)), out, kv_pieces_workspace, kv_pieces_bytes, stream);
 }
 
 extern "C" int se3_rpe_self_attention_stack_fwd(const float* q, const float* k, const float* vt, const float* qp,
@@ -1709,10 +1955,12 @@ extern "C" int se3_rpe_self_attention_stack_fwd(const float* q, const float* k, 
                                                 int64_t v_anchor_stride, const float* const* emb_ptrs,
                                                 const float* const* eq_ptrs, const int64_t* starts, const int64_t* lengths,
                                                 int num_clouds, int num_anchors, int C, int H, float* logits_workspace,
-                                                int64_t out_anchor_stride, float* out, void* stream) {
+                                                int64_t out_anchor_stride, float* out, void* kv_pieces_workspace, size_t kv_pieces_bytes,
+                                                void* stream) {
   return rpe_self_attention_stack(q, k, vt, qp, qe, row_stride, anchor_stride, v_row_stride, v_anchor_stride,
                                   reinterpret_cast<const void* const*>(emb_ptrs), eq_ptrs, starts, lengths, num_clouds,
-                                  num_anchors, C, H, logits_workspace, out_anchor_stride, out, stream, false);
+                                  num_anchors, C, H, logits_workspace, out_anchor_stride, out, kv_pieces_workspace, kv_pieces_bytes, stream,
+                                  false);
 }
 
 extern "C" int se3_rpe_self_attention_stack_bf16_fwd(const float* q, const float* k, const float* vt, const float* qp,
@@ -1721,11 +1969,12 @@ extern "C" int se3_rpe_self_attention_stack_bf16_fwd(const float* q, const float
                                                      const float* const* eq_ptrs, const int64_t* starts,
                                                      const int64_t* lengths, int num_clouds, int num_anchors, int C, int H,
                                                      float* logits_workspace, int64_t out_anchor_stride, float* out,
-                                                     void* stream) {
+                                                     void* kv_pieces_workspace, size_t kv_pieces_bytes, void* stream) {
   SE3_REQUIRE(C % 32 == 0, SE3_ERR_UNSUPPORTED, "rpe_self_attention_stack_bf16: channels %d not a multiple of 32", C);
   return rpe_self_attention_stack(q, k, vt, qp, qe, row_stride, anchor_stride, v_row_stride, v_anchor_stride,
                                   reinterpret_cast<const void* const*>(emb_ptrs), eq_ptrs, starts, lengths, num_clouds,
-                                  num_anchors, C, H, logits_workspace, out_anchor_stride, out, stream, true);
+                                  num_anchors, C, H, logits_workspace, out_anchor_stride, out, kv_pieces_workspace, kv_pieces_bytes, stream,
+                                  true);
 }
 
 extern "C" int se3_cross_eq_stats(const float* q, const float* k, int A, int N, int M, int C, int H, float scale,

@@ -974,7 +974,8 @@ def attention_stack(q, k, vt, bias, bias_offsets, q_starts, q_lengths, k_starts,
                                             _i64_array(bias_offsets) if bias is not None else None, len(q_starts), A, C, H,
                                             q_rs, k_rs, v_rs, q_sa if Aq > 1 else 0, k_sa if Ak > 1 else 0,
                                             v3.stride(0) if Av > 1 else 0, o3.stride(0) if A > 1 else 0,
-                                            1.0 / math.sqrt(C // H), o3.data_ptr(), _stream()), 'se3_attention_stack_fwd')
+                                            1.0 / math.sqrt(C // H), o3.data_ptr(), *_attention_pieces(A, k_starts, k_lengths, C, v_rs, q3.device),
+                                            _stream()), 'se3_attention_stack_fwd')
     return out
 
 
@@ -1022,13 +1023,33 @@ def rpe_self_attention_stack(proj, offs, vt, embs, eq_embs, starts, lengths, num
             check(entry(col('q'), col('k'), v3.data_ptr(), col('qp'), col('qe') if has_eq else None, rs, sa, v3.stride(1),
                         v3.stride(0) if A > 1 else 0, _ptr_array(embs), _ptr_array(eqs) if has_eq else None, _i64_array(starts),
                         _i64_array(lengths), len(embs), A, C, H, logits.data_ptr(), o3.stride(0) if A > 1 else 0, o3.data_ptr(),
-                        _stream()), 'se3_rpe_self_attention_stack_fwd')
+                        *_attention_pieces(A, starts, lengths, C, v3.stride(1), p3.device), _stream()), 'se3_rpe_self_attention_stack_fwd')
         return out
     check(entry(col('q'), col('k'), v3.data_ptr(), col('qp'), col('qe') if has_eq else None, rs, sa, v3.stride(1),
                 v3.stride(0) if A > 1 else 0, _ptr_array(embs), _ptr_array(eqs) if has_eq else None, _i64_array(starts),
                 _i64_array(lengths), len(embs), A, C, H, logits.data_ptr(), o3.stride(0) if A > 1 else 0, o3.data_ptr(),
-                _stream()), 'se3_rpe_self_attention_stack_fwd')
+                *_attention_pieces(A, starts, lengths, C, v3.stride(1), p3.device), _stream()), 'se3_rpe_self_attention_stack_fwd')
     return out
+
+
+ATTENTION_F16 = True          # False: q.k and P.v on the f32 matrix cores (A/B runs; the f16 hi / lo form has the error of an f32 product)
+
+
+def _attention_pieces(A, k_starts, k_lengths, C, v_row_stride, device):
+    """(workspace pointer, bytes) for the f16 hi / lo pieces of K and V^T of one stack-mode attention call: one buffer per stream."""
+    if not ATTENTION_F16:
+        return None, 0
+    rows = max(int(s) + int(n) for s, n in zip(k_starts, k_lengths))
+    nbytes = lib().se3_attention_kv_pieces_bytes(int(A), rows, int(C), int(v_row_stride))
+    if nbytes == 0:
+        return None, 0
+    stream = _stream()
+    key = (device, stream.value, 'attn')
+    ws = _gn_workspace.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty((max(nbytes, 1 << 22),), dtype=torch.uint8, device=device)
+        _gn_workspace[key] = ws
+    return ws.data_ptr(), ws.numel()
 
 
 def cross_attention(q, k, vt, num_heads):
