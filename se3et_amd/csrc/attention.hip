@@ -1626,9 +1626,10 @@ __global__ __launch_bounds__(256) void attn_split_kv_kernel(const float* __restr
 
 struct AttnPieces { const uint4 *k[2], *v[2]; };
 
-template <bool HAS_BIAS>
-__global__ __launch_bounds__(256) void attention_x6_kernel(AttnArgs p, AttnPieces X, int64_t k_piece_sa, int64_t v_piece_sa) {
+template <bool HAS_BIAS, bool PROF = false>
+__global__ __launch_bounds__(256, HAS_BIAS ? 2 : 3) void attention_x6_kernel(AttnArgs p, AttnPieces X, int64_t k_piece_sa, int64_t v_piece_sa) {
   constexpr int D = 64;
+  long long* prof = nullptr;                                // profiling hook (attention variant 12): 32 clock64() stamps per wave
   __shared__ uint4 ktile[2][2][32][kX6KRow];
   __shared__ uint4 vtile[2][2][64][kX6VRow];
   const int A = p.A, C = p.C;
@@ -1639,6 +1640,8 @@ __global__ __launch_bounds__(256) void attention_x6_kernel(AttnArgs p, AttnPiece
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, c32 = lane & 31;
   const int n0 = blockIdx.x * 128 + wave * 32;
   const bool active = n0 < cl.N;                            // (inactive waves still help with the tile copies)
+  if (PROF && p.prof != nullptr) prof = p.prof + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 32;
+  SE3_STAMP(0)
   const int nq = min(n0 + c32, cl.N - 1);
   h2x8_t qf[2][4];
   {
@@ -1686,6 +1689,7 @@ __global__ __launch_bounds__(256) void attention_x6_kernel(AttnArgs p, AttnPiece
   request(1, rk[1], rv[1], rb[1]);
   request(2, rk[2], rv[2], rb[2]);
   __syncthreads();
+  SE3_STAMP(1)
   FlashState<D> st;
   flash_init(st);
   // one step; *_req: the register set that is free now (tile step + 3 goes there), *_pub: the set holding tile step + 1; bias: this step's
@@ -1696,6 +1700,7 @@ __global__ __launch_bounds__(256) void attention_x6_kernel(AttnArgs p, AttnPiece
 #pragma unroll
     for (int g = 0; g < 4; g++) b4[g] = HAS_BIAS ? rb_req[g] : f32x4{0.f, 0.f, 0.f, 0.f};   // (this step's logits sit in the set about to be refilled)
     request(step + 3, rk_req, rv_req, rb_req);
+    if (PROF && step < 5) { SE3_STAMP(2 + 5 * step) }
     if (active) {
       f32x16 s, s2;
 #pragma unroll
@@ -1723,6 +1728,7 @@ __global__ __launch_bounds__(256) void attention_x6_kernel(AttnArgs p, AttnPiece
           mx = fmaxf(mx, val);
         }
       }
+      if (PROF && step < 5) { SE3_STAMP(3 + 5 * step) }
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       const float m_new = fmaxf(st.m, mx);
       const float alpha = __expf(st.m - m_new);
@@ -1744,6 +1750,7 @@ __global__ __launch_bounds__(256) void attention_x6_kernel(AttnArgs p, AttnPiece
         pb[0][j] = __builtin_bit_cast(h2x8_t, p1);
         pb[1][j] = __builtin_bit_cast(h2x8_t, p2);
       }
+      if (PROF && step < 5) { SE3_STAMP(4 + 5 * step) }
 #pragma unroll
       for (int dt = 0; dt < 2; dt++)
 #pragma unroll
@@ -1762,8 +1769,10 @@ __global__ __launch_bounds__(256) void attention_x6_kernel(AttnArgs p, AttnPiece
 #undef SE3_X6_PV
       }
     }
+    if (PROF && step < 5) { SE3_STAMP(5 + 5 * step) }
     publish(buf ^ 1, rk_pub, rv_pub);
     __syncthreads();
+    if (PROF && step < 5) { SE3_STAMP(6 + 5 * step) }
   };
   // The step count is padded to a multiple of 3 (the padding steps see only masked keys: exp(-inf) = 0, the running maximum is finite after
   // the first real tile): with `if (step + 1 < steps)` around the second and third step the paths into the loop's back edge carry different
@@ -1773,6 +1782,7 @@ __global__ __launch_bounds__(256) void attention_x6_kernel(AttnArgs p, AttnPiece
     one_step(step + 1, rk[1], rv[1], rb[1], rk[2], rv[2]);
     one_step(step + 2, rk[2], rv[2], rb[2], rk[0], rv[0]);
   }
+  SE3_STAMP(30)
   if (!active) return;
   const int nrow = n0 + c32;
   if (nrow < cl.N) {
@@ -1819,7 +1829,10 @@ static bool launch_attention_x6(AttnArgs& p, void* ws, size_t ws_bytes, hipStrea
     X.v[pc] = wv + pc * nv;
   }
   const dim3 grid((unsigned)((nmax + 127) / 128), (unsigned)p.H, (unsigned)(p.S.n * p.A));
-  if (p.bias != nullptr) launch_kernel(2, attention_x6_kernel<true>, grid, dim3(256), st, p, X, (int64_t)R * p.C, (int64_t)p.C * p.v_rs);
+  if (g_attn_variant == 12 && p.bias != nullptr) {
+    p.prof = g_attn_prof;
+    launch_kernel(2, attention_x6_kernel<true, true>, grid, dim3(256), st, p, X, (int64_t)R * p.C, (int64_t)p.C * p.v_rs);
+  } else if (p.bias != nullptr) launch_kernel(2, attention_x6_kernel<true>, grid, dim3(256), st, p, X, (int64_t)R * p.C, (int64_t)p.C * p.v_rs);
   else launch_kernel(2, attention_x6_kernel<false>, grid, dim3(256), st, p, X, (int64_t)R * p.C, (int64_t)p.C * p.v_rs);
   return true;
 }
