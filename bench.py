@@ -34,10 +34,11 @@ sys.path.insert(0, ROOT)
 # HBM traffic of one RPE self-attention call relative to its algorithmic bytes, from the rocprofv3 PMC passes committed as
 # profiles/r03_pmc_attention.csv (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of tools/pmc_attention.py on the stack-mode
 # kernels at the bench shape, 16 clouds per launch; gfx950 correction: FETCH_SIZE x2 for the 16-B/lane streaming reads of
-# rpe_bias_kernel, attention_kernel counters raw).  Counters cannot be read inside this process, so the ratio of that run is applied:
-#   eq  call: (2*1311893.3 + 162943.5 + 202416.0 + 35277.9) KiB = 3097.0 MB  vs 2549.0 MB algorithmic
-#   inv call: (2*1088452.0 +  25734.1 +  33736.0 +  5861.9) KiB = 2296.0 MB  vs 2222.9 MB algorithmic
-PMC_TRAFFIC_RATIO = {'eq': 3097.0 / 2549.0, 'inv': 2296.0 / 2222.9}
+# rpe_bias_kernel and attn_split_kv_kernel, attention kernel counters raw).  Counters cannot be read inside this process, so the ratio of that run is applied:
+#   eq  call: (2*1310930.1 + 2*37008.9 + 237874.0 + 202416.0 + 70645.9 + 35140.7) KiB = 3319.8 MB  vs 2549.0 MB algorithmic
+#   inv call: (2*1088284.6 + 2*5933.5  +  38268.5 +  33736.0 + 11774.0 +  5856.0) KiB = 2332.7 MB  vs 2222.9 MB algorithmic
+# (logits kernel, K / V^T split, attention kernel: FETCH + WRITE; x2 on the two streaming readers)
+PMC_TRAFFIC_RATIO = {'eq': 3319.8 / 2549.0, 'inv': 2332.7 / 2222.9}
 PMC_TRAFFIC_FILE = 'profiles/r03_pmc_attention.csv'
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s is achievable
 
