@@ -875,10 +875,23 @@ extern "C" int se3_kpconv_so3_gather_sums(const float* x, const void* table, int
 
 // KPConvInterSO3.forward (blocks_epn.py:454-546) after se3_kpconv_neighbor_table: gather + contraction in one kernel.
 // Few tiles (one pair per forward, the coarse stages): the input-channel chunks of a tile are split over `splits` workgroups.
+// One workgroup per compute unit is resident (12 waves, 149 KB of LDS), so a launch runs in ceil(workgroups / 256) rounds, and a workgroup
+// lasts (chunks / z + 3) steps when the input channels are split over z workgroups (two steps of pipeline fill, one of reduction).  The
+// z with the smallest rounds x steps wins when it saves 10 % or more: 44 tiles (stage 3 of one pair, 32 chunks) -> z = 4; 345 tiles (stage
+// 3 of the 8-pair batch: 2 rounds, the second one-third full) -> z = 2 (3 rounds of 19 steps instead of 2 of 35).
 static int fused_splits(int64_t tiles, int colblocks, int chunks) {
-  int z = 1;
-  while (tiles * colblocks * z < 256 && chunks % (4 * z) == 0 && chunks / (2 * z) >= 4) z *= 2;
-  return z;
+  const int64_t wg = tiles * colblocks;
+  int best = 1;
+  int64_t best_cost = ((wg + 255) / 256) * (chunks + 3);
+  for (int z = 2; z <= 8; z *= 2) {
+    if (chunks % (2 * z) != 0 || chunks / z < 4) break;          // an even number of chunks per workgroup, at least 4
+    const int64_t cost = ((wg * z + 255) / 256) * (chunks / z + 3);
+    if (10 * cost <= 9 * best_cost) {
+      best = z;
+      best_cost = cost;
+    }
+  }
+  return best;
 }
 static int64_t fused_tiles(int64_t num_queries) { return se3_cdiv(num_queries, kTP); }
 static int fused_colblocks(int out_channels) {

@@ -56,10 +56,19 @@ for qs, ss, tab, C in calls:
         t_b = timeit(lambda: check(lib().se3_kpconv_so3_fused(xb.data_ptr(), tabl.data_ptr(), P, Ns, NN, C, C, Wp.data_ptr(), out.data_ptr(), None, 0, 1, st), 'f'))
         tot['blocked'] = tot.get('blocked', 0.0) + t_b
         check(lib().se3_kpconv_so3_fused(x.data_ptr(), tabl.data_ptr(), P, Ns, NN, C, C, Wp.data_ptr(), out.data_ptr(), None, 0, 0, st), 'f')
+    t_s = float('nan')
+    sb = lib().se3_kpconv_fused_split_workspace_bytes(P, C, C)
+    if sb and C % 16 == 0:      # channels split over workgroups (round quantisation: few tiles, or a last round that is mostly empty)
+        sws = torch.zeros((sb,), dtype=torch.uint8, device=dev)
+        t_s = timeit(lambda: check(lib().se3_kpconv_so3_fused(xb.data_ptr(), tabl.data_ptr(), P, s.shape[0], NN, C, C, Wp.data_ptr(), out.data_ptr(), sws.data_ptr(), sb, 1, st), 'f'))
+        tot['split'] = tot.get('split', 0.0) + t_s
+        check(lib().se3_kpconv_so3_fused(x.data_ptr(), tabl.data_ptr(), P, s.shape[0], NN, C, C, Wp.data_ptr(), out.data_ptr(), None, 0, 0, st), 'f')
+    elif C % 16 == 0:
+        tot['split'] = tot.get('split', 0.0) + t_b
     err = float((out - torch.mm(ops.kpconv_slot_sums(x, q, s, idx, kp, kidx, ridx, sig), w.reshape(36 * C, C)).view(P, 6, C)).abs().max() / out.abs().max())
     gf = 2.0 * 6 * q.shape[0] * 36 * C * C / 1e9
     ops.KPCONV_MATRIX_CORE = True; outf = SF.kpconv_inter_so3(x, q, s, idx, kp, w, kidx, ridx, sig); ops.KPCONV_MATRIX_CORE = 'auto'
     errf = float((outf - torch.mm(ops.kpconv_slot_sums(x, q, s, idx, kp, kidx, ridx, sig), w.reshape(36 * C, C)).view(P, 6, C)).abs().max() / outf.abs().max())
-    print('P %6d NN %2d C %3d  gemm %.3f ms  sums %.3f ms (table %.3f + gather %.3f + contract %.3f)  fused %.3f ms (kernel %.3f, blocked x %.3f) (%.0f GF: %.0f TF/s f32-equivalent, %.2f PF/s f16)  err %.1e / %.1e'
-          % (q.shape[0], idx.shape[1], C, res['old'], res['sums'], t_t, t_g, t_c, res['new'], t_f, t_b, gf, gf / res['new'], 3 * gf / res['new'] / 1e3, err, errf))
-print('total gemm %.2f ms  sums %.2f ms  fused %.2f ms (kernels with blocked x: %.2f ms) per 8 pairs' % (tot['old'], tot['sums'], tot['new'], tot.get('blocked', float('nan'))))
+    print('P %6d NN %2d C %3d  gemm %.3f ms  sums %.3f ms (table %.3f + gather %.3f + contract %.3f)  fused %.3f ms (kernel %.3f, blocked x %.3f, + channel split %.3f) (%.0f GF: %.0f TF/s f32-equivalent, %.2f PF/s f16)  err %.1e / %.1e'
+          % (q.shape[0], idx.shape[1], C, res['old'], res['sums'], t_t, t_g, t_c, res['new'], t_f, t_b, t_s, gf, gf / res['new'], 3 * gf / res['new'] / 1e3, err, errf))
+print('total gemm %.2f ms  sums %.2f ms  fused %.2f ms (kernels with blocked x: %.2f ms; with the channel split where it applies: %.2f ms) per 8 pairs' % (tot['old'], tot['sums'], tot['new'], tot.get('blocked', float('nan')), tot.get('split', float('nan'))))
