@@ -113,8 +113,8 @@ def launch_ranks(n, argv, script=None, python=None, poll=0.2, timeout=3600.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=6)
+    ap.add_argument('--steps', type=int, default=60)
+    ap.add_argument('--warmup', type=int, default=9)
     ap.add_argument('--variant', default='se3ete')
     ap.add_argument('--pair', default='c2_5k')
     ap.add_argument('--cpu-baseline-pairs', type=int, default=2)

@@ -11,7 +11,7 @@ tools/prof.sh ${tag} bench.py --no-cpu-baseline --single-pair-steps 0 --train-st
 # one batch in flight, pyramid and model back to back: every kernel alone on the GPU (the per-step categories and the kernels' own durations)
 tools/prof.sh ${tag}seq bench.py --inflight 1 --prefetch 0 --no-cpu-baseline --single-pair-steps 0 --train-steps 0 --roofline-quiet-steps 0 >> $O/prof.txt 2>&1; cp gpurun_out/${tag}seq_kernel_stats.csv $O/${tag}_kernel_stats_sequential.csv
 tools/prof.sh ${tag}b1 bench.py --batch 1 --no-cpu-baseline --single-pair-steps 0 --train-steps 0 >> $O/prof.txt 2>&1; cp gpurun_out/${tag}b1_kernel_stats.csv $O/${tag}_kernel_stats_batch1.csv
-python tools/step_breakdown.py $O/${tag}_kernel_stats_sequential.csv 36 > $O/${tag}_step_breakdown.txt 2>&1      # 30 steps + 6 warm-up
+python tools/step_breakdown.py $O/${tag}_kernel_stats_sequential.csv 69 > $O/${tag}_step_breakdown.txt 2>&1      # 60 steps + 9 warm-up
 timeout 300 python tools/micro/kpconv_paths.py 2>&1 | grep -v "amdgpu.ids\|Warning" > $O/${tag}_kpconv_paths.txt
 timeout 300 python tools/micro/dense_norm_shapes.py 2>&1 | grep -v "amdgpu.ids\|Warning" > $O/${tag}_dense_norm_shapes.txt
 for L in 2 5 8; do echo "== KPConv layer $L (tools/micro/kpconv_layer.py $L fused): counters of kpconv_fused_kernel, average per dispatch"; tools/pmc_kernel.sh kpconv_fused_kernel tools/micro/kpconv_layer.py $L fused 3; tail -1 gpurun_out/pmck.log | grep layer; done > $O/${tag}_pmc_kpconv.txt 2>&1

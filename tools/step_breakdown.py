@@ -1,8 +1,8 @@
 """GPU time per bench step by kernel family, from a rocprofv3 kernel_stats CSV of `bench.py --inflight 1 --prefetch 0 --no-cpu-baseline
---single-pair-steps 0 --train-steps 0` (every kernel alone on the GPU; 30 steps + 6 warm-up = 36):
+--single-pair-steps 0 --train-steps 0` (every kernel alone on the GPU; 60 steps + 9 warm-up = 69):
 python tools/step_breakdown.py <kernel_stats.csv> [steps incl. warm-up]"""
 import csv, sys
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 36
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 69
 fam = [('Cijk_', 'library GEMM'), ('linear_', 'dense f16-split GEMM'), ('dense_norm', 'dense + GroupNorm fused'), ('gn_chain_apply', 'GroupNorm apply (pending forms)'),
        ('gn_', 'GroupNorm'), ('kpconv_gather', 'KPConv gather (G form)'),
        ('kpconv_fused', 'KPConv fused'), ('kpconv_neighbor_table', 'KPConv neighbour table'), ('kpconv_', 'KPConv other'), ('rpe_bias', 'RPE logits'), ('attention_kernel', 'attention'), ('cross_eq', 'cross_eq'),
