@@ -1803,7 +1803,8 @@ extern "C" size_t se3_attention_kv_pieces_bytes(int num_anchors, int64_t key_row
   return (size_t)2 * num_anchors * ((size_t)key_rows * C + (size_t)C * v_row_stride) * sizeof(_Float16) + 256;
 }
 static bool launch_attention_x6(AttnArgs& p, void* ws, size_t ws_bytes, hipStream_t st) {
-  if (ws == nullptr || g_attn_variant == 11 || p.C / p.H != 64 || p.C % 8 || p.v_rs % 16 || p.q_rs % 4 || p.k_rs % 4 ||
+  // (the plain cross-attention calls -- no logits, one or six small value sets -- stay on the f32 kernel: 16 us against 20 + 10 for the split)
+  if (ws == nullptr || p.bias == nullptr || g_attn_variant == 11 || p.C / p.H != 64 || p.C % 8 || p.v_rs % 16 || p.q_rs % 4 || p.k_rs % 4 ||
       (reinterpret_cast<uintptr_t>(ws) & 15) || (reinterpret_cast<uintptr_t>(p.q) & 15) || (reinterpret_cast<uintptr_t>(p.k) & 15) ||
       (reinterpret_cast<uintptr_t>(p.v) & 15) || (p.A > 1 && (p.k_sa == 0 || p.v_sa == 0)))
     return false;
