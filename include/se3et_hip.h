@@ -5,7 +5,9 @@
  *   - tensors are dense, row-major, float32 / int64 / int32 / uint8 as typed below;
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); launches are asynchronous;
  *   - outputs and workspaces are caller-allocated; the library never allocates or frees device memory
- *     and keeps no global state (one stream per process is enough, several are safe);
+ *     and keeps no global state (one stream per process is enough, several are safe: one workspace per stream);
+ *   - three workspaces begin with arrival counters of an in-kernel reduction (se3_dense_norm_fwd, se3_group_norm_stats,
+ *     se3_kpconv_so3_fused's split form): they must be ZERO before their first use; every completed call leaves them zero;
  *   - return value: 0 = ok, otherwise an SE3_ERR_* code (the Python host raises RuntimeError, mirroring the
  *     TORCH_CHECK failures of the reference extension, geotransformer/extensions/common/torch_helper.h:6-35).
  *
@@ -15,7 +17,9 @@
  *   - point_to_node_partition: point_limit <= 128 (the KITTI configuration's patch size);
  *   - attention: anchors * heads <= 32, head dimension in {8, 16, 32, 64}, channels of the relative-position kernel in {32, 64, 128, 256};
  *   - KPConv matrix-core path: input channels a multiple of 8, output channels a multiple of 32, num_support * 6 * in_channels < 2^31, the
- *     SE3ET slot tables (kanchor 6, 15 kernel points), |orbit sums| < 65504; se3_linear_f16: in_features a multiple of 32, |x| < 65504.
+ *     SE3ET slot tables (kanchor 6, 15 kernel points), |orbit sums| < 65504; se3_linear_f16: in_features a multiple of 32, |x| < 65504;
+ *   - se3_dense_norm_fwd: in_features a power of two 32..1024, out_features 32 / 64 / 128 or a multiple of 256 up to 4096, channels per group
+ *     a power of two <= 32, at most 16 segments; the f16 attention form (kv_pieces_workspace): head dimension 64.
  *
  * Each entry point names the reference interface it replaces (paths under the reference repository).
  */
