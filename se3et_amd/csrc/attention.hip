@@ -1155,6 +1155,12 @@ __global__ __launch_bounds__(256) void x6_split_vt_kernel(const float* __restric
   }
 }
 
+// Value of lane i ^ 32 (the other half of the wave): one v_permlane32_swap instead of a ds_bpermute round trip through the LDS pipeline.
+__device__ __forceinline__ float other_half(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
+}
+
 struct X6Pieces { const uint4 *q[2], *k[2], *v[2]; };       // f16 hi / lo pieces, 8 values per uint4
 
 // grid (ceil(QT / 4), H, A * pairs), 4 waves = 4 consecutive 32-query tiles of one (pair, query anchor a, head).  The workgroup walks
@@ -1252,7 +1258,7 @@ __global__ __launch_bounds__(256) void cross_eq_apply_stack_x6_kernel(CrossEqArg
           mx = fmaxf(mx, val);
         }
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mx = fmaxf(mx, other_half(mx));
       const float m_new = fmaxf(st.m, mx);
       const float alpha = __expf(st.m - m_new);
       float ps = 0.f;
@@ -1261,7 +1267,7 @@ __global__ __launch_bounds__(256) void cross_eq_apply_stack_x6_kernel(CrossEqArg
         s[r] = __expf(s[r] - m_new);
         ps += s[r];
       }
-      ps += __shfl_xor(ps, 32);
+      ps += other_half(ps);
       st.l = st.l * alpha + ps;
       st.m = m_new;
       h2x8_t pb[2][2];
@@ -1729,7 +1735,7 @@ __global__ __launch_bounds__(256, HAS_BIAS ? 2 : 3) void attention_x6_kernel(Att
         }
       }
       if (PROF && step < 5) { SE3_STAMP(3 + 5 * step) }
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mx = fmaxf(mx, other_half(mx));
       const float m_new = fmaxf(st.m, mx);
       const float alpha = __expf(st.m - m_new);
       float ps = 0.f;
@@ -1738,7 +1744,7 @@ __global__ __launch_bounds__(256, HAS_BIAS ? 2 : 3) void attention_x6_kernel(Att
         s[r] = __expf(s[r] - m_new);
         ps += s[r];
       }
-      ps += __shfl_xor(ps, 32);
+      ps += other_half(ps);
       st.l = st.l * alpha + ps;
       st.m = m_new;
       h2x8_t pb[2][2];
