@@ -366,6 +366,10 @@ int se3_cross_eq_apply(const float* q, const float* k, const float* vt, const fl
  * (pair, a, e) and the statistics launch is skipped (mean_h S = (scale/H) q_a[n].k_e[m] over all C channels, so the caller can
  * get the sums from two Gram matrices per pair: (scale/H)^2 <Q_a^T Q_a, K_e^T K_e>_F -- 3.5x fewer flops, library GEMMs); mix (num_pairs, A, A); weights (num_pairs, A*A) for mode 0 / (num_pairs, num_rotations) for mode 1; out (A, Rq, C) in
  * the packing of q.  num_pairs <= 16. */
+/* Gram matrices of packed rows: out (num_anchors, num_pairs, C, C) = X^T X over the rows [starts[p], starts[p] + lengths[p]) of x[a]
+ * (x (num_anchors, rows, C), row stride C, anchor_stride floats between anchors); C = 128 or 256, HOST arrays, at most 16 pairs. */
+int se3_gram_stack(const float* x, int num_anchors, int C, int64_t anchor_stride, const int64_t* starts, const int64_t* lengths, int num_pairs,
+                   float* out, void* stream);
 /* The sums_given statistics of the stack mode from per-pair Gram matrices: out (num_pairs, A, A) = factor * <gq[a, p], gk[e, p]>_F, gq / gk
  * (A, num_pairs, elements) contiguous (elements = C * C, a multiple of 4). */
 int se3_gram_frobenius(const float* gq, const float* gk, int A, int num_pairs, int64_t elements, float factor, float* out, void* stream);

@@ -2023,6 +2023,88 @@ extern "C" int se3_cross_eq_mix(const float* partial, int num_partials_per_pair,
   return SE3_OK;
 }
 
+// Gram matrices of the packed rows of every (anchor, pair): G[a, p] = X_p^T X_p (C x C) with X_p = rows [starts[p], starts[p] + lengths[p]) of
+// x[a] -- the operands of the anchor-pair statistics of the equivariant cross attention (se3_gram_frobenius).  v_mfma_f32_16x16x4_f32 with
+// A = X^T read straight from the rows (A[i][k] = X[k][i]).  One workgroup per (a, p, 64 output rows), a wave per 64 columns.  Replaces
+// index_select + mask + batched GEMM (three launches and a (A, P, W, C) copy per tensor).
+namespace {
+struct GramPairs {
+  int n;
+  int start[kMaxClouds], length[kMaxClouds];
+};
+template <int C>
+__global__ __launch_bounds__(256) void gram_stack_kernel(const float* __restrict__ x, int64_t anchor_stride, GramPairs P, float* __restrict__ out) {
+  // A wave owns a 64 x 64 block of G: lane (c, kq) loads ONE float4 of row k for the output rows (channels i0 + 4 c .. + 3) and one for the
+  // columns (j0 + 4 c .. + 3), and the 16 MFMAs (ea, eb) of a K-step take component ea of the first and eb of the second: MFMA row m stands
+  // for channel i0 + 4 m + ea, column n for j0 + 4 n + eb.  2 loads per 16 MFMAs (one dword per lane and MFMA operand took 5 loads per 4
+  // MFMAs and was bound by L1 requests: 43-63 us per launch).
+  constexpr int KS = 4;                                       // K-steps (4 rows each) per iteration
+  const int ap = blockIdx.x, a = ap / P.n, p = ap - a * P.n;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, kq = lane >> 4;
+  const int i0 = blockIdx.y * 64, j0 = wave * 64;
+  const int start = P.start[p], len = P.length[p];
+  const float* xr = x + a * anchor_stride + (int64_t)start * C;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int ea = 0; ea < 4; ea++)
+#pragma unroll
+    for (int eb = 0; eb < 4; eb++) acc[ea][eb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](int k0, f32x4 (&av)[KS], f32x4 (&bv)[KS]) {
+#pragma unroll
+    for (int u = 0; u < KS; u++) {
+      const int row = k0 + 4 * u + kq;
+      const bool valid = row < len;
+      const float* r = xr + (int64_t)(valid ? row : 0) * C;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      av[u] = valid ? *reinterpret_cast<const f32x4*>(r + i0 + 4 * c) : z;
+      bv[u] = valid ? *reinterpret_cast<const f32x4*>(r + j0 + 4 * c) : z;
+    }
+  };
+  f32x4 av[KS], bv[KS], an[KS], bn[KS];
+  fetch(0, av, bv);
+  for (int k0 = 0; k0 < len; k0 += 4 * KS) {
+    fetch(k0 + 4 * KS, an, bn);                               // the next iteration's rows (past the end: zeros) behind this one's 64 MFMAs
+#pragma unroll
+    for (int u = 0; u < KS; u++)
+#pragma unroll
+      for (int ea = 0; ea < 4; ea++)
+#pragma unroll
+        for (int eb = 0; eb < 4; eb++) acc[ea][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][ea], bv[u][eb], acc[ea][eb], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < KS; u++) {
+      av[u] = an[u];
+      bv[u] = bn[u];
+    }
+  }
+  // acc[ea][eb][r] = G[i0 + 4 (4 kq + r) + ea][j0 + 4 c + eb]: the four eb of a lane are 16 contiguous bytes
+  float* o = out + ((int64_t)ap * C + i0) * C + j0 + 4 * c;
+#pragma unroll
+  for (int ea = 0; ea < 4; ea++)
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      *reinterpret_cast<f32x4*>(o + (int64_t)(4 * (4 * kq + r) + ea) * C) = f32x4{acc[ea][0][r], acc[ea][1][r], acc[ea][2][r], acc[ea][3][r]};
+}
+}  // namespace
+
+extern "C" int se3_gram_stack(const float* x, int num_anchors, int C, int64_t anchor_stride, const int64_t* starts, const int64_t* lengths,
+                              int num_pairs, float* out, void* stream) {
+  SE3_REQUIRE(x && starts && lengths && out, SE3_ERR_INVALID_ARG, "gram_stack: null pointer");
+  SE3_REQUIRE(num_anchors >= 1 && num_pairs >= 1 && num_pairs <= kMaxClouds && (C == 128 || C == 256), SE3_ERR_UNSUPPORTED,
+              "gram_stack: %d anchors, %d pairs (<= %d), C = %d (128 or 256)", num_anchors, num_pairs, kMaxClouds, C);
+  GramPairs P{};
+  P.n = num_pairs;
+  for (int p = 0; p < num_pairs; p++) {
+    SE3_REQUIRE(starts[p] >= 0 && lengths[p] >= 1, SE3_ERR_INVALID_ARG, "gram_stack: pair %d rows", p);
+    P.start[p] = (int)starts[p];
+    P.length[p] = (int)lengths[p];
+  }
+  const dim3 grid((unsigned)(num_anchors * num_pairs), (unsigned)(C / 64));
+  if (C == 256) gram_stack_kernel<256><<<grid, 256, 0, (hipStream_t)stream>>>(x, anchor_stride, P, out);
+  else gram_stack_kernel<128><<<grid, 128, 0, (hipStream_t)stream>>>(x, anchor_stride, P, out);
+  SE3_CHECK_LAUNCH("gram_stack");
+  return SE3_OK;
+}
+
 // <Gq[a, p], Gk[e, p]>_F for every (pair p, query anchor a, key anchor e): the anchor-pair statistics of the equivariant cross attention from
 // the per-pair Gram matrices (se3_cross_eq_stack_fwd, sums_given).  gq, gk (A, P, n) contiguous; out (P, A, A) = factor * the inner products.
 // One workgroup per (p, a, e): 2 n floats from L2 (each Gram matrix is read by A workgroups).  The library's batched GEMM took 51 us for
@@ -2034,12 +2116,18 @@ __global__ __launch_bounds__(256) void gram_frobenius_kernel(const float* __rest
   const int e = blockIdx.x % A, a = (blockIdx.x / A) % A, p = blockIdx.x / (A * A);
   const float4* x = reinterpret_cast<const float4*>(gq + ((size_t)a * P + p) * n);
   const float4* y = reinterpret_cast<const float4*>(gk + ((size_t)e * P + p) * n);
-  float acc = 0.f;
-  for (int64_t i = threadIdx.x; i < (n >> 2); i += 256) {
+  float acc = 0.f, acc2 = 0.f;
+  int64_t i = threadIdx.x;
+  for (; i + 768 < (n >> 2); i += 1024) {                     // 8 loads in flight per thread
+    const float4 u0 = x[i], v0 = y[i], u1 = x[i + 256], v1 = y[i + 256], u2 = x[i + 512], v2 = y[i + 512], u3 = x[i + 768], v3 = y[i + 768];
+    acc += u0.x * v0.x + u0.y * v0.y + u0.z * v0.z + u0.w * v0.w + u2.x * v2.x + u2.y * v2.y + u2.z * v2.z + u2.w * v2.w;
+    acc2 += u1.x * v1.x + u1.y * v1.y + u1.z * v1.z + u1.w * v1.w + u3.x * v3.x + u3.y * v3.y + u3.z * v3.z + u3.w * v3.w;
+  }
+  for (; i < (n >> 2); i += 256) {
     const float4 u = x[i], v = y[i];
     acc += u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
   }
-  acc = se3_wave_sum(acc);
+  acc = se3_wave_sum(acc + acc2);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1] + red[2] + red[3]) * factor;

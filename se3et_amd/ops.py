@@ -1109,10 +1109,19 @@ def _pair_rows(starts, lengths, device):
     return idx, mask.view(1, len(key[1]), hit[1], 1), hit[1]
 
 
+GRAM_KERNEL = True            # False: index_select + mask + batched library GEMM (A/B runs, tests)
+
+
 def _gram_per_pair(x, starts, lengths):
-    """x (A, R, C) packed rows -> (A, P, C, C): X_p^T X_p over the rows of every pair (library GEMM)."""
-    idx, mask, W = _pair_rows(starts, lengths, x.device)
+    """x (A, R, C) packed rows -> (A, P, C, C): X_p^T X_p over the rows of every pair (csrc/attention.hip: gram_stack_kernel; other channel
+    counts / strided rows: index_select + library GEMM)."""
     A, P, C = x.shape[0], len(starts), x.shape[2]
+    if GRAM_KERNEL and C in (128, 256) and P <= 16 and x.dtype == torch.float32 and x.stride(2) == 1 and x.stride(1) == C:
+        out = torch.empty((A, P, C, C), dtype=torch.float32, device=x.device)
+        check(lib().se3_gram_stack(x.data_ptr(), A, C, x.stride(0) if A > 1 else 0, _i64_array(starts), _i64_array(lengths), P, out.data_ptr(),
+                                   _stream()), 'se3_gram_stack')
+        return out
+    idx, mask, W = _pair_rows(starts, lengths, x.device)
     win = x.index_select(1, idx).view(A, P, W, C)
     win.mul_(mask)                                   # rows past a cloud's length -> 0 (the mask is 0 / 1: masking both operands is masking one)
     win = win.view(A * P, W, C)

@@ -962,3 +962,26 @@ def test_kpconv_neighbor_table_is_shared_only_for_the_same_geometry():
     assert t2 is not t1 and not torch.equal(t2, t1)
     q2 = q.clone()
     assert ops._kpconv_neighbor_table(q2, s, idx, kp, 0.05, 120, 300, 24, st) is not t2
+
+
+@pytest.mark.parametrize('C', [256, 128])
+def test_gram_stack_kernel_matches_the_library_path(C):
+    """csrc/attention.hip gram_stack_kernel (X_p^T X_p per anchor and pair straight from the packed rows) against index_select + mask +
+    batched GEMM, ragged lengths incl. one that is not a multiple of the 8-row step."""
+    from se3et_amd import ops
+    g = torch.Generator().manual_seed(C)
+    lengths = [382, 350, 13, 129]
+    starts, r = [], 0
+    for n in lengths:
+        starts.append(r)
+        r += (n + 31) // 32 * 32
+    x = torch.randn(6, r, C, generator=g).cuda()
+    got = ops._gram_per_pair(x, starts, lengths)
+    ops.GRAM_KERNEL = False
+    try:
+        want = ops._gram_per_pair(x, starts, lengths)
+    finally:
+        ops.GRAM_KERNEL = True
+    ref = torch.stack([torch.stack([x[a, s:s + n].double().t() @ x[a, s:s + n].double() for s, n in zip(starts, lengths)]) for a in range(6)])
+    e_new, e_lib = float((got.double() - ref).abs().max()), float((want.double() - ref).abs().max())
+    assert e_new <= max(2 * e_lib, 2e-6 * float(ref.abs().max())), (e_new, e_lib)
