@@ -34,8 +34,10 @@ L.se3_kpconv_so3_fused.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int64, ctype
 L.se3_debug_kpconv_set_stamps.argtypes = [vp]
 assert L.se3_debug_kpconv_set_stamps(stamps.data_ptr()) == 0
 torch.cuda.synchronize()
+blocked = len(sys.argv) > 2 and sys.argv[2] == 'blocked' and C % 16 == 0
+xin = x.view(s.shape[0], 3, 2, C // 16, 16).permute(0, 3, 1, 4, 2).contiguous() if blocked else x
 for _ in range(3):
-    rc = L.se3_kpconv_so3_fused(x.data_ptr(), ws.data_ptr(), P, s.shape[0], NN, C, C, Wp.data_ptr(), out.data_ptr(), None, 0, 0, None)
+    rc = L.se3_kpconv_so3_fused(xin.data_ptr(), ws.data_ptr(), P, s.shape[0], NN, C, C, Wp.data_ptr(), out.data_ptr(), None, 0, 1 if blocked else 0, None)
     assert rc == 0
 torch.cuda.synchronize()
 st = stamps.cpu().numpy().astype(np.float64)
@@ -46,8 +48,8 @@ prod = blk[:, nc:nc + 8, :min(steps, 40)]           # (blocks, waves, steps, slo
 ok = prod[..., 0] > 0
 def seg(a, i, j, m): d = (a[..., j] - a[..., i])[m]; return d.mean(), np.percentile(d, 90)
 act = ok & (prod[..., 2] > 0) & (prod[..., 1] > 0)
-print('layer %d: P %d C %d, %d chunks; ticks of s_memtime (100 MHz realtime? -> treat as cycles of the shader clock)' % (layer, P, C, chunks))
-for name, i, j in (('held rows + next requests', 0, 1), ('  (acc init, count)', 1, 5), ('  split operands + 18 MFMAs', 5, 6), ('  extra rounds + next operand requests', 6, 2), ('split result + stores', 2, 3), ('barrier wait', 3, 4)):
+print('layer %d%s: P %d C %d, %d chunks; ticks of s_memtime (100 MHz realtime? -> treat as cycles of the shader clock)' % (layer, ' (blocked x)' if blocked else '', P, C, chunks))
+for name, i, j in (('held rows + next requests', 0, 1), ('  (acc init, count)', 1, 5), ('  split operands + 18 MFMAs', 5, 6), ('  extra rounds (> 40 neighbours)', 6, 7), ('  next operand requests', 7, 2), ('split result + stores', 2, 3), ('barrier wait', 3, 4)):
     m, p90 = seg(prod, i, j, act & (prod[..., j] > 0)); print('  producer %-30s mean %8.0f  p90 %8.0f' % (name, m, p90))
 m, p90 = seg(prod, 0, 4, act & (prod[..., 4] > 0)); print('  producer %-30s mean %8.0f  p90 %8.0f' % ('whole step', m, p90))
 cons = blk[:, :nc, 2:min(steps, 40)]
