@@ -493,14 +493,16 @@ def run_fake(args):
 
 def run_single_pair(model, cfg, args, dev, feats_unused):
     """The reference-shaped path (one pair per forward, experiments/se3ete.3dmatch/model.py:86-98) on the same workload:
-    pairs/s over `--single-pair-steps` pairs after 3 warm-up pairs; host synchronisations of one forward (torch's sync-debug
+    pairs/s over `--single-pair-steps` pairs after 12 warm-up pairs; host synchronisations of one forward (torch's sync-debug
     mode: every blocking copy / .item() / nonzero) and, when no external profiler is attached, kernel launches and summed
     kernel time of one forward from torch.profiler."""
     import warnings
     from se3et_amd.data import precompute_data_stack_mode
     from se3et_amd.synthetic import make_pair
     b = cfg.backbone
-    n_pairs = args.single_pair_steps + 3
+    WU = 12            # warm-up pairs: every pair has row counts of its own, and the caching allocator keeps meeting new block sizes (a
+                       # hipMalloc each, which waits for the GPU) for the first dozen forwards -- 3 warm-up pairs measured 7 % below the steady rate
+    n_pairs = args.single_pair_steps + WU
     inputs = []
     for i in range(n_pairs):
         ref, src, _ = make_pair(args.pair, index=1000 + i)
@@ -513,14 +515,84 @@ def run_single_pair(model, cfg, args, dev, feats_unused):
         data['features'] = ones
         return model(data)
 
-    for i in range(3):
+    for i in range(WU):
         one(i)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(3, n_pairs):
+    for i in range(WU, n_pairs):
         one(i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.single_pair_steps
+
+    # The same one-pair forwards, (a) with the pyramid of pair i+1 built by a worker thread on its own stream while pair i runs through the
+    # model (what the reference's DataLoader workers do on the CPU, geotransformer/utils/data.py collate), (b) with three one-pair forwards
+    # in flight (three host threads, one stream each: independent requests of a server).  Reported beside the sequential rate, never as it.
+    import queue, threading
+    idx = list(range(WU, n_pairs))
+
+    def pipelined():
+        q, side, main, failed = queue.Queue(maxsize=2), torch.cuda.Stream(device=dev), torch.cuda.current_stream(), []
+
+        def producer():
+            try:
+                with torch.cuda.stream(side):
+                    for i in idx:
+                        pts, lens = inputs[i]
+                        data = precompute_data_stack_mode(pts, lens, b.num_stages, b.init_voxel_size, b.init_radius, cfg.neighbor_limits)
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        q.put((data, ev))
+            except BaseException as e:
+                failed.append(e)
+            q.put(None)
+
+        th = threading.Thread(target=producer, daemon=True)
+        th.start()
+        keep = []
+        while True:
+            item = q.get()
+            if item is None:
+                break
+            data, ev = item
+            main.wait_event(ev)
+            for key in ('points', 'neighbors', 'subsampling', 'upsampling'):
+                for t in data[key]:
+                    t.record_stream(main)
+            data['features'] = ones
+            model(data)
+            keep = [data] + keep[:1]
+        th.join(timeout=30)
+        if failed:
+            raise failed[0]
+
+    def concurrent(P=3):
+        failed = []
+
+        def worker(t, stream):
+            try:
+                with torch.cuda.stream(stream):
+                    for i in idx[t::P]:
+                        one(i)
+                    stream.synchronize()
+            except BaseException as e:
+                failed.append(e)
+
+        threads = [threading.Thread(target=worker, args=(t, torch.cuda.Stream(device=dev)), daemon=True) for t in range(P)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        if failed:
+            raise failed[0]
+
+    variants = {}
+    for name, fn in (('pyramid_prefetched', pipelined), ('three_in_flight', concurrent)):
+        fn()                                  # warm-up (per-stream workspaces, caches)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        variants[name] = round(args.single_pair_steps / (time.perf_counter() - t1), 2)
     syncs = [0]
     with warnings.catch_warnings():
         warnings.simplefilter('always')
@@ -551,7 +623,10 @@ def run_single_pair(model, cfg, args, dev, feats_unused):
     return {'pairs_per_s': round(1.0 / dt, 2), 'ms_per_pair': round(dt * 1e3, 3), 'pairs': args.single_pair_steps,
             'host_syncs': syncs[0], 'launches': launches, 'gpu_kernel_ms': gpu_ms,
             'host_ms': None if gpu_ms is None else round(max(dt * 1e3 - gpu_ms, 0.0), 3),
-            'note': 'one pair per forward incl. on-GPU pyramid and LGR; host_ms = wall time per pair not covered by kernel time'}
+            'pairs_per_s_pyramid_prefetched': variants['pyramid_prefetched'], 'pairs_per_s_three_in_flight': variants['three_in_flight'],
+            'note': 'one pair per forward incl. on-GPU pyramid and LGR, forwards strictly one after the other; host_ms = wall time per pair '
+                    'not covered by kernel time.  pyramid_prefetched: the pyramid of the next pair built by a worker thread on its own stream '
+                    '(the reference builds it in DataLoader workers); three_in_flight: three one-pair forwards at a time on three streams'}
 
 
 def run_cpu_baseline(model, cfg, args):

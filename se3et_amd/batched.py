@@ -223,7 +223,8 @@ def registration_pairs(lgr, patches, stacked=None):
     T = torch.where(any_valid[:, None, None], Ts[best], T_all)
     for _ in range(lgr.num_refinement_steps):
         T = SF.weighted_procrustes(src_c, ref_c, sc, bounds, gate_transform=T, gate_radius=lgr.acceptance_radius)
-    cuts = bounds.tolist()                                                    # second (tiny) sync: per-pair slices of the outputs
+    # per-pair slices of the outputs: a second (tiny) sync, except with one pair (all correspondences are its own)
+    cuts = [0, int(b_idx.shape[0])] if P == 1 else bounds.tolist()
     return [(ref_c[cuts[p]:cuts[p + 1]], src_c[cuts[p]:cuts[p + 1]], sc[cuts[p]:cuts[p + 1]], T[p]) for p in range(P)]
 
 
@@ -241,24 +242,32 @@ def forward_pairs(model, data_dict, with_registration=True):
     for ln in lengths:
         o = _offsets(ln.tolist())
         seg.append([o[2 * p] for p in range(B)] + [o[-1]])
-    with SF.norm_segments(seg):
-        feats_list = model.backbone(data_dict['features'], data_dict)
-    feats_c, feats_f = feats_list[-1], feats_list[0]
     points_c, points_f = data_dict['points'][-1], data_dict['points'][1]
     len_c, len_f = lengths[-1].tolist(), lengths[1].tolist()
     oc, of = _offsets(len_c), _offsets(len_f)
     points_0, o0 = data_dict['points'][0], _offsets(lengths[0].tolist())
-
-    X, PA = transformer_pairs(model.transformer, points_c, len_c, feats_c, packed=True)
-    Xn = F.normalize(X, p=2, dim=1)                       # all clouds at once (the padding rows of the packing stay zero)
-    dev = X.device
+    dev = points_c.device
     K = model.num_points_in_patch
-    # every fine point to its nearest superpoint, every superpoint's K nearest own points: all clouds in one call, GLOBAL indices
+    # every fine point to its nearest superpoint, every superpoint's K nearest own points: all clouds in one call, GLOBAL indices.  It needs
+    # the points only, so it goes first: the number of non-empty nodes per cloud travels to the host behind the backbone and the transformer
+    # (read after them, when it has long arrived -- no wait, as in SE3ET._forward)
     _, node_masks, knn, knn_masks = _ops.point_to_node_partition_stack(points_f, points_c, len_f, len_c, K)
     csum = torch.cumsum(node_masks, 0)
     ends = _ops.to_device([o - 1 for o in oc[1:]], torch.int64, dev)
     upto = csum[ends]
-    valid = (upto - torch.cat((upto.new_zeros(1), upto[:-1]))).tolist()      # non-empty nodes per cloud: ONE host sync
+    valid_host = torch.empty(len(len_c), dtype=torch.int64).pin_memory()
+    valid_host.copy_(upto - torch.cat((upto.new_zeros(1), upto[:-1])), non_blocking=True)
+    valid_event = torch.cuda.Event()
+    valid_event.record()
+
+    with SF.norm_segments(seg):
+        feats_list = model.backbone(data_dict['features'], data_dict)
+    feats_c, feats_f = feats_list[-1], feats_list[0]
+
+    X, PA = transformer_pairs(model.transformer, points_c, len_c, feats_c, packed=True)
+    Xn = F.normalize(X, p=2, dim=1)                       # all clouds at once (the padding rows of the packing stay zero)
+    valid_event.synchronize()
+    valid = valid_host.tolist()                           # non-empty nodes per cloud
     ref_rows, src_rows = PA.starts[:B], PA.starts[B:]
     Ns, Ms = [len_c[2 * p] for p in range(B)], [len_c[2 * p + 1] for p in range(B)]
     ref_off, src_off = [oc[2 * p] for p in range(B)], [oc[2 * p + 1] for p in range(B)]

@@ -261,6 +261,20 @@ __global__ void select_kernel(const float* __restrict__ pts, BatchInfo bi, Layou
   L.sel[p0 + v] = best;
 }
 
+// Empty hash table (keys all ones, first-seen index 0x7f7f7f7f, no members) and per-point counters at zero: one launch.
+__global__ void init_kernel(Layout L, int64_t cap_total, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap_total; i += stride) {
+    L.table_key[i] = kEmptyKey;
+    L.table_first[i] = 0x7f7f7f7f;
+    L.table_cnt[i] = 0;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    L.vox_at_point[i] = 0;
+    L.vox_fill[i] = 0;
+  }
+}
+
 // One workgroup per cloud.  seq_a/seq_b hold the node sequence (voxel ids) of the current growth stage.
 __global__ __launch_bounds__(kBlock) void order_kernel(BatchInfo bi, Layout L) {
   __shared__ int sh[kBlock];
@@ -407,13 +421,12 @@ extern "C" int se3_grid_subsample(const float* points, const float* normals, int
   size_t need = carve(n > 0 ? n : 1, batch, cap_total, bk_total, (char*)workspace, &L);
   SE3_REQUIRE(need <= workspace_bytes, SE3_ERR_WORKSPACE, "grid_subsample: workspace %zu < %zu bytes", workspace_bytes, need);
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(L.table_key, 0xff, 8 * cap_total, st);
-  if (e == hipSuccess) e = hipMemsetAsync(L.table_first, 0x7f, 4 * cap_total, st);
-  if (e == hipSuccess) e = hipMemsetAsync(L.table_cnt, 0, 4 * cap_total, st);
-  if (e == hipSuccess) e = hipMemsetAsync(L.vox_at_point, 0, 4 * (n > 0 ? n : 1), st);
-  if (e == hipSuccess) e = hipMemsetAsync(L.vox_fill, 0, 4 * (n > 0 ? n : 1), st);
-  if (e != hipSuccess) { se3_set_error("grid_subsample: memset failed: %s", hipGetErrorString(e)); return SE3_ERR_LAUNCH; }
   const int tpb = 256;
+  {
+    const int64_t most = cap_total > n ? cap_total : (n > 0 ? n : 1);
+    const int64_t blocks = se3_cdiv(most, (int64_t)tpb);
+    init_kernel<<<(unsigned)(blocks < 2048 ? blocks : 2048), tpb, 0, st>>>(L, cap_total, n > 0 ? n : 1);
+  }
   bounds_kernel<<<batch, kBlock, 0, st>>>(points, bi, voxel_size, L);
   if (nmax > 0) {
     dim3 gp((unsigned)se3_cdiv(nmax, tpb), (unsigned)batch);

@@ -448,9 +448,12 @@ extern "C" int se3_radius_grid_build(const float* s_points, int64_t ns, const in
   SE3_REQUIRE(grid_carve(ns, batch, (char*)workspace, &G) <= workspace_bytes, SE3_ERR_WORKSPACE,
               "radius_grid_build: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(G.cell_start, 0, sizeof(int) * (size_t)batch * (kCellCap + 1), st);
-  if (e == hipSuccess) e = hipMemsetAsync(G.cell_fill, 0, sizeof(int) * (size_t)batch * kCellCap, st);
-  if (e != hipSuccess) { se3_set_error("radius_grid_build: memset failed"); return SE3_ERR_LAUNCH; }
+  // cell_start and cell_fill are neighbours in the workspace (grid_carve): one fill over both (and the alignment gap between them)
+  const size_t span = (size_t)((char*)(G.cell_fill + (size_t)batch * kCellCap) - (char*)G.cell_start);
+  if ((char*)G.cell_fill < (char*)G.cell_start || hipMemsetAsync(G.cell_start, 0, span, st) != hipSuccess) {
+    se3_set_error("radius_grid_build: memset failed");
+    return SE3_ERR_LAUNCH;
+  }
   grid_bounds_kernel<<<batch, 1024, 0, st>>>(s_points, bt, radius, G);
   if (smax > 0) {
     dim3 gp((unsigned)se3_cdiv(smax, 256), (unsigned)batch);

@@ -9,7 +9,7 @@ from helpers import assert_close, assert_neighbors_equal, assert_pairs_equal_up_
 pytestmark = pytest.mark.gpu
 
 
-def _run(variant, pair, state=None, synth_seed=None, attention_dtype='float32'):
+def _run(variant, pair, state=None, synth_seed=None, attention_dtype='float32', packed=True):
     from se3et_amd.data import registration_collate_fn_stack_mode
     from se3et_amd.model import create_model, load_synthetic_weights, make_cfg
     from se3et_amd.synthetic import make_pair
@@ -20,6 +20,7 @@ def _run(variant, pair, state=None, synth_seed=None, attention_dtype='float32'):
     else:
         load_synthetic_weights(model, synth_seed)
     model = model.cuda().eval()
+    model.packed_inference = packed      # one pair through the packed-row kernels (default) or through the per-module path
     ref, src, T = make_pair(pair)
     d = dict(ref_points=ref, src_points=src, ref_feats=np.ones((len(ref), 1), np.float32),
              src_feats=np.ones((len(src), 1), np.float32), transform=T)
@@ -58,11 +59,12 @@ def _check_outputs(out, g, full):
         assert_close(out['estimated_transform'].cpu(), g['out/estimated_transform'], 2e-3, 'estimated_transform (correspondence set differs)')
 
 
+@pytest.mark.parametrize('packed', [True, False])
 @pytest.mark.parametrize('variant,fixture', [('micro_e', 'micro_se3ete.npz'), ('micro_i', 'micro_se3eti.npz')])
-def test_micro_model_matches_reference(golden_dir, variant, fixture):
+def test_micro_model_matches_reference(golden_dir, variant, fixture, packed):
     g = np.load(golden_dir + '/' + fixture)
     state = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd/')}
-    model, dd, out = _run(variant, 'micro', state=state)
+    model, dd, out = _run(variant, 'micro', state=state, packed=packed)
     for i in range(4):
         assert dd['lengths'][i].tolist() == g['data/lengths_%d' % i].tolist()
         assert torch.equal(dd['points'][i].cpu(), torch.from_numpy(g['data/points_%d' % i]))
@@ -73,12 +75,13 @@ def test_micro_model_matches_reference(golden_dir, variant, fixture):
         assert key in g.files
 
 
+@pytest.mark.parametrize('packed', [True, False])
 @pytest.mark.parametrize('variant,fixture', [('se3ete2', 'synthw_se3ete2.npz'), ('se3eti2', 'synthw_se3eti2.npz'),
                                              ('se3ete', 'synthw_se3ete.npz'), ('se3eti_kitti', 'synthw_se3eti_kitti.npz'),
                                              ('se3eti2', 'synthw_se3eti2_c1.npz')])      # the last one = BASELINE.json configs[0]: SE3ET-I2, 2k+2k pair
-def test_real_width_model_matches_reference(golden_dir, variant, fixture):
+def test_real_width_model_matches_reference(golden_dir, variant, fixture, packed):
     g = np.load(golden_dir + '/' + fixture)
-    model, dd, out = _run(variant, str(g['pair']), synth_seed=int(g['synth_seed']))
+    model, dd, out = _run(variant, str(g['pair']), synth_seed=int(g['synth_seed']), packed=packed)
     assert np.array_equal(np.stack([l.numpy() for l in dd['lengths']]), g['lengths'])
     _check_outputs(out, g, full=False)
 
@@ -139,6 +142,7 @@ def test_multi_pair_forward_equals_single_pair_forward(variant, preset, num_pair
     from se3et_amd.synthetic import make_pair
     cfg = make_cfg(variant)
     model = load_synthetic_weights(create_model(cfg)).cuda().eval()
+    model.packed_inference = False       # the single-pair side of the comparison runs the per-module path
     b = cfg.backbone
     clouds, singles = [], []
     for p in range(num_pairs):
