@@ -378,17 +378,22 @@ int se3_cross_eq_stack_fwd(const float* q, const float* k, const float* vt, cons
                            int64_t q_anchor_stride, int64_t k_anchor_stride, int v_row_stride, int64_t v_anchor_stride, int mode,
                            const int64_t* trace_idx, int num_rotations, int sums_given, float* partial_workspace, float* mix,
                            float* weights, float* out, void* stream);
-/* The same on the bf16 matrix cores at f32 accuracy (head dimension 64, A <= 6, key starts and v_row_stride multiples of 16, sums_given
- * != 0; anything else is forwarded to se3_cross_eq_stack_fwd): q, k and vt are split into three bf16 pieces each in `workspace`
- * (se3_cross_eq_x6_workspace_bytes bytes, 16-byte aligned; q (A, q_rows, C), k (A, k_rows, C) packed rows) and the six piece products
- * above 2^-24 are accumulated in f32 -- 2.7x fewer matrix-pipe cycles than the f32 MFMAs. */
+/* The same on the f16 matrix cores at f32 accuracy (head dimension 64, A <= 6, key starts and v_row_stride multiples of 16, sums_given
+ * != 0; anything else is forwarded to se3_cross_eq_stack_fwd): q, k and vt are split once into f16 hi / lo pieces in `workspace`
+ * (se3_cross_eq_x6_workspace_bytes bytes, 16-byte aligned; q (A, q_rows, C), k (A, k_rows, C) packed rows) and the three piece products
+ * above 2^-22 are accumulated in f32.
+ * out (A, q_rows, out_groups * C) with anchor stride out_anchor_stride floats: out_groups = 1 is the result itself (out_anchor_stride =
+ * q_anchor_stride for an output in the layout of q).  out_groups = G > 1 (a divisor of A; few pairs, where one workgroup per (query tile,
+ * head, anchor) leaves most of the chip idle): workgroup group g sums the key anchors [g, g + 1) * A / G and writes its partial result at
+ * channel offset g * C; the result is the sum of the G channel blocks, which the caller gets for free from the output projection that
+ * follows by stacking its weights G times along the input dimension.  (G > 1 is refused when the call has to take the f32 kernels.) */
 size_t se3_cross_eq_x6_workspace_bytes(int A, int64_t q_rows, int64_t k_rows, int C, int v_row_stride);
 int se3_cross_eq_stack_x6_fwd(const float* q, const float* k, const float* vt, const int64_t* q_starts, const int64_t* q_lengths,
                               const int64_t* k_starts, const int64_t* k_lengths, int num_pairs, int A, int C, int H, int64_t q_rows,
                               int64_t k_rows, int64_t q_anchor_stride, int64_t k_anchor_stride, int v_row_stride,
                               int64_t v_anchor_stride, int mode, const int64_t* trace_idx, int num_rotations, int sums_given,
-                              float* partial_workspace, float* mix, float* weights, float* out, void* workspace,
-                              size_t workspace_bytes, void* stream);
+                              float* partial_workspace, float* mix, float* weights, float* out, int out_groups,
+                              int64_t out_anchor_stride, void* workspace, size_t workspace_bytes, void* stream);
 
 
 /* ---- G1/G2: geometric structure embedding --------------------------------------------------------------------------

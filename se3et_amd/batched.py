@@ -98,11 +98,14 @@ def _cross_eq(layer, Pq, Pk, xq, xk):
     A, C = xk.shape[0], q.shape[-1]
     w_v, b_v = att.proj_v.weight, att.proj_v.bias
     vt = torch.baddbmm(b_v[None, :, None].expand(A, C, xk.shape[1]), w_v[None].expand(A, C, C), xk.transpose(1, 2))
-    hidden = torch.zeros_like(q)
+    # few pairs: the key anchors divided over G workgroups whose partial results lie side by side along the channels; the output
+    # projection below adds them (its weight repeated G times along the input dimension)
+    G = _ops.cross_eq_groups(A, Pq.lengths, H, C, Pk.starts, vt) if q.is_contiguous() and k.is_contiguous() else 1
+    hidden = torch.zeros((A, q.shape[1], G * C), dtype=torch.float32, device=q.device)
     mixes, _ = _ops.cross_attention_eq_stack(q, k, vt, Pq.starts, Pq.lengths, Pk.starts, Pk.lengths, H, att.attn_mode,
-                                             att.trace_idx_ori, hidden)
+                                             att.trace_idx_ori, hidden, groups=G)
     al = layer.attention
-    hidden = SF.linear(hidden, al.linear.weight)
+    hidden = SF.linear(hidden, al.linear.weight if G == 1 else _ops.stacked_weight(al.linear.weight, G))
     hidden = SF.add_layer_norm(hidden, xq, al.norm.weight, al.norm.bias, al.norm.eps, hidden_bias=al.linear.bias)
     return layer.output(hidden), mixes
 

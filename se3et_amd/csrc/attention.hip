@@ -17,6 +17,7 @@
 //   cross_eq_apply     out[a] = sum_e W[a, e] softmax_m(S[a, e]) v_e (vanilla_transformer.py:812-818; r_soft collapsed from
 //                      24 rotations to the (A, A) anchor pairs, :506-577,839-845).
 #include <hip/hip_ext.h>
+#include <cstdlib>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -25,6 +26,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -996,6 +998,9 @@ struct CrossEqArgs {
   long long q_sa, k_sa, v_sa;  // anchor strides (floats)
   int v_rs;
   float scale;
+  int G;                       // cross_eq_apply_stack_x6_kernel: key-anchor groups (each writes its partial sum at channel offset g * C)
+  int out_rs;                  //   row stride of its output (G * C) and
+  long long out_sa;            //   anchor stride of its output
 };
 
 // grid (QT, A*A, pairs): partial[(pair*A*A + ae) * QT + qt] = sum over the tile's (n, m) of (mean_h S[a,e,h,n,m])^2
@@ -1176,7 +1181,11 @@ __global__ __launch_bounds__(256) void cross_eq_apply_stack_x6_kernel(CrossEqArg
   __shared__ uint4 ktile[2][2][32][kX6KRow];
   __shared__ uint4 vtile[2][2][64][kX6VRow];
   const int A = p.A, C = p.C;
-  const int pair = blockIdx.z / A, a = blockIdx.z - pair * A;
+  // G > 1 (few pairs: 72 workgroups per pair leave most of the chip idle while every wave walks A * tiles dependent steps): workgroup
+  // (.., g) takes the key anchors [g, g + 1) * A / G and writes ITS weighted sum at channel offset g * C of a (A, Rq, G * C) output; the
+  // output projection that follows adds the groups (stacked weights), no reduction pass and no atomics
+  const int zz = blockIdx.z / p.G, grp = blockIdx.z - zz * p.G;
+  const int pair = zz / A, a = zz - pair * A;
   const StackCloud cl = stack_pick(p.S, pair);
   const int h = blockIdx.y;
   if (blockIdx.x * 128 >= cl.N) return;
@@ -1190,7 +1199,7 @@ __global__ __launch_bounds__(256) void cross_eq_apply_stack_x6_kernel(CrossEqArg
   for (int pc = 0; pc < 2; pc++)
 #pragma unroll
     for (int u = 0; u < 4; u++) qf[pc][u] = __builtin_bit_cast(h2x8_t, X.q[pc][(q_off + (int64_t)nq * C + 16 * u + 8 * half) >> 3]);
-  const int tiles = (cl.M + 31) >> 5, steps = A * tiles;
+  const int tiles = (cl.M + 31) >> 5, steps = (A / p.G) * tiles, base = grp * steps;     // this group's steps: base .. base + steps
   // this thread's share of a tile copy: K: 2 pieces x 32 rows x 8 uint4 = 512 -> 2 per thread; V^T: 2 pieces x 64 rows x 4 uint4 = 512 -> 2
   // Three register sets: the tile of step s + 3 is requested at the start of step s and published (written to LDS) at the end of step
   // s + 2 -- two full steps for the L2 round trip.  With one set (distance 1) a step lasted as long as that round trip (~5 000 cycles for
@@ -1198,7 +1207,7 @@ __global__ __launch_bounds__(256) void cross_eq_apply_stack_x6_kernel(CrossEqArg
   // compiler counts them: an `if` around a load turns every later wait into vmcnt(0).
   u32x4r rk[3][2], rv[3][2];                               // (ext_vector_type: arrays of the HIP uint4 struct end up in scratch)
   auto request = [&](int step, u32x4r (&rk)[2], u32x4r (&rv)[2]) {
-    step = step < steps ? step : steps - 1;
+    step = base + (step < steps ? step : steps - 1);
     const int e = step / tiles, m0 = (step - e * tiles) << 5;
     const int64_t k_off = e * k_piece_sa + (int64_t)cl.k_start * C + h * D;
     const int64_t v_off = e * v_piece_sa + (int64_t)h * D * p.v_rs + cl.k_start + m0;
@@ -1228,7 +1237,7 @@ __global__ __launch_bounds__(256) void cross_eq_apply_stack_x6_kernel(CrossEqArg
   // one step; RS: the register set that is free now (tile step + 3 goes there), PS: the set holding tile step + 1
   auto one_step = [&](int step, u32x4r (&rk_req)[2], u32x4r (&rv_req)[2], const u32x4r (&rk_pub)[2], const u32x4r (&rv_pub)[2]) {
     const int buf = step & 1;
-    const int e = step / tiles, tile = step - e * tiles, m0 = tile << 5;
+    const int e = (base + step) / tiles, tile = base + step - e * tiles, m0 = tile << 5;
     request(step + 3, rk_req, rv_req);
     if (active && step < steps) {
       // two accumulators, consecutive MFMAs alternate between them
@@ -1318,7 +1327,7 @@ __global__ __launch_bounds__(256) void cross_eq_apply_stack_x6_kernel(CrossEqArg
   // o[dt][r] = O^T[d = 32 dt + (r & 3) + 8 (r >> 2) + 4 half][query c32]: four consecutive d per (dt, g) -> one float4 per lane
   const int nrow = n0 + c32;
   if (nrow < cl.N) {
-    float* op = out + ((size_t)a * p.q_sa) + ((size_t)cl.q_start + nrow) * C + h * D;
+    float* op = out + ((size_t)a * p.out_sa) + ((size_t)cl.q_start + nrow) * p.out_rs + grp * C + h * D;
 #pragma unroll
     for (int dt = 0; dt < 2; dt++)
 #pragma unroll
@@ -2084,6 +2093,74 @@ __global__ __launch_bounds__(256) void gram_stack_kernel(const float* __restrict
     for (int r = 0; r < 4; r++)
       *reinterpret_cast<f32x4*>(o + (int64_t)(4 * (4 * kq + r) + ea) * C) = f32x4{acc[ea][0][r], acc[ea][1][r], acc[ea][2][r], acc[ea][3][r]};
 }
+// The same product in 32 x 32 blocks per wave (a float2 per lane and operand feeds 4 MFMAs): 4x as many waves with a quarter of the
+// dependent MFMA chain each.  One pair per forward has 24 workgroups of the kernel above (232 compute units idle, 35 us: one wave's chain of
+// 24 x 64 f32 MFMAs plus the exposed load latency); with a single wave per SIMD nothing else hides the L2 round trip, so the rows are
+// requested three iterations (48 rows) ahead in a ring of four register sets.
+template <int C>
+__global__ __launch_bounds__(256) void gram_stack32_kernel(const float* __restrict__ x, int64_t anchor_stride, GramPairs P, float* __restrict__ out) {
+  constexpr int KS = 4, NT = C / 32;
+  const int ap = blockIdx.x, a = ap / P.n, p = ap - a * P.n;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, kq = lane >> 4;
+  // G is symmetric: only the NT (NT + 1) / 2 blocks with ti <= tj are computed, the others are their transposes (stored below)
+  int t = blockIdx.y * 4 + wave, ti = 0;
+  if (t >= NT * (NT + 1) / 2) return;
+  while (t >= NT - ti) {
+    t -= NT - ti;
+    ti++;
+  }
+  const int tj = ti + t, i0 = ti * 32, j0 = tj * 32;
+  const int start = P.start[p], len = P.length[p];
+  const float* xr = x + a * anchor_stride + (int64_t)start * C;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int ea = 0; ea < 2; ea++)
+#pragma unroll
+    for (int eb = 0; eb < 2; eb++) acc[ea][eb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](int it, f32x2 (&av)[KS], f32x2 (&bv)[KS]) {           // unconditional loads (row clamped), rows past the end -> zeros
+#pragma unroll
+    for (int u = 0; u < KS; u++) {
+      const int row = it * 4 * KS + 4 * u + kq;
+      const float keep = row < len ? 1.f : 0.f;
+      const float* r = xr + (int64_t)(row < len ? row : 0) * C;
+      const f32x2 va = *reinterpret_cast<const f32x2*>(r + i0 + 2 * c), vb = *reinterpret_cast<const f32x2*>(r + j0 + 2 * c);
+      av[u] = f32x2{va[0] * keep, va[1] * keep};
+      bv[u] = vb;
+    }
+  };
+  f32x2 ra[4][KS], rb[4][KS];
+  fetch(0, ra[0], rb[0]);
+  fetch(1, ra[1], rb[1]);
+  fetch(2, ra[2], rb[2]);
+  const int iters = (len + 4 * KS - 1) / (4 * KS);
+  for (int it = 0; it < iters; it += 4) {                                 // (the last group may run up to 3 iterations on zeros)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      fetch(it + j + 3, ra[(j + 3) & 3], rb[(j + 3) & 3]);
+#pragma unroll
+      for (int u = 0; u < KS; u++)
+#pragma unroll
+        for (int ea = 0; ea < 2; ea++)
+#pragma unroll
+          for (int eb = 0; eb < 2; eb++)
+            acc[ea][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[j][u][ea], rb[j][u][eb], acc[ea][eb], 0, 0, 0);
+    }
+  }
+  // acc[ea][eb][r] = G[i0 + 2 (4 kq + r) + ea][j0 + 2 c + eb]: the two eb of a lane are 8 contiguous bytes
+  float* o = out + ((int64_t)ap * C + i0) * C + j0 + 2 * c;
+#pragma unroll
+  for (int ea = 0; ea < 2; ea++)
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      *reinterpret_cast<f32x2*>(o + (int64_t)(2 * (4 * kq + r) + ea) * C) = f32x2{acc[ea][0][r], acc[ea][1][r]};
+  if (ti == tj) return;
+  float* ot = out + ((int64_t)ap * C + j0 + 2 * c) * C + i0;             // G[j0 + 2 c + eb][i0 + 2 (4 kq + r) + ea]
+#pragma unroll
+  for (int eb = 0; eb < 2; eb++)
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      *reinterpret_cast<f32x2*>(ot + (int64_t)eb * C + 2 * (4 * kq + r)) = f32x2{acc[0][eb][r], acc[1][eb][r]};
+}
 }  // namespace
 
 extern "C" int se3_gram_stack(const float* x, int num_anchors, int C, int64_t anchor_stride, const int64_t* starts, const int64_t* lengths,
@@ -2097,6 +2174,16 @@ extern "C" int se3_gram_stack(const float* x, int num_anchors, int C, int64_t an
     SE3_REQUIRE(starts[p] >= 0 && lengths[p] >= 1, SE3_ERR_INVALID_ARG, "gram_stack: pair %d rows", p);
     P.start[p] = (int)starts[p];
     P.length[p] = (int)lengths[p];
+  }
+  static const int forced = getenv("SE3_GRAM_TILE") ? atoi(getenv("SE3_GRAM_TILE")) : 0;
+  const bool small = forced ? forced == 32 : num_anchors * num_pairs * (C / 64) <= 192;
+  if (small) {
+    const int NT = C / 32;
+    const dim3 grid((unsigned)(num_anchors * num_pairs), (unsigned)((NT * (NT + 1) / 2 + 3) / 4));
+    if (C == 256) gram_stack32_kernel<256><<<grid, 256, 0, (hipStream_t)stream>>>(x, anchor_stride, P, out);
+    else gram_stack32_kernel<128><<<grid, 256, 0, (hipStream_t)stream>>>(x, anchor_stride, P, out);
+    SE3_CHECK_LAUNCH("gram_stack");
+    return SE3_OK;
   }
   const dim3 grid((unsigned)(num_anchors * num_pairs), (unsigned)(C / 64));
   if (C == 256) gram_stack_kernel<256><<<grid, 256, 0, (hipStream_t)stream>>>(x, anchor_stride, P, out);
@@ -2202,15 +2289,19 @@ extern "C" int se3_cross_eq_stack_x6_fwd(const float* q, const float* k, const f
                                          int A, int C, int H, int64_t q_rows, int64_t k_rows, int64_t q_anchor_stride,
                                          int64_t k_anchor_stride, int v_row_stride, int64_t v_anchor_stride, int mode,
                                          const int64_t* trace_idx, int num_rotations, int sums_given, float* partial_workspace,
-                                         float* mix, float* weights, float* out, void* workspace, size_t workspace_bytes,
-                                         void* stream) {
+                                         float* mix, float* weights, float* out, int out_groups, int64_t out_anchor_stride,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  SE3_REQUIRE(out_groups >= 1 && A >= 1 && A % out_groups == 0, SE3_ERR_INVALID_ARG, "cross_eq_stack_x6: %d groups of %d key anchors", out_groups, A);
   bool ok = workspace != nullptr && H >= 1 && C % H == 0 && C / H == 64 && A >= 1 && A <= 6 && v_row_stride % 16 == 0 && sums_given &&
             num_pairs >= 1 && num_pairs <= kMaxClouds && k_starts != nullptr && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
   for (int c = 0; ok && c < num_pairs; c++) ok = k_starts[c] % 16 == 0;
-  if (!ok)
+  if (!ok) {
+    SE3_REQUIRE(out_groups == 1 && out_anchor_stride == q_anchor_stride, SE3_ERR_UNSUPPORTED,
+                "cross_eq_stack_x6: key-anchor groups / an output stride of its own need the f16 form (head dimension 64, aligned key starts)");
     return se3_cross_eq_stack_fwd(q, k, vt, q_starts, q_lengths, k_starts, k_lengths, num_pairs, A, C, H, q_anchor_stride, k_anchor_stride,
                                   v_row_stride, v_anchor_stride, mode, trace_idx, num_rotations, sums_given, partial_workspace, mix,
                                   weights, out, stream);
+  }
   SE3_REQUIRE(q && k && vt && q_starts && q_lengths && k_lengths && partial_workspace && mix && weights && out, SE3_ERR_INVALID_ARG,
               "cross_eq_stack_x6: null pointer");
   SE3_REQUIRE(workspace_bytes >= se3_cross_eq_x6_workspace_bytes(A, q_rows, k_rows, C, v_row_stride), SE3_ERR_WORKSPACE,
@@ -2232,6 +2323,7 @@ extern "C" int se3_cross_eq_stack_x6_fwd(const float* q, const float* k, const f
   p.A = A; p.C = C; p.H = H; p.QT = qt;
   p.q_sa = q_anchor_stride; p.k_sa = k_anchor_stride; p.v_sa = v_anchor_stride; p.v_rs = v_row_stride;
   p.scale = 1.0f / sqrtf((float)(C / H));
+  p.G = out_groups; p.out_rs = out_groups * C; p.out_sa = out_anchor_stride;
   hipStream_t st = (hipStream_t)stream;
   const size_t nq = (size_t)A * q_rows * C / 8, nk = (size_t)A * k_rows * C / 8, nv = (size_t)A * C * v_row_stride / 8;     // uint4 per piece
   uint4* wq = static_cast<uint4*>(workspace);
@@ -2249,7 +2341,7 @@ extern "C" int se3_cross_eq_stack_x6_fwd(const float* q, const float* k, const f
   }
   cross_eq_mix_kernel<<<(unsigned)num_pairs, 64, 0, st>>>(partial_workspace, 1, 0.f, A, num_rotations, trace_idx, mode, mix, weights, nullptr,
                                                        p.S, 1);
-  cross_eq_apply_stack_x6_kernel<<<dim3((unsigned)((qt + 3) / 4), (unsigned)H, (unsigned)(A * num_pairs)), 256, 0, st>>>(
+  cross_eq_apply_stack_x6_kernel<<<dim3((unsigned)((qt + 3) / 4), (unsigned)H, (unsigned)(A * num_pairs * out_groups)), 256, 0, st>>>(
       p, X, (int64_t)q_rows * C, (int64_t)k_rows * C, (int64_t)C * v_row_stride, mix, out);
   SE3_CHECK_LAUNCH("cross_eq_stack_x6");
   return SE3_OK;

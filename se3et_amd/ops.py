@@ -55,15 +55,19 @@ class _Shared:
     threads of `--inflight N`, one HIP stream each).  A reader on another stream waits -- on the GPU, not the host -- for the event recorded
     behind the kernels that fill them, and tells the caching allocator that its stream uses the memory too.  (Without this the second
     thread's first GEMM could read weight pieces the first thread's split kernel had not written yet.)"""
-    __slots__ = ('tensors', 'stream', 'event')
+    __slots__ = ('tensors', 'stream', 'event', 'raw')
 
     def __init__(self, *tensors):
         self.tensors = tensors
         self.stream = torch.cuda.current_stream()
         self.event = torch.cuda.Event()
         self.event.record(self.stream)
+        self.raw = self.stream.cuda_stream
 
     def get(self):
+        raw = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+        if raw is not None and raw(self.stream.device.index) == self.raw and torch.cuda.current_device() == self.stream.device.index:
+            return self.tensors                              # the builder's own stream: nothing to wait for (and 2.6 us less host time)
         cur = torch.cuda.current_stream()
         if cur != self.stream:
             if not self.event.query():
@@ -88,6 +92,26 @@ def _linear_weight_pieces(weight, stream):
             _linear_piece_cache.clear()
         _linear_piece_cache[key] = (weakref.ref(weight), weight._version, _Shared(Wp))
     return Wp
+
+
+_stacked_weight_cache = {}
+
+
+def stacked_weight(weight, groups):
+    """(N, K) -> (N, groups * K): the weight repeated along its input dimension, so that a dense layer applied to `groups` partial results
+    laid side by side along the channels returns the layer of their SUM (cross_attention_eq_stack with key-anchor groups).  Kept per weight
+    version like the f16 pieces."""
+    key = (weight.data_ptr(), tuple(weight.shape), int(groups), weight.device.index)
+    hit = _stacked_weight_cache.get(key)
+    if hit is not None and hit[0]() is not None and hit[1] == weight._version:
+        return hit[2].get()[0]
+    with torch.no_grad():
+        W = torch.cat([weight.detach()] * int(groups), 1).contiguous()
+    with _TIMING_LOCK:
+        if len(_stacked_weight_cache) > 128:
+            _stacked_weight_cache.clear()
+        _stacked_weight_cache[key] = (weakref.ref(weight), weight._version, _Shared(W))
+    return W
 
 
 def linear_f16_ok(x, weight):
@@ -664,6 +688,7 @@ def _kpconv_weight_pieces(weights, Cin, Cout, stream):
 def clear_weight_caches():
     _weight_piece_cache.clear()
     _linear_piece_cache.clear()
+    _stacked_weight_cache.clear()
 
 
 def kpconv_slot_sums(x, q_pts, s_pts, idx, kernel_points, kidx, ridx, sigma):
@@ -1128,17 +1153,35 @@ def _gram_per_pair(x, starts, lengths):
     return torch.bmm(win.transpose(1, 2), win).view(A, P, C, C)
 
 
-def cross_attention_eq_stack(q, k, vt, q_starts, q_lengths, k_starts, k_lengths, num_heads, mode, trace_idx, out):
+def cross_eq_groups(A, q_lengths, num_heads, C, k_starts, vt):
+    """Key-anchor groups of cross_attention_eq_stack for this call: with few pairs one workgroup per (128 queries, head, anchor) leaves
+    most compute units idle while every wave walks A x key-tiles dependent steps, so the key anchors are divided over 3 (or 2) workgroups
+    whose partial results lie side by side along the channels of the output.  1 = the plain form."""
+    H = int(num_heads)
+    if not CROSS_EQ_BF16X6 or C // H != 64 or C % H or A > 6 or vt.stride(1) % 16 or vt.stride(2) != 1 or any(int(s) % 16 for s in k_starts):
+        return 1
+    wgs = sum((int(n) + 127) // 128 for n in q_lengths) * H * A
+    for G in (3, 2):
+        if A % G == 0 and wgs * G <= 320:
+            return G
+    return 1
+
+
+def cross_attention_eq_stack(q, k, vt, q_starts, q_lengths, k_starts, k_lengths, num_heads, mode, trace_idx, out, groups=1):
     """HIP: equivariant cross attention of all pairs of a batch (se3_cross_eq_stack_fwd).  q (A, Rq, C), k (A, Rk, C) packed rows,
     vt (A, C, Rk) transposed values, out (A, Rq, C) (rows outside the pairs are left untouched).  Returns the per-pair mixing
-    matrices (P, A, A) and weights (P, A*A) ('a_soft') / (P, R) ('r_soft')."""
+    matrices (P, A, A) and weights (P, A*A) ('a_soft') / (P, R) ('r_soft').  groups = G > 1 (cross_eq_groups): out (A, Rq, G * C)
+    contiguous, the result is the sum of its G channel blocks (the caller folds it into the next dense layer: stacked_weight)."""
     q = _req(q, torch.float32, 'q', 3)
     k = _req(k, torch.float32, 'k', 3)
     vt = _req(vt, torch.float32, 'vt', 3)
     out = _req(out, torch.float32, 'out', 3)
     A, Rq, C = q.shape
-    if k.shape[0] != A or k.shape[2] != C or tuple(vt.shape[:2]) != (A, C) or out.shape != q.shape:
+    groups = int(groups)
+    if k.shape[0] != A or k.shape[2] != C or tuple(vt.shape[:2]) != (A, C) or tuple(out.shape) != (A, Rq, groups * C):
         raise RuntimeError('cross_attention_eq_stack: shapes q %s k %s vt %s out %s' % (tuple(q.shape), tuple(k.shape), tuple(vt.shape), tuple(out.shape)))
+    if groups > 1 and not (CROSS_EQ_BF16X6 and out.is_contiguous()):
+        raise RuntimeError('cross_attention_eq_stack: key-anchor groups need the f16 form and a contiguous output')
     if mode not in ('a_soft', 'r_soft'):
         raise RuntimeError('cross_attention_eq_stack: mode %r' % (mode,))
     P = len(q_starts)
@@ -1171,8 +1214,11 @@ def cross_attention_eq_stack(q, k, vt, q_starts, q_lengths, k_starts, k_lengths,
                                               _i64_array(k_starts), _i64_array(k_lengths), P, A, C, int(num_heads), Rq, k.shape[1],
                                               q.stride(0), k.stride(0), vt.stride(1), vt.stride(0), 0 if mode == 'a_soft' else 1,
                                               trace_idx.data_ptr(), R, 1, partial.data_ptr(), mix.data_ptr(), weights.data_ptr(),
-                                              out.data_ptr(), ws.data_ptr(), ws.numel(), stream), 'se3_cross_eq_stack_x6_fwd')
+                                              out.data_ptr(), groups, out.stride(0), ws.data_ptr(), ws.numel(), stream),
+              'se3_cross_eq_stack_x6_fwd')
         return mix, weights
+    if groups > 1:
+        raise RuntimeError('cross_attention_eq_stack: key-anchor groups with strided q / k rows')
     check(lib().se3_cross_eq_stack_fwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(), _i64_array(q_starts), _i64_array(q_lengths),
                                        _i64_array(k_starts), _i64_array(k_lengths), P, A, C, int(num_heads), q.stride(0), k.stride(0),
                                        vt.stride(1), vt.stride(0), 0 if mode == 'a_soft' else 1, trace_idx.data_ptr(), R, 1,

@@ -764,6 +764,19 @@ def test_cross_attention_eq_stack_bf16x6_matches_the_single_pair_kernels(lengths
         want, want_w, want_mix = SF.cross_attention_eq(q[:, s0:s0 + n].contiguous(), k[:, t0:t0 + m].contiguous(), vt1, H, mode, trace)
         assert_close(outs['bf16x6'][0][:, s0:s0 + n], want, 2e-5, 'pair %d hidden' % p)
         assert_close(outs['bf16x6'][1][p], want_mix, 1e-5, 'pair %d mix' % p)
+    # key-anchor groups (what cross_eq_groups picks for few pairs, and every divisor of A): G partial sums side by side along the channels
+    picked = ops.cross_eq_groups(A, [n for n, _ in lengths], H, C, k_starts, vt)
+    assert picked == 3          # (all three cases are small: 72 workgroups or fewer without groups)
+    assert ops.cross_eq_groups(A, [382] * 8, H, C, [416 * i for i in range(8)], vt) == 1          # the bench batch fills the chip as it is
+    for G in (2, 3, 6):
+        out = torch.full((A, rq, G * C), float('nan'), device='cuda')
+        mix, w = ops.cross_attention_eq_stack(q, k, vt, q_starts, [n for n, _ in lengths], k_starts, [m for _, m in lengths], H, mode, trace, out, groups=G)
+        assert torch.equal(mix, outs['bf16x6'][1]) and torch.equal(w, outs['bf16x6'][2])
+        for (n, m), s0 in zip(lengths, q_starts):
+            got = out[:, s0:s0 + n].view(A, n, G, C).sum(2)
+            assert_close(got, outs['bf16x6'][0][:, s0:s0 + n], 2e-6, '%d key-anchor groups' % G)
+    W = torch.randn(64, C, generator=g).cuda()
+    assert torch.equal(ops.stacked_weight(W, 3), torch.cat([W, W, W], 1)) and ops.stacked_weight(W, 3) is ops.stacked_weight(W, 3)
 
 
 @pytest.mark.parametrize('rows,K,N,bias,relu', [(4096, 256, 256, True, False), (5000, 32, 64, False, False), (2049, 1024, 256, True, True),
@@ -965,12 +978,13 @@ def test_kpconv_neighbor_table_is_shared_only_for_the_same_geometry():
 
 
 @pytest.mark.parametrize('C', [256, 128])
-def test_gram_stack_kernel_matches_the_library_path(C):
+@pytest.mark.parametrize('lengths', [[382, 350, 13, 129], [382], [75, 402], [33, 1]])
+def test_gram_stack_kernel_matches_the_library_path(C, lengths):
     """csrc/attention.hip gram_stack_kernel (X_p^T X_p per anchor and pair straight from the packed rows) against index_select + mask +
-    batched GEMM, ragged lengths incl. one that is not a multiple of the 8-row step."""
+    batched GEMM, ragged lengths incl. one that is not a multiple of the 8-row step; one or two pairs run the 32 x 32-block kernel (four times
+    as many waves with a quarter of the MFMA chain each), four pairs the 64 x 64 one."""
     from se3et_amd import ops
     g = torch.Generator().manual_seed(C)
-    lengths = [382, 350, 13, 129]
     starts, r = [], 0
     for n in lengths:
         starts.append(r)
@@ -985,3 +999,4 @@ def test_gram_stack_kernel_matches_the_library_path(C):
     ref = torch.stack([torch.stack([x[a, s:s + n].double().t() @ x[a, s:s + n].double() for s, n in zip(starts, lengths)]) for a in range(6)])
     e_new, e_lib = float((got.double() - ref).abs().max()), float((want.double() - ref).abs().max())
     assert e_new <= max(2 * e_lib, 2e-6 * float(ref.abs().max())), (e_new, e_lib)
+    assert torch.equal(ops._gram_per_pair(x, starts, lengths), got)
