@@ -586,13 +586,18 @@ def run_single_pair(model, cfg, args, dev, feats_unused):
             raise failed[0]
 
     variants = {}
-    for name, fn in (('pyramid_prefetched', pipelined), ('three_in_flight', concurrent)):
-        fn()                                  # warm-up (per-stream workspaces, caches)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        fn()
-        torch.cuda.synchronize()
-        variants[name] = round(args.single_pair_steps / (time.perf_counter() - t1), 2)
+    keep_interval = sys.getswitchinterval()
+    sys.setswitchinterval(float(os.environ.get('SE3_BENCH_SP_SWITCH', '1e-4')))    # host threads issuing ~500 launches of ~10 us each per pair
+    try:
+        for name, fn in (('pyramid_prefetched', pipelined), ('three_in_flight', concurrent)):
+            fn()                                  # warm-up (per-stream workspaces, caches)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            variants[name] = round(args.single_pair_steps / (time.perf_counter() - t1), 2)
+    finally:
+        sys.setswitchinterval(keep_interval)
     syncs = [0]
     with warnings.catch_warnings():
         warnings.simplefilter('always')
@@ -626,7 +631,9 @@ def run_single_pair(model, cfg, args, dev, feats_unused):
             'pairs_per_s_pyramid_prefetched': variants['pyramid_prefetched'], 'pairs_per_s_three_in_flight': variants['three_in_flight'],
             'note': 'one pair per forward incl. on-GPU pyramid and LGR, forwards strictly one after the other; host_ms = wall time per pair '
                     'not covered by kernel time.  pyramid_prefetched: the pyramid of the next pair built by a worker thread on its own stream '
-                    '(the reference builds it in DataLoader workers); three_in_flight: three one-pair forwards at a time on three streams'}
+                    '(the reference builds it in DataLoader workers); three_in_flight: three one-pair forwards at a time on three streams.  '
+                    'Neither helps: one pair per forward is bound by the host (about 500 launches of 10-20 us each from one Python '
+                    'interpreter), which more host threads only contend for -- stack pairs (the headline configuration) instead'}
 
 
 def run_cpu_baseline(model, cfg, args):
