@@ -587,7 +587,7 @@ def run_single_pair(model, cfg, args, dev, feats_unused):
 
     variants = {}
     keep_interval = sys.getswitchinterval()
-    sys.setswitchinterval(float(os.environ.get('SE3_BENCH_SP_SWITCH', '1e-4')))    # host threads issuing ~500 launches of ~10 us each per pair
+    sys.setswitchinterval(1e-4)                  # host threads issuing ~500 launches of ~10 us each per pair (1e-3 and 1e-5 measured no better)
     try:
         for name, fn in (('pyramid_prefetched', pipelined), ('three_in_flight', concurrent)):
             fn()                                  # warm-up (per-stream workspaces, caches)

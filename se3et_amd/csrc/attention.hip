@@ -17,7 +17,6 @@
 //   cross_eq_apply     out[a] = sum_e W[a, e] softmax_m(S[a, e]) v_e (vanilla_transformer.py:812-818; r_soft collapsed from
 //                      24 rotations to the (A, A) anchor pairs, :506-577,839-845).
 #include <hip/hip_ext.h>
-#include <cstdlib>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -2175,8 +2174,9 @@ extern "C" int se3_gram_stack(const float* x, int num_anchors, int C, int64_t an
     P.start[p] = (int)starts[p];
     P.length[p] = (int)lengths[p];
   }
-  static const int forced = getenv("SE3_GRAM_TILE") ? atoi(getenv("SE3_GRAM_TILE")) : 0;
-  const bool small = forced ? forced == 32 : num_anchors * num_pairs * (C / 64) <= 192;
+  // 32 x 32 blocks per wave up to 8 pairs (A = 6, C = 256: 14.7 / 15.4 / 25.5 us at 1 / 4 / 8 pairs against 34.6 / 35.0 / 36.9 us for the
+  // 64 x 64 kernel, tools/micro/gram_tiles.py); beyond that the 64 x 64 kernel's fewer loads per MFMA win
+  const bool small = num_anchors * num_pairs * (C / 64) <= 192;
   if (small) {
     const int NT = C / 32;
     const dim3 grid((unsigned)(num_anchors * num_pairs), (unsigned)((NT * (NT + 1) / 2 + 3) / 4));

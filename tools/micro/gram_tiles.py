@@ -1,15 +1,14 @@
-"""gram_stack at one pair and at eight pairs per forward, 64 x 64 blocks per wave against 32 x 32 (SE3_GRAM_TILE=64 / 32 forces one):
-python tools/micro/gram_tiles.py"""
-import os, subprocess, sys
-R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-if len(sys.argv) == 1:
-    for tile in ('64', '32'):
-        subprocess.run([sys.executable, __file__, tile], env=dict(os.environ, SE3_GRAM_TILE=tile), check=True)
-    sys.exit(0)
-sys.path.insert(0, R)
+"""gram_stack by pair count (A = 6, C = 256): python tools/micro/gram_tiles.py
+se3_gram_stack takes the kernel with 32 x 32 blocks per wave over the upper triangle up to 8 pairs and the one with 64 x 64 blocks beyond.
+Measured when the choice was made (one MI355X box; the 64 x 64 kernel forced for the first row):
+  64 x 64 blocks:                         1 pair 34.6 us   2 pairs 34.3   4 pairs 35.0   8 pairs 36.9
+  32 x 32 blocks, all 64 of them:         1 pair 14.4 us   2 pairs 14.5   4 pairs 24.1   8 pairs 34.5
+  32 x 32 blocks, upper triangle (kept):  1 pair 14.7 us   2 pairs 14.6   4 pairs 15.4   8 pairs 25.5"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from se3et_amd import ops
-for P in (1, 2, 4, 8):
+for P in (1, 2, 4, 8, 16):
     lengths = [382 - 7 * p for p in range(P)]; starts, r = [], 0
     for n in lengths: starts.append(r); r += (n + 31) // 32 * 32
     x = torch.randn(6, r, 256, device='cuda')
@@ -20,4 +19,4 @@ for P in (1, 2, 4, 8):
     for _ in range(50): f()
     e1.record(); torch.cuda.synchronize()
     ref = torch.stack([torch.stack([x[a, s:s + n].double().t() @ x[a, s:s + n].double() for s, n in zip(starts, lengths)]) for a in range(6)])
-    print('tile %s  pairs %d  %.1f us  max err %.1e' % (sys.argv[1], P, e0.elapsed_time(e1) * 20, float((f().double() - ref).abs().max() / ref.abs().max())))
+    print('pairs %2d  %.1f us  max err %.1e' % (P, e0.elapsed_time(e1) * 20, float((f().double() - ref).abs().max() / ref.abs().max())))
