@@ -455,6 +455,15 @@ int se3_point_to_node_partition_stack(const float* points, const float* nodes, c
                                       const int64_t* node_lengths, int num_clouds, int limit, int64_t* point_to_node,
                                       uint8_t* node_masks, int64_t* node_knn_indices, uint8_t* node_knn_masks, void* stream);
 
+/* ---- E1: pairwise squared distances ---------------------------------------------------------------------------------
+ * Replaces pairwise_distance (geotransformer/modules/ops/pairwise_distance.py:4-30, channel-last form): x (batch, N, C), y (batch, M, C)
+ * with unit channel stride, row stride C and the given batch strides (floats; 0 = the same rows for every batch); out (batch, N, M)
+ * contiguous = max(|x_n|^2 - 2 x_n.y_m + |y_m|^2, 0), or max(2 - 2 x_n.y_m, 0) with normalized != 0 (unit vectors).  Any C >= 1 (C = 3:
+ * point coordinates), batch <= 65535; f32 matrix cores.  (The superpoint scores and the point-to-node partition have the distance
+ * matrix fused into their own kernels: E2, E3.) */
+int se3_pairwise_distance(const float* x, const float* y, int64_t batch, int N, int M, int C, int64_t x_batch_stride,
+                          int64_t y_batch_stride, int normalized, float* out, void* stream);
+
 /* ---- E2: superpoint matching scores --------------------------------------------------------------------------------
  * Replaces the score part of SuperPointMatching.forward (geotransformer/modules/geotransformer/superpoint_matching.py:31-39):
  * scores[n, m] = exp(-clamp(2 - 2 ref[n].src[m], 0)), optionally dual-normalised (S / rowsum * S / colsum).

@@ -67,6 +67,7 @@ SIGNATURES = {
     'se3_cross_eq_mix': (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     'se3_cross_eq_x6_workspace_bytes': (_sz, [_i32, _i64, _i64, _i32, _i32]),
     'se3_cross_eq_stack_x6_fwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _i64, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _sz, _vp]),
+    'se3_pairwise_distance': (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i64, _i64, _i32, _vp, _vp]),
     'se3_gram_stack': (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _i32, _vp, _vp]),
     'se3_gram_frobenius': (_i32, [_vp, _vp, _i32, _i32, _i64, _f32, _vp, _vp]),
     'se3_cross_eq_stack_fwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _i64, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),

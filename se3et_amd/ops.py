@@ -334,6 +334,22 @@ def log_optimal_transport_bwd(grad_out, scores, row_masks, col_masks, alpha, num
     return ds, da.sum().reshape(alpha.shape)
 
 
+def pairwise_distance(x, y, normalized=False):
+    """HIP (csrc/pairwise_distance.hip): squared distances (*, N, M) of x (*, N, C) and y (*, M, C), clamped at 0."""
+    x = _req(x.contiguous(), torch.float32, 'x')
+    y = _req(y.contiguous(), torch.float32, 'y')
+    if x.dim() < 2 or x.dim() != y.dim() or x.shape[:-2] != y.shape[:-2] or x.shape[-1] != y.shape[-1]:
+        raise RuntimeError('pairwise_distance: shapes %s and %s' % (tuple(x.shape), tuple(y.shape)))
+    N, M, C = x.shape[-2], y.shape[-2], x.shape[-1]
+    batch = x.numel() // max(N * C, 1) if N * C else 0
+    out = torch.empty(x.shape[:-2] + (N, M), dtype=torch.float32, device=x.device)
+    if C == 0:
+        return out.zero_()
+    check(lib().se3_pairwise_distance(x.data_ptr(), y.data_ptr(), batch, N, M, C, N * C, M * C, 1 if normalized else 0, out.data_ptr(), _stream()),
+          'se3_pairwise_distance')
+    return out
+
+
 def add_layer_norm(hidden, residual, weight, bias, eps, hidden_bias=None):
     """HIP (csrc/rowops.hip): LayerNorm(hidden [+ hidden_bias] + residual); residual may lack leading (anchor) dims of hidden;
     hidden_bias (C,) is the bias of the linear layer that produced hidden (its GEMM then runs bias-free)."""

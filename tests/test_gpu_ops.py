@@ -522,6 +522,43 @@ def test_pairwise_distance_matches_reference_formula():
     assert float(pairwise_distance(xn.cuda(), xn.cuda(), normalized=True).min()) >= 0.0          # clamped: no negative round-off on the diagonal
 
 
+@pytest.mark.parametrize('shape', [((), 382, 350, 256), ((), 5000, 382, 3), ((2,), 65, 64, 3), ((3, 2), 17, 130, 20), ((), 1, 1, 1),
+                                   ((4,), 128, 65, 7), ((), 0, 5, 3), ((), 700, 1, 32)])
+@pytest.mark.parametrize('normalized', [False, True])
+def test_pairwise_distance_kernel_matches_oracle(shape, normalized):
+    """csrc/pairwise_distance.hip against the oracle's restatement of pairwise_distance.py:4-30 (which is pinned to the reference by the
+    model fixtures) and against a float64 evaluation: superpoint features (C = 256), point coordinates (C = 3: the scalar-load
+    instantiation), batch dimensions, sizes that are not multiples of the 64 x 64 block, empty and single-row inputs; the gradient path
+    stays on the reference formula."""
+    from oracle import se3et_oracle as O
+    from se3et_amd import ops
+    from se3et_amd.modules.ops import pairwise_distance
+    batch, N, M, C = shape
+    g = torch.Generator().manual_seed(N * 7 + M + C)
+    x, y = torch.randn(batch + (N, C), generator=g), torch.randn(batch + (M, C), generator=g)
+    if normalized:
+        x, y = torch.nn.functional.normalize(x, dim=-1), torch.nn.functional.normalize(y, dim=-1)
+    got = pairwise_distance(x.cuda(), y.cuda(), normalized=normalized)
+    assert tuple(got.shape) == batch + (N, M)
+    if N == 0:
+        return
+    want = O.pairwise_distance(x, y, normalized=normalized)
+    ref = ((x.double()[..., :, None, :] - y.double()[..., None, :, :]) ** 2).sum(-1)
+    scale = float(ref.abs().max())
+    assert float((got.cpu() - want).abs().max()) <= 1e-5 * scale
+    # not further from the exact distances than the reference formula in float32 (plus a rounding of the largest term)
+    e_new, e_ref = float((got.cpu().double() - ref).abs().max()), float((want.double() - ref).abs().max())
+    assert e_new <= 2 * e_ref + 4e-7 * scale, (e_new, e_ref)
+    assert float(got.min()) >= 0.0
+    if N > 1 and not batch:
+        torch.cuda.synchronize()
+        assert torch.equal(ops.pairwise_distance(x.cuda(), y.cuda(), normalized), got)                       # same launch, same bits
+        xg = x.cuda().requires_grad_(True)                                                                   # losses differentiate through it
+        d = pairwise_distance(xg, y.cuda(), normalized=normalized)
+        d.sum().backward()
+        assert xg.grad is not None and float((d.detach() - got).abs().max()) <= 1e-5 * scale
+
+
 def test_key_masks_take_the_minus_infinity_path():
     """memory_masks / key_masks (True = masked; -inf logits in the reference, rpe_transformer.py:114-119, vanilla_transformer.py:66-67)
     on the invariant RPE layer (incl. the returned score tensor) and on plain cross attention, against the oracle."""
