@@ -311,6 +311,7 @@ def main():
     timings, se3_ops.KERNEL_TIMINGS = se3_ops.KERNEL_TIMINGS, None
 
     roofline = collect_roofline(se3_lib, timings, args)
+    roofline_kpconv = collect_kpconv_roofline(timings)
     # The same kernels with nothing else on the GPU: by default other batches (--inflight) or the next batch's pyramid (--prefetch 1) run on
     # other streams BESIDE the timed kernels, which lengthens them; a few extra steps with one batch in flight (after the timed region)
     # give the kernels' own rate.
@@ -322,6 +323,9 @@ def main():
         torch.cuda.synchronize()
         quiet_timings, se3_ops.KERNEL_TIMINGS = se3_ops.KERNEL_TIMINGS, None
         quiet = collect_roofline(se3_lib, quiet_timings, args)
+        quiet_kp = collect_kpconv_roofline(quiet_timings)
+        if roofline_kpconv is not None and quiet_kp is not None:
+            roofline_kpconv['quiet'] = {k: quiet_kp[k] for k in ('achieved', 'frac', 'launches', 'avg_us', 'f32_equivalent_tflops')}
         roofline['quiet'] = {k: quiet[k] for k in ('achieved', 'frac', 'launches', 'avg_us', 'rpe_bias_kernel_avg_us', 'attention_kernel_avg_us',
                                                    'eq_call_avg_us', 'inv_call_avg_us')}
         roofline['quiet']['note'] = ('same kernels, same shapes, %d extra step(s) after the timed region with ONE batch in flight and no other '
@@ -356,11 +360,34 @@ def main():
                        'variant': args.variant, 'pair_preset': args.pair, 'sharding': 'pairs round-robin over ranks, no collective',
                        'pairs_per_forward': PB, 'batches_in_flight_per_gpu': max(1, args.inflight), 'pyramid_prefetch': bool(args.prefetch),
                        'attention_dtype': args.attention_dtype},
-            'roofline': roofline, 'cpu_baseline': cpu_baseline, 'single_pair': single_pair, 'train_step': train,
+            'roofline': roofline, 'roofline_kpconv': roofline_kpconv, 'cpu_baseline': cpu_baseline, 'single_pair': single_pair, 'train_step': train,
         }
         print(json.dumps(line), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+
+
+MFMA_F16_PEAK_TFLOPS = 2500.0        # dense f16 / bf16 matrix-core peak of one MI355X (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def collect_kpconv_roofline(timings):
+    """The largest kernel family by time (21 % of a step) is matrix-core bound, not HBM bound: kpconv_fused_kernel, one launch per KPConv
+    layer.  Event pair around every launch (se3et_amd/ops.py); the kernel multiplies f16 hi / lo pieces (three products per algorithmic
+    product, f32 accurate), so the executed matrix-core flops are 3 x the algorithmic ones -- those are priced against the f16 dense peak."""
+    ev = timings.get('kpconv_fused', [])
+    if not ev:
+        return None
+    us = sum(e0.elapsed_time(e1) for e0, e1, _ in ev) * 1e3
+    flops = sum(f for _, _, f in ev)
+    executed = 3.0 * flops / (us * 1e-6) / 1e12 if us > 0 else 0.0
+    return {'kernel': 'kpconv_fused_kernel (gather as a product + contraction, one launch per KPConv layer; all layers of the timed steps)',
+            'bound': 'mfma', 'achieved': round(executed, 1), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(executed / MFMA_F16_PEAK_TFLOPS, 4), 'traffic': None,
+            'launches': len(ev), 'avg_us': round(us / len(ev), 2), 'algorithmic_flops_per_launch': int(flops / len(ev)),
+            'f32_equivalent_tflops': round(flops / (us * 1e-6) / 1e12, 1) if us > 0 else 0.0,
+            'note': 'achieved = 3 x algorithmic flops (f16 hi.hi + hi.lo + lo.hi products) / summed launch durations; the kernel is bound by '
+                    'its gather (L2 latency chains and the vector instructions around the MFMAs, profiles/r03_pmc_kpconv.txt), not by the '
+                    'matrix pipe; in the timed region the durations include the time slices of the other batches in flight (`quiet` = alone)'}
 
 
 def collect_roofline(se3_lib, timings, args):

@@ -810,10 +810,12 @@ def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, s
             return out
         sbytes = lib().se3_kpconv_fused_split_workspace_bytes(P, Cin, Cout) if KPCONV_SPLIT else 0
         sws = _zeroed_workspace(_kpconv_split_ws, x.device, stream, sbytes) if sbytes else None
-        check(lib().se3_kpconv_so3_fused(x.data_ptr(), tab.data_ptr(), P, Ns, NN, Cin, Cout, Wp.data_ptr(), out.data_ptr(),
-                                         sws.data_ptr() if sws is not None else None, sws.numel() if sws is not None else 0,
-                                         1 if blocked else 0, stream),
-              'se3_kpconv_so3_fused')
+        # (bench.py: event pair around the launch; algorithmic flops = contraction 2.6P.36Cin.Cout + the gather as a product 2.P.NN.16.6Cin)
+        with _timed('kpconv_fused', 2.0 * 6 * P * 36 * Cin * Cout + 2.0 * P * NN * 16 * 6 * Cin):
+            check(lib().se3_kpconv_so3_fused(x.data_ptr(), tab.data_ptr(), P, Ns, NN, Cin, Cout, Wp.data_ptr(), out.data_ptr(),
+                                             sws.data_ptr() if sws is not None else None, sws.numel() if sws is not None else 0,
+                                             1 if blocked else 0, stream),
+                  'se3_kpconv_so3_fused')
         return out
     G = torch.empty((P * 6, 36 * Cin), dtype=torch.float32, device=x.device)
     check(lib().se3_kpconv_so3_gather(q_pts.data_ptr(), s_pts.data_ptr(), idx.data_ptr(), x.data_ptr(), kp.data_ptr(),
