@@ -11,7 +11,8 @@ kernels are covered by the other batches).  The raw pairs are resident in HBM be
 the job time is the MAX over ranks; value = pairs / second over all ranks.
 
 Prints ONE JSON line: pairs/s plus a `roofline` object for the RPE self-attention kernels (per-launch HIP events on the
-launch stream, live over the timed region; `roofline.quiet`: the same kernels with one batch in flight), a `cpu_baseline` object (the CPU oracle timed on this box's host cores) and a
+launch stream, live over the timed region; `roofline.quiet`: the same kernels with one batch in flight), a `roofline_kpconv` object (the
+fused KPConv kernel -- the largest family by time -- against the f16 matrix-core peak, event pairs around its launches), a `cpu_baseline` object (the CPU oracle timed on this box's host cores) and a
 `single_pair` object (the reference-shaped one-pair-per-forward path: pairs/s, kernel launches, host synchronisations).
 
 Multi-GPU: one process per GPU.  Under `torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE in the environment) every process
