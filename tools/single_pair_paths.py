@@ -27,8 +27,8 @@ def small_gemms_own(i):
     keep = ops.LINEAR_F16_MIN_ROWS; ops.LINEAR_F16_MIN_ROWS = 0
     try: return model(data(i))
     finally: ops.LINEAR_F16_MIN_ROWS = keep
-paths = {'module': module_path, 'packed B=1': lambda i: batched.forward_pairs(model, data(i))[0], 'packed, own GEMM kernel for all row counts': small_gemms_own}
-if len(sys.argv) > 2: paths = {sys.argv[2]: paths[sys.argv[2]]}      # one path only (under rocprofv3)
+paths = {'module': module_path, 'packed B=1': lambda i: batched.forward_pairs(model, data(i))[0], 'packed / own GEMM kernel for all row counts': small_gemms_own}
+if len(sys.argv) > 2: paths = {k: paths[k] for k in sys.argv[2].split('|')}      # one path only (under rocprofv3)
 outs = {}
 for k, (name, f) in enumerate(paths.items()):
     base = k * (n + 5)
