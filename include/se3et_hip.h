@@ -99,6 +99,13 @@ size_t se3_grid_subsample_workspace_bytes(int64_t n, int batch);
 int se3_grid_subsample(const float* points, const float* normals, int64_t n, const int64_t* lengths_host, int batch,
                        float voxel_size, float* s_points, float* s_normals, int64_t* s_lengths, void* workspace,
                        size_t workspace_bytes, void* stream);
+/* The same with the clouds' sizes in DEVICE memory (the s_lengths of a previous call): a pyramid stage that follows another without a
+ * host synchronisation in between (the reference subsamples stage after stage on the CPU, geotransformer/utils/data.py:33-52).  n_rows =
+ * the rows of `points` that exist, an upper bound of the sum of lengths_dev (only the first sum rows are read); outputs and the
+ * workspace (se3_grid_subsample_workspace_bytes(n_rows, batch)) are sized by n_rows.  Results are those of se3_grid_subsample. */
+int se3_grid_subsample_dev(const float* points, const float* normals, int64_t n_rows, const int64_t* lengths_dev, int batch,
+                           float voxel_size, float* s_points, float* s_normals, int64_t* s_lengths, void* workspace,
+                           size_t workspace_bytes, void* stream);
 
 /* ---- E4: log-domain Sinkhorn with dustbin (LearnableLogOptimalTransport.forward) ---------------------------------
  * Replaces geotransformer/modules/sinkhorn/learnable_sinkhorn.py:13-66.  scores (batch, rows, cols) float32,

@@ -25,6 +25,7 @@ SIGNATURES = {
     'se3_radius_neighbors_grid': (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _vp, _f32, _i32, _vp, _vp, _vp]),
     'se3_grid_subsample_workspace_bytes': (_sz, [_i64, _i32]),
     'se3_grid_subsample': (_i32, [_vp, _vp, _i64, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'se3_grid_subsample_dev': (_i32, [_vp, _vp, _i64, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
     'se3_group_norm_workspace_bytes': (_sz, [_i64, _i32, _i32]),
     'se3_group_norm_fwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _i32, _f32, _vp, _vp, _sz, _vp]),
     'se3_group_norm_bwd_workspace_bytes': (_sz, [_i32]),

@@ -41,7 +41,9 @@ struct CloudMeta {          // per cloud, device resident
   int pad;
 };
 
+struct BatchInfo;
 struct Layout {             // device workspace carve-up (per cloud arrays are indexed with the cloud's point offset)
+  BatchInfo* info;                    // the batch descriptor every kernel reads (written by init_kernel: host or device lengths)
   CloudMeta* meta;                    // [batch]
   unsigned long long* table_key;      // [cap_total]
   int* table_first;                   // [cap_total]  first-seen local point index of the slot's voxel
@@ -72,6 +74,12 @@ struct BatchInfo {
   int64_t cap[SE3_MAX_BATCH];        // power of two
   int64_t bk_start[SE3_MAX_BATCH];
 };
+
+__host__ __device__ inline int64_t pow2_at_least(int64_t v) {
+  int64_t c = 16;
+  while (c < v) c <<= 1;
+  return c;
+}
 
 __host__ __device__ inline unsigned long long bucket_cap_for(int64_t n) {
   // smallest member of the libstdc++ growth sequence that holds n elements
@@ -126,8 +134,9 @@ __device__ int block_scan(int* a, int n, bool reverse, int* sh) {
 }
 
 // ---- kernels -------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void bounds_kernel(const float* __restrict__ pts, BatchInfo bi, float voxel,
+__global__ __launch_bounds__(kBlock) void bounds_kernel(const float* __restrict__ pts, const BatchInfo* __restrict__ bip, float voxel,
                                                         Layout L) {
+  const BatchInfo& bi = *bip;
   __shared__ float sh[kBlock / 64];
   const int b = blockIdx.x;
   const int64_t n = bi.count[b];
@@ -157,7 +166,8 @@ __global__ __launch_bounds__(kBlock) void bounds_kernel(const float* __restrict_
   }
 }
 
-__global__ void hash_kernel(const float* __restrict__ pts, BatchInfo bi, Layout L) {
+__global__ void hash_kernel(const float* __restrict__ pts, const BatchInfo* __restrict__ bip, Layout L) {
+  const BatchInfo& bi = *bip;
   const int b = blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= bi.count[b]) return;
@@ -185,7 +195,8 @@ __global__ void hash_kernel(const float* __restrict__ pts, BatchInfo bi, Layout 
   L.slot_of_point[bi.start[b] + i] = (int)h;
 }
 
-__global__ void mark_kernel(BatchInfo bi, Layout L) {       // per table slot: flag the first-seen point of each voxel
+__global__ void mark_kernel(const BatchInfo* __restrict__ bip, Layout L) {       // per table slot: flag the first-seen point of each voxel
+  const BatchInfo& bi = *bip;
   const int b = blockIdx.y;
   const int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= bi.cap[b]) return;
@@ -193,7 +204,8 @@ __global__ void mark_kernel(BatchInfo bi, Layout L) {       // per table slot: f
   if (L.table_key[slot] != kEmptyKey) L.vox_at_point[bi.start[b] + L.table_first[slot]] = (int)h + 1;
 }
 
-__global__ __launch_bounds__(kBlock) void rank_kernel(BatchInfo bi, Layout L) {
+__global__ __launch_bounds__(kBlock) void rank_kernel(const BatchInfo* __restrict__ bip, Layout L) {
+  const BatchInfo& bi = *bip;
   __shared__ int sh[kBlock];
   const int b = blockIdx.x;
   const int n = (int)bi.count[b];
@@ -220,7 +232,8 @@ __global__ __launch_bounds__(kBlock) void rank_kernel(BatchInfo bi, Layout L) {
   if (threadIdx.x == 0) L.meta[b].n_vox = nv;
 }
 
-__global__ void fill_kernel(BatchInfo bi, Layout L) {
+__global__ void fill_kernel(const BatchInfo* __restrict__ bip, Layout L) {
+  const BatchInfo& bi = *bip;
   const int b = blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= bi.count[b]) return;
@@ -230,7 +243,8 @@ __global__ void fill_kernel(BatchInfo bi, Layout L) {
   L.members[p0 + L.vox_off[p0 + v] + k] = (int)i;
 }
 
-__global__ void select_kernel(const float* __restrict__ pts, BatchInfo bi, Layout L) {
+__global__ void select_kernel(const float* __restrict__ pts, const BatchInfo* __restrict__ bip, Layout L) {
+  const BatchInfo& bi = *bip;
   const int b = blockIdx.y;
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= L.meta[b].n_vox) return;
@@ -261,8 +275,28 @@ __global__ void select_kernel(const float* __restrict__ pts, BatchInfo bi, Layou
   L.sel[p0 + v] = best;
 }
 
-// Empty hash table (keys all ones, first-seen index 0x7f7f7f7f, no members) and per-point counters at zero: one launch.
-__global__ void init_kernel(Layout L, int64_t cap_total, int64_t n) {
+// Empty hash table (keys all ones, first-seen index 0x7f7f7f7f, no members) and per-point counters at zero: one launch.  Its first thread
+// also publishes the batch descriptor the other kernels read: the host's (lengths known on the host) or, with lengths_dev, one built from
+// the per-cloud counts a previous launch left in device memory (se3_grid_subsample_dev: a pyramid stage that follows another without a host
+// synchronisation in between).
+__global__ void init_kernel(Layout L, int64_t cap_total, int64_t n, BatchInfo host_info, const int64_t* __restrict__ lengths_dev, int batch) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (lengths_dev == nullptr) {
+      *L.info = host_info;
+    } else {
+      BatchInfo bi;
+      int64_t tot = 0, cap = 0, bk = 0;
+      for (int b = 0; b < SE3_MAX_BATCH; b++) {
+        const int64_t len = b < batch ? lengths_dev[b] : 0;
+        bi.start[b] = tot; bi.count[b] = len;
+        bi.cap_start[b] = cap; bi.cap[b] = pow2_at_least(2 * len);
+        bi.bk_start[b] = bk;
+        tot += len; cap += bi.cap[b];
+        bk += (int64_t)bucket_cap_for(len > 0 ? len : 1);
+      }
+      *L.info = bi;
+    }
+  }
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap_total; i += stride) {
     L.table_key[i] = kEmptyKey;
@@ -276,7 +310,8 @@ __global__ void init_kernel(Layout L, int64_t cap_total, int64_t n) {
 }
 
 // One workgroup per cloud.  seq_a/seq_b hold the node sequence (voxel ids) of the current growth stage.
-__global__ __launch_bounds__(kBlock) void order_kernel(BatchInfo bi, Layout L) {
+__global__ __launch_bounds__(kBlock) void order_kernel(const BatchInfo* __restrict__ bip, Layout L) {
+  const BatchInfo& bi = *bip;
   __shared__ int sh[kBlock];
   const int b = blockIdx.x;
   const int64_t p0 = bi.start[b];
@@ -323,9 +358,10 @@ __global__ __launch_bounds__(kBlock) void order_kernel(BatchInfo bi, Layout L) {
     for (int i = threadIdx.x; i < V; i += kBlock) L.seq_a[p0 + i] = cur[i];
 }
 
-__global__ void gather_kernel(const float* __restrict__ pts, const float* __restrict__ nrm, BatchInfo bi, int batch,
+__global__ void gather_kernel(const float* __restrict__ pts, const float* __restrict__ nrm, const BatchInfo* __restrict__ bip, int batch,
                               Layout L, float* __restrict__ s_pts, float* __restrict__ s_nrm,
                               int64_t* __restrict__ s_len) {
+  const BatchInfo& bi = *bip;
   const int b = blockIdx.y;
   const int o = blockIdx.x * blockDim.x + threadIdx.x;
   const int V = L.meta[b].n_vox;
@@ -346,12 +382,6 @@ struct Sizes {
   int64_t cap_total, bk_total;
 };
 
-inline int64_t pow2_at_least(int64_t v) {
-  int64_t c = 16;
-  while (c < v) c <<= 1;
-  return c;
-}
-
 size_t carve(int64_t n, int batch, int64_t cap_total, int64_t bk_total, char* base, Layout* L) {
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -361,6 +391,7 @@ size_t carve(int64_t n, int batch, int64_t cap_total, int64_t bk_total, char* ba
     return p;
   };
   Layout l;
+  l.info = (BatchInfo*)take(sizeof(BatchInfo));
   l.meta = (CloudMeta*)take(sizeof(CloudMeta) * batch);
   l.table_key = (unsigned long long*)take(8 * cap_total);
   l.table_first = (int*)take(4 * cap_total);
@@ -396,27 +427,41 @@ extern "C" size_t se3_grid_subsample_workspace_bytes(int64_t n, int batch) {
   return carve(n > 0 ? n : 1, batch, cap_total, bk_total, nullptr, nullptr);
 }
 
-extern "C" int se3_grid_subsample(const float* points, const float* normals, int64_t n, const int64_t* lengths_host,
-                                  int batch, float voxel_size, float* s_points, float* s_normals, int64_t* s_lengths,
-                                  void* workspace, size_t workspace_bytes, void* stream) {
+namespace {
+// lengths_host: the clouds' sizes are known (they sum to n, grids and tables are sized by them).  lengths_dev (lengths_host == nullptr): the
+// sizes live in device memory (the s_lengths of a previous stage); n is then only an UPPER bound of their sum (the rows of `points` that
+// exist), the launches cover n points per cloud and the tables take their worst-case sizes -- the kernels themselves bound every access by
+// the descriptor init_kernel builds on the device.
+int run_grid_subsample(const float* points, const float* normals, int64_t n, const int64_t* lengths_host, const int64_t* lengths_dev,
+                       int batch, float voxel_size, float* s_points, float* s_normals, int64_t* s_lengths, void* workspace,
+                       size_t workspace_bytes, void* stream) {
   SE3_REQUIRE(batch >= 1 && batch <= SE3_MAX_BATCH, SE3_ERR_INVALID_ARG, "grid_subsample: batch %d not in [1,%d]", batch,
               SE3_MAX_BATCH);
-  SE3_REQUIRE(points && s_points && s_lengths && lengths_host && workspace, SE3_ERR_INVALID_ARG,
+  SE3_REQUIRE(points && s_points && s_lengths && (lengths_host || lengths_dev) && workspace, SE3_ERR_INVALID_ARG,
               "grid_subsample: null pointer");
   SE3_REQUIRE(voxel_size > 0.f, SE3_ERR_INVALID_ARG, "grid_subsample: voxel size must be positive");
-  SE3_REQUIRE(n < (1ll << 30), SE3_ERR_UNSUPPORTED, "grid_subsample: %lld points not supported", (long long)n);
-  BatchInfo bi;
-  int64_t tot = 0, cap_total = 0, bk_total = 0, nmax = 0;
-  for (int b = 0; b < batch; b++) {
-    SE3_REQUIRE(lengths_host[b] >= 0, SE3_ERR_INVALID_ARG, "grid_subsample: negative length");
-    bi.start[b] = tot; bi.count[b] = lengths_host[b];
-    bi.cap_start[b] = cap_total; bi.cap[b] = pow2_at_least(2 * lengths_host[b]);
-    bi.bk_start[b] = bk_total;
-    tot += lengths_host[b]; cap_total += bi.cap[b];
-    bk_total += (int64_t)bucket_cap_for(lengths_host[b] > 0 ? lengths_host[b] : 1);
-    if (lengths_host[b] > nmax) nmax = lengths_host[b];
+  SE3_REQUIRE(n >= 0 && n < (1ll << 30), SE3_ERR_UNSUPPORTED, "grid_subsample: %lld points not supported", (long long)n);
+  BatchInfo bi{};
+  int64_t cap_total = 0, bk_total = 0, nmax = 0, capmax = 0;
+  if (lengths_host) {
+    int64_t tot = 0;
+    for (int b = 0; b < batch; b++) {
+      SE3_REQUIRE(lengths_host[b] >= 0, SE3_ERR_INVALID_ARG, "grid_subsample: negative length");
+      bi.start[b] = tot; bi.count[b] = lengths_host[b];
+      bi.cap_start[b] = cap_total; bi.cap[b] = pow2_at_least(2 * lengths_host[b]);
+      bi.bk_start[b] = bk_total;
+      tot += lengths_host[b]; cap_total += bi.cap[b];
+      bk_total += (int64_t)bucket_cap_for(lengths_host[b] > 0 ? lengths_host[b] : 1);
+      if (lengths_host[b] > nmax) nmax = lengths_host[b];
+      capmax = bi.cap[b] > capmax ? bi.cap[b] : capmax;
+    }
+    SE3_REQUIRE(tot == n, SE3_ERR_INVALID_ARG, "grid_subsample: lengths sum %lld != n %lld", (long long)tot, (long long)n);
+  } else {
+    cap_total = 4 * n + 32 * batch;              // the worst case over any split (se3_grid_subsample_workspace_bytes)
+    bk_total = 3 * n + 16 * batch;
+    nmax = n;
+    capmax = pow2_at_least(2 * n);
   }
-  SE3_REQUIRE(tot == n, SE3_ERR_INVALID_ARG, "grid_subsample: lengths sum %lld != n %lld", (long long)tot, (long long)n);
   Layout L;
   size_t need = carve(n > 0 ? n : 1, batch, cap_total, bk_total, (char*)workspace, &L);
   SE3_REQUIRE(need <= workspace_bytes, SE3_ERR_WORKSPACE, "grid_subsample: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -425,25 +470,41 @@ extern "C" int se3_grid_subsample(const float* points, const float* normals, int
   {
     const int64_t most = cap_total > n ? cap_total : (n > 0 ? n : 1);
     const int64_t blocks = se3_cdiv(most, (int64_t)tpb);
-    init_kernel<<<(unsigned)(blocks < 2048 ? blocks : 2048), tpb, 0, st>>>(L, cap_total, n > 0 ? n : 1);
+    init_kernel<<<(unsigned)(blocks < 2048 ? blocks : 2048), tpb, 0, st>>>(L, cap_total, n > 0 ? n : 1, bi, lengths_host ? nullptr : lengths_dev,
+                                                                         batch);
   }
-  bounds_kernel<<<batch, kBlock, 0, st>>>(points, bi, voxel_size, L);
+  bounds_kernel<<<batch, kBlock, 0, st>>>(points, L.info, voxel_size, L);
   if (nmax > 0) {
     dim3 gp((unsigned)se3_cdiv(nmax, tpb), (unsigned)batch);
-    hash_kernel<<<gp, tpb, 0, st>>>(points, bi, L);
-    int64_t capmax = 0;
-    for (int b = 0; b < batch; b++) capmax = bi.cap[b] > capmax ? bi.cap[b] : capmax;
-    mark_kernel<<<dim3((unsigned)se3_cdiv(capmax, tpb), (unsigned)batch), tpb, 0, st>>>(bi, L);
+    hash_kernel<<<gp, tpb, 0, st>>>(points, L.info, L);
+    mark_kernel<<<dim3((unsigned)se3_cdiv(capmax, tpb), (unsigned)batch), tpb, 0, st>>>(L.info, L);
   }
-  rank_kernel<<<batch, kBlock, 0, st>>>(bi, L);
+  rank_kernel<<<batch, kBlock, 0, st>>>(L.info, L);
   if (nmax > 0) {
     dim3 gp((unsigned)se3_cdiv(nmax, tpb), (unsigned)batch);
-    fill_kernel<<<gp, tpb, 0, st>>>(bi, L);
-    select_kernel<<<gp, tpb, 0, st>>>(points, bi, L);
+    fill_kernel<<<gp, tpb, 0, st>>>(L.info, L);
+    select_kernel<<<gp, tpb, 0, st>>>(points, L.info, L);
   }
-  order_kernel<<<batch, kBlock, 0, st>>>(bi, L);
+  order_kernel<<<batch, kBlock, 0, st>>>(L.info, L);
   gather_kernel<<<dim3((unsigned)se3_cdiv(nmax > 0 ? nmax : 1, tpb), (unsigned)batch), tpb, 0, st>>>(
-      points, normals, bi, batch, L, s_points, s_normals, s_lengths);
+      points, normals, L.info, batch, L, s_points, s_normals, s_lengths);
   SE3_CHECK_LAUNCH("grid_subsample");
   return SE3_OK;
+}
+}  // namespace
+
+extern "C" int se3_grid_subsample(const float* points, const float* normals, int64_t n, const int64_t* lengths_host,
+                                  int batch, float voxel_size, float* s_points, float* s_normals, int64_t* s_lengths,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+  SE3_REQUIRE(lengths_host, SE3_ERR_INVALID_ARG, "grid_subsample: null pointer");
+  return run_grid_subsample(points, normals, n, lengths_host, nullptr, batch, voxel_size, s_points, s_normals, s_lengths, workspace,
+                            workspace_bytes, stream);
+}
+
+extern "C" int se3_grid_subsample_dev(const float* points, const float* normals, int64_t n_rows, const int64_t* lengths_dev, int batch,
+                                      float voxel_size, float* s_points, float* s_normals, int64_t* s_lengths, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  SE3_REQUIRE(lengths_dev, SE3_ERR_INVALID_ARG, "grid_subsample_dev: null pointer");
+  return run_grid_subsample(points, normals, n_rows, nullptr, lengths_dev, batch, voxel_size, s_points, s_normals, s_lengths, workspace,
+                            workspace_bytes, stream);
 }

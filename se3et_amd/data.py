@@ -1,7 +1,8 @@
 """On-GPU counterpart of the reference's stack-mode collate (geotransformer/utils/data.py:13-97,159-209).
 
 The reference runs grid subsampling and the 3S-2 radius searches on the CPU inside DataLoader workers; here the
-whole pyramid is built on the GPU in the main process right after the raw pair was uploaded.  List structure,
+whole pyramid is built on the GPU in the main process right after the raw pair was uploaded, with two host
+synchronisations (the counts of all subsampling stages, the widths of all neighbour tables).  List structure,
 voxel/radius doubling, the 2000-point cap of the coarsest stage and the column truncation are reproduced exactly
 (pinned by tests/golden/precompute_c1.npz)."""
 import torch
@@ -19,9 +20,19 @@ def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, 
         raise RuntimeError('precompute_data_stack_mode: points must be on the GPU')
     lengths = torch.as_tensor(lengths, dtype=torch.int64).cpu()
     points_list, lengths_list = [], []
+    # the S-1 subsampling stages back to back: every stage takes the per-cloud counts of the one before from DEVICE memory (outputs sized
+    # by the stage-0 row count, an upper bound), and ONE synchronisation fetches the counts of all stages
+    sub_pts, sub_len, cur_pts, cur_len, v = [], [], points, lengths, voxel_size
+    for i in range(1, num_stages):
+        v *= 2
+        cur_pts, _, cur_len = _ops.grid_subsample(cur_pts, cur_len, None, v)
+        sub_pts.append(cur_pts)
+        sub_len.append(cur_len)
+    sub_len = torch.stack(sub_len).cpu() if sub_len else None
     for i in range(num_stages):
         if i > 0:
-            points, lengths, _ = grid_subsample(points, lengths, None, voxel_size)
+            lengths = sub_len[i - 1].clone()
+            points = sub_pts[i - 1][:int(lengths.sum())]
         if i == num_stages - 1 and int(lengths.max()) > 2000:
             # the reference keeps at most 2000 superpoints per cloud (utils/data.py:40-48); any number of stacked clouds here
             keep, start = [], 0

@@ -256,10 +256,24 @@ def radius_neighbors(q_points, s_points, q_lengths, s_lengths, radius, limit, gr
 
 
 def grid_subsample(points, lengths, normals, voxel_size):
-    """Returns (s_points (N,3) [first sum(s_lengths) rows valid], s_normals or None, s_lengths (B,) int64 device)."""
+    """Returns (s_points (N,3) [first sum(s_lengths) rows valid], s_normals or None, s_lengths (B,) int64 device).  `lengths` on the
+    host: they sum to the rows of `points`.  `lengths` a DEVICE int64 tensor (the s_lengths of a previous call): no host synchronisation
+    -- the rows of `points` are then an upper bound of their sum (se3_grid_subsample_dev)."""
     _req(points, torch.float32, 'points', 2)
     if normals is not None:
         _req(normals, torch.float32, 'normals', 2)
+    if torch.is_tensor(lengths) and lengths.is_cuda:
+        ld = _req(lengths.contiguous(), torch.int64, 'lengths', 1)
+        n, nb, dev = points.shape[0], ld.shape[0], points.device
+        ws_bytes = lib().se3_grid_subsample_workspace_bytes(n, nb)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        s_points = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        s_normals = torch.empty((n, 3), dtype=torch.float32, device=dev) if normals is not None else None
+        s_lengths = torch.empty((nb,), dtype=torch.int64, device=dev)
+        check(lib().se3_grid_subsample_dev(points.data_ptr(), normals.data_ptr() if normals is not None else None, n, ld.data_ptr(), nb,
+                                           float(voxel_size), s_points.data_ptr(), s_normals.data_ptr() if s_normals is not None else None,
+                                           s_lengths.data_ptr(), ws.data_ptr(), ws_bytes, _stream()), 'se3_grid_subsample_dev')
+        return s_points, s_normals, s_lengths
     ln, nb = _host_lengths(lengths, 'lengths')
     n = points.shape[0]
     dev = points.device

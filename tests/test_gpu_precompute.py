@@ -31,6 +31,33 @@ def test_grid_subsample_matches_oracle(n1, n2, scale, voxel):
     assert torch.equal(gn[:m].cpu(), sn)
 
 
+@pytest.mark.parametrize('n1,n2,scale,voxel', [(5000, 4000, 1.0, 0.05), (20000, 15000, 2.0, 0.05), (3000, 100, 0.5, 0.1), (7, 1, 0.2, 0.05),
+                                               (1000, 0, 1.0, 0.1)])
+def test_grid_subsample_chain_on_device_lengths_matches_oracle(n1, n2, scale, voxel):
+    """Three stages back to back, every stage reading the counts of the one before from device memory (se3_grid_subsample_dev: no host
+    synchronisation between the stages, the outputs sized by the first stage's rows), against the C oracle run stage by stage: bit-equal
+    points, normals and counts -- also with spare rows behind the clouds of the first stage."""
+    from oracle import native
+    from se3et_amd import ops
+    pts, nrm, lens = _clouds(n1, n2, scale, 1)
+    want, p, n_, l = [], pts, nrm, lens
+    for k in range(3):
+        p, l, n_ = native.grid_subsample(p, l, n_, voxel * 2 ** k)
+        want.append((p, l, n_))
+    spare = torch.full((37, 3), 1e30)
+    gp, gn, gl = torch.cat((pts, spare)).cuda(), torch.cat((nrm, spare)).cuda(), lens.cuda()          # device lengths from the start
+    got = []
+    for k in range(3):
+        gp, gn, gl = ops.grid_subsample(gp, gl, gn, voxel * 2 ** k)
+        assert gp.shape[0] == n1 + n2 + 37
+        got.append((gp, gn, gl))
+    for k, ((sp, sl, sn), (gp, gn, gl)) in enumerate(zip(want, got)):
+        assert gl.cpu().tolist() == sl.tolist(), 'stage %d counts' % k
+        m = int(sl.sum())
+        assert torch.equal(gp[:m].cpu(), sp), 'stage %d points' % k
+        assert torch.equal(gn[:m].cpu(), sn), 'stage %d normals' % k
+
+
 @pytest.mark.parametrize('n1,n2,scale,radius,limit', [(3000, 2500, 1.0, 0.08, 38), (6000, 5000, 1.0, 0.0625, 36),
                                                       (500, 3, 0.3, 0.2, 64), (2000, 2000, 0.2, 0.1, 38)])
 def test_radius_search_matches_oracle(n1, n2, scale, radius, limit):

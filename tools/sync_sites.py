@@ -19,8 +19,10 @@ with torch.no_grad():
 torch.cuda.synchronize()
 sites = collections.Counter()
 def showwarning(message, category, filename, lineno, file=None, line=None):
-    if 'synchroniz' in str(message):
+    if 'synchroniz' in str(message) and 'prototype' not in str(message):
         st = [f for f in traceback.extract_stack() if 'se3et_amd' in f.filename]
+        if not st:
+            st = traceback.extract_stack()[:-1]          # no library frame: show the caller's own
         sites[' <- '.join('%s:%d' % (os.path.basename(f.filename), f.lineno) for f in reversed(st[-3:]))] += 1
 warnings.showwarning = showwarning
 warnings.simplefilter('always')
