@@ -86,7 +86,9 @@ int se3_radius_grid_build(const float* s_points, int64_t ns, const int64_t* s_le
                           void* workspace, size_t workspace_bytes, void* stream);
 int se3_radius_neighbors_grid(const float* q_points, int64_t nq, const int64_t* q_lengths_host, const int64_t* s_lengths_host,
                               int64_t ns, int batch, const void* grid_workspace, float radius, int limit, int64_t* neighbors,
-                              int32_t* max_count, void* stream);
+                              int32_t* max_count, int max_count_is_zero, void* stream);
+/* (max_count_is_zero != 0: the caller cleared max_count itself -- e.g. one fill for the counters of all searches of a pyramid -- and the
+ * call does not clear it again; the search only ever raises the values.) */
 
 /* ---- A1: stack-mode grid subsampling ----------------------------------------------------------------------
  * Replaces geotransformer.ext.grid_subsampling (pybind.cpp:13-17, cpu/grid_subsampling/grid_subsampling.cpp:5-83,

@@ -22,7 +22,7 @@ SIGNATURES = {
     'se3_radius_neighbors': (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _f32, _i32, _vp, _vp, _vp]),
     'se3_radius_grid_workspace_bytes': (_sz, [_i64, _i32]),
     'se3_radius_grid_build': (_i32, [_vp, _i64, _vp, _i32, _f32, _vp, _sz, _vp]),
-    'se3_radius_neighbors_grid': (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _vp, _f32, _i32, _vp, _vp, _vp]),
+    'se3_radius_neighbors_grid': (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _vp, _f32, _i32, _vp, _vp, _i32, _vp]),
     'se3_grid_subsample_workspace_bytes': (_sz, [_i64, _i32]),
     'se3_grid_subsample': (_i32, [_vp, _vp, _i64, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
     'se3_grid_subsample_dev': (_i32, [_vp, _vp, _i64, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),

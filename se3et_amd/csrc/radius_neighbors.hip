@@ -469,7 +469,8 @@ extern "C" int se3_radius_grid_build(const float* s_points, int64_t ns, const in
 
 extern "C" int se3_radius_neighbors_grid(const float* q_points, int64_t nq, const int64_t* q_lengths_host,
                                          const int64_t* s_lengths_host, int64_t ns, int batch, const void* grid_workspace,
-                                         float radius, int limit, int64_t* neighbors, int32_t* max_count, void* stream) {
+                                         float radius, int limit, int64_t* neighbors, int32_t* max_count, int max_count_is_zero,
+                                         void* stream) {
   SE3_REQUIRE(q_points && q_lengths_host && s_lengths_host && grid_workspace && neighbors && max_count, SE3_ERR_INVALID_ARG,
               "radius_neighbors_grid: null pointer");
   SE3_REQUIRE(batch >= 1 && batch <= SE3_MAX_BATCH, SE3_ERR_INVALID_ARG, "radius_neighbors_grid: batch");
@@ -481,7 +482,7 @@ extern "C" int se3_radius_neighbors_grid(const float* q_points, int64_t nq, cons
   GridLayout G;
   grid_carve(ns, batch, (char*)grid_workspace, &G);
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(max_count, 0, sizeof(int32_t) * batch, st) != hipSuccess) {
+  if (!max_count_is_zero && hipMemsetAsync(max_count, 0, sizeof(int32_t) * batch, st) != hipSuccess) {
     se3_set_error("radius_neighbors_grid: memset failed");
     return SE3_ERR_LAUNCH;
   }

@@ -57,17 +57,22 @@ def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, 
                           if s_pts.shape[0] >= _ops.GRID_SEARCH_MIN_SUPPORT else None)
         return grids[key]
 
+    counters = torch.zeros((3 * num_stages - 2, len(lengths_list[0])), dtype=torch.int32, device=points.device)   # one fill for all searches
     for i in range(num_stages):
         cur, cl = points_list[i], lengths_list[i]
-        jobs.append(('neighbors', _ops.radius_neighbors(cur, cur, cl, cl, radius, neighbor_limits[i], grid=grid_for(i, radius))))
+        jobs.append(('neighbors', _ops.radius_neighbors(cur, cur, cl, cl, radius, neighbor_limits[i], grid=grid_for(i, radius),
+                                                        zeroed_max_count=counters[len(jobs)])))
         if i < num_stages - 1:
             sub, sl = points_list[i + 1], lengths_list[i + 1]
             jobs.append(('subsampling', _ops.radius_neighbors(sub, cur, sl, cl, radius, neighbor_limits[i],
-                                                              grid=grid_for(i, radius))))
+                                                              grid=grid_for(i, radius), zeroed_max_count=counters[len(jobs)])))
             jobs.append(('upsampling', _ops.radius_neighbors(cur, sub, cl, sl, radius * 2, neighbor_limits[i + 1],
-                                                             grid=grid_for(i + 1, radius * 2))))
+                                                             grid=grid_for(i + 1, radius * 2), zeroed_max_count=counters[len(jobs)])))
         radius *= 2
-    counts = torch.stack([mc for _, (_, mc) in jobs]).cpu()                       # (jobs, clouds)
+    for j, (_, (_, mc)) in enumerate(jobs):       # (a search on a small support takes the exhaustive kernel, which fills a counter of its own)
+        if mc.data_ptr() != counters[j].data_ptr():
+            counters[j].copy_(mc)
+    counts = counters.cpu()                                                       # (jobs, clouds): the ONE synchronisation of the searches
     num_pairs = counts.shape[1] // 2
     pair_counts = counts.view(counts.shape[0], num_pairs, 2).amax(2).tolist() if counts.shape[1] % 2 == 0 else None
     out = {'points': points_list, 'lengths': lengths_list, 'neighbors': [], 'subsampling': [], 'upsampling': []}

@@ -216,21 +216,28 @@ class RadiusGrid:
         check(lib().se3_radius_grid_build(self.s_points.data_ptr(), self.ns, self.lengths, self.batch, self.radius,
                                           self.ws.data_ptr(), nbytes, _stream()), 'se3_radius_grid_build')
 
-    def search(self, q_points, q_lengths, limit):
+    def search(self, q_points, q_lengths, limit, zeroed_max_count=None):
+        """zeroed_max_count: a (batch,) int32 device tensor the caller has already cleared (one fill for all searches of a pyramid)."""
         _req(q_points, torch.float32, 'q_points', 2)
         ql, nb = _host_lengths(q_lengths, 'q_lengths')
         if nb != self.batch:
             raise RuntimeError('q_lengths and s_lengths differ in batch size')
         nq = q_points.shape[0]
         out = torch.empty((nq, limit), dtype=torch.int64, device=q_points.device)
-        max_count = torch.empty((nb,), dtype=torch.int32, device=q_points.device)
+        if zeroed_max_count is not None:
+            max_count = _req(zeroed_max_count, torch.int32, 'zeroed_max_count', 1)
+            if max_count.shape[0] != nb or not max_count.is_contiguous():
+                raise RuntimeError('radius search: zeroed_max_count must be a contiguous (batch,) int32 tensor')
+        else:
+            max_count = torch.empty((nb,), dtype=torch.int32, device=q_points.device)
         check(lib().se3_radius_neighbors_grid(q_points.data_ptr(), nq, ql, self.lengths, self.ns, self.batch, self.ws.data_ptr(),
-                                              self.radius, int(limit), out.data_ptr(), max_count.data_ptr(), _stream()),
+                                              self.radius, int(limit), out.data_ptr(), max_count.data_ptr(),
+                                              1 if zeroed_max_count is not None else 0, _stream()),
               'se3_radius_neighbors_grid')
         return out, max_count
 
 
-def radius_neighbors(q_points, s_points, q_lengths, s_lengths, radius, limit, grid=None):
+def radius_neighbors(q_points, s_points, q_lengths, s_lengths, radius, limit, grid=None, zeroed_max_count=None):
     """Returns (neighbors (Nq, limit) int64 padded with Ns, max_count (batch,) int32 device tensor: per cloud the largest
     in-radius count).  Large supports go through
     a uniform grid (pass a prebuilt RadiusGrid to share it between searches); results are identical either way."""
@@ -241,7 +248,7 @@ def radius_neighbors(q_points, s_points, q_lengths, s_lengths, radius, limit, gr
     if grid is not None:
         if grid.s_points.data_ptr() != s_points.data_ptr() or grid.radius != float(radius):
             raise RuntimeError('radius_neighbors: the grid was built for another support cloud / radius')
-        return grid.search(q_points, q_lengths, limit)
+        return grid.search(q_points, q_lengths, limit, zeroed_max_count)
     ql, nb = _host_lengths(q_lengths, 'q_lengths')
     sl, nb2 = _host_lengths(s_lengths, 's_lengths')
     if nb != nb2:
