@@ -529,7 +529,7 @@ def run_single_pair(model, cfg, args, dev, feats_unused):
     from se3et_amd.synthetic import make_pair
     b = cfg.backbone
     WU = 12            # warm-up pairs: every pair has row counts of its own, and the caching allocator keeps meeting new block sizes (a
-                       # hipMalloc each, which waits for the GPU) for the first dozen forwards -- 3 warm-up pairs measured 7 % below the steady rate
+                       # hipMalloc each, which waits for the GPU) during the first forwards
     n_pairs = args.single_pair_steps + WU
     inputs = []
     for i in range(n_pairs):
