@@ -144,6 +144,8 @@ def main():
                     '(rank 0 at --gpus 1 only; 0 = skip)')
     ap.add_argument('--roofline-quiet-steps', type=int, default=3, help='extra steps after the timed region with one batch in flight and no '
                     'other stream, for `roofline.quiet` (0 = skip)')
+    ap.add_argument('--force-dist', action='store_true', help='initialise torch.distributed (RCCL) also with ONE rank: the device barrier and the '
+                    'MAX all-reduce of the job clock then run on the GPU at world size 1 (tests/test_gpu_bench.py)')
     ap.add_argument('--fake-device', action='store_true', help='launcher self-test: gloo rendezvous, sharding, barriers and the '
                     'MAX-over-ranks clock run for real, the step is a host sleep (no GPU needed; tests/test_bench_launch.py)')
     args = ap.parse_args()
@@ -162,7 +164,15 @@ def main():
     from se3et_amd.model import create_model, load_synthetic_weights, make_cfg
     from se3et_amd.synthetic import PAIR_PRESETS, make_pair
 
-    rank, world, local = sharding.init_distributed('nccl')
+    if args.force_dist and 'MASTER_PORT' not in os.environ:      # a single rank started by hand: any free port on 127.0.0.1
+        import socket
+        sock = socket.socket()
+        sock.bind(('127.0.0.1', 0))
+        os.environ['MASTER_PORT'] = str(sock.getsockname()[1])
+        sock.close()
+    if torch.cuda.is_available():
+        torch.cuda.set_device(sharding.rank_world()[2])
+    rank, world, local = sharding.init_distributed('nccl', force=args.force_dist)
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     torch.cuda.set_device(local)
@@ -202,11 +212,16 @@ def main():
 
     import threading
 
-    def run(indices, stream):
-        # one host thread + one HIP stream per pair in flight: while one pair waits on a data-dependent size (3 host syncs
-        # per pair), the other keeps the GPU and the launch queue busy
+    def run(take, stream):
+        # one host thread + one HIP stream per batch in flight: while one batch waits on a data-dependent size (3 host syncs
+        # per forward), the others keep the GPU and the launch queue busy.  `take()` hands out the next step index of a queue shared
+        # by the threads (None = empty): whichever thread is free takes the next step, so the tail of the timed region is balanced
+        # whatever the step count (a static deal of 20 steps over 3 threads is 7 / 7 / 6, and a slow thread keeps its share).
         with torch.cuda.stream(stream):
-            for i in indices:
+            while True:
+                i = take()
+                if i is None:
+                    break
                 step(i)
             stream.synchronize()
 
@@ -265,7 +280,9 @@ def main():
         if failed:
             raise failed[0]
 
-    def run_all(indices):
+    def run_all(indices, per_thread=None):
+        """per_thread: list of index lists, one per in-flight thread (priming: every thread / stream runs ITS list); default: the threads
+        draw from one shared queue of `indices`."""
         P = max(1, args.inflight)
         if P == 1:
             if args.prefetch:
@@ -275,14 +292,24 @@ def main():
                 step(i)
             return
         failed = []
+        lock = threading.Lock()
+        pending = list(indices)
 
-        def guarded(idx, stream):
+        def take_shared():
+            with lock:
+                return pending.pop(0) if pending and not failed else None
+
+        def guarded(t, stream):
             try:
-                run(idx, stream)
+                if per_thread is None:
+                    run(take_shared, stream)
+                else:
+                    own = list(per_thread[t])
+                    run(lambda: own.pop(0) if own and not failed else None, stream)
             except BaseException as e:
                 failed.append(e)
 
-        threads = [threading.Thread(target=guarded, args=(indices[t::P], streams[t]), daemon=True) for t in range(P)]
+        threads = [threading.Thread(target=guarded, args=(t, streams[t]), daemon=True) for t in range(P)]
         for t in threads:
             t.start()
         for t in threads:
@@ -299,9 +326,18 @@ def main():
     while time.perf_counter() - t_ramp < 1.0:
         ramp @ ramp
     torch.cuda.synchronize()
+    # Priming (untimed, before the W warm-up steps, whatever W is): EVERY in-flight stream runs two steps of its own, so that per-stream
+    # state -- GroupNorm / split workspaces, embedding and neighbour tables, the allocator's per-stream blocks, the weight pieces shared
+    # through events -- exists before t0 on all of them.  With 3 threads, `--warmup 5` alone left one stream with a single warm step and
+    # its first timed steps paid for the initialisation (BENCH_r03: 360 pairs/s at --steps 20 --warmup 5 against 409-443 at 60 + 9).
+    if args.inflight > 1:
+        prime = [i % max(1, args.warmup) if args.warmup > 0 else 0 for i in range(2)]
+        run_all([], per_thread=[list(prime) for _ in range(args.inflight)])
+        torch.cuda.synchronize()
     run_all(list(range(args.warmup)))
     torch.cuda.synchronize()
     sharding.barrier(dev)
+    cpu0 = time.process_time()
     se3_ops.KERNEL_TIMINGS = {}
     se3_lib.lib().se3_debug_kernel_timing(1)        # every RPE attention launch gets its own HIP event pair
     t0 = time.perf_counter()
@@ -309,6 +345,7 @@ def main():
     torch.cuda.synchronize()
     sharding.barrier(dev)
     elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
+    host_cpu_s = time.process_time() - cpu0           # CPU seconds of this rank's process (all host threads) over the timed region
     timings, se3_ops.KERNEL_TIMINGS = se3_ops.KERNEL_TIMINGS, None
 
     roofline = collect_roofline(se3_lib, timings, args)
@@ -353,11 +390,11 @@ def main():
             'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32' if args.attention_dtype == 'float32' else 'f32 (geometric embedding stored in bf16)',
-            'data': 'synthetic',
+            'data': 'synthetic', 'host_cpu_s_per_step': round(host_cpu_s / max(args.steps, 1), 5),
             'config': {'workload': 'SE3ET-E forward (pyramid + backbone + transformer + matching + Sinkhorn + LGR) on '
                                    'synthetic %d+%d-point pairs, %d pair(s) per rank per step' % (n, n, PB) +
                                    (' = BASELINE.json configs[3]: 64 independent pairs per step over 8 GPUs' if world == 8 and PB == 8 else ''),
-                       'ranks_seen': ranks_seen,
+                       'ranks_seen': ranks_seen, 'collectives': 'rccl' if torch.distributed.is_initialized() else 'none (one rank)',
                        'variant': args.variant, 'pair_preset': args.pair, 'sharding': 'pairs round-robin over ranks, no collective',
                        'pairs_per_forward': PB, 'batches_in_flight_per_gpu': max(1, args.inflight), 'pyramid_prefetch': bool(args.prefetch),
                        'attention_dtype': args.attention_dtype},
@@ -374,7 +411,10 @@ MFMA_F16_PEAK_TFLOPS = 2500.0        # dense f16 / bf16 matrix-core peak of one 
 def collect_kpconv_roofline(timings):
     """The largest kernel family by time (21 % of a step) is matrix-core bound, not HBM bound: kpconv_fused_kernel, one launch per KPConv
     layer.  Event pair around every launch (se3et_amd/ops.py); the kernel multiplies f16 hi / lo pieces (three products per algorithmic
-    product, f32 accurate), so the executed matrix-core flops are 3 x the algorithmic ones -- those are priced against the f16 dense peak."""
+    product, f32 accurate) in BOTH of its stages -- the contraction (v_mfma_f32_32x32x16_f16 in the consumer waves) and, since late round 3,
+    the gather as a product (v_mfma_f32_16x16x32_f16 in the producer waves: csrc/kpconv_mfma.hip gather_multiply issues al.bh, ah.bl, ah.bh) --
+    so the executed matrix-core flops are 3 x the algorithmic ones of both terms; those are priced against the f16 dense peak.  (The gather
+    term counts the table's real width NN; the MFMAs run over 32 or 40 padded slots, which is not counted.)"""
     ev = timings.get('kpconv_fused', [])
     if not ev:
         return None

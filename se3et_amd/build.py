@@ -25,6 +25,11 @@ def build(force=False, verbose=True):
         os.path.join(os.path.dirname(os.path.dirname(CSRC)), 'include', 'se3et_hip.h')]
     objs, jobs = [], []
     os.makedirs(os.path.join(CSRC, 'build'), exist_ok=True)
+    # objects whose source is gone (renamed / deleted kernels) are removed, never linked
+    names = {os.path.basename(s)[:-4] for s in srcs}
+    for o in glob.glob(os.path.join(CSRC, 'build', '*.o')):
+        if os.path.basename(o)[:-2] not in names:
+            os.remove(o)
     for s in srcs:
         o = os.path.join(CSRC, 'build', os.path.basename(s)[:-4] + '.o')
         objs.append(o)

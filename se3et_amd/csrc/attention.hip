@@ -1945,10 +1945,6 @@ extern "C" int se3_attention_stack_fwd(const float* q, const float* k, const flo
     SE3_CHECK_LAUNCH("attention (f16 pieces)");
     return SE3_OK;
   }
-  if (launch_attention_x6(p, kv_pieces_workspace, kv_pieces_bytes, (hipStream_t)stream)) {
-    SE3_CHECK_LAUNCH("attention (f16 pieces)");
-    return SE3_OK;
-  }
   return launch_attention(p, (hipStream_t)stream);
 }
 

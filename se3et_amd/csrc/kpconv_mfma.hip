@@ -28,14 +28,13 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;      // (an array of HIP uint4 structs ends up in scratch)
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-#ifdef SE3_KPCONV_STAMPS      // diagnostic build of tools/micro/kpconv_stamps.hip only: wave time stamps of the first workgroups
-__device__ long long* g_stamps = nullptr;
-constexpr int kStampBlocks = 64, kStampSteps = 40, kStampSlots = 8;
-#define SE3_STAMP(step_, slot_)                                                                                            \
-  if (g_stamps && blockIdx.x < kStampBlocks && blockIdx.y == 0 && (step_) < kStampSteps && lane == 0)                      \
-    g_stamps[(((int64_t)blockIdx.x * 16 + wave) * kStampSteps + (step_)) * kStampSlots + (slot_)] = __builtin_amdgcn_s_memtime();
-#else
+// Diagnostic hooks, empty in the product: tools/micro/kpconv_stamps.hip defines them (wave time stamps, fixed weight fragments) before it
+// includes this file and builds a library of its own.
+#ifndef SE3_STAMP
 #define SE3_STAMP(step_, slot_)
+#endif
+#ifndef SE3_DIAG_WEIGHT_STEP
+#define SE3_DIAG_WEIGHT_STEP(gs_, ksp_) (gs_)
 #endif
 
 constexpr int kTile4 = kTileB / 16;          // uint4 per tile image (3109)
@@ -642,9 +641,7 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
         {
           int64_t gs = (int64_t)cc * kSteps + st + BD * KS;              // unconditional (clamped) so that the compiler can count the requests
           gs = gs < last_step ? gs : last_step;
-#ifdef SE3_DIAG_FIXED_B                                                  // (diagnostic build only: the same fragments every step -- L1 hits)
-          gs = ksp;
-#endif
+          gs = SE3_DIAG_WEIGHT_STEP(gs, ksp);
 #pragma unroll
           for (int n = 0; n < CT; n++) {
             bq[jb][n][0] = wbase[gs * wstep + n * 128];

@@ -166,6 +166,18 @@ class SE3ET(nn.Module):
         self.stage_hook = None              # optional callable invoked between backbone and transformer (pipelined drivers)
         self.emit_ground_truth = False      # inference: also emit gt_node_corr_indices / _overlaps when data_dict has 'transform'
 
+    # Load paths drop the derived-weight caches of se3et_amd.ops (f16 pieces, stacked weights): load_state_dict copies in place (it bumps
+    # the version counters anyway), `.to()` / `.float()` / `.half()` go through _apply and may swap a Parameter's storage.
+    def load_state_dict(self, *args, **kwargs):
+        from . import ops as _ops
+        _ops.clear_weight_caches()
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        from . import ops as _ops
+        _ops.clear_weight_caches()
+        return super()._apply(fn, *args, **kwargs)
+
     def forward(self, data_dict, with_registration=True, train=False, targets=None, rng=None):
         """`train=False`: INFERENCE forward (no autograd), below.  `train=True`: the training forward of the reference
         (experiments/se3ete.3dmatch/model.py:110-131,172-178) with autograd through the HIP ops (se3et_amd.autograd): ground-truth

@@ -77,20 +77,30 @@ class _Shared:
         return self.tensors
 
 
+def _fingerprint(weight):
+    """Device-side content fingerprint of a weight tensor (wrapping int64 sum of its bit patterns; one small launch when a cache entry is
+    built, no host synchronisation): what validate_weight_caches() compares against the weight's current contents."""
+    with torch.no_grad():
+        return weight.detach().reshape(-1).view(torch.int32).sum(dtype=torch.int64)
+
+
 def _linear_weight_pieces(weight, stream):
-    """f16 hi / lo MFMA fragments of an (N, K) weight, kept per weight VERSION (torch bumps `_version` on every in-place update: optimizer
-    steps, load_state_dict, copy_; call clear_weight_caches() after rewriting weights behind torch's back)."""
+    """f16 hi / lo MFMA fragments of an (N, K) weight.  An entry is used only for the SAME Parameter object (weak reference compared by
+    identity: a freed tensor's address and version can be inherited by another tensor) at the same `_version` (torch bumps it on every
+    in-place update: optimizer steps, load_state_dict, copy_).  Writes that bypass the version counter (`p.data.copy_()`, `p.data = ...`,
+    raw pointers) are invisible to it: SE3ET.load_state_dict / .to() / ._apply() clear the caches, and validate_weight_caches() compares
+    every entry with the weight's current contents on the device."""
     N, K = weight.shape
     key = (weight.data_ptr(), N, K, weight.device.index)
     hit = _linear_piece_cache.get(key)
-    if hit is not None and hit[0]() is not None and hit[1] == weight._version:
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
         return hit[2].get()[0]
     Wp = torch.empty((lib().se3_linear_weight_pieces_bytes(N, K),), dtype=torch.uint8, device=weight.device)
     check(lib().se3_linear_split_weights_f16(weight.data_ptr(), N, K, Wp.data_ptr(), stream), 'se3_linear_split_weights_f16')
     with _TIMING_LOCK:
         if len(_linear_piece_cache) > 512:
             _linear_piece_cache.clear()
-        _linear_piece_cache[key] = (weakref.ref(weight), weight._version, _Shared(Wp))
+        _linear_piece_cache[key] = (weakref.ref(weight), weight._version, _Shared(Wp), _fingerprint(weight))
     return Wp
 
 
@@ -103,14 +113,14 @@ def stacked_weight(weight, groups):
     version like the f16 pieces."""
     key = (weight.data_ptr(), tuple(weight.shape), int(groups), weight.device.index)
     hit = _stacked_weight_cache.get(key)
-    if hit is not None and hit[0]() is not None and hit[1] == weight._version:
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
         return hit[2].get()[0]
     with torch.no_grad():
         W = torch.cat([weight.detach()] * int(groups), 1).contiguous()
     with _TIMING_LOCK:
         if len(_stacked_weight_cache) > 128:
             _stacked_weight_cache.clear()
-        _stacked_weight_cache[key] = (weakref.ref(weight), weight._version, _Shared(W))
+        _stacked_weight_cache[key] = (weakref.ref(weight), weight._version, _Shared(W), _fingerprint(weight))
     return W
 
 
@@ -710,7 +720,7 @@ def _kpconv_weight_pieces(weights, Cin, Cout, stream):
     key = (w.data_ptr(), Cin, Cout, w.device.index)
     if cacheable:
         hit = _weight_piece_cache.get(key)
-        if hit is not None and hit[0]() is not None and hit[1] == weights._version:
+        if hit is not None and hit[0]() is weights and hit[1] == weights._version:
             return hit[2].get()[0]
     Wp = torch.empty((lib().se3_kpconv_weight_pieces_bytes(Cin, Cout),), dtype=torch.uint8, device=w.device)
     check(lib().se3_kpconv_split_weights_f16(w.data_ptr(), Cin, Cout, Wp.data_ptr(), stream), 'se3_kpconv_split_weights_f16')
@@ -718,7 +728,7 @@ def _kpconv_weight_pieces(weights, Cin, Cout, stream):
         with _TIMING_LOCK:
             if len(_weight_piece_cache) > 256:
                 _weight_piece_cache.clear()
-            _weight_piece_cache[key] = (weakref.ref(weights), weights._version, _Shared(Wp))
+            _weight_piece_cache[key] = (weakref.ref(weights), weights._version, _Shared(Wp), _fingerprint(weights))
     return Wp
 
 
@@ -726,6 +736,31 @@ def clear_weight_caches():
     _weight_piece_cache.clear()
     _linear_piece_cache.clear()
     _stacked_weight_cache.clear()
+
+
+def validate_weight_caches():
+    """Compares the content fingerprint of every cached weight with the weight's CURRENT values (all sums on the device, one host
+    synchronisation in all) and drops the entries that no longer match or whose Parameter is gone.  For code that writes weights behind
+    torch's version counter (`p.data.copy_()`, EMA swaps through `.data`, hand-written checkpoint loaders).  Returns the number of entries
+    dropped."""
+    entries = []
+    for cache in (_weight_piece_cache, _linear_piece_cache, _stacked_weight_cache):
+        for key, hit in list(cache.items()):
+            w = hit[0]()
+            if w is None or w.data_ptr() != key[0]:
+                cache.pop(key, None)
+                entries.append(None)
+            else:
+                entries.append((cache, key, hit[3], _fingerprint(w)))
+    live = [e for e in entries if e is not None]
+    dropped = len(entries) - len(live)
+    if live:
+        same = (torch.stack([e[2].to(live[0][2].device) for e in live]) == torch.stack([e[3].to(live[0][2].device) for e in live])).tolist()
+        for ok, (cache, key, _, _) in zip(same, live):
+            if not ok:
+                cache.pop(key, None)
+                dropped += 1
+    return dropped
 
 
 def kpconv_slot_sums(x, q_pts, s_pts, idx, kernel_points, kidx, ridx, sigma):

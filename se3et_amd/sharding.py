@@ -14,10 +14,13 @@ def rank_world():
     return int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('LOCAL_RANK', '0'))
 
 
-def init_distributed(backend='nccl'):
-    """Initialise torch.distributed from the torchrun environment if WORLD_SIZE > 1.  Returns (rank, world, local_rank)."""
+def init_distributed(backend='nccl', force=False):
+    """Initialise torch.distributed from the torchrun environment if WORLD_SIZE > 1.  Returns (rank, world, local_rank).
+    force=True (or SE3ET_FORCE_DIST=1): also with ONE rank, so that the collectives of a run (device barrier, MAX all-reduce on a device
+    tensor over RCCL) execute on a single GPU -- the only way to exercise them where no multi-GPU node is at hand."""
     rank, world, local = rank_world()
-    if world > 1 and not dist.is_initialized():
+    force = force or os.environ.get('SE3ET_FORCE_DIST', '0') == '1'
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

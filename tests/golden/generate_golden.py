@@ -360,7 +360,7 @@ def gen_train(variant, fname, micro=True, pair='micro', synth_seed=None, full_gr
 
 def gen_vgtk():
     """Inputs / outputs of the importable PyTorch twins of the EPN toolkit's CUDA kernels (vgtk/spconv/functional.py:373-399
-    inter_zpconv_grouping_naive, batched_index_select) on seeded random data, incl. the gradient of the inter grouping."""
+    inter_zpconv_grouping_naive, :252-270 intra_zpconv_grouping_naive, batched_index_select) on seeded random data, incl. the gradient of the inter grouping."""
     ref_shims.install()
     import vgtk.spconv.functional as L
     g = torch.Generator().manual_seed(5)
@@ -374,9 +374,20 @@ def gen_vgtk():
     pts = torch.randn(b, c, q, generator=g)
     gi = torch.randint(0, q, (b, 41), generator=g)
     gathered = L.batched_index_select(pts, 2, gi)
+    # intra (anchor-axis) grouping: vgtk/spconv/functional.py:252-270 intra_zpconv_grouping_naive, forward + gradient (drawn AFTER the
+    # entries above, so those keep their values)
+    na_in, na_out, iks, ann, ip, ic = 12, 12, 3, 4, 31, 5
+    intra_idx = torch.randint(0, na_in, (na_out, ann), generator=g)
+    intra_w = torch.rand(na_out, iks, ann, generator=g)
+    intra_feats = torch.randn(b, ic, ip, na_in, generator=g, requires_grad=True)
+    intra_out = L.intra_zpconv_grouping_naive(intra_idx, intra_w, intra_feats)           # (b, c, ks, p, na_out)
+    intra_cot = torch.randn(intra_out.shape, generator=g)
+    (intra_out * intra_cot).sum().backward()
     np.savez_compressed(os.path.join(HERE, 'vgtk_ops.npz'), inter_idx=idx.numpy().astype(np.int32), inter_w=_np(w), feats=_np(feats),
                         inter_out=_np(out), cotangent=_np(cot), feats_grad=_np(feats.grad), points=_np(pts),
-                        gather_idx=gi.numpy().astype(np.int32), gathered=_np(gathered))
+                        gather_idx=gi.numpy().astype(np.int32), gathered=_np(gathered),
+                        intra_idx=intra_idx.numpy().astype(np.int32), intra_w=_np(intra_w), intra_feats=_np(intra_feats),
+                        intra_out=_np(intra_out), intra_cotangent=_np(intra_cot), intra_feats_grad=_np(intra_feats.grad))
 
 
 if __name__ == '__main__':

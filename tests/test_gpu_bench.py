@@ -1,0 +1,48 @@
+"""bench.py as the driver runs it, on one GPU: (a) `--force-dist` makes the rank initialise torch.distributed on the `nccl` (= RCCL) backend
+at world size 1, so bench's OWN collectives -- the device barrier in front of and behind the timed region and the MAX all-reduce of the job
+clock on a device tensor -- execute on the GPU (they had never run in any test, `init_distributed` returns early at world
+1); (b) the driver's exact step counts (`--steps 20 --warmup 5` is what BENCH_rNN records) run with three batches in flight and every
+in-flight stream primed before t0."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(extra, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=timeout)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.lstrip().startswith('{')]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    return json.loads(lines[0])
+
+
+LIGHT = ['--no-cpu-baseline', '--single-pair-steps', '0', '--train-steps', '0', '--roofline-quiet-steps', '0']
+
+
+def test_bench_collectives_run_on_rccl_at_world_size_one():
+    line = _bench(['--gpus', '1', '--steps', '2', '--warmup', '1', '--batch', '2', '--force-dist'] + LIGHT)
+    cfg = line['config']
+    # both come from torch.distributed AFTER the device barrier + MAX all-reduce of the timed region ran through it
+    assert cfg['ranks_seen'] == 1 and cfg['collectives'] == 'rccl'
+    assert line['n_gpus'] == 1 and line['steps'] == 2 and line['value'] > 0
+    # without the flag one rank uses no collective at all
+    line = _bench(['--gpus', '1', '--steps', '2', '--warmup', '1', '--batch', '2'] + LIGHT)
+    assert line['config']['collectives'].startswith('none')
+
+
+def test_bench_at_the_drivers_step_counts():
+    line = _bench(['--gpus', '1', '--steps', '20', '--warmup', '5'] + LIGHT)
+    assert line['steps'] == 20 and line['warmup'] == 5 and line['config']['batches_in_flight_per_gpu'] == 3
+    assert abs(line['value'] - 20 * 8 / (line['ms_per_step'] * 20 / 1e3)) <= 0.01 * line['value']
+    assert line['roofline']['launches'] == 20 * 5            # five RPE self-attention calls per SE3ET-E forward, all of them timed
+    assert line['host_cpu_s_per_step'] > 0

@@ -844,6 +844,42 @@ def test_linear_f16_split_has_f32_accuracy(rows, K, N, bias, relu):
     assert float((got2.double() - ref2).abs().max()) <= 2e-6 * float(ref2.abs().max()) + 2 * e_lib
 
 
+@pytest.mark.gpu
+def test_weight_caches_survive_writes_behind_the_version_counter():
+    """the f16 weight-piece caches are keyed by (address, shape, version).  (a) An entry must belong to the SAME tensor object
+    (identity, not liveness): another tensor that inherits a freed address and an equal version must not be served the old pieces.
+    (b) `.data.copy_()` bypasses the version counter: validate_weight_caches() compares the contents on the device and drops the entry;
+    SE3ET.load_state_dict / ._apply clear the caches."""
+    from se3et_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(256, 256, generator=g).cuda()
+    w = torch.nn.Parameter((torch.randn(128, 256, generator=g) / 16).cuda(), requires_grad=False)
+    ref = lambda w_: torch.nn.functional.linear(x.double(), w_.double())
+    ops.clear_weight_caches()
+    y0 = ops.linear_f16(x, w)
+    assert float((y0.double() - ref(w)).abs().max()) < 1e-5
+    # (b) a write that torch's version counter does not see
+    v = w._version
+    w.data.copy_(w.data * -2.0)
+    assert w._version == v
+    assert ops.validate_weight_caches() >= 1
+    y1 = ops.linear_f16(x, w)
+    assert float((y1.double() - ref(w)).abs().max()) < 1e-5
+    assert ops.validate_weight_caches() == 0
+    # (a) same address, same shape, same version, another tensor object
+    key = (w.data_ptr(), 128, 256, w.device.index)
+    assert key in ops._linear_piece_cache
+    entry = ops._linear_piece_cache[key]
+    other = torch.nn.Parameter(torch.empty_like(w), requires_grad=False)
+    other.data = w.data                          # shares the storage (same data_ptr), its own version counter (0 like w's)
+    assert other.data_ptr() == w.data_ptr() and other._version == w._version
+    assert entry[0]() is w and entry[0]() is not other
+    w.data.copy_(w.data * 0.5)                   # stale pieces in the cache now; `other` must not be served them
+    y2 = ops.linear_f16(x, other)
+    assert float((y2.double() - ref(other)).abs().max()) < 1e-5
+    ops.clear_weight_caches()
+
+
 def _pending_reference(x, stages, seg):
     """float64: the stages v -> lrelu(v * scale + shift, slope) applied per segment."""
     x = x.double().clone()

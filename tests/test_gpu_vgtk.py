@@ -84,6 +84,23 @@ def test_furthest_point_sampling_tie_order():
     assert np.array_equal(got, VO.furthest_point_sampling(pc, 40))
 
 
+def test_intra_zpconv_grouping_matches_reference_twin(golden_dir):
+    """Pinned: the reference's importable twin vgtk/spconv/functional.py:252-270 intra_zpconv_grouping_naive (fixture: forward + gradient),
+    1e-5 both ways; bit-identical on repetition (the reference's kernel adds with atomicAdd)."""
+    from se3et_amd import vgtk
+    g = np.load(golden_dir + '/vgtk_ops.npz')
+    nbr, w = torch.from_numpy(g['intra_idx']).cuda(), torch.from_numpy(g['intra_w']).cuda()
+    feats = torch.from_numpy(g['intra_feats']).cuda().requires_grad_(True)
+    out = vgtk.intra_zpconv_grouping(nbr, w, feats)
+    assert_close(out.detach().cpu(), g['intra_out'], 1e-5, 'intra zpconv forward vs reference twin')
+    (out * torch.from_numpy(g['intra_cotangent']).cuda()).sum().backward()
+    assert_close(feats.grad.cpu(), g['intra_feats_grad'], 1e-5, 'intra zpconv backward vs reference twin')
+    f2 = torch.from_numpy(g['intra_feats']).cuda().requires_grad_(True)
+    out2 = vgtk.intra_zpconv_grouping(nbr, w, f2)
+    (out2 * torch.from_numpy(g['intra_cotangent']).cuda()).sum().backward()
+    assert torch.equal(out2, out) and torch.equal(f2.grad, feats.grad)
+
+
 def test_intra_zpconv_grouping_matches_source_restatement():
     from oracle import vgtk_oracle as VO
     from se3et_amd import vgtk

@@ -31,3 +31,13 @@ def test_intra_zpconv_is_a_weighted_anchor_gather():
     out = VO.intra_zpconv(nbr, w, feats)
     assert out.shape == (2, 1, 1, 3, 2)
     assert out[0, 0, 0, 0].tolist() == [0 + 1, 2 + 3]
+
+
+def test_intra_zpconv_restatement_matches_reference_twin(golden_dir):
+    """The numpy restatement of intraspherical_conv_forward against the reference's own importable twin
+    (vgtk/spconv/functional.py:252-270 intra_zpconv_grouping_naive; fixture from tests/golden/generate_golden.py vgtk)."""
+    from oracle import vgtk_oracle as VO
+    g = np.load(golden_dir + '/vgtk_ops.npz')
+    out = VO.intra_zpconv(g['intra_idx'], g['intra_w'], g['intra_feats'])
+    assert out.shape == g['intra_out'].shape
+    assert np.abs(out - g['intra_out']).max() <= 1e-5 * np.abs(g['intra_out']).max()
