@@ -169,7 +169,8 @@ int se3_group_norm_segments_bwd(const float* x, const float* x_bias, const float
  *                          in_features a power of two 32..1024; out_features 32, 64, 128 or a multiple of 256; f16 hi/lo split arithmetic
  *                          (f32 accuracy, |T(x)| < 65504); out_features / groups a power of two <= 32.  Workspace:
  *                          se3_dense_norm_workspace_bytes(groups) bytes, ZERO before the first call (it starts with the arrival counters
- *                          of the in-kernel finalize; every call leaves them zero), one per stream. */
+ *                          of the in-kernel finalize; every call leaves them zero), one per stream.  out == NULL: statistics only (the
+ *                          product is reduced to affine_out and never stored). */
 size_t se3_group_norm_stats_workspace_bytes(int channels);
 int se3_group_norm_stats(const float* x, const float* in_affine, float in_slope, const float* x_bias, const float* weight, const float* bias,
                          int64_t rows, int channels, int groups, const int64_t* segment_row_offsets_host, int num_segments, float eps,
@@ -182,6 +183,17 @@ int se3_dense_norm_fwd(const float* x, int64_t rows, int in_features, const floa
                        float in_slope_b, const void* weight_pieces, int out_features, const float* linear_bias, const float* norm_weight,
                        const float* norm_bias, int groups, float eps, const int64_t* segment_row_offsets_host, int num_segments, float* out,
                        float* affine_out, void* workspace, size_t workspace_bytes, void* stream);
+/* Round 4 -- the tail of ResnetBottleneckBlockEPN (blocks_epn.py:838-852: `x = self.unary2(x); return leaky_relu(x + shortcut)`) without the
+ * raw output of the expanding layers ever reaching HBM.  (1) se3_dense_norm_fwd with out == NULL: the GEMM of unary2 (and of skip_conv) is run
+ * for its GroupNorm statistics only -> affine table.  (2) se3_dense_residual_fwd runs the GEMM again and writes
+ *     out = lrelu( (T_b(T_a(x)) W^T) * scale + shift + R, final_slope ),   (scale, shift) = affine[segment] of step (1),
+ * R = residual (rows, out_features), or the shortcut layer (x2 W2^T) * scale2 + shift2 (x2 (rows, in_features2) concrete, weight_pieces2,
+ * affine2 from its own step (1); its norm weight must be non-zero: the two products share one accumulator set through the ratio
+ * scale / scale2), or nothing (both NULL).  Same shape limits as se3_dense_norm_fwd; no workspace. */
+int se3_dense_residual_fwd(const float* x, int64_t rows, int in_features, const float* in_affine_a, float in_slope_a, const float* in_affine_b,
+                           float in_slope_b, const void* weight_pieces, const float* affine, const float* x2, int in_features2,
+                           const void* weight_pieces2, const float* affine2, const float* residual, int out_features, float final_slope,
+                           const int64_t* segment_row_offsets_host, int num_segments, float* out, void* stream);
 /* Tuning hook (tools/micro): workgroups se3_dense_norm_fwd aims at (default 768 = 3 per compute unit, all resident at once). */
 void se3_dense_norm_set_target_chunks(int workgroups);
 

@@ -7,6 +7,15 @@
 //                           chunk's row tiles in registers: the GroupNorm that follows needs no pass over y (rowops.hip: gn_partial4_kernel);
 //                           the layer's bias is not added to y: it shifts the means (gn_finalize_kernel) and nothing else
 //
+// Round 4: the EXPANDING layers of a bottleneck block (unary2: mid -> 4 mid channels, skip_conv: in -> 2 in) no longer write their raw
+// output at all.  Writing y (rows x N), reading it back in the apply pass and writing the normalised result moved 3 N floats per row for a
+// GEMM whose input is N / 4 (N / 2) wide; recomputing the GEMM is cheaper than one of those passes.  Two more modes of the same kernel:
+//   MODE 1 (statistics only)   the GEMM with the Welford epilogue and NO store: -> the affine table of GroupNorm(y + bias)
+//   MODE 2 / 3 (final)         the GEMM again, epilogue out = lrelu(y scale + shift + R): R = a residual tensor (MODE 2: identity shortcut)
+//                              or a SECOND GEMM over the shortcut's input with the shortcut norm's own table (MODE 3: skip_conv), the two
+//                              products sharing one accumulator set (the first is rescaled by scale_1 / scale_2 per column in between)
+// so the block's output is written once and nothing else of its width ever exists (blocks_epn.py:798-852; se3et_amd/modules/e2pn).
+//
 // Arithmetic as csrc/linear_f16.hip: f16 hi + lo pieces of both operands, three products on v_mfma_f32_32x32x16_f16, f32 accumulation
 // (error 2^-22 per term).  One workgroup (4 waves) owns one row chunk of one segment (the chunks of the GroupNorm statistics: a chunk
 // never straddles two pairs of the stacked batch) and walks its row tiles with the loads two K-steps ahead of the multiplies, across tile
@@ -43,21 +52,40 @@ struct DenseArgs {
   int groups;
   float eps;
   SegTable T;
+  // final modes (2, 3): out = lrelu(y scale + shift + R, final_slope)
+  const float* affine1;      // [segment][2][N]: the table of this layer's own GroupNorm (from a MODE 1 call)
+  const float* residual;     // MODE 2: (rows, N) tensor R
+  const float* x2;           // MODE 3: (rows, K2) input of the shortcut layer, R = GroupNorm_2(x2 W2^T + b2) = x2 W2^T scale_2 + shift_2
+  int K2;
+  const u32x4* Wf2;
+  const float* hdr2;
+  const float* affine2;      // [segment][2][N]
+  float final_slope;
 };
 
 
-// WM x WN waves, each RT x CT MFMA tiles of 32 x 32: rows per tile TR = 32 RT WM, columns per workgroup BN = 32 CT WN
-template <int WM, int WN, int RT, int CT>
-__global__ __launch_bounds__(256, 3) void dense_norm_kernel(const DenseArgs a) {
+// WM x WN waves, each RT x CT MFMA tiles of 32 x 32: rows per tile TR = 32 RT WM, columns per workgroup BN = 32 CT WN.
+// MODE 0: store y + statistics; 1: statistics only; 2: final with a residual tensor; 3: final with a second (shortcut) GEMM.
+// The K-steps of a row tile are those of source 1 (K / 32) followed, in MODE 3, by those of source 2 (K2 / 32); the walk over (tile, step)
+// is three uniform counters (request: three steps ahead, stage: one ahead, multiply).
+struct StepPos {
+  int tile, kk;
+};
+// (MODE 3 keeps the constants of two layers and two operand streams alive: 2 workgroups per compute unit, 256 registers, instead of 3 with
+// spills -- a scratch reload inside the tile loop drains every prefetched load, DESIGN.md section 4 "RPE" lesson 2.)
+template <int WM, int WN, int RT, int CT, int MODE>
+__global__ __launch_bounds__(256, MODE == 3 ? 2 : 3) void dense_norm_kernel(const DenseArgs a) {
   static_assert(WM * WN == 4, "4 waves");
   constexpr int TR = 32 * RT * WM, BN = 32 * CT * WN, U = TR / 32;      // U: float4 units per thread and K-step
   constexpr int kPieceB = TR * kRowB, kBufB = 2 * kPieceB;
+  constexpr bool kStats = MODE <= 1, kDual = MODE == 3;
   __shared__ __align__(16) unsigned char lds[2 * kBufB];
   extern __shared__ __align__(16) float aff[];                           // [stage][2][K] of this workgroup's segment
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int i32 = lane & 31, h = lane >> 5;
   const int K = a.K, N = a.N;
+  const int K2 = kDual ? a.K2 : 32;
   long long r0, r1;
   chunk_rows(a.T, blockIdx.x, r0, r1);
   if (r1 < r0) r1 = r0;                                                  // (a chunk emptied by the row quantum: no tiles, partials that count nothing)
@@ -74,40 +102,53 @@ __global__ __launch_bounds__(256, 3) void dense_norm_kernel(const DenseArgs a) {
   const int stages = (a.in_affine[0] != nullptr) + (a.in_affine[1] != nullptr);
   for (int st = 0; st < stages; st++)
     for (int i = tid; i < 2 * K; i += 256) aff[st * 2 * K + i] = a.in_affine[st][(size_t)seg * 2 * K + i];
-  const int nk = K >> 5, lognk = 31 - __builtin_clz(nk);
+  const int nk1 = K >> 5, nk2 = kDual ? (K2 >> 5) : 0, nkt = nk1 + nk2;
   const int ntiles = (int)((r1 - r0 + TR - 1) / TR);
-  const int total = ntiles * nk;
+  const int total = ntiles * nkt;
+  auto advance = [&](StepPos& p) {
+    p.kk++;
+    if (p.kk == nkt) {
+      p.kk = 0;
+      p.tile++;
+    }
+  };
   // A staging: unit j of a thread = 4 consecutive floats of row (tid >> 3) + 32 j, floats 4 (tid & 7) .. + 3 of the K-step
   // Buffer addressing (uniform base and step offset, 32-bit lane offsets): rows past the end of the chunk read as zeros.
   const int q = tid & 7, urow = tid >> 3;
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (r1 > r0 ? r0 : 0) * K), 0, (int)((r1 - r0) * K * 4), 0x00020000);
-  const int xoff = (urow * K + 4 * q) * 4;
-  auto request = [&](int s, f32x4 (&v)[U]) {
-    const int tile = s >> lognk, kk = s & (nk - 1);
-    const int soff = (tile * TR * K + kk * 32) * 4;
+  const long long rbase = r1 > r0 ? r0 : 0;
+  const int nrows = (int)(r1 - r0);
+  const int xoff1 = (urow * K + 4 * q) * 4, xoff2 = (urow * K2 + 4 * q) * 4;
+  auto request = [&](const StepPos& p, f32x4 (&v)[U]) {
+    const bool two = kDual && p.kk >= nk1;                               // uniform
+    const int Ks = two ? K2 : K, kloc = two ? p.kk - nk1 : p.kk;
+    const float* base = two ? a.x2 + rbase * K2 : a.x + rbase * K;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, nrows * Ks * 4, 0x00020000);
+    const int soff = (p.tile * TR * Ks + kloc * 32) * 4, xoff = two ? xoff2 : xoff1, jstep = 32 * Ks * 4;
 #pragma unroll
-    for (int j = 0; j < U; j++) v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff + j * 32 * K * 4, soff, 0));
+    for (int j = 0; j < U; j++) v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff + j * jstep, soff, 0));
   };
-  auto stage = [&](int buf, int s, const f32x4 (&v)[U]) {               // T(v) -> f16 hi / lo -> LDS image `buf`
-    const int k = (s & (nk - 1)) * 32 + 4 * q;
+  auto stage = [&](int buf, const StepPos& p, const f32x4 (&v)[U]) {    // T(v) -> f16 hi / lo -> LDS image `buf`
+    const bool two = kDual && p.kk >= nk1;
+    const int st_here = two ? 0 : stages;                                // the shortcut's input is a concrete tensor
+    const int k = (two ? 0 : p.kk) * 32 + 4 * q;
     f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sh0 = {0.f, 0.f, 0.f, 0.f}, sc1 = sc0, sh1 = sh0;
-    if (stages > 0) {
+    if (st_here > 0) {
       sc0 = *reinterpret_cast<const f32x4*>(aff + k);
       sh0 = *reinterpret_cast<const f32x4*>(aff + K + k);
     }
-    if (stages > 1) {
+    if (st_here > 1) {
       sc1 = *reinterpret_cast<const f32x4*>(aff + 2 * K + k);
       sh1 = *reinterpret_cast<const f32x4*>(aff + 3 * K + k);
     }
 #pragma unroll
     for (int j = 0; j < U; j++) {
       f32x4 t = v[j];
-      if (stages > 0) {
+      if (st_here > 0) {
         t = t * sc0 + sh0;
 #pragma unroll
         for (int e = 0; e < 4; e++) t[e] = t[e] > 0.f ? t[e] : t[e] * a.in_slope[0];
       }
-      if (stages > 1) {
+      if (st_here > 1) {
         t = t * sc1 + sh1;
 #pragma unroll
         for (int e = 0; e < 4; e++) t[e] = t[e] > 0.f ? t[e] : t[e] * a.in_slope[1];
@@ -125,10 +166,33 @@ __global__ __launch_bounds__(256, 3) void dense_norm_kernel(const DenseArgs a) {
   };
   const int a_read = (wm * (RT * 32) + i32) * kRowB + h * 16;           // + rt * 32 * kRowB + ks * 32 + piece * kPieceB
   const int ct0 = blockIdx.y * (BN / 32) + wn * CT;
-  const u32x4* wbase = a.Wf + (int64_t)ct0 * 2 * 64 + lane;
-  const int64_t wstep = (int64_t)a.NCT * 2 * 64;                        // u32x4 per K16-step
-  const int nk16 = 2 * nk;
+  const u32x4* wbase1 = a.Wf + (int64_t)ct0 * 2 * 64 + lane;
+  const u32x4* wbase2 = kDual ? a.Wf2 + (int64_t)ct0 * 2 * 64 + lane : wbase1;
+  const int64_t wstep = (int64_t)a.NCT * 2 * 64;                        // u32x4 per K16-step (the same for both sources: same N)
   const float inv_scale = a.hdr[0];
+  // final modes: per-column constants of this lane's CT columns
+  float fs[CT], bs[CT], rescale[CT];
+#pragma unroll
+  for (int c = 0; c < CT; c++) fs[c] = bs[c] = rescale[c] = 1.f;
+  if constexpr (MODE >= 2) {
+#pragma unroll
+    for (int c = 0; c < CT; c++) {
+      const int col = (ct0 + c) * 32 + i32;
+      const float a1 = a.affine1[(size_t)seg * 2 * N + col], b1 = a.affine1[(size_t)seg * 2 * N + N + col];
+      if constexpr (kDual) {
+        // acc = S1 G1 after source 1 (S: the power-of-two scale of the weight pieces); rescaled to S2 G1 a1 / a2 it takes S2 G2 on top,
+        // and out = acc a2 / S2 + (b1 + b2).  (a2 = 0 has no such form: the host keeps layers with a zero norm weight off this path.)
+        const float a2 = a.affine2[(size_t)seg * 2 * N + col], b2 = a.affine2[(size_t)seg * 2 * N + N + col];
+        const float inv2 = a.hdr2[0];
+        rescale[c] = (a1 / a2) * (inv_scale / inv2);
+        fs[c] = a2 * inv2;
+        bs[c] = b1 + b2;
+      } else {
+        fs[c] = a1 * inv_scale;
+        bs[c] = b1;
+      }
+    }
+  }
   f32x16 acc[RT][CT];
 #pragma unroll
   for (int r = 0; r < RT; r++)
@@ -144,13 +208,24 @@ __global__ __launch_bounds__(256, 3) void dense_norm_kernel(const DenseArgs a) {
   for (int j = 0; j < 2; j++)
 #pragma unroll
     for (int c = 0; c < CT; c++) {
-      const int g = j & (nk16 - 1);
-      bq[j][c][0] = wbase[g * wstep + c * 128];
-      bq[j][c][1] = wbase[g * wstep + c * 128 + 64];
+      bq[j][c][0] = wbase1[j * wstep + c * 128];
+      bq[j][c][1] = wbase1[j * wstep + c * 128 + 64];
     }
 
-  auto multiply = [&](int buf, int s) {
+  auto multiply = [&](int buf, const StepPos& p) {
+    if constexpr (kDual) {
+      if (p.kk == nk1) {                                                 // between the two products: S1 G1 -> S2 G1 a1 / a2
+#pragma unroll
+        for (int r = 0; r < RT; r++)
+#pragma unroll
+          for (int c = 0; c < CT; c++) acc[r][c] *= rescale[c];
+      }
+    }
     const unsigned char* img = lds + buf * kBufB + a_read;
+    // weight fragments of the NEXT K-step (the sequence wraps at a tile end)
+    const int kn = p.kk + 1 == nkt ? 0 : p.kk + 1;
+    const bool two_n = kDual && kn >= nk1;
+    const u32x4* wnext = (two_n ? wbase2 : wbase1) + (int64_t)(2 * (two_n ? kn - nk1 : kn)) * wstep;
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
       f16x8 av[RT][2];
@@ -177,23 +252,51 @@ __global__ __launch_bounds__(256, 3) void dense_norm_kernel(const DenseArgs a) {
 #pragma unroll
         for (int r = 0; r < RT; r++) acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[r][0], b0, acc[r][c], 0, 0, 0);
       }
-      {
-        const int g = (2 * ((s + 1) & (nk - 1)) + ks) & (nk16 - 1);    // the same sub-step of the next K-step (the sequence wraps at a tile end)
 #pragma unroll
-        for (int c = 0; c < CT; c++) {
-          bq[ks][c][0] = wbase[g * wstep + c * 128];
-          bq[ks][c][1] = wbase[g * wstep + c * 128 + 64];
-        }
+      for (int c = 0; c < CT; c++) {
+        bq[ks][c][0] = wnext[ks * wstep + c * 128];
+        bq[ks][c][1] = wnext[ks * wstep + c * 128 + 64];
       }
     }
-    if ((s & (nk - 1)) != nk - 1) return;
-    // ---- end of a row tile: store y, fold the tile into the running statistics of this wave's columns, clear the accumulators
-    const int tile = s >> lognk;
-    const long long trow0 = r0 + (long long)tile * TR + wm * (RT * 32);            // uniform
+    if (p.kk != nkt - 1) return;
+    // ---- end of a row tile
+    const long long trow0 = r0 + (long long)p.tile * TR + wm * (RT * 32);          // uniform
     const int rows_here = (int)(r1 - trow0 < RT * 32 ? (r1 - trow0 > 0 ? r1 - trow0 : 0) : RT * 32);
+    if constexpr (MODE >= 2) {
+      // out = lrelu(y scale + shift + R): the rows of this wave's block as buffers of rows_here rows (rows past the chunk read as zeros
+      // and are dropped on the store)
+      const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(a.out + trow0 * N, 0, rows_here * N * 4, 0x00020000);
+      const bool has_res = MODE == 2 && a.residual != nullptr;            // (no residual: an empty buffer, every load returns zero)
+      const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_res ? a.residual + trow0 * N : a.out), 0,
+                                                                           has_res ? rows_here * N * 4 : 0, 0x00020000);
+#pragma unroll
+      for (int c = 0; c < CT; c++) {
+        const int lane_off = (4 * h * N + (ct0 + c) * 32 + i32) * 4;
+#pragma unroll
+        for (int r = 0; r < RT; r++) {
+          float res[16];
+          if constexpr (MODE == 2) {
+#pragma unroll
+            for (int v = 0; v < 16; v++)
+              res[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, lane_off, (r * 32 + (v & 3) + 8 * (v >> 2)) * N * 4, 0));
+          }
+#pragma unroll
+          for (int v = 0; v < 16; v++) {
+            const int rr = r * 32 + (v & 3) + 8 * (v >> 2);
+            float val = acc[r][c][v] * fs[c] + bs[c];
+            if constexpr (MODE == 2) val += res[v];
+            val = val > 0.f ? val : val * a.final_slope;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ors, lane_off, rr * N * 4, 0);
+            acc[r][c][v] = 0.f;
+          }
+        }
+      }
+      return;
+    }
+    // MODE 0 / 1: [store y,] fold the tile into the running statistics of this wave's columns, clear the accumulators
     const int left = rows_here - 4 * h;                                            // rows of this lane's column slice that exist
     // the rows of this wave's block as a buffer of rows_here rows: stores to rows past the chunk fall outside and are dropped
-    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(a.out + trow0 * N, 0, rows_here * N * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(MODE == 0 ? a.out + trow0 * N : nullptr, 0, MODE == 0 ? rows_here * N * 4 : 0, 0x00020000);
 #pragma unroll
     for (int c = 0; c < CT; c++) {
       const int lane_off = (4 * h * N + (ct0 + c) * 32 + i32) * 4;
@@ -205,7 +308,7 @@ __global__ __launch_bounds__(256, 3) void dense_norm_kernel(const DenseArgs a) {
           const int rr = r * 32 + (v & 3) + 8 * (v >> 2);
           const float val = acc[r][c][v] * inv_scale;
           acc[r][c][v] = val;
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ors, lane_off, rr * N * 4, 0);
+          if constexpr (MODE == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ors, lane_off, rr * N * 4, 0);
           if (rr < left) {
             cnt += 1.f;
             sum += val;
@@ -230,23 +333,32 @@ __global__ __launch_bounds__(256, 3) void dense_norm_kernel(const DenseArgs a) {
   };
 
   f32x4 ra[U], rb[U];                                                   // the operands of steps s + 1 and s + 2
-  request(0, ra);
-  request(1, rb);
+  StepPos pr{0, 0}, ps{0, 0}, pm{0, 0};                                  // request / stage / multiply positions
+  request(pr, ra);
+  advance(pr);
+  request(pr, rb);
+  advance(pr);
   __syncthreads();                                                       // the affine table
-  stage(0, 0, ra);
+  stage(0, ps, ra);
+  advance(ps);
 #pragma unroll
   for (int j = 0; j < U; j++) ra[j] = rb[j];
-  request(2, rb);
+  request(pr, rb);
+  advance(pr);
   __syncthreads();
 #pragma unroll 1
   for (int s = 0; s < total; s++) {
-    multiply(s & 1, s);
-    stage((s + 1) & 1, s + 1, ra);
+    multiply(s & 1, pm);
+    advance(pm);
+    stage((s + 1) & 1, ps, ra);
+    advance(ps);
 #pragma unroll
     for (int j = 0; j < U; j++) ra[j] = rb[j];
-    request(s + 3, rb);
+    request(pr, rb);
+    advance(pr);
     __syncthreads();
   }
+  if constexpr (!kStats) return;
   // ---- the chunk's statistics: + bias, waves that share columns merged through LDS, channels merged into their groups across lanes
   __syncthreads();
   const int cpg = N / a.groups;                                          // channels per group: a power of two <= 32 (host-checked)
@@ -289,35 +401,19 @@ extern "C" size_t se3_dense_norm_workspace_bytes(int groups) {
   return kCounterB + (size_t)(kGNMaxChunks + kGNMaxSegments) * (groups > 0 ? groups : 1) * 3 * sizeof(float);
 }
 
-extern "C" int se3_dense_norm_fwd(const float* x, int64_t rows, int in_features, const float* in_affine_a, float in_slope_a,
-                                  const float* in_affine_b, float in_slope_b, const void* weight_pieces, int out_features,
-                                  const float* linear_bias, const float* norm_weight, const float* norm_bias, int groups, float eps,
-                                  const int64_t* segment_row_offsets_host, int num_segments, float* out, float* affine_out, void* workspace,
-                                  size_t workspace_bytes, void* stream) {
-  SE3_REQUIRE(x && weight_pieces && norm_weight && norm_bias && out && affine_out && workspace, SE3_ERR_INVALID_ARG, "dense_norm: null pointer");
-  const int K = in_features, N = out_features;
-  SE3_REQUIRE(K >= 32 && K <= 1024 && (K & (K - 1)) == 0 && N >= 32 && N % 32 == 0 && (N < 256 ? (N & (N - 1)) == 0 : N % 256 == 0),
-              SE3_ERR_UNSUPPORTED, "dense_norm: %d -> %d features (in: a power of two 32..1024; out: 32, 64, 128 or a multiple of 256)", K, N);
-  SE3_REQUIRE(rows >= 1 && groups >= 1 && N % groups == 0, SE3_ERR_INVALID_ARG, "dense_norm: rows %lld groups %d", (long long)rows, groups);
-  {
-    const int cpg = N / groups;
-    SE3_REQUIRE(cpg <= 32 && (cpg & (cpg - 1)) == 0 && N / (N >= 256 ? 256 : N) <= kGNMaxColumnBlocks, SE3_ERR_UNSUPPORTED,
-                "dense_norm: %d channels per group (a power of two <= 32), %d output features (<= %d)", cpg, N, 256 * kGNMaxColumnBlocks);
-  }
-  SE3_REQUIRE(num_segments >= 1 && num_segments <= kGNMaxSegments && (num_segments == 1 || segment_row_offsets_host), SE3_ERR_UNSUPPORTED,
-              "dense_norm: %d segments (1..%d)", num_segments, kGNMaxSegments);
-  SE3_REQUIRE(((uintptr_t)x & 15) == 0 && (in_affine_a || !in_affine_b), SE3_ERR_INVALID_ARG, "dense_norm: x must be 16-byte aligned; stage b needs stage a");
-  SE3_REQUIRE(workspace_bytes >= se3_dense_norm_workspace_bytes(groups), SE3_ERR_WORKSPACE, "dense_norm: workspace too small");
-  const int TR = N >= 256 ? 64 : 128, BN = N >= 256 ? 256 : N;
-  const int ncb = N / BN;
-  // row chunks: whole row tiles, about g_target_chunks workgroups in all, never across a segment boundary
-  SegTable T{};
+namespace {
+// row chunks: whole row tiles, about g_target_chunks workgroups in all, never across a segment boundary
+int dense_chunks(int64_t rows, int N, const int64_t* segment_row_offsets_host, int num_segments, SegTable& T, int& TR, int& BN, int& ncb) {
+  TR = N >= 256 ? 64 : 128;
+  BN = N >= 256 ? 256 : N;
+  ncb = N / BN;
+  T = SegTable{};
   T.n = num_segments;
   T.quantum = TR;
   int64_t tiles = 0;
   for (int s = 0; s < num_segments; s++) {
     const int64_t b0 = num_segments == 1 ? 0 : segment_row_offsets_host[s], b1 = num_segments == 1 ? rows : segment_row_offsets_host[s + 1];
-    SE3_REQUIRE(b1 > b0 && b0 >= 0 && b1 <= rows, SE3_ERR_INVALID_ARG, "dense_norm: segment %d rows [%lld, %lld)", s, (long long)b0, (long long)b1);
+    if (!(b1 > b0 && b0 >= 0 && b1 <= rows)) return -1;
     tiles += se3_cdiv(b1 - b0, TR);
   }
   int64_t want = g_target_chunks / ncb;
@@ -338,8 +434,43 @@ extern "C" int se3_dense_norm_fwd(const float* x, int64_t rows, int in_features,
     chunks += (int)se3_cdiv(se3_cdiv(b1 - b0, TR), tiles_per_chunk);
     T.chunk_begin[s + 1] = chunks;
   }
-  SE3_REQUIRE(T.row_begin[0] == 0 && T.row_begin[num_segments] == rows && chunks <= kGNMaxChunks + kGNMaxSegments, SE3_ERR_INVALID_ARG,
-              "dense_norm: the segments must cover all rows");
+  if (!(T.row_begin[0] == 0 && T.row_begin[num_segments] == rows && chunks <= kGNMaxChunks + kGNMaxSegments)) return -1;
+  return chunks;
+}
+
+template <int MODE>
+void dense_launch(const DenseArgs& a, int N, dim3 grid, size_t dyn, hipStream_t st) {
+  if (N >= 256) dense_norm_kernel<1, 4, 2, 2, MODE><<<grid, 256, dyn, st>>>(a);
+  else if (N == 128) dense_norm_kernel<2, 2, 2, 2, MODE><<<grid, 256, dyn, st>>>(a);
+  else if (N == 64) dense_norm_kernel<4, 1, 1, 2, MODE><<<grid, 256, dyn, st>>>(a);
+  else dense_norm_kernel<4, 1, 1, 1, MODE><<<grid, 256, dyn, st>>>(a);
+}
+}  // namespace
+
+// out == NULL: statistics only (MODE 1) -- the GEMM runs, its result is reduced to the affine table and never stored.
+extern "C" int se3_dense_norm_fwd(const float* x, int64_t rows, int in_features, const float* in_affine_a, float in_slope_a,
+                                  const float* in_affine_b, float in_slope_b, const void* weight_pieces, int out_features,
+                                  const float* linear_bias, const float* norm_weight, const float* norm_bias, int groups, float eps,
+                                  const int64_t* segment_row_offsets_host, int num_segments, float* out, float* affine_out, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  SE3_REQUIRE(x && weight_pieces && norm_weight && norm_bias && affine_out && workspace, SE3_ERR_INVALID_ARG, "dense_norm: null pointer");
+  const int K = in_features, N = out_features;
+  SE3_REQUIRE(K >= 32 && K <= 1024 && (K & (K - 1)) == 0 && N >= 32 && N % 32 == 0 && (N < 256 ? (N & (N - 1)) == 0 : N % 256 == 0),
+              SE3_ERR_UNSUPPORTED, "dense_norm: %d -> %d features (in: a power of two 32..1024; out: 32, 64, 128 or a multiple of 256)", K, N);
+  SE3_REQUIRE(rows >= 1 && groups >= 1 && N % groups == 0, SE3_ERR_INVALID_ARG, "dense_norm: rows %lld groups %d", (long long)rows, groups);
+  {
+    const int cpg = N / groups;
+    SE3_REQUIRE(cpg <= 32 && (cpg & (cpg - 1)) == 0 && N / (N >= 256 ? 256 : N) <= kGNMaxColumnBlocks, SE3_ERR_UNSUPPORTED,
+                "dense_norm: %d channels per group (a power of two <= 32), %d output features (<= %d)", cpg, N, 256 * kGNMaxColumnBlocks);
+  }
+  SE3_REQUIRE(num_segments >= 1 && num_segments <= kGNMaxSegments && (num_segments == 1 || segment_row_offsets_host), SE3_ERR_UNSUPPORTED,
+              "dense_norm: %d segments (1..%d)", num_segments, kGNMaxSegments);
+  SE3_REQUIRE(((uintptr_t)x & 15) == 0 && (in_affine_a || !in_affine_b), SE3_ERR_INVALID_ARG, "dense_norm: x must be 16-byte aligned; stage b needs stage a");
+  SE3_REQUIRE(workspace_bytes >= se3_dense_norm_workspace_bytes(groups), SE3_ERR_WORKSPACE, "dense_norm: workspace too small");
+  SegTable T;
+  int TR, BN, ncb;
+  const int chunks = dense_chunks(rows, N, segment_row_offsets_host, num_segments, T, TR, BN, ncb);
+  SE3_REQUIRE(chunks > 0, SE3_ERR_INVALID_ARG, "dense_norm: the segments must be non-empty, ascending and cover all %lld rows", (long long)rows);
   DenseArgs a{};
   a.x = x;
   a.in_affine[0] = in_affine_a;
@@ -364,10 +495,64 @@ extern "C" int se3_dense_norm_fwd(const float* x, int64_t rows, int in_features,
   const size_t dyn = (size_t)((in_affine_a != nullptr) + (in_affine_b != nullptr)) * 2 * K * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)chunks, (unsigned)ncb);
-  if (N >= 256) dense_norm_kernel<1, 4, 2, 2><<<grid, 256, dyn, st>>>(a);
-  else if (N == 128) dense_norm_kernel<2, 2, 2, 2><<<grid, 256, dyn, st>>>(a);
-  else if (N == 64) dense_norm_kernel<4, 1, 1, 2><<<grid, 256, dyn, st>>>(a);
-  else dense_norm_kernel<4, 1, 1, 1><<<grid, 256, dyn, st>>>(a);
+  if (out != nullptr) dense_launch<0>(a, N, grid, dyn, st);
+  else dense_launch<1>(a, N, grid, dyn, st);
   SE3_CHECK_LAUNCH("dense_norm");
+  return SE3_OK;
+}
+
+// The tail of a bottleneck block (blocks_epn.py:838-852: x = unary2(x); return lrelu(x + shortcut)) with nothing of the output's width
+// written but the output: out = lrelu( GroupNorm(T(x) W^T + b) + R ), the GroupNorm given by its table `affine` (a statistics-only
+// se3_dense_norm_fwd call on the same operands), R = `residual` (rows, out_features), or GroupNorm_2(x2 W2^T + b2) of the shortcut layer
+// given by (x2, weight_pieces2, affine2), or nothing.
+extern "C" int se3_dense_residual_fwd(const float* x, int64_t rows, int in_features, const float* in_affine_a, float in_slope_a,
+                                      const float* in_affine_b, float in_slope_b, const void* weight_pieces, const float* affine,
+                                      const float* x2, int in_features2, const void* weight_pieces2, const float* affine2,
+                                      const float* residual, int out_features, float final_slope, const int64_t* segment_row_offsets_host,
+                                      int num_segments, float* out, void* stream) {
+  SE3_REQUIRE(x && weight_pieces && affine && out, SE3_ERR_INVALID_ARG, "dense_residual: null pointer");
+  const int K = in_features, N = out_features, K2 = in_features2;
+  SE3_REQUIRE(K >= 32 && K <= 1024 && (K & (K - 1)) == 0 && N >= 32 && N % 32 == 0 && (N < 256 ? (N & (N - 1)) == 0 : N % 256 == 0),
+              SE3_ERR_UNSUPPORTED, "dense_residual: %d -> %d features (in: a power of two 32..1024; out: 32, 64, 128 or a multiple of 256)", K, N);
+  SE3_REQUIRE(!(x2 && residual), SE3_ERR_INVALID_ARG, "dense_residual: a residual tensor OR a shortcut layer");
+  SE3_REQUIRE(!x2 || (weight_pieces2 && affine2 && K2 >= 32 && K2 <= 1024 && (K2 & (K2 - 1)) == 0 && ((uintptr_t)x2 & 15) == 0), SE3_ERR_UNSUPPORTED,
+              "dense_residual: shortcut layer with %d input features (a power of two 32..1024, 16-byte aligned rows)", K2);
+  SE3_REQUIRE(rows >= 1 && num_segments >= 1 && num_segments <= kGNMaxSegments && (num_segments == 1 || segment_row_offsets_host), SE3_ERR_UNSUPPORTED,
+              "dense_residual: rows %lld, %d segments (1..%d)", (long long)rows, num_segments, kGNMaxSegments);
+  SE3_REQUIRE(((uintptr_t)x & 15) == 0 && (in_affine_a || !in_affine_b), SE3_ERR_INVALID_ARG, "dense_residual: x must be 16-byte aligned; stage b needs stage a");
+  SegTable T;
+  int TR, BN, ncb;
+  const int chunks = dense_chunks(rows, N, segment_row_offsets_host, num_segments, T, TR, BN, ncb);
+  SE3_REQUIRE(chunks > 0, SE3_ERR_INVALID_ARG, "dense_residual: the segments must be non-empty, ascending and cover all %lld rows", (long long)rows);
+  DenseArgs a{};
+  a.x = x;
+  a.in_affine[0] = in_affine_a;
+  a.in_affine[1] = in_affine_b;
+  a.in_slope[0] = in_slope_a;
+  a.in_slope[1] = in_slope_b;
+  a.K = K;
+  a.N = N;
+  a.NCT = (N + 63) / 64 * 2;
+  a.hdr = static_cast<const float*>(weight_pieces);
+  a.Wf = reinterpret_cast<const u32x4*>(static_cast<const unsigned char*>(weight_pieces) + kHeaderB);
+  a.out = out;
+  a.T = T;
+  a.affine1 = affine;
+  a.residual = residual;
+  a.final_slope = final_slope;
+  const size_t dyn = (size_t)((in_affine_a != nullptr) + (in_affine_b != nullptr)) * 2 * K * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)chunks, (unsigned)ncb);
+  if (x2 != nullptr) {
+    a.x2 = x2;
+    a.K2 = K2;
+    a.hdr2 = static_cast<const float*>(weight_pieces2);
+    a.Wf2 = reinterpret_cast<const u32x4*>(static_cast<const unsigned char*>(weight_pieces2) + kHeaderB);
+    a.affine2 = affine2;
+    dense_launch<3>(a, N, grid, dyn, st);
+  } else {
+    dense_launch<2>(a, N, grid, dyn, st);      // (residual == NULL: the kernel reads an empty buffer = zeros)
+  }
+  SE3_CHECK_LAUNCH("dense_residual");
   return SE3_OK;
 }

@@ -193,6 +193,24 @@ def dense_norm(x, weight, linear_bias, norm_weight, norm_bias, groups, eps):
     return _ops.dense_norm(x, weight, linear_bias, norm_weight, norm_bias, groups, eps, segments)
 
 
+RECOMPUTE_TAIL = True         # False: the round-3 block tail (unary2 / skip_conv store their raw output, one apply pass adds them: A/B runs)
+
+
+@_hip
+def dense_stats(x, weight, linear_bias, norm_weight, norm_bias, groups, eps):
+    """The affine table of GroupNorm(T(x) W^T + bias) from a GEMM whose product is never stored (csrc/dense_norm.hip, statistics-only mode)."""
+    segments = x.segments if isinstance(x, Pending) else row_segments(x)
+    return _ops.dense_stats(x, weight, linear_bias, norm_weight, norm_bias, groups, eps, segments)
+
+
+@_hip
+def dense_residual(x, weight, affine, residual=None, shortcut=None, final_slope=1.0):
+    """lrelu(GroupNorm(T(x) W^T + b) + R) with the GroupNorm as its table `affine` (dense_stats) and R a tensor, a shortcut layer
+    (x2, weight2, affine2) evaluated in the same kernel, or nothing: the block's output is the only wide tensor written."""
+    segments = x.segments if isinstance(x, Pending) else row_segments(x)
+    return _ops.dense_residual(x, weight, affine, residual, shortcut, final_slope, segments)
+
+
 @_hip
 def norm_stats(x, norm_weight, norm_bias, groups, eps, slope, x_bias=None):
     """x (tensor, or Pending with one stage) -> x with one more pending GroupNorm + LeakyReLU(slope) stage."""

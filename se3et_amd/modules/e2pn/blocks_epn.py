@@ -104,6 +104,12 @@ class UnaryBlockEPN(nn.Module):
         p.slopes[-1] = 1.0 if self.no_relu else 0.1
         return p
 
+    def stats(self, x):
+        """Inference: the affine table of norm(mlp(x)) from a GEMM that stores nothing (the expanding layers of a block: their product is
+        recomputed by the block's last kernel instead of making a round trip through HBM)."""
+        n = self.norm
+        return SF.dense_stats(x, self.mlp.weight, self.mlp.bias, n.norm.weight, n.norm.bias, n.num_groups, n.norm.eps)
+
 
 class LastUnaryBlockEPN(nn.Module):
     def __init__(self, in_dim, out_dim, bias=True):
@@ -160,6 +166,14 @@ class ResnetBottleneckBlockEPN(nn.Module):
         self.unary2 = UnaryBlockEPN(mid, out_dim, group_norm, bn, no_relu=True)
         self.skip_conv = UnaryBlockEPN(in_dim, out_dim, group_norm, bn, no_relu=True) if in_dim != out_dim else nn.Identity()
 
+    def _recompute_pays(self, rows):
+        """The recomputed tail runs the GEMMs of unary2 (and skip_conv) twice and saves two passes over the block's output: a gain while the
+        products are short (measured at the bench shapes, tools/micro/block_tail.py -> profiles/r04_block_tail.txt: mid + shortcut input
+        width <= 192, or a 128 -> 512 layer with an identity shortcut over >= 100 000 rows), a loss on the wide coarse layers, where the
+        second GEMM costs more than the two passes."""
+        k = self.unary2.in_dim + (0 if isinstance(self.skip_conv, nn.Identity) else self.skip_conv.in_dim)
+        return k <= 192 or (k == 128 and rows >= 100000)
+
     def _forward_pending(self, x, q_pts, s_pts, neighb_inds):
         """Inference (blocks_epn.py:798-852 with the norms in pending form): every dense layer takes the statistics of the norm behind it
         from its accumulators and applies the norm in front of it while loading; activations are written once, raw, and only the
@@ -171,6 +185,16 @@ class ResnetBottleneckBlockEPN(nn.Module):
         y = self.norm.pending(y, 0.1)                                         # norm of the activated norm: a second statistics pass
         if 'strided' in self.block_name:
             skip = SF.neighbor_max_pool(skip, neighb_inds)
+        if SF.RECOMPUTE_TAIL and self.unary2.no_relu and self._recompute_pays(y.raw.numel() // y.raw.shape[-1]) and (
+                isinstance(self.skip_conv, nn.Identity) or (self.skip_conv.no_relu and SF._ops.norm_weight_nonzero(self.skip_conv.norm.norm.weight))):
+            # unary2 (mid -> 4 mid channels) and skip_conv as statistics-only GEMMs, then ONE kernel that runs both products again and writes
+            # lrelu(norm(unary2) + shortcut): nothing of the output's width exists but the output (csrc/dense_norm.hip, round 4)
+            aff2 = self.unary2.stats(y)
+            if isinstance(self.skip_conv, nn.Identity):
+                return SF.dense_residual(y, self.unary2.mlp.weight, aff2, residual=skip, final_slope=0.1)
+            skip = skip.contiguous()
+            return SF.dense_residual(y, self.unary2.mlp.weight, aff2, shortcut=(skip, self.skip_conv.mlp.weight, self.skip_conv.stats(skip)),
+                                     final_slope=0.1)
         if not isinstance(self.skip_conv, nn.Identity):
             skip = self.skip_conv.pending(skip)
         return SF.norm_apply(self.unary2.pending(y), residual=skip, final_slope=0.1)

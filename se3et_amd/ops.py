@@ -612,6 +612,87 @@ def dense_norm(x, weight, linear_bias, norm_weight, norm_bias, groups, eps, segm
     return Pending(out, [affine], [1.0], segments)
 
 
+def dense_stats(x, weight, linear_bias, norm_weight, norm_bias, groups, eps, segments=None):
+    """HIP (csrc/dense_norm.hip, statistics-only mode): the affine table (nseg, 2, N) of GroupNorm(T(x) W^T + linear_bias) -- the GEMM runs and
+    is reduced to its statistics, the product is never written.  x: a tensor or a Pending (at most two stages)."""
+    pend = x if isinstance(x, Pending) else Pending(x, [], [], segments)
+    raw = _req(pend.raw, torch.float32, 'x')
+    if len(pend.affines) > 2:
+        raise RuntimeError('dense_stats: at most two pending stages')
+    segments = pend.segments if segments is None else segments
+    N, K = weight.shape
+    rows = raw.numel() // K
+    stream = _stream()
+    Wp = _linear_weight_pieces(weight, stream)
+    nseg = 1 if segments is None else len(segments) - 1
+    affine = torch.empty((nseg, 2, N), dtype=torch.float32, device=raw.device)
+    ws = _dense_workspace(raw.device, stream, lib().se3_dense_norm_workspace_bytes(int(groups)))
+    aa = pend.affines + [None, None]
+    sl = pend.slopes + [1.0, 1.0]
+    check(lib().se3_dense_norm_fwd(raw.data_ptr(), rows, K, aa[0].data_ptr() if aa[0] is not None else None, float(sl[0]),
+                                   aa[1].data_ptr() if aa[1] is not None else None, float(sl[1]), Wp.data_ptr(), N,
+                                   linear_bias.data_ptr() if linear_bias is not None else None, norm_weight.data_ptr(), norm_bias.data_ptr(),
+                                   int(groups), float(eps), _i64_array(segments) if nseg > 1 else None, nseg, None,
+                                   affine.data_ptr(), ws.data_ptr(), ws.numel(), stream), 'se3_dense_norm_fwd (statistics only)')
+    return affine
+
+
+_nonzero_norm_cache = {}
+
+
+def norm_weight_nonzero(weight):
+    """True when no entry of a GroupNorm weight is zero (one host synchronisation per weight version): dense_residual's shortcut form divides
+    by the shortcut norm's scale."""
+    key = (weight.data_ptr(), weight.device.index, tuple(weight.shape))
+    hit = _nonzero_norm_cache.get(key)
+    if hit is None or hit[0]() is not weight or hit[1] != weight._version:
+        hit = (weakref.ref(weight), weight._version, bool((weight.detach().abs() > 1e-30).all()))
+        if len(_nonzero_norm_cache) > 256:
+            _nonzero_norm_cache.clear()
+        _nonzero_norm_cache[key] = hit
+    return hit[2]
+
+
+def dense_residual(x, weight, affine, residual=None, shortcut=None, final_slope=1.0, segments=None):
+    """HIP (csrc/dense_norm.hip, final modes): out = lrelu( (T(x) W^T) * scale + shift + R ) with (scale, shift) = `affine` from dense_stats on
+    the same operands; R = `residual` (rows.., N) tensor, or the shortcut layer `shortcut` = (x2 tensor, weight2 (N, K2), affine2) evaluated in
+    the same kernel, or nothing.  The tail of a bottleneck block with only its output written."""
+    pend = x if isinstance(x, Pending) else Pending(x, [], [], segments)
+    raw = _req(pend.raw, torch.float32, 'x')
+    if len(pend.affines) > 2:
+        raise RuntimeError('dense_residual: at most two pending stages')
+    segments = pend.segments if segments is None else segments
+    N, K = weight.shape
+    rows = raw.numel() // K
+    stream = _stream()
+    Wp = _linear_weight_pieces(weight, stream)
+    nseg = 1 if segments is None else len(segments) - 1
+    if tuple(affine.shape) != (nseg, 2, N):
+        raise RuntimeError('dense_residual: affine table %s for %d segment(s) x %d features' % (tuple(affine.shape), nseg, N))
+    out = torch.empty(raw.shape[:-1] + (N,), dtype=torch.float32, device=raw.device)
+    x2p = wp2 = aff2 = resp = None
+    K2 = 0
+    if shortcut is not None:
+        x2, w2, aff2t = shortcut
+        x2 = _req(x2, torch.float32, 'shortcut input')
+        K2 = w2.shape[1]
+        if w2.shape[0] != N or x2.numel() != rows * K2 or tuple(aff2t.shape) != (nseg, 2, N) or residual is not None:
+            raise RuntimeError('dense_residual: shortcut layer shapes')
+        x2p, wp2, aff2 = x2.data_ptr(), _linear_weight_pieces(w2, stream).data_ptr(), aff2t.data_ptr()
+    elif residual is not None:
+        residual = _req(residual, torch.float32, 'residual')
+        if residual.numel() != rows * N:
+            raise RuntimeError('dense_residual: residual shape %s' % (tuple(residual.shape),))
+        resp = residual.data_ptr()
+    aa = pend.affines + [None, None]
+    sl = pend.slopes + [1.0, 1.0]
+    check(lib().se3_dense_residual_fwd(raw.data_ptr(), rows, K, aa[0].data_ptr() if aa[0] is not None else None, float(sl[0]),
+                                       aa[1].data_ptr() if aa[1] is not None else None, float(sl[1]), Wp.data_ptr(), affine.data_ptr(),
+                                       x2p, K2, wp2, aff2, resp, N, float(final_slope), _i64_array(segments) if nseg > 1 else None, nseg,
+                                       out.data_ptr(), stream), 'se3_dense_residual_fwd')
+    return out
+
+
 def group_norm_stats(x, weight, bias, groups, eps, x_bias=None, segments=None):
     """HIP (csrc/rowops.hip): the affine table (nseg, 2, C) of GroupNorm over T(x) (x: tensor, or Pending with ONE stage)."""
     pend = x if isinstance(x, Pending) else Pending(x, [], [], segments)

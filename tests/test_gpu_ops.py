@@ -946,6 +946,71 @@ def test_dense_norm_matches_linear_then_group_norm(rows, K, N, groups, nstage, s
     assert float((got4 - ref4).abs().max()) <= 2e-5 * max(1.0, float(ref4.abs().max()))
 
 
+@pytest.mark.parametrize('rows,K,N,K2,groups,nstage,seg', [
+    (6000, 32, 128, 0, 32, 2, None), (5001, 64, 256, 0, 32, 2, [0, 1999, 5001]), (4100, 32, 128, 64, 32, 2, [0, 130, 2000, 4100]),
+    (7000, 64, 256, 128, 32, 2, [0, 3500, 7000]), (3000, 128, 512, 256, 32, 1, None), (1300, 256, 1024, 512, 32, 2, [0, 64, 1300]),
+    (2500, 32, 64, 0, 16, 0, [0, 700, 2500]), (900, 64, 32, 32, 16, 1, None), (70, 256, 1024, 0, 32, 2, None)])
+def test_block_tail_recomputed_matches_stored_form(rows, K, N, K2, groups, nstage, seg):
+    """csrc/dense_norm.hip round 4: the statistics-only GEMM (dense_stats) gives the table of the storing form, and dense_residual --
+    lrelu(GroupNorm(T(x) W^T + b) + R), R a tensor (K2 = 0) or a shortcut layer GroupNorm_2(x2 W2^T + b2) evaluated in the same kernel --
+    equals the float64 formula and the round-3 composition (dense_norm + group_norm_apply)."""
+    from se3et_amd import ops
+    g = torch.Generator().manual_seed(rows + K + N + K2)
+    x = (torch.randn(rows, K, generator=g) * 2).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    gw, gb = (torch.rand(N, generator=g) + 0.5).cuda(), torch.randn(N, generator=g).cuda()
+    segs = seg or [0, rows]
+    nseg = len(segs) - 1
+    stages = [((torch.randn(nseg, 2, K, generator=g) * 0.5 + torch.tensor([1.0, 0.0])[None, :, None]).cuda(), sl) for sl in (0.1, 0.2)[:nstage]]
+    pend = ops.Pending(x, [a for a, _ in stages], [sl for _, sl in stages], seg)
+    stored = ops.dense_norm(pend, w, b, gw, gb, groups, 1e-5, seg)
+    aff = ops.dense_stats(pend, w, b, gw, gb, groups, 1e-5, seg)
+    assert torch.allclose(aff, stored.affines[0], rtol=1e-5, atol=1e-6)
+
+    def gn64(y, weight, bias):
+        out = torch.empty_like(y)
+        for s in range(nseg):
+            v = y[segs[s]:segs[s + 1]].reshape(-1, groups, N // groups)
+            m, var = v.mean((0, 2), keepdim=True), v.var((0, 2), unbiased=False, keepdim=True)
+            out[segs[s]:segs[s + 1]] = ((v - m) / (var + 1e-5).sqrt()).reshape(-1, N) * weight.double() + bias.double()
+        return out
+
+    main = gn64(_pending_reference(x, stages, segs) @ w.double().t() + b.double(), gw, gb)
+    if K2 == 0:
+        res = torch.randn(rows, N, generator=g).cuda()
+        got = ops.dense_residual(pend, w, aff, residual=res, final_slope=0.1, segments=seg)
+        ref = main + res.double()
+        old = ops.group_norm_apply(stored, res, 0.1)
+        # no residual at all
+        got0 = ops.dense_residual(pend, w, aff, final_slope=0.1, segments=seg)
+        ref0 = torch.where(main > 0, main, main * 0.1)
+        assert float((got0.double() - ref0).abs().max()) <= 2e-5 * max(1.0, float(ref0.abs().max()))
+    else:
+        x2 = torch.randn(rows, K2, generator=g).cuda()
+        w2 = (torch.randn(N, K2, generator=g) / K2 ** 0.5).cuda()
+        b2 = torch.randn(N, generator=g).cuda()
+        gw2, gb2 = (torch.rand(N, generator=g) + 0.5).cuda() * torch.where(torch.rand(N, generator=g) < 0.5, -1.0, 1.0).cuda(), torch.randn(N, generator=g).cuda()
+        assert ops.norm_weight_nonzero(gw2)
+        aff2 = ops.dense_stats(x2, w2, b2, gw2, gb2, groups, 1e-5, seg)
+        got = ops.dense_residual(pend, w, aff, shortcut=(x2, w2, aff2), final_slope=0.1, segments=seg)
+        ref = main + gn64(x2.double() @ w2.double().t() + b2.double(), gw2, gb2)
+        old = ops.group_norm_apply(stored, ops.dense_norm(ops.Pending(x2, [], [], seg), w2, b2, gw2, gb2, groups, 1e-5, seg), 0.1)
+    ref = torch.where(ref > 0, ref, ref * 0.1)
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((got.double() - ref).abs().max()) <= 2e-5 * scale
+    assert float((got - old).abs().max()) <= 2e-5 * scale
+
+
+def test_norm_weight_nonzero_gate():
+    from se3et_amd import ops
+    w = torch.nn.Parameter(torch.ones(64).cuda())
+    assert ops.norm_weight_nonzero(w)
+    with torch.no_grad():
+        w[3] = 0.0
+    assert not ops.norm_weight_nonzero(w)
+
+
 @pytest.mark.parametrize('P,Ns,NN,Cin,Cout,box', [(77, 90, 38, 24, 32, 0.05), (130, 130, 40, 40, 96, 0.04), (33, 64, 36, 8, 64, 0.05),
                                                   (200, 260, 48, 72, 160, 0.06), (16, 16, 16, 16, 32, 0.03), (95, 400, 64, 64, 256, 0.08),
                                                   (100, 150, 36, 128, 128, 0.05), (50, 90, 38, 256, 256, 0.05), (700, 900, 38, 256, 256, 0.12)])
