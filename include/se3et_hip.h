@@ -194,6 +194,15 @@ int se3_dense_residual_fwd(const float* x, int64_t rows, int in_features, const 
                            float in_slope_b, const void* weight_pieces, const float* affine, const float* x2, int in_features2,
                            const void* weight_pieces2, const float* affine2, const float* residual, int out_features, float final_slope,
                            const int64_t* segment_row_offsets_host, int num_segments, float* out, void* stream);
+/* Round 4 -- the streaming kernel as a plain dense layer for ANY row count and row strides: out = act(x W^T + bias), weight_pieces from
+ * se3_linear_split_weights_f16 (in_features % 32 == 0, |x| < 65504, f32 accuracy).  Replaces the library GEMMs of the transformer's nn.Linear
+ * layers (rpe_transformer.py:56-73,134-165; vanilla_transformer.py:22-37; output_layer.py:7-47; geotransformer.py:213-317).
+ * se3_linear_stream_transposed stores the product of every block of `block_rows` rows transposed, out_t (rows / block_rows, out_features, ld):
+ * the value projection in the attention kernels' operand layout V^T (A, C, Rp) straight from the packed rows (A, R, C). */
+int se3_linear_stream(const float* x, int64_t rows, int in_features, int64_t x_row_stride, const void* weight_pieces, const float* bias,
+                      int out_features, int apply_relu, float* out, int64_t out_row_stride, void* stream);
+int se3_linear_stream_transposed(const float* x, int64_t rows, int in_features, int64_t x_row_stride, const void* weight_pieces,
+                                 const float* bias, int out_features, int block_rows, float* out_t, int64_t ld, void* stream);
 /* Tuning hook (tools/micro): workgroups se3_dense_norm_fwd aims at (default 768 = 3 per compute unit, all resident at once). */
 void se3_dense_norm_set_target_chunks(int workgroups);
 

@@ -73,12 +73,11 @@ def _cross_plain(layer, Pq, Pk, xq, xk, xv):
     k = SF.linear(xk, att.proj_k.weight, att.proj_k.bias)
     C = q.shape[-1]
     w_v, b_v = att.proj_v.weight, att.proj_v.bias
+    vt = SF.project_values_transposed(xv.contiguous(), w_v, b_v)           # (C, Rk) or (A, C, Rk): Rk a multiple of 32 (packed rows)
     if xv.dim() == 2:
-        vt = torch.addmm(b_v[:, None].expand(C, xv.shape[0]), w_v, xv.t())
         hidden = torch.zeros((Pq.rows, C), dtype=torch.float32, device=q.device)
     else:
         A = xv.shape[0]
-        vt = torch.baddbmm(b_v[None, :, None].expand(A, C, xv.shape[1]), w_v[None].expand(A, C, C), xv.transpose(1, 2))
         hidden = torch.zeros((A, Pq.rows, C), dtype=torch.float32, device=q.device)
     _ops.attention_stack(q, k, vt, None, None, Pq.starts, Pq.lengths, Pk.starts, Pk.lengths, H, hidden)
     al = layer.attention
@@ -97,7 +96,7 @@ def _cross_eq(layer, Pq, Pk, xq, xk):
     k = SF.linear(xk, att.proj_k.weight, att.proj_k.bias)
     A, C = xk.shape[0], q.shape[-1]
     w_v, b_v = att.proj_v.weight, att.proj_v.bias
-    vt = torch.baddbmm(b_v[None, :, None].expand(A, C, xk.shape[1]), w_v[None].expand(A, C, C), xk.transpose(1, 2))
+    vt = SF.project_values_transposed(xk.contiguous(), w_v, b_v)
     # few pairs: the key anchors divided over G workgroups whose partial results lie side by side along the channels; the output
     # projection below adds them (its weight repeated G times along the input dimension)
     G = _ops.cross_eq_groups(A, Pq.lengths, H, C, Pk.starts, vt) if q.is_contiguous() and k.is_contiguous() else 1

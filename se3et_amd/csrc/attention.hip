@@ -1495,6 +1495,8 @@ static int launch_rpe_bias(const float* qp, const float* qe, int row_stride, int
   }
   SE3_REQUIRE(total < (1ll << 31), SE3_ERR_UNSUPPORTED, "rpe_bias: too many (row, key tile) units");
   S.total_units = (int)total;
+  if (g_bias_variant == 9)      // diagnostic (tools/micro/rpe_eq_breakdown.py): every cloud writes its logits over the first cloud's block -- 1/16 of the bytes
+    for (int c = 1; c < S.n; c++) S.c[c].bias_off = S.c[0].bias_off;
   // one resident round, each workgroup with a balanced range of units: 3 workgroups of 4 waves per CU (LDS: fragments + staging) for the
   // f32 / bf16-embedding kernels, 2 for the f16-split kernel (the splits need ~190 registers; 8 waves x 16 KB stay in flight per CU)
   const bool half_split = !emb_bf16 && g_bias_variant != 2 && g_bias_variant != 3 && (qe == nullptr || H % 4 == 0);

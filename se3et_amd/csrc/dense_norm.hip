@@ -61,11 +61,17 @@ struct DenseArgs {
   const float* hdr2;
   const float* affine2;      // [segment][2][N]
   float final_slope;
+  // plain modes (4, 5): out = act(T(x) W^T + bias); x rows x_rs floats apart, out rows out_rs floats apart (0: K / N)
+  int x_rs, out_rs;
+  int t_rows;                // MODE 5: rows per output block (anchor): out is (rows / t_rows, N, t_ld) -- the product transposed per block
+  int t_ld;
 };
 
 
 // WM x WN waves, each RT x CT MFMA tiles of 32 x 32: rows per tile TR = 32 RT WM, columns per workgroup BN = 32 CT WN.
-// MODE 0: store y + statistics; 1: statistics only; 2: final with a residual tensor; 3: final with a second (shortcut) GEMM.
+// MODE 0: store y + statistics; 1: statistics only; 2: final with a residual tensor; 3: final with a second (shortcut) GEMM;
+// 4: plain dense layer, out = act(x W^T + bias) (any K % 32 == 0, any N, row strides: the transformer's linears, se3_linear_stream);
+// 5: the same with the product stored TRANSPOSED per block of t_rows rows (the value projection in the attention kernels' operand layout).
 // The K-steps of a row tile are those of source 1 (K / 32) followed, in MODE 3, by those of source 2 (K2 / 32); the walk over (tile, step)
 // is three uniform counters (request: three steps ahead, stage: one ahead, multiply).
 struct StepPos {
@@ -78,7 +84,7 @@ __global__ __launch_bounds__(256, MODE == 3 ? 2 : 3) void dense_norm_kernel(cons
   static_assert(WM * WN == 4, "4 waves");
   constexpr int TR = 32 * RT * WM, BN = 32 * CT * WN, U = TR / 32;      // U: float4 units per thread and K-step
   constexpr int kPieceB = TR * kRowB, kBufB = 2 * kPieceB;
-  constexpr bool kStats = MODE <= 1, kDual = MODE == 3;
+  constexpr bool kStats = MODE <= 1, kDual = MODE == 3, kPlain = MODE >= 4;
   __shared__ __align__(16) unsigned char lds[2 * kBufB];
   extern __shared__ __align__(16) float aff[];                           // [stage][2][K] of this workgroup's segment
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,6 +92,7 @@ __global__ __launch_bounds__(256, MODE == 3 ? 2 : 3) void dense_norm_kernel(cons
   const int i32 = lane & 31, h = lane >> 5;
   const int K = a.K, N = a.N;
   const int K2 = kDual ? a.K2 : 32;
+  const int XS = kPlain ? a.x_rs : K, OS = kPlain ? a.out_rs : N;        // row strides of x and out in floats
   long long r0, r1;
   chunk_rows(a.T, blockIdx.x, r0, r1);
   if (r1 < r0) r1 = r0;                                                  // (a chunk emptied by the row quantum: no tiles, partials that count nothing)
@@ -117,11 +124,11 @@ __global__ __launch_bounds__(256, MODE == 3 ? 2 : 3) void dense_norm_kernel(cons
   const int q = tid & 7, urow = tid >> 3;
   const long long rbase = r1 > r0 ? r0 : 0;
   const int nrows = (int)(r1 - r0);
-  const int xoff1 = (urow * K + 4 * q) * 4, xoff2 = (urow * K2 + 4 * q) * 4;
+  const int xoff1 = (urow * XS + 4 * q) * 4, xoff2 = (urow * K2 + 4 * q) * 4;
   auto request = [&](const StepPos& p, f32x4 (&v)[U]) {
     const bool two = kDual && p.kk >= nk1;                               // uniform
-    const int Ks = two ? K2 : K, kloc = two ? p.kk - nk1 : p.kk;
-    const float* base = two ? a.x2 + rbase * K2 : a.x + rbase * K;
+    const int Ks = two ? K2 : XS, kloc = two ? p.kk - nk1 : p.kk;
+    const float* base = two ? a.x2 + rbase * K2 : a.x + rbase * XS;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, nrows * Ks * 4, 0x00020000);
     const int soff = (p.tile * TR * Ks + kloc * 32) * 4, xoff = two ? xoff2 : xoff1, jstep = 32 * Ks * 4;
 #pragma unroll
@@ -168,13 +175,23 @@ __global__ __launch_bounds__(256, MODE == 3 ? 2 : 3) void dense_norm_kernel(cons
   const int ct0 = blockIdx.y * (BN / 32) + wn * CT;
   const u32x4* wbase1 = a.Wf + (int64_t)ct0 * 2 * 64 + lane;
   const u32x4* wbase2 = kDual ? a.Wf2 + (int64_t)ct0 * 2 * 64 + lane : wbase1;
+  int coff[CT];                                                          // fragment offset of this wave's column tile c (plain modes: N need
+#pragma unroll                                                           // not fill the last column block -- tiles past the end re-read the last one)
+  for (int c = 0; c < CT; c++) coff[c] = kPlain ? ((ct0 + c < a.NCT ? ct0 + c : a.NCT - 1) - ct0) * 128 : c * 128;
   const int64_t wstep = (int64_t)a.NCT * 2 * 64;                        // u32x4 per K16-step (the same for both sources: same N)
   const float inv_scale = a.hdr[0];
   // final modes: per-column constants of this lane's CT columns
   float fs[CT], bs[CT], rescale[CT];
 #pragma unroll
   for (int c = 0; c < CT; c++) fs[c] = bs[c] = rescale[c] = 1.f;
-  if constexpr (MODE >= 2) {
+  if constexpr (kPlain) {
+#pragma unroll
+    for (int c = 0; c < CT; c++) {
+      const int col = (ct0 + c) * 32 + i32;
+      fs[c] = inv_scale;
+      bs[c] = (a.xb != nullptr && col < N) ? a.xb[col] : 0.f;
+    }
+  } else if constexpr (MODE >= 2) {
 #pragma unroll
     for (int c = 0; c < CT; c++) {
       const int col = (ct0 + c) * 32 + i32;
@@ -208,8 +225,8 @@ __global__ __launch_bounds__(256, MODE == 3 ? 2 : 3) void dense_norm_kernel(cons
   for (int j = 0; j < 2; j++)
 #pragma unroll
     for (int c = 0; c < CT; c++) {
-      bq[j][c][0] = wbase1[j * wstep + c * 128];
-      bq[j][c][1] = wbase1[j * wstep + c * 128 + 64];
+      bq[j][c][0] = wbase1[j * wstep + coff[c]];
+      bq[j][c][1] = wbase1[j * wstep + coff[c] + 64];
     }
 
   auto multiply = [&](int buf, const StepPos& p) {
@@ -254,14 +271,62 @@ __global__ __launch_bounds__(256, MODE == 3 ? 2 : 3) void dense_norm_kernel(cons
       }
 #pragma unroll
       for (int c = 0; c < CT; c++) {
-        bq[ks][c][0] = wnext[ks * wstep + c * 128];
-        bq[ks][c][1] = wnext[ks * wstep + c * 128 + 64];
+        bq[ks][c][0] = wnext[ks * wstep + coff[c]];
+        bq[ks][c][1] = wnext[ks * wstep + coff[c] + 64];
       }
     }
     if (p.kk != nkt - 1) return;
     // ---- end of a row tile
     const long long trow0 = r0 + (long long)p.tile * TR + wm * (RT * 32);          // uniform
     const int rows_here = (int)(r1 - trow0 < RT * 32 ? (r1 - trow0 > 0 ? r1 - trow0 : 0) : RT * 32);
+    if constexpr (MODE == 4) {
+      // out = act(acc / S + bias): rows past the chunk and columns past N get an out-of-range offset (dropped by the buffer bounds check:
+      // the store instruction itself stays unconditional, so the number of outstanding memory operations does not depend on the path)
+      const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(a.out + trow0 * OS, 0, rows_here > 0 ? ((rows_here - 1) * OS + N) * 4 : 0, 0x00020000);
+#pragma unroll
+      for (int c = 0; c < CT; c++) {
+        const int col = (ct0 + c) * 32 + i32;
+        const int lane_off = col < N ? (4 * h * OS + col) * 4 : 0x7ffffff0;
+#pragma unroll
+        for (int r = 0; r < RT; r++)
+#pragma unroll
+          for (int v = 0; v < 16; v++) {
+            const int rr = r * 32 + (v & 3) + 8 * (v >> 2);
+            float val = acc[r][c][v] * fs[c] + bs[c];
+            val = val > 0.f ? val : val * a.final_slope;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ors, lane_off, rr * OS * 4, 0);
+            acc[r][c][v] = 0.f;
+          }
+      }
+      return;
+    }
+    if constexpr (MODE == 5) {
+      // transposed per block of t_rows rows: out[(row / t_rows) N + col][row % t_rows]; a lane's four consecutive rows are one 16-byte store
+      // (t_rows % 4 == 0, tiles start at multiples of 32 rows: a group of four never straddles a block or the end of the rows)
+      const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+      for (int c = 0; c < CT; c++) {
+        const int col = (ct0 + c) * 32 + i32;
+#pragma unroll
+        for (int r = 0; r < RT; r++)
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            const long long row = trow0 + r * 32 + 8 * g + 4 * h;
+            const int blk = (int)(row / a.t_rows), rloc = (int)(row - (long long)blk * a.t_rows);
+            f32x4 v4;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              float val = acc[r][c][4 * g + j] * fs[c] + bs[c];
+              v4[j] = val > 0.f ? val : val * a.final_slope;
+              acc[r][c][4 * g + j] = 0.f;
+            }
+            const bool ok = col < N && row < r1;
+            const int off = ok ? (int)((((long long)blk * N + col) * a.t_ld + rloc) * 4) : 0x7ffffff0;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), ors, off, 0, 0);
+          }
+      }
+      return;
+    }
     if constexpr (MODE >= 2) {
       // out = lrelu(y scale + shift + R): the rows of this wave's block as buffers of rows_here rows (rows past the chunk read as zeros
       // and are dropped on the store)
@@ -403,10 +468,13 @@ extern "C" size_t se3_dense_norm_workspace_bytes(int groups) {
 
 namespace {
 // row chunks: whole row tiles, about g_target_chunks workgroups in all, never across a segment boundary
-int dense_chunks(int64_t rows, int N, const int64_t* segment_row_offsets_host, int num_segments, SegTable& T, int& TR, int& BN, int& ncb) {
-  TR = N >= 256 ? 64 : 128;
-  BN = N >= 256 ? 256 : N;
-  ncb = N / BN;
+int dense_chunks(int64_t rows, int N, const int64_t* segment_row_offsets_host, int num_segments, SegTable& T, int& TR, int& BN, int& ncb,
+                 bool given = false) {
+  if (!given) {
+    TR = N >= 256 ? 64 : 128;
+    BN = N >= 256 ? 256 : N;
+  }
+  ncb = (N + BN - 1) / BN;
   T = SegTable{};
   T.n = num_segments;
   T.quantum = TR;
@@ -555,4 +623,89 @@ extern "C" int se3_dense_residual_fwd(const float* x, int64_t rows, int in_featu
   }
   SE3_CHECK_LAUNCH("dense_residual");
   return SE3_OK;
+}
+
+
+// ---- the same streaming kernel as a plain dense layer (the transformer's nn.Linear layers: rpe_transformer.py:56-73,134-165,
+// vanilla_transformer.py:22-37, output_layer.py:7-47; geotransformer.py:213-317 in_proj / out_proj) -----------------------------------------
+// out = act(x W^T + bias) for ANY row count: small products (a few thousand rows: the invariant layers, one pair per forward) take 64 x 128
+// or 64 x 64 tiles so that every compute unit gets a workgroup, large ones 64 x 256; the loads run two K-steps ahead across tile boundaries.
+namespace {
+template <int WM, int WN, int RT, int CT>
+void plain_launch(const DenseArgs& a, bool transposed, dim3 grid, hipStream_t st) {
+  if (transposed) dense_norm_kernel<WM, WN, RT, CT, 5><<<grid, 256, 0, st>>>(a);
+  else dense_norm_kernel<WM, WN, RT, CT, 4><<<grid, 256, 0, st>>>(a);
+}
+int linear_stream(const float* x, int64_t rows, int K, int64_t x_rs, const void* weight_pieces, const float* bias, int N, int relu, float* out,
+                  int64_t out_rs, int t_rows, int64_t t_ld, void* stream) {
+  SE3_REQUIRE(x && weight_pieces && out, SE3_ERR_INVALID_ARG, "linear_stream: null pointer");
+  SE3_REQUIRE(K > 0 && K % 32 == 0 && N > 0, SE3_ERR_UNSUPPORTED, "linear_stream: in_features %d must be a multiple of 32", K);
+  SE3_REQUIRE(x_rs >= K && x_rs % 4 == 0 && ((uintptr_t)x & 15) == 0 && rows * x_rs < (1ll << 29), SE3_ERR_INVALID_ARG,
+              "linear_stream: x rows must be 16-byte aligned, row stride %lld, below 2 GB", (long long)x_rs);
+  const bool transposed = t_rows > 0;
+  if (transposed)
+    SE3_REQUIRE(t_rows % 4 == 0 && rows % t_rows == 0 && t_ld >= t_rows && t_ld % 4 == 0 && ((uintptr_t)out & 15) == 0 &&
+                    (rows / t_rows) * N * t_ld < (1ll << 29),
+                SE3_ERR_INVALID_ARG, "linear_stream: transposed output blocks of %d rows (a multiple of 4 dividing %lld), leading dimension %lld",
+                t_rows, (long long)rows, (long long)t_ld);
+  else
+    SE3_REQUIRE(out_rs >= N && rows * out_rs < (1ll << 29), SE3_ERR_INVALID_ARG, "linear_stream: out row stride %lld", (long long)out_rs);
+  if (rows == 0) return SE3_OK;
+  // tile: 64 x 256 when that fills the chip, else 64 x 128, else 64 x 64 (N <= 64: 128 x 64 / 128 x 32 as the unary layers)
+  int TR, BN, cfg;
+  const int64_t rt64 = se3_cdiv(rows, 64);
+  if (N > 128) {
+    if (rt64 * se3_cdiv(N, 256) >= 512) { TR = 64; BN = 256; cfg = 0; }
+    else if (rt64 * se3_cdiv(N, 128) >= 320 || N % 128 > 64 || N % 128 == 0) { TR = 64; BN = 128; cfg = 1; }
+    else { TR = 64; BN = 64; cfg = 2; }
+  } else if (N > 64) { TR = rt64 >= 512 ? 128 : 64; BN = 128; cfg = rt64 >= 512 ? 3 : 1; }
+  else if (N > 32) { TR = rt64 >= 512 ? 128 : 64; BN = 64; cfg = rt64 >= 512 ? 4 : 2; }
+  else { TR = 128; BN = 32; cfg = 5; }
+  if (transposed && cfg == 3) { TR = 64; cfg = 1; }          // (the 128 x 128 tile with the transposed epilogue spills)
+  SegTable T;
+  int ncb;
+  const int chunks = dense_chunks(rows, N, nullptr, 1, T, TR, BN, ncb, true);
+  SE3_REQUIRE(chunks > 0, SE3_ERR_INVALID_ARG, "linear_stream: %lld rows", (long long)rows);
+  DenseArgs a{};
+  a.x = x;
+  a.K = K;
+  a.N = N;
+  a.NCT = (N + 63) / 64 * 2;
+  a.hdr = static_cast<const float*>(weight_pieces);
+  a.Wf = reinterpret_cast<const u32x4*>(static_cast<const unsigned char*>(weight_pieces) + kHeaderB);
+  a.out = out;
+  a.xb = bias;
+  a.T = T;
+  a.final_slope = relu ? 0.f : 1.f;
+  a.x_rs = (int)x_rs;
+  a.out_rs = (int)out_rs;
+  a.t_rows = t_rows;
+  a.t_ld = (int)t_ld;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)chunks, (unsigned)ncb);
+  switch (cfg) {
+    case 0: plain_launch<1, 4, 2, 2>(a, transposed, grid, st); break;
+    case 1: plain_launch<2, 2, 1, 2>(a, transposed, grid, st); break;
+    case 2: plain_launch<2, 2, 1, 1>(a, transposed, grid, st); break;
+    case 3: plain_launch<2, 2, 2, 2>(a, transposed, grid, st); break;
+    case 4: plain_launch<4, 1, 1, 2>(a, transposed, grid, st); break;
+    default: plain_launch<4, 1, 1, 1>(a, transposed, grid, st); break;
+  }
+  SE3_CHECK_LAUNCH("linear_stream");
+  return SE3_OK;
+}
+}  // namespace
+
+extern "C" int se3_linear_stream(const float* x, int64_t rows, int in_features, int64_t x_row_stride, const void* weight_pieces, const float* bias,
+                                 int out_features, int apply_relu, float* out, int64_t out_row_stride, void* stream) {
+  return linear_stream(x, rows, in_features, x_row_stride, weight_pieces, bias, out_features, apply_relu, out, out_row_stride, 0, 0, stream);
+}
+
+// out_t (rows / block_rows, out_features, ld): the product of every block of `block_rows` consecutive rows stored transposed -- the value
+// projection V^T (A, C, Rp) of the attention kernels from packed rows (A, R, C) in ONE launch (rpe_transformer.py:60-62 proj_v + the
+// 'b n (h c) -> b h n c' rearrange; se3et_amd.functional.project_values_transposed).
+extern "C" int se3_linear_stream_transposed(const float* x, int64_t rows, int in_features, int64_t x_row_stride, const void* weight_pieces,
+                                            const float* bias, int out_features, int block_rows, float* out_t, int64_t ld, void* stream) {
+  SE3_REQUIRE(block_rows > 0, SE3_ERR_INVALID_ARG, "linear_stream_transposed: block_rows %d", block_rows);
+  return linear_stream(x, rows, in_features, x_row_stride, weight_pieces, bias, out_features, 0, out_t, 0, block_rows, ld, stream);
 }

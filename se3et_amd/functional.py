@@ -6,6 +6,7 @@ design allows for non-fused GEMMs).  Nothing here runs on the CPU: tensors must 
 library raises (se3et_amd._lib).
 """
 import math
+import os
 
 import threading
 
@@ -33,12 +34,21 @@ shared_tensors = _ops._Shared          # device tensors cached across host threa
 to_device = _ops.to_device
 
 
+LINEAR_STREAM = os.environ.get('SE3_LINEAR_STREAM', '1') != '0'          # False: round-3 routing (tile kernel for the long-K shapes, library GEMMs otherwise: A/B runs)
+
+
 def linear(x, weight, bias=None, relu=False):
     """x W^T [+ b] [ReLU]: the f16 hi / lo split kernel (csrc/linear_f16.hip, f32 accuracy) for the large inference GEMMs, a library GEMM
     otherwise (with relu=True the activation rides in the GEMM epilogue either way)."""
     if AG.needs_grad(x, weight, bias):                      # training: the library GEMM through torch's own autograd
         y = F.linear(x, weight, bias)
         return F.relu(y) if relu else y
+    if LINEAR_STREAM:
+        # round 4: every inference dense layer on the streaming f16-split kernel (csrc/dense_norm.hip plain mode; faster than the library
+        # and than the tile kernel on every transformer shape, tools/micro/linear_stream_shapes.py -> profiles/r04_linear_stream_shapes.txt)
+        xs = x if (x.is_contiguous() or x.dim() == 2) else x.contiguous()       # (a row range of packed (A, R, C) features: copied)
+        if _ops.linear_stream_ok(xs, weight):
+            return _ops.linear_stream(xs, weight, bias, relu)
     if _ops.linear_f16_ok(x, weight):
         return _ops.linear_f16(x, weight, bias, relu)
     if x.dim() == 3 and not x.is_contiguous() and x.stride(2) == 1 and not relu:
@@ -73,6 +83,9 @@ def project_values_transposed(x, w_v, b_v):
     zero-padded to the key stride (padded keys carry probability 0, their values never matter)."""
     M = x.shape[-2]
     Mp = _ops.key_stride(M)
+    if LINEAR_STREAM and Mp == M and not AG.needs_grad(x, w_v, b_v) and x.is_contiguous() and _ops.linear_stream_ok(x, w_v):
+        vt = _ops.linear_stream_transposed(x if x.dim() == 3 else x.unsqueeze(0), w_v, b_v)
+        return vt if x.dim() == 3 else vt[0]
     xp = F.pad(x, (0, 0, 0, Mp - M)) if Mp != M else x
     C = w_v.shape[0]
     if xp.dim() == 2:
@@ -193,7 +206,7 @@ def dense_norm(x, weight, linear_bias, norm_weight, norm_bias, groups, eps):
     return _ops.dense_norm(x, weight, linear_bias, norm_weight, norm_bias, groups, eps, segments)
 
 
-RECOMPUTE_TAIL = True         # False: the round-3 block tail (unary2 / skip_conv store their raw output, one apply pass adds them: A/B runs)
+RECOMPUTE_TAIL = os.environ.get('SE3_RECOMPUTE_TAIL', '1') != '0'         # False: the round-3 block tail (unary2 / skip_conv store their raw output, one apply pass adds them: A/B runs)
 
 
 @_hip
@@ -364,8 +377,7 @@ def rpe_self_attention_packed(x, starts, lengths, embs, eq_embs, w_stack, b_stac
     C = x.shape[-1]
     x3 = x if x.dim() == 3 else x.unsqueeze(0)
     proj = linear(x3, w_stack, b_stack)                                    # (A, R, 2C + HC [+ 4H])
-    A_, R_ = x3.shape[0], x3.shape[1]
-    vt = torch.baddbmm(b_v[None, :, None].expand(A_, C, R_), w_v[None].expand(A_, C, C), x3.transpose(1, 2))   # (A, C, R)
+    vt = project_values_transposed(x3, w_v, b_v)                           # (A, C, R): R is a multiple of 32 (packed rows)
     hidden = torch.zeros_like(x3)
     _ops.rpe_self_attention_stack(proj, offs, vt, embs, eq_embs, starts, lengths, H, hidden)
     return hidden if x.dim() == 3 else hidden[0]

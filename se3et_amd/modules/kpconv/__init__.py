@@ -16,8 +16,8 @@ def _upsampled_linear(coarse, upsample_indices, skip, weight):
     padded index gathers a zero row either way), so the product with the coarse features runs on the coarse rows (4x fewer) and neither the
     upsampled features nor the concatenation are written.  kpconv/modules.py:105-113 + e2pn backbone decoder (backbone.py)."""
     cu = coarse.shape[1]
-    up = nearest_upsample(SF.mm(coarse, weight[:, :cu].t()), upsample_indices)
-    return torch.addmm(up, skip, weight[:, cu:].t())
+    up = nearest_upsample(SF.linear(coarse, weight[:, :cu]), upsample_indices)
+    return SF.linear(skip, weight[:, cu:]).add_(up)
 
 
 class GroupNorm(nn.Module):

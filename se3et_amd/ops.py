@@ -89,18 +89,22 @@ def _linear_weight_pieces(weight, stream):
     identity: a freed tensor's address and version can be inherited by another tensor) at the same `_version` (torch bumps it on every
     in-place update: optimizer steps, load_state_dict, copy_).  Writes that bypass the version counter (`p.data.copy_()`, `p.data = ...`,
     raw pointers) are invisible to it: SE3ET.load_state_dict / .to() / ._apply() clear the caches, and validate_weight_caches() compares
-    every entry with the weight's current contents on the device."""
+    every entry with the weight's current contents on the device.  A column / row block of a Parameter (`weight[:, :k]`: the decoder's
+    split dense layer) is keyed by its own address, shape and row stride and owned by its BASE tensor (the view object is a temporary)."""
     N, K = weight.shape
-    key = (weight.data_ptr(), N, K, weight.device.index)
+    owner = weight._base if weight._base is not None else weight
+    key = (weight.data_ptr(), N, K, weight.stride(0), weight.device.index)
     hit = _linear_piece_cache.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
+    if hit is not None and hit[0]() is owner and hit[1] == owner._version:
         return hit[2].get()[0]
     Wp = torch.empty((lib().se3_linear_weight_pieces_bytes(N, K),), dtype=torch.uint8, device=weight.device)
-    check(lib().se3_linear_split_weights_f16(weight.data_ptr(), N, K, Wp.data_ptr(), stream), 'se3_linear_split_weights_f16')
+    w = weight.detach()
+    w = w if w.is_contiguous() else w.contiguous()
+    check(lib().se3_linear_split_weights_f16(w.data_ptr(), N, K, Wp.data_ptr(), stream), 'se3_linear_split_weights_f16')
     with _TIMING_LOCK:
         if len(_linear_piece_cache) > 512:
             _linear_piece_cache.clear()
-        _linear_piece_cache[key] = (weakref.ref(weight), weight._version, _Shared(Wp), _fingerprint(weight))
+        _linear_piece_cache[key] = (weakref.ref(owner), owner._version, _Shared(Wp), _fingerprint(weight), weight.stride(0))
     return Wp
 
 
@@ -146,6 +150,52 @@ def linear_f16(x, weight, bias=None, relu=False):
     b = None if bias is None else _req(bias.detach().contiguous(), torch.float32, 'bias', 1)
     check(lib().se3_linear_f16(x.data_ptr(), rows, K, K, Wp.data_ptr(), None if b is None else b.data_ptr(), N, 1 if relu else 0,
                                out.data_ptr(), N, stream), 'se3_linear_f16')
+    return out
+
+
+def linear_stream_ok(x, weight):
+    """True when linear_stream applies: inference, f32 GPU tensors, unit-stride rows aligned to 16 bytes, in_features a multiple of 32."""
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+        return False
+    if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 2 and weight.stride(1) == 1):
+        return False
+    K = weight.shape[1]
+    return x.shape[-1] == K and K % 32 == 0 and x.stride(-1) == 1 and x.data_ptr() % 16 == 0 and (x.is_contiguous() or (x.dim() == 2 and x.stride(0) % 4 == 0))
+
+
+def linear_stream(x, weight, bias=None, relu=False, out=None):
+    """y = x W^T [+ bias] [ReLU] on the streaming f16-split kernel (csrc/dense_norm.hip, plain mode): any row count; x contiguous (..., K) or
+    a 2-D view with a row stride; out: optional 2-D view (rows, N) with unit column stride to write into."""
+    stream = _stream()
+    N, K = weight.shape
+    rows = x.numel() // K
+    x_rs = x.stride(0) if (x.dim() == 2 and not x.is_contiguous()) else K
+    Wp = _linear_weight_pieces(weight, stream)
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+        out_rs = N
+    else:
+        if out.dim() != 2 or out.shape[0] != rows or out.shape[1] != N or out.stride(1) != 1 or out.dtype != torch.float32:
+            raise RuntimeError('linear_stream: out must be a (rows, N) float32 view with unit column stride')
+        out_rs = out.stride(0)
+    b = None if bias is None else _req(bias.detach().contiguous(), torch.float32, 'bias', 1)
+    check(lib().se3_linear_stream(x.data_ptr(), rows, K, x_rs, Wp.data_ptr(), None if b is None else b.data_ptr(), N, 1 if relu else 0,
+                                  out.data_ptr(), out_rs, stream), 'se3_linear_stream')
+    return out
+
+
+def linear_stream_transposed(x, weight, bias, ld=None):
+    """x (A, R, K) contiguous -> (A, N, ld) with [a, :, :R] = (x[a] W^T + bias)^T: the value projection in the attention kernels' operand
+    layout V^T, one launch for all anchors (columns R .. ld are left as allocated: callers pass ld = R padded rows)."""
+    A, R, K = x.shape
+    N = weight.shape[0]
+    ld = R if ld is None else int(ld)
+    stream = _stream()
+    Wp = _linear_weight_pieces(weight, stream)
+    out = torch.empty((A, N, ld), dtype=torch.float32, device=x.device)
+    b = None if bias is None else _req(bias.detach().contiguous(), torch.float32, 'bias', 1)
+    check(lib().se3_linear_stream_transposed(x.data_ptr(), A * R, K, K, Wp.data_ptr(), None if b is None else b.data_ptr(), N, R, out.data_ptr(), ld,
+                                             stream), 'se3_linear_stream_transposed')
     return out
 
 
@@ -828,6 +878,10 @@ def validate_weight_caches():
     for cache in (_weight_piece_cache, _linear_piece_cache, _stacked_weight_cache):
         for key, hit in list(cache.items()):
             w = hit[0]()
+            if w is not None and cache is _linear_piece_cache and w.data_ptr() != key[0]:
+                # a block of its owner (key: address, N, K, row stride): rebuild the view
+                off = (key[0] - w.data_ptr()) // w.element_size()
+                w = torch.as_strided(w, (key[1], key[2]), (key[3], 1), w.storage_offset() + off) if 0 <= off < w.numel() else None
             if w is None or w.data_ptr() != key[0]:
                 cache.pop(key, None)
                 entries.append(None)

@@ -867,7 +867,7 @@ def test_weight_caches_survive_writes_behind_the_version_counter():
     assert float((y1.double() - ref(w)).abs().max()) < 1e-5
     assert ops.validate_weight_caches() == 0
     # (a) same address, same shape, same version, another tensor object
-    key = (w.data_ptr(), 128, 256, w.device.index)
+    key = (w.data_ptr(), 128, 256, w.stride(0), w.device.index)
     assert key in ops._linear_piece_cache
     entry = ops._linear_piece_cache[key]
     other = torch.nn.Parameter(torch.empty_like(w), requires_grad=False)
@@ -878,6 +878,47 @@ def test_weight_caches_survive_writes_behind_the_version_counter():
     y2 = ops.linear_f16(x, other)
     assert float((y2.double() - ref(other)).abs().max()) < 1e-5
     ops.clear_weight_caches()
+
+
+@pytest.mark.parametrize('rows,K,N,bias,relu', [(5000, 256, 256, True, False), (352, 256, 512, True, True), (33, 512, 256, False, False),
+                                               (4224, 256, 1552, True, False), (1, 32, 7, True, True), (700, 1536, 512, True, True),
+                                               (20001, 64, 100, False, False), (130, 1024, 256, True, False), (9000, 128, 32, True, True)])
+def test_linear_stream_has_f32_accuracy(rows, K, N, bias, relu):
+    """csrc/dense_norm.hip plain mode (se3_linear_stream: the transformer's nn.Linear layers in inference) against a float64 evaluation: not
+    worse than twice the library f32 GEMM's own error; row counts from 1 to 20 000 (every tile configuration), output widths that do not fill
+    a column block, bias / ReLU epilogues; strided input rows and a strided output view."""
+    from se3et_amd import ops
+    g = torch.Generator().manual_seed(rows + K + N)
+    x = (torch.randn(rows, K, generator=g) * torch.rand(rows, 1, generator=g) * 3).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda() if bias else None
+    got = ops.linear_stream(x, w, b, relu)
+    ref = torch.nn.functional.linear(x.double(), w.double(), None if b is None else b.double())
+    lib32 = torch.nn.functional.linear(x, w, b)
+    if relu:
+        ref, lib32 = ref.clamp_min(0), lib32.clamp_min(0)
+    e_new, e_lib = float((got.double() - ref).abs().max()), float((lib32.double() - ref).abs().max())
+    assert e_new <= max(2 * e_lib, 2e-6 * float(ref.abs().max())), (e_new, e_lib)
+    # a column block of a wider tensor as input, a column block of a wider tensor as output
+    wide = torch.zeros(rows, K + 64, device='cuda')
+    wide[:, 32:32 + K] = x
+    out_wide = torch.full((rows, N + 12), 7.0, device='cuda')
+    ops.linear_stream(wide[:, 32:32 + K], w, b, relu, out=out_wide[:, 4:4 + N])
+    assert torch.equal(out_wide[:, 4:4 + N], got)
+    assert bool((out_wide[:, :4] == 7.0).all()) and bool((out_wide[:, 4 + N:] == 7.0).all())
+
+
+@pytest.mark.parametrize('A,R,K,N', [(6, 704, 256, 256), (1, 352, 256, 256), (6, 5632, 256, 256), (2, 96, 128, 128), (3, 32, 64, 40)])
+def test_linear_stream_transposed_is_the_value_projection(A, R, K, N):
+    """se3_linear_stream_transposed: (x[a] W^T + b)^T for every anchor block in one launch = project_values_transposed of the packed rows."""
+    from se3et_amd import ops
+    g = torch.Generator().manual_seed(A + R)
+    x = torch.randn(A, R, K, generator=g).cuda()
+    w, b = (torch.randn(N, K, generator=g) / K ** 0.5).cuda(), torch.randn(N, generator=g).cuda()
+    got = ops.linear_stream_transposed(x, w, b, ld=R + 8)
+    ref = (torch.einsum('ark,nk->anr', x.double(), w.double()) + b.double()[None, :, None])
+    assert tuple(got.shape) == (A, N, R + 8)
+    assert float((got[..., :R].double() - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
 
 
 def _pending_reference(x, stages, seg):
