@@ -597,6 +597,17 @@ int se3_grid_subsample_host(const float* points, const float* normals, int64_t n
 int se3_radius_neighbors_host(const float* q_points, int64_t nq, const float* s_points, int64_t ns, const int64_t* q_lengths,
                               const int64_t* s_lengths, int batch, float radius, int64_t limit, int64_t* out, int64_t* max_count);
 
+/* ---- round 4: the remaining library products of the inference forward as kernels --------------------------------------------------------
+ * se3_patch_scores   experiments/se3ete.3dmatch/model.py:186-203 -- the fine-matching score matrices of all patch pairs with the two feature
+ *                    gathers fused: out (num_patches, K, K) = <feats[ref_idx[b, n]], feats[src_idx[b, m]]> * scale; an index outside
+ *                    [0, num_rows) selects a zero row (the reference's padded feature row); K = patch_points in {64, 128}, C % 64 == 0.
+ * se3_anchor_mix_stack  conditional_transformer.py:209-249 (eq2inv_soft) for all pairs of a batch: out[a, r, :] = sum_e mix[p(r)][a, e]
+ *                    x[e, r, :] for the packed rows r of pair p (rows of no pair: zero); x, out (6, rows, channels), mix (pairs, 6, 6). */
+int se3_patch_scores(const float* feats, const int64_t* ref_idx, const int64_t* src_idx, int64_t num_patches, int patch_points,
+                     int64_t num_rows, int C, float scale, float* out, void* stream);
+int se3_anchor_mix_stack(const float* x, int64_t rows, int channels, const float* mix, const int64_t* starts_host, const int64_t* lengths_host,
+                         int num_pairs, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,8 @@ SIGNATURES = {
     'se3_dense_residual_fwd': (_i32, [_vp, _i64, _i32, _vp, _f32, _vp, _f32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _f32, _vp, _i32, _vp, _vp]),
     'se3_linear_stream': (_i32, [_vp, _i64, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _i64, _vp]),
     'se3_linear_stream_transposed': (_i32, [_vp, _i64, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _i64, _vp]),
+    'se3_patch_scores': (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i32, _f32, _vp, _vp]),
+    'se3_anchor_mix_stack': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp]),
     'se3_dense_norm_set_target_chunks': (None, [_i32]),
     'se3_linear_weight_pieces_bytes': (_sz, [_i32, _i32]),
     'se3_linear_split_weights_f16': (_i32, [_vp, _i32, _i32, _vp, _vp]),

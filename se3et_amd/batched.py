@@ -172,9 +172,12 @@ def transformer_pairs(gt, points_c, lengths_c, feats_c, packed=False):
             X = torch.cat((y0, y1), 1)
             if block == 'cross_r_soft' and nxt is not None and not _block_is_eq(nxt):
                 # eq2inv_soft: src features re-expressed in the frame the ref<-src rotation weights prefer, per pair
-                y1p = torch.zeros_like(y1)
-                for (s1, n1), mix in zip(zip(P1.starts, P1.lengths), mixes0):
-                    y1p[:, s1:s1 + n1] = SF.rotation_weighted_permute(y1[None, :, s1:s1 + n1], mix)[0]
+                if y1.shape[0] == 6 and y1.shape[2] % 4 == 0:      # all pairs in one launch (csrc/rowops.hip: anchor_mix_stack_kernel)
+                    y1p = _ops.anchor_mix_stack(y1.contiguous(), mixes0, P1.starts, P1.lengths)
+                else:
+                    y1p = torch.zeros_like(y1)
+                    for (s1, n1), mix in zip(zip(P1.starts, P1.lengths), mixes0):
+                        y1p[:, s1:s1 + n1] = SF.rotation_weighted_permute(y1[None, :, s1:s1 + n1], mix)[0]
                 X = torch.cat((tr.rotcompress(y0[None])[0], tr.rotcompress(y1p[None])[0]), 0)
                 X_eq = None
     X = SF.linear(X, gt.out_proj.weight, gt.out_proj.bias)
@@ -297,7 +300,9 @@ def forward_pairs(model, data_dict, with_registration=True):
     ref_ck, src_ck = knn[gr], knn[gs]                                         # (sum k, K) global fine-point indices
     ref_cm, src_cm = knn_masks[gr], knn_masks[gs]
     ref_cp, src_cp = SF.gather_rows_padded(points_f, ref_ck), SF.gather_rows_padded(points_f, src_ck)
-    rk, sk = SF.gather_rows_padded(feats_f, ref_ck), SF.gather_rows_padded(feats_f, src_ck)
+    fused_scores = _ops.patch_scores_ok(feats_f, K)
+    if not fused_scores:
+        rk, sk = SF.gather_rows_padded(feats_f, ref_ck), SF.gather_rows_padded(feats_f, src_ck)
     outs, patches = [], []
     po = _offsets(ks)
     for p in range(B):
@@ -316,7 +321,10 @@ def forward_pairs(model, data_dict, with_registration=True):
         patches.append((None, None, ref_cm[a:b], src_cm[a:b], ref_cp[a:b], src_cp[a:b], node_scores[p]))
     counts = ks
     # all patch pairs of all registration pairs through ONE Sinkhorn launch
-    scores = torch.einsum('bnd,bmd->bnm', rk, sk) / feats_f.shape[1] ** 0.5
+    if fused_scores:      # gathers + products + scale in one kernel (csrc/matching.hip: patch_scores_kernel)
+        scores = _ops.patch_scores(feats_f, ref_ck, src_ck, 1.0 / feats_f.shape[1] ** 0.5)
+    else:
+        scores = torch.einsum('bnd,bmd->bnm', rk, sk) / feats_f.shape[1] ** 0.5
     scores = model.optimal_transport(scores, ref_cm, src_cm)
     start, per_pair = 0, []
     for out, n, t in zip(outs, counts, patches):

@@ -640,7 +640,9 @@ int linear_stream(const float* x, int64_t rows, int K, int64_t x_rs, const void*
                   int64_t out_rs, int t_rows, int64_t t_ld, void* stream) {
   SE3_REQUIRE(x && weight_pieces && out, SE3_ERR_INVALID_ARG, "linear_stream: null pointer");
   SE3_REQUIRE(K > 0 && K % 32 == 0 && N > 0, SE3_ERR_UNSUPPORTED, "linear_stream: in_features %d must be a multiple of 32", K);
-  SE3_REQUIRE(x_rs >= K && x_rs % 4 == 0 && ((uintptr_t)x & 15) == 0 && rows * x_rs < (1ll << 29), SE3_ERR_INVALID_ARG,
+  // (x_rs < K is allowed: every row is then read past its end into the next one -- for weights whose columns beyond x_rs are zero; the
+  // last row reads zeros beyond the buffer)
+  SE3_REQUIRE(x_rs >= 4 && x_rs % 4 == 0 && ((uintptr_t)x & 15) == 0 && rows * x_rs < (1ll << 29), SE3_ERR_INVALID_ARG,
               "linear_stream: x rows must be 16-byte aligned, row stride %lld, below 2 GB", (long long)x_rs);
   const bool transposed = t_rows > 0;
   if (transposed)

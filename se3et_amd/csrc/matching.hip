@@ -204,3 +204,82 @@ extern "C" int se3_superpoint_scores(const float* ref_feats, const float* src_fe
   SE3_CHECK_LAUNCH("superpoint_scores");
   return SE3_OK;
 }
+
+
+// ---- E4 (first half): fine matching scores of all patch pairs, gathers fused -------------------------------------------------------------
+// experiments/se3ete.3dmatch/model.py:186-203: ref_node_corr_knn_feats = index_select(padded fine features, ref_node_corr_knn_indices) (a
+// padding index selects a zero row), the same for src, matching_scores = einsum('bnd,bmd->bnm') / sqrt(C).  One workgroup per patch pair:
+// the K (= 64 or 128) rows of both patches are gathered straight into LDS in 64-channel slices (no (B, K, C) copies in HBM: 0.27 GB written
+// and read back per 8-pair step before) and multiplied on the f32 matrix cores (v_mfma_f32_16x16x4_f32: exact f32 products, as the
+// library GEMM it replaces).
+namespace {
+using f32x4m = __attribute__((ext_vector_type(4))) float;
+constexpr int kPSlice = 64;                     // channels per LDS slice
+constexpr int kPRow = kPSlice + 4;              // floats per staged row (+4: the 16 rows of an MFMA operand read hit different banks)
+
+template <int KP>                               // points per patch (64: 3DMatch configurations, 128: KITTI)
+__global__ __launch_bounds__(256) void patch_scores_kernel(const float* __restrict__ feats, const int64_t* __restrict__ ref_idx,
+                                                           const int64_t* __restrict__ src_idx, int64_t n_rows, int C, float scale,
+                                                           float* __restrict__ out) {
+  __shared__ __align__(16) float sa[KP * kPRow], sb[KP * kPRow];
+  __shared__ long long rows_a[KP], rows_b[KP];
+  const int64_t b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 2 * KP; i += 256) {
+    const int64_t r = i < KP ? ref_idx[b * KP + i] : src_idx[b * KP + i - KP];
+    (i < KP ? rows_a : rows_b)[i < KP ? i : i - KP] = (r >= 0 && r < n_rows) ? r : -1;
+  }
+  __syncthreads();
+  // wave w owns output rows [w KP / 4, (w + 1) KP / 4) x all KP columns in 16 x 16 tiles
+  constexpr int RT = KP / 64, CTN = KP / 16;    // row tiles per wave, column tiles
+  f32x4m acc[RT][CTN];
+#pragma unroll
+  for (int r = 0; r < RT; r++)
+#pragma unroll
+    for (int c = 0; c < CTN; c++) acc[r][c] = f32x4m{0.f, 0.f, 0.f, 0.f};
+  const int m16 = lane & 15, kq = lane >> 4;
+  for (int c0 = 0; c0 < C; c0 += kPSlice) {
+    // stage: thread -> (row, float4 of the slice); 16 float4 per row
+    for (int i = tid; i < 2 * KP * (kPSlice / 4); i += 256) {
+      const int which = i / (KP * (kPSlice / 4)), rem = i - which * (KP * (kPSlice / 4)), row = rem / (kPSlice / 4), q = rem - row * (kPSlice / 4);
+      const long long src = (which ? rows_b : rows_a)[row];
+      const float4 v = src >= 0 ? *reinterpret_cast<const float4*>(feats + src * C + c0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>((which ? sb : sa) + row * kPRow + 4 * q) = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k4 = 0; k4 < kPSlice / 4; k4++) {
+      float av[RT], bv[CTN];
+#pragma unroll
+      for (int r = 0; r < RT; r++) av[r] = sa[(wave * (KP / 4) + r * 16 + m16) * kPRow + 4 * k4 + kq];
+#pragma unroll
+      for (int c = 0; c < CTN; c++) bv[c] = sb[(c * 16 + m16) * kPRow + 4 * k4 + kq];
+#pragma unroll
+      for (int r = 0; r < RT; r++)
+#pragma unroll
+        for (int c = 0; c < CTN; c++) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[c], acc[r][c], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // acc[r][c][j]: row wave KP / 4 + 16 r + 4 kq + j, column 16 c + m16
+  float* o = out + b * KP * KP;
+#pragma unroll
+  for (int r = 0; r < RT; r++)
+#pragma unroll
+    for (int c = 0; c < CTN; c++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) o[(wave * (KP / 4) + r * 16 + 4 * kq + j) * KP + c * 16 + m16] = acc[r][c][j] * scale;
+}
+}  // namespace
+
+extern "C" int se3_patch_scores(const float* feats, const int64_t* ref_idx, const int64_t* src_idx, int64_t num_patches, int patch_points,
+                                int64_t num_rows, int C, float scale, float* out, void* stream) {
+  SE3_REQUIRE(feats && ref_idx && src_idx && out, SE3_ERR_INVALID_ARG, "patch_scores: null pointer");
+  SE3_REQUIRE((patch_points == 64 || patch_points == 128) && C >= 64 && C % 64 == 0 && (reinterpret_cast<uintptr_t>(feats) & 15) == 0,
+              SE3_ERR_UNSUPPORTED, "patch_scores: %d points per patch (64 or 128), %d channels (a multiple of 64)", patch_points, C);
+  if (num_patches == 0) return SE3_OK;
+  if (patch_points == 64) patch_scores_kernel<64><<<(unsigned)num_patches, 256, 0, (hipStream_t)stream>>>(feats, ref_idx, src_idx, num_rows, C, scale, out);
+  else patch_scores_kernel<128><<<(unsigned)num_patches, 256, 0, (hipStream_t)stream>>>(feats, ref_idx, src_idx, num_rows, C, scale, out);
+  SE3_CHECK_LAUNCH("patch_scores");
+  return SE3_OK;
+}

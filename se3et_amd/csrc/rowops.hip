@@ -953,3 +953,59 @@ extern "C" int se3_neighbor_max_pool(const float* x, const int64_t* idx, int64_t
   SE3_CHECK_LAUNCH("neighbor_max_pool");
   return SE3_OK;
 }
+
+
+// ---- eq2inv_soft for all pairs of a batch (conditional_transformer.py:209-249): out[a, r, :] = sum_e mix[pair(r)][a, e] x[e, r, :] ----------
+// feats1_inv[a] = sum_r w0[r] feats1[trace[r, a]] with the 24 rotation weights collapsed onto the (A, A) matrix `mix` of the pair the packed
+// row r belongs to (rows outside every pair: zero).  One launch instead of an einsum + a copy per pair.
+namespace {
+struct MixPairs {
+  int n;
+  int start[16], length[16];
+};
+__global__ __launch_bounds__(256) void anchor_mix_stack_kernel(const float* __restrict__ x, int64_t R, int C4, const float* __restrict__ mix,
+                                                               MixPairs P, float* __restrict__ out) {
+  const int64_t total = R * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / C4;
+    int p = -1;
+    for (int q = 0; q < P.n; q++)
+      if (r >= P.start[q] && r < P.start[q] + P.length[q]) p = q;
+    float4 v[6];
+#pragma unroll
+    for (int e = 0; e < 6; e++) v[e] = *reinterpret_cast<const float4*>(x + (e * R * C4 + i) * 4);
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p >= 0) {
+#pragma unroll
+        for (int e = 0; e < 6; e++) {
+          const float w = mix[(p * 6 + a) * 6 + e];
+          o.x += w * v[e].x; o.y += w * v[e].y; o.z += w * v[e].z; o.w += w * v[e].w;
+        }
+      }
+      *reinterpret_cast<float4*>(out + (a * R * C4 + i) * 4) = o;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int se3_anchor_mix_stack(const float* x, int64_t rows, int channels, const float* mix, const int64_t* starts, const int64_t* lengths,
+                                    int num_pairs, float* out, void* stream) {
+  SE3_REQUIRE(x && mix && starts && lengths && out, SE3_ERR_INVALID_ARG, "anchor_mix_stack: null pointer");
+  SE3_REQUIRE(num_pairs >= 1 && num_pairs <= 16 && channels % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+              SE3_ERR_UNSUPPORTED, "anchor_mix_stack: %d pairs (1..16), %d channels (a multiple of 4)", num_pairs, channels);
+  if (rows == 0) return SE3_OK;
+  MixPairs P{};
+  P.n = num_pairs;
+  for (int p = 0; p < num_pairs; p++) {
+    P.start[p] = (int)starts[p];
+    P.length[p] = (int)lengths[p];
+  }
+  const int64_t work = rows * (channels / 4);
+  anchor_mix_stack_kernel<<<(unsigned)(se3_cdiv(work, 256) > 8192 ? 8192 : se3_cdiv(work, 256)), 256, 0, (hipStream_t)stream>>>(
+      x, rows, channels / 4, mix, P, out);
+  SE3_CHECK_LAUNCH("anchor_mix_stack");
+  return SE3_OK;
+}

@@ -864,6 +864,7 @@ def _kpconv_weight_pieces(weights, Cin, Cout, stream):
 
 
 def clear_weight_caches():
+    _padded_weight_cache.clear()
     _weight_piece_cache.clear()
     _linear_piece_cache.clear()
     _stacked_weight_cache.clear()
@@ -1012,7 +1013,37 @@ def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, s
     check(lib().se3_kpconv_so3_gather(q_pts.data_ptr(), s_pts.data_ptr(), idx.data_ptr(), x.data_ptr(), kp.data_ptr(),
                                       kt.data_ptr(), rt.data_ptr(), float(sigma), P, Ns, NN, Cin, G.data_ptr(), _stream()),
           'se3_kpconv_so3_gather')
-    return mm(G, weights.reshape(36 * Cin, Cout)).view(P, 6, Cout)
+    Kg = 36 * Cin
+    if not torch.is_grad_enabled() and Kg % 4 == 0 and Kg <= 1024:
+        # (the first layer of the backbone, Cin = 1: K = 36.)  The streaming kernel multiplies K rounded up to 32 wide: the rows of G are read
+        # past their end into the next row (finite values) against weight columns that are zero; the last row reads zeros (buffer bounds).
+        Kp = (Kg + 31) // 32 * 32
+        Wt = _padded_transposed_weight(weights, Kg, Kp, Cout)
+        out = torch.empty((P * 6, Cout), dtype=torch.float32, device=x.device)
+        stream = _stream()
+        check(lib().se3_linear_stream(G.data_ptr(), P * 6, Kp, Kg, _linear_weight_pieces(Wt, stream).data_ptr(), None, Cout, 0, out.data_ptr(), Cout,
+                                      stream), 'se3_linear_stream (KPConv slot sums)')
+        return out.view(P, 6, Cout)
+    return mm(G, weights.reshape(Kg, Cout)).view(P, 6, Cout)
+
+
+_padded_weight_cache = {}
+
+
+def _padded_transposed_weight(weights, Kg, Kp, Cout):
+    """(6, 6, Cin, Cout) KPConv weights as a dense layer's (Cout, Kp) weight: transposed, zero columns from Kg to Kp; kept per weight version."""
+    key = (weights.data_ptr(), Kg, Kp, Cout, weights.device.index)
+    hit = _padded_weight_cache.get(key)
+    if hit is not None and hit[0]() is weights and hit[1] == weights._version:
+        return hit[2].get()[0]
+    with torch.no_grad():
+        Wt = torch.zeros((Cout, Kp), dtype=torch.float32, device=weights.device)
+        Wt[:, :Kg] = weights.detach().reshape(Kg, Cout).t()
+    with _TIMING_LOCK:
+        if len(_padded_weight_cache) > 64:
+            _padded_weight_cache.clear()
+        _padded_weight_cache[key] = (weakref.ref(weights), weights._version, _Shared(Wt))
+    return Wt
 
 
 def key_stride(M):
@@ -1607,6 +1638,37 @@ def superpoint_scores_stack(feats, node_masks, ref_rows, src_rows, ref_lengths, 
                                             _i64_array(src_mask_offsets), B, C, 1 if dual_normalization else 0, stride,
                                             scores.data_ptr(), ws.data_ptr(), _stream()), 'se3_superpoint_scores_stack')
     return scores
+
+
+def patch_scores(feats, ref_idx, src_idx, scale):
+    """HIP (csrc/matching.hip): fine-matching scores (B, K, K) of all patch pairs, scale * <feats[ref_idx[b, n]], feats[src_idx[b, m]]>, the
+    two gathers fused (an index outside [0, rows) selects the reference's zero padding row)."""
+    feats = _req(feats, torch.float32, 'feats', 2)
+    ref_idx, src_idx = _req(ref_idx.contiguous(), torch.int64, 'ref_idx', 2), _req(src_idx.contiguous(), torch.int64, 'src_idx', 2)
+    B, K = ref_idx.shape
+    if tuple(src_idx.shape) != (B, K):
+        raise RuntimeError('patch_scores: index shapes %s and %s' % (tuple(ref_idx.shape), tuple(src_idx.shape)))
+    out = torch.empty((B, K, K), dtype=torch.float32, device=feats.device)
+    check(lib().se3_patch_scores(feats.data_ptr(), ref_idx.data_ptr(), src_idx.data_ptr(), B, K, feats.shape[0], feats.shape[1], float(scale),
+                                 out.data_ptr(), _stream()), 'se3_patch_scores')
+    return out
+
+
+def patch_scores_ok(feats, K):
+    return feats.is_cuda and feats.dtype == torch.float32 and feats.is_contiguous() and feats.shape[1] % 64 == 0 and K in (64, 128) and \
+        not (torch.is_grad_enabled() and feats.requires_grad)
+
+
+def anchor_mix_stack(x, mixes, starts, lengths):
+    """HIP (csrc/rowops.hip): out[a, r] = sum_e mixes[p][a, e] x[e, r] for the packed rows r of pair p (rows of no pair: zero); x (6, R, C)."""
+    x = _req(x, torch.float32, 'x', 3)
+    mixes = _req(mixes.contiguous(), torch.float32, 'mixes', 3)
+    if x.shape[0] != 6 or tuple(mixes.shape) != (len(starts), 6, 6):
+        raise RuntimeError('anchor_mix_stack: x %s, mixes %s for %d pairs' % (tuple(x.shape), tuple(mixes.shape), len(starts)))
+    out = torch.empty_like(x)
+    check(lib().se3_anchor_mix_stack(x.data_ptr(), x.shape[1], x.shape[2], mixes.data_ptr(), _i64_array(starts), _i64_array(lengths), len(starts),
+                                     out.data_ptr(), _stream()), 'se3_anchor_mix_stack')
+    return out
 
 
 def superpoint_scores(ref_feats, src_feats, dual_normalization):

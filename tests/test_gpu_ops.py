@@ -921,6 +921,36 @@ def test_linear_stream_transposed_is_the_value_projection(A, R, K, N):
     assert float((got[..., :R].double() - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize('B,K,C,rows', [(37, 64, 256, 5000), (5, 128, 256, 900), (300, 64, 128, 70)])
+def test_patch_scores_fuse_the_gathers(B, K, C, rows):
+    """csrc/matching.hip patch_scores_kernel = index_select of the zero-padded fine features + einsum('bnd,bmd->bnm') / sqrt(C)
+    (experiments/se3ete.3dmatch/model.py:186-203), exact f32 products."""
+    from se3et_amd import ops
+    g = torch.Generator().manual_seed(B + K)
+    feats = torch.randn(rows, C, generator=g).cuda()
+    ri = torch.randint(0, rows + 1, (B, K), generator=g).cuda()          # rows = the padding index
+    si = torch.randint(0, rows + 1, (B, K), generator=g).cuda()
+    padded = torch.cat((feats, torch.zeros(1, C, device='cuda')), 0).double()
+    ref = torch.einsum('bnd,bmd->bnm', padded[ri], padded[si]) / C ** 0.5
+    got = ops.patch_scores(feats, ri, si, 1.0 / C ** 0.5)
+    assert float((got.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+def test_anchor_mix_stack_matches_per_pair_einsum():
+    """csrc/rowops.hip anchor_mix_stack_kernel = eq2inv_soft's sum_e mix[a, e] feats[e] (conditional_transformer.py:209-249) for every pair."""
+    from se3et_amd import ops
+    g = torch.Generator().manual_seed(3)
+    starts, lengths = [0, 320, 704], [304, 382, 350]
+    x = torch.randn(6, 1056, 256, generator=g).cuda()
+    mixes = torch.rand(3, 6, 6, generator=g).cuda()
+    got = ops.anchor_mix_stack(x, mixes, starts, lengths)
+    want = torch.zeros_like(x)
+    for p, (s0, n) in enumerate(zip(starts, lengths)):
+        want[:, s0:s0 + n] = torch.einsum('ae,enc->anc', mixes[p], x[:, s0:s0 + n])
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    assert float(got[:, 304:320].abs().max()) == 0.0
+
+
 def _pending_reference(x, stages, seg):
     """float64: the stages v -> lrelu(v * scale + shift, slope) applied per segment."""
     x = x.double().clone()
