@@ -436,24 +436,26 @@ def collect_roofline(se3_lib, timings, args):
     C-ABI call for all clouds of the batch.  Each launch carries its own start / stop HIP event pair on the launch stream
     (hipExtLaunchKernelGGL: the dispatch's begin / end timestamps); the call's time is the sum of the two."""
     import ctypes
-    calls = timings.get('rpe_self_attention_calls', [])
-    cap = 4 * len(calls) + 64 * args.steps
+    cap = 4096 + 256 * (args.steps + args.warmup)
     us = (ctypes.c_float * cap)()
     tags = (ctypes.c_int * cap)()
+    aux = (ctypes.c_double * cap)()
     se3_lib.lib().se3_debug_kernel_timing(0)
-    n_ev = se3_lib.lib().se3_debug_kernel_timing_collect(us, tags, cap)
-    per_call, i = [], 0
+    n_ev = se3_lib.lib().se3_debug_kernel_timing_collect_ex(us, tags, aux, cap)
+    # The library records, per logits launch of a stack-mode self-attention call, the call's algorithmic bytes (SURVEY 8d; negative: equivariant
+    # call) -- the launches may be issued from C (se3_transformer_forward), so the host keeps no list of its own.
+    calls, per_call, i = [], [], 0
+    bf16 = args.attention_dtype != 'float32'
     while i < n_ev:                                   # tag 1 (logits kernel) is always followed by its attention launch: tag 2, with the
         j, pre = i + 1, 0.0                           # K / V^T split in front of it (tag 3) when the f16 form runs -- counted with it
         if tags[i] == 1 and j < n_ev and tags[j] == 3:
             pre, j = us[j], j + 1
-        if tags[i] == 1 and j < n_ev and tags[j] == 2:
+        if tags[i] == 1 and aux[i] != 0.0 and j < n_ev and tags[j] == 2:
             per_call.append((us[i], pre + us[j]))
+            calls.append((abs(aux[i]), ('eq' if aux[i] < 0 else 'inv') + ('_bf16' if bf16 else '')))
             i = j + 1
         else:
             i += 1                                    # attention launches of the cross-attention layers
-    if len(per_call) != len(calls):
-        raise SystemExit('bench.py: %d timed RPE calls for %d recorded calls' % (len(per_call), len(calls)))
     kinds = {'eq': [0, 0.0, 0.0, 0.0], 'inv': [0, 0.0, 0.0, 0.0]}      # count, bytes, bias us, attention us
     for (nbytes, kind), (t_bias, t_attn) in zip(calls, per_call):
         k = kinds[kind.replace('_bf16', '')]

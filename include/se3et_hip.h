@@ -56,6 +56,9 @@ void se3_debug_set_attention_profile(long long* stamps);
  * durations (us) and tags (1 = relative-position logits kernel, 2 = attention kernel) in launch order. */
 void se3_debug_kernel_timing(int enable);
 int se3_debug_kernel_timing_collect(float* microseconds, int* tags, int capacity);
+/* The same, plus per record the algorithmic bytes of the call (negative = equivariant call) for the logits launches (tag 1) of
+ * se3_rpe_self_attention_stack*_fwd and 0 for every other launch. */
+int se3_debug_kernel_timing_collect_ex(float* microseconds, int* tags, double* aux, int capacity);
 
 /* ---- A2: stack-mode radius neighbour search ---------------------------------------------------------------
  * Replaces geotransformer.ext.radius_neighbors (geotransformer/extensions/pybind.cpp:6-11,
@@ -607,6 +610,58 @@ int se3_patch_scores(const float* feats, const int64_t* ref_idx, const int64_t* 
                      int64_t num_rows, int C, float scale, float* out, void* stream);
 int se3_anchor_mix_stack(const float* x, int64_t rows, int channels, const float* mix, const int64_t* starts_host, const int64_t* lengths_host,
                          int num_pairs, float* out, void* stream);
+
+/* ---- D7 / D8: the coarse transformer of a batch of pairs, every launch issued from C ---------------------------------------------------------
+ * RPEConditionalTransformer.forward (conditional_transformer.py:251-390) with the layers it schedules (rpe_transformer.py:134-194,
+ * vanilla_transformer.py:872-946, output_layer.py:7-47) and GeometricTransformer's out_proj (geotransformer.py:310-317) as ONE host call:
+ * about 130 launches on the caller's stream, no interpreter between them (one pair per forward was bound by ~480 Python-issued launches).
+ * The plan is a HOST structure of device pointers: weights as se3_linear_split_weights_f16 pieces (+ f32 biases), the per-cloud geometric
+ * embeddings, the packed-row layout (refs of all pairs first, then srcs; cloud starts multiples of 32).  x_in (A, rows, C) = in_proj of the
+ * superpoint features in that layout, out (rows, out_proj.out_features).  Block types: 0 'self', 1 'self_eq', 2 'cross', 3 'cross_a_soft',
+ * 4 'cross_r_soft' (followed by eq2inv_soft + RotCompressOutput when the next block is invariant).  Supported: the SE3ET-E / -E2 and
+ * SE3ET-I / -I2 / KITTI block lists, A = 6, head dimension 64 for the key-anchor groups of the equivariant cross attention. */
+#define SE3_MAX_BLOCKS 16
+typedef struct {
+  const void* pieces;       /* se3_linear_split_weights_f16 of the (out_features, in_features) weight */
+  const float* bias;        /* (out_features) or NULL */
+  int in_features, out_features;
+} se3_linear_t;
+typedef struct {
+  int type;
+  int off_q, off_k, off_qp, off_qe;        /* self blocks: column offsets of [q | k | W_p^T q | W_eq^T q] in the stacked projection (off_qe < 0: none) */
+  se3_linear_t stack;                      /* self blocks: the composed projection */
+  se3_linear_t q, k, v;                    /* cross blocks: proj_q, proj_k; all blocks: proj_v */
+  se3_linear_t out;                        /* attention.linear (its bias is applied by the LayerNorm kernel) */
+  const void* out_pieces_g2;               /* equivariant cross blocks: the same weight repeated 2 / 3 times along in_features (key-anchor groups) */
+  const void* out_pieces_g3;
+  const float* ln1_w;
+  const float* ln1_b;
+  float ln1_eps;
+  se3_linear_t expand, squeeze;            /* AttentionOutput (the squeeze bias is applied by the LayerNorm kernel) */
+  const float* ln2_w;
+  const float* ln2_b;
+  float ln2_eps;
+  const int64_t* trace_idx;                /* equivariant cross blocks: (num_rotations, 6) int64 on the device */
+  int num_rotations;
+} se3_layer_t;
+typedef struct {
+  int A, C, H, num_blocks, num_pairs, emb_bf16;
+  se3_layer_t layers[SE3_MAX_BLOCKS];
+  se3_linear_t rc_expand, rc_squeeze;      /* RotCompressOutput (only read behind a cross_r_soft block) */
+  const float* rc_ln_w;
+  const float* rc_ln_b;
+  float rc_ln_eps;
+  se3_linear_t out_proj;
+  int64_t starts[SE3_MAX_BATCH], lengths[SE3_MAX_BATCH];   /* packed row start / length of every cloud: ref0 .. ref(B-1), src0 .. src(B-1) */
+  int64_t rows0, rows;                     /* packed rows of all refs; of all clouds */
+  const float* emb[SE3_MAX_BATCH];         /* (N_c, N_c, C) geometric embedding of cloud c (bfloat16 when emb_bf16) */
+  const float* eq[SE3_MAX_BATCH];          /* (A, N_c, N_c, 4) equivariant embedding or NULL */
+} se3_transformer_plan_t;
+size_t se3_transformer_workspace_bytes(const se3_transformer_plan_t* plan);
+int se3_transformer_forward(const se3_transformer_plan_t* plan, const float* x_in, float* out, void* workspace, size_t workspace_bytes,
+                            void* stream);
+int se3_linear_stream_segments(const float* x, int64_t rows, int in_features, int seg_channels, int64_t seg_stride, const void* weight_pieces,
+                               const float* bias, int out_features, int apply_relu, float* out, int64_t out_row_stride, void* stream);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,7 @@ SIGNATURES = {
     'se3_debug_set_attention_profile': (None, [_vp]),
     'se3_debug_kernel_timing': (None, [_i32]),
     'se3_debug_kernel_timing_collect': (_i32, [_vp, _vp, _i32]),
+    'se3_debug_kernel_timing_collect_ex': (_i32, [_vp, _vp, _vp, _i32]),
     'se3_radius_neighbors': (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _f32, _i32, _vp, _vp, _vp]),
     'se3_radius_grid_workspace_bytes': (_sz, [_i64, _i32]),
     'se3_radius_grid_build': (_i32, [_vp, _i64, _vp, _i32, _f32, _vp, _sz, _vp]),
@@ -43,6 +44,9 @@ SIGNATURES = {
     'se3_linear_stream_transposed': (_i32, [_vp, _i64, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _i64, _vp]),
     'se3_patch_scores': (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i32, _f32, _vp, _vp]),
     'se3_anchor_mix_stack': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp]),
+    'se3_linear_stream_segments': (_i32, [_vp, _i64, _i32, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _i64, _vp]),
+    'se3_transformer_workspace_bytes': (_sz, [_vp]),
+    'se3_transformer_forward': (_i32, [_vp, _vp, _vp, _vp, _sz, _vp]),
     'se3_dense_norm_set_target_chunks': (None, [_i32]),
     'se3_linear_weight_pieces_bytes': (_sz, [_i32, _i32]),
     'se3_linear_split_weights_f16': (_i32, [_vp, _i32, _i32, _vp, _vp]),

@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from . import functional as SF
+from . import cdriver as _cdriver
 from . import ops as _ops
 from .modules.transformer import _block_is_eq
 
@@ -141,6 +142,14 @@ def transformer_pairs(gt, points_c, lengths_c, feats_c, packed=False):
     X = PA.pack_rows(x, order, offs)                                                                 # (A, R, C)
     embs_o, eqs_o = [embs[c] for c in order], [eqs[c] for c in order]
 
+    if _cdriver.supported(gt) and not torch.is_grad_enabled():
+        # every launch of the ten blocks and of out_proj from ONE library call (csrc/transformer_driver.hip): the same kernels with the same
+        # operands as the schedule below, no interpreter between them
+        X = _cdriver.transformer_forward(gt, X.contiguous(), PA, R0, embs_o, eqs_o)
+        if packed:
+            return X, PA
+        outs = PA.unpack(X)
+        return outs[:B], outs[B:]
     tr = gt.transformer
     blocks, layers = tr.blocks, tr.layers
     X_eq = None                      # anchor features (A, R, C) kept next to their anchor-max X (R, C) inside 'cross' runs

@@ -1421,7 +1421,9 @@ int dispatch_head_dim(int D, F&& f, const char* what) {
 struct TimedLaunch {
   hipEvent_t start, stop;
   int tag;              // 1 = rpe_bias_kernel, 2 = attention_kernel
+  double aux;           // tag 1 inside se3_rpe_self_attention_stack*_fwd: the call's algorithmic bytes, negative for an equivariant call
 };
+static thread_local double g_next_aux = 0.0;      // set by the stack-mode self-attention entry for its logits launch
 static bool g_time_kernels = false;
 static std::vector<TimedLaunch> g_timed;
 static std::recursive_mutex g_timed_mutex;      // several host threads may launch (one HIP stream each)
@@ -1429,7 +1431,8 @@ static std::recursive_mutex g_timed_mutex;      // several host threads may laun
 template <typename K, typename... Args>
 static void launch_kernel(int tag, K kernel, dim3 grid, dim3 block, hipStream_t st, Args... args) {
   if (g_time_kernels) {
-    TimedLaunch t{nullptr, nullptr, tag};
+    TimedLaunch t{nullptr, nullptr, tag, tag == 1 ? g_next_aux : 0.0};
+    if (tag == 1) g_next_aux = 0.0;
     if (hipEventCreate(&t.start) == hipSuccess && hipEventCreate(&t.stop) == hipSuccess) {
       std::lock_guard<std::recursive_mutex> lock(g_timed_mutex);
       hipExtLaunchKernelGGL(kernel, grid, block, 0, st, t.start, t.stop, 0, args...);
@@ -1452,6 +1455,26 @@ extern "C" int se3_debug_kernel_timing_collect(float* microseconds, int* tags, i
     if (hipEventSynchronize(t.stop) == hipSuccess && hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess && n < capacity) {
       microseconds[n] = ms * 1e3f;
       tags[n] = t.tag;
+      n++;
+    }
+    (void)hipEventDestroy(t.start);
+    (void)hipEventDestroy(t.stop);
+  }
+  g_timed.clear();
+  return n;
+}
+
+// The same with the algorithmic bytes recorded for the logits launches of the stack-mode self-attention calls (0 elsewhere): the caller
+// needs no record of its own of which call was which (the launches may come from se3_transformer_forward).
+extern "C" int se3_debug_kernel_timing_collect_ex(float* microseconds, int* tags, double* aux, int capacity) {
+  std::lock_guard<std::recursive_mutex> lock(g_timed_mutex);
+  int n = 0;
+  for (const TimedLaunch& t : g_timed) {
+    float ms = 0.f;
+    if (hipEventSynchronize(t.stop) == hipSuccess && hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess && n < capacity) {
+      microseconds[n] = ms * 1e3f;
+      tags[n] = t.tag;
+      aux[n] = t.aux;
       n++;
     }
     (void)hipEventDestroy(t.start);
@@ -1967,7 +1990,16 @@ static int rpe_self_attention_stack(const float* q, const float* k, const float*
   }
   // the two timed launches of one call stay adjacent in the record even when several host threads launch
   std::unique_lock<std::recursive_mutex> lock(g_timed_mutex, std::defer_lock);
-  if (g_time_kernels) lock.lock();
+  if (g_time_kernels) {
+    lock.lock();
+    // algorithmic bytes of the call: q, k, v in + out, the embedding, the equivariant embedding
+    double bytes = 0.0;
+    for (int c = 0; c < num_clouds; c++) {
+      const double n = (double)lengths[c];
+      bytes += 4.0 * (4.0 * num_anchors * n * C + (qe ? num_anchors * n * n * 4.0 : 0.0)) + (emb_bf16 ? 2.0 : 4.0) * n * n * C;
+    }
+    g_next_aux = qe ? -bytes : bytes;
+  }
   int rc = rpe_bias_stack(qp, qe, row_stride, anchor_stride, emb_ptrs, eq_ptrs, starts, lengths, lengths, offsets, num_clouds, C,
                           num_anchors * H, H, logits_workspace, stream, emb_bf16);
   if (rc != SE3_OK) return rc;

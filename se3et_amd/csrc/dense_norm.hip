@@ -65,6 +65,11 @@ struct DenseArgs {
   int x_rs, out_rs;
   int t_rows;                // MODE 5: rows per output block (anchor): out is (rows / t_rows, N, t_ld) -- the product transposed per block
   int t_ld;
+  // K-segmented input (plain modes): every `seg_steps` K-steps of 32 channels come from the next of several (rows, x_rs) arrays `seg_stride`
+  // floats apart -- the anchor-concatenated rows of RotCompressOutput (output_layer.py:38-47: 'b a n c -> b n (a c)') read in place from
+  // (A, rows, C); seg_steps = 0: one array
+  int seg_steps;
+  long long seg_stride;
 };
 
 
@@ -129,8 +134,17 @@ __global__ __launch_bounds__(256, MODE == 3 ? 2 : 3) void dense_norm_kernel(cons
     const bool two = kDual && p.kk >= nk1;                               // uniform
     const int Ks = two ? K2 : XS, kloc = two ? p.kk - nk1 : p.kk;
     const float* base = two ? a.x2 + rbase * K2 : a.x + rbase * XS;
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, nrows * Ks * 4, 0x00020000);
-    const int soff = (p.tile * TR * Ks + kloc * 32) * 4, xoff = two ? xoff2 : xoff1, jstep = 32 * Ks * 4;
+    const long long xbytes = (kPlain && a.seg_steps > 0) ? ((long long)(K / (32 * a.seg_steps) - 1) * a.seg_stride + (long long)nrows * Ks) * 4
+                                                         : (long long)nrows * Ks * 4;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)xbytes, 0x00020000);
+    int soff = (p.tile * TR * Ks + kloc * 32) * 4;
+    const int xoff = two ? xoff2 : xoff1, jstep = 32 * Ks * 4;
+    if constexpr (kPlain) {
+      if (a.seg_steps > 0) {                                             // segment s = kloc / seg_steps: channels (kloc % seg_steps) * 32 of array s
+        const int sg = kloc / a.seg_steps;
+        soff = (int)(((long long)p.tile * TR * Ks + (kloc - sg * a.seg_steps) * 32 + sg * a.seg_stride) * 4);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < U; j++) v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff + j * jstep, soff, 0));
   };
@@ -637,7 +651,7 @@ void plain_launch(const DenseArgs& a, bool transposed, dim3 grid, hipStream_t st
   else dense_norm_kernel<WM, WN, RT, CT, 4><<<grid, 256, 0, st>>>(a);
 }
 int linear_stream(const float* x, int64_t rows, int K, int64_t x_rs, const void* weight_pieces, const float* bias, int N, int relu, float* out,
-                  int64_t out_rs, int t_rows, int64_t t_ld, void* stream) {
+                  int64_t out_rs, int t_rows, int64_t t_ld, void* stream, int seg_channels = 0, int64_t seg_stride = 0) {
   SE3_REQUIRE(x && weight_pieces && out, SE3_ERR_INVALID_ARG, "linear_stream: null pointer");
   SE3_REQUIRE(K > 0 && K % 32 == 0 && N > 0, SE3_ERR_UNSUPPORTED, "linear_stream: in_features %d must be a multiple of 32", K);
   // (x_rs < K is allowed: every row is then read past its end into the next one -- for weights whose columns beyond x_rs are zero; the
@@ -683,6 +697,12 @@ int linear_stream(const float* x, int64_t rows, int K, int64_t x_rs, const void*
   a.out_rs = (int)out_rs;
   a.t_rows = t_rows;
   a.t_ld = (int)t_ld;
+  if (seg_channels > 0) {
+    SE3_REQUIRE(seg_channels % 32 == 0 && K % seg_channels == 0 && seg_stride >= rows * x_rs && (K / seg_channels) * seg_stride < (1ll << 29),
+                SE3_ERR_INVALID_ARG, "linear_stream: %d input channels in segments of %d", K, seg_channels);
+    a.seg_steps = seg_channels / 32;
+    a.seg_stride = seg_stride;
+  }
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)chunks, (unsigned)ncb);
   switch (cfg) {
@@ -710,4 +730,15 @@ extern "C" int se3_linear_stream_transposed(const float* x, int64_t rows, int in
                                             const float* bias, int out_features, int block_rows, float* out_t, int64_t ld, void* stream) {
   SE3_REQUIRE(block_rows > 0, SE3_ERR_INVALID_ARG, "linear_stream_transposed: block_rows %d", block_rows);
   return linear_stream(x, rows, in_features, x_row_stride, weight_pieces, bias, out_features, 0, out_t, 0, block_rows, ld, stream);
+}
+
+
+// x given as in_features / seg_channels arrays (rows, seg_channels) that lie seg_stride floats apart: row n of the product's input is the
+// concatenation of row n of every array -- RotCompressOutput's 'b a n c -> b n (a c)' (output_layer.py:38-47) without the rearranged copy.
+extern "C" int se3_linear_stream_segments(const float* x, int64_t rows, int in_features, int seg_channels, int64_t seg_stride,
+                                          const void* weight_pieces, const float* bias, int out_features, int apply_relu, float* out,
+                                          int64_t out_row_stride, void* stream) {
+  SE3_REQUIRE(seg_channels > 0, SE3_ERR_INVALID_ARG, "linear_stream_segments: seg_channels %d", seg_channels);
+  return linear_stream(x, rows, in_features, seg_channels, weight_pieces, bias, out_features, apply_relu, out, out_row_stride, 0, 0, stream,
+                       seg_channels, seg_stride);
 }

@@ -197,3 +197,49 @@ def test_multi_pair_forward_equals_single_pair_forward(variant, preset, num_pair
             assert float((got['matching_scores'][valid] - want['matching_scores'][valid]).abs().max()) <= 1e-4 * float(want['matching_scores'][valid].abs().max())
             if got['ref_corr_points'].shape == want['ref_corr_points'].shape:
                 assert_close(got['estimated_transform'].cpu(), want['estimated_transform'].cpu(), 2e-3, 'pair %d transform' % p)
+
+
+@pytest.mark.parametrize('variant,preset,num_pairs', [('micro_e', 'micro', 2), ('micro_i', 'micro', 1), ('se3ete', 'c2_5k', 1), ('se3ete', 'c2_5k', 3),
+                                                      ('se3eti', 'c2_5k', 2), ('se3eti_kitti', 'c3_20k', 2)])
+def test_transformer_issued_from_c_equals_the_python_schedule(variant, preset, num_pairs):
+    """csrc/transformer_driver.hip (se3_transformer_forward: the ten blocks and out_proj as ONE host call, ~130 launches issued from C) against
+    se3et_amd.batched.transformer_pairs' Python schedule: the same kernels with the same operands in the same order, so the forward's outputs
+    must be IDENTICAL -- SE3ET-E (self_eq / cross_a_soft / cross_r_soft + eq2inv + rotcompress / self / cross), SE3ET-I (anchor values
+    through the plain cross blocks), the KITTI configuration, the micro models (head dimension 8: f32 attention kernels)."""
+    from se3et_amd import cdriver
+    from se3et_amd.batched import forward_pairs
+    from se3et_amd.data import precompute_data_stack_mode
+    from se3et_amd.model import create_model, load_synthetic_weights, make_cfg
+    from se3et_amd.synthetic import make_pair
+    cfg = make_cfg(variant)
+    model = load_synthetic_weights(create_model(cfg)).cuda().eval()
+    if variant == 'micro_e':              # 32 channels: the equivariant cross attention's Gram statistics kernel takes 128 / 256 -> Python schedule
+        assert not cdriver.supported(model.transformer)
+        return
+    assert cdriver.supported(model.transformer)
+    b = cfg.backbone
+    clouds = []
+    for p in range(num_pairs):
+        ref, src, _ = make_pair(preset, index=p)
+        clouds += [ref, src]
+    pts = torch.from_numpy(np.concatenate(clouds, 0)).cuda()
+
+    def run():
+        dd = precompute_data_stack_mode(pts, torch.tensor([len(c) for c in clouds]), b.num_stages, b.init_voxel_size, b.init_radius,
+                                        cfg.neighbor_limits)
+        dd['features'] = torch.ones((pts.shape[0], 1), device='cuda')
+        return forward_pairs(model, dd)
+
+    saved = cdriver.ENABLED
+    try:
+        cdriver.ENABLED = True
+        got = run()
+        got2 = run()                      # (cached plan, reused workspace)
+        cdriver.ENABLED = False
+        want = run()
+    finally:
+        cdriver.ENABLED = saved
+    for p in range(num_pairs):
+        for key in ('ref_feats_c', 'src_feats_c', 'ref_node_corr_indices', 'src_node_corr_indices', 'matching_scores', 'estimated_transform'):
+            assert torch.equal(got[p][key], want[p][key]), (p, key, float((got[p][key].double() - want[p][key].double()).abs().max()))
+            assert torch.equal(got2[p][key], want[p][key]), (p, key)
