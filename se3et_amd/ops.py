@@ -1579,7 +1579,23 @@ def geometric_embedding_bwd(grad_emb, points, div_term, w_d, b_d, w_a, b_a, sigm
                                                g.data_ptr(), S.data_ptr(), dEk.data_ptr(), _stream()), 'se3_geo_embedding_bwd_operands')
     g2 = g.reshape(N * N, C)
     db = g2.sum(0)
-    return mm(g2.t(), S[0]), db, mm(dEk.t(), S[1:].reshape(3 * N * N, C)), db.clone()
+    return mm_tn_splitk(g2, S[0]), db, mm_tn_splitk(dEk, S[1:].reshape(3 * N * N, C)), db.clone()
+
+
+def mm_tn_splitk(a, b, splits=64):
+    """a (K, M)^T @ b (K, N) for K >> M, N (the weight gradients of the geometric embedding: K = N^2 .. 3 N^2 = 1.5e5 .. 4.4e5 rows onto a
+    256 x 256 result).  As ONE product the library runs 32 workgroups for 0.6 ms per call (2.4 ms of a 42 ms training step,
+    profiles/r04_kernel_stats_train.csv); cut into `splits` row blocks it is a batched product that fills the chip, the partial results summed
+    in a fixed order."""
+    K, M = a.shape
+    k = K // splits
+    if k < 512:
+        return mm(a.t(), b)
+    head = splits * k
+    out = torch.bmm(a[:head].view(splits, k, M).transpose(1, 2), b[:head].view(splits, k, b.shape[1])).sum(0)
+    if head < K:
+        out += mm(a[head:].t(), b[head:])
+    return out
 
 
 def point_to_node_partition(points, nodes, point_limit):
