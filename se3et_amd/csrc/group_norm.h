@@ -135,6 +135,15 @@ __device__ __forceinline__ void gn_store_partial(float* p, const WF& w) {       
   __hip_atomic_store(p + 1, w.mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(p + 2, w.m2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Memory model note: the hand-off below is the sc1 / sc1 form of /opt/skills/guides/MI355X_MICROARCH.md, "Valid forms
+// besides Guideline 16's R1/R2" -- every store of the handed-off partials is an agent-scope (sc1, write-through) store, every storing wave
+// drains them with `s_waitcnt vmcnt(0)`, the ONE signalling lane adds to the counter behind the workgroup barrier that follows those waits,
+// and every load of the partials is an agent-scope (sc1) load issued only by the workgroup whose add returned the last ticket, behind a
+// workgroup barrier -- the row "ONE lane of each storing workgroup ... an agent-scope atomic add / the workgroup whose add came last" of that
+// guide's table (measured valid on gfx950 / ROCm 7.2; not an architectural guarantee: tools/micro/buffer_sc1_soffset.hip pins the sc1
+// lowering this relies on).  A release / acquire fence pair would be the portable form and costs a write-back + invalidate of the XCD's L2
+// per workgroup (1.7 -> 3.3 ms over the unary shapes).  The counters must be zero before a launch: the host clears the
+// workspace when a call returns an error (se3et_amd/ops.py::_check_counters).
 // true in every thread of the workgroup that arrives last of `expected`; resets the counter for the next launch.  No agent-scope fence:
 // on this chip that is a write-back and an invalidate of the whole L2 of the XCD (every workgroup of a streaming kernel doing one halves
 // the kernel's rate); the partials are agent-scope atomic stores and loads (they go through to the memory side on their own), so all that

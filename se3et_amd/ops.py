@@ -594,6 +594,14 @@ def _dense_workspace(device, stream, nbytes):
     return _zeroed_workspace(_dense_ws, device, stream, nbytes)
 
 
+def _check_counters(status, what, ws):
+    """check() for the calls whose workspace begins with arrival counters: a failed or rejected call may leave them non-zero (every later call on
+    the stream would then finalize at the wrong arrival), so the workspace is cleared before the error is raised."""
+    if status != 0 and ws is not None:
+        ws.zero_()
+    check(status, what)
+
+
 class Pending:
     """An activation in its pending form: `raw` (rows.., C) float32 plus up to two stages v -> lrelu(v * scale + shift, slope) that its
     consumer applies while loading it (the GroupNorm [+ LeakyReLU] of the producer, reduced to per-(segment, channel) affine tables by
@@ -654,11 +662,11 @@ def dense_norm(x, weight, linear_bias, norm_weight, norm_bias, groups, eps, segm
     ws = _dense_workspace(raw.device, stream, lib().se3_dense_norm_workspace_bytes(int(groups)))
     aa = pend.affines + [None, None]
     sl = pend.slopes + [1.0, 1.0]
-    check(lib().se3_dense_norm_fwd(raw.data_ptr(), rows, K, aa[0].data_ptr() if aa[0] is not None else None, float(sl[0]),
+    _check_counters(lib().se3_dense_norm_fwd(raw.data_ptr(), rows, K, aa[0].data_ptr() if aa[0] is not None else None, float(sl[0]),
                                    aa[1].data_ptr() if aa[1] is not None else None, float(sl[1]), Wp.data_ptr(), N,
                                    linear_bias.data_ptr() if linear_bias is not None else None, norm_weight.data_ptr(), norm_bias.data_ptr(),
                                    int(groups), float(eps), _i64_array(segments) if nseg > 1 else None, nseg, out.data_ptr(),
-                                   affine.data_ptr(), ws.data_ptr(), ws.numel(), stream), 'se3_dense_norm_fwd')
+                                   affine.data_ptr(), ws.data_ptr(), ws.numel(), stream), 'se3_dense_norm_fwd', ws)
     return Pending(out, [affine], [1.0], segments)
 
 
@@ -679,11 +687,11 @@ def dense_stats(x, weight, linear_bias, norm_weight, norm_bias, groups, eps, seg
     ws = _dense_workspace(raw.device, stream, lib().se3_dense_norm_workspace_bytes(int(groups)))
     aa = pend.affines + [None, None]
     sl = pend.slopes + [1.0, 1.0]
-    check(lib().se3_dense_norm_fwd(raw.data_ptr(), rows, K, aa[0].data_ptr() if aa[0] is not None else None, float(sl[0]),
+    _check_counters(lib().se3_dense_norm_fwd(raw.data_ptr(), rows, K, aa[0].data_ptr() if aa[0] is not None else None, float(sl[0]),
                                    aa[1].data_ptr() if aa[1] is not None else None, float(sl[1]), Wp.data_ptr(), N,
                                    linear_bias.data_ptr() if linear_bias is not None else None, norm_weight.data_ptr(), norm_bias.data_ptr(),
                                    int(groups), float(eps), _i64_array(segments) if nseg > 1 else None, nseg, None,
-                                   affine.data_ptr(), ws.data_ptr(), ws.numel(), stream), 'se3_dense_norm_fwd (statistics only)')
+                                   affine.data_ptr(), ws.data_ptr(), ws.numel(), stream), 'se3_dense_norm_fwd (statistics only)', ws)
     return affine
 
 
@@ -757,10 +765,10 @@ def group_norm_stats(x, weight, bias, groups, eps, x_bias=None, segments=None):
     affine = torch.empty((nseg, 2, C), dtype=torch.float32, device=raw.device)
     ws = _dense_workspace(raw.device, stream, lib().se3_group_norm_stats_workspace_bytes(C))
     pa = pend.affines[0] if pend.affines else None
-    check(lib().se3_group_norm_stats(raw.data_ptr(), pa.data_ptr() if pa is not None else None, float(pend.slopes[0]) if pa is not None else 1.0,
+    _check_counters(lib().se3_group_norm_stats(raw.data_ptr(), pa.data_ptr() if pa is not None else None, float(pend.slopes[0]) if pa is not None else 1.0,
                                      x_bias.data_ptr() if x_bias is not None else None, weight.data_ptr(), bias.data_ptr(), rows, C,
                                      int(groups), _i64_array(segments) if nseg > 1 else None, nseg, float(eps), affine.data_ptr(),
-                                     ws.data_ptr(), ws.numel(), stream), 'se3_group_norm_stats')
+                                     ws.data_ptr(), ws.numel(), stream), 'se3_group_norm_stats', ws)
     return affine
 
 
@@ -1004,10 +1012,10 @@ def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, s
         sws = _zeroed_workspace(_kpconv_split_ws, x.device, stream, sbytes) if sbytes else None
         # (bench.py: event pair around the launch; algorithmic flops = contraction 2.6P.36Cin.Cout + the gather as a product 2.P.NN.16.6Cin)
         with _timed('kpconv_fused', 2.0 * 6 * P * 36 * Cin * Cout + 2.0 * P * NN * 16 * 6 * Cin):
-            check(lib().se3_kpconv_so3_fused(x.data_ptr(), tab.data_ptr(), P, Ns, NN, Cin, Cout, Wp.data_ptr(), out.data_ptr(),
-                                             sws.data_ptr() if sws is not None else None, sws.numel() if sws is not None else 0,
-                                             1 if blocked else 0, stream),
-                  'se3_kpconv_so3_fused')
+            _check_counters(lib().se3_kpconv_so3_fused(x.data_ptr(), tab.data_ptr(), P, Ns, NN, Cin, Cout, Wp.data_ptr(), out.data_ptr(),
+                                                       sws.data_ptr() if sws is not None else None, sws.numel() if sws is not None else 0,
+                                                       1 if blocked else 0, stream),
+                            'se3_kpconv_so3_fused', sws)
         return out
     G = torch.empty((P * 6, 36 * Cin), dtype=torch.float32, device=x.device)
     check(lib().se3_kpconv_so3_gather(q_pts.data_ptr(), s_pts.data_ptr(), idx.data_ptr(), x.data_ptr(), kp.data_ptr(),

@@ -2,6 +2,9 @@
 # Everything under profiles/rNN_* in one GPU call: tools/collect_profiles.sh r03   (writes gpurun_out/profiles_r03/; copy what is to be kept)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; tag=${1:-rXX}; O=$R/gpurun_out/profiles_$tag; mkdir -p $O; cd $R
 timeout 900 python bench.py > $O/${tag}_bench.json 2> $O/bench.err
+# the driver's exact command (BENCH_rNN.json), twice
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${tag}_bench_20_5.json 2>> $O/bench.err
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/${tag}_bench_20_5_b.json 2>> $O/bench.err
 timeout 900 python bench.py --batch 1 --no-cpu-baseline --single-pair-steps 0 --train-steps 0 > $O/${tag}_bench_batch1.json 2>> $O/bench.err
 timeout 900 python bench.py --inflight 1 --no-cpu-baseline --single-pair-steps 0 --train-steps 0 > $O/${tag}_bench_inflight1.json 2>> $O/bench.err
 timeout 900 python bench.py --inflight 1 --prefetch 0 --no-cpu-baseline --single-pair-steps 0 --train-steps 0 > $O/${tag}_bench_noprefetch.json 2>> $O/bench.err
@@ -12,6 +15,16 @@ tools/prof.sh ${tag} bench.py --no-cpu-baseline --single-pair-steps 0 --train-st
 tools/prof.sh ${tag}seq bench.py --inflight 1 --prefetch 0 --no-cpu-baseline --single-pair-steps 0 --train-steps 0 --roofline-quiet-steps 0 >> $O/prof.txt 2>&1; cp gpurun_out/${tag}seq_kernel_stats.csv $O/${tag}_kernel_stats_sequential.csv
 tools/prof.sh ${tag}b1 bench.py --batch 1 --no-cpu-baseline --single-pair-steps 0 --train-steps 0 >> $O/prof.txt 2>&1; cp gpurun_out/${tag}b1_kernel_stats.csv $O/${tag}_kernel_stats_batch1.csv
 python tools/step_breakdown.py $O/${tag}_kernel_stats_sequential.csv 69 > $O/${tag}_step_breakdown.txt 2>&1      # 60 steps + 9 warm-up
+# BASELINE.json configs[2] (SE3ET-I KITTI configuration, 20k+20k pairs): every kernel alone, per-step categories (10 steps + 3 warm-up)
+tools/prof.sh ${tag}c3 bench.py --variant se3eti_kitti --pair c3_20k --batch 4 --steps 10 --warmup 3 --inflight 1 --prefetch 0 --no-cpu-baseline --single-pair-steps 0 --train-steps 0 --roofline-quiet-steps 0 >> $O/prof.txt 2>&1; cp gpurun_out/${tag}c3_kernel_stats.csv $O/${tag}_kernel_stats_c3.csv
+python tools/step_breakdown.py $O/${tag}_kernel_stats_c3.csv 13 > $O/${tag}_step_breakdown_c3.txt 2>&1
+# the training step, kernel by kernel (5 steps + 2 warm-up)
+tools/prof.sh ${tag}train tools/train_bench.py --steps 5 --warmup 2 >> $O/prof.txt 2>&1; cp gpurun_out/${tag}train_kernel_stats.csv $O/${tag}_kernel_stats_train.csv
+# how busy the GPU is with three batches in flight
+( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kt && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -o kt -- python3 $R/bench.py --no-cpu-baseline --single-pair-steps 0 --train-steps 0 --roofline-quiet-steps 0 > $O/kt.log 2>&1; f=$(find /tmp/kt -name "*kernel_trace.csv" | head -1); python3 $R/tools/gpu_busy.py $f > $O/${tag}_gpu_busy.txt 2>&1 )
+timeout 300 python tools/micro/block_tail.py 2>&1 | grep -v "amdgpu.ids\|Warning" > $O/${tag}_block_tail.txt
+timeout 300 python tools/micro/linear_stream_shapes.py 2>&1 | grep -v "amdgpu.ids\|Warning" > $O/${tag}_linear_stream_shapes.txt
+timeout 300 python tools/micro/rpe_eq_breakdown.py 2>&1 | grep -v "amdgpu.ids\|Warning" > $O/${tag}_rpe_eq_breakdown.txt
 timeout 300 python tools/micro/kpconv_paths.py 2>&1 | grep -v "amdgpu.ids\|Warning" > $O/${tag}_kpconv_paths.txt
 timeout 300 python tools/micro/dense_norm_shapes.py 2>&1 | grep -v "amdgpu.ids\|Warning" > $O/${tag}_dense_norm_shapes.txt
 for L in 2 5 8; do echo "== KPConv layer $L (tools/micro/kpconv_layer.py $L fused): counters of kpconv_fused_kernel, average per dispatch"; tools/pmc_kernel.sh kpconv_fused_kernel tools/micro/kpconv_layer.py $L fused 3; tail -1 gpurun_out/pmck.log | grep layer; done > $O/${tag}_pmc_kpconv.txt 2>&1

@@ -13,7 +13,9 @@ emb_gb = sum(n * n for n in lengths) * 256 * 4 / 1e9
 for rep in range(2):
     for name, A, eq, bv, split in (('A=6 eq (default)', 6, True, 0, 0), ('A=6 without the eq term', 6, False, 0, 0), ('A=6 eq, logits over one block', 6, True, 9, 0),
                                    ('A=6 no eq, logits over one block', 6, False, 9, 0), ('A=1 invariant', 1, False, 0, 0), ('A=1 invariant, logits over one block', 1, False, 9, 0),
-                                   ('A=6 eq, 3 workgroups per CU queued', 6, True, 0, 3), ('A=6 eq, 4 workgroups per CU queued', 6, True, 0, 4)):
+                                   ('A=6 eq, 3 workgroups per CU queued', 6, True, 0, 3), ('A=6 eq, 4 workgroups per CU queued', 6, True, 0, 4),
+                                   ('A=1 invariant, 3 workgroups per CU (136 registers: all resident)', 1, False, 0, 3),
+                                   ('A=1 invariant, 4 workgroups per CU queued', 1, False, 0, 4)):
         tb, ta, nbytes = B.run(A, lengths, eq, bv, split, 0, iters=20)
         print('%-40s logits kernel %6.1f us  (embedding stream alone %.2f GB -> %.2f TB/s)   attention %6.1f us' % (name, tb, emb_gb, emb_gb / tb * 1e3, ta))
 lib().se3_debug_set_bias_variant(0, 0)
