@@ -112,17 +112,22 @@ constexpr int kStageStride = 36;     // floats per staged logits row (32 keys + 
 // queries split once when they are staged in LDS, the embedding values in registers right behind their load -- three products
 // hi hi + hi lo + lo hi in f32 (2^-22 per term: 1e-6 on logits of magnitude 4).  A lane's two float4 of a 32-channel step are not
 // consecutive channels; the A fragments are staged with the same permutation of the K index.
-template <int CT, int RT, bool NEXT, bool EQ, bool UA, bool BF, bool HS = false>
+// TL (round 4, with HS): the embedding tile is REQUESTED with four adjacent lanes on one key's 64 contiguous bytes (lane l: key l >> 2,
+// 16-byte piece l & 3) instead of the MFMA operand's own order (key l & 15, piece l >> 4: the four lanes of a 64-byte segment 16 lanes apart,
+// every quarter-wave of a load touching 16 different cache lines), and brought into operand order through a wave-private LDS block right
+// before its use (ds_write_b128 / ds_read_b128 of one wave complete in order: no barrier).
+template <int CT, int RT, bool NEXT, bool EQ, bool UA, bool BF, bool HS = false, bool TL = false>
 __device__ __forceinline__ void bias_tile(float4 (&b)[BF ? CT / 2 : CT], const float4* afrag, const float4* qe_s, float* stage,
                                           int col0, const float* Erow, const float* eq_row, unsigned eq_anchor_stride, int tile,
-                                          int next_tile, int M, int AH, int H) {
+                                          int next_tile, int M, int AH, int H, float4* tbuf = nullptr) {
   constexpr int CTB = BF ? CT / 2 : CT;      // 16-byte register chunks per tile and lane
   constexpr int CE = CTB * 16;               // embedding row stride in 4-byte words
   constexpr int NF = BF ? 2 * RT : RT;       // A fragments per chunk (bf16: hi and lo)
   const int lane = threadIdx.x & 63, col = lane & 15, kq = lane >> 4;
   asm volatile("" ::: "memory");        // keeps the LDS fragment reads inside the tile loop (otherwise hoisted and spilled)
   const int m = (tile << 4) + col;
-  const float* Enext = Erow + ((unsigned)min((next_tile << 4) + col, M - 1) * CE + 4 * kq);     // chunk t at +16 t (immediate)
+  const float* Enext = TL ? Erow + ((unsigned)min((next_tile << 4) + (lane >> 2), M - 1) * CE + 4 * (lane & 3))
+                          : Erow + ((unsigned)min((next_tile << 4) + col, M - 1) * CE + 4 * kq);     // chunk t at +16 t (immediate)
   float4 e4[RT];
   if (EQ && UA) {
 #pragma unroll
@@ -144,7 +149,13 @@ __device__ __forceinline__ void bias_tile(float4 (&b)[BF ? CT / 2 : CT], const f
         ah[rt] = afrag[(rt * KT + j) * 64 + lane];
         al[rt] = afrag[((RT + rt) * KT + j) * 64 + lane];
       }
-      const float4 b0 = b[2 * j], b1 = b[2 * j + 1];
+      float4 b0 = b[2 * j], b1 = b[2 * j + 1];
+      if (TL) {      // request order (key l >> 2, piece l & 3) -> operand order (key l & 15, piece l >> 4); rows 5 float4 apart (80 B)
+        tbuf[(lane >> 2) * 5 + (lane & 3)] = b0;
+        tbuf[80 + (lane >> 2) * 5 + (lane & 3)] = b1;
+        b0 = tbuf[col * 5 + kq];
+        b1 = tbuf[80 + col * 5 + kq];
+      }
       uint2 h0, l0, h1, l1;
       split_f16x4(b0, h0, l0);
       split_f16x4(b1, h1, l1);
@@ -221,7 +232,7 @@ __device__ __forceinline__ void bias_tile(float4 (&b)[BF ? CT / 2 : CT], const f
 // range [w U / G, (w+1) U / G) and walks it row segment by row segment (the folded queries of the segment's row are staged
 // in LDS in MFMA-fragment order); inside a segment the 4 waves stride over the units.  A unit = two 16-key tiles whose
 // logits are collected in a wave-private LDS block and written out as full 128-byte row segments (float4 per lane).
-template <int CT, int RT, int MINW, bool EQ, bool UA, bool BF = false, bool HS = false>
+template <int CT, int RT, int MINW, bool EQ, bool UA, bool BF = false, bool HS = false, bool TL = false>
 __global__ __launch_bounds__(256, MINW) void rpe_bias_kernel(const float* __restrict__ qp, const float* __restrict__ qe,
                                                              int qp_rs, long long qp_sa, Stack S, int AH, int H,
                                                              float* __restrict__ bias) {
@@ -230,8 +241,10 @@ __global__ __launch_bounds__(256, MINW) void rpe_bias_kernel(const float* __rest
   __shared__ float4 afrag[RT * CT * 64];                    // bf16: hi fragments, then lo fragments (same size)
   __shared__ float4 qe_s[32];
   __shared__ __attribute__((aligned(16))) float stage_s[4 * RT * 16 * kStageStride];
+  __shared__ float4 tbuf_s[TL ? 4 * 160 : 1];                 // TL: per wave two 16-row blocks of 80 bytes per row
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, kq = lane >> 4;
   float* stage = stage_s + wave * (RT * 16 * kStageStride);
+  float4* tbuf = tbuf_s + (TL ? wave * 160 : 0);
   int f = (int)((long long)blockIdx.x * S.total_units / gridDim.x);
   const int f_end = (int)((long long)(blockIdx.x + 1) * S.total_units / gridDim.x);
   while (f < f_end) {
@@ -271,7 +284,8 @@ __global__ __launch_bounds__(256, MINW) void rpe_bias_kernel(const float* __rest
     }
     float4 b[CTB];
     if (unit < u_hi) {
-      const float* E0 = Erow + ((unsigned)min((unit << 5) + col, cl.M - 1) * CE + 4 * kq);
+      const float* E0 = TL ? Erow + ((unsigned)min((unit << 5) + (lane >> 2), cl.M - 1) * CE + 4 * (lane & 3))
+                           : Erow + ((unsigned)min((unit << 5) + col, cl.M - 1) * CE + 4 * kq);
 #pragma unroll
       for (int t = 0; t < CTB; t++) b[t] = ld4(E0 + 16 * t);
     }
@@ -317,11 +331,11 @@ __global__ __launch_bounds__(256, MINW) void rpe_bias_kernel(const float* __rest
     const unsigned bias_ah = (unsigned)cl.N * cl.Mp;
     for (; unit < u_hi; unit += 4) {
       const int t0 = unit << 1;
-      bias_tile<CT, RT, true, EQ, UA, BF, HS>(b, afrag, qe_s, stage, 0, Erow, eq_row, eq_sa, t0, t0 + 1, cl.M, AH, H);
+      bias_tile<CT, RT, true, EQ, UA, BF, HS, TL>(b, afrag, qe_s, stage, 0, Erow, eq_row, eq_sa, t0, t0 + 1, cl.M, AH, H, tbuf);
       if (unit + 4 < u_hi)
-        bias_tile<CT, RT, true, EQ, UA, BF, HS>(b, afrag, qe_s, stage, 16, Erow, eq_row, eq_sa, t0 + 1, t0 + 8, cl.M, AH, H);
+        bias_tile<CT, RT, true, EQ, UA, BF, HS, TL>(b, afrag, qe_s, stage, 16, Erow, eq_row, eq_sa, t0 + 1, t0 + 8, cl.M, AH, H, tbuf);
       else
-        bias_tile<CT, RT, false, EQ, UA, BF, HS>(b, afrag, qe_s, stage, 16, Erow, eq_row, eq_sa, t0 + 1, t0 + 1, cl.M, AH, H);
+        bias_tile<CT, RT, false, EQ, UA, BF, HS, TL>(b, afrag, qe_s, stage, 16, Erow, eq_row, eq_sa, t0 + 1, t0 + 1, cl.M, AH, H, tbuf);
       // the unit's (rows, 32 keys) block: 8 lanes cover one row's 128 bytes
       const int r8 = lane >> 3, m4 = (lane & 7) * 4;
 #pragma unroll
@@ -1523,7 +1537,9 @@ static int launch_rpe_bias(const float* qp, const float* qe, int row_stride, int
   // one resident round, each workgroup with a balanced range of units: 3 workgroups of 4 waves per CU (LDS: fragments + staging) for the
   // f32 / bf16-embedding kernels, 2 for the f16-split kernel (the splits need ~190 registers; 8 waves x 16 KB stay in flight per CU)
   const bool half_split = !emb_bf16 && g_bias_variant != 2 && g_bias_variant != 3 && (qe == nullptr || H % 4 == 0);
-  int wgs = (half_split ? 2 : 3) * device_cu_count();
+  // (round 4: with the quad-contiguous requests the f16-split kernel of <= 16 folded-query rows takes 130 registers: three resident
+  // workgroups per compute unit, 337 against 351 us per invariant call; the 24-row form takes 176: two)
+  int wgs = (half_split && !(AH <= 16 && g_bias_variant != 5) ? 2 : 3) * device_cu_count();
   if (g_bias_split > 0) wgs = g_bias_split * device_cu_count();
   if (wgs > (total + 3) / 4) wgs = (int)((total + 3) / 4);
   if (wgs < 1) wgs = 1;
@@ -1537,11 +1553,13 @@ static int launch_rpe_bias(const float* qp, const float* qe, int row_stride, int
   } else if (qe == nullptr) {                                                                                               \
     if (g_bias_variant == 2) launch_kernel(1, rpe_bias_kernel<CT, RT, 2, false, true>, grid, dim3(256), st, SE3_BIAS_ARGS);           \
     else if (g_bias_variant == 3) launch_kernel(1, rpe_bias_kernel<CT, RT, 3, false, true>, grid, dim3(256), st, SE3_BIAS_ARGS);      \
-    else launch_kernel(1, rpe_bias_kernel<CT, RT, 2, false, true, false, true>, grid, dim3(256), st, SE3_BIAS_ARGS);                  \
+    else if (g_bias_variant == 5) launch_kernel(1, rpe_bias_kernel<CT, RT, 2, false, true, false, true>, grid, dim3(256), st, SE3_BIAS_ARGS);       \
+    else launch_kernel(1, rpe_bias_kernel<CT, RT, 2, false, true, false, true, true>, grid, dim3(256), st, SE3_BIAS_ARGS);            \
   } else if (H % 4 == 0) {                                                                                           \
     if (g_bias_variant == 2) launch_kernel(1, rpe_bias_kernel<CT, RT, 2, true, true>, grid, dim3(256), st, SE3_BIAS_ARGS);            \
     else if (g_bias_variant == 3) launch_kernel(1, rpe_bias_kernel<CT, RT, 3, true, true>, grid, dim3(256), st, SE3_BIAS_ARGS);       \
-    else launch_kernel(1, rpe_bias_kernel<CT, RT, 2, true, true, false, true>, grid, dim3(256), st, SE3_BIAS_ARGS);                   \
+    else if (g_bias_variant == 5) launch_kernel(1, rpe_bias_kernel<CT, RT, 2, true, true, false, true>, grid, dim3(256), st, SE3_BIAS_ARGS);        \
+    else launch_kernel(1, rpe_bias_kernel<CT, RT, 2, true, true, false, true, true>, grid, dim3(256), st, SE3_BIAS_ARGS);             \
   } else {                                                                                                           \
     launch_kernel(1, rpe_bias_kernel<CT, RT, 2, true, false>, grid, dim3(256), st, SE3_BIAS_ARGS);                                    \
   }
