@@ -21,6 +21,7 @@ child processes of itself (the reference's one-process-per-GPU launch, geotransf
 each, rendezvous on 127.0.0.1, prints rank 0's JSON line and exits with the worst child status.  `--gpus 8 --batch 8` is
 BASELINE.json configs[3] (64 independent pairs per step, 8 per rank)."""
 import argparse
+import gc
 import json
 import os
 import sys
@@ -33,14 +34,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # HBM traffic of one RPE self-attention call relative to its algorithmic bytes, from the rocprofv3 PMC passes committed as
-# profiles/r03_pmc_attention.csv (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of tools/pmc_attention.py on the stack-mode
+# profiles/r04_pmc_attention_raw.txt (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of tools/pmc_attention.py on the stack-mode
 # kernels at the bench shape, 16 clouds per launch; gfx950 correction: FETCH_SIZE x2 for the 16-B/lane streaming reads of
 # rpe_bias_kernel and attn_split_kv_kernel, attention kernel counters raw).  Counters cannot be read inside this process, so the ratio of that run is applied:
-#   eq  call: (2*1310930.1 + 2*37008.9 + 237874.0 + 202416.0 + 70645.9 + 35140.7) KiB = 3319.8 MB  vs 2549.0 MB algorithmic
-#   inv call: (2*1088284.6 + 2*5933.5  +  38268.5 +  33736.0 + 11774.0 +  5856.0) KiB = 2332.7 MB  vs 2222.9 MB algorithmic
+#   eq  call: (2*1311993.8 + 2*36956.1 + 238093.8 + 202416.0 + 70645.6 + 35146.1) KiB = 3322.1 MB  vs 2549.0 MB algorithmic
+#   inv call: (2*1088291.5 + 2*5933.5  +  38268.4 +  33736.0 + 11774.0 +  5856.0) KiB = 2332.8 MB  vs 2222.9 MB algorithmic
 # (logits kernel, K / V^T split, attention kernel: FETCH + WRITE; x2 on the two streaming readers)
-PMC_TRAFFIC_RATIO = {'eq': 3319.8 / 2549.0, 'inv': 2332.7 / 2222.9}
-PMC_TRAFFIC_FILE = 'profiles/r03_pmc_attention.csv'
+PMC_TRAFFIC_RATIO = {'eq': 3322.1 / 2549.0, 'inv': 2332.8 / 2222.9}
+PMC_TRAFFIC_FILE = 'profiles/r04_pmc_attention_raw.txt'
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s is achievable
 
 
@@ -492,6 +493,9 @@ def run_train_step(cfg_variant, args, dev):
     from se3et_amd.synthetic import make_pair
     from se3et_amd.training import OverallLoss, make_optimizer, train_step
     cfg = make_cfg(cfg_variant)
+    gc.collect()
+    torch.cuda.empty_cache()
+    held = torch.cuda.memory_allocated()       # what the inference phases of this process keep alive (models, resident pairs, workspaces, caches)
     model = load_synthetic_weights(create_model(cfg)).to(dev).train()
     loss_fn, opt = OverallLoss(cfg), make_optimizer(model, cfg)
     b = cfg.backbone
@@ -528,7 +532,8 @@ def run_train_step(cfg_variant, args, dev):
     torch.cuda.synchronize()
     return {'s_per_step': round(dt, 4), 'pairs_per_s': round(1.0 / dt, 2), 'steps': args.train_steps,
             'forward_loss_ms': round(ev[0].elapsed_time(ev[1]), 2), 'backward_ms': round(ev[1].elapsed_time(ev[2]), 2),
-            'adam_ms': round(ev[2].elapsed_time(ev[3]), 2), 'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            'adam_ms': round(ev[2].elapsed_time(ev[3]), 2),
+            'peak_mem_gb': round((torch.cuda.max_memory_allocated() - held) / 2 ** 30, 2), 'held_by_earlier_phases_gb': round(held / 2 ** 30, 2),
             'loss': round(float(losses['loss'].detach()), 4),
             'note': 'BASELINE.json configs[4] on one GPU: forward (training mode) + OverallLoss + backward + Adam, one synthetic 5k+5k pair per '
                     'step incl. the on-GPU pyramid; pinned against the reference by tests/test_gpu_training.py::test_fullsize_training_step_matches_reference'}

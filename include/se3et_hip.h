@@ -658,6 +658,9 @@ typedef struct {
   const float* eq[SE3_MAX_BATCH];          /* (A, N_c, N_c, 4) equivariant embedding or NULL */
 } se3_transformer_plan_t;
 size_t se3_transformer_workspace_bytes(const se3_transformer_plan_t* plan);
+/* layout[6] = sizeof(se3_linear_t), sizeof(se3_layer_t), sizeof(se3_transformer_plan_t), offsetof(plan, layers), offsetof(plan, starts),
+ * offsetof(plan, emb): a binding in another language checks its mirror of the structs against the library it loaded. */
+void se3_transformer_plan_layout(size_t* layout);
 int se3_transformer_forward(const se3_transformer_plan_t* plan, const float* x_in, float* out, void* workspace, size_t workspace_bytes,
                             void* stream);
 int se3_linear_stream_segments(const float* x, int64_t rows, int in_features, int seg_channels, int64_t seg_stride, const void* weight_pieces,

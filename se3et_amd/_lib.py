@@ -46,6 +46,7 @@ SIGNATURES = {
     'se3_anchor_mix_stack': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp]),
     'se3_linear_stream_segments': (_i32, [_vp, _i64, _i32, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _i64, _vp]),
     'se3_transformer_workspace_bytes': (_sz, [_vp]),
+    'se3_transformer_plan_layout': (None, [_vp]),
     'se3_transformer_forward': (_i32, [_vp, _vp, _vp, _vp, _sz, _vp]),
     'se3_dense_norm_set_target_chunks': (None, [_i32]),
     'se3_linear_weight_pieces_bytes': (_sz, [_i32, _i32]),

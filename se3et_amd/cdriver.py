@@ -34,6 +34,16 @@ class Plan(ctypes.Structure):
                 ('eq', _vp * MAX_BATCH)]
 
 
+def check_layout():
+    """The ctypes mirror against the loaded library (se3_transformer_plan_layout): sizes of the three structs and three field offsets."""
+    got = (ctypes.c_size_t * 6)()
+    lib().se3_transformer_plan_layout(got)
+    mine = (ctypes.sizeof(Linear), ctypes.sizeof(Layer), ctypes.sizeof(Plan), Plan.layers.offset, Plan.starts.offset, Plan.emb.offset)
+    if tuple(got) != mine:
+        raise RuntimeError('se3et_amd.cdriver: plan structs %s do not match the library\'s %s' % (mine, tuple(got)))
+
+
+_layout_checked = False
 _TYPES = {'self': 0, 'self_eq': 1, 'cross': 2, 'cross_a_soft': 3, 'cross_r_soft': 4}
 ENABLED = os.environ.get('SE3_CDRIVER', '1') != '0'            # False: the Python schedule of se3et_amd.batched (A/B runs, tests)
 
@@ -128,6 +138,10 @@ def transformer_forward(gt, X, PA, R0, embs, eqs):
     """X (A, R, C) packed in_proj features (refs of all pairs, then srcs), PA the packing (se3et_amd.batched._Packed over all 2 B clouds in
     that order), R0 the packed rows of the refs, embs / eqs the clouds' embeddings in the same order (eqs entries None for models without
     the equivariant embedding).  -> (R, C_out) packed output rows of out_proj."""
+    global _layout_checked
+    if not _layout_checked:
+        check_layout()
+        _layout_checked = True
     stream = _ops._stream()
     static, keep = _static_plan(gt, stream)
     plan = Plan.from_buffer_copy(static)

@@ -8,6 +8,7 @@
 // se3_rpe_self_attention_stack_fwd, se3_attention_stack_fwd, se3_cross_eq_stack_x6_fwd, se3_add_layer_norm_fwd, ...), in the order and
 // with the operands of se3et_amd/batched.py::transformer_pairs, whose results it reproduces bit for bit.  Layout: packed rows, the refs of
 // all pairs first (rows0 rows), then the srcs; every cloud starts at a multiple of 32 rows.
+#include <cstddef>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -92,6 +93,16 @@ int eq_groups(int A, const Half& q, int H, int C, const Half& k, int64_t v_row_s
 }
 
 }  // namespace
+
+extern "C" void se3_transformer_plan_layout(size_t* layout) {
+  if (layout == nullptr) return;
+  layout[0] = sizeof(se3_linear_t);
+  layout[1] = sizeof(se3_layer_t);
+  layout[2] = sizeof(se3_transformer_plan_t);
+  layout[3] = offsetof(se3_transformer_plan_t, layers);
+  layout[4] = offsetof(se3_transformer_plan_t, starts);
+  layout[5] = offsetof(se3_transformer_plan_t, emb);
+}
 
 extern "C" size_t se3_transformer_workspace_bytes(const se3_transformer_plan_t* plan) {
   if (plan == nullptr) return 0;

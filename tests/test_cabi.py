@@ -25,6 +25,13 @@ def test_library_exports_every_declared_symbol():
     assert b'gfx950' in L.se3_version()
 
 
+def test_plan_structs_match_the_library():
+    """The ctypes mirror of se3_linear_t / se3_layer_t / se3_transformer_plan_t (se3et_amd/cdriver.py) has the library's sizes and offsets."""
+    from se3et_amd import cdriver
+    cdriver.check_layout()
+    assert ctypes.sizeof(cdriver.Plan) > 16 * ctypes.sizeof(cdriver.Layer)
+
+
 def test_argument_validation_without_gpu():
     from se3et_amd import _lib
     L = _lib.lib()
