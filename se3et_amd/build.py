@@ -19,6 +19,16 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def extra_flags(src):
+    """Per-source flags, selected by markers in the source text."""
+    text = open(src).read()
+    # the bit-exact geometry kernels must not fuse a*b+c (they mirror unfused x86 float arithmetic)
+    extra = ['-ffp-contract=off'] if 'SE3_EXACT_FP' in text else []
+    # (csrc/geo_records.hip: no packed-f32 arithmetic from the SLP vectoriser)
+    extra += ['-fno-slp-vectorize'] if 'SE3_NO_SLP_VECTORIZE' in text else []
+    return extra
+
+
 def build(force=False, verbose=True):
     srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')))
     hdrs = sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [
@@ -34,9 +44,7 @@ def build(force=False, verbose=True):
         o = os.path.join(CSRC, 'build', os.path.basename(s)[:-4] + '.o')
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            # the bit-exact geometry kernels must not fuse a*b+c (they mirror unfused x86 float arithmetic)
-            extra = ['-ffp-contract=off'] if 'SE3_EXACT_FP' in open(s).read() else []
-            jobs.append([HIPCC] + FLAGS + extra + ['-c', s, '-o', o])
+            jobs.append([HIPCC] + FLAGS + extra_flags(s) + ['-c', s, '-o', o])
 
     def run(cmd):
         if verbose:

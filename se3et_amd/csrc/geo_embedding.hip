@@ -15,14 +15,12 @@
 //
 // Mapping: one workgroup per (n, block of m); thread c owns channel c (table rows are read fully coalesced).
 #include "common.h"
+#include "geo_records.h"
 
 namespace {
 
-struct EmbParams {
-  float sigma_d_inv, factor_a;        // index scales
-  float d_inv_h, a_inv_h;             // table resolutions (entries per index unit)
-  int d_entries, a_entries;           // table lengths
-};
+using se3geo::EmbParams;
+using se3geo::hermite_weights;
 
 __device__ __forceinline__ float hermite(const float2* __restrict__ tab, int C, int c, float x, float inv_h, int entries,
                                          bool& ok) {
@@ -32,10 +30,8 @@ __device__ __forceinline__ float hermite(const float2* __restrict__ tab, int C, 
   j = min(max(j, 0), entries - 2);
   const float t = u - (float)j;
   const float2 p0 = tab[(size_t)j * C + c], p1 = tab[(size_t)(j + 1) * C + c];
-  const float h = 1.0f / inv_h;
-  const float t2 = t * t, t3 = t2 * t;
-  const float h00 = 2.f * t3 - 3.f * t2 + 1.f, h10 = t3 - 2.f * t2 + t, h01 = -2.f * t3 + 3.f * t2, h11 = t3 - t2;
-  return (h00 * p0.x + h01 * p1.x) + h * (h10 * p0.y + h11 * p1.y);
+  const float4 w = hermite_weights(t, 1.0f / inv_h);
+  return (w.x * p0.x + w.y * p1.x) + (w.z * p0.y + w.w * p1.y);
 }
 
 // exact evaluation W[c, :] . emb(x) + b[c] (fallback for indices outside the table)
@@ -103,10 +99,9 @@ __global__ void geo_embedding_kernel(const float* __restrict__ pts, const int64_
         const int j = (int)floorf(u);
         const bool ok = (j >= 0) && (j + 1 < entries);
         const float tt = u - (float)j, h = 1.0f / inv_h;
-        const float t2 = tt * tt, t3 = t2 * tt;
         idx_s[threadIdx.x][t] = x[t];
         j_s[threadIdx.x][t] = ok ? j : -1;
-        wt_s[threadIdx.x][t] = make_float4(2.f * t3 - 3.f * t2 + 1.f, -2.f * t3 + 3.f * t2, h * (t3 - 2.f * t2 + tt), h * (t3 - t2));
+        wt_s[threadIdx.x][t] = hermite_weights(tt, h);
       }
       // unit vector of p_n - p_m for the equivariant embedding (zero vector -> 0, as F.normalize with eps 1e-12)
       const float len = sqrtf(vx * vx + vy * vy + vz * vz);
@@ -178,65 +173,6 @@ constexpr int kCS = 32;      // channels per workgroup
 constexpr int kSliceThreads = 1024;
 constexpr int kRecBlock = 16;                                  // pairs per staged record block
 constexpr int kRecBytes = kRecBlock * (64 + 16);               // weights (4 float4) + intervals (int4) per pair
-
-__device__ __forceinline__ void pair_term_record(float x, float inv_h, int entries, int& j_out, float4& w_out) {
-  const float u = x * inv_h;
-  const int j = (int)floorf(u);
-  const bool ok = (j >= 0) && (j + 1 < entries);
-  const float tt = u - (float)j, h = 1.0f / inv_h;
-  const float t2 = tt * tt, t3 = t2 * tt;
-  j_out = ok ? j : -1;
-  // outside the table: the index itself, for the exact evaluation
-  w_out = ok ? make_float4(2.f * t3 - 3.f * t2 + 1.f, -2.f * t3 + 3.f * t2, h * (t3 - 2.f * t2 + tt), h * (t3 - t2)) : make_float4(x, 0.f, 0.f, 0.f);
-}
-
-// one thread per (n, m): the four indices, their table intervals and Hermite weights (80 contiguous bytes of records), and Eeq
-__global__ __launch_bounds__(256) void geo_pair_terms_kernel(const float* __restrict__ pts, const int64_t* __restrict__ knn, int N,
-                                                             EmbParams P, const float* __restrict__ wigner_d1, int4* __restrict__ jrec,
-                                                             float4* __restrict__ wrec, float* __restrict__ eq_emb, int A) {
-  const unsigned pair = blockIdx.x * 256u + threadIdx.x;
-  if (pair >= (unsigned)N * (unsigned)N) return;
-  const int n = (int)(pair / (unsigned)N), m = (int)(pair - (unsigned)n * (unsigned)N);
-  const float px = pts[3 * n], py = pts[3 * n + 1], pz = pts[3 * n + 2];
-  const float qx = pts[3 * m], qy = pts[3 * m + 1], qz = pts[3 * m + 2];
-  const float vx = qx - px, vy = qy - py, vz = qz - pz;
-  int j[4];
-  float4 w[4];
-  {
-    const float nn2 = px * px + py * py + pz * pz;
-    const float d2 = fmaxf(nn2 - 2.f * (px * qx + py * qy + pz * qz) + (qx * qx + qy * qy + qz * qz), 0.f);
-    pair_term_record(sqrtf(d2) * P.sigma_d_inv, P.d_inv_h, P.d_entries, j[0], w[0]);
-  }
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    const int64_t jn = knn[3 * n + k];
-    const float rx = pts[3 * jn] - px, ry = pts[3 * jn + 1] - py, rz = pts[3 * jn + 2] - pz;
-    const float cx = ry * vz - rz * vy, cy = rz * vx - rx * vz, cz = rx * vy - ry * vx;
-    const float sn = sqrtf(cx * cx + cy * cy + cz * cz);
-    float cs = rx * vx + ry * vy + rz * vz;
-    cs = (cs == 0.f) ? 0.f : cs;        // see geo_embedding_kernel
-    pair_term_record(atan2f(sn, cs) * P.factor_a, P.a_inv_h, P.a_entries, j[1 + k], w[1 + k]);
-  }
-  jrec[pair] = make_int4(j[0], j[1], j[2], j[3]);
-#pragma unroll
-  for (int t = 0; t < 4; t++) wrec[(size_t)pair * 4 + t] = w[t];
-  if (eq_emb != nullptr) {
-    // unit vector of p_n - p_m (zero vector -> 0, as F.normalize with eps 1e-12)
-    const float len = sqrtf(vx * vx + vy * vy + vz * vz);
-    const float inv = 1.f / fmaxf(len, 1e-12f);
-    const float ux = -vx * inv, uy = -vy * inv, uz = -vz * inv;
-    const float c1 = 0.4886025119029199f;        // sqrt(3 / (4 pi))
-    for (int a = 0; a < A; a++) {
-      const float* D = wigner_d1 + 9 * a;        // D^1_a (3, 3): out_c = sum_d D[c][d] Y1_d
-      float4 o;
-      o.x = 0.28209479177387814f;                // 1 / (2 sqrt(pi))
-      o.y = c1 * (D[0] * ux + D[1] * uy + D[2] * uz);
-      o.z = c1 * (D[3] * ux + D[4] * uy + D[5] * uz);
-      o.w = c1 * (D[6] * ux + D[7] * uy + D[8] * uz);
-      reinterpret_cast<float4*>(eq_emb)[(size_t)a * N * N + pair] = o;
-    }
-  }
-}
 
 struct ExactArgs { const float *Wd, *bd, *Wa, *ba, *div_term; };    // only the cold path (index outside a table) reads these
 
@@ -396,9 +332,8 @@ __global__ void geo_embedding_bwd_operands_kernel(const float* __restrict__ pts,
           const int j = (int)floorf(u);
           const bool ok = (j >= 0) && (j + 1 < P.a_entries);
           const float tt = u - (float)j, h = 1.0f / P.a_inv_h;
-          const float t2 = tt * tt, t3 = t2 * tt;
-          j_s[threadIdx.x][t] = ok ? j : -1;
-          wt_s[threadIdx.x][t] = make_float4(2.f * t3 - 3.f * t2 + 1.f, -2.f * t3 + 3.f * t2, h * (t3 - 2.f * t2 + tt), h * (t3 - t2));
+            j_s[threadIdx.x][t] = ok ? j : -1;
+          wt_s[threadIdx.x][t] = hermite_weights(tt, h);
         }
       }
     }
@@ -587,8 +522,7 @@ static int geo_embedding(const float* points, const int64_t* knn, int N, int C, 
     const size_t pairs = (size_t)N * N;
     int4* jrec = static_cast<int4*>(workspace);
     float4* wrec = reinterpret_cast<float4*>(jrec + pairs);
-    geo_pair_terms_kernel<<<(unsigned)((pairs + 255) / 256), 256, 0, (hipStream_t)stream>>>(points, knn, N, P, wigner_d1, jrec, wrec,
-                                                                                                    eq_emb, num_anchors);
+    se3geo::launch_pair_terms(points, knn, N, P, wigner_d1, jrec, wrec, eq_emb, num_anchors, (hipStream_t)stream);
     // one workgroup per CU (LDS): row blocks so that slices x blocks is a multiple of the 256 CUs when N allows
     const int slices = C / kCS;
     int row_blocks = 256 / slices > 0 ? 256 / slices : 1;
