@@ -82,25 +82,46 @@ __global__ __launch_bounds__(256) void gn_partial4_kernel(const float* __restric
   chunk_rows(T, blockIdx.x, r0, r1);
   WF w[4] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
   const float4* xq = reinterpret_cast<const float4*>(x) + q;
-  long long r = r0 + rl;
-  for (; r + 7 * RL < r1; r += 8 * RL) {
-    float4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) v[u] = pre(xq[(r + u * RL) * Q]);
+  // Two batches of eight rows per row lane in flight (a chunk is 15-20 rows per lane at the sizes of the pyramid: with ONE batch in flight
+  // and a remainder loop of single loads the pass was a chain of up to nine memory round trips, 2 TB/s -- tools/micro/gn_stats_rate.py).
+  // Rows past the chunk are requested again at the chunk's last row and not counted; the four channels of a lane share their count, so
+  // one reciprocal per row serves all four Welford updates (same operations per channel as wf_push: the statistics are bit-identical).
+  auto request = [&](float4 (&v)[8], long long r) {
 #pragma unroll
     for (int u = 0; u < 8; u++) {
-      wf_push(w[0], v[u].x);
-      wf_push(w[1], v[u].y);
-      wf_push(w[2], v[u].z);
-      wf_push(w[3], v[u].w);
+      const long long row = r + u * RL;
+      v[u] = xq[(row < r1 ? row : r1 - 1) * Q];
     }
-  }
-  for (; r < r1; r += RL) {
-    const float4 v = pre(xq[r * Q]);
-    wf_push(w[0], v.x);
-    wf_push(w[1], v.y);
-    wf_push(w[2], v.z);
-    wf_push(w[3], v.w);
+  };
+  auto consume = [&](const float4 (&v)[8], long long r) {
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (r + u * RL < r1) {
+        const float4 t = pre(v[u]);
+        const float n = w[0].n + 1.f, inv = __frcp_rn(n);
+        const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          w[k].n = n;
+          const float d = tv[k] - w[k].mean;
+          w[k].mean += d * inv;
+          w[k].m2 += d * (tv[k] - w[k].mean);
+        }
+      }
+  };
+  {
+    float4 va[8], vb[8];
+    long long r = r0 + rl;
+    if (r < r1) request(va, r);
+    while (r < r1) {
+      const long long rb = r + 8 * RL, rc = r + 16 * RL;
+      if (rb < r1) request(vb, rb);
+      consume(va, r);
+      if (rb >= r1) break;
+      if (rc < r1) request(va, rc);
+      consume(vb, rb);
+      r = rc;
+    }
   }
 #pragma unroll
   for (int k = 0; k < 4; k++) sh[threadIdx.x][k] = w[k];
@@ -281,6 +302,7 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
   float s1 = 0.f, t2 = 0.f, s4 = 0.f;
   if (c < C) {
     const float sc = affine[c], sf = affine[C + c];
+#pragma unroll 8
     for (long long r = r0 + rl; r < r1; r += 4) {
       const float xv = x[r * C + c];
       float dz = dout[r * C + c];
