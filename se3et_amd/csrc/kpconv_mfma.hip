@@ -569,8 +569,9 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
   // weight fragments (hi, lo) of this wave's next BD K16-steps: a ring of BD register sets, each refilled behind the MFMAs that read it
   // (with the fragments always L1-resident a chunk of the 256-wide layer takes 13.4 K cycles instead of 19.7 K: the L2 round trip of the
   // weight stream is the consumers' main stall, tools/micro/kpconv_stamps.py with -DSE3_DIAG_FIXED_B)
-  constexpr int BD = (CT == 2 && KS > 1) ? 2 : 3;                       // ring depth (the K-split two-tile form has no registers for a third set)
-  constexpr int U = BD == 3 ? 6 : 2;                                    // unroll = lcm(2 A buffers, BD)
+  constexpr int BD = (CT == 2 && KS > 1) ? 2 : (CT == 1 ? 6 : 3);        // ring depth (the K-split two-tile form has no registers for a third set;
+                                                                        // one column tile per wave leaves room for six: the producers' branch sets the kernel's register count)
+  constexpr int U = BD == 2 ? 2 : 6;                                    // unroll = lcm(2 A buffers, BD)
   static_assert(kSPW % U == 0, "K16-steps per wave and chunk must be a multiple of the unroll");
   const int64_t wstep = (int64_t)NCT * 2 * 64;                          // uint4 per K16-step over the whole layer
   const u32x4* wbase = Wf + (int64_t)chunk0 * kSteps * wstep + (int64_t)ct0 * 2 * 64 + lane;
