@@ -234,16 +234,29 @@ __global__ __launch_bounds__(256, MODE == 3 ? 2 : 3) void dense_norm_kernel(cons
   WF run[CT];
 #pragma unroll
   for (int c = 0; c < CT; c++) run[c] = {0.f, 0.f, 0.f};
-  u32x4 bq[2][CT][2];                                                   // weight fragments of the next two K16 sub-steps
+  // Weight fragments of the next WD K-steps (two K16 sub-steps each), a ring of register sets: set s % WD holds K-step s and is refilled
+  // with K-step s + WD behind the MFMAs that read it.  One set (the fragments requested one K-step = 100-200 ns of MFMAs ahead of an L2
+  // round trip of ~700) is enough where three workgroups per compute unit walk many row tiles; the transformer's layers are ONE tile per
+  // workgroup on fewer workgroups than compute units -- a chain of K / 32 round trips -- and their small tiles leave the registers for more.
+  constexpr int WD = (kPlain && RT == 1 && WM == 2) ? (CT == 1 ? 4 : 2) : 1;
+  u32x4 bq[WD][2][CT][2];
+  auto weights_of = [&](int kstep) -> const u32x4* {                      // fragments of K-step `kstep` of the tile's sequence (uniform)
+    const bool two = kDual && kstep >= nk1;
+    return (two ? wbase2 : wbase1) + (int64_t)(2 * (two ? kstep - nk1 : kstep)) * wstep;
+  };
 #pragma unroll
-  for (int j = 0; j < 2; j++)
+  for (int d = 0; d < WD; d++) {
+    const u32x4* w0 = weights_of(d % nkt);
 #pragma unroll
-    for (int c = 0; c < CT; c++) {
-      bq[j][c][0] = wbase1[j * wstep + coff[c]];
-      bq[j][c][1] = wbase1[j * wstep + coff[c] + 64];
-    }
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int c = 0; c < CT; c++) {
+        bq[d][j][c][0] = w0[j * wstep + coff[c]];
+        bq[d][j][c][1] = w0[j * wstep + coff[c] + 64];
+      }
+  }
 
-  auto multiply = [&](int buf, const StepPos& p) {
+  auto multiply = [&](int buf, const StepPos& p, u32x4 (&bq)[2][CT][2]) {
     if constexpr (kDual) {
       if (p.kk == nk1) {                                                 // between the two products: S1 G1 -> S2 G1 a1 / a2
 #pragma unroll
@@ -253,10 +266,10 @@ __global__ __launch_bounds__(256, MODE == 3 ? 2 : 3) void dense_norm_kernel(cons
       }
     }
     const unsigned char* img = lds + buf * kBufB + a_read;
-    // weight fragments of the NEXT K-step (the sequence wraps at a tile end)
-    const int kn = p.kk + 1 == nkt ? 0 : p.kk + 1;
-    const bool two_n = kDual && kn >= nk1;
-    const u32x4* wnext = (two_n ? wbase2 : wbase1) + (int64_t)(2 * (two_n ? kn - nk1 : kn)) * wstep;
+    // weight fragments of K-step + WD go where this step's were (the sequence wraps at a tile end)
+    int kn = p.kk + WD;
+    while (kn >= nkt) kn -= nkt;
+    const u32x4* wnext = weights_of(kn);
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
       f16x8 av[RT][2];
@@ -425,17 +438,36 @@ __global__ __launch_bounds__(256, MODE == 3 ? 2 : 3) void dense_norm_kernel(cons
   request(pr, rb);
   advance(pr);
   __syncthreads();
+  if constexpr (WD == 1) {
 #pragma unroll 1
-  for (int s = 0; s < total; s++) {
-    multiply(s & 1, pm);
-    advance(pm);
-    stage((s + 1) & 1, ps, ra);
-    advance(ps);
+    for (int s = 0; s < total; s++) {
+      multiply(s & 1, pm, bq[0]);
+      advance(pm);
+      stage((s + 1) & 1, ps, ra);
+      advance(ps);
 #pragma unroll
-    for (int j = 0; j < U; j++) ra[j] = rb[j];
-    request(pr, rb);
-    advance(pr);
-    __syncthreads();
+      for (int j = 0; j < U; j++) ra[j] = rb[j];
+      request(pr, rb);
+      advance(pr);
+      __syncthreads();
+    }
+  } else {                                                               // WD (even) steps per trip: static ring and image indices
+#pragma unroll 1
+    for (int s = 0; s < total; s += WD) {
+#pragma unroll
+      for (int j = 0; j < WD; j++) {
+        if (s + j >= total) break;                                       // (uniform)
+        multiply(j & 1, pm, bq[j]);
+        advance(pm);
+        stage((j + 1) & 1, ps, ra);
+        advance(ps);
+#pragma unroll
+        for (int u = 0; u < U; u++) ra[u] = rb[u];
+        request(pr, rb);
+        advance(pr);
+        __syncthreads();
+      }
+    }
   }
   if constexpr (!kStats) return;
   // ---- the chunk's statistics: + bias, waves that share columns merged through LDS, channels merged into their groups across lanes
