@@ -584,46 +584,56 @@ __global__ void gather_rows_kernel(const float* __restrict__ x, const int64_t* _
 
 __global__ __launch_bounds__(256) void neighbor_max_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
                                                            int64_t n, int64_t m, int nn, int64_t width, float* __restrict__ out) {
-  __shared__ unsigned row_s[64];         // element offset of the neighbour's row; padded entries (row n) and absent columns read row 0
-  __shared__ float fill_s[64];           // and contribute this instead: 0 for a padded entry (the zero row), -inf for an absent column
-  __shared__ unsigned char use_s[64];
+  // The REAL neighbours of the point, compacted (the tables of the fine stages are mostly padding: 34 % / 55 % / 86 % real entries in the
+  // three pooling tables of the 5k-point pyramid, tools/micro/neighbor_fill.py): element offsets of their rows, the list filled up to a
+  // multiple of 8 with its last row (a repeated row does not change a maximum).  A padded entry (index n: the reference's zero row)
+  // contributes 0 once; a column beyond the pair's own table width (-1, several pairs stacked) contributes nothing.
+  __shared__ unsigned row_s[64];
+  __shared__ int cnt_s, pad_s;
   const int64_t r = blockIdx.x;
-  const int nn8 = (nn + 7) & ~7;
-  for (int j = threadIdx.x; j < nn8; j += blockDim.x) {
-    const int64_t s = j < nn ? idx[r * nn + j] : -1;      // s < 0: column beyond the pair's own table width (several pairs stacked)
+  if (threadIdx.x < 64) {
+    const int j = threadIdx.x;
+    const int64_t s = j < nn ? idx[r * nn + j] : -1;
     const bool real = s >= 0 && s < n;
-    row_s[j] = real ? (unsigned)(s * width) : 0u;
-    use_s[j] = real ? 1 : 0;
-    fill_s[j] = s < 0 ? -INFINITY : 0.f;
+    const unsigned long long mask = __ballot(real), pads = __ballot(s >= n);
+    const int cnt = __popcll(mask);
+    if (real) row_s[__popcll(mask & ((1ull << j) - 1ull))] = (unsigned)(s * width);
+    const int last = 63 - __clzll((long long)(mask | 1ull));              // lane of the last real entry (lane 0 when there is none)
+    const unsigned last_row = (unsigned)__shfl(real ? (unsigned)(s * width) : 0u, last);
+    const int cnt8 = (cnt + 7) & ~7;
+    if (j >= cnt && j < cnt8) row_s[j] = last_row;
+    if (j == 0) {
+      cnt_s = cnt;
+      pad_s = pads != 0ull;
+    }
   }
   __syncthreads();
+  const int cnt = cnt_s, cnt8 = (cnt + 7) & ~7;
+  const float floor_v = pad_s ? 0.f : -INFINITY;
   // 8 gathered rows in flight per thread (the loop was one L2 round trip per neighbour)
   if ((width & 3) == 0) {
     const int64_t w4 = width >> 2;
     for (int64_t c = threadIdx.x; c < w4; c += blockDim.x) {
-      float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-      for (int j0 = 0; j0 < nn8; j0 += 8) {
+      float4 best = make_float4(floor_v, floor_v, floor_v, floor_v);
+      for (int j0 = 0; j0 < cnt8; j0 += 8) {
         float4 v[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) v[u] = reinterpret_cast<const float4*>(x + row_s[j0 + u])[c];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const float f = fill_s[j0 + u];
-          const float4 t = use_s[j0 + u] ? v[u] : make_float4(f, f, f, f);
-          best = make_float4(fmaxf(best.x, t.x), fmaxf(best.y, t.y), fmaxf(best.z, t.z), fmaxf(best.w, t.w));
-        }
+        for (int u = 0; u < 8; u++)
+          best = make_float4(fmaxf(best.x, v[u].x), fmaxf(best.y, v[u].y), fmaxf(best.z, v[u].z), fmaxf(best.w, v[u].w));
       }
       reinterpret_cast<float4*>(out + r * width)[c] = best;
     }
   } else {
     for (int64_t c = threadIdx.x; c < width; c += blockDim.x) {
-      float best = -INFINITY;
-      for (int j0 = 0; j0 < nn8; j0 += 8) {
+      float best = floor_v;
+      for (int j0 = 0; j0 < cnt8; j0 += 8) {
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) v[u] = x[row_s[j0 + u] + c];
 #pragma unroll
-        for (int u = 0; u < 8; u++) best = fmaxf(best, use_s[j0 + u] ? v[u] : fill_s[j0 + u]);
+        for (int u = 0; u < 8; u++) best = fmaxf(best, v[u]);
       }
       out[r * width + c] = best;
     }
