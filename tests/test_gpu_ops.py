@@ -1209,3 +1209,35 @@ def test_gram_stack_kernel_matches_the_library_path(C, lengths):
     e_new, e_lib = float((got.double() - ref).abs().max()), float((want.double() - ref).abs().max())
     assert e_new <= max(2 * e_lib, 2e-6 * float(ref.abs().max())), (e_new, e_lib)
     assert torch.equal(ops._gram_per_pair(x, starts, lengths), got)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows', [6, 42, 48, 54, 378, 384, 390, 6000, 6144 + 6, 100002])
+@pytest.mark.parametrize('channels', [32, 256])
+def test_group_norm_statistics_pass_handles_every_remainder(rows, channels):
+    """The statistics pass keeps two batches of eight rows per lane in flight and clamps the last one (csrc/rowops.hip: gn_partial4_kernel):
+    row counts around every batch boundary, with and without a pending stage, against torch's group_norm per segment."""
+    from se3et_amd import ops
+    torch.manual_seed(rows + channels)
+    dev = torch.device('cuda')
+    x = torch.randn(rows, channels, device=dev) * 2 + 0.5
+    w = torch.rand(channels, device=dev) + 0.5
+    b = torch.randn(channels, device=dev)
+    cut = rows // 2 // 6 * 6
+    segs = [None] if cut == 0 else [None, [0, cut, rows]]
+    for seg in segs:
+        bounds = [0, rows] if seg is None else seg
+        aff = ops.group_norm_stats(x, w, b, 32, 1e-5, segments=seg)
+        for i in range(len(bounds) - 1):
+            xs = x[bounds[i]:bounds[i + 1]]
+            want = torch.nn.functional.group_norm(xs.t()[None], 32, w, b, 1e-5)[0].t()
+            got = xs * aff[i, 0] + aff[i, 1]
+            assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max())), (rows, channels, seg, i)
+        # through one pending stage: statistics of lrelu(norm_1(x)) without materialising it
+        pend = ops.Pending(x, [aff], [0.1], seg)
+        aff2 = ops.group_norm_stats(pend, w, b, 32, 1e-5)
+        for i in range(len(bounds) - 1):
+            xs = torch.nn.functional.leaky_relu(x[bounds[i]:bounds[i + 1]] * aff[i, 0] + aff[i, 1], 0.1)
+            want = torch.nn.functional.group_norm(xs.t()[None], 32, w, b, 1e-5)[0].t()
+            got = xs * aff2[i, 0] + aff2[i, 1]
+            assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max())), (rows, channels, seg, i, 'pending')
