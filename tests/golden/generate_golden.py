@@ -298,7 +298,8 @@ def gen_precompute_cap():
 def gen_train(variant, fname, micro=True, pair='micro', synth_seed=None, full_grads=None):
     """BASELINE.json configs[4] pieces through the genuine reference in TRAINING mode: forward with ground-truth superpoint
     targets, OverallLoss (weighted circle loss + fine NLL), backward, one Adam step.  Stored: the loss values, the ground-truth
-    correspondences, the gradient norm of every parameter and a few complete gradients, the total norm, and a parameter checksum
+    correspondences, the gradient norm, a strided slice and the largest magnitude of every parameter's gradient, a few complete gradients, the
+    total norm, and a parameter checksum
     after the optimizer step.  Micro config with the reference-initialised weights of micro_se3ete.npz (seed 0)."""
     make_cfg, create_model = ref_shims.load_experiment(variant)
     import loss as loss_mod                     # experiments/<variant>/loss.py
@@ -344,6 +345,16 @@ def gen_train(variant, fname, micro=True, pair='micro', synth_seed=None, full_gr
         norms.append(float(g.norm()))
         total += float((g * g).sum())
     res['grad/names'], res['grad/norms'], res['grad/total_norm'] = np.array(names), np.array(norms), np.float64(total ** 0.5)
+    # a strided slice (up to 64 entries) and the largest magnitude of EVERY gradient: a wrong gradient with the right norm does not pass
+    slices, offsets, absmax = [], [0], []
+    params_ = dict(model.named_parameters())
+    for n in names:
+        flat = params_[n].grad.reshape(-1)
+        sl = flat[::max(1, flat.numel() // 64)][:64]
+        slices.append(_np(sl))
+        offsets.append(offsets[-1] + sl.numel())
+        absmax.append(float(flat.abs().max()))
+    res['grad/slices'], res['grad/slice_offsets'], res['grad/absmax'] = np.concatenate(slices), np.array(offsets), np.array(absmax)
     for n in full_grads or ('backbone.encoder1_1.interso3.conv.weights', 'backbone.encoder4_3.unary2.mlp.weight',
                             'transformer.embedding.proj_d.weight', 'transformer.transformer.layers.0.attention.attention.proj_eq.weight',
                             'transformer.transformer.layers.3.attention.attention.proj_q.weight', 'transformer.out_proj.weight',

@@ -56,6 +56,15 @@ def _check_training_step(g, cfg, model, dd, grad_tol=1e-3, full_tol=2e-3):
     for key in g.files:
         if key.startswith('grad/full/'):
             assert_close(params[key[len('grad/full/'):]].grad.cpu(), g[key], full_tol, key)
+    # a strided slice of EVERY gradient (up to 64 entries each), within full_tol of the gradient's largest entry: the norms alone would let a
+    # wrong gradient of the right size through
+    offs, absmax = g['grad/slice_offsets'], g['grad/absmax']
+    for i, n in enumerate(names):
+        flat = params[n].grad.reshape(-1)
+        got = flat[::max(1, flat.numel() // 64)][:64].cpu().double().numpy()
+        want_sl = g['grad/slices'][offs[i]:offs[i + 1]].astype('float64')
+        assert got.shape == want_sl.shape, n
+        assert float(abs(got - want_sl).max()) <= full_tol * float(absmax[i]) + 1e-6 * big, (n, float(abs(got - want_sl).max()), float(absmax[i]))
     opt.step()
     assert_close(model.transformer.out_proj.weight.detach().cpu(), g['after_step/out_proj_weight'], 1e-4, 'out_proj.weight after Adam')
     psum = sum(float(p.detach().double().sum()) for p in model.parameters())
