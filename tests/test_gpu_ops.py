@@ -1241,3 +1241,84 @@ def test_group_norm_statistics_pass_handles_every_remainder(rows, channels):
             want = torch.nn.functional.group_norm(xs.t()[None], 32, w, b, 1e-5)[0].t()
             got = xs * aff2[i, 0] + aff2[i, 1]
             assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max())), (rows, channels, seg, i, 'pending')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('scale,bound', [(1e-4, 6e-4), (1e-2, 1e-5), (1.0, 2e-6), (1e2, 2e-6), (1.2e4, 2e-6)])
+def test_f16_split_accuracy_over_input_magnitudes(scale, bound):
+    """Where the f16 hi + lo split of the ACTIVATIONS keeps the accuracy of an f32 product: the split is unscaled, so a value's
+    lo piece is a normal f16 number for 2^-3 <= |x| < 65504 (error 2^-22 |x|), a subnormal one below (absolute error 2^-25: 1e-5 relative at
+    |x| ~ 1e-2, and at |x| ~ 1e-4 the lo piece is gone -- f16 accuracy, 2^-12), and the hi piece overflows at 65504.  The bounds asserted
+    here are the documented ones; test_dense_inputs_of_the_c2_forward_stay_in_the_split_range shows where the model's activations lie."""
+    from se3et_amd import ops
+    torch.manual_seed(3)
+    dev = torch.device('cuda')
+    x = torch.randn(4096, 256, device=dev) * scale
+    w = torch.randn(256, 256, device=dev) / 16
+    out = ops.linear_stream(x, w)
+    assert bool(torch.isfinite(out).all())
+    ref = x.double() @ w.double().t()
+    err = float((out.double() - ref).abs().max() / ref.abs().max())
+    assert err <= bound, (scale, err)
+
+
+@pytest.mark.gpu
+def test_dense_inputs_of_the_c2_forward_stay_in_the_split_range():
+    """Every tensor that the inference forward of the headline configuration hands to an f16-split kernel (dense layers plain / with pending
+    norms, KPConv) lies inside the range in which the split is f32-accurate: far from the f16 overflow (largest magnitude below 65504 / 64 --
+    the KPConv sums ~40 weighted neighbours) and not a tensor of tiny numbers (RMS above 2^-7: the bulk of the values have normal lo pieces
+    or contribute below the f32 round-off of the larger ones)."""
+    from se3et_amd import cdriver, ops
+    from se3et_amd.batched import forward_pairs
+    from se3et_amd.data import precompute_data_stack_mode
+    from se3et_amd.model import create_model, load_synthetic_weights, make_cfg
+    from se3et_amd.synthetic import make_pair
+    cfg = make_cfg('se3ete')
+    model = load_synthetic_weights(create_model(cfg)).cuda().eval()
+    b = cfg.backbone
+    ref, src, _ = make_pair('c2_5k', index=0)
+    pts = torch.from_numpy(np.concatenate([ref, src], 0)).cuda()
+    lens = torch.tensor([len(ref), len(src)])
+    seen = []
+
+    def concrete(x):
+        if isinstance(x, ops.Pending):
+            v = x.raw
+            segs = x.segments
+            for aff, slope in zip(x.affines, x.slopes):
+                if aff.shape[0] == 1:
+                    v = v * aff[0, 0] + aff[0, 1]
+                else:
+                    v = torch.cat([v[segs[i]:segs[i + 1]] * aff[i, 0] + aff[i, 1] for i in range(aff.shape[0])], 0) if v.dim() == 2 else v
+                v = torch.nn.functional.leaky_relu(v, slope) if slope != 1.0 else v
+            return v
+        if isinstance(x, ops.BlockedFeatures):
+            return x.plain()
+        return x
+
+    def wrap(name):
+        orig = getattr(ops, name)
+
+        def f(x, *a, **k):
+            v = concrete(x).detach().float()
+            seen.append((name, tuple(v.shape), float(v.abs().max()), float(v.pow(2).mean().sqrt())))
+            return orig(x, *a, **k)
+        setattr(ops, name, f)
+        return orig
+    names = ('linear_stream', 'linear_stream_transposed', 'dense_norm', 'dense_stats', 'dense_residual', 'kpconv_inter_so3')
+    saved = {n: wrap(n) for n in names}
+    enabled, cdriver.ENABLED = cdriver.ENABLED, False          # (the C-issued transformer would bypass the Python front ends hooked here)
+    try:
+        with torch.no_grad():
+            data = precompute_data_stack_mode(pts, lens, b.num_stages, b.init_voxel_size, b.init_radius, cfg.neighbor_limits)
+            data['features'] = torch.ones((pts.shape[0], 1), device='cuda')
+            forward_pairs(model, data)
+    finally:
+        cdriver.ENABLED = enabled
+        for n, f in saved.items():
+            setattr(ops, n, f)
+    assert len(seen) > 100
+    worst_max = max(s[2] for s in seen)
+    worst_rms = min(s[3] for s in seen)
+    assert worst_max < 65504.0 / 64, sorted(seen, key=lambda s: -s[2])[:3]
+    assert worst_rms > 2.0 ** -7, sorted(seen, key=lambda s: s[3])[:3]
