@@ -208,10 +208,13 @@ __device__ __forceinline__ void gn_finalize_groups(const float* part, int groups
 
 static bool gn_fast_path(int channels) { return channels >= 16 && channels <= 1024 && (channels & (channels - 1)) == 0; }
 
-// chunks per segment: up to 256 (more only move time into the finalize pass: 1024 chunks of a one-pair tensor cost it 11 us instead of 6)
+// chunks per segment: 256 in all (one workgroup per compute unit), shared by the segments.  More chunks only move time into the merge of
+// the last workgroup to arrive, a chain of memory round trips behind the whole pass: with 1 024 chunks over the 8 segments of a batch the
+// statistics passes of a step took 0.59 ms, with 512 0.45, with 256 0.43 (tools/micro/gn_stats_rate.py; a one-pair tensor: 11 us with
+// 1 024 chunks, 6 with 256).
+constexpr int kGNStatChunks = 256;
 static int gn_chunk_cap(int num_segments) {
-  int cap = kGNMaxChunks / num_segments;
-  if (cap > 256) cap = 256;
+  int cap = kGNStatChunks / num_segments;
   return cap > 8 ? cap : 8;
 }
 
