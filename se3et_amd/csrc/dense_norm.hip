@@ -699,12 +699,13 @@ int linear_stream(const float* x, int64_t rows, int K, int64_t x_rs, const void*
   else
     SE3_REQUIRE(out_rs >= N && rows * out_rs < (1ll << 29), SE3_ERR_INVALID_ARG, "linear_stream: out row stride %lld", (long long)out_rs);
   if (rows == 0) return SE3_OK;
-  // tile: 64 x 256 when that fills the chip, else 64 x 128, else 64 x 64 (N <= 64: 128 x 64 / 128 x 32 as the unary layers)
+  // tile: 64 x 256 when that fills the chip, else 64 x 128 when THAT gives every compute unit a workgroup, else 64 x 64 (its weight ring is
+  // four K-steps deep: -3 us on the K = 512 layers of a few thousand rows, -9 us at K = 1536; N <= 64: 128 x 64 / 128 x 32 as the unary layers)
   int TR, BN, cfg;
   const int64_t rt64 = se3_cdiv(rows, 64);
   if (N > 128) {
     if (rt64 * se3_cdiv(N, 256) >= 512) { TR = 64; BN = 256; cfg = 0; }
-    else if (rt64 * se3_cdiv(N, 128) >= 320 || N % 128 > 64 || N % 128 == 0) { TR = 64; BN = 128; cfg = 1; }
+    else if (rt64 * se3_cdiv(N, 128) >= 320 || N % 128 > 64) { TR = 64; BN = 128; cfg = 1; }
     else { TR = 64; BN = 64; cfg = 2; }
   } else if (N > 64) { TR = rt64 >= 512 ? 128 : 64; BN = 128; cfg = rt64 >= 512 ? 3 : 1; }
   else if (N > 32) { TR = rt64 >= 512 ? 128 : 64; BN = 64; cfg = rt64 >= 512 ? 4 : 2; }
