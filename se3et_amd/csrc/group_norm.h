@@ -212,9 +212,12 @@ static bool gn_fast_path(int channels) { return channels >= 16 && channels <= 10
 // the last workgroup to arrive, a chain of memory round trips behind the whole pass: with 1 024 chunks over the 8 segments of a batch the
 // statistics passes of a step took 0.59 ms, with 512 0.45, with 256 0.43 (tools/micro/gn_stats_rate.py; a one-pair tensor: 11 us with
 // 1 024 chunks, 6 with 256).
-constexpr int kGNStatChunks = 256;
+// The merge works per SEGMENT, so a tensor of one segment takes at most 128 (a one-pair tensor of 30 000 rows: 18.3 us with 256 chunks, 14.0
+// with 128; 128 chunks in all for the 8-segment batch are too few workgroups for the stream: 0.54 ms).
+constexpr int kGNStatChunks = 256, kGNSegmentChunks = 128;
 static int gn_chunk_cap(int num_segments) {
   int cap = kGNStatChunks / num_segments;
+  if (cap > kGNSegmentChunks) cap = kGNSegmentChunks;
   return cap > 8 ? cap : 8;
 }
 
