@@ -37,10 +37,10 @@ sys.path.insert(0, ROOT)
 # profiles/r04_pmc_attention_raw.txt (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of tools/pmc_attention.py on the stack-mode
 # kernels at the bench shape, 16 clouds per launch; gfx950 correction: FETCH_SIZE x2 for the 16-B/lane streaming reads of
 # rpe_bias_kernel and attn_split_kv_kernel, attention kernel counters raw).  Counters cannot be read inside this process, so the ratio of that run is applied:
-#   eq  call: (2*1313074.0 + 2*36940.4 + 238020.0 + 202416.0 + 70646.5 + 35143.7) KiB = 3324.2 MB  vs 2549.0 MB algorithmic
-#   inv call: (2*1091025.3 + 2*5932.5  +  38268.6 +  33736.0 + 11774.0 +  5856.0) KiB = 2338.4 MB  vs 2222.9 MB algorithmic
+#   eq  call: (2*1314761.7 + 2*36936.7 + 238017.8 + 202416.0 + 70646.0 + 35142.6) KiB = 3327.6 MB  vs 2549.0 MB algorithmic
+#   inv call: (2*1091026.8 + 2*5932.5  +  38268.5 +  33736.0 + 11774.0 +  5856.0) KiB = 2338.4 MB  vs 2222.9 MB algorithmic
 # (logits kernel, K / V^T split, attention kernel: FETCH + WRITE; x2 on the two streaming readers)
-PMC_TRAFFIC_RATIO = {'eq': 3324.2 / 2549.0, 'inv': 2338.4 / 2222.9}
+PMC_TRAFFIC_RATIO = {'eq': 3327.6 / 2549.0, 'inv': 2338.4 / 2222.9}
 PMC_TRAFFIC_FILE = 'profiles/r04_pmc_attention_raw.txt'
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s is achievable
 
