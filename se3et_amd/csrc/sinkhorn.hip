@@ -37,7 +37,6 @@ __global__ __launch_bounds__(kThreads) void sinkhorn_kernel(const float* __restr
                                                             const float* __restrict__ alpha_p, int R, int C, int iters,
                                                             float inf, float* __restrict__ out) {
   __shared__ float u[160], v[160], log_mu[160], log_nu[160];
-  __shared__ float s_cnt[2];
   const int b = blockIdx.x;
   const int R1 = R + 1, C1 = C + 1;
   const int tid = threadIdx.x;
@@ -47,15 +46,9 @@ __global__ __launch_bounds__(kThreads) void sinkhorn_kernel(const float* __restr
   const uint8_t* rm = row_masks + (size_t)b * R;
   const uint8_t* cm = col_masks + (size_t)b * C;
 
-  if (tid == 0) {
-    float nr = 0.f, nc = 0.f;
-    for (int i = 0; i < R; i++) nr += rm[i] ? 1.f : 0.f;
-    for (int j = 0; j < C; j++) nc += cm[j] ? 1.f : 0.f;
-    s_cnt[0] = nr;
-    s_cnt[1] = nc;
-  }
-  __syncthreads();
-  const float nvr = s_cnt[0], nvc = s_cnt[1];
+  // valid rows / columns, counted by all threads (one thread walking the mask bytes was a chain of global loads in front of everything: 4 %)
+  const float nvr = (float)__syncthreads_count(tid < R && rm[tid < R ? tid : 0] != 0);
+  const float nvc = (float)__syncthreads_count(tid < C && cm[tid < C ? tid : 0] != 0);
   const float norm = -logf(nvr + nvc);
   for (int i = tid; i < R1; i += kThreads) {
     const bool masked = i < R && !rm[i];
@@ -145,7 +138,7 @@ __global__ __launch_bounds__(kThreads) void sinkhorn_bwd_kernel(const float* __r
                                                                 float* __restrict__ grad_scores, float* __restrict__ grad_alpha_partial) {
   extern __shared__ float hist[];                        // u_t: [iters][R1], then v_t: [iters][C1]
   __shared__ float u[160], v[160], log_mu[160], log_nu[160], du[160], dv[160];
-  __shared__ float s_cnt[2], s_alpha[kThreads / 64];
+  __shared__ float s_alpha[kThreads / 64];
   const int b = blockIdx.x;
   const int R1 = R + 1, C1 = C + 1;
   float* uh = hist;
@@ -157,15 +150,9 @@ __global__ __launch_bounds__(kThreads) void sinkhorn_bwd_kernel(const float* __r
   const float* GO = grad_out + (size_t)b * R1 * C1;
   const uint8_t* rm = row_masks + (size_t)b * R;
   const uint8_t* cm = col_masks + (size_t)b * C;
-  if (tid == 0) {
-    float nr = 0.f, nc = 0.f;
-    for (int i = 0; i < R; i++) nr += rm[i] ? 1.f : 0.f;
-    for (int j = 0; j < C; j++) nc += cm[j] ? 1.f : 0.f;
-    s_cnt[0] = nr;
-    s_cnt[1] = nc;
-  }
-  __syncthreads();
-  const float nvr = s_cnt[0], nvc = s_cnt[1];
+  // valid rows / columns, counted by all threads (one thread walking the mask bytes was a chain of global loads in front of everything: 4 %)
+  const float nvr = (float)__syncthreads_count(tid < R && rm[tid < R ? tid : 0] != 0);
+  const float nvc = (float)__syncthreads_count(tid < C && cm[tid < C ? tid : 0] != 0);
   const float norm = -logf(nvr + nvc);
   for (int i = tid; i < R1; i += kThreads) {
     const bool masked = i < R && !rm[i];

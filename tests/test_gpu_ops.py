@@ -45,6 +45,27 @@ def test_sinkhorn_matches_oracle(B, R, C, frac):
     assert torch.isfinite(got).all()
 
 
+@pytest.mark.parametrize('scale', [8.0, 14.0, 30.0])
+def test_sinkhorn_wide_score_ranges_match_oracle(scale):
+    """Score ranges around and beyond the bound of the scaling form (csrc/sinkhorn.hip: valid scores within 40 of their row's maximum): patches
+    on either side of it -- the workgroup-uniform choice between the scaling form and the log-domain loop -- against the oracle."""
+    from oracle import se3et_oracle as O
+    from se3et_amd import functional as SF
+    g = torch.Generator().manual_seed(int(scale))
+    B, R, C = 48, 64, 64
+    scores = torch.randn(B, R, C, generator=g) * scale
+    scores[::2] *= 0.25                                   # every other patch stays narrow
+    rm, cm = torch.rand(B, R, generator=g) < 0.8, torch.rand(B, C, generator=g) < 0.8
+    rm[:, 0], cm[:, 0] = True, True
+    alpha = torch.tensor(0.7)
+    want = O.log_optimal_transport(scores, rm, cm, alpha, 100)
+    got = SF.log_optimal_transport(scores.cuda(), rm.cuda(), cm.cuda(), alpha.cuda(), 100, 1e12).cpu()
+    valid = want > -1e11
+    assert torch.equal(got > -1e11, valid)
+    assert torch.isfinite(got).all()
+    assert float((got[valid] - want[valid]).abs().max()) <= 1e-4 * float(want[valid].abs().max())
+
+
 def test_sinkhorn_matches_reference_fixture(golden_dir):
     from se3et_amd import functional as SF
     g = _golden(golden_dir)
