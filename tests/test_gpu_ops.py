@@ -1343,3 +1343,48 @@ def test_dense_inputs_of_the_c2_forward_stay_in_the_split_range():
     worst_rms = min(s[3] for s in seen)
     assert worst_max < 65504.0 / 64, sorted(seen, key=lambda s: -s[2])[:3]
     assert worst_rms > 2.0 ** -7, sorted(seen, key=lambda s: s[3])[:3]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('nn,width', [(1, 6), (7, 24), (8, 96), (9, 100), (16, 192), (22, 192), (38, 768), (64, 3072)])
+def test_neighbor_max_pool_with_padded_and_absent_entries(nn, width):
+    """The pool compacts the real neighbours before it gathers (csrc/rowops.hip): rows whose entries are all padding (index n: the zero row ->
+    0), all absent (-1 beyond the pair's own table width -> -inf never wins against a padded 0, and a row of only absent columns does not
+    occur: column 0 is the point itself), mixtures, real counts on both sides of a multiple of 8, float4 and scalar widths -- against a
+    gather + amax."""
+    from se3et_amd import ops
+    g = torch.Generator().manual_seed(nn * 1000 + width)
+    n, m = 300, 257
+    x = torch.randn(n, width, generator=g)
+    idx = torch.randint(0, n, (m, nn), generator=g)
+    kind = torch.rand(m, nn, generator=g)
+    idx[kind < 0.25] = n                                    # padded entries
+    idx[kind > 0.85] = -1                                   # absent columns
+    idx[:, 0] = torch.randint(0, n, (m,), generator=g)      # column 0 is always a real neighbour ...
+    idx[0] = n                                              # ... except in the rows built here: all padding,
+    idx[1, 1:] = -1                                         # one real entry and absent columns,
+    if nn >= 8:
+        idx[2, :8] = torch.randint(0, n, (8,), generator=g); idx[2, 8:] = n     # exactly eight real entries
+    xp = torch.cat((x, torch.zeros(1, width)), 0)
+    want = xp[idx.clamp(min=0)].masked_fill((idx < 0)[:, :, None], float('-inf')).amax(1)
+    got = ops.neighbor_max_pool(x.cuda(), idx.cuda()).cpu()
+    assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows', [1, 63, 64, 65, 700, 10176, 10240, 10304])
+@pytest.mark.parametrize('K,N', [(32, 64), (256, 192), (256, 256), (512, 320), (64, 1552)])
+def test_linear_stream_tile_policies_agree_with_float64(rows, K, N):
+    """Row counts on both sides of the tile-policy thresholds of the plain dense layer (64 x 64 / 64 x 128 / 64 x 256 tiles by workgroup
+    count, csrc/dense_norm.hip: linear_stream), ragged last tiles, output widths that are not multiples of the tile: against float64."""
+    from se3et_amd import ops
+    torch.manual_seed(rows + K + N)
+    dev = torch.device('cuda')
+    x = torch.randn(rows, K, device=dev)
+    w = torch.randn(N, K, device=dev) / K ** 0.5
+    b = torch.randn(N, device=dev)
+    for relu in (False, True):
+        out = ops.linear_stream(x, w, b, relu=relu)
+        ref = x.double() @ w.double().t() + b.double()
+        ref = ref.clamp_min(0) if relu else ref
+        assert float((out.double() - ref).abs().max()) <= 3e-6 * max(1.0, float(ref.abs().max())), (rows, K, N, relu)
