@@ -398,6 +398,7 @@ def main():
                        'ranks_seen': ranks_seen, 'collectives': 'rccl' if torch.distributed.is_initialized() else 'none (one rank)',
                        'variant': args.variant, 'pair_preset': args.pair, 'sharding': 'pairs round-robin over ranks, no collective',
                        'pairs_per_forward': PB, 'batches_in_flight_per_gpu': max(1, args.inflight), 'pyramid_prefetch': bool(args.prefetch),
+                       'chained_sections': sorted(__import__('se3et_amd.batched', fromlist=['x']).CHAINED_SECTIONS),
                        'attention_dtype': args.attention_dtype},
             'roofline': roofline, 'roofline_kpconv': roofline_kpconv, 'cpu_baseline': cpu_baseline, 'single_pair': single_pair, 'train_step': train,
         }

@@ -24,6 +24,38 @@ def _offsets(lengths):
     return out
 
 
+import contextlib as _contextlib
+import os as _os
+import threading as _threading
+
+# Sections of the forward that the batches in flight (one host thread + HIP stream each) run ONE AFTER THE OTHER on the GPU: a section waits
+# for the event behind the launches of the same section of the batch before it -- kernels of the same kind (the HBM-bound logits kernels,
+# the register-full KPConv / dense kernels) then do not time-slice against each other, while different sections of different batches still
+# overlap.  SE3_CHAIN = comma list of section names ('transformer', 'backbone', 'tail'), '' = none.
+CHAINED_SECTIONS = set(filter(None, _os.environ.get('SE3_CHAIN', 'transformer').split(',')))
+_chains = {}
+_chains_guard = _threading.Lock()
+
+
+@_contextlib.contextmanager
+def _chained(section):
+    if section not in CHAINED_SECTIONS or not torch.cuda.is_available():
+        yield
+        return
+    with _chains_guard:
+        st = _chains.setdefault(section, [_threading.Lock(), None])
+    with st[0]:
+        cur = torch.cuda.current_stream()
+        if st[1] is not None:
+            cur.wait_event(st[1])
+        try:
+            yield
+        finally:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            st[1] = ev
+
+
 _pack_index_cache = {}     # (cloud order, cloud offsets, device) -> destination row of every stacked row (device tensor shared by the host threads)
 
 
@@ -145,7 +177,8 @@ def transformer_pairs(gt, points_c, lengths_c, feats_c, packed=False):
     if _cdriver.supported(gt) and not torch.is_grad_enabled():
         # every launch of the ten blocks and of out_proj from ONE library call (csrc/transformer_driver.hip): the same kernels with the same
         # operands as the schedule below, no interpreter between them
-        X = _cdriver.transformer_forward(gt, X.contiguous(), PA, R0, embs_o, eqs_o)
+        with _chained('transformer'):
+            X = _cdriver.transformer_forward(gt, X.contiguous(), PA, R0, embs_o, eqs_o)
         if packed:
             return X, PA
         outs = PA.unpack(X)
@@ -274,7 +307,7 @@ def forward_pairs(model, data_dict, with_registration=True):
     valid_event = torch.cuda.Event()
     valid_event.record()
 
-    with SF.norm_segments(seg):
+    with SF.norm_segments(seg), _chained('backbone'):
         feats_list = model.backbone(data_dict['features'], data_dict)
     feats_c, feats_f = feats_list[-1], feats_list[0]
 
