@@ -48,18 +48,53 @@ _TYPES = {'self': 0, 'self_eq': 1, 'cross': 2, 'cross_a_soft': 3, 'cross_r_soft'
 ENABLED = os.environ.get('SE3_CDRIVER', '1') != '0'            # False: the Python schedule of se3et_amd.batched (A/B runs, tests)
 
 
+def _schedule_ok(blocks, has_rotcompress):
+    """The scheduler state of se3_transformer_forward (csrc/transformer_driver.hip: X_is_eq / Xeq) run over a block list: False wherever the
+    driver would return SE3_ERR_UNSUPPORTED / SE3_ERR_INVALID_ARG -- a plain cross block on anchor features, anchor values without a
+    self_eq block in front, an equivariant cross block on invariant features, eq2inv without the rotcompress layer, a list that ends on
+    anchor features."""
+    x_is_eq, has_xeq = True, False
+    types = [_TYPES[b] for b in blocks]
+    for i, t in enumerate(types):
+        nxt = types[i + 1] if i + 1 < len(types) else -1
+        prev = types[i - 1] if i > 0 else -1
+        if t <= 1:
+            anchors = has_xeq or x_is_eq
+            if t == 1 and nxt == 2:
+                has_xeq, x_is_eq = True, False
+            else:
+                x_is_eq = anchors
+        elif t == 2:
+            if x_is_eq:
+                return False
+            if nxt == 1 or (nxt < 0 and prev == 1):
+                if not has_xeq:
+                    return False
+        else:
+            if not x_is_eq:
+                return False
+            if t == 4 and 0 <= nxt < 3 and nxt != 1:
+                if not has_rotcompress:
+                    return False
+                x_is_eq, has_xeq = False, False
+    return not x_is_eq
+
+
 def supported(gt):
-    """The block lists of the SE3ET experiments on the kernels' sizes: every block type known, 6 anchors, channels a multiple of 32, the
-    last block invariant."""
+    """The block lists of the SE3ET experiments on the kernels' sizes: every block type known, 6 anchors, channels a multiple of 32 and of
+    the head count, and a block order the driver's scheduler accepts (_schedule_ok mirrors its SE3_REQUIREs: anything it would refuse keeps
+    the Python schedule instead of surfacing as a RuntimeError)."""
     tr = gt.transformer
     C = gt.in_proj.out_features
     if not ENABLED or len(tr.blocks) > MAX_BLOCKS or any(b not in _TYPES for b in tr.blocks) or gt.na != 6 or C % 32:
+        return False
+    if C % tr.layers[0].attention.attention.num_heads:
         return False
     if tr.blocks[0] not in ('self_eq', 'cross_a_soft', 'cross_r_soft'):      # (the input is the (A, rows, C) in_proj of anchor features)
         return False
     if any(b in ('cross_a_soft', 'cross_r_soft') for b in tr.blocks) and C not in (128, 256):
         return False                      # (the Gram-matrix statistics kernel of the equivariant cross attention: 128 or 256 channels)
-    return True
+    return _schedule_ok(tr.blocks, hasattr(tr, 'rotcompress'))
 
 
 def _linear(weight, bias, stream, keep):
@@ -74,11 +109,12 @@ def _linear(weight, bias, stream, keep):
 
 
 def _static_plan(gt, stream):
-    """The weight part of the plan, rebuilt when any parameter's version changes (an optimizer step, load_state_dict): pointers into the
-    per-weight piece caches of se3et_amd.ops (which own the device memory)."""
+    """The weight part of the plan, rebuilt when any parameter's version changes (an optimizer step, load_state_dict) or when
+    ops.clear_weight_caches() / ops.validate_weight_caches() dropped cached pieces (ops.CACHE_EPOCH: writes behind the version counter):
+    pointers into the per-weight piece caches of se3et_amd.ops (which own the device memory)."""
     tr = gt.transformer
     params = list(gt.parameters())
-    key = (tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+    key = (_ops.CACHE_EPOCH[0], tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
     plans = gt.__dict__.setdefault('_cdriver_plans', {})            # one per launch stream (the pieces' cross-stream waits happen at build time)
     hit = plans.get(stream.value)
     if hit is not None and hit[0] == key:

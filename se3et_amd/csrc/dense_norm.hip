@@ -161,9 +161,18 @@ __global__ __launch_bounds__(256, MODE == 3 ? 2 : 3) void dense_norm_kernel(cons
       sc1 = *reinterpret_cast<const f32x4*>(aff + 2 * K + k);
       sh1 = *reinterpret_cast<const f32x4*>(aff + 3 * K + k);
     }
+    // (plain modes with x_rs < K: a row is read past its end into the next one against zero weight columns -- those values are dropped
+    // here, not multiplied: an Inf / NaN / > 65504 in the neighbouring row would turn 0 * x into NaN.  Uniform condition.)
+    const bool tail_mask = kPlain && XS < K && a.seg_steps == 0 && k + 4 > XS;
 #pragma unroll
     for (int j = 0; j < U; j++) {
       f32x4 t = v[j];
+      if constexpr (kPlain) {
+        if (tail_mask) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) t[e] = k + e < XS ? t[e] : 0.f;
+        }
+      }
       if (st_here > 0) {
         t = t * sc0 + sh0;
 #pragma unroll
@@ -682,8 +691,8 @@ void plain_launch(const DenseArgs& a, bool transposed, dim3 grid, hipStream_t st
   if (transposed) dense_norm_kernel<WM, WN, RT, CT, 5><<<grid, 256, 0, st>>>(a);
   else dense_norm_kernel<WM, WN, RT, CT, 4><<<grid, 256, 0, st>>>(a);
 }
-int linear_stream(const float* x, int64_t rows, int K, int64_t x_rs, const void* weight_pieces, const float* bias, int N, int relu, float* out,
-                  int64_t out_rs, int t_rows, int64_t t_ld, void* stream, int seg_channels = 0, int64_t seg_stride = 0) {
+int linear_stream_one(const float* x, int64_t rows, int K, int64_t x_rs, const void* weight_pieces, const float* bias, int N, int relu, float* out,
+                      int64_t out_rs, int t_rows, int64_t t_ld, void* stream, int seg_channels = 0, int64_t seg_stride = 0) {
   SE3_REQUIRE(x && weight_pieces && out, SE3_ERR_INVALID_ARG, "linear_stream: null pointer");
   SE3_REQUIRE(K > 0 && K % 32 == 0 && N > 0, SE3_ERR_UNSUPPORTED, "linear_stream: in_features %d must be a multiple of 32", K);
   // (x_rs < K is allowed: every row is then read past its end into the next one -- for weights whose columns beyond x_rs are zero; the
@@ -747,6 +756,36 @@ int linear_stream(const float* x, int64_t rows, int K, int64_t x_rs, const void*
     default: plain_launch<4, 1, 1, 1>(a, transposed, grid, st); break;
   }
   SE3_CHECK_LAUNCH("linear_stream");
+  return SE3_OK;
+}
+
+// The kernel addresses its operands with 32-bit byte offsets from one base (buffer addressing: < 2 GB per operand).  Larger activations
+// (more or larger clouds per forward: ADVICE round 4) are multiplied in row ranges of whole 256-row units (whole transposed blocks) that fit.
+int linear_stream(const float* x, int64_t rows, int K, int64_t x_rs, const void* weight_pieces, const float* bias, int N, int relu, float* out,
+                  int64_t out_rs, int t_rows, int64_t t_ld, void* stream, int seg_channels = 0, int64_t seg_stride = 0) {
+  const int64_t lim = (1ll << 29) - 1;
+  const bool transposed = t_rows > 0;
+  const bool fits = rows >= 0 && x_rs > 0 && rows * x_rs <= lim &&
+                    (transposed ? (rows / t_rows) * (int64_t)N * t_ld <= lim : rows * (out_rs > N ? out_rs : (int64_t)N) <= lim);
+  if (fits || seg_channels > 0 || !x || !out || N <= 0) return linear_stream_one(x, rows, K, x_rs, weight_pieces, bias, N, relu, out, out_rs, t_rows, t_ld, stream, seg_channels, seg_stride);
+  int64_t step;
+  if (transposed) {
+    SE3_REQUIRE(rows % t_rows == 0 && t_ld >= t_rows, SE3_ERR_INVALID_ARG, "linear_stream: transposed output blocks of %d rows", t_rows);
+    const int64_t per_block = std::max((int64_t)t_rows * x_rs, (int64_t)N * t_ld);
+    SE3_REQUIRE(per_block <= lim, SE3_ERR_UNSUPPORTED, "linear_stream: one transposed block of %d rows exceeds 2 GB", t_rows);
+    step = lim / per_block * t_rows;
+  } else {
+    SE3_REQUIRE(out_rs >= N, SE3_ERR_INVALID_ARG, "linear_stream: out row stride %lld", (long long)out_rs);
+    step = lim / std::max(x_rs, out_rs) / 256 * 256;
+    SE3_REQUIRE(step > 0, SE3_ERR_UNSUPPORTED, "linear_stream: row strides %lld / %lld too large", (long long)x_rs, (long long)out_rs);
+  }
+  for (int64_t r0 = 0; r0 < rows; r0 += step) {
+    const int64_t n = std::min(step, rows - r0);
+    float* o = transposed ? out + (r0 / t_rows) * (int64_t)N * t_ld : out + r0 * out_rs;
+    // (x_rs < K: the last row of a range reads zeros past the buffer bound where the single launch read the next row -- against zero weight columns)
+    const int rc = linear_stream_one(x + r0 * x_rs, n, K, x_rs, weight_pieces, bias, N, relu, o, out_rs, t_rows, t_ld, stream);
+    if (rc != SE3_OK) return rc;
+  }
   return SE3_OK;
 }
 }  // namespace

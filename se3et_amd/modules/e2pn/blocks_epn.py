@@ -169,10 +169,10 @@ class ResnetBottleneckBlockEPN(nn.Module):
     def _recompute_pays(self, rows):
         """The recomputed tail runs the GEMMs of unary2 (and skip_conv) twice and saves two passes over the block's output: a gain while the
         products are short (measured at the bench shapes, tools/micro/block_tail.py -> profiles/r04_block_tail.txt: mid + shortcut input
-        width <= 192, or a 128 -> 512 layer with an identity shortcut over >= 100 000 rows), a loss on the wide coarse layers, where the
-        second GEMM costs more than the two passes."""
+        width <= 192 -- except the 128 -> 512 layers with an identity shortcut, which gain only over >= 100 000 rows: 0.272 -> 0.227 ms at
+        128 466 rows, 0.072 -> 0.074 ms at 33 036), a loss on the wide coarse layers, where the second GEMM costs more than the two passes."""
         k = self.unary2.in_dim + (0 if isinstance(self.skip_conv, nn.Identity) else self.skip_conv.in_dim)
-        return k <= 192 or (k == 128 and rows >= 100000)
+        return k <= 192 and (k != 128 or rows >= 100000)
 
     def _forward_pending(self, x, q_pts, s_pts, neighb_inds):
         """Inference (blocks_epn.py:798-852 with the norms in pending form): every dense layer takes the statistics of the norm behind it

@@ -871,7 +871,11 @@ def _kpconv_weight_pieces(weights, Cin, Cout, stream):
     return Wp
 
 
+CACHE_EPOCH = [0]          # bumped whenever cached weight pieces are dropped: part of the key of plans that hold raw pointers into them (cdriver)
+
+
 def clear_weight_caches():
+    CACHE_EPOCH[0] += 1
     _padded_weight_cache.clear()
     _weight_piece_cache.clear()
     _linear_piece_cache.clear()
@@ -884,7 +888,7 @@ def validate_weight_caches():
     torch's version counter (`p.data.copy_()`, EMA swaps through `.data`, hand-written checkpoint loaders).  Returns the number of entries
     dropped."""
     entries = []
-    for cache in (_weight_piece_cache, _linear_piece_cache, _stacked_weight_cache):
+    for cache in (_weight_piece_cache, _linear_piece_cache, _stacked_weight_cache, _padded_weight_cache):
         for key, hit in list(cache.items()):
             w = hit[0]()
             if w is not None and cache is _linear_piece_cache and w.data_ptr() != key[0]:
@@ -904,6 +908,8 @@ def validate_weight_caches():
             if not ok:
                 cache.pop(key, None)
                 dropped += 1
+    if dropped:
+        CACHE_EPOCH[0] += 1          # plans holding pointers to the dropped pieces (cdriver._static_plan) are rebuilt
     return dropped
 
 
@@ -1050,7 +1056,7 @@ def _padded_transposed_weight(weights, Kg, Kp, Cout):
     with _TIMING_LOCK:
         if len(_padded_weight_cache) > 64:
             _padded_weight_cache.clear()
-        _padded_weight_cache[key] = (weakref.ref(weights), weights._version, _Shared(Wt))
+        _padded_weight_cache[key] = (weakref.ref(weights), weights._version, _Shared(Wt), _fingerprint(weights))
     return Wt
 
 

@@ -56,3 +56,18 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
     with pytest.raises(RuntimeError, match='no CPU / eager fallback'):
         _lib.lib()
+
+
+def test_cdriver_supported_mirrors_the_drivers_scheduler():
+    """cdriver.supported() must refuse every block list se3_transformer_forward would refuse (csrc/transformer_driver.hip:
+    SE3_REQUIREs on the X_is_eq / Xeq state), so that such models keep the Python schedule instead of raising."""
+    from se3et_amd.cdriver import _schedule_ok
+    e = ['self_eq', 'cross_a_soft', 'self_eq', 'cross_r_soft', 'self', 'cross', 'self', 'cross', 'self', 'cross']
+    i = ['self_eq', 'cross', 'self_eq', 'cross', 'self_eq', 'cross']
+    assert _schedule_ok(e, True) and _schedule_ok(i, True)
+    assert not _schedule_ok(e, False)                                   # eq2inv without the rotcompress layer
+    assert not _schedule_ok(['self_eq', 'cross_a_soft'], True)          # ends on anchor features
+    assert not _schedule_ok(['self_eq', 'cross_r_soft'], True)
+    assert not _schedule_ok(['self_eq', 'self', 'cross'], True)         # plain cross attention on anchor features
+    assert not _schedule_ok(['self_eq', 'cross', 'cross_a_soft'], True)  # equivariant cross attention on invariant features
+    assert _schedule_ok(['self_eq', 'cross_r_soft', 'self', 'cross'], True)

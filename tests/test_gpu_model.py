@@ -243,3 +243,48 @@ def test_transformer_issued_from_c_equals_the_python_schedule(variant, preset, n
         for key in ('ref_feats_c', 'src_feats_c', 'ref_node_corr_indices', 'src_node_corr_indices', 'matching_scores', 'estimated_transform'):
             assert torch.equal(got[p][key], want[p][key]), (p, key, float((got[p][key].double() - want[p][key].double()).abs().max()))
             assert torch.equal(got2[p][key], want[p][key]), (p, key)
+
+
+def test_c_issued_transformer_sees_weights_written_behind_the_version_counter():
+    """cdriver's plan holds raw pointers to the f16 weight pieces.  After `p.data.copy_()` (no version bump) and the documented
+    `ops.validate_weight_caches()` (or `clear_weight_caches()`), the C-issued transformer must multiply with the NEW weights: its outputs must
+    equal the Python schedule's on the same weights, and differ from the outputs before the write."""
+    from se3et_amd import cdriver, ops
+    from se3et_amd.batched import forward_pairs
+    from se3et_amd.data import precompute_data_stack_mode
+    from se3et_amd.model import create_model, load_synthetic_weights, make_cfg
+    from se3et_amd.synthetic import make_pair
+    cfg = make_cfg('se3ete')
+    model = load_synthetic_weights(create_model(cfg)).cuda().eval()
+    b = cfg.backbone
+    ref, src, _ = make_pair('c2_5k', index=0)
+    pts = torch.from_numpy(np.concatenate([ref, src], 0)).cuda()
+
+    def run():
+        dd = precompute_data_stack_mode(pts, torch.tensor([len(ref), len(src)]), b.num_stages, b.init_voxel_size, b.init_radius, cfg.neighbor_limits)
+        dd['features'] = torch.ones((pts.shape[0], 1), device='cuda')
+        return forward_pairs(model, dd)[0]
+
+    saved = cdriver.ENABLED
+    try:
+        cdriver.ENABLED = True
+        before = run()
+        for how in ('validate', 'clear'):
+            lin = model.transformer.transformer.layers[4].output.expand           # an FFN layer issued from inside the C driver
+            with torch.no_grad():
+                lin.weight.data.copy_(lin.weight.data * 1.5)                      # behind the version counter
+                model.transformer.out_proj.weight.data.copy_(model.transformer.out_proj.weight.data * 0.5)
+            if how == 'validate':
+                assert ops.validate_weight_caches() >= 2
+            else:
+                ops.clear_weight_caches()
+            got = run()
+            cdriver.ENABLED = False
+            want = run()
+            cdriver.ENABLED = True
+            assert not torch.equal(got['ref_feats_c'], before['ref_feats_c'])
+            for key in ('ref_feats_c', 'src_feats_c', 'matching_scores', 'estimated_transform'):
+                assert torch.equal(got[key], want[key]), (how, key)
+            before = got
+    finally:
+        cdriver.ENABLED = saved
