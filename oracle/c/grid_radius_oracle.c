@@ -98,9 +98,11 @@ static int64_t single_grid_subsample(const float *pts, const float *nrm, int64_t
 
   uint64_t *pkey = (uint64_t *)malloc(sizeof(uint64_t) * n);
   for (int64_t i = 0; i < n; i++) {
-    uint64_t ix = (uint64_t)floorf((pts[3 * i + 0] - org[0]) / voxel);
-    uint64_t iy = (uint64_t)floorf((pts[3 * i + 1] - org[1]) / voxel);
-    uint64_t iz = (uint64_t)floorf((pts[3 * i + 2] - org[2]) / voxel);
+    /* (size_t)floor(..) of the reference on x86-64 goes through the signed conversion: the -1 that float rounding can give the cloud's own
+     * minimum (data/demo/src.npy) wraps to 2^64 - 1; written out so that it does not rest on the compiler's choice for a negative input */
+    uint64_t ix = (uint64_t)(int64_t)floorf((pts[3 * i + 0] - org[0]) / voxel);
+    uint64_t iy = (uint64_t)(int64_t)floorf((pts[3 * i + 1] - org[1]) / voxel);
+    uint64_t iz = (uint64_t)(int64_t)floorf((pts[3 * i + 2] - org[2]) / voxel);
     pkey[i] = ix + nx * iy + nx * ny * iz;
   }
   /* distinct voxels in first-seen order, via an open-addressing table */

@@ -36,6 +36,30 @@ static inline int64_t se3_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 __device__ __forceinline__ float se3_exact_div(float a, float b) { return (float)((double)a / (double)b); }
 __device__ __forceinline__ float se3_exact_sqrt(float a) { return (float)sqrt((double)a); }
 
+// Squared distance of two 3-D points as geotransformer/modules/ops/pairwise_distance.py:4-30 evaluates it in float32 -- x2 - 2 xy + y2 with
+// x2 = (x^2 + y^2) + z^2 (torch.sum over the last dim, unfused), xy the K = 3 matmul = fma(z, z', fma(y, y', x x')) (k ascending, fused:
+// bit-identical to torch.matmul on the build container's CPU for all 168 100 pairs of the demo pair's superpoints), (x2 - 2 xy) + y2,
+// clamped at 0.  The expression cancels: at coordinates of ~3 m its rounding noise is ~2e-6 in d^2, i.e. a SELF distance of up to
+// 1.4 mm instead of 0 and +-5e-3 on the distance index of the geometric embedding (d / sigma_d, sigma_d = 0.2) -- the reference's
+// embedding of near-coincident superpoints is a function of this noise, so it is restated operation by operation, not approximated (found on data/demo: 2.6e-2 on the first transformer layer with the products fused differently).
+// (hipcc's __fmul_rn / __fadd_rn are plain operators -- the contraction pass fuses them like any a * b + c --, so the unfused steps
+// are fenced with the scoped pragma, which tags the instructions themselves and survives inlining.)
+__device__ __forceinline__ float se3_ref_sq_norm(float x, float y, float z) {
+#pragma clang fp contract(off)
+  const float xx = x * x, yy = y * y, zz = z * z;
+  const float s = xx + yy;
+  return s + zz;
+}
+__device__ __forceinline__ float se3_ref_sq_dist(float px, float py, float pz, float p2, float qx, float qy, float qz, float q2) {
+#pragma clang fp contract(off)
+  const float xx = px * qx;
+  const float dot = __builtin_fmaf(pz, qz, __builtin_fmaf(py, qy, xx));
+  const float two = 2.f * dot;
+  const float a = p2 - two;
+  const float b = a + q2;
+  return fmaxf(b, 0.f);
+}
+
 __device__ __forceinline__ int se3_lane() { return threadIdx.x & (SE3_WAVE - 1); }
 
 __device__ __forceinline__ float se3_wave_sum(float v) {

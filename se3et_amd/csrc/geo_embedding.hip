@@ -73,13 +73,13 @@ __global__ void geo_embedding_kernel(const float* __restrict__ pts, const int64_
     const int64_t j = knn[3 * n + k];
     rx[k] = pts[3 * j] - px; ry[k] = pts[3 * j + 1] - py; rz[k] = pts[3 * j + 2] - pz;
   }
-  const float nn2 = px * px + py * py + pz * pz;
+  const float nn2 = se3_ref_sq_norm(px, py, pz);
   for (int m0 = m_begin; m0 < m_end; m0 += kMB) {
     __syncthreads();
     if (threadIdx.x < kMB) {
       const int m = min(m0 + (int)threadIdx.x, N - 1);
       const float qx = pts[3 * m], qy = pts[3 * m + 1], qz = pts[3 * m + 2];
-      const float d2 = fmaxf(nn2 - 2.f * (px * qx + py * qy + pz * qz) + (qx * qx + qy * qy + qz * qz), 0.f);
+      const float d2 = se3_ref_sq_dist(px, py, pz, nn2, qx, qy, qz, se3_ref_sq_norm(qx, qy, qz));
       float x[4];
       x[0] = sqrtf(d2) * P.sigma_d_inv;
       const float vx = qx - px, vy = qy - py, vz = qz - pz;
@@ -305,14 +305,14 @@ __global__ void geo_embedding_bwd_operands_kernel(const float* __restrict__ pts,
     const int64_t j = knn[3 * n + k];
     rx[k] = pts[3 * j] - px; ry[k] = pts[3 * j + 1] - py; rz[k] = pts[3 * j + 2] - pz;
   }
-  const float nn2 = px * px + py * py + pz * pz;
+  const float nn2 = se3_ref_sq_norm(px, py, pz);
   const size_t plane = (size_t)N * N * C;
   for (int m0 = m_begin; m0 < m_end; m0 += kMB) {
     __syncthreads();
     if (threadIdx.x < kMB) {
       const int m = min(m0 + (int)threadIdx.x, N - 1);
       const float qx = pts[3 * m], qy = pts[3 * m + 1], qz = pts[3 * m + 2];
-      const float d2 = fmaxf(nn2 - 2.f * (px * qx + py * qy + pz * qz) + (qx * qx + qy * qy + qz * qz), 0.f);
+      const float d2 = se3_ref_sq_dist(px, py, pz, nn2, qx, qy, qz, se3_ref_sq_norm(qx, qy, qz));
       float x[4];
       x[0] = sqrtf(d2) * P.sigma_d_inv;
       const float vx = qx - px, vy = qy - py, vz = qz - pz;

@@ -34,8 +34,8 @@ __global__ __launch_bounds__(256) void geo_pair_terms_kernel(const float* __rest
   int j[4];
   float4 w[4];
   {
-    const float nn2 = px * px + py * py + pz * pz;
-    const float d2 = fmaxf(nn2 - 2.f * (px * qx + py * qy + pz * qz) + (qx * qx + qy * qy + qz * qz), 0.f);
+    const float nn2 = se3_ref_sq_norm(px, py, pz);
+    const float d2 = se3_ref_sq_dist(px, py, pz, nn2, qx, qy, qz, se3_ref_sq_norm(qx, qy, qz));
     pair_term_record(sqrtf(d2) * P.sigma_d_inv, P.d_inv_h, P.d_entries, j[0], w[0]);
   }
 #pragma unroll

@@ -28,7 +28,16 @@
 namespace {
 
 constexpr int kBlock = 1024;
-constexpr unsigned long long kEmptyKey = ~0ull;
+// Empty-slot marker of the voxel hash table.  Voxel keys are ix + nx iy + nx ny iz evaluated in size_t arithmetic with every index in
+// [-1, n] (see voxel_index: an index of -1 wraps, as in the reference), i.e. within nx ny (nz + 2) of 0 (mod 2^64): 2^63 is never a key
+// (all-ones IS one: ix = -1, iy = iz = 0).
+constexpr unsigned long long kEmptyKey = 0x8000000000000000ull;
+
+// (size_t)floor(x) as the reference's x86-64 build evaluates it (grid_subsampling_cpu.cpp:47-49): through the SIGNED conversion, so the
+// -1 that float rounding can produce for the cloud's own minimum (origin = floor(min * float(1 / v)) * v can land one ulp ABOVE min:
+// data/demo/src.npy holds such a point) becomes 2^64 - 1 and the key wraps.  The GPU's float -> unsigned conversion saturates at 0 instead,
+// which put that point's voxel into another bucket of the order emulation.
+__device__ inline unsigned long long voxel_index(float q) { return (unsigned long long)(long long)floorf(q); }
 __constant__ unsigned long long kBucketSeq[24] = {13ull, 29ull, 59ull, 127ull, 257ull, 541ull, 1109ull, 2357ull, 5087ull,
     10273ull, 20753ull, 42043ull, 85229ull, 172933ull, 351061ull, 712697ull, 1447153ull, 2938679ull, 5967347ull,
     12117689ull, 24607243ull, 49969847ull, 101473717ull, 0ull};
@@ -173,9 +182,9 @@ __global__ void hash_kernel(const float* __restrict__ pts, const BatchInfo* __re
   if (i >= bi.count[b]) return;
   const CloudMeta m = L.meta[b];
   const float* p = pts + 3 * (bi.start[b] + i);
-  const unsigned long long ix = (unsigned long long)floorf(se3_exact_div(__fsub_rn(p[0], m.org[0]), m.voxel));
-  const unsigned long long iy = (unsigned long long)floorf(se3_exact_div(__fsub_rn(p[1], m.org[1]), m.voxel));
-  const unsigned long long iz = (unsigned long long)floorf(se3_exact_div(__fsub_rn(p[2], m.org[2]), m.voxel));
+  const unsigned long long ix = voxel_index(se3_exact_div(__fsub_rn(p[0], m.org[0]), m.voxel));
+  const unsigned long long iy = voxel_index(se3_exact_div(__fsub_rn(p[1], m.org[1]), m.voxel));
+  const unsigned long long iz = voxel_index(se3_exact_div(__fsub_rn(p[2], m.org[2]), m.voxel));
   const unsigned long long key = ix + m.nx * iy + m.nx * m.ny * iz;
   const unsigned long long mask = (unsigned long long)bi.cap[b] - 1ull;
   unsigned long long h = (key * 0x9E3779B97F4A7C15ull) >> 20 & mask;

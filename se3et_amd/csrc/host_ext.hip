@@ -35,8 +35,10 @@ int64_t grid_subsample_one(const float* pts, const float* nrm, int64_t n, float 
   std::vector<Cell> cells;
   std::vector<int64_t> cell_of((size_t)n);
   for (int64_t i = 0; i < n; i++) {
-    const size_t ix = (size_t)floorf((pts[3 * i] - org[0]) / voxel), iy = (size_t)floorf((pts[3 * i + 1] - org[1]) / voxel),
-                 iz = (size_t)floorf((pts[3 * i + 2] - org[2]) / voxel);
+    // (through the signed conversion, explicitly: an index of -1 -- float rounding at the cloud's own minimum -- wraps as in the reference's
+    // x86-64 build, grid_subsampling_cpu.cpp:47-49)
+    const size_t ix = (size_t)(int64_t)floorf((pts[3 * i] - org[0]) / voxel), iy = (size_t)(int64_t)floorf((pts[3 * i + 1] - org[1]) / voxel),
+                 iz = (size_t)(int64_t)floorf((pts[3 * i + 2] - org[2]) / voxel);
     const size_t key = ix + nx * iy + nx * ny * iz;
     auto it = slot_of.find(key);
     if (it == slot_of.end()) {

@@ -12,10 +12,9 @@
 
 namespace {
 
-__device__ __forceinline__ float sq_norm(float x, float y, float z) { return (x * x + y * y) + z * z; }
+__device__ __forceinline__ float sq_norm(float x, float y, float z) { return se3_ref_sq_norm(x, y, z); }
 __device__ __forceinline__ float pair_dist(float qx, float qy, float qz, float q2, float sx, float sy, float sz, float s2) {
-  const float dot = fmaf(qz, sz, fmaf(qy, sy, qx * sx));
-  return fmaxf((q2 - 2.f * dot) + s2, 0.f);
+  return se3_ref_sq_dist(qx, qy, qz, q2, sx, sy, sz, s2);          // (common.h: the reference's float32 expression, operation by operation)
 }
 __device__ __forceinline__ unsigned long long make_key(float d, unsigned idx) {
   return ((unsigned long long)__float_as_uint(d) << 32) | idx;            // d >= 0: float bits order like the values

@@ -20,6 +20,8 @@ Fixtures
   c2_se3ete_5k.npz         BASELINE.json configs[1] at FULL size: SE3ET-E on the 5k+5k pairs 0..7 (the pairs of one bench step),
                            synthetic weights; per-layer outputs and index-table checksums for pair 0
   c3_se3eti_kitti_20k.npz  BASELINE.json configs[2] at FULL size: SE3ET-I (KITTI configuration) on the 20k+20k pair
+  demo_se3ete.npz          the reference's real pair data/demo/{ref,src,gt}.npy (demo.py:44-58) through the genuine collate and SE3ET-E
+  table_tiecanon.npz       tie-canonical checksums of the reference's tables for the clouds that hold exact distance ties (C3, cap pair)
 """
 import os
 import sys
@@ -32,6 +34,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
 from oracle import ref_shims  # noqa: E402
+sys.path.insert(0, os.path.dirname(HERE))
+from helpers import tie_canonical  # noqa: E402  (tests/helpers.py: shared with the tests that compare against these checksums)
 from se3et_amd.synthetic import make_pair, synth_tensor  # noqa: E402
 
 LEARNED_LEAVES = ('weight', 'bias', 'weights', 'alpha')
@@ -146,7 +150,7 @@ def run_model(variant, micro, synth_seed=None, pair='micro', index=0, light=Fals
             if k.rsplit('.', 1)[-1] in LEARNED_LEAVES and sd[k].dtype == torch.float32 and 'anchors' not in k:
                 sd[k] = torch.from_numpy(np.asarray(synth_tensor(k, sd[k].shape, synth_seed)))
         model.load_state_dict(sd)
-    ref, src, T = make_pair(pair, index=index)
+    ref, src, T = pair if isinstance(pair, tuple) else make_pair(pair, index=index)
     dd = collate(ref, src, T, cfg.backbone.num_stages, cfg.backbone.init_voxel_size, cfg.backbone.init_radius,
                  [38, 36, 36, 38, 38][:cfg.backbone.num_stages])
     ops = {}
@@ -279,6 +283,108 @@ def gen_fullsize(variant, fname, pair, num_pairs, row_step=8):
             res['points_last'] = _np(dd['points'][-1])
         print(fname, 'pair', index, 'done', flush=True)
     np.savez_compressed(os.path.join(HERE, fname), **res)
+
+
+def _table_geometry(dd):
+    """(key, i) -> (query points, support points) of the ten index tables of a collated pyramid (geotransformer/utils/data.py:46-93)."""
+    pts = [p.numpy() for p in dd['points']]
+    geo = {}
+    for i in range(len(pts)):
+        geo['neighbors', i] = (pts[i], pts[i])
+    for i in range(len(pts) - 1):
+        geo['subsampling', i] = (pts[i + 1], pts[i])
+        geo['upsampling', i] = (pts[i], pts[i + 1])
+    return geo
+
+
+def pack_table_checksums(dd, res, prefix=''):
+    geo = _table_geometry(dd)
+    for key in ('neighbors', 'subsampling', 'upsampling'):
+        res[prefix + 'checksum/' + key] = np.array([_index_checksum(t.numpy()) for t in dd[key]], dtype=np.uint64)
+        res[prefix + 'width/' + key] = np.array([t.shape[1] for t in dd[key]])
+        res[prefix + 'rowset/' + key] = np.array([_index_checksum(np.sort(t.numpy(), 1)) for t in dd[key]], dtype=np.uint64)
+        canon = [tie_canonical(*geo[key, i], t.numpy()) for i, t in enumerate(dd[key])]
+        res[prefix + 'tiecanon/' + key] = np.array([_index_checksum(c[0]) for c in canon], dtype=np.uint64)
+        res[prefix + 'tierows/' + key] = np.array([c[1] for c in canon])
+        res[prefix + 'tieentries/' + key] = np.array([c[2] for c in canon])
+    res[prefix + 'points_last'] = _np(dd['points'][-1])
+    res[prefix + 'lengths'] = np.stack([_np(l) for l in dd['lengths']])
+
+
+def gen_tiecanon():
+    """Tie-canonical checksums (tie_canonical) of the reference's tables for the clouds that DO hold exact float32 distance ties: the
+    KITTI-sized 20k+20k pair, the 30k+30k cap pair -- collate only, no model."""
+    ref_shims.install()
+    res = {}
+    for name, stages, voxel, radius, limits in (('c3_20k', 5, 0.3, 1.275, [38, 36, 36, 38, 38]), ('cap_30k', 4, 0.025, 0.0625, [38, 36, 36, 38]),
+                                                ('c2_5k', 4, 0.025, 0.0625, [38, 36, 36, 38])):
+        ref, src, T = make_pair(name)
+        dd = collate(ref, src, T, stages, voxel, radius, limits)
+        pack_table_checksums(dd, res, name + '/')
+        print(name, {k: res[name + '/tierows/' + k].tolist() for k in ('neighbors', 'subsampling', 'upsampling')}, flush=True)
+    np.savez_compressed(os.path.join(HERE, 'table_tiecanon.npz'), **res)
+
+
+def gen_demo(row_step=8):
+    """The reference's only real data: data/demo/{ref,src,gt}.npy (18 977 + 15 953 points, experiments/se3ete.3dmatch/demo.py:44-58, neighbour
+    limits [38, 36, 36, 38] at :53) through the genuine collate and SE3ET-E with the name-keyed synthetic weights (seed 7; the released
+    checkpoint is not in the repository).  Stored: the three input arrays, stage lengths, checksums of all ten tables (order-sensitive, row
+    sets, tie-canonical), the last stage's points, per-layer strided taps and the outputs, as gen_fullsize stores them for pair 0."""
+    demo = '/root/reference/data/demo/'
+    ref, src, T = (np.load(demo + f).astype(np.float32) for f in ('ref.npy', 'src.npy', 'gt.npy'))
+    cfg, model, _, dd, ops, feats, out = run_model('se3ete.3dmatch', micro=False, synth_seed=7, pair=(ref, src, T), light=True)
+    res = {'ref': ref, 'src': src, 'transform': T, 'synth_seed': np.int64(7), 'row_step': np.int64(row_step),
+           'blocks': np.array(cfg.geotransformer.blocks)}
+    pack_table_checksums(dd, res)
+    P = 'p0/'
+    res[P + 'lengths'] = res['lengths']
+    res[P + 'feats_c'] = _np(feats['c'])[::row_step, :, ::4]
+    res[P + 'feats_c_sum'] = np.float64(feats['c'].double().sum())
+    res[P + 'feats_c_abs'] = np.float64(feats['c'].double().abs().max())
+    res[P + 'feats_f'] = _np(feats['f'])[::4 * row_step]
+    res[P + 'feats_f_sum'] = np.float64(feats['f'].double().sum())
+    res[P + 'feats_f_abs'] = np.float64(feats['f'].double().abs().max())
+    for k in ('ref_feats_c', 'src_feats_c'):
+        res[P + k] = _np(out[k])
+        res[P + k + '_sum'] = np.float64(out[k].double().sum())
+    for k in ('ref_node_corr_indices', 'src_node_corr_indices', 'estimated_transform'):
+        res[P + k] = _np(out[k])
+    res[P + 'num_corr'] = np.int64(out['ref_corr_points'].shape[0])
+    res[P + 'corr_score_sum'] = np.float64(out['corr_scores'].double().sum())
+    ms = out['matching_scores']
+    res[P + 'matching_scores_head'] = _np(ms[:4])
+    res[P + 'matching_scores_rowsum'] = _np(ms[:, :-1, :-1].exp().sum((1, 2)))
+    for name, rec in ops.items():
+        t = torch.from_numpy(rec['out0'])
+        res['op/%s/out0' % name] = rec['out0'][..., ::row_step, :]
+        res['op/%s/sum' % name] = np.float64(t.double().sum())
+        res['op/%s/abs' % name] = np.float64(t.double().abs().max())
+    # Rows whose neighbour SET the reference's unstable sort decided (a group of exactly tied distances cut by the neighbour limit): against
+    # the tables with ties in ascending index order (oracle.precompute == the HIP path, bit for bit) -- the rows and the reference's
+    # content, so that a test can run the model on exactly the reference's neighbourhoods
+    from oracle import se3et_oracle as O
+    mine = O.precompute(torch.from_numpy(np.concatenate([ref, src], 0)), torch.tensor([len(ref), len(src)]), cfg.backbone.num_stages,
+                        cfg.backbone.init_voxel_size, cfg.backbone.init_radius, [38, 36, 36, 38])
+    for key in ('neighbors', 'subsampling', 'upsampling'):
+        for i, t in enumerate(dd[key]):
+            a, b = t.numpy(), mine[key][i].numpy()
+            differ = (np.sort(a, 1) != np.sort(b, 1)).any(1)
+            if key == 'upsampling':
+                differ |= a[:, 0] != b[:, 0]          # nearest_upsample reads column 0 (kpconv/functional.py:6-22): the ORDER of a tie matters there
+            rows = np.nonzero(differ)[0]
+            res['patch/%s_%d_rows' % (key, i)] = rows.astype(np.int32)
+            res['patch/%s_%d_vals' % (key, i)] = a[rows].astype(np.int32)
+            res['orderdiff/%s_%d' % (key, i)] = np.int64((a != b).any(1).sum())
+    # the 3 nearest superpoints of every superpoint as the reference's own expression selects them (geotransformer.py:69-90: top-(k+1) of
+    # the distance map, first column dropped) -- exact ties at the cut are torch.topk's choice (rows 179 / 344 of ref, 89 of src here)
+    from geotransformer.modules.ops import pairwise_distance as ref_pairwise_distance
+    n0 = int(dd['lengths'][-1][0])
+    for name, pc in (('ref', dd['points'][-1][:n0]), ('src', dd['points'][-1][n0:])):
+        dist = torch.sqrt(ref_pairwise_distance(pc.unsqueeze(0), pc.unsqueeze(0)))
+        res['patch/knn3_' + name] = dist.topk(k=4, dim=2, largest=False)[1][0, :, 1:].numpy().astype(np.int32)
+    print('demo pair: lengths', res['lengths'].tolist(), 'widths', res['width/neighbors'].tolist(), 'tie rows',
+          {k: res['tierows/' + k].tolist() for k in ('neighbors', 'subsampling', 'upsampling')}, 'corr', int(res[P + 'num_corr']), flush=True)
+    np.savez_compressed(os.path.join(HERE, 'demo_se3ete.npz'), **res)
 
 
 def gen_precompute_cap():
@@ -433,6 +539,10 @@ if __name__ == '__main__':
                               'optimal_transport.alpha'))
     if 'cap' in which:
         gen_precompute_cap()
+    if 'tiecanon' in which:
+        gen_tiecanon()
+    if 'demo' in which:
+        gen_demo()
     if 'fullsize' in which:
         gen_fullsize('se3ete.3dmatch', 'c2_se3ete_5k.npz', 'c2_5k', 8)
     if 'fullsize_kitti' in which or 'fullsize' in which:

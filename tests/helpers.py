@@ -72,3 +72,40 @@ def index_checksum(t):
     v = np.asarray(t).astype(np.uint64).reshape(-1)
     w = (np.arange(v.size, dtype=np.uint64) % np.uint64(65521)) + np.uint64(1)
     return int((v * w).sum() % np.uint64(2 ** 61 - 1))
+
+
+def table_sq_dists(q, s, t):
+    """float32 ((dx*dx + dy*dy) + dz*dz) of every entry of a neighbour table (padding index = len(s): +inf): the metric of
+    radius_neighbors_cpu.cpp / nanoflann and of the kernels."""
+    q, s, t = np.asarray(q, np.float32), np.asarray(s, np.float32), np.asarray(t).astype(np.int64)
+    sp = np.concatenate([s, np.full((1, 3), np.inf, np.float32)], 0)
+    d = q[:, None, :] - sp[t]
+    d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    d2[t == len(s)] = np.inf
+    return d2
+
+
+def tie_canonical(q, s, t):
+    """A neighbour table with the reference's one degree of freedom removed: entries of a row whose float32 squared distances are EQUAL are
+    put in ascending index order (the reference leaves them to an unstable std::sort), and the members of the tie group that ends a FULL row
+    (it may have been cut by the neighbour limit: which of its members survive is again the sort's choice) are replaced by the bit pattern
+    of their distance.  Two tables with the same canonical form differ only inside groups of exactly tied entries.
+    -> (canonical int64 table, number of rows holding a tie, number of tied entries)."""
+    t = np.asarray(t).astype(np.int64)
+    d2 = table_sq_dists(q, s, t)
+    if t.shape[1] > 1:
+        assert bool((d2[:, 1:] >= d2[:, :-1]).all()), 'a neighbour table must be sorted by distance'
+    o1 = np.argsort(t, axis=1, kind='stable')
+    t1, d1 = np.take_along_axis(t, o1, 1), np.take_along_axis(d2, o1, 1)
+    o2 = np.argsort(d1, axis=1, kind='stable')
+    tc, dc = np.take_along_axis(t1, o2, 1), np.take_along_axis(d1, o2, 1)
+    tied = np.zeros(t.shape, dtype=bool)
+    if t.shape[1] > 1:
+        eq = (dc[:, 1:] == dc[:, :-1]) & np.isfinite(dc[:, 1:])
+        tied[:, 1:] |= eq
+        tied[:, :-1] |= eq
+    full = t[:, -1] != len(s)
+    last = (dc == dc[:, -1:]) & full[:, None]
+    bits = np.ascontiguousarray(dc.astype(np.float32)).view(np.int32).astype(np.int64) + (1 << 40)
+    tc = np.where(last, bits, tc)
+    return tc, int(tied.any(1).sum()), int(tied.sum())

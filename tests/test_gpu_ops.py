@@ -274,7 +274,8 @@ def test_rpe_attention_matches_oracle(A, N, C, H, eq):
 
 @pytest.mark.parametrize('A,lengths,C,H,eq', [(6, (59, 53), 32, 4, True), (6, (382, 350), 256, 4, True), (1, (304, 382), 256, 4, False),
                                               (6, (100,), 128, 4, True), (1, (33, 17, 64), 128, 4, False), (3, (17, 40), 64, 2, True),
-                                              (6, (40, 31, 65, 32), 64, 4, True)])
+                                              (6, (40, 31, 65, 32), 64, 4, True), (6, (410, 300), 256, 4, True), (1, (410, 300), 256, 4, False),
+                                              (6, (513,), 256, 4, True)])
 def test_rpe_self_attention_stack_matches_oracle(A, lengths, C, H, eq):
     """Stack mode (all clouds of a pair in ONE launch per kernel, se3_rpe_bias_stack_fwd + se3_attention_stack_fwd) against the
     oracle run cloud by cloud; also pins the composed [q | k | W_p^T q | W_eq^T q] projection."""

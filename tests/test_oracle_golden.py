@@ -207,3 +207,45 @@ def test_c2_fullsize_forward_matches_reference(golden_dir):
     if sorted(zip(ri.tolist(), si.tolist())) == sorted(zip(out['ref_node_corr_indices'].tolist(), out['src_node_corr_indices'].tolist())):
         assert out['ref_corr_points'].shape[0] == int(g['p0/num_corr'])
         assert_close(out['estimated_transform'], g['p0/estimated_transform'], 1e-4, 'estimated_transform')
+
+
+def test_demo_pair_oracle_matches_reference(golden_dir):
+    """The reference's real pair data/demo/{ref,src}.npy (demo_se3ete.npz): the oracle's pyramid -- stage lengths, last-stage points (incl. the
+    voxel whose z index is -1 and wraps, grid_subsampling_cpu.cpp:47-49), all ten tables in tie-canonical form (they differ from the
+    reference's ONLY inside groups of exactly tied distances: 57 % of the stage-0 rows hold one) -- and, on the reference's choice for the cut
+    tie groups and the tied 3-NN rows, every transformer layer, the features and the transform at 1e-5."""
+    from helpers import index_checksum, tie_canonical
+    from oracle import se3et_oracle as O
+    from se3et_amd.model import create_model, load_synthetic_weights, make_cfg
+    g = np.load(golden_dir + '/demo_se3ete.npz')
+    cfg = make_cfg('se3ete')
+    sd = {k: v.detach() for k, v in load_synthetic_weights(create_model(cfg), int(g['synth_seed'])).state_dict().items()}
+    ref, src = g['ref'], g['src']
+    pts = torch.from_numpy(np.concatenate([ref, src], 0))
+    b = cfg.backbone
+    data = O.precompute(pts, torch.tensor([len(ref), len(src)]), b.num_stages, b.init_voxel_size, b.init_radius, [38, 36, 36, 38])
+    assert np.array_equal(np.stack([l.numpy() for l in data['lengths']]), g['lengths'])
+    assert torch.equal(data['points'][-1], torch.from_numpy(g['points_last']))
+    P = [p.numpy() for p in data['points']]
+    for key in ('neighbors', 'subsampling', 'upsampling'):
+        for i, t in enumerate(data[key]):
+            q, s = {'neighbors': (P[i], P[i]), 'subsampling': (P[min(i + 1, 3)], P[i]), 'upsampling': (P[i], P[min(i + 1, 3)])}[key]
+            canon, rows, _ = tie_canonical(q, s, t.numpy())
+            assert index_checksum(canon) == int(g['tiecanon/' + key][i]), '%s[%d]' % (key, i)
+            assert rows == int(g['tierows/' + key][i])
+            rows = torch.from_numpy(g['patch/%s_%d_rows' % (key, i)]).long()
+            if len(rows):
+                t[rows] = torch.from_numpy(g['patch/%s_%d_vals' % (key, i)]).long()
+            assert index_checksum(np.sort(t.numpy(), 1)) == int(g['rowset/' + key][i]), '%s[%d] row sets on the reference tie choice' % (key, i)
+    data['features'] = torch.ones((pts.shape[0], 1))
+    taps = {}
+    with torch.no_grad():
+        out = O.forward(sd, O.OracleConfig.from_model_cfg(cfg), data, layer_tap=lambda i, t: taps.__setitem__(i, t))
+    rs = int(g['row_step'])
+    for i, block in enumerate(g['blocks']):
+        assert_close(taps[i][..., ::rs, :], g['op/layer_%d/out0' % i][0], 1e-5, 'layer %d (%s)' % (i, block))
+    assert_close(out['feats_c'][::rs, :, ::4], g['p0/feats_c'], 1e-5, 'feats_c')
+    assert_close(out['feats_f'][::4 * rs], g['p0/feats_f'], 1e-5, 'feats_f')
+    assert_close(out['ref_feats_c'], g['p0/ref_feats_c'], 1e-5, 'ref_feats_c')
+    assert_close(out['src_feats_c'], g['p0/src_feats_c'], 1e-5, 'src_feats_c')
+    assert_close(out['estimated_transform'], g['p0/estimated_transform'], 1e-4, 'estimated_transform')
