@@ -33,15 +33,81 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# HBM traffic of one RPE self-attention call relative to its algorithmic bytes, from the rocprofv3 PMC passes committed as
-# profiles/r04_pmc_attention_raw.txt (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of tools/pmc_attention.py on the stack-mode
-# kernels at the bench shape, 16 clouds per launch; gfx950 correction: FETCH_SIZE x2 for the 16-B/lane streaming reads of
-# rpe_bias_kernel and attn_split_kv_kernel, attention kernel counters raw).  Counters cannot be read inside this process, so the ratio of that run is applied:
-#   eq  call: (2*1314761.7 + 2*36936.7 + 238017.8 + 202416.0 + 70646.0 + 35142.6) KiB = 3327.6 MB  vs 2549.0 MB algorithmic
-#   inv call: (2*1091026.8 + 2*5932.5  +  38268.5 +  33736.0 + 11774.0 +  5856.0) KiB = 2338.4 MB  vs 2222.9 MB algorithmic
-# (logits kernel, K / V^T split, attention kernel: FETCH + WRITE; x2 on the two streaming readers)
-PMC_TRAFFIC_RATIO = {'eq': 3327.6 / 2549.0, 'inv': 2338.4 / 2222.9}
-PMC_TRAFFIC_FILE = 'profiles/r04_pmc_attention_raw.txt'
+# HBM traffic of one RPE self-attention call relative to its algorithmic bytes: PARSED AT RUN TIME from the committed rocprofv3 PMC passes
+# (profiles/rNN_pmc_attention_raw.txt: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of tools/pmc_attention.py on the stack-mode kernels
+# at the bench shape, 16 clouds per launch, collected by tools/pmc_passes.sh; one line per (kernel, grid, counter): average KiB per dispatch;
+# '#' lines: the collecting commit and the algorithmic bytes of the two calls).  Counters cannot be read inside this process, so the ratio
+# of that run is applied to the calls of this run.  gfx950 correction (/opt/skills/guides/MI355X_MICROARCH.md, HBM): FETCH_SIZE x2 for the
+# 16-B/lane streaming reads of rpe_bias_kernel and attn_split_kv_kernel; the attention kernel's counters as reported.
+PMC_TRAFFIC_FILES = ('profiles/r05_pmc_attention_raw.txt', 'profiles/r04_pmc_attention_raw.txt')
+PMC_ALGORITHMIC_MB_R04 = {'eq': 2549.0, 'inv': 2222.9}      # (the round-4 file carries no '# algorithmic' lines: tools/pmc_attention.py at its shape)
+
+
+def load_pmc_traffic():
+    """-> (ratios {'eq', 'inv'}: HBM-side bytes per algorithmic byte of one call, source string) from the newest committed PMC file."""
+    import hashlib
+    for rel in PMC_TRAFFIC_FILES:
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        text = open(path).read()
+        algo, commit = dict(PMC_ALGORITHMIC_MB_R04) if 'r04' in rel else {}, 'not recorded in the file'
+        kib = {'eq': 0.0, 'inv': 0.0}
+        kind = None
+        for line in text.splitlines():
+            line = line.strip()
+            if line.startswith('#'):
+                if 'commit' in line:
+                    commit = line.split('commit', 1)[1].strip(' :')
+                if 'algorithmic bytes per call' in line:          # "# A=6 eq=1: algorithmic bytes per call N"
+                    algo['eq' if 'eq=1' in line else 'inv'] = float(line.rsplit(' ', 1)[1]) / 1e6
+                continue
+            parts = line.rsplit(',', 4)                            # "name<...>",grid,counter,count,KiB   (the name holds commas)
+            if len(parts) != 5:
+                continue
+            name, _, counter, _, value = parts
+            if 'rpe_bias_kernel' in name:                          # template argument 4: the equivariant term
+                args_t = name.split('<', 1)[1].split(',')
+                kind = 'eq' if args_t[3].strip() == 'true' else 'inv'
+            if kind is None:
+                continue
+            streaming = 'rpe_bias_kernel' in name or 'attn_split_kv_kernel' in name
+            kib[kind] += float(value) * (2.0 if (counter == 'FETCH_SIZE' and streaming) else 1.0)
+        if kib['eq'] > 0 and kib['inv'] > 0 and 'eq' in algo and 'inv' in algo:
+            ratios = {k: kib[k] * 1024.0 / 1e6 / algo[k] for k in kib}
+            return ratios, '%s (collected at commit %s; sha256 %s)' % (rel, commit, hashlib.sha256(text.encode()).hexdigest()[:12])
+    return None, 'no PMC file under profiles/'
+
+
+def load_pmc_step():
+    """HBM-side bytes of ONE 8-pair bench step by kernel family from the committed whole-step PMC passes (tools/pmc_step.sh ->
+    profiles/r05_pmc_step.txt) -> (total bytes, {family: bytes}, source) or (None, None, reason)."""
+    import hashlib
+    rel = 'profiles/r05_pmc_step.txt'
+    path = os.path.join(ROOT, rel)
+    if not os.path.exists(path):
+        return None, None, rel + ' missing'
+    text = open(path).read()
+    fams, total, commit = {}, None, 'not recorded in the file'
+    for line in text.splitlines():
+        if line.startswith('#'):
+            if 'commit' in line:
+                commit = line.split('commit', 1)[1].strip(' :')
+            continue
+        parts = line.strip().rsplit(',', 4)
+        if len(parts) != 5:
+            continue
+        name = parts[0].strip('"')
+        nbytes = (float(parts[4]) + float(parts[3])) * 1024.0       # FETCH (corrected) + WRITE
+        if name == 'total':
+            total = nbytes
+        else:
+            fams[name] = nbytes
+    if total is None:
+        return None, None, rel + ' holds no total line'
+    return total, fams, '%s (collected at commit %s; sha256 %s)' % (rel, commit, hashlib.sha256(text.encode()).hexdigest()[:12])
+
+
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s is achievable
 
 
@@ -64,6 +130,37 @@ def visible_gpus():
         return None
 
 
+def rank_cpu_set(local_rank, local_world, available=None):
+    """The host cores of one rank: the `local_rank`-th of `local_world` equal, disjoint slices of the cores this process may run on
+    (sorted; the remainder stays unused).  A rank's host side is `--inflight` Python threads that launch ~1000 kernels per step each --
+    3.7 busy cores per rank at the default 3 batches in flight (BENCH_r04 host_cpu_s_per_step) -- so eight ranks must not wander over each
+    other's cores.  None when the cores cannot be split (fewer cores than ranks, or no affinity interface)."""
+    if available is None:
+        try:
+            available = os.sched_getaffinity(0)
+        except (AttributeError, OSError):
+            return None
+    cores = sorted(available)
+    per = len(cores) // max(1, local_world)
+    if per < 1:
+        return None
+    return set(cores[local_rank * per:(local_rank + 1) * per])
+
+
+def inflight_for_cores(cores_per_rank, requested=None, batch=8):
+    """Batches in flight per rank that `cores_per_rank` host cores carry: one core per in-flight thread plus one for the process (allocator,
+    HIP runtime threads).  Default 3 (same-box optimum on an unshared host); a request above the budget is refused -- lower --inflight."""
+    if batch <= 1:
+        return 1 if requested is None else requested
+    budget = max(1, cores_per_rank - 1) if cores_per_rank else 3
+    if requested is None:
+        return min(3, budget)
+    if requested > budget and cores_per_rank:
+        raise SystemExit('bench.py: --inflight %d needs %d host cores per rank, this rank has %d: lower --inflight to %d (or give the job '
+                         'more cores)' % (requested, requested + 1, cores_per_rank, budget))
+    return requested
+
+
 def launch_ranks(n, argv, script=None, python=None, poll=0.2, timeout=3600.0):
     """Parent of a self-launched multi-GPU run: N children `python bench.py <argv>`, one rank each.  Never initialises a GPU.  All
     children are watched: the first non-zero exit ends the others (which this launcher started), so a rank that dies before the
@@ -82,8 +179,12 @@ def launch_ranks(n, argv, script=None, python=None, poll=0.2, timeout=3600.0):
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port))
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC (RCCL across processes on this driver)
+        cpus = rank_cpu_set(r, n)                                    # a disjoint slice of the host cores per rank (inherited by its threads)
+        if cpus:
+            env['SE3_RANK_CPUS'] = ','.join(str(c) for c in sorted(cpus))
         procs.append(subprocess.Popen([python or sys.executable, os.path.abspath(script or __file__)] + list(argv), env=env,
-                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL,
+                                      preexec_fn=(lambda c=cpus: os.sched_setaffinity(0, c)) if cpus else None))
     t_end = time.monotonic() + timeout
     failed = None
     while failed is None and any(p.poll() is None for p in procs) and time.monotonic() < t_end:
@@ -121,7 +222,7 @@ def main():
     ap.add_argument('--pair', default='c2_5k')
     ap.add_argument('--cpu-baseline-pairs', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--batch', type=int, default=8, help='registration pairs per forward / step (se3et_amd.batched), 1..8; '
+    ap.add_argument('--batch', type=int, default=8, help='registration pairs per forward / step (se3et_amd.batched), 1..16; '
                     '1 = the single-pair forward of the reference API')
     ap.add_argument('--switch-interval', type=float, default=1e-3)
     ap.add_argument('--prefetch', type=int, default=None, help='build the pyramid of the next batch on a second host thread / HIP '
@@ -183,8 +284,19 @@ def main():
     model = load_synthetic_weights(create_model(cfg)).to(dev).eval()
     total_steps = args.steps + args.warmup
     PB = max(1, args.batch)
-    if args.inflight is None:
-        args.inflight = 3 if PB > 1 else 1
+    # host cores of this rank: under an external launcher (torch.distributed.run) every rank takes its slice of the node's cores itself;
+    # ranks started by launch_ranks() arrive pinned
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
+    host_cores = os.cpu_count()
+    if world > 1 and 'SE3_RANK_CPUS' not in os.environ:
+        cpus = rank_cpu_set(local, local_world)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+    try:
+        cores_here = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores_here = host_cores
+    args.inflight = inflight_for_cores(cores_here, args.inflight, PB)
     if args.inflight > 1:
         args.prefetch = 0                 # every in-flight thread builds its own pyramid
     if args.prefetch is None:
@@ -351,6 +463,8 @@ def main():
 
     roofline = collect_roofline(se3_lib, timings, args)
     roofline_kpconv = collect_kpconv_roofline(timings)
+    roofline_dense = collect_dense_roofline(timings)
+    roofline_step = collect_step_roofline(elapsed, args.steps, args)
     # The same kernels with nothing else on the GPU: by default other batches (--inflight) or the next batch's pyramid (--prefetch 1) run on
     # other streams BESIDE the timed kernels, which lengthens them; a few extra steps with one batch in flight (after the timed region)
     # give the kernels' own rate.
@@ -363,6 +477,10 @@ def main():
         quiet_timings, se3_ops.KERNEL_TIMINGS = se3_ops.KERNEL_TIMINGS, None
         quiet = collect_roofline(se3_lib, quiet_timings, args)
         quiet_kp = collect_kpconv_roofline(quiet_timings)
+        quiet_dense = collect_dense_roofline(quiet_timings)
+        if roofline_dense is not None and quiet_dense is not None:
+            roofline_dense['quiet'] = {k: quiet_dense[k] for k in ('achieved', 'frac', 'launches', 'avg_us')}
+            roofline_dense['ms_per_step_of_this_family'] = round(quiet_dense['avg_us'] * quiet_dense['launches'] / max(args.roofline_quiet_steps, 1) / 1e3, 3)
         if roofline_kpconv is not None and quiet_kp is not None:
             roofline_kpconv['quiet'] = {k: quiet_kp[k] for k in ('achieved', 'frac', 'launches', 'avg_us', 'f32_equivalent_tflops')}
         roofline['quiet'] = {k: quiet[k] for k in ('achieved', 'frac', 'launches', 'avg_us', 'rpe_bias_kernel_avg_us', 'attention_kernel_avg_us',
@@ -398,9 +516,10 @@ def main():
                        'ranks_seen': ranks_seen, 'collectives': 'rccl' if torch.distributed.is_initialized() else 'none (one rank)',
                        'variant': args.variant, 'pair_preset': args.pair, 'sharding': 'pairs round-robin over ranks, no collective',
                        'pairs_per_forward': PB, 'batches_in_flight_per_gpu': max(1, args.inflight), 'pyramid_prefetch': bool(args.prefetch),
+                       'host_cores': host_cores, 'host_cores_per_rank': cores_here,
                        'chained_sections': sorted(__import__('se3et_amd.batched', fromlist=['x']).CHAINED_SECTIONS),
                        'attention_dtype': args.attention_dtype},
-            'roofline': roofline, 'roofline_kpconv': roofline_kpconv, 'cpu_baseline': cpu_baseline, 'single_pair': single_pair, 'train_step': train,
+            'roofline': roofline, 'roofline_kpconv': roofline_kpconv, 'roofline_dense': roofline_dense, 'roofline_step': roofline_step, 'cpu_baseline': cpu_baseline, 'single_pair': single_pair, 'train_step': train,
         }
         print(json.dumps(line), flush=True)
     if torch.distributed.is_initialized():
@@ -408,6 +527,39 @@ def main():
 
 
 MFMA_F16_PEAK_TFLOPS = 2500.0        # dense f16 / bf16 matrix-core peak of one MI355X (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def collect_dense_roofline(timings):
+    """The dense + GroupNorm family of the backbone (the largest share of a step since round 4): every
+    dense_norm_kernel launch the backbone issues from Python -- se3_dense_norm_fwd (GEMM + statistics, output written or statistics only) and
+    se3_dense_residual_fwd (the recomputed block tail) -- between an event pair (se3et_amd/ops.py).  HBM bound: algorithmic bytes = the
+    activations read and written once, 4 (rows K [+ rows K2] [+ rows N residual] [+ rows N out]), the weights (K N, L2 resident) not counted."""
+    ev = timings.get('dense', [])
+    if not ev:
+        return None
+    ms = [a.elapsed_time(b) for a, b, _ in ev]
+    nbytes = sum(f for _, _, f in ev)
+    achieved = nbytes / (sum(ms) * 1e-3) / 1e9
+    return {'kernel': 'dense_norm_kernel: the unary / shortcut dense layers of the E2PN backbone fused with their GroupNorm statistics, and the '
+                      'recomputed block tails (one launch per event pair)',
+            'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+            'traffic': None, 'launches': len(ev), 'avg_us': round(1e3 * sum(ms) / len(ev), 2),
+            'algorithmic_bytes_per_launch': int(nbytes / len(ev)), 'ms_per_step_of_this_family': None}
+
+
+def collect_step_roofline(elapsed, steps, args):
+    """Whole-step HBM figure: the HBM-side bytes of one 8-pair step by kernel family from the committed whole-step
+    PMC passes (tools/pmc_step.sh), over this run's time per step."""
+    total, fams, source = load_pmc_step()
+    if total is None or args.batch != 8 or args.variant != 'se3ete' or args.pair != 'c2_5k' or args.attention_dtype != 'float32':
+        return {'bytes_per_step': None, 'source': source if total is None else 'the PMC passes were taken on the default workload (8 x c2_5k pairs, se3ete, f32)'}
+    s_per_step = elapsed / max(steps, 1)
+    achieved = total / s_per_step / 1e9
+    return {'bound': 'hbm', 'bytes_per_step': int(total), 'ms_per_step': round(s_per_step * 1e3, 3), 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+            'per_family_MB': {k: round(v / 1e6, 1) for k, v in sorted(fams.items(), key=lambda kv: -kv[1])},
+            'source': 'HBM-side bytes (FETCH_SIZE, x2 for the families of 16-B/lane streams, + WRITE_SIZE) of one step with one batch in flight, '
+                      'parsed at run time from ' + source + '; time per step of THIS run'}
 
 
 def collect_kpconv_roofline(timings):
@@ -466,15 +618,17 @@ def collect_roofline(se3_lib, timings, args):
     bytes_call = sum(k[1] for k in kinds.values())
     us_call = sum(k[2] + k[3] for k in kinds.values())
     achieved = bytes_call / (us_call * 1e-6) / 1e9 if us_call > 0 else 0.0
-    traffic = sum(PMC_TRAFFIC_RATIO[name] * k[1] for name, k in kinds.items()) / max(n_call, 1)
+    ratios, source = load_pmc_traffic()
+    traffic = sum(ratios[name] * k[1] for name, k in kinds.items()) / max(n_call, 1) if ratios else None
     if args.attention_dtype != 'float32':
         traffic = None                 # the PMC passes were taken on the f32 kernels
     return {
         'kernel': 'RPE self-attention call = rpe_bias_kernel + attention kernel incl. its K / V^T split (all clouds of the batch per launch)',
         'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None if traffic is None else int(traffic),
-        'traffic_source': 'bytes per call; PMC FETCH_SIZE(x2 on the streaming kernel)+WRITE_SIZE per algorithmic byte from '
-                          '%s, applied to the calls of this run' % PMC_TRAFFIC_FILE,
+        'traffic_source': 'bytes per call; PMC FETCH_SIZE(x2 on the streaming kernels)+WRITE_SIZE per algorithmic byte, parsed at run time from '
+                          '%s, applied to the calls of this run' % source,
+        'traffic_per_algorithmic_byte': None if not ratios else {k: round(v, 4) for k, v in ratios.items()},
         'launches': n_call, 'avg_us': round(us_call / max(n_call, 1), 2),
         'algorithmic_bytes_per_launch': int(bytes_call / max(n_call, 1)),
         'rpe_bias_kernel_avg_us': round(sum(k[2] for k in kinds.values()) / max(n_call, 1), 2),
@@ -556,13 +710,20 @@ def run_fake(args):
     sharding.barrier()
     elapsed = sharding.max_over_ranks(time.perf_counter() - t0)
     total = sharding.sum_over_ranks(len(mine))
+    # the host cores every rank runs on (pinned by the launcher): gathered so that the test can see that they are disjoint
+    mine_cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else []
+    cpu_sets = [None] * world
+    if world > 1:
+        torch.distributed.all_gather_object(cpu_sets, mine_cpus)
+    else:
+        cpu_sets = [mine_cpus]
     if rank == 0:
         print(json.dumps({'metric': 'launcher self-test (no GPU work)', 'value': round(world * args.steps * PB / elapsed, 3),
                           'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                           'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
                           'vs_baseline': None, 'dtype': 'none', 'data': 'none (fake device)',
                           'config': {'workload': 'fake device', 'ranks_seen': torch.distributed.get_world_size() if world > 1 else 1,
-                                     'pairs_sharded': int(total), 'pairs_per_forward': PB}}), flush=True)
+                                     'pairs_sharded': int(total), 'pairs_per_forward': PB, 'rank_cpus': cpu_sets}}), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

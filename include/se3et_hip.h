@@ -12,7 +12,7 @@
  *     TORCH_CHECK failures of the reference extension, geotransformer/extensions/common/torch_helper.h:6-35).
  *
  * Hard limits (requests beyond them return SE3_ERR_UNSUPPORTED, nothing is truncated silently):
- *   - stacked calls take at most SE3_MAX_BATCH = 16 clouds (8 registration pairs per forward);
+ *   - stacked calls take at most SE3_MAX_BATCH = 32 clouds (16 registration pairs per forward);
  *   - radius search keeps at most SE3_MAX_NEIGHBOR_LIMIT = 64 neighbours per query (the reference's limits are 36 / 38);
  *   - point_to_node_partition: point_limit <= 128 (the KITTI configuration's patch size);
  *   - attention: anchors * heads <= 32, head dimension in {8, 16, 32, 64}, channels of the relative-position kernel in {32, 64, 128, 256};
@@ -39,7 +39,7 @@ extern "C" {
 #define SE3_ERR_LAUNCH 3
 #define SE3_ERR_WORKSPACE 4
 
-#define SE3_MAX_BATCH 16          /* clouds per stacked call (the reference always stacks 2: ref, src) */
+#define SE3_MAX_BATCH 32          /* clouds per stacked call = 16 registration pairs per forward (the reference always stacks 2: ref, src) */
 #define SE3_MAX_NEIGHBOR_LIMIT 64 /* radius search keeps at most this many nearest neighbours */
 
 /* Library / build identification. */
@@ -51,6 +51,13 @@ const char* se3_last_error(void);   /* text of the last failure on the calling t
 void se3_debug_set_bias_variant(int variant, int split);
 void se3_debug_set_attention_variant(int variant);
 void se3_debug_set_attention_profile(long long* stamps);
+/* Variant bits of the fused KPConv kernel (se3_kpconv_so3_fused): 1 = consecutive 16-point tiles on ONE XCD (workgroup i runs on XCD i mod 8:
+ * tile = start of that XCD's contiguous tile range + i / 8) instead of tile = workgroup index -- for row orders with spatial locality. */
+void se3_debug_set_kpconv_variant(int variant);
+/* Rows of dense launches (se3_linear_stream*, se3_dense_norm_fwd, se3_dense_residual_fwd, se3_linear_f16) whose values left the headroom of the
+ * row's f16-split scale -- more than 2^8 times the largest magnitude of the row's first 32 values -- or held NaN / Inf, since the last
+ * reset: such values are clamped to the f16 range (finite, wrong) and counted here (events: once per row, K-step and column block).  Synchronises the device; reset != 0 zeroes the count. */
+unsigned long long se3_debug_dense_saturated_rows(int reset);
 /* Per-launch timing of the two RPE self-attention kernels (bench.py): while enabled every launch carries its own start / stop
  * HIP event pair (hipExtLaunchKernelGGL) on the launch stream; collect() waits for them, returns the count and fills the
  * durations (us) and tags (1 = relative-position logits kernel, 2 = attention kernel) in launch order. */

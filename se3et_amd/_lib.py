@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libse3et_hip.so')
+# (SE3_LIB: another build of the same library, for A/B runs of two kernel versions on ONE box -- tools/r5/build_ab.sh)
+LIB_PATH = os.environ.get('SE3_LIB') or os.path.join(_HERE, 'csrc', 'libse3et_hip.so')
 
 _vp, _i64, _i32, _f32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 
@@ -16,6 +17,8 @@ SIGNATURES = {
     'se3_last_error': (ctypes.c_char_p, []),
     'se3_debug_set_bias_variant': (None, [_i32, _i32]),
     'se3_debug_set_attention_variant': (None, [_i32]),
+    'se3_debug_set_kpconv_variant': (None, [_i32]),
+    'se3_debug_dense_saturated_rows': (ctypes.c_uint64, [_i32]),
     'se3_debug_set_attention_profile': (None, [_vp]),
     'se3_debug_kernel_timing': (None, [_i32]),
     'se3_debug_kernel_timing_collect': (_i32, [_vp, _vp, _i32]),

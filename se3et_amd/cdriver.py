@@ -12,7 +12,7 @@ import torch
 from . import ops as _ops
 from ._lib import check, lib
 
-MAX_BLOCKS, MAX_BATCH = 16, 16
+MAX_BLOCKS, MAX_BATCH = 16, 32
 _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
 

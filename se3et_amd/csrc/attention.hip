@@ -37,7 +37,7 @@ __device__ __forceinline__ float f4get(const float4& v, int i) { return i == 0 ?
 // ---------------------------------------------------------------------------------------------------------------------
 // stack mode: the clouds of a pair (ref, src) share one launch
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kMaxClouds = 16;
+constexpr int kMaxClouds = SE3_MAX_BATCH;        // 32 clouds = 16 pairs per launch (descriptors: 48 B each in the kernel-argument segment)
 struct StackCloud {
   const float* emb;     // (N, M, C) geometric embedding (bias kernel only)
   const float* eq;      // (A, N, M, 4) equivariant embedding or null

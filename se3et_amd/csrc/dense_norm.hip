@@ -31,6 +31,15 @@ using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+
+// rows whose values left the headroom of their f16-split scale (or were NaN / Inf) since the last reset: se3_debug_dense_saturated_rows
+__device__ unsigned long long g_dense_saturated_rows = 0;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {                      // the value of another lane of the same row of 16 (DPP control CTRL)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 
 constexpr int kHeaderB = 256;                 // weight pieces: se3_linear_split_weights_f16 (csrc/linear_f16.hip)
 constexpr int kRowB = 80;                     // bytes per (piece, row) of the A image of one K-step: 32 f16 + 16 B pad
@@ -91,6 +100,18 @@ __global__ __launch_bounds__(256, MODE == 3 ? 2 : 3) void dense_norm_kernel(cons
   constexpr int kPieceB = TR * kRowB, kBufB = 2 * kPieceB;
   constexpr bool kStats = MODE <= 1, kDual = MODE == 3, kPlain = MODE >= 4;
   __shared__ __align__(16) unsigned char lds[2 * kBufB];
+  // Row scales of the f16 split (the split used to be exact only for 2^-3 <= |x| < 65504, with nothing guarding the
+  // window).  Every row of the A operand takes its scale from the largest magnitude of its FIRST 32 values (the first K-step of the row
+  // tile): inside [2^-4, 2^7) the row is split as it is (exponent 141: error <= 2^-21 of that magnitude, 2^8 of headroom to the top of
+  // f16); outside, the row is multiplied by the power of two that puts that magnitude into [2^6, 2^7) (exact), and the epilogue takes the
+  // scale out of the accumulators with v_ldexp.  A row whose first 32 values are all zero stays unscaled.  The scale of a row is fixed
+  // for the tile: a later value that exceeds the row's headroom (more than 2^8 times its first 32 values -- or NaN / Inf) is clamped to
+  // the f16 range and COUNTED (se3_debug_dense_saturated_rows): loud instead of Inf.  A row's scale is a function of that row's values
+  // only: rows -- the padding rows of a packed batch included -- do not influence each other.
+  __shared__ __align__(16) int row_exp[2][TR];                           // per image: exponent - 141 of a scaled row, valid for the tile ending in step ...
+  __shared__ __align__(16) int row_exp_step[2][TR];                      // ... row_exp_step (any other tile: 0)
+  __shared__ int row_run[TR];                                            // exponent of the rows of the tile being staged (only while a wave is off the plain path)
+  __shared__ int row_scl[2];                                             // per image: the step number if some row of the tile ending in it is scaled
   extern __shared__ __align__(16) float aff[];                           // [stage][2][K] of this workgroup's segment
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
@@ -114,6 +135,8 @@ __global__ __launch_bounds__(256, MODE == 3 ? 2 : 3) void dense_norm_kernel(cons
   const int stages = (a.in_affine[0] != nullptr) + (a.in_affine[1] != nullptr);
   for (int st = 0; st < stages; st++)
     for (int i = tid; i < 2 * K; i += 256) aff[st * 2 * K + i] = a.in_affine[st][(size_t)seg * 2 * K + i];
+  if (tid < 2) row_scl[tid] = -1;
+  for (int i = tid; i < 2 * TR; i += 256) row_exp_step[0][i] = -1;
   const int nk1 = K >> 5, nk2 = kDual ? (K2 >> 5) : 0, nkt = nk1 + nk2;
   const int ntiles = (int)((r1 - r0 + TR - 1) / TR);
   const int total = ntiles * nkt;
@@ -130,6 +153,7 @@ __global__ __launch_bounds__(256, MODE == 3 ? 2 : 3) void dense_norm_kernel(cons
   const long long rbase = r1 > r0 ? r0 : 0;
   const int nrows = (int)(r1 - r0);
   const int xoff1 = (urow * XS + 4 * q) * 4, xoff2 = (urow * K2 + 4 * q) * 4;
+  bool plain_rows = true;                                                // (uniform per wave) every row this wave stages is at exponent 141
   auto request = [&](const StepPos& p, f32x4 (&v)[U]) {
     const bool two = kDual && p.kk >= nk1;                               // uniform
     const int Ks = two ? K2 : XS, kloc = two ? p.kk - nk1 : p.kk;
@@ -164,9 +188,9 @@ __global__ __launch_bounds__(256, MODE == 3 ? 2 : 3) void dense_norm_kernel(cons
     // (plain modes with x_rs < K: a row is read past its end into the next one against zero weight columns -- those values are dropped
     // here, not multiplied: an Inf / NaN / > 65504 in the neighbouring row would turn 0 * x into NaN.  Uniform condition.)
     const bool tail_mask = kPlain && XS < K && a.seg_steps == 0 && k + 4 > XS;
-#pragma unroll
-    for (int j = 0; j < U; j++) {
-      f32x4 t = v[j];
+    const bool first_step = p.kk == 0, last_step = p.kk == nkt - 1;      // (uniform) of the row tile
+    auto transformed = [&](const f32x4& raw) {                          // T(v): tail mask, the pending norm stages
+      f32x4 t = raw;
       if constexpr (kPlain) {
         if (tail_mask) {
 #pragma unroll
@@ -183,6 +207,27 @@ __global__ __launch_bounds__(256, MODE == 3 ? 2 : 3) void dense_norm_kernel(cons
 #pragma unroll
         for (int e = 0; e < 4; e++) t[e] = t[e] > 0.f ? t[e] : t[e] * a.in_slope[1];
       }
+      return t;
+    };
+    // One decision per call, wave-uniform, from four vector instructions per unit (two maxima, two compares; the rest is scalar): every row this
+    // wave stages is at exponent 141, nothing of this K-step reaches 2^15 (first step: 2^7) and -- in a tile's first step -- every row holds
+    // something at 2^-4 or above.  That is the straight-line common path (the unscaled split); anything else takes the exact path.
+    unsigned long long odd = 0;                                          // lanes that see a value at / above 2^15 (NaN included) [or, first step, a row below 2^-4]
+    f32x4 tv[U];
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+      const f32x4 t = transformed(v[j]);
+      tv[j] = t;
+      const float m = fmaxf(fmaxf(__builtin_fabsf(t[0]), __builtin_fabsf(t[1])), fmaxf(__builtin_fabsf(t[2]), __builtin_fabsf(t[3])));
+      odd |= __builtin_amdgcn_ballot_w64(!(m < (first_step ? 128.f : 32768.f)));
+      // a row = 8 adjacent lanes = one byte of the ballot: the bytes are OR-folded on the scalar unit, a zero byte is a row below 2^-4
+      unsigned long long ge = __builtin_amdgcn_ballot_w64(m >= 0.0625f);
+      ge |= ge >> 4;
+      ge |= ge >> 2;
+      ge |= ge >> 1;
+      odd |= first_step ? (~ge & 0x0101010101010101ull) : 0ull;
+    }
+    auto split_store = [&](int j, const f32x4& t) {
       f16x4 hi, lo;
 #pragma unroll
       for (int e = 0; e < 4; e++) {
@@ -192,7 +237,61 @@ __global__ __launch_bounds__(256, MODE == 3 ? 2 : 3) void dense_norm_kernel(cons
       unsigned char* dst = lds + buf * kBufB + (urow + 32 * j) * kRowB + q * 8;
       *reinterpret_cast<f16x4*>(dst) = hi;
       *reinterpret_cast<f16x4*>(dst + kPieceB) = lo;
+    };
+    if (__builtin_expect(odd == 0 && (plain_rows || first_step), 1)) {
+#pragma unroll
+      for (int j = 0; j < U; j++) split_store(j, tv[j]);
+      plain_rows = true;
+      return;
     }
+    // ---- the exact path: per row the largest magnitude of this K-step -> (first step) the row's scale, (later) the saturation check.  NOT
+    // unrolled over the units (the unit is picked with selects): the code of this cold path sits inside the hot loop, and its size alone
+    // costs the loop time (measured: the same branch, never taken, with the unrolled body: +5 % on the unary shapes).
+    bool any_scaled = false;
+    int saturated = 0;
+#pragma unroll 1
+    for (int j = 0; j < U; j++) {
+      f32x4 t = tv[0];
+#pragma unroll
+      for (int jj = 1; jj < U; jj++) t = j == jj ? tv[jj] : t;
+      float m = fmaxf(fmaxf(__builtin_fabsf(t[0]), __builtin_fabsf(t[1])), fmaxf(__builtin_fabsf(t[2]), __builtin_fabsf(t[3])));
+      const bool nan = (t[0] != t[0]) | (t[1] != t[1]) | (t[2] != t[2]) | (t[3] != t[3]);
+      m = nan ? __builtin_bit_cast(float, 0x7fc00000) : m;              // (fmaxf drops NaN)
+      int mb = __builtin_bit_cast(int, m);                               // non-negative floats order like their bit patterns, NaN last
+      mb = max(mb, __builtin_amdgcn_update_dpp(0, mb, 0xB1, 0xf, 0xf, true));     // the row's 32 values sit in 8 adjacent lanes: quad_perm [1, 0, 3, 2],
+      mb = max(mb, __builtin_amdgcn_update_dpp(0, mb, 0x4E, 0xf, 0xf, true));     // quad_perm [2, 3, 0, 1],
+      mb = max(mb, __builtin_amdgcn_update_dpp(0, mb, 0x141, 0xf, 0xf, true));    // row_half_mirror
+      const int e_here = (mb >> 23) & 0xff;                              // biased exponent of the row's largest magnitude in this step
+      const int row = urow + 32 * j;
+      int e_row;
+      if (first_step)        // plain inside [2^-4, 2^7) (exponents 123 .. 133) and for an all-zero start; else the magnitude goes to [2^6, 2^7)
+        e_row = ((e_here >= 123 && e_here <= 133) || e_here == 0) ? 141 : (e_here >= 255 ? 141 : min(e_here + 8, 254));
+      else
+        e_row = plain_rows ? 141 : row_run[row];
+      if (first_step && q == 0) row_run[row] = e_row;
+      const bool sat = e_here > e_row;                                   // beyond the row's headroom (NaN / Inf: 255)
+      f16x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        float te = __builtin_ldexpf(t[e], 141 - e_row);
+        te = fminf(fmaxf(te, -65000.f), 65000.f);                        // (saturation: finite, and counted below; NaN becomes -65000)
+        hi[e] = (_Float16)te;
+        lo[e] = (_Float16)(te - (float)hi[e]);
+      }
+      unsigned char* dst = lds + buf * kBufB + row * kRowB + q * 8;
+      *reinterpret_cast<f16x4*>(dst) = hi;
+      *reinterpret_cast<f16x4*>(dst + kPieceB) = lo;
+      if (last_step && e_row != 141 && q == 0) {
+        row_exp[buf][row] = e_row - 141;
+        row_exp_step[buf][row] = p.tile * nkt + p.kk;
+      }
+      saturated += (sat && q == 0) ? 1 : 0;
+      any_scaled |= e_row != 141;
+    }
+    const bool w_scaled = __builtin_amdgcn_ballot_w64(any_scaled) != 0;
+    plain_rows = !w_scaled;
+    if (last_step && w_scaled && lane == 0) row_scl[buf] = p.tile * nkt + p.kk;      // (every writer stores the same number)
+    if (saturated) atomicAdd(&g_dense_saturated_rows, (unsigned long long)saturated);
   };
   const int a_read = (wm * (RT * 32) + i32) * kRowB + h * 16;           // + rt * 32 * kRowB + ks * 32 + piece * kPieceB
   const int ct0 = blockIdx.y * (BN / 32) + wn * CT;
@@ -315,6 +414,20 @@ __global__ __launch_bounds__(256, MODE == 3 ? 2 : 3) void dense_norm_kernel(cons
     // ---- end of a row tile
     const long long trow0 = r0 + (long long)p.tile * TR + wm * (RT * 32);          // uniform
     const int rows_here = (int)(r1 - trow0 < RT * 32 ? (r1 - trow0 > 0 ? r1 - trow0 : 0) : RT * 32);
+    // the row scales out again: acc 2^(E - 141), exact (v_ldexp: gradual underflow instead of a flushed factor); tiles without a scaled
+    // row -- all of them, for activations of ordinary magnitude -- skip this on one flag
+    if (__builtin_expect(row_scl[buf] == p.tile * nkt + p.kk, 0)) {
+#pragma unroll
+      for (int r = 0; r < RT; r++)
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+          const int row = (wm * RT + r) * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+          const int ev = row_exp_step[buf][row] == p.tile * nkt + p.kk ? row_exp[buf][row] : 0;
+#pragma unroll
+          for (int c = 0; c < CT; c++) acc[r][c][v] = __builtin_ldexpf(acc[r][c][v], ev);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
     if constexpr (MODE == 4) {
       // out = act(acc / S + bias): rows past the chunk and columns past N get an out-of-range offset (dropped by the buffer bounds check:
       // the store instruction itself stays unconditional, so the number of outstanding memory operations does not depend on the path)
@@ -329,7 +442,7 @@ __global__ __launch_bounds__(256, MODE == 3 ? 2 : 3) void dense_norm_kernel(cons
           for (int v = 0; v < 16; v++) {
             const int rr = r * 32 + (v & 3) + 8 * (v >> 2);
             float val = acc[r][c][v] * fs[c] + bs[c];
-            val = val > 0.f ? val : val * a.final_slope;
+            val = fmaxf(val, val * a.final_slope);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ors, lane_off, rr * OS * 4, 0);
             acc[r][c][v] = 0.f;
           }
@@ -353,7 +466,7 @@ __global__ __launch_bounds__(256, MODE == 3 ? 2 : 3) void dense_norm_kernel(cons
 #pragma unroll
             for (int j = 0; j < 4; j++) {
               float val = acc[r][c][4 * g + j] * fs[c] + bs[c];
-              v4[j] = val > 0.f ? val : val * a.final_slope;
+              v4[j] = fmaxf(val, val * a.final_slope);
               acc[r][c][4 * g + j] = 0.f;
             }
             const bool ok = col < N && row < r1;
@@ -386,7 +499,7 @@ __global__ __launch_bounds__(256, MODE == 3 ? 2 : 3) void dense_norm_kernel(cons
             const int rr = r * 32 + (v & 3) + 8 * (v >> 2);
             float val = acc[r][c][v] * fs[c] + bs[c];
             if constexpr (MODE == 2) val += res[v];
-            val = val > 0.f ? val : val * a.final_slope;
+            val = fmaxf(val, val * a.final_slope);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ors, lane_off, rr * N * 4, 0);
             acc[r][c][v] = 0.f;
           }
@@ -512,6 +625,18 @@ int g_target_chunks = 768;                   // workgroups (row chunks x column 
 
 }  // namespace
 
+// Rows (of any dense launch of this process) whose values left the headroom of their f16-split scale, or held NaN / Inf, since the last
+// reset: they were clamped to the f16 range instead of producing Inf.  Synchronises the device.  reset != 0: back to zero.
+extern "C" unsigned long long se3_debug_dense_saturated_rows(int reset) {
+  unsigned long long n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_dense_saturated_rows), sizeof(n)) != hipSuccess) return ~0ull;
+  if (reset) {
+    const unsigned long long zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dense_saturated_rows), &zero, sizeof(zero));
+  }
+  return n;
+}
+
 extern "C" void se3_dense_norm_set_target_chunks(int workgroups) { g_target_chunks = workgroups > 0 ? workgroups : 768; }
 
 constexpr size_t kCounterB = kGNCounterB;
@@ -589,6 +714,7 @@ extern "C" int se3_dense_norm_fwd(const float* x, int64_t rows, int in_features,
   SE3_REQUIRE(num_segments >= 1 && num_segments <= kGNMaxSegments && (num_segments == 1 || segment_row_offsets_host), SE3_ERR_UNSUPPORTED,
               "dense_norm: %d segments (1..%d)", num_segments, kGNMaxSegments);
   SE3_REQUIRE(((uintptr_t)x & 15) == 0 && (in_affine_a || !in_affine_b), SE3_ERR_INVALID_ARG, "dense_norm: x must be 16-byte aligned; stage b needs stage a");
+  SE3_REQUIRE(in_slope_a >= 0.f && in_slope_a <= 1.f && in_slope_b >= 0.f && in_slope_b <= 1.f, SE3_ERR_INVALID_ARG, "dense_norm: LeakyReLU slopes must lie in [0, 1]");
   SE3_REQUIRE(workspace_bytes >= se3_dense_norm_workspace_bytes(groups), SE3_ERR_WORKSPACE, "dense_norm: workspace too small");
   SegTable T;
   int TR, BN, ncb;
@@ -643,6 +769,8 @@ extern "C" int se3_dense_residual_fwd(const float* x, int64_t rows, int in_featu
   SE3_REQUIRE(rows >= 1 && num_segments >= 1 && num_segments <= kGNMaxSegments && (num_segments == 1 || segment_row_offsets_host), SE3_ERR_UNSUPPORTED,
               "dense_residual: rows %lld, %d segments (1..%d)", (long long)rows, num_segments, kGNMaxSegments);
   SE3_REQUIRE(((uintptr_t)x & 15) == 0 && (in_affine_a || !in_affine_b), SE3_ERR_INVALID_ARG, "dense_residual: x must be 16-byte aligned; stage b needs stage a");
+  SE3_REQUIRE(in_slope_a >= 0.f && in_slope_a <= 1.f && in_slope_b >= 0.f && in_slope_b <= 1.f && final_slope >= 0.f && final_slope <= 1.f, SE3_ERR_INVALID_ARG,
+              "dense_residual: LeakyReLU slopes must lie in [0, 1]");
   SegTable T;
   int TR, BN, ncb;
   const int chunks = dense_chunks(rows, N, segment_row_offsets_host, num_segments, T, TR, BN, ncb);

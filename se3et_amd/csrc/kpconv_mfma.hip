@@ -422,6 +422,7 @@ __global__ __launch_bounds__(256) void kpconv_orbit_gather_kernel(const float* _
 }
 
 // ---- fused form: stages 2 and 3 in one kernel ------------------------------------------------------------------------------------------
+static int g_kpconv_variant = 0;
 // One 11- or 12-wave workgroup per compute unit and 16-point tile; three tile images in LDS (3 x 48.6 KB).
 // Schedule: step u = 0 .. chunks + 1, one barrier between steps.  CONSUMER waves multiply chunk u - 2 (image (u - 2) % 3) in step u >= 2.
 // A PRODUCER wave (8 of them) handles ONE point per step over a PAIR of chunks (16 channels): in step u = 2T its first point, in step 2T + 1 its
@@ -433,7 +434,7 @@ template <int NCW, int KS, int CT, bool EXT, bool BLK>      // consumer waves: N
 __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
     const float* __restrict__ x, const float* __restrict__ hwt, const int* __restrict__ nbr, const int* __restrict__ cnt, int NNp,
     const u32x4* __restrict__ Wf, const float* __restrict__ hdr, int64_t P, int Cin, int Cout, float* __restrict__ out,
-    float* __restrict__ split_part, int* __restrict__ split_count) {
+    float* __restrict__ split_part, int* __restrict__ split_count, int variant) {
   constexpr int NC = NCW * KS;                                         // consumer waves
   constexpr int NPW = 8;                                               // producer waves: two points of the tile each
   constexpr int kSPW = kSteps / KS;                                    // K16-steps per consumer wave and chunk
@@ -442,7 +443,13 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
   unsigned* tab = reinterpret_cast<unsigned*>(lds + 3 * kTileB);       // [K16-step][rsel][h]: three 8-bit run numbers (anchor pairs 0..2)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t tile = blockIdx.x, p0 = tile * kTP;
+  // variant bit 0: workgroup i runs on XCD i mod 8 -- give every XCD one contiguous range of tiles (its L2 then sees neighbouring tiles)
+  int64_t tile = blockIdx.x;
+  if (variant & 1) {
+    const int n = (int)gridDim.x, xcd = (int)blockIdx.x & 7, per = n >> 3, rem = n & 7;
+    tile = (int64_t)xcd * per + (xcd < rem ? xcd : rem) + ((int)blockIdx.x >> 3);
+  }
+  const int64_t p0 = tile * kTP;
   // gridDim.z > 1 (few tiles: one pair per forward): the input-channel chunks are split over gridDim.z workgroups, whose partial outputs
   // the last one to arrive adds up in a fixed order (see the epilogue)
   const int chunks = Cin / kCC / (int)gridDim.z, chunk0 = blockIdx.z * chunks, pairs = (chunks + 1) / 2;
@@ -949,7 +956,7 @@ extern "C" int se3_kpconv_so3_fused(const float* x, const void* table, int64_t n
     }                                                                                                                                     \
     kpconv_fused_kernel<NCW_, KS_, CT_, EXT_, BLK_>                                                                                       \
         <<<dim3((unsigned)tiles, (unsigned)(NCT / (NCW_ * CT_)), (unsigned)splits), 64 * (NCW_ * KS_ + 8), lds, st>>>(                    \
-            x, t.hwt, t.nbr, t.cnt, t.NNp, Wf, hdr, num_queries, in_channels, out_channels, out, split_part, split_count);                \
+            x, t.hwt, t.nbr, t.cnt, t.NNp, Wf, hdr, num_queries, in_channels, out_channels, out, split_part, split_count, g_kpconv_variant);                \
   }
 #define SE3_FUSED(NCW_, KS_, CT_)                                  \
   {                                                                \
@@ -971,3 +978,5 @@ extern "C" int se3_kpconv_so3_fused(const float* x, const void* table, int64_t n
   SE3_CHECK_LAUNCH("kpconv_so3_fused");
   return SE3_OK;
 }
+
+extern "C" void se3_debug_set_kpconv_variant(int variant) { g_kpconv_variant = variant; }

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void node_knn_kernel(const float* __restrict__
 }
 
 // ---- stack mode: the clouds of several pairs in one launch -------------------------------------------------------------
-constexpr int kMaxPartClouds = 16;
+constexpr int kMaxPartClouds = SE3_MAX_BATCH;
 struct PartClouds {
   int p0[kMaxPartClouds + 1];     // first point of cloud c in the stacked point array (p0[n] = total points)
   int m0[kMaxPartClouds + 1];     // first node of cloud c in the stacked node array

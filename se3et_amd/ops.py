@@ -153,6 +153,12 @@ def linear_f16(x, weight, bias=None, relu=False):
     return out
 
 
+def dense_saturated_rows(reset=True):
+    """Rows of the dense launches since the last reset whose values left the headroom of their f16-split scale (csrc/dense_norm.hip: a later
+    input channel more than 2^8 times the row's first 32 values) or held NaN / Inf: clamped, counted.  One device synchronisation."""
+    return int(lib().se3_debug_dense_saturated_rows(1 if reset else 0))
+
+
 def linear_stream_ok(x, weight):
     """True when linear_stream applies: inference, f32 GPU tensors, unit-stride rows aligned to 16 bytes, in_features a multiple of 32."""
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
@@ -662,11 +668,12 @@ def dense_norm(x, weight, linear_bias, norm_weight, norm_bias, groups, eps, segm
     ws = _dense_workspace(raw.device, stream, lib().se3_dense_norm_workspace_bytes(int(groups)))
     aa = pend.affines + [None, None]
     sl = pend.slopes + [1.0, 1.0]
-    _check_counters(lib().se3_dense_norm_fwd(raw.data_ptr(), rows, K, aa[0].data_ptr() if aa[0] is not None else None, float(sl[0]),
-                                   aa[1].data_ptr() if aa[1] is not None else None, float(sl[1]), Wp.data_ptr(), N,
-                                   linear_bias.data_ptr() if linear_bias is not None else None, norm_weight.data_ptr(), norm_bias.data_ptr(),
-                                   int(groups), float(eps), _i64_array(segments) if nseg > 1 else None, nseg, out.data_ptr(),
-                                   affine.data_ptr(), ws.data_ptr(), ws.numel(), stream), 'se3_dense_norm_fwd', ws)
+    with _timed('dense', 4.0 * rows * (K + N)):           # (bench.py roofline_dense: activations read + product written)
+        _check_counters(lib().se3_dense_norm_fwd(raw.data_ptr(), rows, K, aa[0].data_ptr() if aa[0] is not None else None, float(sl[0]),
+                                       aa[1].data_ptr() if aa[1] is not None else None, float(sl[1]), Wp.data_ptr(), N,
+                                       linear_bias.data_ptr() if linear_bias is not None else None, norm_weight.data_ptr(), norm_bias.data_ptr(),
+                                       int(groups), float(eps), _i64_array(segments) if nseg > 1 else None, nseg, out.data_ptr(),
+                                       affine.data_ptr(), ws.data_ptr(), ws.numel(), stream), 'se3_dense_norm_fwd', ws)
     return Pending(out, [affine], [1.0], segments)
 
 
@@ -687,11 +694,12 @@ def dense_stats(x, weight, linear_bias, norm_weight, norm_bias, groups, eps, seg
     ws = _dense_workspace(raw.device, stream, lib().se3_dense_norm_workspace_bytes(int(groups)))
     aa = pend.affines + [None, None]
     sl = pend.slopes + [1.0, 1.0]
-    _check_counters(lib().se3_dense_norm_fwd(raw.data_ptr(), rows, K, aa[0].data_ptr() if aa[0] is not None else None, float(sl[0]),
-                                   aa[1].data_ptr() if aa[1] is not None else None, float(sl[1]), Wp.data_ptr(), N,
-                                   linear_bias.data_ptr() if linear_bias is not None else None, norm_weight.data_ptr(), norm_bias.data_ptr(),
-                                   int(groups), float(eps), _i64_array(segments) if nseg > 1 else None, nseg, None,
-                                   affine.data_ptr(), ws.data_ptr(), ws.numel(), stream), 'se3_dense_norm_fwd (statistics only)', ws)
+    with _timed('dense', 4.0 * rows * K):                 # (statistics only: the activations read, nothing written)
+        _check_counters(lib().se3_dense_norm_fwd(raw.data_ptr(), rows, K, aa[0].data_ptr() if aa[0] is not None else None, float(sl[0]),
+                                       aa[1].data_ptr() if aa[1] is not None else None, float(sl[1]), Wp.data_ptr(), N,
+                                       linear_bias.data_ptr() if linear_bias is not None else None, norm_weight.data_ptr(), norm_bias.data_ptr(),
+                                       int(groups), float(eps), _i64_array(segments) if nseg > 1 else None, nseg, None,
+                                       affine.data_ptr(), ws.data_ptr(), ws.numel(), stream), 'se3_dense_norm_fwd (statistics only)', ws)
     return affine
 
 
@@ -744,10 +752,11 @@ def dense_residual(x, weight, affine, residual=None, shortcut=None, final_slope=
         resp = residual.data_ptr()
     aa = pend.affines + [None, None]
     sl = pend.slopes + [1.0, 1.0]
-    check(lib().se3_dense_residual_fwd(raw.data_ptr(), rows, K, aa[0].data_ptr() if aa[0] is not None else None, float(sl[0]),
-                                       aa[1].data_ptr() if aa[1] is not None else None, float(sl[1]), Wp.data_ptr(), affine.data_ptr(),
-                                       x2p, K2, wp2, aff2, resp, N, float(final_slope), _i64_array(segments) if nseg > 1 else None, nseg,
-                                       out.data_ptr(), stream), 'se3_dense_residual_fwd')
+    with _timed('dense', 4.0 * rows * (K + K2 + N + (N if resp is not None else 0))):
+        check(lib().se3_dense_residual_fwd(raw.data_ptr(), rows, K, aa[0].data_ptr() if aa[0] is not None else None, float(sl[0]),
+                                           aa[1].data_ptr() if aa[1] is not None else None, float(sl[1]), Wp.data_ptr(), affine.data_ptr(),
+                                           x2p, K2, wp2, aff2, resp, N, float(final_slope), _i64_array(segments) if nseg > 1 else None, nseg,
+                                           out.data_ptr(), stream), 'se3_dense_residual_fwd')
     return out
 
 

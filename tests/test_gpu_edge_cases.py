@@ -63,8 +63,24 @@ def _compare(got, want, context, radius):
     wi = {pair: n for n, pair in enumerate(zip(want['ref_node_corr_indices'].tolist(), want['src_node_corr_indices'].tolist()))}
     common = sorted(set(gi) & set(wi))
     assert len(common) >= len(wi) - 8, '%s: only %d of %d superpoint pairs in common' % (context, len(common), len(wi))
-    mg = got['matching_scores'].cpu()[[gi[p] for p in common]]
-    mw = want['matching_scores'][[wi[p] for p in common]]
+    # (the K nearest points of a superpoint are listed by ascending distance; points at EXACTLY the same float32 distance -- frequent once
+    # the cloud sits 10 m from the origin, where the distance expression is quantised at 8e-6 -- are ordered by torch.topk's whim in the
+    # reference and by index here: the rows / columns of a patch are put into one canonical order, by the points' coordinates, first)
+    def canonical(o, idx):
+        m = o['matching_scores'].cpu()[idx] if torch.is_tensor(o['matching_scores']) else o['matching_scores'][idx]
+        out = []
+        for n, i in enumerate(idx):
+            perm = []
+            for side in ('ref', 'src'):
+                pts = torch.as_tensor(o[side + '_node_corr_knn_points'])[i].cpu().double()
+                msk = torch.as_tensor(o[side + '_node_corr_knn_masks'])[i].cpu()
+                key = torch.where(msk[:, None], pts, torch.full_like(pts, float('inf')))
+                order = sorted(range(key.shape[0]), key=lambda r: tuple(key[r].tolist()))
+                perm.append(torch.tensor(order + [key.shape[0]]))           # (the dustbin row / column stays last)
+            out.append(m[n][perm[0]][:, perm[1]])
+        return torch.stack(out)
+    mg = canonical(got, [gi[p] for p in common])
+    mw = canonical(want, [wi[p] for p in common])
     valid = mw > -1e11
     assert torch.equal(mg > -1e11, valid), '%s: padding pattern of the matching scores' % context
     assert float((mg[valid] - mw[valid]).abs().max()) < 2e-3, '%s: matching scores (log domain, magnitude ~10)' % context

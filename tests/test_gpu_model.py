@@ -131,7 +131,8 @@ def test_bf16_attention_kitti_sized_pair():
 
 
 @pytest.mark.parametrize('variant,preset,num_pairs', [('micro_e', 'micro', 2), ('micro_i', 'micro', 3), ('se3ete', 'c1_2k', 2),
-                                                      ('se3ete', 'c2_5k', 3), ('se3eti', 'c2_5k', 2), ('se3eti_kitti', 'c3_20k', 2)])
+                                                      ('se3ete', 'c2_5k', 3), ('se3eti', 'c2_5k', 2), ('se3eti_kitti', 'c3_20k', 2),
+                                                      ('se3ete', 'c2_5k', 16), ('se3eti', 'c1_2k', 16)])      # 16 pairs = SE3_MAX_BATCH clouds
 def test_multi_pair_forward_equals_single_pair_forward(variant, preset, num_pairs):
     """se3et_amd.batched.forward_pairs (B pairs stacked through pyramid, backbone and transformer) against the single-pair
     forward of the same pairs: identical pyramids per pair, features to float32 round-off (the only arithmetic difference is

@@ -3,6 +3,7 @@
 #   tools/pmc_passes.sh   -> gpurun_out/pmc_fetch.txt, gpurun_out/pmc_write.txt (average per dispatch, KiB)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
+echo "# rocprofv3 --pmc passes of tools/pmc_attention.py (tools/pmc_passes.sh), collected at commit ${SE3_COMMIT:-unknown}"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
   ( cd $R && timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python3 tools/pmc_attention.py > $R/gpurun_out/pmc_$c.log 2>&1 )
@@ -20,3 +21,4 @@ for (n, g, c), (cnt, tot) in agg.items():
 PY
   cat $R/gpurun_out/pmc_$c.txt
 done
+grep 'algorithmic bytes per call' $R/gpurun_out/pmc_WRITE_SIZE.log | sed 's/^/# /'
