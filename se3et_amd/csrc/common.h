@@ -46,7 +46,9 @@ __device__ __forceinline__ float se3_exact_sqrt(float a) { return (float)sqrt((d
 // are fenced with the scoped pragma, which tags the instructions themselves and survives inlining.)
 __device__ __forceinline__ float se3_ref_sq_norm(float x, float y, float z) {
 #pragma clang fp contract(off)
-  const float xx = x * x, yy = y * y, zz = z * z;
+  float xx = x * x, yy = y * y;
+  asm volatile("" : "+v"(xx), "+v"(yy));          // (scalar products: the SLP vectoriser would pack x x and y y into one v_pk_mul_f32 followed by
+  const float zz = z * z;                          // an op_sel shuffle of its fresh result -- the shape tests/test_isa_hazard.py keeps out of the library)
   const float s = xx + yy;
   return s + zz;
 }
