@@ -517,6 +517,7 @@ def main():
                        'variant': args.variant, 'pair_preset': args.pair, 'sharding': 'pairs round-robin over ranks, no collective',
                        'pairs_per_forward': PB, 'batches_in_flight_per_gpu': max(1, args.inflight), 'pyramid_prefetch': bool(args.prefetch),
                        'host_cores': host_cores, 'host_cores_per_rank': cores_here,
+                       'host_waits': 'hipDeviceScheduleBlockingSync ' + __import__('se3et_amd').BLOCKING_SYNC_STATUS,
                        'chained_sections': sorted(__import__('se3et_amd.batched', fromlist=['x']).CHAINED_SECTIONS),
                        'attention_dtype': args.attention_dtype},
             'roofline': roofline, 'roofline_kpconv': roofline_kpconv, 'roofline_dense': roofline_dense, 'roofline_step': roofline_step, 'cpu_baseline': cpu_baseline, 'single_pair': single_pair, 'train_step': train,

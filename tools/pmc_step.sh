@@ -1,15 +1,16 @@
 #!/bin/bash
 # HBM-side traffic of ONE bench step by kernel family: two counter passes (FETCH_SIZE, WRITE_SIZE: they do not fit
-# one pass; counters only, no trace domain beside --pmc) over `bench.py --inflight 1 --prefetch 0 --steps 3 --warmup 1` = 4 steps of 8 pairs.
+# one pass; counters only, no trace domain beside --pmc) over tools/one_step.py = ONE step of 8 pairs (a dispatch costs ~0.1 s under the
+# counters: the bench command itself does not finish in 15 minutes).
 #   tools/pmc_step.sh [tag]  -> gpurun_out/<tag>_pmc_step.txt   (copy to profiles/ to have bench.py's `roofline_step` read it)
 # Per family: dispatches per step, FETCH_SIZE and WRITE_SIZE KiB per step as the counters report them, and the FETCH figure doubled for the
 # families whose reads are 16-byte-per-lane streams (/opt/skills/guides/MI355X_MICROARCH.md "HBM": gfx950 tallies such 128-byte requests at
 # 64 bytes; other access widths are uncalibrated and left as reported).
-R=${GRAFT_REPO_ROOT:-$(pwd)}; tag=${1:-rXX}; STEPS=4
+R=${GRAFT_REPO_ROOT:-$(pwd)}; tag=${1:-rXX}; STEPS=1
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmcs_$c
-  ( cd $R && timeout 900 rocprofv3 --pmc $c --output-format csv -d /tmp/pmcs_$c -o p -- python3 bench.py --inflight 1 --prefetch 0 --steps 3 --warmup 1 --no-cpu-baseline --single-pair-steps 0 --train-steps 0 --roofline-quiet-steps 0 > $R/gpurun_out/pmcs_$c.log 2>&1 )
+  ( cd $R && timeout 1500 rocprofv3 --pmc $c --output-format csv -d /tmp/pmcs_$c -o p -- python3 tools/one_step.py 1 > $R/gpurun_out/pmcs_$c.log 2>&1 )
 done
 python3 - "$(find /tmp/pmcs_FETCH_SIZE -name '*counter_collection.csv' | head -1)" "$(find /tmp/pmcs_WRITE_SIZE -name '*counter_collection.csv' | head -1)" $STEPS > $R/gpurun_out/${tag}_pmc_step.txt <<'PY'
 import collections, csv, sys
@@ -32,7 +33,7 @@ for i, path in enumerate(sys.argv[1:3]):
         if i == 0: t[0] += 1
         t[1 + i] += float(r['Counter_Value'])
 import os
-print('# HBM-side traffic per bench step (8 pairs, one batch in flight, %d steps averaged): rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, KiB; collected at commit %s' % (steps, os.environ.get('SE3_COMMIT', 'unknown')))
+print('# HBM-side traffic per bench step (8 pairs, one batch in flight, %d step incl. the one-off weight splits of a fresh process): rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, KiB; collected at commit %s' % (steps, os.environ.get('SE3_COMMIT', 'unknown')))
 print('# family, dispatches per step, FETCH_SIZE KiB per step (as reported), WRITE_SIZE KiB per step, FETCH corrected (x2 where the reads are 16 B / lane streams)')
 sf = sw = sc = 0.0
 for k, (n, f, w) in sorted(tot.items(), key=lambda kv: -(kv[1][1] + kv[1][2])):
