@@ -954,7 +954,13 @@ def kpconv_inter_so3_bwd(grad_out, x, q_pts, s_pts, idx, kernel_points, weights,
         del G
     if need_x:
         kp, kt, rt = _host_table(kernel_points, torch.float32), _host_table(kidx, torch.int64), _host_table(ridx, torch.int64)
-        dG = mm(d2, weights.detach().reshape(36 * Cin, Cout).t())
+        W2 = weights.detach().reshape(36 * Cin, Cout)              # as a dense layer's (N = 36 Cin, K = Cout) weight: dG = dout W2^T
+        if Cout % 32 == 0 and d2.data_ptr() % 16 == 0 and P * 6 * max(Cout, 36 * Cin) < 2 ** 31:
+            # round 5: on the f16-split streaming kernel (csrc/dense_norm.hip; f32 accurate, ~2x the library's f32-MFMA rate on these shapes);
+            # its weight pieces are cached per weight version like every dense layer's (keyed on the view's address / shape, owned by `weights`)
+            dG = linear_stream(d2, weights.detach().view(36 * Cin, Cout) if weights.is_contiguous() else W2.contiguous())
+        else:
+            dG = mm(d2, W2.t())
         dx = torch.zeros_like(x)
         check(lib().se3_kpconv_so3_gather_bwd(q_pts.data_ptr(), s_pts.data_ptr(), idx.data_ptr(), dG.data_ptr(), kp.data_ptr(),
                                               kt.data_ptr(), rt.data_ptr(), float(sigma), P, Ns, NN, Cin, dx.data_ptr(), _stream()),

@@ -264,6 +264,10 @@ def gen_fullsize(variant, fname, pair, num_pairs, row_step=8):
             res[P + k] = _np(out[k])
         res[P + 'num_corr'] = np.int64(out['ref_corr_points'].shape[0])
         res[P + 'corr_score_sum'] = np.float64(out['corr_scores'].double().sum())
+        # the dense correspondences themselves (points + scores): a test can then attribute every correspondence that differs to the threshold it
+        # sits on (mutual top-k boundary, the 0.05 confidence) instead of only counting
+        res[P + 'corr_ref_points'], res[P + 'corr_src_points'] = _np(out['ref_corr_points']), _np(out['src_corr_points'])
+        res[P + 'corr_scores'] = _np(out['corr_scores'])
         ms = out['matching_scores']
         res[P + 'matching_scores_head'] = _np(ms[:4])
         res[P + 'matching_scores_rowsum'] = _np(ms[:, :-1, :-1].exp().sum((1, 2)))
