@@ -147,17 +147,25 @@ def rank_cpu_set(local_rank, local_world, available=None):
     return set(cores[local_rank * per:(local_rank + 1) * per])
 
 
-def inflight_for_cores(cores_per_rank, requested=None, batch=8):
-    """Batches in flight per rank that `cores_per_rank` host cores carry: one core per in-flight thread plus one for the process (allocator,
-    HIP runtime threads).  Default 3 (same-box optimum on an unshared host); a request above the budget is refused -- lower --inflight."""
+def inflight_for_cores(cores_per_rank, requested=None, batch=8, blocking_waits=False):
+    """Batches in flight per rank that `cores_per_rank` host cores carry.  With SPINNING waits (the runtime's default) every in-flight thread
+    is a busy core while it waits for the GPU: one core per thread plus one for the process.  With BLOCKING waits (se3et_amd asks for them at
+    import) a thread sleeps while it waits and the three threads of a rank keep 0.7 cores busy (host_cpu_s_per_step 0.012 s per 16.7 ms
+    step): three in flight on any slice, two threads per core beyond that.  Default 3 (same-box optimum on an unshared host); a request
+    above the budget is refused -- lower --inflight."""
     if batch <= 1:
         return 1 if requested is None else requested
-    budget = max(1, cores_per_rank - 1) if cores_per_rank else 3
+    if not cores_per_rank:
+        budget = 3
+    elif blocking_waits:
+        budget = max(3, 2 * cores_per_rank)
+    else:
+        budget = max(1, cores_per_rank - 1)
     if requested is None:
         return min(3, budget)
     if requested > budget and cores_per_rank:
-        raise SystemExit('bench.py: --inflight %d needs %d host cores per rank, this rank has %d: lower --inflight to %d (or give the job '
-                         'more cores)' % (requested, requested + 1, cores_per_rank, budget))
+        raise SystemExit('bench.py: --inflight %d is above what %d host core(s) per rank carry with %s waits (%d): lower --inflight (or give the '
+                         'job more cores)' % (requested, cores_per_rank, 'blocking' if blocking_waits else 'spinning', budget))
     return requested
 
 
@@ -296,7 +304,7 @@ def main():
         cores_here = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         cores_here = host_cores
-    args.inflight = inflight_for_cores(cores_here, args.inflight, PB)
+    args.inflight = inflight_for_cores(cores_here, args.inflight, PB, blocking_waits=__import__('se3et_amd').BLOCKING_SYNC_STATUS == 'set')
     if args.inflight > 1:
         args.prefetch = 0                 # every in-flight thread builds its own pyramid
     if args.prefetch is None:

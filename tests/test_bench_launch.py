@@ -90,6 +90,7 @@ def test_launcher_gives_every_rank_a_disjoint_slice_of_the_host_cores():
     assert bench.rank_cpu_set(0, 16, {0, 1, 2}) is None
     assert bench.inflight_for_cores(32, None) == 3 and bench.inflight_for_cores(3, None) == 2 and bench.inflight_for_cores(2, None) == 1
     assert bench.inflight_for_cores(8, 3) == 3
+    assert bench.inflight_for_cores(1, None, blocking_waits=True) == 3 and bench.inflight_for_cores(2, 4, blocking_waits=True) == 4      # threads that sleep while they wait
     try:
         bench.inflight_for_cores(3, 3)
         raise AssertionError('an --inflight above the core budget must be refused')
