@@ -54,6 +54,9 @@ void se3_debug_set_attention_profile(long long* stamps);
 /* Variant bits of the fused KPConv kernel (se3_kpconv_so3_fused): 1 = consecutive 16-point tiles on ONE XCD (workgroup i runs on XCD i mod 8:
  * tile = start of that XCD's contiguous tile range + i / 8) instead of tile = workgroup index -- for row orders with spatial locality. */
 void se3_debug_set_kpconv_variant(int variant);
+/* Diagnostic bits of se3_kpconv_so3_union (timing only: results are wrong with any bit set): 1 producers skip the gather product, 2 the row loads,
+ * 4 the A fragments; 8 consumers skip their MFMAs. */
+void se3_debug_set_kpconv_union_variant(int variant);
 /* Rows of dense launches (se3_linear_stream*, se3_dense_norm_fwd, se3_dense_residual_fwd, se3_linear_f16) whose values left the headroom of the
  * row's f16-split scale -- more than 2^8 times the largest magnitude of the row's first 32 values -- or held NaN / Inf, since the last
  * reset: such values are clamped to the f16 range (finite, wrong) and counted here (events: once per row, K-step and column block).  Synchronises the device; reset != 0 zeroes the count. */
@@ -172,7 +175,8 @@ int se3_group_norm_segments_bwd(const float* x, const float* x_bias, const float
  *                          (residual_affine: the shortcut branch's own pending GroupNorm), the plain residual, or nothing.  A slope of 1
  *                          is "no LeakyReLU".  channels % 4 == 0.  blocked_layout = 1: x is (points, 6, channels) and out is written as
  *                          [point][channels / 16][anchor pair][16][2], the layout se3_kpconv_so3_fused gathers whole cache lines from
- *                          (x_blocked = 1; channels % 16 == 0).
+ *                          (x_blocked = 1; channels % 16 == 0).  blocked_layout = 2: out as [point][channels / 8][6 anchors][8], the
+ *                          layout se3_kpconv_so3_union loads whole 192-byte row chunks from (x_chunked = 1; channels % 8 == 0).
  *   se3_dense_norm_fwd     UnaryBlockEPN (blocks_epn.py:639-665) = mlp + GroupNormEPN with both of the above folded into the GEMM
  *                          (csrc/dense_norm.hip): out = T_b(T_a(x)) W^T WITHOUT the bias (raw), affine_out = the table of
  *                          GroupNorm(out + linear_bias) computed from the accumulators.  weight_pieces: se3_linear_split_weights_f16.
@@ -308,6 +312,30 @@ size_t se3_kpconv_fused_split_workspace_bytes(int64_t num_queries, int in_channe
 int se3_kpconv_so3_fused(const float* x, const void* table, int64_t num_queries, int64_t num_support, int num_neighbors, int in_channels,
                          int out_channels, const void* weight_pieces, float* out, void* split_workspace, size_t split_workspace_bytes,
                          int x_blocked, void* stream);
+/* Union-staged form of se3_kpconv_so3_fused (csrc/kpconv_union.hip, round 5): a workgroup owns 16 points that are spatial neighbours, reads
+ * the DISTINCT support rows of their neighbour lists once (whole rows, 16 B per lane) and forms every point's orbit sums as a product of
+ * its orbit weights, scattered over the tile's row list, with the shared rows.  Tile membership only: no tensor is reordered.
+ *   se3_point_order_keys / _place: a spatial order of one stage's stacked points: key = cloud << 32 | 30-bit Morton code of floor(p / cell);
+ *     the caller sorts the keys (any stable sort; torch.sort) and _place writes `order` (se3_point_order_groups(lengths) * 16 int32: the point
+ *     at every position, -1 = padding; every cloud starts a new group of 16, so a cloud's groups do not depend on what else is stacked).
+ *   se3_kpconv_union_plan: per group of 16 order positions the distinct rows of the neighbour lists (se3_kpconv_neighbor_table) sorted by row
+ *     number and every list slot's index into them; groups with more than 160 distinct rows are cut into halves (sub-tiles) until they
+ *     fit.  plan: se3_kpconv_union_plan_bytes bytes; a function of (order, table) only.
+ *   se3_kpconv_so3_union: KPConvInterSO3.forward (blocks_epn.py:454-546) as se3_kpconv_so3_fused; x_chunked = 1: x in the layout written by
+ *     se3_group_norm_apply(blocked_layout = 2).  split_workspace: se3_kpconv_union_split_workspace_bytes bytes, same contract as the fused form.
+ *     Summation order inside a point's neighbourhood: ascending support row; results agree with se3_kpconv_so3_fused to f32 rounding. */
+int64_t se3_point_order_groups(const int64_t* cloud_lengths_host, int num_clouds);
+int se3_point_order_keys(const float* points, int64_t num_points, const int64_t* cloud_lengths_host, int num_clouds, float cell, int64_t* keys,
+                         void* stream);
+int se3_point_order_place(const int64_t* sorted_keys, const int64_t* sorted_index, int64_t num_points, const int64_t* cloud_lengths_host,
+                          int num_clouds, int32_t* order, void* stream);
+size_t se3_kpconv_union_plan_bytes(int64_t num_groups, int num_neighbors);
+int se3_kpconv_union_plan(const void* table, int64_t num_queries, int num_neighbors, const int32_t* order, int64_t num_groups, void* plan,
+                          size_t plan_bytes, void* stream);
+size_t se3_kpconv_union_split_workspace_bytes(int64_t num_groups, int in_channels, int out_channels);
+int se3_kpconv_so3_union(const float* x, const void* table, const void* plan, int64_t num_groups, int64_t num_queries, int64_t num_support,
+                         int num_neighbors, int in_channels, int out_channels, const void* weight_pieces, float* out, void* split_workspace,
+                         size_t split_workspace_bytes, int x_chunked, void* stream);
 size_t se3_kpconv_sums_bytes(int64_t num_queries, int in_channels);
 int se3_kpconv_so3_gather_sums(const float* x, const void* table, int64_t num_queries, int64_t num_support, int num_neighbors,
                                int in_channels, void* sums, void* stream);

@@ -18,6 +18,7 @@ SIGNATURES = {
     'se3_debug_set_bias_variant': (None, [_i32, _i32]),
     'se3_debug_set_attention_variant': (None, [_i32]),
     'se3_debug_set_kpconv_variant': (None, [_i32]),
+    'se3_debug_set_kpconv_union_variant': (None, [_i32]),
     'se3_debug_dense_saturated_rows': (ctypes.c_uint64, [_i32]),
     'se3_debug_set_attention_profile': (None, [_vp]),
     'se3_debug_kernel_timing': (None, [_i32]),
@@ -69,6 +70,13 @@ SIGNATURES = {
     'se3_kpconv_neighbor_table': (_i32, [_vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _vp, _sz, _vp]),
     'se3_kpconv_fused_split_workspace_bytes': (_sz, [_i64, _i32, _i32]),
     'se3_kpconv_so3_fused': (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _i32, _vp]),
+    'se3_point_order_groups': (_i64, [_vp, _i32]),
+    'se3_point_order_keys': (_i32, [_vp, _i64, _vp, _i32, _f32, _vp, _vp]),
+    'se3_point_order_place': (_i32, [_vp, _vp, _i64, _vp, _i32, _vp, _vp]),
+    'se3_kpconv_union_plan_bytes': (_sz, [_i64, _i32]),
+    'se3_kpconv_union_plan': (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _sz, _vp]),
+    'se3_kpconv_union_split_workspace_bytes': (_sz, [_i64, _i32, _i32]),
+    'se3_kpconv_so3_union': (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _i32, _vp]),
     'se3_rpe_bias_fwd': (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     'se3_attention_fwd': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _f32, _vp, _vp]),
     'se3_rpe_bias_stack_fwd': (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),

@@ -285,6 +285,36 @@ __global__ __launch_bounds__(256) void gn_chain_apply_blocked_kernel(ChainArgs p
   }
 }
 
+// The same, written in the layout the union-staged KPConv loads whole rows from (csrc/kpconv_union.hip, BLK): x (points, 6 anchors, C) ->
+// [point][C / 8][6 anchors][8 channels]: the 192 bytes of a point's 8-channel chunk are contiguous.  A thread owns one anchor row x 4 channels,
+// indexed by its OUTPUT position (consecutive threads write consecutive 16 bytes; reads are 32-byte pieces).
+__global__ __launch_bounds__(256) void gn_chain_apply_chunked_kernel(ChainArgs p, SegTable T) {
+  const int C = p.C, Q = 6 * C >> 2;                       // float4 per point
+  const int64_t total = (p.rows / 6) * Q;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t n = i / Q;
+    const int rem = (int)(i - n * Q);
+    const int chunk = rem / 12, q = rem - chunk * 12;
+    const int a = q >> 1, c0 = chunk * 8 + (q & 1) * 4;
+    const int64_t r = n * 6 + a;
+    const size_t so = (size_t)(T.n > 1 ? seg_of_row(T, r) : 0) * 2 * C;
+    const int64_t at = (r * C + c0) >> 2;
+    float4 o = affine_lrelu(reinterpret_cast<const float4*>(p.x)[at], p.affine_a + so, C, c0, p.slope_a);
+    if (p.affine_b) o = affine_lrelu(o, p.affine_b + so, C, c0, p.slope_b);
+    if (p.res) {
+      float4 t = reinterpret_cast<const float4*>(p.res)[at];
+      if (p.affine_r) t = affine_lrelu(t, p.affine_r + so, C, c0, 1.f);
+      o = make_float4(o.x + t.x, o.y + t.y, o.z + t.z, o.w + t.w);
+    }
+    o.x = o.x > 0.f ? o.x : o.x * p.slope_f;
+    o.y = o.y > 0.f ? o.y : o.y * p.slope_f;
+    o.z = o.z > 0.f ? o.z : o.z * p.slope_f;
+    o.w = o.w > 0.f ? o.w : o.w * p.slope_f;
+    reinterpret_cast<float4*>(p.y)[i] = o;
+  }
+}
+
 // ---- GroupNorm backward (training step) ------------------------------------------------------------------------------------------------
 // y = lrelu(xhat w + b [+ res]),  xhat = (x + xb - mean_g) rstd_g  per (segment, group).  With dz = dy lrelu'(.):
 //   dres = dz,   db[c] = sum_r dz,   dw[c] = sum_r dz xhat,
@@ -816,11 +846,16 @@ extern "C" int se3_group_norm_apply(const float* x, const float* affine_a, float
   int chunks;
   const int rc = gn_segment_table("group_norm_apply", rows, channels, segment_row_offsets_host, num_segments, false, T, chunks);
   if (rc != SE3_OK) return rc;
-  SE3_REQUIRE(!blocked_layout || (channels % 16 == 0 && rows % 6 == 0), SE3_ERR_UNSUPPORTED,
+  SE3_REQUIRE(blocked_layout != 1 || (channels % 16 == 0 && rows % 6 == 0), SE3_ERR_UNSUPPORTED,
               "group_norm_apply: the blocked layout is for (points, 6, channels) with channels %% 16 == 0 (rows %lld, channels %d)", (long long)rows,
               channels);
+  SE3_REQUIRE(blocked_layout != 2 || (channels % 8 == 0 && rows % 6 == 0), SE3_ERR_UNSUPPORTED,
+              "group_norm_apply: the chunked layout is for (points, 6, channels) with channels %% 8 == 0 (rows %lld, channels %d)", (long long)rows,
+              channels);
+  SE3_REQUIRE(blocked_layout >= 0 && blocked_layout <= 2, SE3_ERR_INVALID_ARG, "group_norm_apply: blocked_layout %d", blocked_layout);
   ChainArgs p{x, affine_a, affine_b, residual, residual_affine, slope_a, slope_b, final_slope, rows, channels, out};
-  if (blocked_layout) gn_chain_apply_blocked_kernel<<<grid_for(rows * channels / 8, 256), 256, 0, (hipStream_t)stream>>>(p, T);
+  if (blocked_layout == 2) gn_chain_apply_chunked_kernel<<<grid_for(rows * channels / 4, 256), 256, 0, (hipStream_t)stream>>>(p, T);
+  else if (blocked_layout) gn_chain_apply_blocked_kernel<<<grid_for(rows * channels / 8, 256), 256, 0, (hipStream_t)stream>>>(p, T);
   else gn_chain_apply_kernel<<<grid_for(rows * channels / 4, 256), 256, 0, (hipStream_t)stream>>>(p, T);
   SE3_CHECK_LAUNCH("group_norm_apply");
   return SE3_OK;

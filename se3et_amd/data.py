@@ -45,6 +45,9 @@ def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, 
         lengths_list.append(lengths)
         voxel_size *= 2
 
+    # a spatial order of every stage's points for the union-staged KPConv (tile membership only; csrc/kpconv_union.hip)
+    for i in range(num_stages):
+        _ops.register_point_order(points_list[i], lengths_list[i], voxel_size / 2 ** (num_stages - i))
     # all 3S-2 searches are launched back to back; their column counts are fetched with ONE synchronisation
     jobs = []
     grids = {}

@@ -232,11 +232,13 @@ def norm_stats(x, norm_weight, norm_bias, groups, eps, slope, x_bias=None):
 
 
 @_hip
-def norm_apply(x, residual=None, final_slope=1.0, blocked=False):
+def norm_apply(x, residual=None, final_slope=1.0, blocked=False, union=False):
     """A Pending made concrete, optionally + residual (tensor or one-stage Pending) and a final LeakyReLU.  blocked=True: as the fused
     KPConv's gather layout (ops.BlockedFeatures; only kpconv_inter_so3 takes it)."""
-    return _ops.group_norm_apply(x, residual, final_slope, blocked and _ops.KPCONV_BLOCKED and x.raw.dim() == 3 and x.raw.shape[1] == 6
-                                 and x.raw.shape[2] % 16 == 0)
+    kind = 0
+    if blocked and _ops.KPCONV_BLOCKED and x.raw.dim() == 3 and x.raw.shape[1] == 6:
+        kind = 2 if (union and x.raw.shape[2] % 8 == 0) else (1 if x.raw.shape[2] % 16 == 0 else 0)
+    return _ops.group_norm_apply(x, residual, final_slope, kind)
 
 
 def group_norm_rows(x, weight, bias, groups, eps, leaky_slope=None, residual=None, x_bias=None, segments=None):
@@ -252,6 +254,12 @@ def group_norm_rows(x, weight, bias, groups, eps, leaky_slope=None, residual=Non
         return AG.hip_backward(lambda x_, w, b, r, xb: _ops.group_norm_rows(x_, w, b, groups, eps, leaky_slope, r, xb, segments), bwd,
                                'group_norm_rows', x, weight, bias, residual, x_bias)
     return _ops.group_norm_rows(x, weight, bias, groups, eps, leaky_slope, residual, x_bias, segments)
+
+
+def kpconv_takes_union(q_pts, s_pts, Cin, Cout):
+    """True when kpconv_inter_so3 will run the union-staged kernel for this layer (a spatial order of q_pts is registered and the policy
+    picks it): its input is then written in that kernel's row layout (ops.BlockedFeatures kind 2)."""
+    return bool(_ops.KPCONV_UNION and q_pts.is_cuda and _ops._kpconv_union_pays(Cin, Cout, q_pts is s_pts) and _ops.point_order(q_pts) is not None)
 
 
 def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, sigma):

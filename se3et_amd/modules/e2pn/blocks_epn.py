@@ -180,7 +180,9 @@ class ResnetBottleneckBlockEPN(nn.Module):
         convolution's input and the block's output are made concrete."""
         skip = x
         if not isinstance(self.unary1, nn.Identity):
-            x = SF.norm_apply(self.unary1.pending(x), blocked=True)           # the convolution gathers rows: concrete, in its gather layout
+            conv = self.interso3.conv                                           # the convolution gathers rows: concrete, in ITS gather layout
+            x = SF.norm_apply(self.unary1.pending(x), blocked=True,
+                              union=SF.kpconv_takes_union(q_pts, s_pts, conv.in_channels, conv.out_channels))
         y = self.interso3.norm.pending(self.interso3.conv(q_pts, s_pts, neighb_inds, x), 0.1)
         y = self.norm.pending(y, 0.1)                                         # norm of the activated norm: a second statistics pass
         if 'strided' in self.block_name:

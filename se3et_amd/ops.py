@@ -622,19 +622,33 @@ class Pending:
 
 
 class BlockedFeatures:
-    """(points, 6, C) features stored as [point][C / 16][anchor pair][16 channels][2 anchors] -- the layout the fused KPConv gathers whole
-    cache lines from (group_norm_apply(blocked=True) writes it, kpconv_inter_so3 reads it); `plain()` is the ordinary tensor."""
-    __slots__ = ('data', 'shape')
+    """(points, 6, C) features in a layout a fused KPConv kernel reads whole cache lines / rows from (group_norm_apply(blocked=True) writes
+    it, kpconv_inter_so3 reads it); `plain()` is the ordinary tensor.
+    kind 1: [point][C / 16][anchor pair][16 channels][2 anchors] (csrc/kpconv_mfma.hip: per-lane gathers of 8 bytes)
+    kind 2: [point][C / 8][6 anchors][8 channels]                (csrc/kpconv_union.hip: a point's 8-channel chunk is 192 contiguous bytes)"""
+    __slots__ = ('data', 'shape', 'kind')
 
-    def __init__(self, data, shape):
-        self.data, self.shape = data, tuple(shape)
+    def __init__(self, data, shape, kind=1):
+        self.data, self.shape, self.kind = data, tuple(shape), kind
 
     def plain(self):
         n, a, c = self.shape
+        if self.kind == 2:
+            return self.data.view(n, c // 8, a, 8).permute(0, 2, 1, 3).reshape(n, a, c)
         return self.data.view(n, c // 16, a // 2, 16, 2).permute(0, 2, 4, 1, 3).reshape(n, a, c)
 
 
 KPCONV_BLOCKED = True          # False: the KPConv input in the plain layout (A/B runs)
+# The union-staged fused KPConv (csrc/kpconv_union.hip), wherever a spatial order of the query points is registered (se3et_amd/data.py):
+# SE3_KPCONV_UNION = 0 never; 1 (default) where it measured faster than the per-lane-gather kernel alone on the GPU (output widths <= 64 of the
+# stride-1 layers and the first strided one: profiles/r05_kpconv_union.txt); all: every layer
+_KPCONV_UNION_ENV = os.environ.get('SE3_KPCONV_UNION', '1')
+KPCONV_UNION = _KPCONV_UNION_ENV != '0'
+KPCONV_UNION_ALL = _KPCONV_UNION_ENV == 'all'
+
+
+def _kpconv_union_pays(Cin, Cout, same_cloud):
+    return KPCONV_UNION_ALL or (Cout <= 64 and (same_cloud or Cout <= 32))
 
 
 def dense_norm_ok(x, weight, groups):
@@ -805,10 +819,10 @@ def group_norm_apply(x, residual=None, final_slope=1.0, blocked=False):
     sl = x.slopes + [1.0]
     check(lib().se3_group_norm_apply(raw.data_ptr(), aa[0].data_ptr(), float(sl[0]), aa[1].data_ptr() if aa[1] is not None else None, float(sl[1]),
                                      res.data_ptr() if res is not None else None, res_aff.data_ptr() if res_aff is not None else None,
-                                     float(final_slope), rows, C, _i64_array(segments) if nseg > 1 else None, nseg, 1 if blocked else 0,
+                                     float(final_slope), rows, C, _i64_array(segments) if nseg > 1 else None, nseg, int(blocked),
                                      out.data_ptr(), _stream()),
           'se3_group_norm_apply')
-    return BlockedFeatures(out, raw.shape) if blocked else out
+    return BlockedFeatures(out, raw.shape, int(blocked)) if blocked else out
 
 
 _host_table_cache = {}
@@ -990,6 +1004,57 @@ def _kpconv_neighbor_table(q_pts, s_pts, idx, kernel_points, sigma, P, Ns, NN, s
     return tab
 
 
+_point_orders = {}               # points.data_ptr() -> (weakref to the points tensor, its version, order (G * 16 int32), G)
+_union_plan_cache = {}           # stream -> (key, weakrefs, plan)
+_kpconv_union_split_ws = {}
+
+
+def register_point_order(points, lengths, cell):
+    """A spatial order of one stage's stacked points (per cloud: Morton order of floor(p / cell)), kept while the `points` tensor lives: the
+    union-staged fused KPConv (csrc/kpconv_union.hip) takes its 16-point tiles along it.  Tile membership only -- no tensor is reordered.
+    Called by the pyramid builder (se3et_amd/data.py); lengths: the stage's per-cloud counts (host)."""
+    lens = [int(v) for v in (lengths.tolist() if hasattr(lengths, 'tolist') else lengths)]
+    n = points.shape[0]
+    if not KPCONV_UNION or not points.is_cuda or n == 0 or len(lens) > 32 or sum(lens) != n:
+        return None
+    points = _req(points, torch.float32, 'points', 2)
+    stream = _stream()
+    la = _i64_array(lens)
+    G = int(lib().se3_point_order_groups(la, len(lens)))
+    keys = torch.empty((n,), dtype=torch.int64, device=points.device)
+    check(lib().se3_point_order_keys(points.data_ptr(), n, la, len(lens), float(cell), keys.data_ptr(), stream), 'se3_point_order_keys')
+    sk, si = torch.sort(keys, stable=True)
+    order = torch.empty((G * 16,), dtype=torch.int32, device=points.device)
+    check(lib().se3_point_order_place(sk.data_ptr(), si.data_ptr(), n, la, len(lens), order.data_ptr(), stream), 'se3_point_order_place')
+    with _TIMING_LOCK:
+        if len(_point_orders) > 256:
+            for k in [k for k, v in _point_orders.items() if v[0]() is None]:
+                del _point_orders[k]
+        _point_orders[points.data_ptr()] = (weakref.ref(points), points._version, order, G)
+    return order
+
+
+def point_order(points):
+    hit = _point_orders.get(points.data_ptr())
+    if hit is None or hit[0]() is not points or hit[1] != points._version:
+        return None
+    return hit[2], hit[3]
+
+
+def _kpconv_union_plan(tab, q_pts, s_pts, idx, order, G, P, NN, stream):
+    """Per group of 16 order positions the distinct support rows of its neighbour lists and every list slot's index into them
+    (se3_kpconv_union_plan): a function of (order, neighbour table); kept per stream for the last table seen."""
+    hit = _union_plan_cache.get(stream.value)
+    if hit is not None and hit[0] is tab and hit[1] is order:
+        return hit[2]
+    nbytes = lib().se3_kpconv_union_plan_bytes(G, NN)
+    plan = torch.empty((nbytes,), dtype=torch.uint8, device=q_pts.device)
+    order.record_stream(torch.cuda.current_stream())
+    check(lib().se3_kpconv_union_plan(tab.data_ptr(), P, NN, order.data_ptr(), G, plan.data_ptr(), nbytes, stream), 'se3_kpconv_union_plan')
+    _union_plan_cache[stream.value] = (tab, order, plan)
+    return plan
+
+
 def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, sigma):
     """Fused matrix-core kernel (csrc/kpconv_mfma.hip) for channel counts that are multiples of (8, 32); otherwise the HIP gather of
     the slot-summed neighbourhood features (csrc/kpconv_so3.hip) + one library GEMM with the (36 Cin, Cout) weight matrix.
@@ -1010,8 +1075,10 @@ def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, s
     kp, kt, rt = _host_table(kernel_points, torch.float32), _host_table(kidx, torch.int64), _host_table(ridx, torch.int64)
     path = _kpconv_use_matrix_core(Cin, Cout, P)
     fused_ok = bool(path) and Cin % 8 == 0 and Cout % 32 == 0 and Ns * 6 * Cin < 2 ** 31 and _builtin_slot_tables(kt, rt)
-    if blocked and not (fused_ok and path != 'sums' and Cin % 16 == 0):
-        x, blocked = x.plain().contiguous(), False              # (only the fused kernel reads the blocked layout)
+    po = point_order(q_pts) if (fused_ok and path is True and KPCONV_UNION and _kpconv_union_pays(Cin, Cout, q_pts is s_pts)) else None
+    want = 0 if not blocked else x.kind
+    if blocked and not (fused_ok and path != 'sums' and ((want == 2 and po is not None) or (want == 1 and po is None and Cin % 16 == 0))):
+        x, blocked = x.plain().contiguous(), False              # (each fused kernel reads its own blocked layout only)
     if fused_ok:
         if blocked:
             x = xb
@@ -1028,6 +1095,18 @@ def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, s
                   'se3_kpconv_so3_gather_sums')
             check(lib().se3_kpconv_so3_contract_f16(Hs.data_ptr(), Wp.data_ptr(), P, Cin, Cout, out.data_ptr(), stream),
                   'se3_kpconv_so3_contract_f16')
+            return out
+        if po is not None:
+            # union-staged form (csrc/kpconv_union.hip): 16 spatial neighbours per workgroup, their distinct support rows read once
+            order, G = po
+            plan = _kpconv_union_plan(tab, q_pts, s_pts, idx, order, G, P, NN, stream)
+            sbytes = lib().se3_kpconv_union_split_workspace_bytes(G, Cin, Cout) if KPCONV_SPLIT else 0
+            sws = _zeroed_workspace(_kpconv_union_split_ws, x.device, stream, sbytes) if sbytes else None
+            with _timed('kpconv_fused', 2.0 * 6 * P * 36 * Cin * Cout + 2.0 * P * NN * 16 * 6 * Cin):
+                _check_counters(lib().se3_kpconv_so3_union(x.data_ptr(), tab.data_ptr(), plan.data_ptr(), G, P, Ns, NN, Cin, Cout, Wp.data_ptr(),
+                                                           out.data_ptr(), sws.data_ptr() if sws is not None else None,
+                                                           sws.numel() if sws is not None else 0, 1 if blocked else 0, stream),
+                                'se3_kpconv_so3_union', sws)
             return out
         sbytes = lib().se3_kpconv_fused_split_workspace_bytes(P, Cin, Cout) if KPCONV_SPLIT else 0
         sws = _zeroed_workspace(_kpconv_split_ws, x.device, stream, sbytes) if sbytes else None

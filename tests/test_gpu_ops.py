@@ -1169,6 +1169,96 @@ def test_fused_kpconv_edge_shapes(P, Ns, NN, Cin, Cout, box):
         assert torch.equal(SF.kpconv_inter_so3(*args).cpu(), again)
 
 
+@pytest.mark.parametrize('P,Ns,NN,Cin,Cout,box,clouds', [(77, 90, 38, 24, 32, 0.05, 1), (130, 130, 40, 40, 96, 0.04, 2), (33, 64, 36, 8, 64, 0.05, 1),
+                                                         (200, 260, 48, 72, 160, 0.06, 3), (16, 16, 16, 16, 32, 0.03, 1), (95, 400, 64, 64, 256, 0.08, 2),
+                                                         (100, 150, 36, 128, 128, 0.05, 1), (700, 900, 38, 256, 256, 0.12, 4), (1500, 1500, 64, 32, 64, 0.2, 3)])
+def test_union_kpconv_edge_shapes(P, Ns, NN, Cin, Cout, box, clouds):
+    """The union-staged fused kernel (csrc/kpconv_union.hip) at the corners of the per-lane-gather kernel's test: tables wider than 32, odd chunk
+    counts, K-split consumers, point counts that are no multiple of the 16-point group, 64 neighbours -- plus what is its own: several
+    clouds (every cloud starts a new group: padding positions), groups whose distinct rows exceed the 160-row cap (dense boxes: several
+    passes per group), the chunked row layout, the channel split, bit-identical repeats.  Against the float64 formula and the f32 path."""
+    from se3et_amd import functional as SF
+    from se3et_amd import ops
+    g = torch.Generator().manual_seed(P + Cin)
+    radius, sigma = 0.0625, 0.05
+    s_pts = torch.rand(Ns, 3, generator=g) * box
+    q_pts = s_pts[torch.randperm(Ns, generator=g)[:P]].contiguous()
+    d = ((q_pts[:, None] - s_pts[None]) ** 2).sum(-1)
+    idx = d.topk(min(NN, Ns), dim=1, largest=False)[1]
+    if idx.shape[1] < NN:
+        idx = torch.cat((idx, torch.full((P, NN - idx.shape[1]), Ns, dtype=idx.dtype)), 1)
+    idx[torch.cat((d, torch.full((P, 1), 1e9)), 1).gather(1, idx) > radius ** 2] = Ns
+    x = torch.randn(Ns, 6, Cin, generator=g)
+    st = _conv_state(Cin, Cout, radius)
+    qc = q_pts.cuda()
+    args = (x.cuda(), qc, s_pts.cuda(), idx.cuda(), st['kernel_points'].cuda(), st['weights'].cuda(),
+            st['kidx_rot'][:, 0, :].cuda(), st['ridx_rot'][0].cuda(), sigma)
+    # the query rows as `clouds` stacked clouds of uneven sizes (tile membership only: any partition gives the same sums up to their order)
+    cuts = sorted(set([0, P] + [int(P * (i + 1) ** 2 / (clouds ** 2 + 1)) for i in range(clouds - 1)]))
+    lens = [b - a for a, b in zip(cuts[:-1], cuts[1:])]
+    saved = (ops.KPCONV_UNION, ops.KPCONV_UNION_ALL, ops.KPCONV_MATRIX_CORE)
+    try:
+        ops.KPCONV_UNION = ops.KPCONV_UNION_ALL = True
+        order = ops.register_point_order(qc, lens, radius / 2.5)
+        assert order is not None
+        o = order.cpu()
+        assert sorted(o[o >= 0].tolist()) == list(range(P))                      # every point exactly once
+        groups = o.view(-1, 16)
+        start, row = 0, 0
+        for n in lens:                                                          # every cloud's points fill whole groups of their own
+            gcount = (n + 15) // 16
+            mine = groups[start:start + gcount].reshape(-1)
+            assert sorted(mine[mine >= 0].tolist()) == list(range(row, row + n))
+            start, row = start + gcount, row + n
+        assert start == groups.shape[0]
+        union = SF.kpconv_inter_so3(*args).cpu()
+        assert torch.equal(SF.kpconv_inter_so3(*args).cpu(), union)             # the plan is a pure function of (order, table): identical repeats
+        ops.KPCONV_UNION = False
+        fused = SF.kpconv_inter_so3(*args).cpu()
+        ops.KPCONV_MATRIX_CORE = False
+        f32 = SF.kpconv_inter_so3(*args).cpu()
+        ops.KPCONV_MATRIX_CORE = saved[2]
+        ops.KPCONV_UNION = True
+        xs = torch.cat((x, torch.zeros(1, 6, Cin))).double()
+        sp = torch.cat((s_pts, torch.full((1, 3), 1e6))).double()
+        nb = sp[idx] - q_pts.double()[:, None]
+        w = (1 - (nb[:, :, None] - st['kernel_points'].double()[None, None]).norm(dim=-1) / sigma).clamp(min=0)
+        Fk = torch.einsum('pnk,pnac->pkac', w, xs[idx])
+        W = st['weights'].double()[st['kidx_rot'][:, 0, :][:, None, :], st['ridx_rot'][0][None, :, :]]
+        ref = torch.einsum('pkac,karcd->prd', Fk, W)
+        e_old = float((f32.double() - ref).abs().max())
+        e_new = float((union.double() - ref).abs().max())
+        assert e_new <= max(2 * e_old, 2e-6 * float(ref.abs().max())), (e_new, e_old)
+        assert float((union - fused).abs().max()) <= 4e-6 * float(ref.abs().max())
+        # the chunked row layout [point][Cin / 8][6 anchors][8 channels]: the same arithmetic
+        xb = ops.BlockedFeatures(x.view(Ns, 6, Cin // 8, 8).permute(0, 2, 1, 3).contiguous().cuda(), (Ns, 6, Cin), 2)
+        assert torch.equal(xb.plain().cpu(), x)
+        assert torch.equal(SF.kpconv_inter_so3(xb, *args[1:]).cpu(), union)
+        # ... and a kind-1 blocked input is converted, not misread
+        if Cin % 16 == 0:
+            xb1 = ops.BlockedFeatures(x.view(Ns, 3, 2, Cin // 16, 16).permute(0, 3, 1, 4, 2).contiguous().cuda(), (Ns, 6, Cin), 1)
+            assert torch.equal(SF.kpconv_inter_so3(xb1, *args[1:]).cpu(), union)
+        G = order.numel() // 16
+        if ops.lib().se3_kpconv_union_split_workspace_bytes(G, Cin, Cout):
+            ops.KPCONV_SPLIT = False
+            try:
+                whole = SF.kpconv_inter_so3(*args).cpu()
+            finally:
+                ops.KPCONV_SPLIT = True
+            assert float((whole - union).abs().max()) <= 5e-6 * float(ref.abs().max())
+            assert torch.equal(SF.kpconv_inter_so3(*args).cpu(), union)         # the arrival counters are back at zero
+        # the passes of the plan: the dense box of the last case exceeds the cap
+        hit = ops._union_plan_cache.get(ops._stream().value)
+        plan = hit[2].cpu().numpy()
+        a16 = lambda v: (v + 15) & ~15
+        nsub = plan[a16(G * 64):a16(G * 64) + 4 * G].view(np.int32)
+        assert nsub.min() >= 1 and nsub.max() <= 16
+        if P == 1500:
+            assert nsub.max() > 1
+    finally:
+        ops.KPCONV_UNION, ops.KPCONV_UNION_ALL, ops.KPCONV_MATRIX_CORE = saved
+
+
 def test_neighbor_table_trim_marks_each_pairs_surplus_columns():
     """csrc/radius_neighbors.hip: the stacked neighbour table cut to the batch's width with the columns past every PAIR's own width set to
     -1 -- against the column copy + per-pair strided fill it replaces."""
