@@ -325,6 +325,12 @@ int se3_kpconv_so3_fused(const float* x, const void* table, int64_t num_queries,
  *     se3_group_norm_apply(blocked_layout = 2).  split_workspace: se3_kpconv_union_split_workspace_bytes bytes, same contract as the fused form.
  *     Summation order inside a point's neighbourhood: ascending support row; results agree with se3_kpconv_so3_fused to f32 rounding. */
 int64_t se3_point_order_groups(const int64_t* cloud_lengths_host, int num_clouds);
+/* (the same order in one launch, one workgroup per cloud sorting in LDS: clouds of at most 8192 points, SE3_ERR_UNSUPPORTED beyond) */
+int se3_point_order(const float* points, int64_t num_points, const int64_t* cloud_lengths_host, int num_clouds, float cell, int32_t* order,
+                   void* stream);
+/* (up to four stages of one pyramid in one launch: arrays of the single-stage arguments) */
+int se3_point_order_stages(const float* const* points, const int64_t* num_points, const int64_t* const* cloud_lengths_host, const int* num_clouds,
+                           const float* cell, int32_t* const* order, int num_stages, void* stream);
 int se3_point_order_keys(const float* points, int64_t num_points, const int64_t* cloud_lengths_host, int num_clouds, float cell, int64_t* keys,
                          void* stream);
 int se3_point_order_place(const int64_t* sorted_keys, const int64_t* sorted_index, int64_t num_points, const int64_t* cloud_lengths_host,

@@ -71,6 +71,8 @@ SIGNATURES = {
     'se3_kpconv_fused_split_workspace_bytes': (_sz, [_i64, _i32, _i32]),
     'se3_kpconv_so3_fused': (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _i32, _vp]),
     'se3_point_order_groups': (_i64, [_vp, _i32]),
+    'se3_point_order': (_i32, [_vp, _i64, _vp, _i32, _f32, _vp, _vp]),
+    'se3_point_order_stages': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     'se3_point_order_keys': (_i32, [_vp, _i64, _vp, _i32, _f32, _vp, _vp]),
     'se3_point_order_place': (_i32, [_vp, _vp, _i64, _vp, _i32, _vp, _vp]),
     'se3_kpconv_union_plan_bytes': (_sz, [_i64, _i32]),

@@ -88,45 +88,38 @@ NeighborTable table_views(const void* table, int64_t P, int NN) {
   return t;
 }
 
-// One workgroup per group of 16 order positions: its list entries (row, owner, slot) sorted by row; per candidate range of owners the
+// One WAVE per group of 16 order positions: its list entries (row, owner, slot) sorted by row in LDS; per candidate range of owners the
 // distinct rows counted; a range whose union fits (or a single point) becomes a sub-tile, any other is halved.
-__global__ __launch_bounds__(256) void kpconv_union_plan_kernel(const int* __restrict__ nbr, const int* __restrict__ cnt, int NNp,
-                                                                const int* __restrict__ order_in, PlanViews pv) {
+__global__ __launch_bounds__(64) void kpconv_union_plan_kernel(const int* __restrict__ nbr, const int* __restrict__ cnt, int NNp,
+                                                               const int* __restrict__ order_in, PlanViews pv) {
   __shared__ unsigned long long keys[1024];
-  __shared__ int pids[16], cnts[16], offs[17];
-  __shared__ int wsum[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = threadIdx.x;
   const int64_t group = blockIdx.x;
-  if (tid < 16) {
-    const int pid = order_in[group * 16 + tid];
-    pids[tid] = pid;
-    int c = pid >= 0 ? cnt[pid] : 0;
-    cnts[tid] = c < 64 ? c : 64;
-    pv.order[group * 16 + tid] = pid;
+  // lanes 0-15: the group's points and their list lengths; exclusive prefix = first entry of every owner
+  const int pid = lane < 16 ? order_in[group * 16 + lane] : -1;
+  int c = pid >= 0 ? cnt[pid] : 0;
+  c = c < 64 ? c : 64;
+  if (lane < 16) pv.order[group * 16 + lane] = pid;
+  int off = c;
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) {
+    const int v = __shfl_up(off, o);
+    if (lane >= o) off += v;
   }
-  for (int e = tid; e < 1024; e += 256) keys[e] = ~0ull;
-  __syncthreads();
-  if (tid == 0) {
-    int s = 0;
-    for (int i = 0; i < 16; i++) {
-      offs[i] = s;
-      s += cnts[i];
-    }
-    offs[16] = s;
-  }
-  __syncthreads();
-  const int E = offs[16];
-  for (int i = 0; i < 16; i++) {
-    const int c = cnts[i];
-    for (int s = tid; s < c; s += 256)
-      keys[offs[i] + s] = ((unsigned long long)(unsigned)nbr[(int64_t)pids[i] * NNp + s] << 10) | (unsigned)(i << 6) | (unsigned)s;
-  }
+  const int E = __shfl(off, 15);
+  off -= c;
   int n2 = 64;
   while (n2 < E) n2 <<= 1;
+  for (int e = lane; e < n2; e += 64) keys[e] = ~0ull;
+  __syncthreads();
+  for (int i = 0; i < 16; i++) {
+    const int ci = __shfl(c, i), oi = __shfl(off, i), pi = __shfl(pid, i);
+    if (lane < ci) keys[oi + lane] = ((unsigned long long)(unsigned)nbr[(int64_t)pi * NNp + lane] << 10) | (unsigned)(i << 6) | (unsigned)lane;
+  }
   __syncthreads();
   for (int k = 2; k <= n2; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < (n2 >> 1); t += 256) {
+      for (int t = lane; t < (n2 >> 1); t += 64) {
         const int a = ((t & ~(j - 1)) << 1) | (t & (j - 1)), b = a | j;
         const bool up = (a & k) == 0;
         const unsigned long long x = keys[a], y = keys[b];
@@ -137,7 +130,8 @@ __global__ __launch_bounds__(256) void kpconv_union_plan_kernel(const int* __res
       }
       __syncthreads();
     }
-  // uniform work stack of owner ranges (depth <= 5)
+  // uniform work stack of owner ranges (depth <= 5); a lane owns the entries lane * per .. + per - 1
+  const int per = n2 >> 6;
   int st_lo[6], st_n[6], sp = 0, ustart = 0, nsub = 0;
   st_lo[0] = 0;
   st_n[0] = 16;
@@ -147,61 +141,58 @@ __global__ __launch_bounds__(256) void kpconv_union_plan_kernel(const int* __res
   while (sp > 0) {
     sp--;
     const int lo = st_lo[sp], n = st_n[sp];
-    // entries 4 tid .. 4 tid + 3
-    unsigned long long kk[4];
-    bool fl[4], first[4];
+    // pass 1: distinct rows of the range among this lane's entries (an entry is FIRST when no earlier entry of the range has its row)
     int mine = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int e = 4 * tid + q;
-      kk[q] = e < E ? keys[e] : ~0ull;
-      const int owner = (int)((kk[q] >> 6) & 15);
-      fl[q] = e < E && owner >= lo && owner < lo + n;
-      first[q] = fl[q];
-      if (fl[q]) {
-        const unsigned long long row = kk[q] >> 10;
-        for (int j = e - 1; j >= 0; j--) {
-          const unsigned long long o = keys[j];
-          if ((o >> 10) != row) break;
-          const int ow = (int)((o >> 6) & 15);
-          if (ow >= lo && ow < lo + n) {
-            first[q] = false;
-            break;
-          }
+    for (int q = 0; q < per; q++) {
+      const int e = lane * per + q;
+      if (e >= E) break;
+      const unsigned long long kq = keys[e];
+      const int owner = (int)((kq >> 6) & 15);
+      if (owner < lo || owner >= lo + n) continue;
+      bool first = true;
+      for (int j = e - 1; j >= 0; j--) {
+        const unsigned long long o = keys[j];
+        if ((o >> 10) != (kq >> 10)) break;
+        const int ow = (int)((o >> 6) & 15);
+        if (ow >= lo && ow < lo + n) {
+          first = false;
+          break;
         }
       }
-      mine += first[q] ? 1 : 0;
+      mine += first ? 1 : 0;
     }
-    // inclusive scan of `mine` over the 256 threads
     int incl = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const int v = __shfl_up(incl, o);
       if (lane >= o) incl += v;
     }
-    __syncthreads();                    // (wsum of the previous iteration has been read)
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int before = 0, U = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-      if (w < wave) before += wsum[w];
-      U += wsum[w];
-    }
+    const int U = __shfl(incl, 63);
     if (U <= kUCap || n == 1) {
-      int run = before + incl - mine;    // firsts in front of this thread's entries
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        if (first[q]) {
-          if (run < kUCap) urow[ustart + run] = (int)(kk[q] >> 10);
+      int run = incl - mine;                                             // firsts in front of this lane's entries
+      for (int q = 0; q < per; q++) {
+        const int e = lane * per + q;
+        if (e >= E) break;
+        const unsigned long long kq = keys[e];
+        const int owner = (int)((kq >> 6) & 15);
+        if (owner < lo || owner >= lo + n) continue;
+        bool first = true;
+        for (int j = e - 1; j >= 0; j--) {
+          const unsigned long long o = keys[j];
+          if ((o >> 10) != (kq >> 10)) break;
+          const int ow = (int)((o >> 6) & 15);
+          if (ow >= lo && ow < lo + n) {
+            first = false;
+            break;
+          }
+        }
+        if (first) {
+          if (run < kUCap) urow[ustart + run] = (int)(kq >> 10);
           run++;
         }
-        if (fl[q]) {
-          const int owner = (int)((kk[q] >> 6) & 15), slot = (int)(kk[q] & 63);
-          loc[owner * NNp + slot] = (unsigned char)(run - 1 < kUCap ? run - 1 : kUCap - 1);
-        }
+        loc[owner * NNp + (int)(kq & 63)] = (unsigned char)(run - 1 < kUCap ? run - 1 : kUCap - 1);
       }
-      if (tid == 0) pv.desc[group * kMaxSub + nsub] = make_int4(lo, n, ustart, U < kUCap ? U : kUCap);
+      if (lane == 0) pv.desc[group * kMaxSub + nsub] = make_int4(lo, n, ustart, U < kUCap ? U : kUCap);
       ustart += U < kUCap ? U : kUCap;
       nsub++;
     } else {
@@ -213,7 +204,7 @@ __global__ __launch_bounds__(256) void kpconv_union_plan_kernel(const int* __res
       sp++;
     }
   }
-  if (tid == 0) pv.nsub[group] = nsub;
+  if (lane == 0) pv.nsub[group] = nsub;
 }
 
 // ---- spatial order of a stage's points (tile membership) -----------------------------------------------------------------------------
@@ -252,6 +243,65 @@ __global__ void point_order_place_kernel(const int64_t* __restrict__ sorted_keys
     pad += (16 - (len & 15)) & 15;
   }
   order[r + pad] = (int)sorted_idx[r];
+}
+
+// The same order in ONE launch for clouds of up to 8192 points: one workgroup per cloud sorts (Morton code, local index) in LDS.
+constexpr int kOrderCap = 8192;
+struct OrderStages {                   // up to four stages of one pyramid per launch (blockIdx.y)
+  const float* pts[4];
+  int* order[4];
+  float inv_cell[4];
+  CloudOffsets co[4];
+};
+__global__ __launch_bounds__(1024) void point_order_cloud_kernel(const OrderStages S) {
+  extern __shared__ __align__(16) unsigned long long okeys[];
+  const int cloud = blockIdx.x, tid = threadIdx.x;
+  const float* __restrict__ pts = S.pts[0];
+  int* __restrict__ order = S.order[0];
+  float inv_cell = S.inv_cell[0];
+  const CloudOffsets* cop = &S.co[0];
+#pragma unroll
+  for (int y = 1; y < 4; y++)
+    if ((int)blockIdx.y == y) {
+      pts = S.pts[y];
+      order = S.order[y];
+      inv_cell = S.inv_cell[y];
+      cop = &S.co[y];
+    }
+  const CloudOffsets& co = *cop;
+  if (cloud >= co.n) return;
+  const int64_t start = co.start[cloud];
+  const int n = (int)(co.start[cloud + 1] - start);
+  int64_t pos0 = 0;                                                      // first order position of this cloud: whole groups of the clouds before
+  for (int c = 0; c < cloud; c++) pos0 += ((co.start[c + 1] - co.start[c] + 15) >> 4) << 4;
+  int n2 = 64;
+  while (n2 < n) n2 <<= 1;
+  for (int i = tid; i < n2; i += 1024) {
+    unsigned long long k = ~0ull;
+    if (i < n) {
+      const float* p = pts + 3 * (start + i);
+      const int x = (int)floorf(p[0] * inv_cell) + 512, y = (int)floorf(p[1] * inv_cell) + 512, z = (int)floorf(p[2] * inv_cell) + 512;
+      const unsigned m = spread10((unsigned)x) | (spread10((unsigned)y) << 1) | (spread10((unsigned)z) << 2);
+      k = ((unsigned long long)m << 16) | (unsigned)i;
+    }
+    okeys[i] = k;
+  }
+  __syncthreads();
+  for (int k = 2; k <= n2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (n2 >> 1); t += 1024) {
+        const int a = ((t & ~(j - 1)) << 1) | (t & (j - 1)), b = a | j;
+        const bool up = (a & k) == 0;
+        const unsigned long long x = okeys[a], y = okeys[b];
+        if ((x > y) == up) {
+          okeys[a] = y;
+          okeys[b] = x;
+        }
+      }
+      __syncthreads();
+    }
+  const int npad = ((n + 15) >> 4) << 4;
+  for (int r = tid; r < npad; r += 1024) order[pos0 + r] = r < n ? (int)(start + (int64_t)(okeys[r] & 0xffffu)) : -1;
 }
 
 // ---- the kernel ---------------------------------------------------------------------------------------------------------------------------
@@ -784,6 +834,55 @@ extern "C" int64_t se3_point_order_groups(const int64_t* cloud_lengths_host, int
   return g;
 }
 
+extern "C" int se3_point_order_stages(const float* const* points, const int64_t* num_points, const int64_t* const* cloud_lengths_host,
+                                      const int* num_clouds, const float* cell, int32_t* const* order, int num_stages, void* stream) {
+  SE3_REQUIRE(points && num_points && cloud_lengths_host && num_clouds && cell && order, SE3_ERR_INVALID_ARG, "point_order: null pointer");
+  SE3_REQUIRE(num_stages >= 1 && num_stages <= 4, SE3_ERR_UNSUPPORTED, "point_order: %d stages per call (max 4)", num_stages);
+  OrderStages S;
+  int64_t longest = 0, total = 0;
+  int max_clouds = 0;
+  for (int y = 0; y < 4; y++) {
+    const int yy = y < num_stages ? y : 0;
+    SE3_REQUIRE(points[yy] && order[yy] && cloud_lengths_host[yy], SE3_ERR_INVALID_ARG, "point_order: null pointer");
+    SE3_REQUIRE(num_clouds[yy] >= 1 && num_clouds[yy] <= SE3_MAX_BATCH && cell[yy] > 0.f, SE3_ERR_UNSUPPORTED, "point_order: %d clouds (max %d)",
+                num_clouds[yy], SE3_MAX_BATCH);
+    S.pts[y] = points[yy];
+    S.order[y] = order[yy];
+    S.inv_cell[y] = 1.f / cell[yy];
+    S.co[y].n = num_clouds[yy];
+    S.co[y].start[0] = 0;
+    for (int c = 0; c < num_clouds[yy]; c++) {
+      S.co[y].start[c + 1] = S.co[y].start[c] + cloud_lengths_host[yy][c];
+      longest = cloud_lengths_host[yy][c] > longest ? cloud_lengths_host[yy][c] : longest;
+    }
+    if (y < num_stages) {
+      SE3_REQUIRE(S.co[y].start[num_clouds[yy]] == num_points[yy], SE3_ERR_INVALID_ARG, "point_order: cloud lengths do not add up to the point count");
+      total += num_points[yy];
+      max_clouds = num_clouds[yy] > max_clouds ? num_clouds[yy] : max_clouds;
+    }
+  }
+  SE3_REQUIRE(longest <= kOrderCap, SE3_ERR_UNSUPPORTED, "point_order: a cloud of %lld points (one-launch form: at most %d; use se3_point_order_keys + a sort + _place)",
+              (long long)longest, kOrderCap);
+  if (total == 0) return SE3_OK;
+  int n2 = 64;
+  while (n2 < longest) n2 <<= 1;
+  const size_t lds = (size_t)n2 * sizeof(unsigned long long);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&point_order_cloud_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(kOrderCap * sizeof(unsigned long long)));
+    attr_set = true;
+  }
+  point_order_cloud_kernel<<<dim3((unsigned)max_clouds, (unsigned)num_stages), 1024, lds, (hipStream_t)stream>>>(S);
+  SE3_CHECK_LAUNCH("point_order");
+  return SE3_OK;
+}
+
+extern "C" int se3_point_order(const float* points, int64_t num_points, const int64_t* cloud_lengths_host, int num_clouds, float cell,
+                               int32_t* order, void* stream) {
+  return se3_point_order_stages(&points, &num_points, &cloud_lengths_host, &num_clouds, &cell, &order, 1, stream);
+}
+
 extern "C" int se3_point_order_keys(const float* points, int64_t num_points, const int64_t* cloud_lengths_host, int num_clouds, float cell,
                                     int64_t* keys, void* stream) {
   SE3_REQUIRE(points && keys && cloud_lengths_host, SE3_ERR_INVALID_ARG, "point_order_keys: null pointer");
@@ -834,7 +933,7 @@ extern "C" int se3_kpconv_union_plan(const void* table, int64_t num_queries, int
   if (num_groups == 0) return SE3_OK;
   const NeighborTable t = table_views(table, num_queries, num_neighbors);
   const PlanViews pv = plan_views(plan, num_groups, t.NNp);
-  kpconv_union_plan_kernel<<<(unsigned)num_groups, 256, 0, (hipStream_t)stream>>>(t.nbr, t.cnt, t.NNp, order, pv);
+  kpconv_union_plan_kernel<<<(unsigned)num_groups, 64, 0, (hipStream_t)stream>>>(t.nbr, t.cnt, t.NNp, order, pv);
   SE3_CHECK_LAUNCH("kpconv_union_plan");
   return SE3_OK;
 }

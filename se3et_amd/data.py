@@ -46,8 +46,10 @@ def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, 
         voxel_size *= 2
 
     # a spatial order of every stage's points for the union-staged KPConv (tile membership only; csrc/kpconv_union.hip)
-    for i in range(num_stages):
-        _ops.register_point_order(points_list[i], lengths_list[i], voxel_size / 2 ** (num_stages - i))
+    # (the default policy runs that kernel on the layers whose queries are stage 0 / 1 points: ops._kpconv_union_pays)
+    ns = num_stages if _ops.KPCONV_UNION_ALL else min(2, num_stages)
+    if _ops.KPCONV_UNION:
+        _ops.register_point_orders(points_list[:ns], lengths_list[:ns], [voxel_size / 2 ** (num_stages - i) for i in range(ns)])
     # all 3S-2 searches are launched back to back; their column counts are fetched with ONE synchronisation
     jobs = []
     grids = {}

@@ -647,6 +647,10 @@ KPCONV_UNION = _KPCONV_UNION_ENV != '0'
 KPCONV_UNION_ALL = _KPCONV_UNION_ENV == 'all'
 
 
+if os.environ.get('SE3_KPCONV_UNION_WGS'):        # A/B runs: workgroups per launch of the union-staged kernel (default: 256 up to 64 output channels, 1024 beyond)
+    lib().se3_debug_set_kpconv_union_variant(int(os.environ['SE3_KPCONV_UNION_WGS']) << 8)
+
+
 def _kpconv_union_pays(Cin, Cout, same_cloud):
     return KPCONV_UNION_ALL or (Cout <= 64 and (same_cloud or Cout <= 32))
 
@@ -1021,17 +1025,47 @@ def register_point_order(points, lengths, cell):
     stream = _stream()
     la = _i64_array(lens)
     G = int(lib().se3_point_order_groups(la, len(lens)))
-    keys = torch.empty((n,), dtype=torch.int64, device=points.device)
-    check(lib().se3_point_order_keys(points.data_ptr(), n, la, len(lens), float(cell), keys.data_ptr(), stream), 'se3_point_order_keys')
-    sk, si = torch.sort(keys, stable=True)
     order = torch.empty((G * 16,), dtype=torch.int32, device=points.device)
-    check(lib().se3_point_order_place(sk.data_ptr(), si.data_ptr(), n, la, len(lens), order.data_ptr(), stream), 'se3_point_order_place')
+    if max(lens) <= 8192:
+        # one launch: a workgroup per cloud sorts (Morton code, index) in LDS
+        check(lib().se3_point_order(points.data_ptr(), n, la, len(lens), float(cell), order.data_ptr(), stream), 'se3_point_order')
+    else:
+        keys = torch.empty((n,), dtype=torch.int64, device=points.device)
+        check(lib().se3_point_order_keys(points.data_ptr(), n, la, len(lens), float(cell), keys.data_ptr(), stream), 'se3_point_order_keys')
+        sk, si = torch.sort(keys, stable=True)
+        check(lib().se3_point_order_place(sk.data_ptr(), si.data_ptr(), n, la, len(lens), order.data_ptr(), stream), 'se3_point_order_place')
     with _TIMING_LOCK:
         if len(_point_orders) > 256:
             for k in [k for k, v in _point_orders.items() if v[0]() is None]:
                 del _point_orders[k]
         _point_orders[points.data_ptr()] = (weakref.ref(points), points._version, order, G)
     return order
+
+
+def register_point_orders(points_list, lengths_list, cells):
+    """register_point_order for several stages of one pyramid, in ONE launch when every cloud has at most 8192 points."""
+    lens = [[int(v) for v in (l.tolist() if hasattr(l, 'tolist') else l)] for l in lengths_list]
+    ok = KPCONV_UNION and 1 <= len(points_list) <= 4 and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.shape[0] > 0
+                                                             and len(l) <= 32 and sum(l) == p.shape[0] and max(l) <= 8192
+                                                             for p, l in zip(points_list, lens))
+    if not ok:
+        return [register_point_order(p, l, c) for p, l, c in zip(points_list, lengths_list, cells)]
+    S = len(points_list)
+    las = [_i64_array(l) for l in lens]
+    Gs = [int(lib().se3_point_order_groups(la, len(l))) for la, l in zip(las, lens)]
+    orders = [torch.empty((G * 16,), dtype=torch.int32, device=p.device) for G, p in zip(Gs, points_list)]
+    vp = ctypes.c_void_p
+    check(lib().se3_point_order_stages((vp * S)(*[p.data_ptr() for p in points_list]), _i64_array([p.shape[0] for p in points_list]),
+                                       (vp * S)(*[ctypes.cast(la, vp).value for la in las]), (ctypes.c_int * S)(*[len(l) for l in lens]),
+                                       (ctypes.c_float * S)(*[float(c) for c in cells]), (vp * S)(*[o.data_ptr() for o in orders]), S, _stream()),
+          'se3_point_order_stages')
+    with _TIMING_LOCK:
+        if len(_point_orders) > 256:
+            for k in [k for k, v in _point_orders.items() if v[0]() is None]:
+                del _point_orders[k]
+        for p, o, G in zip(points_list, orders, Gs):
+            _point_orders[p.data_ptr()] = (weakref.ref(p), p._version, o, G)
+    return orders
 
 
 def point_order(points):
@@ -1044,14 +1078,16 @@ def point_order(points):
 def _kpconv_union_plan(tab, q_pts, s_pts, idx, order, G, P, NN, stream):
     """Per group of 16 order positions the distinct support rows of its neighbour lists and every list slot's index into them
     (se3_kpconv_union_plan): a function of (order, neighbour table); kept per stream for the last table seen."""
+    # (the plan reads the table's compacted lists and counts only -- the geometry, not the layer's kernel points: layers with tables of
+    # their own over the same (queries, supports, neighbour indices) share it)
     hit = _union_plan_cache.get(stream.value)
-    if hit is not None and hit[0] is tab and hit[1] is order:
+    if hit is not None and hit[1] is order and all(r() is t for r, t in zip(hit[0], (q_pts, s_pts, idx))) and hit[3] == (q_pts._version, s_pts._version, idx._version):
         return hit[2]
     nbytes = lib().se3_kpconv_union_plan_bytes(G, NN)
     plan = torch.empty((nbytes,), dtype=torch.uint8, device=q_pts.device)
     order.record_stream(torch.cuda.current_stream())
     check(lib().se3_kpconv_union_plan(tab.data_ptr(), P, NN, order.data_ptr(), G, plan.data_ptr(), nbytes, stream), 'se3_kpconv_union_plan')
-    _union_plan_cache[stream.value] = (tab, order, plan)
+    _union_plan_cache[stream.value] = (tuple(weakref.ref(t) for t in (q_pts, s_pts, idx)), order, plan, (q_pts._version, s_pts._version, idx._version))
     return plan
 
 

@@ -1203,6 +1203,17 @@ def test_union_kpconv_edge_shapes(P, Ns, NN, Cin, Cout, box, clouds):
         assert order is not None
         o = order.cpu()
         assert sorted(o[o >= 0].tolist()) == list(range(P))                      # every point exactly once
+        # the one-launch order (a workgroup per cloud sorting in LDS) is the order of the general form (keys + a stable sort + placement)
+        la = ops._i64_array(lens)
+        keys = torch.empty((P,), dtype=torch.int64, device='cuda')
+        ops.check(ops.lib().se3_point_order_keys(qc.data_ptr(), P, la, len(lens), radius / 2.5, keys.data_ptr(), ops._stream()), 'keys')
+        sk, si = torch.sort(keys, stable=True)
+        order2 = torch.empty_like(order)
+        ops.check(ops.lib().se3_point_order_place(sk.data_ptr(), si.data_ptr(), P, la, len(lens), order2.data_ptr(), ops._stream()), 'place')
+        assert torch.equal(order, order2)
+        both = ops.register_point_orders([qc, args[2]], [lens, [Ns]], [radius / 2.5, radius / 2.5])      # two stages in one launch
+        assert torch.equal(both[0], order) and both[1].numel() == (Ns + 15) // 16 * 16
+        assert sorted(both[1][both[1] >= 0].tolist()) == list(range(Ns))
         groups = o.view(-1, 16)
         start, row = 0, 0
         for n in lens:                                                          # every cloud's points fill whole groups of their own

@@ -1,5 +1,5 @@
 """One KPConv layer of the bench shape (8 pairs per forward, real pyramid) on one path, a few calls: the workload for rocprofv3 --pmc passes.
-python tools/micro/kpconv_layer.py <layer 0..9> [fused|sums|gemm] [calls]"""
+python tools/micro/kpconv_layer.py <layer 0..9> [fused|union|sums|gemm] [calls]      (union: csrc/kpconv_union.hip, whatever the dispatch policy says)"""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from se3et_amd import ops, functional as SF, tables
@@ -8,6 +8,7 @@ from se3et_amd.model import make_cfg
 from se3et_amd.synthetic import make_pair
 layer = int(sys.argv[1]); path = sys.argv[2] if len(sys.argv) > 2 else 'fused'; calls = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 dev = torch.device('cuda'); cfg = make_cfg('se3ete'); b = cfg.backbone
+ops.KPCONV_UNION_ALL = True
 clouds = []
 for j in range(8):
     ref, src, _ = make_pair('c2_5k', index=j); clouds += [ref, src]
@@ -24,7 +25,8 @@ x = torch.randn(s.shape[0], 6, C, generator=g).to(dev)
 w = (torch.randn(6, 6, C, C, generator=g) / (36 * C) ** 0.5).to(dev)
 kp = torch.from_numpy(tables.kernel_points(b.init_radius * 2 ** ss)).to(dev)
 sig = b.init_sigma * 2 ** ss
-ops.KPCONV_MATRIX_CORE = {'fused': True, 'sums': 'sums', 'gemm': False}[path]
+ops.KPCONV_MATRIX_CORE = {'fused': True, 'union': True, 'sums': 'sums', 'gemm': False}[path]
+ops.KPCONV_UNION = path == 'union'
 valid = ((idx >= 0) & (idx < s.shape[0])).sum(1).float()
 with torch.no_grad():
     for _ in range(calls):

@@ -25,7 +25,7 @@ dd = precompute_data_stack_mode(pts, torch.tensor([len(c) for c in clouds]), b.n
 calls = [(0, 0, 'neighbors', 32), (1, 0, 'subsampling', 32), (1, 1, 'neighbors', 64), (2, 1, 'subsampling', 64),
          (2, 2, 'neighbors', 128), (3, 2, 'subsampling', 128), (3, 3, 'neighbors', 256)]
 g = torch.Generator(device='cpu').manual_seed(0)
-names = {0: 'all', 1: '-gather', 2: '-loads', 4: '-abuild', 8: '-consumer MFMA', 7: 'producers idle', 15: 'barriers only', 3: '-gather -loads', 9: '-gather -consumer'}
+names = {23: 'cons, weights in L1', 39: 'cons, no A reads', 55: 'cons, neither', 16: 'all, weights in L1', 0: 'all', 1: '-gather', 2: '-loads', 4: '-abuild', 8: '-consumer MFMA', 7: 'producers idle', 15: 'barriers only', 3: '-gather -loads', 9: '-gather -consumer'}
 for qs, ss, tab, C in calls:
     q, s = dd['points'][qs], dd['points'][ss]
     idx = dd[tab][qs if tab == 'neighbors' else ss]
@@ -41,7 +41,7 @@ for qs, ss, tab, C in calls:
     told = timeit(lambda: SF.kpconv_inter_so3(bf1, q, s, idx, kp, w, kidx, ridx, sig))
     ops.KPCONV_UNION = True
     out = ['fused %.3f' % told]
-    for v in (0, 1, 2, 4, 8, 3, 9, 7, 15):
+    for v in (0, 1, 2, 4, 8, 7, 15):
         lib().se3_debug_set_kpconv_union_variant(v)
         out.append('%s %.3f' % (names[v], timeit(f)))
     lib().se3_debug_set_kpconv_union_variant(0)
