@@ -47,8 +47,9 @@ def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, 
 
     # a spatial order of every stage's points for the union-staged KPConv (tile membership only; csrc/kpconv_union.hip)
     # (the default policy runs that kernel on the layers whose queries are stage 0 / 1 points: ops._kpconv_union_pays)
+    # ... and only on stacked batches: with one pair per forward (10 000 stage-0 points) the order and the plans cost what the kernels gain
     ns = num_stages if _ops.KPCONV_UNION_ALL else min(2, num_stages)
-    if _ops.KPCONV_UNION:
+    if _ops.KPCONV_UNION and (_ops.KPCONV_UNION_ALL or points_list[0].shape[0] >= _ops.KPCONV_UNION_MIN_POINTS):
         _ops.register_point_orders(points_list[:ns], lengths_list[:ns], [voxel_size / 2 ** (num_stages - i) for i in range(ns)])
     # all 3S-2 searches are launched back to back; their column counts are fetched with ONE synchronisation
     jobs = []

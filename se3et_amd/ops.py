@@ -645,6 +645,7 @@ KPCONV_BLOCKED = True          # False: the KPConv input in the plain layout (A/
 _KPCONV_UNION_ENV = os.environ.get('SE3_KPCONV_UNION', '1')
 KPCONV_UNION = _KPCONV_UNION_ENV != '0'
 KPCONV_UNION_ALL = _KPCONV_UNION_ENV == 'all'
+KPCONV_UNION_MIN_POINTS = 24000           # stage-0 points of a pyramid from which the pyramid builder registers orders (single pairs stay on the gather kernel)
 
 
 if os.environ.get('SE3_KPCONV_UNION_WGS'):        # A/B runs: workgroups per launch of the union-staged kernel (default: 256 up to 64 output channels, 1024 beyond)
