@@ -527,6 +527,7 @@ def main():
                        'host_cores': host_cores, 'host_cores_per_rank': cores_here,
                        'host_waits': 'hipDeviceScheduleBlockingSync ' + __import__('se3et_amd').BLOCKING_SYNC_STATUS,
                        'chained_sections': sorted(__import__('se3et_amd.batched', fromlist=['x']).CHAINED_SECTIONS),
+                       'priority_sections': sorted(__import__('se3et_amd.batched', fromlist=['x']).PRIORITY_SECTIONS),
                        'attention_dtype': args.attention_dtype},
             'roofline': roofline, 'roofline_kpconv': roofline_kpconv, 'roofline_dense': roofline_dense, 'roofline_step': roofline_step, 'cpu_baseline': cpu_baseline, 'single_pair': single_pair, 'train_step': train,
         }

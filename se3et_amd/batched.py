@@ -35,21 +35,56 @@ import threading as _threading
 CHAINED_SECTIONS = set(filter(None, _os.environ.get('SE3_CHAIN', 'transformer').split(',')))
 _chains = {}
 _chains_guard = _threading.Lock()
+# SE3_CHAIN_PRIORITY = comma list of chained sections that run on ONE shared high-priority stream (round 5): the section's kernels -- the
+# transformer's HBM-bound RPE calls -- are dispatched ahead of the other batches' backbone / matching kernels instead of time-slicing with
+# them; the caller's stream waits for the section and goes on.  Tensors the section returns are allocated on that stream: the caller marks
+# them as used on its own (`adopt`).
+PRIORITY_SECTIONS = set(filter(None, _os.environ.get('SE3_CHAIN_PRIORITY', '').split(',')))
+_priority_streams = {}
+
+
+class _Section:
+    def __init__(self, caller, stream):
+        self.caller, self.stream = caller, stream
+
+    def adopt(self, *tensors):
+        """Outputs of the section that the caller's stream goes on to use."""
+        if self.stream is not None:
+            for t in tensors:
+                if torch.is_tensor(t):
+                    t.record_stream(self.caller)
+        return tensors[0] if len(tensors) == 1 else tensors
 
 
 @_contextlib.contextmanager
 def _chained(section):
     if section not in CHAINED_SECTIONS or not torch.cuda.is_available():
-        yield
+        yield _Section(None, None)
         return
     with _chains_guard:
         st = _chains.setdefault(section, [_threading.Lock(), None])
     with st[0]:
         cur = torch.cuda.current_stream()
+        if section in PRIORITY_SECTIONS:
+            key = (section, cur.device.index)
+            hp = _priority_streams.get(key)
+            if hp is None:
+                hp = _priority_streams[key] = torch.cuda.Stream(device=cur.device, priority=-1)
+            ev_in = torch.cuda.Event()
+            ev_in.record(cur)
+            hp.wait_event(ev_in)                    # (sections follow each other on hp by themselves)
+            try:
+                with torch.cuda.stream(hp):
+                    yield _Section(cur, hp)
+            finally:
+                ev = torch.cuda.Event()
+                ev.record(hp)
+                cur.wait_event(ev)
+            return
         if st[1] is not None:
             cur.wait_event(st[1])
         try:
-            yield
+            yield _Section(None, None)
         finally:
             ev = torch.cuda.Event()
             ev.record(cur)
@@ -177,8 +212,8 @@ def transformer_pairs(gt, points_c, lengths_c, feats_c, packed=False):
     if _cdriver.supported(gt) and not torch.is_grad_enabled():
         # every launch of the ten blocks and of out_proj from ONE library call (csrc/transformer_driver.hip): the same kernels with the same
         # operands as the schedule below, no interpreter between them
-        with _chained('transformer'):
-            X = _cdriver.transformer_forward(gt, X.contiguous(), PA, R0, embs_o, eqs_o)
+        with _chained('transformer') as sec:
+            X = sec.adopt(_cdriver.transformer_forward(gt, X.contiguous(), PA, R0, embs_o, eqs_o))
         if packed:
             return X, PA
         outs = PA.unpack(X)

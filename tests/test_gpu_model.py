@@ -289,3 +289,41 @@ def test_c_issued_transformer_sees_weights_written_behind_the_version_counter():
             before = got
     finally:
         cdriver.ENABLED = saved
+
+
+@pytest.mark.parametrize('scale', [1e4, 1e-4])
+def test_forward_with_scaled_input_features(scale):
+    """un-normalised input features.  The features x s with the first layer's weights / s are the same network: the
+    first KPConv (one input channel: slot sums + the dense kernel with per-row f16-split scales) sees magnitudes of 1e4 / 1e-4 where the
+    bench sees 1, everything behind its GroupNorm is unchanged -- the outputs must stay at 1e-4 of the unscaled run, nothing may saturate."""
+    from se3et_amd import ops
+    from se3et_amd.data import registration_collate_fn_stack_mode
+    from se3et_amd.model import create_model, load_synthetic_weights, make_cfg
+    from se3et_amd.synthetic import make_pair
+    cfg = make_cfg('se3ete')
+    model = load_synthetic_weights(create_model(cfg), 3).cuda().eval()
+    ref, src, T = make_pair('c1_2k')
+
+    def run(s):
+        d = dict(ref_points=ref, src_points=src, ref_feats=np.full((len(ref), 1), s, np.float32),
+                 src_feats=np.full((len(src), 1), s, np.float32), transform=T)
+        dd = registration_collate_fn_stack_mode([d], cfg.backbone.num_stages, cfg.backbone.init_voxel_size, cfg.backbone.init_radius,
+                                                cfg.neighbor_limits)
+        with torch.no_grad():
+            return model(dd)
+    base = run(1.0)
+    w = model.backbone.encoder1_1.interso3.conv.weights
+    saved = w.detach().clone()
+    ops.dense_saturated_rows(reset=True)
+    try:
+        with torch.no_grad():
+            w.mul_(1.0 / scale)                     # (in place: the version counter moves, every weight cache follows)
+        out = run(scale)
+    finally:
+        with torch.no_grad():
+            w.copy_(saved)
+    assert ops.dense_saturated_rows() == 0
+    for key in ('feats_c', 'feats_f', 'ref_feats_c', 'src_feats_c'):
+        assert_close(out[key].cpu(), base[key].cpu().numpy(), 1e-4, key + ' with features x %g' % scale)
+    assert torch.equal(out['ref_node_corr_indices'], base['ref_node_corr_indices']) or \
+        float((out['estimated_transform'] - base['estimated_transform']).abs().max()) <= 5e-3
