@@ -626,6 +626,9 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
             av[ja ^ 1][rt][0] = *reinterpret_cast<const f16x8*>(img + off);
             av[ja ^ 1][rt][1] = *reinterpret_cast<const f16x8*>(img + off + kPieceB);
           }
+          // (round 5, late: the six reads stay HERE, a whole K-step ahead of their use -- left alone the scheduler sinks each ds_read_b128 to
+          // the MFMA that consumes it and the MFMA then waits out the LDS latency: the consumers lost 18 % to it)
+          if constexpr (CT == 1) __builtin_amdgcn_sched_barrier(0);
         }
         // smallest terms first; consecutive MFMAs go to different accumulators
 #pragma unroll

@@ -625,6 +625,9 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_union_kernel(const
             av[ja ^ 1][rt][0] = *reinterpret_cast<const f16x8*>(img + off);
             av[ja ^ 1][rt][1] = *reinterpret_cast<const f16x8*>(img + off + kPieceB);
           }
+          // (the six reads stay HERE, a whole K-step ahead of their use: left alone the scheduler sinks each ds_read_b128 to the MFMA that
+          // consumes it, which then waits out the LDS latency)
+          if constexpr (CT == 1) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int n = 0; n < CT; n++) {
