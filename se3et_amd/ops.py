@@ -996,8 +996,14 @@ def _kpconv_neighbor_table(q_pts, s_pts, idx, kernel_points, sigma, P, Ns, NN, s
     LAST geometry seen -- identified by the tensor objects themselves (weak references: a freed tensor's address can be reused) and their
     version counters (in-place changes)."""
     kpd = _req(kernel_points.detach().contiguous(), torch.float32, 'kernel_points', 2)
-    key = (q_pts.data_ptr(), q_pts._version, s_pts.data_ptr(), s_pts._version, idx.data_ptr(), idx._version, kernel_points.data_ptr(),
-           kernel_points._version, float(sigma), P, Ns, NN)
+    # (the kernel points enter by VALUE -- the bytes of their cached host copy: the layers of a stage own different Parameter objects holding
+    # the same 15 points, and shared one table only by accident of the cache's depth before round 5: 10 -> 7 table launches per forward)
+    kph = _host_table(kernel_points, torch.float32)
+    kp_key = getattr(kph, '_se3_bytes', None)
+    if kp_key is None:
+        kp_key = kph.numpy().tobytes()
+        kph._se3_bytes = kp_key
+    key = (q_pts.data_ptr(), q_pts._version, s_pts.data_ptr(), s_pts._version, idx.data_ptr(), idx._version, kp_key, float(sigma), P, Ns, NN)
     hit = _neighbor_table_cache.get(stream.value)
     if hit is not None and hit[0] == key and all(r() is t for r, t in zip(hit[1], (q_pts, s_pts, idx))):
         return hit[2]

@@ -1306,7 +1306,11 @@ def test_kpconv_neighbor_table_is_shared_only_for_the_same_geometry():
     t2 = ops._kpconv_neighbor_table(q, s, idx, kp, 0.05, 120, 300, 24, st)
     assert t2 is not t1 and not torch.equal(t2, t1)
     q2 = q.clone()
-    assert ops._kpconv_neighbor_table(q2, s, idx, kp, 0.05, 120, 300, 24, st) is not t2
+    t3 = ops._kpconv_neighbor_table(q2, s, idx, kp, 0.05, 120, 300, 24, st)
+    assert t3 is not t2
+    # the kernel points enter by value: another layer's copy of the same 15 points shares the table, other points do not
+    assert ops._kpconv_neighbor_table(q2, s, idx, kp.clone(), 0.05, 120, 300, 24, st) is t3
+    assert ops._kpconv_neighbor_table(q2, s, idx, kp * 1.01, 0.05, 120, 300, 24, st) is not t3
 
 
 @pytest.mark.parametrize('C', [256, 128])
