@@ -28,6 +28,9 @@ timeout 300 python tools/micro/rpe_eq_breakdown.py 2>&1 | grep -v "amdgpu.ids\|W
 timeout 300 python tools/micro/kpconv_paths.py 2>&1 | grep -v "amdgpu.ids\|Warning" > $O/${tag}_kpconv_paths.txt
 timeout 300 python tools/micro/dense_norm_shapes.py 2>&1 | grep -v "amdgpu.ids\|Warning" > $O/${tag}_dense_norm_shapes.txt
 for L in 2 5 8; do echo "== KPConv layer $L (tools/micro/kpconv_layer.py $L fused): counters of kpconv_fused_kernel, average per dispatch"; tools/pmc_kernel.sh kpconv_fused_kernel tools/micro/kpconv_layer.py $L fused 3; tail -1 gpurun_out/pmck.log | grep layer; done > $O/${tag}_pmc_kpconv.txt 2>&1
+for L in 0 2 5; do echo "== KPConv layer $L (tools/micro/kpconv_layer.py $L union): counters of kpconv_union_kernel, average per dispatch"; tools/pmc_kernel.sh kpconv_union_kernel tools/micro/kpconv_layer.py $L union 3; tail -1 gpurun_out/pmck.log | grep layer; done > $O/${tag}_pmc_kpconv_union.txt 2>&1
+timeout 300 python tools/r5/union_check.py 2>&1 | grep -v "amdgpu.ids\|Warning" > $O/${tag}_kpconv_union_check.txt
+timeout 300 python tools/r5/union_variants.py 2>&1 | grep -v "amdgpu.ids\|Warning" > $O/${tag}_kpconv_union_variants.txt
 tools/pmc_passes.sh > $O/${tag}_pmc_attention_raw.txt 2>&1
 tools/pmc_step.sh ${tag} > $O/pmc_step.log 2>&1; cp gpurun_out/${tag}_pmc_step.txt $O/${tag}_pmc_step.txt
 for K in rpe_bias_kernel attention_x6_kernel; do echo "== $K (tools/pmc_attention.py: 16 clouds per launch; equivariant and invariant dispatches averaged together)"; tools/pmc_kernel.sh $K tools/pmc_attention.py; done > $O/${tag}_pmc_attention_sq.txt 2>&1
