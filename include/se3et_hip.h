@@ -192,6 +192,12 @@ int se3_group_norm_stats(const float* x, const float* in_affine, float in_slope,
 int se3_group_norm_apply(const float* x, const float* affine_a, float slope_a, const float* affine_b, float slope_b, const float* residual,
                          const float* residual_affine, float final_slope, int64_t rows, int channels,
                          const int64_t* segment_row_offsets_host, int num_segments, int blocked_layout, float* out, void* stream);
+/* ... the same with the largest |out| of the call atomicMax-ed (as a bit pattern) into *amax_out (blocked layouts 1 / 2 only; the caller zeroes
+ * the word): se3_kpconv_so3_fused_scaled / se3_kpconv_so3_union scale their input by a power of two from it before the f16 split. */
+int se3_group_norm_apply_amax(const float* x, const float* affine_a, float slope_a, const float* affine_b, float slope_b, const float* residual,
+                              const float* residual_affine, float final_slope, int64_t rows, int channels,
+                              const int64_t* segment_row_offsets_host, int num_segments, int blocked_layout, float* out, float* amax_out,
+                              void* stream);
 size_t se3_dense_norm_workspace_bytes(int groups);
 int se3_dense_norm_fwd(const float* x, int64_t rows, int in_features, const float* in_affine_a, float in_slope_a, const float* in_affine_b,
                        float in_slope_b, const void* weight_pieces, int out_features, const float* linear_bias, const float* norm_weight,
@@ -312,6 +318,11 @@ size_t se3_kpconv_fused_split_workspace_bytes(int64_t num_queries, int in_channe
 int se3_kpconv_so3_fused(const float* x, const void* table, int64_t num_queries, int64_t num_support, int num_neighbors, int in_channels,
                          int out_channels, const void* weight_pieces, float* out, void* split_workspace, size_t split_workspace_bytes,
                          int x_blocked, void* stream);
+/* ... x_amax: DEVICE word holding the largest |x| (se3_group_norm_apply_amax) or NULL.  Outside [2^-4, 2^7) the features are scaled by the power
+ * of two that brings it to [2^6, 2^7) before their f16 split and the output is scaled back: no magnitude window on x (NULL: |H| < 65504 as before). */
+int se3_kpconv_so3_fused_scaled(const float* x, const void* table, int64_t num_queries, int64_t num_support, int num_neighbors, int in_channels,
+                                int out_channels, const void* weight_pieces, float* out, void* split_workspace, size_t split_workspace_bytes,
+                                int x_blocked, const float* x_amax, void* stream);
 /* Union-staged form of se3_kpconv_so3_fused (csrc/kpconv_union.hip, round 5): a workgroup owns 16 points that are spatial neighbours, reads
  * the DISTINCT support rows of their neighbour lists once (whole rows, 16 B per lane) and forms every point's orbit sums as a product of
  * its orbit weights, scattered over the tile's row list, with the shared rows.  Tile membership only: no tensor is reordered.
@@ -341,7 +352,7 @@ int se3_kpconv_union_plan(const void* table, int64_t num_queries, int num_neighb
 size_t se3_kpconv_union_split_workspace_bytes(int64_t num_groups, int in_channels, int out_channels);
 int se3_kpconv_so3_union(const float* x, const void* table, const void* plan, int64_t num_groups, int64_t num_queries, int64_t num_support,
                          int num_neighbors, int in_channels, int out_channels, const void* weight_pieces, float* out, void* split_workspace,
-                         size_t split_workspace_bytes, int x_chunked, void* stream);
+                         size_t split_workspace_bytes, int x_chunked, const float* x_amax, void* stream);
 size_t se3_kpconv_sums_bytes(int64_t num_queries, int in_channels);
 int se3_kpconv_so3_gather_sums(const float* x, const void* table, int64_t num_queries, int64_t num_support, int num_neighbors,
                                int in_channels, void* sums, void* stream);

@@ -78,7 +78,9 @@ SIGNATURES = {
     'se3_kpconv_union_plan_bytes': (_sz, [_i64, _i32]),
     'se3_kpconv_union_plan': (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _sz, _vp]),
     'se3_kpconv_union_split_workspace_bytes': (_sz, [_i64, _i32, _i32]),
-    'se3_kpconv_so3_union': (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _i32, _vp]),
+    'se3_kpconv_so3_union': (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _i32, _vp, _vp]),
+    'se3_kpconv_so3_fused_scaled': (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _i32, _vp, _vp]),
+    'se3_group_norm_apply_amax': (_i32, [_vp, _vp, _f32, _vp, _f32, _vp, _vp, _f32, _i64, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     'se3_rpe_bias_fwd': (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     'se3_attention_fwd': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _f32, _vp, _vp]),
     'se3_rpe_bias_stack_fwd': (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),

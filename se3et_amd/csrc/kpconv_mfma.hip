@@ -330,7 +330,7 @@ __device__ __forceinline__ void split2(float v0, float v1, f16x8& hi, f16x8& lo)
 }
 // tail: the round has more than 32 valid neighbours (uniform)
 template <bool EXT>
-__device__ __forceinline__ void gather_multiply(const GatherOps<EXT>& q, bool tail, f32x4 (&acc)[kA]) {
+__device__ __forceinline__ void gather_multiply(const GatherOps<EXT>& q, bool tail, f32x4 (&acc)[kA], float xs = 1.f) {      // xs: kpsum::x_split_scale
   f16x8 ah, al;
   {
     const float w8[kGN] = {q.aw[0], q.aw[1], q.aw[2], q.aw[3], q.aw[4], q.aw[5], q.aw[6], q.aw[7]};
@@ -338,7 +338,7 @@ __device__ __forceinline__ void gather_multiply(const GatherOps<EXT>& q, bool ta
   }
 #pragma unroll
   for (int a = 0; a < kA; a++) {
-    const float v8[kGN] = {q.xb[a][0], q.xb[a][1], q.xb[a][2], q.xb[a][3], q.xb[a][4], q.xb[a][5], q.xb[a][6], q.xb[a][7]};
+    const float v8[kGN] = {q.xb[a][0] * xs, q.xb[a][1] * xs, q.xb[a][2] * xs, q.xb[a][3] * xs, q.xb[a][4] * xs, q.xb[a][5] * xs, q.xb[a][6] * xs, q.xb[a][7] * xs};
     f16x8 bh, bl;
     split8(v8, bh, bl);
     acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[a], 0, 0, 0);
@@ -351,7 +351,7 @@ __device__ __forceinline__ void gather_multiply(const GatherOps<EXT>& q, bool ta
 #pragma unroll
       for (int a = 0; a < kA; a++) {
         f16x8 bh, bl;
-        split2(q.xb[a][8], q.xb[a][9], bh, bl);
+        split2(q.xb[a][8] * xs, q.xb[a][9] * xs, bh, bl);
         acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[a], 0, 0, 0);
         acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[a], 0, 0, 0);
         acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[a], 0, 0, 0);
@@ -434,8 +434,9 @@ template <int NCW, int KS, int CT, bool EXT, bool BLK>      // consumer waves: N
 __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
     const float* __restrict__ x, const float* __restrict__ hwt, const int* __restrict__ nbr, const int* __restrict__ cnt, int NNp,
     const u32x4* __restrict__ Wf, const float* __restrict__ hdr, int64_t P, int Cin, int Cout, float* __restrict__ out,
-    float* __restrict__ split_part, int* __restrict__ split_count, int variant) {
+    float* __restrict__ split_part, int* __restrict__ split_count, int variant, const float* __restrict__ x_amax) {
   constexpr int NC = NCW * KS;                                         // consumer waves
+  const float xs = x_split_scale(x_amax);                              // power-of-two scale of x before its f16 split (1 inside the plain range)
   constexpr int NPW = 8;                                               // producer waves: two points of the tile each
   constexpr int kSPW = kSteps / KS;                                    // K16-steps per consumer wave and chunk
   static_assert(kSteps % KS == 0, "K split must divide the 18 K16-steps of a chunk");
@@ -521,14 +522,14 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
         for (int a = 0; a < kA; a++) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int nv = __builtin_amdgcn_readfirstlane(nv_cur);
         SE3_STAMP(u, 5)
-        if (nv > 0) gather_multiply<EXT>(ops, nv > 32, acc);
+        if (nv > 0) gather_multiply<EXT>(ops, nv > 32, acc, xs);
         SE3_STAMP(u, 6)
         for (int rd = 1; S * rd < nv; rd++) {                             // more valid neighbours than a round holds: further rounds, requested on the spot
           int nbv[kGN + (EXT ? kGX : 0)];
           GatherOps<EXT> q;
           gather_request_rows<EXT>(nbr + pc * NNp, rd, g, nbv);
           gather_request_ops<EXT, BLK>(x, hwt + pc * NNp * 16, NNp, rd, g, c16, nbv, rowlen, col_of(u), Cin, nv, q);
-          gather_multiply<EXT>(q, nv > S * rd + 32, acc);
+          gather_multiply<EXT>(q, nv > S * rd + 32, acc, xs);
         }
         SE3_STAMP(u, 7)
         // the next step's operands leave now (their neighbour numbers have arrived behind the MFMAs)
@@ -688,7 +689,7 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_fused_kernel(
 #pragma unroll
           for (int v = 0; v < 16; v++) acc[n][rt][v] += red[((((k - 1) * NCW + cw) * CT + n) * 48 + rt * 16 + v) * 64 + lane];
   }
-  const float inv_scale = hdr[0];
+  const float inv_scale = hdr[0] / xs;
   // Output addressing: row (point v, rotation r = 2 rt + (h ^ s[v >> 2])), s = 0, 1, 1, 0 -- the accumulator's row order; buffer stores with
   // the tile as the buffer (rows past the last point fall outside and are dropped), lane part in two offsets, the rest uniform.
   const int row_b = Cout * 4;
@@ -922,6 +923,13 @@ extern "C" size_t se3_kpconv_fused_split_workspace_bytes(int64_t num_queries, in
 extern "C" int se3_kpconv_so3_fused(const float* x, const void* table, int64_t num_queries, int64_t num_support, int num_neighbors,
                                     int in_channels, int out_channels, const void* weight_pieces, float* out, void* split_workspace,
                                     size_t split_workspace_bytes, int x_blocked, void* stream) {
+  return se3_kpconv_so3_fused_scaled(x, table, num_queries, num_support, num_neighbors, in_channels, out_channels, weight_pieces, out,
+                                     split_workspace, split_workspace_bytes, x_blocked, nullptr, stream);
+}
+
+extern "C" int se3_kpconv_so3_fused_scaled(const float* x, const void* table, int64_t num_queries, int64_t num_support, int num_neighbors,
+                                           int in_channels, int out_channels, const void* weight_pieces, float* out, void* split_workspace,
+                                           size_t split_workspace_bytes, int x_blocked, const float* x_amax, void* stream) {
   SE3_REQUIRE(x && table && weight_pieces && out, SE3_ERR_INVALID_ARG, "kpconv_so3_fused: null pointer");
   SE3_REQUIRE(num_neighbors >= 1 && num_neighbors <= 64, SE3_ERR_UNSUPPORTED, "kpconv_so3_fused: %d neighbours (max 64)", num_neighbors);
   SE3_REQUIRE(in_channels > 0 && in_channels % kCC == 0 && out_channels >= 32 && out_channels % 32 == 0, SE3_ERR_UNSUPPORTED,
@@ -959,7 +967,7 @@ extern "C" int se3_kpconv_so3_fused(const float* x, const void* table, int64_t n
     }                                                                                                                                     \
     kpconv_fused_kernel<NCW_, KS_, CT_, EXT_, BLK_>                                                                                       \
         <<<dim3((unsigned)tiles, (unsigned)(NCT / (NCW_ * CT_)), (unsigned)splits), 64 * (NCW_ * KS_ + 8), lds, st>>>(                    \
-            x, t.hwt, t.nbr, t.cnt, t.NNp, Wf, hdr, num_queries, in_channels, out_channels, out, split_part, split_count, g_kpconv_variant);                \
+            x, t.hwt, t.nbr, t.cnt, t.NNp, Wf, hdr, num_queries, in_channels, out_channels, out, split_part, split_count, g_kpconv_variant, x_amax);                \
   }
 #define SE3_FUSED(NCW_, KS_, CT_)                                  \
   {                                                                \

@@ -9,6 +9,7 @@
 // bits) and the matrix-core kernel only READS fragments: G[p, r, (s, t), c] = H[p, orbit_id[s][r], anchor_of[t][r], c].
 #pragma once
 #include <stdint.h>
+#include <hip/hip_runtime.h>
 
 namespace kpsum {
 
@@ -66,6 +67,18 @@ constexpr OrbitTable make_orbits() {
 }
 __device__ constexpr OrbitTable kOrb = make_orbits();
 static_assert(make_orbits().count == kOrbits, "the SE3ET slot tables have 16 distinct kernel-point orbits");
+
+// Power-of-two scale of the input features of the fused kernels before their f16 split, from the largest magnitude of the tensor (written by
+// the GroupNorm apply pass that produces it, se3_group_norm_apply_amax): inside [2^-4, 2^7) -- or unknown, zero, NaN / Inf -- the features are
+// split as they are (bit-identical to the unscaled kernels); outside, the largest magnitude goes to [2^6, 2^7) (exact), the orbit sums of
+// up to 64 neighbours x 4 kernel points stay below 2^15, and the epilogue takes the scale out again.
+__device__ __forceinline__ float x_split_scale(const float* amax) {
+  if (amax == nullptr) return 1.f;
+  const unsigned b = *reinterpret_cast<const unsigned*>(amax);
+  const int e = (int)((b >> 23) & 0xff);
+  if (e == 0 || e == 0xff || (e >= 123 && e <= 133)) return 1.f;
+  return __builtin_bit_cast(float, (unsigned)(127 + 133 - e) << 23);
+}
 
 // 16-byte run of (orbit, anchor) inside a point's row: anchor-major, so that the 16 orbits a producer wave holds for one anchor are contiguous
 __host__ __device__ constexpr int run_of(int orbit, int a) { return a * kOrbits + orbit; }

@@ -331,6 +331,7 @@ struct UnionArgs {
   float* out;
   float* split_part;
   int* split_count;
+  const float* x_amax;       // largest |x| of the tensor (se3_group_norm_apply_amax) or null: kpsum::x_split_scale
   int variant;               // diagnostic bits (se3_debug_set_kpconv_union_variant; results are wrong with any of them set): 1 producers skip the gather
                              // product and the image stores, 2 skip the row loads and the B image, 4 skip the A fragments, 8 consumers skip their MFMAs
 };
@@ -379,6 +380,7 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_union_kernel(const
     const int g = lane >> 4, col = lane & 15, odd = col & 1, half = col >> 3, cpair = (col & 7) >> 1;
     const unsigned rowlen = (unsigned)(kA * Cin);
     const bool v_gather = !(a.variant & 1), v_load = !(a.variant & 2), v_abuild = !(a.variant & 4);
+    const float xs = x_split_scale(a.x_amax);
     // loader task of this lane: rows 8 oct + 4 jh .. + 3 of the union, 16-byte part q of a row's 192-byte chunk (60 lanes per wave)
     const int task = pw * 60 + lane, oh = task / 12, q = task - oh * 12, oct = oh >> 1, jh = oh & 1;
     const unsigned qoff = BLK ? (unsigned)(q * 4) : (unsigned)((q >> 1) * Cin + (q & 1) * 4);
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_union_kernel(const
         f16x4 hi, lo4;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const float v = V[j][i];
+          const float v = V[j][i] * xs;
           hi[j] = (_Float16)v;
           lo4[j] = (_Float16)(v - (float)hi[j]);
         }
@@ -662,7 +664,7 @@ __global__ __launch_bounds__(64 * (NCW * KS + 8)) void kpconv_union_kernel(const
   // Output of one group: accumulator register v of lane (column i32, half h) of row tile rt = (point v of the group, rotation 2 rt + (h ^ s[v >> 2])),
   // s = 0, 1, 1, 0; the point's row in `out` comes from the order (a scalar per v); absent points are skipped.
   auto epilogue = [&](int64_t group, int par) {
-    const float inv_scale = a.hdr[0];
+    const float inv_scale = a.hdr[0] / x_split_scale(a.x_amax);
     const int row_b = Cout * 4;
     int voff[CT][2];
 #pragma unroll
@@ -950,7 +952,8 @@ extern "C" size_t se3_kpconv_union_split_workspace_bytes(int64_t num_groups, int
 
 extern "C" int se3_kpconv_so3_union(const float* x, const void* table, const void* plan, int64_t num_groups, int64_t num_queries,
                                     int64_t num_support, int num_neighbors, int in_channels, int out_channels, const void* weight_pieces,
-                                    float* out, void* split_workspace, size_t split_workspace_bytes, int x_chunked, void* stream) {
+                                    float* out, void* split_workspace, size_t split_workspace_bytes, int x_chunked, const float* x_amax,
+                                    void* stream) {
   SE3_REQUIRE(x && table && plan && weight_pieces && out, SE3_ERR_INVALID_ARG, "kpconv_so3_union: null pointer");
   SE3_REQUIRE(num_neighbors >= 1 && num_neighbors <= 64, SE3_ERR_UNSUPPORTED, "kpconv_so3_union: %d neighbours (max 64)", num_neighbors);
   SE3_REQUIRE(in_channels > 0 && in_channels % kCC == 0 && out_channels >= 32 && out_channels % 32 == 0, SE3_ERR_UNSUPPORTED,
@@ -981,6 +984,7 @@ extern "C" int se3_kpconv_so3_union(const float* x, const void* table, const voi
   a.split_part = nullptr;
   a.split_count = nullptr;
   a.variant = g_union_variant;
+  a.x_amax = x_amax;
   const size_t lds = (size_t)2 * kTileB + 2 * kBImgB + kSteps * 4 * sizeof(unsigned) + 32 * sizeof(int);
   int splits = 1;
   if (split_workspace != nullptr) {

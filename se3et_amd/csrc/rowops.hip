@@ -217,7 +217,36 @@ struct ChainArgs {
   int64_t rows;
   int C;
   float* y;
+  float* amax;               // blocked / chunked layouts: the largest |y| of the call is atomicMax-ed into this word (or null): the fused KPConv
+                             // kernels scale their input by a power of two from it before the f16 split (no magnitude window)
 };
+// largest magnitude over the workgroup (256 threads) -> at most one atomicMax per workgroup (non-negative floats order like their bit patterns;
+// a NaN's pattern is the largest).  Same-line atomics serialise in the L2 (~7 ns each) and one per WAVE of a 16 000-wave launch doubled the
+// pass; the running maximum is monotonic, so a plain, possibly stale read filters most of the rest.
+__device__ __forceinline__ void amax_commit(float* amax, float m) {
+  __shared__ unsigned wave_max[4];
+  if (amax == nullptr) return;
+  unsigned b = __float_as_uint(m);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned t = (unsigned)__shfl_xor((int)b, o);
+    b = t > b ? t : b;
+  }
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = b;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    b = wave_max[0];
+    for (int w = 1; w < 4; w++) b = wave_max[w] > b ? wave_max[w] : b;
+    if (b > __atomic_load_n(reinterpret_cast<unsigned*>(amax), __ATOMIC_RELAXED)) atomicMax(reinterpret_cast<unsigned*>(amax), b);
+  }
+}
+__device__ __forceinline__ float abs_max4(float m, const float4& o) {
+  // (fmaxf drops a NaN beside a number: a NaN / Inf in y is carried as +Inf's pattern or above through the integer maximum instead)
+  const unsigned a = __float_as_uint(fabsf(o.x)), b = __float_as_uint(fabsf(o.y)), c = __float_as_uint(fabsf(o.z)), d = __float_as_uint(fabsf(o.w));
+  unsigned r = __float_as_uint(m);
+  r = a > r ? a : r; r = b > r ? b : r; r = c > r ? c : r; r = d > r ? d : r;
+  return __uint_as_float(r);
+}
 __device__ __forceinline__ float4 affine_lrelu(float4 v, const float* aff, int C, int c0, float slope) {
   const float4 sc = *reinterpret_cast<const float4*>(aff + c0), sf = *reinterpret_cast<const float4*>(aff + C + c0);
   float4 o = make_float4(v.x * sc.x + sf.x, v.y * sc.y + sf.y, v.z * sc.z + sf.z, v.w * sc.w + sf.w);
@@ -256,6 +285,7 @@ __global__ __launch_bounds__(256) void gn_chain_apply_blocked_kernel(ChainArgs p
   const int C = p.C, Q = C >> 2;
   const int64_t total = (p.rows >> 1) * Q;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float am = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const int64_t pr = i / Q;                              // anchor-pair row: point n = pr / 3, pair ap = pr % 3
     const int c0 = (int)(i - pr * Q) << 2;
@@ -282,7 +312,9 @@ __global__ __launch_bounds__(256) void gn_chain_apply_blocked_kernel(ChainArgs p
     float4* dst = reinterpret_cast<float4*>(p.y + n * 6 * C + (c0 >> 4) * 96 + ap * 32 + (c0 & 15) * 2);
     dst[0] = make_float4(o[0].x, o[1].x, o[0].y, o[1].y);
     dst[1] = make_float4(o[0].z, o[1].z, o[0].w, o[1].w);
+    am = abs_max4(abs_max4(am, o[0]), o[1]);
   }
+  amax_commit(p.amax, am);
 }
 
 // The same, written in the layout the union-staged KPConv loads whole rows from (csrc/kpconv_union.hip, BLK): x (points, 6 anchors, C) ->
@@ -292,6 +324,7 @@ __global__ __launch_bounds__(256) void gn_chain_apply_chunked_kernel(ChainArgs p
   const int C = p.C, Q = 6 * C >> 2;                       // float4 per point
   const int64_t total = (p.rows / 6) * Q;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float am = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const int64_t n = i / Q;
     const int rem = (int)(i - n * Q);
@@ -312,7 +345,9 @@ __global__ __launch_bounds__(256) void gn_chain_apply_chunked_kernel(ChainArgs p
     o.z = o.z > 0.f ? o.z : o.z * p.slope_f;
     o.w = o.w > 0.f ? o.w : o.w * p.slope_f;
     reinterpret_cast<float4*>(p.y)[i] = o;
+    am = abs_max4(am, o);
   }
+  amax_commit(p.amax, am);
 }
 
 // ---- GroupNorm backward (training step) ------------------------------------------------------------------------------------------------
@@ -838,7 +873,16 @@ extern "C" int se3_group_norm_stats(const float* x, const float* in_affine, floa
 extern "C" int se3_group_norm_apply(const float* x, const float* affine_a, float slope_a, const float* affine_b, float slope_b,
                                     const float* residual, const float* residual_affine, float final_slope, int64_t rows, int channels,
                                     const int64_t* segment_row_offsets_host, int num_segments, int blocked_layout, float* out, void* stream) {
+  return se3_group_norm_apply_amax(x, affine_a, slope_a, affine_b, slope_b, residual, residual_affine, final_slope, rows, channels,
+                                   segment_row_offsets_host, num_segments, blocked_layout, out, nullptr, stream);
+}
+
+extern "C" int se3_group_norm_apply_amax(const float* x, const float* affine_a, float slope_a, const float* affine_b, float slope_b,
+                                         const float* residual, const float* residual_affine, float final_slope, int64_t rows, int channels,
+                                         const int64_t* segment_row_offsets_host, int num_segments, int blocked_layout, float* out,
+                                         float* amax_out, void* stream) {
   SE3_REQUIRE(x && affine_a && out, SE3_ERR_INVALID_ARG, "group_norm_apply: null pointer");
+  SE3_REQUIRE(amax_out == nullptr || blocked_layout != 0, SE3_ERR_UNSUPPORTED, "group_norm_apply: amax_out is written by the blocked / chunked layouts only");
   SE3_REQUIRE(rows >= 1 && channels >= 4 && channels % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, SE3_ERR_UNSUPPORTED,
               "group_norm_apply: rows %lld channels %d (a multiple of 4)", (long long)rows, channels);
   SE3_REQUIRE(residual || !residual_affine, SE3_ERR_INVALID_ARG, "group_norm_apply: residual_affine without a residual");
@@ -853,9 +897,11 @@ extern "C" int se3_group_norm_apply(const float* x, const float* affine_a, float
               "group_norm_apply: the chunked layout is for (points, 6, channels) with channels %% 8 == 0 (rows %lld, channels %d)", (long long)rows,
               channels);
   SE3_REQUIRE(blocked_layout >= 0 && blocked_layout <= 2, SE3_ERR_INVALID_ARG, "group_norm_apply: blocked_layout %d", blocked_layout);
-  ChainArgs p{x, affine_a, affine_b, residual, residual_affine, slope_a, slope_b, final_slope, rows, channels, out};
-  if (blocked_layout == 2) gn_chain_apply_chunked_kernel<<<grid_for(rows * channels / 4, 256), 256, 0, (hipStream_t)stream>>>(p, T);
-  else if (blocked_layout) gn_chain_apply_blocked_kernel<<<grid_for(rows * channels / 8, 256), 256, 0, (hipStream_t)stream>>>(p, T);
+  ChainArgs p{x, affine_a, affine_b, residual, residual_affine, slope_a, slope_b, final_slope, rows, channels, out, amax_out};
+  // (with the magnitude word: at most 1024 workgroups, i.e. at most 1024 -- mostly filtered -- atomics; the loops are grid-strided)
+  const unsigned cap = amax_out ? 1024u : 4096u;
+  if (blocked_layout == 2) gn_chain_apply_chunked_kernel<<<min(grid_for(rows * channels / 4, 256), cap), 256, 0, (hipStream_t)stream>>>(p, T);
+  else if (blocked_layout) gn_chain_apply_blocked_kernel<<<min(grid_for(rows * channels / 8, 256), cap), 256, 0, (hipStream_t)stream>>>(p, T);
   else gn_chain_apply_kernel<<<grid_for(rows * channels / 4, 256), 256, 0, (hipStream_t)stream>>>(p, T);
   SE3_CHECK_LAUNCH("group_norm_apply");
   return SE3_OK;

@@ -626,10 +626,12 @@ class BlockedFeatures:
     it, kpconv_inter_so3 reads it); `plain()` is the ordinary tensor.
     kind 1: [point][C / 16][anchor pair][16 channels][2 anchors] (csrc/kpconv_mfma.hip: per-lane gathers of 8 bytes)
     kind 2: [point][C / 8][6 anchors][8 channels]                (csrc/kpconv_union.hip: a point's 8-channel chunk is 192 contiguous bytes)"""
-    __slots__ = ('data', 'shape', 'kind')
+    __slots__ = ('data', 'shape', 'kind', 'amax')
 
-    def __init__(self, data, shape, kind=1):
-        self.data, self.shape, self.kind = data, tuple(shape), kind
+    def __init__(self, data, shape, kind=1, amax=None):
+        # amax: one-element device tensor holding the largest |value| (written by the apply pass that produced `data`), or None: the fused
+        # kernels scale the features by a power of two from it before their f16 split (csrc/kpconv_sums.h: x_split_scale)
+        self.data, self.shape, self.kind, self.amax = data, tuple(shape), kind, amax
 
     def plain(self):
         n, a, c = self.shape
@@ -652,6 +654,24 @@ KPCONV_UNION_MIN_POINTS = 24000           # stage-0 points of a pyramid from whi
 
 if os.environ.get('SE3_KPCONV_UNION_WGS'):        # A/B runs: workgroups per launch of the union-staged kernel (default: 256 up to 64 output channels, 1024 beyond)
     lib().se3_debug_set_kpconv_union_variant(int(os.environ['SE3_KPCONV_UNION_WGS']) << 8)
+
+
+_amax_rings = {}
+
+
+def _amax_slot(device, stream):
+    """A zeroed device word for one apply pass to atomicMax the largest magnitude of its output into: taken from a per-stream ring of 4096
+    words that is cleared (one fill, in stream order) every time it wraps."""
+    key = (device, stream.value)
+    ring = _amax_rings.get(key)
+    if ring is None:
+        ring = _amax_rings[key] = [torch.zeros((4096,), dtype=torch.float32, device=device), 0]
+    if ring[1] == 4096:
+        ring[0].zero_()
+        ring[1] = 0
+    slot = ring[0][ring[1]:ring[1] + 1]
+    ring[1] += 1
+    return slot
 
 
 def _kpconv_union_pays(Cin, Cout, same_cloud):
@@ -824,12 +844,14 @@ def group_norm_apply(x, residual=None, final_slope=1.0, blocked=False):
     out = torch.empty_like(raw)
     aa = x.affines + [None]
     sl = x.slopes + [1.0]
-    check(lib().se3_group_norm_apply(raw.data_ptr(), aa[0].data_ptr(), float(sl[0]), aa[1].data_ptr() if aa[1] is not None else None, float(sl[1]),
-                                     res.data_ptr() if res is not None else None, res_aff.data_ptr() if res_aff is not None else None,
-                                     float(final_slope), rows, C, _i64_array(segments) if nseg > 1 else None, nseg, int(blocked),
-                                     out.data_ptr(), _stream()),
+    stream = _stream()
+    amax = _amax_slot(raw.device, stream) if blocked else None
+    check(lib().se3_group_norm_apply_amax(raw.data_ptr(), aa[0].data_ptr(), float(sl[0]), aa[1].data_ptr() if aa[1] is not None else None, float(sl[1]),
+                                          res.data_ptr() if res is not None else None, res_aff.data_ptr() if res_aff is not None else None,
+                                          float(final_slope), rows, C, _i64_array(segments) if nseg > 1 else None, nseg, int(blocked),
+                                          out.data_ptr(), amax.data_ptr() if amax is not None else None, stream),
           'se3_group_norm_apply')
-    return BlockedFeatures(out, raw.shape, int(blocked)) if blocked else out
+    return BlockedFeatures(out, raw.shape, int(blocked), amax) if blocked else out
 
 
 _host_table_cache = {}
@@ -1108,6 +1130,7 @@ def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, s
     x: (Ns, 6, Cin) tensor or BlockedFeatures (inference: written by group_norm_apply(blocked=True))."""
     blocked = isinstance(x, BlockedFeatures)
     xb = x.data if blocked else None
+    x_amax = x.amax if blocked else None
     if blocked:
         Ns, A, Cin = x.shape
     else:
@@ -1125,7 +1148,7 @@ def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, s
     po = point_order(q_pts) if (fused_ok and path is True and KPCONV_UNION and _kpconv_union_pays(Cin, Cout, q_pts is s_pts)) else None
     want = 0 if not blocked else x.kind
     if blocked and not (fused_ok and path != 'sums' and ((want == 2 and po is not None) or (want == 1 and po is None and Cin % 16 == 0))):
-        x, blocked = x.plain().contiguous(), False              # (each fused kernel reads its own blocked layout only)
+        x, blocked = x.plain().contiguous(), False              # (each fused kernel reads its own blocked layout only; the values, and their amax, stay)
     if fused_ok:
         if blocked:
             x = xb
@@ -1152,16 +1175,17 @@ def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, s
             with _timed('kpconv_fused', 2.0 * 6 * P * 36 * Cin * Cout + 2.0 * P * NN * 16 * 6 * Cin):
                 _check_counters(lib().se3_kpconv_so3_union(x.data_ptr(), tab.data_ptr(), plan.data_ptr(), G, P, Ns, NN, Cin, Cout, Wp.data_ptr(),
                                                            out.data_ptr(), sws.data_ptr() if sws is not None else None,
-                                                           sws.numel() if sws is not None else 0, 1 if blocked else 0, stream),
+                                                           sws.numel() if sws is not None else 0, 1 if blocked else 0,
+                                                           x_amax.data_ptr() if x_amax is not None else None, stream),
                                 'se3_kpconv_so3_union', sws)
             return out
         sbytes = lib().se3_kpconv_fused_split_workspace_bytes(P, Cin, Cout) if KPCONV_SPLIT else 0
         sws = _zeroed_workspace(_kpconv_split_ws, x.device, stream, sbytes) if sbytes else None
         # (bench.py: event pair around the launch; algorithmic flops = contraction 2.6P.36Cin.Cout + the gather as a product 2.P.NN.16.6Cin)
         with _timed('kpconv_fused', 2.0 * 6 * P * 36 * Cin * Cout + 2.0 * P * NN * 16 * 6 * Cin):
-            _check_counters(lib().se3_kpconv_so3_fused(x.data_ptr(), tab.data_ptr(), P, Ns, NN, Cin, Cout, Wp.data_ptr(), out.data_ptr(),
-                                                       sws.data_ptr() if sws is not None else None, sws.numel() if sws is not None else 0,
-                                                       1 if blocked else 0, stream),
+            _check_counters(lib().se3_kpconv_so3_fused_scaled(x.data_ptr(), tab.data_ptr(), P, Ns, NN, Cin, Cout, Wp.data_ptr(), out.data_ptr(),
+                                                              sws.data_ptr() if sws is not None else None, sws.numel() if sws is not None else 0,
+                                                              1 if blocked else 0, x_amax.data_ptr() if x_amax is not None else None, stream),
                             'se3_kpconv_so3_fused', sws)
         return out
     G = torch.empty((P * 6, 36 * Cin), dtype=torch.float32, device=x.device)

@@ -327,3 +327,42 @@ def test_forward_with_scaled_input_features(scale):
         assert_close(out[key].cpu(), base[key].cpu().numpy(), 1e-4, key + ' with features x %g' % scale)
     assert torch.equal(out['ref_node_corr_indices'], base['ref_node_corr_indices']) or \
         float((out['estimated_transform'] - base['estimated_transform']).abs().max()) <= 5e-3
+
+
+@pytest.mark.parametrize('mode', ['policy', 'all'])
+def test_union_kpconv_forward_matches_the_default_forward(mode):
+    """The forward of a stacked batch with the union-staged KPConv selected (SE3_KPCONV_UNION=1: the four narrow layers; all: every layer,
+    the wide ones as 128-column blocks, the coarse strided ones in several passes) against the default forward of the same batch: the same
+    arithmetic up to the order of a neighbourhood's sum."""
+    from se3et_amd import ops
+    from se3et_amd.batched import forward_pairs
+    from se3et_amd.data import precompute_data_stack_mode
+    from se3et_amd.model import create_model, load_synthetic_weights, make_cfg
+    from se3et_amd.synthetic import make_pair
+    cfg = make_cfg('se3ete')
+    model = load_synthetic_weights(create_model(cfg)).cuda().eval()
+    b = cfg.backbone
+    clouds = []
+    for p in range(3):                                     # 30 000 stage-0 points: above ops.KPCONV_UNION_MIN_POINTS
+        ref, src, _ = make_pair('c2_5k', index=p)
+        clouds += [ref, src]
+    pts = torch.from_numpy(np.concatenate(clouds, 0)).cuda()
+
+    def run():
+        dd = precompute_data_stack_mode(pts, torch.tensor([len(c) for c in clouds]), b.num_stages, b.init_voxel_size, b.init_radius,
+                                        cfg.neighbor_limits)
+        dd['features'] = torch.ones((pts.shape[0], 1), device='cuda')
+        return dd, forward_pairs(model, dd)
+    saved = (ops.KPCONV_UNION, ops.KPCONV_UNION_ALL)
+    try:
+        ops.KPCONV_UNION = ops.KPCONV_UNION_ALL = False
+        dd0, want = run()
+        assert ops.point_order(dd0['points'][0]) is None
+        ops.KPCONV_UNION, ops.KPCONV_UNION_ALL = True, mode == 'all'
+        dd1, got = run()
+        assert ops.point_order(dd1['points'][0]) is not None and (ops.point_order(dd1['points'][3]) is not None) == (mode == 'all')
+    finally:
+        ops.KPCONV_UNION, ops.KPCONV_UNION_ALL = saved
+    for p, (w, g) in enumerate(zip(want, got)):
+        for key in ('feats_c', 'feats_f', 'ref_feats_c', 'src_feats_c'):
+            assert_close(g[key].cpu(), w[key].cpu(), 2e-5, 'pair %d %s' % (p, key))
