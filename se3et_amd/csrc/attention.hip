@@ -119,7 +119,7 @@ constexpr int kStageStride = 36;     // floats per staged logits row (32 keys + 
 template <int CT, int RT, bool NEXT, bool EQ, bool UA, bool BF, bool HS = false, bool TL = false>
 __device__ __forceinline__ void bias_tile(float4 (&b)[BF ? CT / 2 : CT], const float4* afrag, const float4* qe_s, float* stage,
                                           int col0, const float* Erow, const float* eq_row, unsigned eq_anchor_stride, int tile,
-                                          int next_tile, int M, int AH, int H, float4* tbuf = nullptr) {
+                                          int next_tile, int M, int AH, int H, float4* tbuf = nullptr, float inv_qs = 1.f) {
   constexpr int CTB = BF ? CT / 2 : CT;      // 16-byte register chunks per tile and lane
   constexpr int CE = CTB * 16;               // embedding row stride in 4-byte words
   constexpr int NF = BF ? 2 * RT : RT;       // A fragments per chunk (bf16: hi and lo)
@@ -216,7 +216,7 @@ __device__ __forceinline__ void bias_tile(float4 (&b)[BF ? CT / 2 : CT], const f
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int row = 16 * rt + 4 * kq + j;      // rows >= AH: zero queries, never written out
-      float val = BF ? acc[rt][j] + acc_lo[rt][j] : acc[rt][j];
+      float val = (BF ? acc[rt][j] + acc_lo[rt][j] : acc[rt][j]) * inv_qs;      // (the folded queries were scaled by a power of two before their split)
       if (EQ) {
         const float4 e = UA ? e4[rt]
                             : ld4(eq_row + ((unsigned)min(row / H, AH / H - 1) * eq_anchor_stride + (unsigned)min(m, M - 1) * 4));
@@ -242,6 +242,12 @@ __global__ __launch_bounds__(256, MINW) void rpe_bias_kernel(const float* __rest
   __shared__ float4 qe_s[32];
   __shared__ __attribute__((aligned(16))) float stage_s[4 * RT * 16 * kStageStride];
   __shared__ float4 tbuf_s[TL ? 4 * 160 : 1];                 // TL: per wave two 16-row blocks of 80 bytes per row
+  // Round 5, late (the logits kernel's half): the folded queries of a query point are scaled by ONE power of two
+  // before their f16 / bf16 split -- the largest magnitude over the point's (anchor, head) rows goes to [2^6, 2^7) unless it already lies in
+  // [2^-4, 2^7) (then nothing changes: bit-identical) -- and the logits are scaled back in the tile epilogue: no overflow to Inf above 65504,
+  // no loss of the lo piece below 2^-3.  The four wave maxima travel through LDS in front of the barrier the staging has anyway.
+  __shared__ unsigned qmax_s[2][4];
+  int seg_parity = 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, kq = lane >> 4;
   float* stage = stage_s + wave * (RT * 16 * kStageStride);
   float4* tbuf = tbuf_s + (TL ? wave * 160 : 0);
@@ -289,7 +295,32 @@ __global__ __launch_bounds__(256, MINW) void rpe_bias_kernel(const float* __rest
 #pragma unroll
       for (int t = 0; t < CTB; t++) b[t] = ld4(E0 + 16 * t);
     }
+    float qs = 1.f, inv_qs = 1.f;
+    if (BF || HS) {
+      unsigned mb = 0;                     // (non-negative floats order like their bit patterns; NaN / Inf end up on top: no scaling)
+#pragma unroll
+      for (int u = 0; u < QI; u++) {
+        mb = max(mb, __float_as_uint(fabsf(qv[u].x)));
+        mb = max(mb, __float_as_uint(fabsf(qv[u].y)));
+        mb = max(mb, __float_as_uint(fabsf(qv[u].z)));
+        mb = max(mb, __float_as_uint(fabsf(qv[u].w)));
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, o));
+      if (lane == 0) qmax_s[seg_parity][wave] = mb;
+    }
     __syncthreads();                      // the previous segment's fragment reads are done
+    if (BF || HS) {
+      const unsigned mb = max(max(qmax_s[seg_parity][0], qmax_s[seg_parity][1]), max(qmax_s[seg_parity][2], qmax_s[seg_parity][3]));
+      seg_parity ^= 1;
+      const int e = (int)((mb >> 23) & 0xff);
+      if (!(e == 0 || e == 0xff || (e >= 123 && e <= 133))) {
+        qs = __uint_as_float((unsigned)(127 + 133 - e) << 23);
+        inv_qs = __uint_as_float((unsigned)(127 - 133 + e) << 23);
+#pragma unroll
+        for (int u = 0; u < QI; u++) qv[u] = make_float4(qv[u].x * qs, qv[u].y * qs, qv[u].z * qs, qv[u].w * qs);
+      }
+    }
 #pragma unroll
     for (int u = 0; u < QI; u++) {
       const int i = threadIdx.x + 256 * u;
@@ -331,11 +362,11 @@ __global__ __launch_bounds__(256, MINW) void rpe_bias_kernel(const float* __rest
     const unsigned bias_ah = (unsigned)cl.N * cl.Mp;
     for (; unit < u_hi; unit += 4) {
       const int t0 = unit << 1;
-      bias_tile<CT, RT, true, EQ, UA, BF, HS, TL>(b, afrag, qe_s, stage, 0, Erow, eq_row, eq_sa, t0, t0 + 1, cl.M, AH, H, tbuf);
+      bias_tile<CT, RT, true, EQ, UA, BF, HS, TL>(b, afrag, qe_s, stage, 0, Erow, eq_row, eq_sa, t0, t0 + 1, cl.M, AH, H, tbuf, inv_qs);
       if (unit + 4 < u_hi)
-        bias_tile<CT, RT, true, EQ, UA, BF, HS, TL>(b, afrag, qe_s, stage, 16, Erow, eq_row, eq_sa, t0 + 1, t0 + 8, cl.M, AH, H, tbuf);
+        bias_tile<CT, RT, true, EQ, UA, BF, HS, TL>(b, afrag, qe_s, stage, 16, Erow, eq_row, eq_sa, t0 + 1, t0 + 8, cl.M, AH, H, tbuf, inv_qs);
       else
-        bias_tile<CT, RT, false, EQ, UA, BF, HS, TL>(b, afrag, qe_s, stage, 16, Erow, eq_row, eq_sa, t0 + 1, t0 + 1, cl.M, AH, H, tbuf);
+        bias_tile<CT, RT, false, EQ, UA, BF, HS, TL>(b, afrag, qe_s, stage, 16, Erow, eq_row, eq_sa, t0 + 1, t0 + 1, cl.M, AH, H, tbuf, inv_qs);
       // the unit's (rows, 32 keys) block: 8 lanes cover one row's 128 bytes
       const int r8 = lane >> 3, m4 = (lane & 7) * 4;
 #pragma unroll
