@@ -626,12 +626,12 @@ class BlockedFeatures:
     it, kpconv_inter_so3 reads it); `plain()` is the ordinary tensor.
     kind 1: [point][C / 16][anchor pair][16 channels][2 anchors] (csrc/kpconv_mfma.hip: per-lane gathers of 8 bytes)
     kind 2: [point][C / 8][6 anchors][8 channels]                (csrc/kpconv_union.hip: a point's 8-channel chunk is 192 contiguous bytes)"""
-    __slots__ = ('data', 'shape', 'kind', 'amax')
+    __slots__ = ('data', 'shape', 'kind', 'amax', 'amax_tag')
 
-    def __init__(self, data, shape, kind=1, amax=None):
+    def __init__(self, data, shape, kind=1, amax=None, amax_tag=None):
         # amax: one-element device tensor holding the largest |value| (written by the apply pass that produced `data`), or None: the fused
         # kernels scale the features by a power of two from it before their f16 split (csrc/kpconv_sums.h: x_split_scale)
-        self.data, self.shape, self.kind, self.amax = data, tuple(shape), kind, amax
+        self.data, self.shape, self.kind, self.amax, self.amax_tag = data, tuple(shape), kind, amax, amax_tag
 
     def plain(self):
         n, a, c = self.shape
@@ -665,13 +665,23 @@ def _amax_slot(device, stream):
     key = (device, stream.value)
     ring = _amax_rings.get(key)
     if ring is None:
-        ring = _amax_rings[key] = [torch.zeros((4096,), dtype=torch.float32, device=device), 0]
+        ring = _amax_rings[key] = [torch.zeros((4096,), dtype=torch.float32, device=device), 0, 0]
     if ring[1] == 4096:
         ring[0].zero_()
         ring[1] = 0
+        ring[2] += 1                     # generation: words handed out before the wrap are no longer their owners'
     slot = ring[0][ring[1]:ring[1] + 1]
     ring[1] += 1
-    return slot
+    return slot, (ring, ring[2], ring[1] - 1)
+
+
+def _amax_live(blocked):
+    """The magnitude word of a BlockedFeatures, or None when the ring it came from has wrapped past it since (an object kept for more than
+    4096 apply passes of its stream: its word may describe another tensor by now -- the kernels then split the features as they are)."""
+    if blocked.amax is None or blocked.amax_tag is None:
+        return blocked.amax
+    ring, gen, pos = blocked.amax_tag
+    return blocked.amax if (ring[2] == gen or (ring[2] == gen + 1 and ring[1] <= pos)) else None
 
 
 def _kpconv_union_pays(Cin, Cout, same_cloud):
@@ -845,13 +855,13 @@ def group_norm_apply(x, residual=None, final_slope=1.0, blocked=False):
     aa = x.affines + [None]
     sl = x.slopes + [1.0]
     stream = _stream()
-    amax = _amax_slot(raw.device, stream) if blocked else None
+    amax, amax_tag = _amax_slot(raw.device, stream) if blocked else (None, None)
     check(lib().se3_group_norm_apply_amax(raw.data_ptr(), aa[0].data_ptr(), float(sl[0]), aa[1].data_ptr() if aa[1] is not None else None, float(sl[1]),
                                           res.data_ptr() if res is not None else None, res_aff.data_ptr() if res_aff is not None else None,
                                           float(final_slope), rows, C, _i64_array(segments) if nseg > 1 else None, nseg, int(blocked),
                                           out.data_ptr(), amax.data_ptr() if amax is not None else None, stream),
           'se3_group_norm_apply')
-    return BlockedFeatures(out, raw.shape, int(blocked), amax) if blocked else out
+    return BlockedFeatures(out, raw.shape, int(blocked), amax, amax_tag) if blocked else out
 
 
 _host_table_cache = {}
@@ -1130,7 +1140,7 @@ def kpconv_inter_so3(x, q_pts, s_pts, idx, kernel_points, weights, kidx, ridx, s
     x: (Ns, 6, Cin) tensor or BlockedFeatures (inference: written by group_norm_apply(blocked=True))."""
     blocked = isinstance(x, BlockedFeatures)
     xb = x.data if blocked else None
-    x_amax = x.amax if blocked else None
+    x_amax = _amax_live(x) if blocked else None
     if blocked:
         Ns, A, Cin = x.shape
     else:

@@ -1345,6 +1345,26 @@ def test_rpe_logits_query_scale_over_magnitudes(scale, A):
     assert float((err / ref).max()) <= 3e-6, (scale, A, float((err / ref).max()))
 
 
+def test_magnitude_word_of_blocked_features_expires_with_its_ring():
+    """ops._amax_slot hands out words of a per-stream ring that is cleared every 4096 apply passes: a BlockedFeatures kept beyond that must not
+    be scaled by a word that describes another tensor by then (ops._amax_live: None -> the features are split as they are)."""
+    from se3et_amd import ops
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(40, 6, 16, generator=g).cuda()
+    aff = torch.stack((torch.ones(16), torch.zeros(16)))[None].cuda()
+    first = ops.group_norm_apply(ops.Pending(x, [aff], [1.0], None), None, 1.0, 2)
+    assert ops._amax_live(first) is first.amax and float(first.amax.cpu()) == float(x.abs().max().cpu())
+    ring = first.amax_tag[0]
+    ring[1] = 4096                                                    # the ring is about to wrap
+    second = ops.group_norm_apply(ops.Pending(x * 3, [aff], [1.0], None), None, 1.0, 2)
+    assert ops._amax_live(second) is second.amax and float(second.amax.cpu()) == float((x * 3).abs().max().cpu())
+    assert second.amax_tag[2] == 0 and first.amax_tag[2] > 0 and ops._amax_live(first) is first.amax      # its word has not been handed out again yet
+    ring[1] = first.amax_tag[2] + 1                                   # ... now it has
+    assert ops._amax_live(first) is None
+    ring[1], ring[2] = 5, ring[2] + 1                                 # a second wrap: everything of the old generations is gone
+    assert ops._amax_live(second) is None
+
+
 def test_neighbor_table_trim_marks_each_pairs_surplus_columns():
     """csrc/radius_neighbors.hip: the stacked neighbour table cut to the batch's width with the columns past every PAIR's own width set to
     -1 -- against the column copy + per-pair strided fill it replaces."""
