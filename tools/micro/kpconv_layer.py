@@ -8,7 +8,7 @@ from se3et_amd.model import make_cfg
 from se3et_amd.synthetic import make_pair
 layer = int(sys.argv[1]); path = sys.argv[2] if len(sys.argv) > 2 else 'fused'; calls = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 dev = torch.device('cuda'); cfg = make_cfg('se3ete'); b = cfg.backbone
-ops.KPCONV_UNION_ALL = True
+ops.KPCONV_UNION = ops.KPCONV_UNION_ALL = True          # (orders for every stage while the pyramid is built; the path is picked below)
 clouds = []
 for j in range(8):
     ref, src, _ = make_pair('c2_5k', index=j); clouds += [ref, src]

@@ -7,7 +7,7 @@ from se3et_amd.data import precompute_data_stack_mode
 from se3et_amd.model import make_cfg
 from se3et_amd.synthetic import make_pair
 dev = torch.device('cuda'); cfg = make_cfg('se3ete'); b = cfg.backbone
-ops.KPCONV_UNION_ALL = True          # every layer on the union-staged kernel, whatever the dispatch policy says
+ops.KPCONV_UNION = ops.KPCONV_UNION_ALL = True          # every layer on the union-staged kernel, whatever the default / the dispatch policy say
 kidx = torch.from_numpy(tables.kernel_slot_table()).to(dev); ridx = torch.from_numpy(tables.anchor_slot_table()).to(dev)
 def timeit(f, n=10):
     f(); torch.cuda.synchronize()
