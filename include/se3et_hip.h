@@ -61,6 +61,9 @@ void se3_debug_set_kpconv_union_variant(int variant);
  * row's f16-split scale -- more than 2^8 times the largest magnitude of the row's first 32 values -- or held NaN / Inf, since the last
  * reset: such values are clamped to the f16 range (finite, wrong) and counted here (events: once per row, K-step and column block).  Synchronises the device; reset != 0 zeroes the count. */
 unsigned long long se3_debug_dense_saturated_rows(int reset);
+/* values of q / K / V^T that the stand-alone operand splits of the f16 attention kernels clamped to the f16 range (|x| > 65000, NaN, Inf) since the
+ * last reset: those operands are split as they are (projections of LayerNorm outputs); a non-zero count says the scores are not the reference's. */
+unsigned long long se3_debug_attention_saturated(int reset);
 /* Per-launch timing of the two RPE self-attention kernels (bench.py): while enabled every launch carries its own start / stop
  * HIP event pair (hipExtLaunchKernelGGL) on the launch stream; collect() waits for them, returns the count and fills the
  * durations (us) and tags (1 = relative-position logits kernel, 2 = attention kernel) in launch order. */

@@ -20,6 +20,7 @@ SIGNATURES = {
     'se3_debug_set_kpconv_variant': (None, [_i32]),
     'se3_debug_set_kpconv_union_variant': (None, [_i32]),
     'se3_debug_dense_saturated_rows': (ctypes.c_uint64, [_i32]),
+    'se3_debug_attention_saturated': (ctypes.c_uint64, [_i32]),
     'se3_debug_set_attention_profile': (None, [_vp]),
     'se3_debug_kernel_timing': (None, [_i32]),
     'se3_debug_kernel_timing_collect': (_i32, [_vp, _vp, _i32]),

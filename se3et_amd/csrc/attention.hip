@@ -1170,26 +1170,49 @@ __device__ __forceinline__ void h2_split8(const float (&x)[8], uint4& hi, uint4&
   lo = __builtin_bit_cast(uint4, l);
 }
 
+// The stand-alone operand splits of the f16 attention kernels (q / K rows, V^T) take their values as they are -- projections of LayerNorm
+// outputs -- but never let one leave the f16 range silently: a value beyond 65000 (NaN / Inf included) is clamped, and the launch counts it
+// (se3_debug_attention_saturated: loud instead of Inf in every key's score; the open remainder of the f16-window item).
+__device__ unsigned long long g_attn_saturated = 0;
+__device__ __forceinline__ bool h2_split8_sat(const float (&x)[8], uint4& hi, uint4& lo) {
+  float c[8];
+  bool sat = false;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    c[i] = fminf(fmaxf(x[i], -65000.f), 65000.f);              // (NaN -> -65000)
+    sat |= !(c[i] == x[i]);
+  }
+  h2_split8(c, hi, lo);
+  return sat;
+}
+__device__ __forceinline__ void count_saturated(bool sat) {
+  const unsigned long long m = __ballot(sat);
+  if (m != 0ull && (threadIdx.x & 63) == 0) atomicAdd(&g_attn_saturated, (unsigned long long)__popcll(m));
+}
+
 // rows (A, R, C) with anchor stride -> pieces [2][A][R][C] f16; one thread per 8 channels
 __global__ __launch_bounds__(256) void x6_split_rows_kernel(const float* __restrict__ x, int A, int64_t R, int C, int64_t anchor_stride,
                                                             uint4* __restrict__ out) {
   const int64_t per = R * (C / 8), total = A * per;
+  bool sat = false;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t a = i / per, rem = i - a * per;
     const float* src = x + a * anchor_stride + rem * 8;
     const float4 lo = ld4(src), hi = ld4(src + 4);
     const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     uint4 p1, p2;
-    h2_split8(v, p1, p2);
+    sat |= h2_split8_sat(v, p1, p2);
     out[i] = p1;
     out[total + i] = p2;
   }
+  count_saturated(sat);
 }
 // transposed values (A, C, v_rs) with anchor stride -> pieces [2][A][C][v_rs] f16, the keys of every aligned block of 16 in the order
 // 0..3, 8..11, 4..7, 12..15; one thread per 16 keys
 __global__ __launch_bounds__(256) void x6_split_vt_kernel(const float* __restrict__ vt, int A, int C, int v_rs, int64_t anchor_stride,
                                                           uint4* __restrict__ out) {
   const int64_t blocks = v_rs / 16, per = (int64_t)C * blocks, total = A * per;
+  bool sat = false;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t a = i / per, rem = i - a * per;
     const float* src = vt + a * anchor_stride + rem * 16;
@@ -1197,11 +1220,12 @@ __global__ __launch_bounds__(256) void x6_split_vt_kernel(const float* __restric
     const float lo[8] = {q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, q2.z, q2.w};      // keys 0..3, 8..11
     const float hi[8] = {q1.x, q1.y, q1.z, q1.w, q3.x, q3.y, q3.z, q3.w};      // keys 4..7, 12..15
     uint4 a1, a2, b1, b2;
-    h2_split8(lo, a1, a2);
-    h2_split8(hi, b1, b2);
+    sat |= h2_split8_sat(lo, a1, a2);
+    sat |= h2_split8_sat(hi, b1, b2);
     out[2 * i] = a1; out[2 * i + 1] = b1;
     out[2 * (total + i)] = a2; out[2 * (total + i) + 1] = b2;
   }
+  count_saturated(sat);
 }
 
 // Value of lane i ^ 32 (the other half of the wave): one v_permlane32_swap instead of a ds_bpermute round trip through the LDS pipeline.
@@ -1687,6 +1711,7 @@ extern "C" int se3_rpe_bias_stack_bf16_fwd(const float* qp, const float* qe, int
 __global__ __launch_bounds__(256) void attn_split_kv_kernel(const float* __restrict__ k, int k_rs, int64_t k_sa, const float* __restrict__ vt, int v_rs,
                                                             int64_t v_sa, int A, int64_t R, int C, uint4* __restrict__ outk, uint4* __restrict__ outv) {
   const int64_t kper = R * (C / 8), ktot = A * kper, vblocks = v_rs / 16, vper = (int64_t)C * vblocks, vtot = A * vper;
+  bool sat = false;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ktot + vtot; i += (int64_t)gridDim.x * 256) {
     if (i < ktot) {
       const int64_t a = i / kper, rem = i - a * kper, row = rem / (C / 8), c8 = rem - row * (C / 8);
@@ -1694,7 +1719,7 @@ __global__ __launch_bounds__(256) void attn_split_kv_kernel(const float* __restr
       const float4 lo = ld4(src), hi = ld4(src + 4);
       const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
       uint4 p1, p2;
-      h2_split8(v, p1, p2);
+      sat |= h2_split8_sat(v, p1, p2);
       outk[i] = p1;
       outk[ktot + i] = p2;
     } else {
@@ -1704,12 +1729,13 @@ __global__ __launch_bounds__(256) void attn_split_kv_kernel(const float* __restr
       const float lo[8] = {q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, q2.z, q2.w};      // keys 0..3, 8..11
       const float hi[8] = {q1.x, q1.y, q1.z, q1.w, q3.x, q3.y, q3.z, q3.w};      // keys 4..7, 12..15
       uint4 a1, a2, b1, b2;
-      h2_split8(lo, a1, a2);
-      h2_split8(hi, b1, b2);
+      sat |= h2_split8_sat(lo, a1, a2);
+      sat |= h2_split8_sat(hi, b1, b2);
       outv[2 * j] = a1; outv[2 * j + 1] = b1;
       outv[2 * (vtot + j)] = a2; outv[2 * (vtot + j) + 1] = b2;
     }
   }
+  count_saturated(sat);
 }
 
 struct AttnPieces { const uint4 *k[2], *v[2]; };
@@ -2439,4 +2465,14 @@ extern "C" int se3_cross_eq_apply(const float* q, const float* k, const float* v
   if (rc != SE3_OK) return rc;
   SE3_CHECK_LAUNCH("cross_eq_apply");
   return SE3_OK;
+}
+
+extern "C" unsigned long long se3_debug_attention_saturated(int reset) {
+  unsigned long long n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_attn_saturated), sizeof(n)) != hipSuccess) return ~0ull;
+  if (reset) {
+    const unsigned long long zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_saturated), &zero, sizeof(zero));
+  }
+  return n;
 }

@@ -159,6 +159,12 @@ def dense_saturated_rows(reset=True):
     return int(lib().se3_debug_dense_saturated_rows(1 if reset else 0))
 
 
+def attention_saturated(reset=True):
+    """Values of q / K / V^T that the operand splits of the f16 attention kernels clamped to the f16 range since the last reset (csrc/attention.hip:
+    h2_split8_sat).  One device synchronisation."""
+    return int(lib().se3_debug_attention_saturated(1 if reset else 0))
+
+
 def linear_stream_ok(x, weight):
     """True when linear_stream applies: inference, f32 GPU tensors, unit-stride rows aligned to 16 bytes, in_features a multiple of 32."""
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):

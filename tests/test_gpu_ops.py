@@ -1365,6 +1365,34 @@ def test_magnitude_word_of_blocked_features_expires_with_its_ring():
     assert ops._amax_live(second) is None
 
 
+def test_attention_operand_splits_clamp_and_count_instead_of_overflowing():
+    """The q / K / V^T operands of the f16 attention kernels are split as they are (the open remainder of the f16-window item): a value beyond
+    the f16 range must not become Inf -- it is clamped and the launch counts it (ops.attention_saturated); normal magnitudes count nothing."""
+    from se3et_amd import functional as SF
+    from se3et_amd import ops
+    g = torch.Generator().manual_seed(9)
+    A, lengths, C, H = 6, (70, 64), 256, 4
+    st = _attn_state(C, True)
+    xs = [torch.randn(A, n, C, generator=g) for n in lengths]
+    embs = [torch.randn(n, n, C, generator=g) for n in lengths]
+    eqs = [torch.randn(A, n, n, 4, generator=g) for n in lengths]
+    w_stack, b_stack, offs = SF.compose_self_attention_weights(st['l.proj_q.weight'], st['l.proj_q.bias'], st['l.proj_k.weight'],
+                                                               st['l.proj_k.bias'], st['l.proj_p.weight'], st['l.proj_eq.weight'], H)
+
+    def run(bias_k):
+        packed, starts = SF.pack_rows([x.cuda() for x in xs])
+        b = b_stack.clone()
+        b[offs['k'] + 3] += bias_k                          # one key channel of every row far outside the f16 range
+        return SF.rpe_self_attention_packed(packed, starts, list(lengths), [e.cuda() for e in embs], [e.cuda() for e in eqs], w_stack.cuda(),
+                                            b.cuda(), offs, st['l.proj_v.weight'].cuda(), st['l.proj_v.bias'].cuda(), H).cpu()
+    ops.attention_saturated(reset=True)
+    base = run(0.0)
+    assert ops.attention_saturated() == 0 and torch.isfinite(base).all()
+    out = run(1e7)
+    assert ops.attention_saturated() > 0
+    assert torch.isfinite(out).all()
+
+
 def test_neighbor_table_trim_marks_each_pairs_surplus_columns():
     """csrc/radius_neighbors.hip: the stacked neighbour table cut to the batch's width with the columns past every PAIR's own width set to
     -1 -- against the column copy + per-pair strided fill it replaces."""
