@@ -291,6 +291,29 @@ int se3_kpconv_so3_gather(const float* q_pts, const float* s_pts, const int64_t*
 int se3_kpconv_so3_gather_bwd(const float* q_pts, const float* s_pts, const int64_t* idx, const float* dG,
                               const float* kernel_points_host, const int64_t* kidx_host, const int64_t* ridx_host, float sigma,
                               int64_t num_queries, int64_t num_support, int num_neighbors, int in_channels, float* dx, void* stream);
+/* The same with an ORDER-INDEPENDENT sum (round 5): the contributions are added as 64-bit fixed-point integers at a scale taken from max |dG|
+ * (max_abs_dG: DEVICE word, any upper bound), so two runs are bit-identical; dx_fixed (num_support, 6, in_channels) int64, ZERO on entry;
+ * se3_kpconv_fixed_to_float(dx_fixed, num_support * 6 * in_channels, max_abs_dG, num_queries, dx) converts the sums to float32. */
+int se3_kpconv_so3_gather_bwd_fixed(const float* q_pts, const float* s_pts, const int64_t* idx, const float* dG,
+                                    const float* kernel_points_host, const int64_t* kidx_host, const int64_t* ridx_host, float sigma,
+                                    int64_t num_queries, int64_t num_support, int num_neighbors, int in_channels, const float* max_abs_dG,
+                                    long long* dx_fixed, void* stream);
+int se3_kpconv_fixed_to_float(const long long* dx_fixed, int64_t count, const float* max_abs_dG, int64_t num_queries, float* dx, void* stream);
+/* Order-independent (bit-identical) forms of the other scatter-adds of the training step, the same 64-bit fixed-point scheme (csrc/common.h:
+ * se3_fixed_scale_exp): se3_fixed_to_float(fixed, count, bound, terms, growth, out) converts sums accumulated with the same (bound, terms, growth).
+ *   se3_neighbor_max_pool_bwd_fixed   backward of se3_neighbor_max_pool (terms = rows of idx, growth 0)
+ *   se3_scatter_add_rows_fixed        backward of se3_gather_rows_padded (terms = gathered rows, growth 0)
+ *   se3_add_layer_norm_bwd_partials   backward of se3_add_layer_norm_fwd with per-workgroup partial parameter sums
+ *                                     (se3_add_layer_norm_bwd_blocks(rows), 3, channels) that the caller adds in order */
+int se3_fixed_to_float(const long long* fixed, int64_t count, const float* bound, int64_t terms, int growth, float* out, void* stream);
+int se3_neighbor_max_pool_bwd_fixed(const float* x, const int64_t* idx, const float* dout, int64_t n, int64_t m, int nn, int64_t width,
+                                    const float* max_abs_dout, long long* dx_fixed, void* stream);
+int se3_scatter_add_rows_fixed(const float* g, const int64_t* idx, int64_t n, int64_t m, int64_t width, const float* max_abs_g,
+                               long long* dx_fixed, void* stream);
+int64_t se3_add_layer_norm_bwd_blocks(int64_t rows);
+int se3_add_layer_norm_bwd_partials(const float* hidden, const float* hidden_bias, const float* residual, const float* weight,
+                                    const float* grad_out, int64_t rows, int64_t residual_rows, int channels, float eps, float* grad_hidden,
+                                    float* grad_params_partials, void* stream);
 
 /* Matrix-core form of the same convolution (csrc/kpconv_sums.h, csrc/kpconv_mfma.hip; input channels a multiple of 8, output channels a
  * multiple of 32, SE3ET slot tables compiled in; num_support * 6 * in_channels < 2^31).  Over all (weight slot s, output anchor r) only 16

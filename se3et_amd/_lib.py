@@ -62,6 +62,13 @@ SIGNATURES = {
     'se3_neighbor_max_pool_bwd': (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i64, _vp, _vp]),
     'se3_kpconv_so3_gather': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _i32, _vp, _vp]),
     'se3_kpconv_so3_gather_bwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _i32, _vp, _vp]),
+    'se3_kpconv_so3_gather_bwd_fixed': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
+    'se3_kpconv_fixed_to_float': (_i32, [_vp, _i64, _vp, _i64, _vp, _vp]),
+    'se3_fixed_to_float': (_i32, [_vp, _i64, _vp, _i64, _i32, _vp, _vp]),
+    'se3_neighbor_max_pool_bwd_fixed': (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i64, _vp, _vp, _vp]),
+    'se3_scatter_add_rows_fixed': (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
+    'se3_add_layer_norm_bwd_blocks': (_i64, [_i64]),
+    'se3_add_layer_norm_bwd_partials': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _f32, _vp, _vp, _vp]),
     'se3_kpconv_sums_bytes': (_sz, [_i64, _i32]),
     'se3_kpconv_so3_gather_sums': (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp]),
     'se3_kpconv_weight_pieces_bytes': (_sz, [_i32, _i32]),

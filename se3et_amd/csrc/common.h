@@ -62,6 +62,23 @@ __device__ __forceinline__ float se3_ref_sq_dist(float px, float py, float pz, f
   return fmaxf(b, 0.f);
 }
 
+// Order-independent accumulation (the training step's scatter-adds): contributions are added as 64-bit FIXED-POINT integers -- integer
+// addition is associative, so the sum does not depend on the arrival order of the atomics and two runs are bit-identical.  The scale comes
+// from an upper bound of the contributions (*bound: max |gradient| of the call, a DEVICE word), `growth` = log2 of how much one contribution
+// can exceed it, and the number of contributions that can meet in one element (<= terms): 2^(61 - e) with 2^e >= 2^growth terms bound cannot
+// overflow and resolves bound 2^-(54 - growth - log2 terms) -- below the float32 rounding of the sum the float atomics produce.
+__device__ __forceinline__ int se3_fixed_scale_exp(const float* bound, int64_t terms, int growth) {
+  const unsigned b = __float_as_uint(*bound);
+  const int eb = (int)((b >> 23) & 0xff) - 126;                          // bound < 2^eb
+  int lg = 1;
+  while ((1ll << lg) < terms + 1) lg++;
+  return 61 - (eb + growth + lg);
+}
+__device__ __forceinline__ void se3_fixed_add(unsigned long long* acc, float v, double scale) {
+  const long long q = __double2ll_rn((double)v * scale);
+  if (q != 0) atomicAdd(acc, (unsigned long long)q);                      // (two's complement: unsigned wrap-around addition is signed addition)
+}
+
 __device__ __forceinline__ int se3_lane() { return threadIdx.x & (SE3_WAVE - 1); }
 
 __device__ __forceinline__ float se3_wave_sum(float v) {

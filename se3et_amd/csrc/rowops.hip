@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float* __restrict__ h
 // dh = dv (also the residual's gradient; summed over the anchor blocks by the caller when the residual was broadcast); per-channel sums
 // params[0] = sum_rows dy xhat (d weight), params[1] = sum_rows dy (d bias), params[2] = sum_rows dv (d hidden_bias): a wave walks 8 rows with the
 // sums in registers, the four waves of a workgroup meet in LDS, one float atomic per channel, sum and workgroup (params zero-initialised).
-template <int VPL>
+template <int VPL, bool PARTIALS = false>      // PARTIALS: params is [workgroup][3][C], written, not accumulated (se3_add_layer_norm_bwd_partials)
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict__ h, const float* __restrict__ hb,
                                                          const float* __restrict__ res, const float* __restrict__ w,
                                                          const float* __restrict__ dy, int64_t rows, int64_t res_rows, int C, float eps,
@@ -630,7 +630,8 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
     float t = 0.f;
 #pragma unroll
     for (int wv = 0; wv < 4; wv++) t += reinterpret_cast<const float*>(&red[which][wv][0])[c];
-    unsafeAtomicAdd(params + e, t);
+    if (PARTIALS) params[(size_t)blockIdx.x * 3 * C + e] = t;                  // per-block sums: the caller adds them in block order (deterministic)
+    else unsafeAtomicAdd(params + e, t);
   }
 }
 
@@ -708,9 +709,12 @@ __global__ __launch_bounds__(256) void neighbor_max_kernel(const float* __restri
 // Backward of neighbor_max_kernel: the gradient of out[r, c] goes to the neighbour that holds the maximum (the first one in table order on
 // ties, as torch.max(dim) picks a single index; nothing when the maximum is the zero row of a padded entry).  dx is accumulated with
 // hardware float atomics (several rows share a neighbour) and must be zero-initialised by the caller.
+template <bool FIXED = false>      // FIXED: 64-bit fixed-point sums (common.h: order-independent, bit-identical runs), dxf zero on entry
 __global__ __launch_bounds__(256) void neighbor_max_bwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
                                                                const float* __restrict__ dout, int64_t n, int64_t m, int nn,
-                                                               int64_t width, float* __restrict__ dx) {
+                                                               int64_t width, float* __restrict__ dx, const float* __restrict__ bound = nullptr,
+                                                               unsigned long long* __restrict__ dxf = nullptr) {
+  const double fscale = FIXED ? ldexp(1.0, se3_fixed_scale_exp(bound, m, 0)) : 1.0;
   __shared__ int64_t nb[64];
   const int64_t r = blockIdx.x;
   for (int j = threadIdx.x; j < nn; j += blockDim.x) nb[j] = idx[r * nn + j];
@@ -727,7 +731,10 @@ __global__ __launch_bounds__(256) void neighbor_max_bwd_kernel(const float* __re
         arg = s;
       }
     }
-    if (arg >= 0 && arg < n) unsafeAtomicAdd(dx + arg * width + c, dout[r * width + c]);
+    if (arg >= 0 && arg < n) {
+      if constexpr (FIXED) se3_fixed_add(dxf + arg * width + c, dout[r * width + c], fscale);
+      else unsafeAtomicAdd(dx + arg * width + c, dout[r * width + c]);
+    }
   }
 }
 
@@ -998,6 +1005,31 @@ extern "C" int se3_add_layer_norm_fwd(const float* hidden, const float* hidden_b
   return SE3_OK;
 }
 
+// The same with per-workgroup partial sums instead of float atomics: grad_params_partials is (se3_add_layer_norm_bwd_blocks(rows), 3, channels),
+// every element written; the caller adds the blocks in order (a deterministic reduction: two runs are bit-identical).
+extern "C" int64_t se3_add_layer_norm_bwd_blocks(int64_t rows) { return se3_cdiv(rows, 32); }
+extern "C" int se3_add_layer_norm_bwd_partials(const float* hidden, const float* hidden_bias, const float* residual, const float* weight,
+                                               const float* grad_out, int64_t rows, int64_t residual_rows, int channels, float eps,
+                                               float* grad_hidden, float* grad_params_partials, void* stream) {
+  SE3_REQUIRE(hidden && residual && weight && grad_out && grad_hidden && grad_params_partials, SE3_ERR_INVALID_ARG, "add_layer_norm_bwd: null pointer");
+  SE3_REQUIRE(channels >= 4 && channels % 4 == 0 && channels <= 2048 && residual_rows >= 1 && rows % residual_rows == 0, SE3_ERR_UNSUPPORTED,
+              "add_layer_norm_bwd: channels %d (multiple of 4, <= 2048), rows %lld / residual rows %lld", channels, (long long)rows,
+              (long long)residual_rows);
+  if (rows == 0) return SE3_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)se3_cdiv(rows, 32);
+  if (channels <= 256)
+    add_ln_bwd_kernel<1, true><<<grid, 256, 0, st>>>(hidden, hidden_bias, residual, weight, grad_out, rows, residual_rows, channels, eps, grad_hidden, grad_params_partials);
+  else if (channels <= 512)
+    add_ln_bwd_kernel<2, true><<<grid, 256, 0, st>>>(hidden, hidden_bias, residual, weight, grad_out, rows, residual_rows, channels, eps, grad_hidden, grad_params_partials);
+  else if (channels <= 1024)
+    add_ln_bwd_kernel<4, true><<<grid, 256, 0, st>>>(hidden, hidden_bias, residual, weight, grad_out, rows, residual_rows, channels, eps, grad_hidden, grad_params_partials);
+  else
+    add_ln_bwd_kernel<8, true><<<grid, 256, 0, st>>>(hidden, hidden_bias, residual, weight, grad_out, rows, residual_rows, channels, eps, grad_hidden, grad_params_partials);
+  SE3_CHECK_LAUNCH("add_layer_norm_bwd");
+  return SE3_OK;
+}
+
 // Backward of se3_add_layer_norm_fwd: grad_hidden (rows, channels) (= the gradient of the un-broadcast residual), grad_params (3, channels) =
 // (d weight, d bias, d hidden_bias), zero-initialised by the caller (float atomics).
 extern "C" int se3_add_layer_norm_bwd(const float* hidden, const float* hidden_bias, const float* residual, const float* weight,
@@ -1052,8 +1084,45 @@ extern "C" int se3_neighbor_max_pool_bwd(const float* x, const int64_t* idx, con
   SE3_REQUIRE(x && idx && dout && dx && nn >= 1 && nn <= 64, SE3_ERR_INVALID_ARG, "neighbor_max_pool_bwd: bad arguments (nn <= 64)");
   if (m * width == 0) return SE3_OK;
   const int threads = width >= 256 ? 256 : (width >= 128 ? 128 : 64);
-  neighbor_max_bwd_kernel<<<(unsigned)m, threads, 0, (hipStream_t)stream>>>(x, idx, dout, n, m, nn, width, dx);
+  neighbor_max_bwd_kernel<false><<<(unsigned)m, threads, 0, (hipStream_t)stream>>>(x, idx, dout, n, m, nn, width, dx);
   SE3_CHECK_LAUNCH("neighbor_max_pool_bwd");
+  return SE3_OK;
+}
+
+// The same with order-independent 64-bit fixed-point sums: dx_fixed (n, width) int64, ZERO on entry; max_abs_dout: DEVICE word (any upper bound
+// of |dout|); se3_fixed_to_float(dx_fixed, n * width, max_abs_dout, m, 0, dx) converts.
+extern "C" int se3_neighbor_max_pool_bwd_fixed(const float* x, const int64_t* idx, const float* dout, int64_t n, int64_t m, int nn,
+                                               int64_t width, const float* max_abs_dout, long long* dx_fixed, void* stream) {
+  SE3_REQUIRE(x && idx && dout && max_abs_dout && dx_fixed && nn >= 1 && nn <= 64, SE3_ERR_INVALID_ARG, "neighbor_max_pool_bwd_fixed: bad arguments (nn <= 64)");
+  if (m * width == 0) return SE3_OK;
+  const int threads = width >= 256 ? 256 : (width >= 128 ? 128 : 64);
+  neighbor_max_bwd_kernel<true><<<(unsigned)m, threads, 0, (hipStream_t)stream>>>(x, idx, dout, n, m, nn, width, nullptr, max_abs_dout,
+                                                                                  reinterpret_cast<unsigned long long*>(dx_fixed));
+  SE3_CHECK_LAUNCH("neighbor_max_pool_bwd_fixed");
+  return SE3_OK;
+}
+
+// Transpose of se3_gather_rows_padded (its backward): dx_fixed[idx[i], :] += g[i, :] for idx[i] in [0, n) as 64-bit fixed-point sums (order-
+// independent); dx_fixed (n, width) int64 ZERO on entry; se3_fixed_to_float(dx_fixed, n * width, max_abs_g, m, 0, dx) converts.
+namespace {
+__global__ __launch_bounds__(256) void scatter_add_rows_fixed_kernel(const float* __restrict__ g, const int64_t* __restrict__ idx, int64_t n, int64_t m,
+                                                                     int64_t width, const float* __restrict__ bound,
+                                                                     unsigned long long* __restrict__ dxf) {
+  const double fscale = ldexp(1.0, se3_fixed_scale_exp(bound, m, 0));
+  const int64_t total = m * width;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / width, c = i - r * width, j = idx[r];
+    if (j >= 0 && j < n) se3_fixed_add(dxf + j * width + c, g[i], fscale);
+  }
+}
+}  // namespace
+extern "C" int se3_scatter_add_rows_fixed(const float* g, const int64_t* idx, int64_t n, int64_t m, int64_t width, const float* max_abs_g,
+                                          long long* dx_fixed, void* stream) {
+  SE3_REQUIRE(g && idx && max_abs_g && dx_fixed, SE3_ERR_INVALID_ARG, "scatter_add_rows_fixed: null pointer");
+  if (m * width == 0) return SE3_OK;
+  scatter_add_rows_fixed_kernel<<<grid_for(m * width, 256), 256, 0, (hipStream_t)stream>>>(g, idx, n, m, width, max_abs_g,
+                                                                                          reinterpret_cast<unsigned long long*>(dx_fixed));
+  SE3_CHECK_LAUNCH("scatter_add_rows_fixed");
   return SE3_OK;
 }
 

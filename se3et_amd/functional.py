@@ -119,8 +119,10 @@ def anchor_max(x, dim=1):
 def gather_rows_padded(x, idx):
     """x[idx] where idx == x.shape[0] addresses an implicit all-zero row."""
     if AG.needs_grad(x):
-        def bwd(g, needs, x_, idx_):        # rows back onto their sources; the padding row n is dropped (index_add: float atomics)
+        def bwd(g, needs, x_, idx_):        # rows back onto their sources; the padding row n is dropped
             n = x_.shape[0]
+            if _ops.TRAINING_DETERMINISTIC and g.is_cuda:      # order-independent fixed-point sums (index_add_: float atomics)
+                return _ops.scatter_add_rows(g, idx_, n), None
             dx = g.new_zeros((n + 1,) + tuple(x_.shape[1:]))
             flat = torch.where((idx_ < 0) | (idx_ > n), torch.full_like(idx_, n), idx_).reshape(-1)
             dx.index_add_(0, flat, g.reshape((-1,) + tuple(x_.shape[1:])))

@@ -470,10 +470,18 @@ def add_layer_norm_bwd(grad_out, hidden, residual, weight, eps, hidden_bias=None
     res = _req(residual.contiguous(), torch.float32, 'residual')
     rows, res_rows = hidden.numel() // C, res.numel() // C
     dh = torch.empty_like(hidden)
-    params = torch.zeros((3, C), dtype=torch.float32, device=hidden.device)
-    check(lib().se3_add_layer_norm_bwd(hidden.data_ptr(), hidden_bias.data_ptr() if hidden_bias is not None else None, res.data_ptr(),
-                                       weight.data_ptr(), g.data_ptr(), rows, res_rows, C, float(eps), dh.data_ptr(), params.data_ptr(),
-                                       _stream()), 'se3_add_layer_norm_bwd')
+    if TRAINING_DETERMINISTIC:
+        # per-workgroup partial sums added in order by one torch reduction (no float atomics: bit-identical runs)
+        part = torch.empty((int(lib().se3_add_layer_norm_bwd_blocks(rows)), 3, C), dtype=torch.float32, device=hidden.device)
+        check(lib().se3_add_layer_norm_bwd_partials(hidden.data_ptr(), hidden_bias.data_ptr() if hidden_bias is not None else None, res.data_ptr(),
+                                                    weight.data_ptr(), g.data_ptr(), rows, res_rows, C, float(eps), dh.data_ptr(), part.data_ptr(),
+                                                    _stream()), 'se3_add_layer_norm_bwd_partials')
+        params = part.sum(0)
+    else:
+        params = torch.zeros((3, C), dtype=torch.float32, device=hidden.device)
+        check(lib().se3_add_layer_norm_bwd(hidden.data_ptr(), hidden_bias.data_ptr() if hidden_bias is not None else None, res.data_ptr(),
+                                           weight.data_ptr(), g.data_ptr(), rows, res_rows, C, float(eps), dh.data_ptr(), params.data_ptr(),
+                                           _stream()), 'se3_add_layer_norm_bwd')
     dres = dh if res_rows == rows else dh.reshape(rows // res_rows, res_rows, C).sum(0)
     return dh, dres.reshape(residual.shape), params[0], params[1], (params[2] if hidden_bias is not None else None)
 
@@ -520,10 +528,35 @@ def neighbor_max_pool_bwd(x, idx, grad_out):
     g = _req(grad_out.contiguous(), torch.float32, 'grad_out')
     n = x.shape[0]
     width = x.numel() // max(n, 1)
+    if TRAINING_DETERMINISTIC:
+        bound = g.abs().max().reshape(1)
+        fixed = torch.zeros(x.shape, dtype=torch.int64, device=x.device)
+        dx = torch.empty_like(x)
+        check(lib().se3_neighbor_max_pool_bwd_fixed(x.data_ptr(), idx.data_ptr(), g.data_ptr(), n, idx.shape[0], idx.shape[1], width,
+                                                    bound.data_ptr(), fixed.data_ptr(), _stream()), 'se3_neighbor_max_pool_bwd_fixed')
+        check(lib().se3_fixed_to_float(fixed.data_ptr(), fixed.numel(), bound.data_ptr(), idx.shape[0], 0, dx.data_ptr(), _stream()), 'se3_fixed_to_float')
+        return dx
     dx = torch.zeros_like(x)
     check(lib().se3_neighbor_max_pool_bwd(x.data_ptr(), idx.data_ptr(), g.data_ptr(), n, idx.shape[0], idx.shape[1], width, dx.data_ptr(),
                                           _stream()), 'se3_neighbor_max_pool_bwd')
     return dx
+
+
+def scatter_add_rows(g, idx, n):
+    """Transpose of gather_rows_padded (its backward): out[idx[i]] += g[i] for idx[i] in [0, n), as order-independent 64-bit fixed-point sums
+    (csrc/rowops.hip: scatter_add_rows_fixed_kernel; bit-identical runs).  g (m.., width..), idx (m..) -> (n, width..)."""
+    g = _req(g.contiguous(), torch.float32, 'grad')
+    idx = _req(idx.contiguous(), torch.int64, 'idx')
+    m = idx.numel()
+    width = g.numel() // max(m, 1)
+    tail = tuple(g.shape[idx.dim():])
+    bound = g.abs().max().reshape(1) if g.numel() else g.new_zeros(1)
+    fixed = torch.zeros((n,) + tail, dtype=torch.int64, device=g.device)
+    out = torch.empty((n,) + tail, dtype=torch.float32, device=g.device)
+    check(lib().se3_scatter_add_rows_fixed(g.data_ptr(), idx.data_ptr(), n, m, width, bound.data_ptr(), fixed.data_ptr(), _stream()),
+          'se3_scatter_add_rows_fixed')
+    check(lib().se3_fixed_to_float(fixed.data_ptr(), fixed.numel(), bound.data_ptr(), m, 0, out.data_ptr(), _stream()), 'se3_fixed_to_float')
+    return out
 
 
 _gn_workspace = {}       # (device, stream) -> partial-statistics workspace
@@ -1020,13 +1053,28 @@ def kpconv_inter_so3_bwd(grad_out, x, q_pts, s_pts, idx, kernel_points, weights,
             dG = linear_stream(d2, weights.detach().view(36 * Cin, Cout) if weights.is_contiguous() else W2.contiguous())
         else:
             dG = mm(d2, W2.t())
-        dx = torch.zeros_like(x)
-        check(lib().se3_kpconv_so3_gather_bwd(q_pts.data_ptr(), s_pts.data_ptr(), idx.data_ptr(), dG.data_ptr(), kp.data_ptr(),
-                                              kt.data_ptr(), rt.data_ptr(), float(sigma), P, Ns, NN, Cin, dx.data_ptr(), _stream()),
-              'se3_kpconv_so3_gather_bwd')
+        if KPCONV_BACKWARD_DETERMINISTIC:
+            # order-independent sums (64-bit fixed point at a scale from max |dG|): bit-identical runs (csrc/kpconv_so3.hip)
+            # (an upper bound of |dG| = |dout W^T| from the small operands -- max |dout| times the largest absolute row sum of W -- instead of a pass
+            # over the (6 P, 36 Cin) product: the scale only has to prevent overflow)
+            bound = (d2.abs().max() * W2.abs().sum(1).max()).reshape(1)
+            fixed = torch.zeros(x.shape, dtype=torch.int64, device=x.device)
+            dx = torch.empty_like(x)
+            check(lib().se3_kpconv_so3_gather_bwd_fixed(q_pts.data_ptr(), s_pts.data_ptr(), idx.data_ptr(), dG.data_ptr(), kp.data_ptr(),
+                                                        kt.data_ptr(), rt.data_ptr(), float(sigma), P, Ns, NN, Cin, bound.data_ptr(),
+                                                        fixed.data_ptr(), _stream()), 'se3_kpconv_so3_gather_bwd_fixed')
+            check(lib().se3_kpconv_fixed_to_float(fixed.data_ptr(), fixed.numel(), bound.data_ptr(), P, dx.data_ptr(), _stream()),
+                  'se3_kpconv_fixed_to_float')
+        else:
+            dx = torch.zeros_like(x)
+            check(lib().se3_kpconv_so3_gather_bwd(q_pts.data_ptr(), s_pts.data_ptr(), idx.data_ptr(), dG.data_ptr(), kp.data_ptr(),
+                                                  kt.data_ptr(), rt.data_ptr(), float(sigma), P, Ns, NN, Cin, dx.data_ptr(), _stream()),
+                  'se3_kpconv_so3_gather_bwd')
     return dx, dw
 
 
+KPCONV_BACKWARD_DETERMINISTIC = os.environ.get('SE3_KPCONV_BWD', 'fixed') != 'float'      # 64-bit fixed-point scatter (bit-identical runs); 'float': hardware float atomics
+TRAINING_DETERMINISTIC = KPCONV_BACKWARD_DETERMINISTIC      # the other scatter-adds of the training step (max-pool, row gather, LayerNorm parameter sums) follow the same switch
 _neighbor_table_cache = {}
 
 
