@@ -356,7 +356,7 @@ int se3_kpconv_so3_fused_scaled(const float* x, const void* table, int64_t num_q
  *     the caller sorts the keys (any stable sort; torch.sort) and _place writes `order` (se3_point_order_groups(lengths) * 16 int32: the point
  *     at every position, -1 = padding; every cloud starts a new group of 16, so a cloud's groups do not depend on what else is stacked).
  *   se3_kpconv_union_plan: per group of 16 order positions the distinct rows of the neighbour lists (se3_kpconv_neighbor_table) sorted by row
- *     number and every list slot's index into them; groups with more than 160 distinct rows are cut into halves (sub-tiles) until they
+ *     number and every list slot's index into them; groups with more than 128 distinct rows are cut into halves (sub-tiles) until they
  *     fit.  plan: se3_kpconv_union_plan_bytes bytes; a function of (order, table) only.
  *   se3_kpconv_so3_union: KPConvInterSO3.forward (blocks_epn.py:454-546) as se3_kpconv_so3_fused; x_chunked = 1: x in the layout written by
  *     se3_group_norm_apply(blocked_layout = 2).  split_workspace: se3_kpconv_union_split_workspace_bytes bytes, same contract as the fused form.

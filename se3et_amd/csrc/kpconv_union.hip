@@ -11,14 +11,14 @@
 // tile membership only; no tensor is reordered, every point still walks its own table and writes its own output row).  Their neighbour
 // lists overlap: 46 / 84 / 115 distinct rows per tile on average at the bench shape instead of 126 / 304 / 503 list entries
 // (tools/r5/union_sizes.py).  Per 8-channel chunk:
-//   loaders   the tile's DISTINCT support rows ("union", <= 160) are read once, whole: 192 contiguous bytes per row and chunk, 16 B per lane
+//   loaders   the tile's DISTINCT support rows ("union", <= 128) are read once, whole: 192 contiguous bytes per row and chunk, 16 B per lane
 //             (<= 30 wave requests per chunk instead of 232), split into f16 hi / lo and left in LDS as MFMA B fragments (B image)
 //   gather    H[p, o, (a, c)] = sum_u A_p[o, u] X[u, (a, c)]: the point's orbit weights scattered over the union's index u as the A operand
 //             (zero where u is not a neighbour of p; built ONCE per tile -- it does not depend on the channel -- and kept in registers),
 //             the B image shared by all 16 points: v_mfma_f32_16x16x32_f16, three products.  No per-lane gather, no per-point split of x.
 //   result    split into f16 hi / lo and stored into the tile image the consumers read, exactly as before.
-// Two tile images instead of three (a producer step is one chunk, not a pair), two B images: 160.9 KB of LDS.
-// A tile whose union exceeds 160 rows is processed in several passes over halves of its points (the plan's sub-tiles), all passes adding
+// Two tile images instead of three (a producer step is one chunk, not a pair), two B images: 148.9 KB of LDS.
+// A tile whose union exceeds 128 rows is processed in several passes over halves of its points (the plan's sub-tiles), all passes adding
 // into the same accumulators (rows of points outside a pass are zero): rare at the bench shapes except the coarsest strided layer.
 // Summation order: a point's neighbours are added in the order of their support row numbers inside 32-row K-steps; the plan is a pure
 // function of (order, table), so runs are bit-identical; results differ from csrc/kpconv_mfma.hip in the last bits (f32 association).
@@ -35,7 +35,8 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kHeaderB = 256;                // weight-fragment buffer header (csrc/kpconv_mfma.hip)
-constexpr int kUCap = 160;                   // distinct support rows per (sub-)tile
+constexpr int kUCap = 128;                   // distinct support rows per (sub-)tile (160 measured: 64 -> 80 registers of A fragments, 27 instead of 10 spilled, 13 KB
+                                             // more LDS -- the narrow layers the policy gives this kernel ran 0.401 / 0.283 / 0.544 ms instead of 0.345 / 0.236 / 0.526)
 constexpr int kKSM = kUCap / 32;             // K32-steps of the gather product
 constexpr int kBFragB = 1024;                // one B fragment: 64 lanes x 16 B
 constexpr int kBImgB = 2 * 3 * kKSM * kBFragB;   // [piece][anchor pair][K32-step][lane]: 30 720 B

@@ -681,11 +681,11 @@ class BlockedFeatures:
 
 KPCONV_BLOCKED = True          # False: the KPConv input in the plain layout (A/B runs)
 # The union-staged fused KPConv (csrc/kpconv_union.hip), wherever a spatial order of the query points is registered (se3et_amd/data.py):
-# SE3_KPCONV_UNION = 0 (default) never; 1 where it measured faster than the per-lane-gather kernel alone on the GPU (output widths <= 64 of the
-# stride-1 layers and the first strided one: profiles/r05_kpconv_union.txt); all: every layer.  Off by default: its kernels are 6-12 % faster on
-# those layers (27 % with three batches in flight), but with the order and plan launches the forward as a whole reads 1-1.5 % LOWER in
-# alternating bench runs (492 / 493 against 487 / 484 pairs/s; 483 against 474-481 on another box).
-_KPCONV_UNION_ENV = os.environ.get('SE3_KPCONV_UNION', '0')
+# SE3_KPCONV_UNION = 0 never; 1 (default) where it measured faster than the per-lane-gather kernel alone on the GPU (output widths <= 64 of the
+# stride-1 layers and the first strided one: profiles/r05_kpconv_union_check.txt: 18-26 % on those layers with the 128-row cap); all: every
+# layer.  With the order and plan launches the forward as a whole reads the same or slightly higher in alternating bench runs (488.1 / 488.6
+# against 487.7 / 483.0 pairs/s; with the first form's 160-row cap it read 1-1.5 % lower and was off).
+_KPCONV_UNION_ENV = os.environ.get('SE3_KPCONV_UNION', '1')
 KPCONV_UNION = _KPCONV_UNION_ENV != '0'
 KPCONV_UNION_ALL = _KPCONV_UNION_ENV == 'all'
 KPCONV_UNION_MIN_POINTS = 24000           # stage-0 points of a pyramid from which the pyramid builder registers orders (single pairs stay on the gather kernel)
