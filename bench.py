@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 # at the bench shape, 16 clouds per launch, collected by tools/pmc_passes.sh; one line per (kernel, grid, counter): average KiB per dispatch;
 # '#' lines: the collecting commit and the algorithmic bytes of the two calls).  Counters cannot be read inside this process, so the ratio
 # of that run is applied to the calls of this run.  gfx950 correction (/opt/skills/guides/MI355X_MICROARCH.md, HBM): FETCH_SIZE x2 for the
-# 16-B/lane streaming reads of rpe_bias_kernel and attn_split_kv_kernel; the attention kernel's counters as reported.
+# 16-B/lane streaming reads of rpe_bias_kernel and the operand split (x6_split_kernel; attn_split_kv_kernel in files of earlier commits); the attention kernel's counters as reported.
 PMC_TRAFFIC_FILES = ('profiles/r05_pmc_attention_raw.txt', 'profiles/r04_pmc_attention_raw.txt')
 PMC_ALGORITHMIC_MB_R04 = {'eq': 2549.0, 'inv': 2222.9}      # (the round-4 file carries no '# algorithmic' lines: tools/pmc_attention.py at its shape)
 
@@ -71,7 +71,7 @@ def load_pmc_traffic():
                 kind = 'eq' if args_t[3].strip() == 'true' else 'inv'
             if kind is None:
                 continue
-            streaming = 'rpe_bias_kernel' in name or 'attn_split_kv_kernel' in name
+            streaming = 'rpe_bias_kernel' in name or 'attn_split_kv_kernel' in name or 'x6_split_kernel' in name
             kib[kind] += float(value) * (2.0 if (counter == 'FETCH_SIZE' and streaming) else 1.0)
         if kib['eq'] > 0 and kib['inv'] > 0 and 'eq' in algo and 'inv' in algo:
             ratios = {k: kib[k] * 1024.0 / 1e6 / algo[k] for k in kib}

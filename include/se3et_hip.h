@@ -61,8 +61,10 @@ void se3_debug_set_kpconv_union_variant(int variant);
  * row's f16-split scale -- more than 2^8 times the largest magnitude of the row's first 32 values -- or held NaN / Inf, since the last
  * reset: such values are clamped to the f16 range (finite, wrong) and counted here (events: once per row, K-step and column block).  Synchronises the device; reset != 0 zeroes the count. */
 unsigned long long se3_debug_dense_saturated_rows(int reset);
-/* values of q / K / V^T that the stand-alone operand splits of the f16 attention kernels clamped to the f16 range (|x| > 65000, NaN, Inf) since the
- * last reset: those operands are split as they are (projections of LayerNorm outputs); a non-zero count says the scores are not the reference's. */
+/* NaN / Inf values of K / V^T (and of the equivariant cross attention's q) that the operand split of the f16 attention kernels clamped since the
+ * last reset.  Finite values of any size are not clamped: a query row of one head, 8 key rows of one head and a value channel of one cloud are
+ * each scaled by their own power of two before the f16 hi / lo split and the kernels take the scales out of the f32 logits / output
+ * (csrc/attention.hip: x6_split_kernel).  A non-zero count says the input already held NaN / Inf. */
 unsigned long long se3_debug_attention_saturated(int reset);
 /* Per-launch timing of the two RPE self-attention kernels (bench.py): while enabled every launch carries its own start / stop
  * HIP event pair (hipExtLaunchKernelGGL) on the launch stream; collect() waits for them, returns the count and fills the

@@ -1170,9 +1170,11 @@ __device__ __forceinline__ void h2_split8(const float (&x)[8], uint4& hi, uint4&
   lo = __builtin_bit_cast(uint4, l);
 }
 
-// The stand-alone operand splits of the f16 attention kernels (q / K rows, V^T) take their values as they are -- projections of LayerNorm
-// outputs -- but never let one leave the f16 range silently: a value beyond 65000 (NaN / Inf included) is clamped, and the launch counts it
-// (se3_debug_attention_saturated: loud instead of Inf in every key's score; the open remainder of the f16-window item).
+// The operand splits of the f16 attention kernels carry their own powers of two (round 5: the last part of the f16-window item, DESIGN
+// section 4 "Range of the f16 split"): a query row of one head, a block of 8 key rows of one head and a value channel of one cloud are each
+// brought to [2^6, 2^7) before the split -- exact, and the kernels take the scales out of the f32 logits (per lane: the query; per register
+// group of the S^T tile: the key block) and of the output (per channel).  Nothing finite leaves the f16 range any more; a NaN / Inf still
+// must not become Inf in every key's score: it is clamped and the launch counts it (se3_debug_attention_saturated).
 __device__ unsigned long long g_attn_saturated = 0;
 __device__ __forceinline__ bool h2_split8_sat(const float (&x)[8], uint4& hi, uint4& lo) {
   float c[8];
@@ -1189,44 +1191,168 @@ __device__ __forceinline__ void count_saturated(bool sat) {
   const unsigned long long m = __ballot(sat);
   if (m != 0ull && (threadIdx.x & 63) == 0) atomicAdd(&g_attn_saturated, (unsigned long long)__popcll(m));
 }
+// magnitude (integer maximum of |x| bit patterns: non-negative floats order like their bits) -> the power of two that brings it to
+// [2^6, 2^7) and its inverse; zero or non-finite: 1; both stay normal floats (a denormal maximum gets 2^126)
+struct SplitScale { float scale, inv; };
+__device__ __forceinline__ SplitScale split_scale_of(unsigned amax_bits) {
+  const int e = (int)(amax_bits >> 23) & 0xff;
+  int k = amax_bits == 0u || e == 0xff ? 0 : 133 - e;          // (a NaN / Inf among the values: no scaling, the clamp takes it)
+  k = k > 126 ? 126 : k;
+  return SplitScale{__uint_as_float((unsigned)(127 + k) << 23), __uint_as_float((unsigned)(127 - k) << 23)};
+}
+__device__ __forceinline__ unsigned abs_bits_max8(const float (&v)[8]) {
+  unsigned m = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) m = max(m, __float_as_uint(v[i]) & 0x7fffffffu);
+  return m;
+}
 
-// rows (A, R, C) with anchor stride -> pieces [2][A][R][C] f16; one thread per 8 channels
-__global__ __launch_bounds__(256) void x6_split_rows_kernel(const float* __restrict__ x, int A, int64_t R, int C, int64_t anchor_stride,
-                                                            uint4* __restrict__ out) {
-  const int64_t per = R * (C / 8), total = A * per;
+// ONE launch splits every operand of a call: per anchor workgroups [0, q_groups) the query rows (cross attention only: the self-attention
+// kernel splits its queries itself) and [q_groups, q_groups + k_groups) the key rows, then C / 4 workgroups for the transposed values;
+// grid (A (q_groups + k_groups) + C / 4, clouds).
+//   rows (A, R, row stride, anchor stride) -> pieces [2][A][R][C] f16; a wave = 8 rows x the 64 channels of one head, a lane 8 channels;
+//     queries: scale per (row, head) -> qinv[(a H + h) R + row]; keys: per (8-row block, head) -> kinv[(a H + h) nblk + row / 8]
+//     (key starts are multiples of 16: a block never spans two clouds; rows past the cloud's end do not count)
+//   V^T (A, C, v_rs) -> pieces [2][A][C][v_rs] f16, the keys of every aligned block of 16 in the order 0..3, 8..11, 4..7, 12..15 (the
+//     register order of P in the S^T accumulators); a wave = one channel of one cloud over all anchors (a lane: (anchor, 16-key block)
+//     units, held in registers between the maximum and the split), scale per (cloud, channel) -> vinv[cloud C + c]: uniform along the
+//     keys AND the anchors, so the kernels take it out once, in their epilogue
+struct X6SplitArgs {
+  Stack S;
+  int A, C, H;
+  const float *q, *k, *vt;
+  int q_rs, k_rs, v_rs;
+  long long q_sa, k_sa, v_sa;
+  long long q_rows, k_rows;                 // rows of the piece tensors
+  uint4 *outq, *outk, *outv;
+  float *qinv, *kinv, *vinv;
+  int q_groups, k_groups;                   // workgroups (4 waves) of the query / key part
+};
+__global__ __launch_bounds__(256) void x6_split_kernel(X6SplitArgs p) {
+  const int ci = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const StackCloud cl = stack_pick(p.S, ci);
   bool sat = false;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t a = i / per, rem = i - a * per;
-    const float* src = x + a * anchor_stride + rem * 8;
-    const float4 lo = ld4(src), hi = ld4(src + 4);
-    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    uint4 p1, p2;
-    sat |= h2_split8_sat(v, p1, p2);
-    out[i] = p1;
-    out[total + i] = p2;
+  const int row_groups = p.q_groups + p.k_groups;
+  if ((int)blockIdx.x < p.A * row_groups) {
+    const int a = (int)blockIdx.x / row_groups, bx = (int)blockIdx.x - a * row_groups;
+    const bool isq = bx < p.q_groups;
+    const int item = (bx - (isq ? 0 : p.q_groups)) * 4 + wave;
+    const int rg = item / p.H, h = item - rg * p.H;
+    const int rows = isq ? cl.N : cl.M, start = isq ? cl.q_start : cl.k_start;
+    if (rg * 8 < rows) {
+      const int r = lane >> 3, c8 = lane & 7, row = rg * 8 + r;
+      const bool live = row < rows;
+      const float* x = isq ? p.q : p.k;
+      const int rs = isq ? p.q_rs : p.k_rs;
+      const long long sa = isq ? p.q_sa : p.k_sa, R = isq ? p.q_rows : p.k_rows;
+      const float* src = x + a * sa + (int64_t)(start + (live ? row : rows - 1)) * rs + h * 64 + c8 * 8;
+      const float4 lo = ld4(src), hi = ld4(src + 4);
+      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      unsigned m = live ? abs_bits_max8(v) : 0u;
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));          // the row's 64 channels
+      if (!isq) {
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));       // the block's 8 rows
+      }
+      const SplitScale sc = split_scale_of(m);
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] *= sc.scale;
+      uint4 p1, p2;
+      const bool s1 = h2_split8_sat(v, p1, p2);
+      if (live) {
+        sat |= s1;
+        uint4* out = isq ? p.outq : p.outk;
+        const int64_t o = (((int64_t)a * R + start + row) * p.C + h * 64 + c8 * 8) >> 3, total = ((int64_t)p.A * R * p.C) >> 3;
+        out[o] = p1;
+        out[total + o] = p2;
+        if (isq) {
+          if (c8 == 0) p.qinv[((int64_t)a * p.H + h) * R + start + row] = sc.inv;
+        } else if (lane == 0) {
+          p.kinv[((int64_t)a * p.H + h) * ((R + 7) >> 3) + ((start + row) >> 3)] = sc.inv;
+        }
+      }
+    }
+  } else {
+    const int c = ((int)blockIdx.x - p.A * row_groups) * 4 + wave;
+    if (c < p.C) {
+      const int nb = ((cl.M + 31) >> 5) << 1;                      // 16-key blocks of the cloud's padded key range
+      const int items = p.A * nb;                                  // (anchor, block) units of this channel: lane l takes l, l + 64, ..
+      const int64_t vblocks = p.v_rs >> 4, vtot = (int64_t)p.A * p.C * vblocks;
+      const float* chan = p.vt + (int64_t)c * p.v_rs + cl.k_start;
+      auto unit_max = [&](int b, const float4 (&x)[4]) {
+        unsigned m = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int key = 16 * b + 4 * u;
+          m = max(m, key + 0 < cl.M ? __float_as_uint(x[u].x) & 0x7fffffffu : 0u);
+          m = max(m, key + 1 < cl.M ? __float_as_uint(x[u].y) & 0x7fffffffu : 0u);
+          m = max(m, key + 2 < cl.M ? __float_as_uint(x[u].z) & 0x7fffffffu : 0u);
+          m = max(m, key + 3 < cl.M ? __float_as_uint(x[u].w) & 0x7fffffffu : 0u);
+        }
+        return m;
+      };
+      auto emit = [&](int aa, int b, const float4 (&x)[4], float s) {
+        const float lo[8] = {x[0].x * s, x[0].y * s, x[0].z * s, x[0].w * s, x[2].x * s, x[2].y * s, x[2].z * s, x[2].w * s};      // keys 0..3, 8..11
+        const float hi[8] = {x[1].x * s, x[1].y * s, x[1].z * s, x[1].w * s, x[3].x * s, x[3].y * s, x[3].z * s, x[3].w * s};      // keys 4..7, 12..15
+        uint4 a1, a2, b1, b2;
+        // (the padding keys of the last tile are multiplied by P = 0: they only have to be finite, which the clamp sees to)
+        const bool s1 = h2_split8_sat(lo, a1, a2), s2 = h2_split8_sat(hi, b1, b2);
+        sat |= (s1 || s2) && 16 * b < cl.M;
+        const int64_t j = ((int64_t)aa * p.C + c) * vblocks + (cl.k_start >> 4) + b;
+        p.outv[2 * j] = a1; p.outv[2 * j + 1] = b1;
+        p.outv[2 * (vtot + j)] = a2; p.outv[2 * (vtot + j) + 1] = b2;
+      };
+      constexpr int kHeld = 3;                                     // units a lane keeps in registers between the maximum and the split
+      unsigned m = 0;
+      if (items <= 64 * kHeld) {                                   // (6 anchors x 512 keys: every batch of the benches) one pass, all loads at once
+        float4 x[kHeld][4];
+        int ua[kHeld], ub[kHeld];
+#pragma unroll
+        for (int t = 0; t < kHeld; t++) {
+          const int it = lane + 64 * t, ok = it < items;
+          ua[t] = ok ? it / nb : 0;
+          ub[t] = ok ? it - ua[t] * nb : 0;
+#pragma unroll
+          for (int u = 0; u < 4; u++) x[t][u] = ld4(chan + ua[t] * p.v_sa + 16 * ub[t] + 4 * u);
+        }
+#pragma unroll
+        for (int t = 0; t < kHeld; t++) m = max(m, lane + 64 * t < items ? unit_max(ub[t], x[t]) : 0u);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+        const SplitScale sc = split_scale_of(m);
+#pragma unroll
+        for (int t = 0; t < kHeld; t++)
+          if (lane + 64 * t < items) emit(ua[t], ub[t], x[t], sc.scale);
+        if (lane == 0) p.vinv[(int64_t)ci * p.C + c] = sc.inv;
+      } else {                                                     // two passes, the second out of L1 / L2
+        for (int it = lane; it < items; it += 64) {
+          const int aa = it / nb, b = it - aa * nb;
+          float4 x[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) x[u] = ld4(chan + aa * p.v_sa + 16 * b + 4 * u);
+          m = max(m, unit_max(b, x));
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+        const SplitScale sc = split_scale_of(m);
+        for (int it = lane; it < items; it += 64) {
+          const int aa = it / nb, b = it - aa * nb;
+          float4 x[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) x[u] = ld4(chan + aa * p.v_sa + 16 * b + 4 * u);
+          emit(aa, b, x, sc.scale);
+        }
+        if (lane == 0) p.vinv[(int64_t)ci * p.C + c] = sc.inv;
+      }
+    }
   }
   count_saturated(sat);
 }
-// transposed values (A, C, v_rs) with anchor stride -> pieces [2][A][C][v_rs] f16, the keys of every aligned block of 16 in the order
-// 0..3, 8..11, 4..7, 12..15; one thread per 16 keys
-__global__ __launch_bounds__(256) void x6_split_vt_kernel(const float* __restrict__ vt, int A, int C, int v_rs, int64_t anchor_stride,
-                                                          uint4* __restrict__ out) {
-  const int64_t blocks = v_rs / 16, per = (int64_t)C * blocks, total = A * per;
-  bool sat = false;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t a = i / per, rem = i - a * per;
-    const float* src = vt + a * anchor_stride + rem * 16;
-    const float4 q0 = ld4(src), q1 = ld4(src + 4), q2 = ld4(src + 8), q3 = ld4(src + 12);
-    const float lo[8] = {q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, q2.z, q2.w};      // keys 0..3, 8..11
-    const float hi[8] = {q1.x, q1.y, q1.z, q1.w, q3.x, q3.y, q3.z, q3.w};      // keys 4..7, 12..15
-    uint4 a1, a2, b1, b2;
-    sat |= h2_split8_sat(lo, a1, a2);
-    sat |= h2_split8_sat(hi, b1, b2);
-    out[2 * i] = a1; out[2 * i + 1] = b1;
-    out[2 * (total + i)] = a2; out[2 * (total + i) + 1] = b2;
-  }
-  count_saturated(sat);
-}
+// sizes of the scale tables behind the pieces (floats); `rows` of keys -> ceil(rows / 8) blocks
+static inline size_t x6_kinv_floats(int A, int C, int64_t k_rows) { return (size_t)A * (size_t)(C / 64 + 1) * (size_t)((k_rows + 7) / 8 + 4); }
+static inline size_t x6_qinv_floats(int A, int C, int64_t q_rows) { return (size_t)A * (size_t)(C / 64 + 1) * (size_t)(q_rows + 4); }
+static inline size_t x6_vinv_floats(int C) { return (size_t)kMaxClouds * (size_t)C; }
 
 // Value of lane i ^ 32 (the other half of the wave): one v_permlane32_swap instead of a ds_bpermute round trip through the LDS pipeline.
 __device__ __forceinline__ float other_half(float v) {
@@ -1234,7 +1360,17 @@ __device__ __forceinline__ float other_half(float v) {
   return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
 }
 
-struct X6Pieces { const uint4 *q[2], *k[2], *v[2]; };       // f16 hi / lo pieces, 8 values per uint4
+struct X6Pieces {
+  const uint4 *q[2], *k[2], *v[2];       // f16 hi / lo pieces, 8 values per uint4
+  const float *qinv, *kinv, *vinv;       // inverse scales: [(a H + h) q_rows + row], [(e H + h) nblk + row / 8], [pair C + c] (x6_split_kernel)
+  long long q_rows;
+  int nblk;
+};
+// lane i ^ 32's value of an integer
+__device__ __forceinline__ unsigned other_half_u32(unsigned v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return (threadIdx.x & 32) ? r[0] : r[1];
+}
 
 // grid (ceil(QT / 4), H, A * pairs), 4 waves = 4 consecutive 32-query tiles of one (pair, query anchor a, head).  The workgroup walks
 // the (key anchor e, 32-key tile) sequence once; every K / V^T tile (3 pieces each: 24 KB) goes global -> registers -> LDS one step ahead
@@ -1267,6 +1403,9 @@ __global__ __launch_bounds__(256) void cross_eq_apply_stack_x6_kernel(CrossEqArg
   for (int pc = 0; pc < 2; pc++)
 #pragma unroll
     for (int u = 0; u < 4; u++) qf[pc][u] = __builtin_bit_cast(h2x8_t, X.q[pc][(q_off + (int64_t)nq * C + 16 * u + 8 * half) >> 3]);
+  // logits = (scaled q . scaled k) / (query scale x key-block scale) x 1 / sqrt(d): the lane's factor, the block's is multiplied in per step
+  const float q_unscale = X.qinv[((int64_t)a * p.H + h) * X.q_rows + cl.q_start + nq] * p.scale;
+  const int last_blk = (cl.M - 1) >> 3;
   const int tiles = (cl.M + 31) >> 5, steps = (A / p.G) * tiles, base = grp * steps;     // this group's steps: base .. base + steps
   // this thread's share of a tile copy: K: 2 pieces x 32 rows x 8 uint4 = 512 -> 2 per thread; V^T: 2 pieces x 64 rows x 4 uint4 = 512 -> 2
   // Three register sets: the tile of step s + 3 is requested at the start of step s and published (written to LDS) at the end of step
@@ -1274,9 +1413,11 @@ __global__ __launch_bounds__(256) void cross_eq_apply_stack_x6_kernel(CrossEqArg
   // 24 MFMAs + a 32-key softmax), the kernel was latency bound at 2.25 waves per SIMD.  Requests are unconditional (clamped) so that the
   // compiler counts them: an `if` around a load turns every later wait into vmcnt(0).
   u32x4r rk[3][2], rv[3][2];                               // (ext_vector_type: arrays of the HIP uint4 struct end up in scratch)
-  auto request = [&](int step, u32x4r (&rk)[2], u32x4r (&rv)[2]) {
+  float rs[3];                                             // lane l: the inverse scale of key block (l & 3) of the tile
+  auto request = [&](int step, u32x4r (&rk)[2], u32x4r (&rv)[2], float& rs) {
     step = base + (step < steps ? step : steps - 1);
     const int e = step / tiles, m0 = (step - e * tiles) << 5;
+    rs = X.kinv[((int64_t)e * p.H + h) * X.nblk + (cl.k_start >> 3) + min((m0 >> 3) + (lane & 3), last_blk)];
     const int64_t k_off = e * k_piece_sa + (int64_t)cl.k_start * C + h * D;
     const int64_t v_off = e * v_piece_sa + (int64_t)h * D * p.v_rs + cl.k_start + m0;
 #pragma unroll
@@ -1294,19 +1435,21 @@ __global__ __launch_bounds__(256) void cross_eq_apply_stack_x6_kernel(CrossEqArg
       vtile[buf][i][tid >> 2][tid & 3] = __builtin_bit_cast(uint4, rv[i]);
     }
   };
-  request(0, rk[0], rv[0]);
+  request(0, rk[0], rv[0], rs[0]);
   publish(0, rk[0], rv[0]);
-  request(1, rk[1], rv[1]);
-  request(2, rk[2], rv[2]);
+  request(1, rk[1], rv[1], rs[1]);
+  request(2, rk[2], rv[2], rs[2]);
   __syncthreads();
   FlashState<D> tot, st;
   flash_init(tot);
   flash_init(st);
   // one step; RS: the register set that is free now (tile step + 3 goes there), PS: the set holding tile step + 1
-  auto one_step = [&](int step, u32x4r (&rk_req)[2], u32x4r (&rv_req)[2], const u32x4r (&rk_pub)[2], const u32x4r (&rv_pub)[2]) {
+  auto one_step = [&](int step, u32x4r (&rk_req)[2], u32x4r (&rv_req)[2], float& rs_req, const u32x4r (&rk_pub)[2],
+                      const u32x4r (&rv_pub)[2]) {
     const int buf = step & 1;
     const int e = (base + step) / tiles, tile = base + step - e * tiles, m0 = tile << 5;
-    request(step + 3, rk_req, rv_req);
+    const float ks = rs_req;                                  // (this step's block scales sit in the set about to be refilled)
+    request(step + 3, rk_req, rv_req, rs_req);
     if (active && step < steps) {
       // two accumulators, consecutive MFMAs alternate between them
       f32x16 s, s2;
@@ -1323,13 +1466,17 @@ __global__ __launch_bounds__(256) void cross_eq_apply_stack_x6_kernel(CrossEqArg
       }
 #pragma unroll
       for (int r = 0; r < 16; r++) s[r] += s2[r];
+      const float unscale[4] = {__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ks), 0)) * q_unscale,
+                                __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ks), 1)) * q_unscale,
+                                __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ks), 2)) * q_unscale,
+                                __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ks), 3)) * q_unscale};
       float mx = -INFINITY;
 #pragma unroll
       for (int g = 0; g < 4; g++) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const int key = m0 + 8 * g + 4 * half + j;
-          float val = s[4 * g + j] * p.scale;
+          float val = s[4 * g + j] * unscale[g];
           val = key < cl.M ? val : -INFINITY;
           s[4 * g + j] = val;
           mx = fmaxf(mx, val);
@@ -1387,21 +1534,25 @@ __global__ __launch_bounds__(256) void cross_eq_apply_stack_x6_kernel(CrossEqArg
   };
   // (unconditional three-step body: see attention_x6_kernel; steps = A * tiles, padded steps fall on key anchor e >= A and are skipped whole)
   for (int step = 0; step < steps; step += 3) {                // set of tile t = t % 3 (tile 0 went through set 0 above)
-    one_step(step, rk[0], rv[0], rk[1], rv[1]);
-    one_step(step + 1, rk[1], rv[1], rk[2], rv[2]);
-    one_step(step + 2, rk[2], rv[2], rk[0], rv[0]);
+    one_step(step, rk[0], rv[0], rs[0], rk[1], rv[1]);
+    one_step(step + 1, rk[1], rv[1], rs[1], rk[2], rv[2]);
+    one_step(step + 2, rk[2], rv[2], rs[2], rk[0], rv[0]);
   }
   if (!active) return;
-  // o[dt][r] = O^T[d = 32 dt + (r & 3) + 8 (r >> 2) + 4 half][query c32]: four consecutive d per (dt, g) -> one float4 per lane
+  // o[dt][r] = O^T[d = 32 dt + (r & 3) + 8 (r >> 2) + 4 half][query c32]: four consecutive d per (dt, g) -> one float4 per lane; the
+  // values' channel scales (uniform over keys and key anchors) leave here
   const int nrow = n0 + c32;
   if (nrow < cl.N) {
     float* op = out + ((size_t)a * p.out_sa) + ((size_t)cl.q_start + nrow) * p.out_rs + grp * C + h * D;
+    const float* vi = X.vinv + (size_t)pair * C + h * D;
 #pragma unroll
     for (int dt = 0; dt < 2; dt++)
 #pragma unroll
-      for (int g = 0; g < 4; g++)
+      for (int g = 0; g < 4; g++) {
+        const float4 w = ld4(vi + 32 * dt + 8 * g + 4 * half);
         *reinterpret_cast<float4*>(op + 32 * dt + 8 * g + 4 * half) =
-            make_float4(tot.o[dt][4 * g], tot.o[dt][4 * g + 1], tot.o[dt][4 * g + 2], tot.o[dt][4 * g + 3]);
+            make_float4(tot.o[dt][4 * g] * w.x, tot.o[dt][4 * g + 1] * w.y, tot.o[dt][4 * g + 2] * w.z, tot.o[dt][4 * g + 3] * w.w);
+      }
   }
 }
 
@@ -1703,42 +1854,16 @@ extern "C" int se3_rpe_bias_stack_bf16_fwd(const float* qp, const float* qe, int
 // ---- RPE / plain attention of a stack of clouds on the f16 matrix cores (head dimension 64) ---------------------------------------------
 // attention_kernel above multiplies on the f32 matrix cores (57 % of their peak at A = 6: 160 us per call) and its f16-split form
 // (MODE 4) splits every K and V^T tile again in every workgroup that reads it -- vector-ALU bound, no gain.  Here K and V^T are split ONCE
-// per call (attn_split_kv_kernel: the pieces have the byte size of the f32 tensors) and the kernel has the structure of
+// per call (x6_split_kernel: the pieces have the byte size of the f32 tensors) and the kernel has the structure of
 // cross_eq_apply_stack_x6_kernel: 4 waves = 4 consecutive 32-query tiles of one (cloud, anchor, head), every 32-key K / V^T tile goes
 // global -> registers -> LDS THREE steps ahead and is read by the four waves from LDS, the logits tile of a wave (16 floats per lane, written
 // by rpe_bias_kernel on other XCDs: a trip to the memory side) is requested three steps ahead as well.  No merge over waves: a wave owns
 // its queries.  S = (q.k [+ bias]) * scale, online softmax, P split into f16 hi / lo in registers, three products each for q.k and P.v.
-__global__ __launch_bounds__(256) void attn_split_kv_kernel(const float* __restrict__ k, int k_rs, int64_t k_sa, const float* __restrict__ vt, int v_rs,
-                                                            int64_t v_sa, int A, int64_t R, int C, uint4* __restrict__ outk, uint4* __restrict__ outv) {
-  const int64_t kper = R * (C / 8), ktot = A * kper, vblocks = v_rs / 16, vper = (int64_t)C * vblocks, vtot = A * vper;
-  bool sat = false;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ktot + vtot; i += (int64_t)gridDim.x * 256) {
-    if (i < ktot) {
-      const int64_t a = i / kper, rem = i - a * kper, row = rem / (C / 8), c8 = rem - row * (C / 8);
-      const float* src = k + a * k_sa + row * k_rs + c8 * 8;
-      const float4 lo = ld4(src), hi = ld4(src + 4);
-      const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-      uint4 p1, p2;
-      sat |= h2_split8_sat(v, p1, p2);
-      outk[i] = p1;
-      outk[ktot + i] = p2;
-    } else {
-      const int64_t j = i - ktot, a = j / vper, rem = j - a * vper, row = rem / vblocks, blk = rem - row * vblocks;
-      const float* src = vt + a * v_sa + row * v_rs + blk * 16;
-      const float4 q0 = ld4(src), q1 = ld4(src + 4), q2 = ld4(src + 8), q3 = ld4(src + 12);
-      const float lo[8] = {q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, q2.z, q2.w};      // keys 0..3, 8..11
-      const float hi[8] = {q1.x, q1.y, q1.z, q1.w, q3.x, q3.y, q3.z, q3.w};      // keys 4..7, 12..15
-      uint4 a1, a2, b1, b2;
-      sat |= h2_split8_sat(lo, a1, a2);
-      sat |= h2_split8_sat(hi, b1, b2);
-      outv[2 * j] = a1; outv[2 * j + 1] = b1;
-      outv[2 * (vtot + j)] = a2; outv[2 * (vtot + j) + 1] = b2;
-    }
-  }
-  count_saturated(sat);
-}
-
-struct AttnPieces { const uint4 *k[2], *v[2]; };
+struct AttnPieces {
+  const uint4 *k[2], *v[2];
+  const float *kinv, *vinv;       // inverse scales: [(a H + h) nblk + row / 8], [cloud C + c] (x6_split_kernel)
+  int nblk;
+};
 
 template <bool HAS_BIAS, bool PROF = false>
 __global__ __launch_bounds__(256, HAS_BIAS ? 2 : 3) void attention_x6_kernel(AttnArgs p, AttnPieces X, int64_t k_piece_sa, int64_t v_piece_sa) {
@@ -1758,27 +1883,44 @@ __global__ __launch_bounds__(256, HAS_BIAS ? 2 : 3) void attention_x6_kernel(Att
   SE3_STAMP(0)
   const int nq = min(n0 + c32, cl.N - 1);
   h2x8_t qf[2][4];
+  float q_unscale;              // logits = ((scaled q . scaled k) / (query scale x key-block scale) + bias) / sqrt(d): the lane's factor
   {
     const float* qr = p.q + a * p.q_sa + ((size_t)cl.q_start + nq) * p.q_rs + h * D + 8 * half;
+    float v8[4][8];
+    unsigned m = 0;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const float4 lo = ld4(qr + 16 * u), hi = ld4(qr + 16 * u + 4);
-      const float v8[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      v8[u][0] = lo.x; v8[u][1] = lo.y; v8[u][2] = lo.z; v8[u][3] = lo.w;
+      v8[u][4] = hi.x; v8[u][5] = hi.y; v8[u][6] = hi.z; v8[u][7] = hi.w;
+      m = max(m, abs_bits_max8(v8[u]));
+    }
+    m = max(m, other_half_u32(m));                          // the query's 64 channels of this head: its own power of two
+    const SplitScale sc = split_scale_of(m);
+    q_unscale = sc.inv * p.scale;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) v8[u][i] *= sc.scale;         // (a NaN / Inf query stays one: its own output row, nobody else's)
       uint4 p1, p2;
-      h2_split8(v8, p1, p2);
+      h2_split8(v8[u], p1, p2);
       qf[0][u] = __builtin_bit_cast(h2x8_t, p1);
       qf[1][u] = __builtin_bit_cast(h2x8_t, p2);
     }
   }
+  const int last_blk = (cl.M - 1) >> 3;
+  const float* kinv_row = X.kinv + ((int64_t)a * p.H + h) * X.nblk + (cl.k_start >> 3);
   const int steps = (cl.M + 31) >> 5;
   const int64_t k_off = a * k_piece_sa + (int64_t)cl.k_start * C + h * D;
   const int64_t v_off0 = a * v_piece_sa + (int64_t)h * D * p.v_rs + cl.k_start;
   const float* bias_row = HAS_BIAS ? p.bias + cl.bias_off + ((size_t)(a * p.H + h) * cl.N + nq) * cl.Mp + 4 * half : nullptr;
   u32x4r rk[3][2], rv[3][2];
   f32x4 rb[3][4];
-  auto request = [&](int step, u32x4r (&rk)[2], u32x4r (&rv)[2], f32x4 (&rb)[4]) {
+  float rs[3];                                             // lane l: the inverse scale of key block (l & 3) of the tile
+  auto request = [&](int step, u32x4r (&rk)[2], u32x4r (&rv)[2], f32x4 (&rb)[4], float& rs) {
     step = step < steps ? step : steps - 1;
     const int m0 = step << 5;
+    rs = kinv_row[min((m0 >> 3) + (lane & 3), last_blk)];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int row = tid >> 3, q8 = tid & 7;               // piece i: 32 rows x 8 uint4
@@ -1798,22 +1940,23 @@ __global__ __launch_bounds__(256, HAS_BIAS ? 2 : 3) void attention_x6_kernel(Att
       vtile[buf][i][tid >> 2][tid & 3] = __builtin_bit_cast(uint4, rv[i]);
     }
   };
-  request(0, rk[0], rv[0], rb[0]);
+  request(0, rk[0], rv[0], rb[0], rs[0]);
   publish(0, rk[0], rv[0]);
-  request(1, rk[1], rv[1], rb[1]);
-  request(2, rk[2], rv[2], rb[2]);
+  request(1, rk[1], rv[1], rb[1], rs[1]);
+  request(2, rk[2], rv[2], rb[2], rs[2]);
   __syncthreads();
   SE3_STAMP(1)
   FlashState<D> st;
   flash_init(st);
   // one step; *_req: the register set that is free now (tile step + 3 goes there), *_pub: the set holding tile step + 1; bias: this step's
-  auto one_step = [&](int step, u32x4r (&rk_req)[2], u32x4r (&rv_req)[2], f32x4 (&rb_req)[4], const u32x4r (&rk_pub)[2],
+  auto one_step = [&](int step, u32x4r (&rk_req)[2], u32x4r (&rv_req)[2], f32x4 (&rb_req)[4], float& rs_req, const u32x4r (&rk_pub)[2],
                       const u32x4r (&rv_pub)[2]) {
     const int buf = step & 1, m0 = step << 5;
     f32x4 b4[4];
 #pragma unroll
     for (int g = 0; g < 4; g++) b4[g] = HAS_BIAS ? rb_req[g] : f32x4{0.f, 0.f, 0.f, 0.f};   // (this step's logits sit in the set about to be refilled)
-    request(step + 3, rk_req, rv_req, rb_req);
+    const float ks = rs_req;                                                                //  and so do its key-block scales
+    request(step + 3, rk_req, rv_req, rb_req, rs_req);
     if (PROF && step < 5) { SE3_STAMP(2 + 5 * step) }
     if (active) {
       f32x16 s, s2;
@@ -1830,13 +1973,17 @@ __global__ __launch_bounds__(256, HAS_BIAS ? 2 : 3) void attention_x6_kernel(Att
       }
 #pragma unroll
       for (int r = 0; r < 16; r++) s[r] += s2[r];
+      const float unscale[4] = {__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ks), 0)) * q_unscale,
+                                __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ks), 1)) * q_unscale,
+                                __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ks), 2)) * q_unscale,
+                                __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ks), 3)) * q_unscale};
       float mx = -INFINITY;
 #pragma unroll
       for (int g = 0; g < 4; g++) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const int key = m0 + 8 * g + 4 * half + j;
-          float val = (s[4 * g + j] + b4[g][j]) * p.scale;
+          float val = fmaf(s[4 * g + j], unscale[g], b4[g][j] * p.scale);
           val = key < cl.M ? val : -INFINITY;
           s[4 * g + j] = val;
           mx = fmaxf(mx, val);
@@ -1892,9 +2039,9 @@ __global__ __launch_bounds__(256, HAS_BIAS ? 2 : 3) void attention_x6_kernel(Att
   // the first real tile): with `if (step + 1 < steps)` around the second and third step the paths into the loop's back edge carry different
   // numbers of outstanding loads and the compiler waits vmcnt(0) there -- the full latency of the tile just requested, every third step.
   for (int step = 0; step < steps; step += 3) {                // set of tile t = t % 3
-    one_step(step, rk[0], rv[0], rb[0], rk[1], rv[1]);
-    one_step(step + 1, rk[1], rv[1], rb[1], rk[2], rv[2]);
-    one_step(step + 2, rk[2], rv[2], rb[2], rk[0], rv[0]);
+    one_step(step, rk[0], rv[0], rb[0], rs[0], rk[1], rv[1]);
+    one_step(step + 1, rk[1], rv[1], rb[1], rs[1], rk[2], rv[2]);
+    one_step(step + 2, rk[2], rv[2], rb[2], rs[2], rk[0], rv[0]);
   }
   SE3_STAMP(30)
   if (!active) return;
@@ -1902,19 +2049,24 @@ __global__ __launch_bounds__(256, HAS_BIAS ? 2 : 3) void attention_x6_kernel(Att
   if (nrow < cl.N) {
     const float inv_l = 1.0f / st.l;
     float* op = p.out + a * p.o_sa + ((size_t)cl.q_start + nrow) * C + h * D;
+    const float* vi = X.vinv + (size_t)ci * C + h * D;        // the values' channel scales leave here
 #pragma unroll
     for (int dt = 0; dt < 2; dt++)
 #pragma unroll
-      for (int g = 0; g < 4; g++)
+      for (int g = 0; g < 4; g++) {
+        const float4 w = ld4(vi + 32 * dt + 8 * g + 4 * half);
         *reinterpret_cast<float4*>(op + 32 * dt + 8 * g + 4 * half) =
-            make_float4(st.o[dt][4 * g] * inv_l, st.o[dt][4 * g + 1] * inv_l, st.o[dt][4 * g + 2] * inv_l, st.o[dt][4 * g + 3] * inv_l);
+            make_float4(st.o[dt][4 * g] * inv_l * w.x, st.o[dt][4 * g + 1] * inv_l * w.y, st.o[dt][4 * g + 2] * inv_l * w.z,
+                        st.o[dt][4 * g + 3] * inv_l * w.w);
+      }
   }
 }
 
 // K / V^T pieces + the f16 kernel; false = this shape stays on attention_kernel (head dimension other than 64, unaligned rows, no workspace)
 extern "C" size_t se3_attention_kv_pieces_bytes(int num_anchors, int64_t key_rows, int C, int v_row_stride) {
   if (num_anchors < 1 || key_rows < 1 || C < 8 || v_row_stride < 16) return 0;
-  return (size_t)2 * num_anchors * ((size_t)key_rows * C + (size_t)C * v_row_stride) * sizeof(_Float16) + 256;
+  return (size_t)2 * num_anchors * ((size_t)key_rows * C + (size_t)C * v_row_stride) * sizeof(_Float16) + 256 +
+         (x6_kinv_floats(num_anchors, C, key_rows) + x6_vinv_floats(C)) * sizeof(float);
 }
 static bool launch_attention_x6(AttnArgs& p, void* ws, size_t ws_bytes, hipStream_t st) {
   // (the plain cross-attention calls -- no logits, one or six small value sets -- stay on the f32 kernel: 16 us against 20 + 10 for the split)
@@ -1934,15 +2086,23 @@ static bool launch_attention_x6(AttnArgs& p, void* ws, size_t ws_bytes, hipStrea
   const int64_t nk = (int64_t)p.A * R * (p.C / 8), nv = (int64_t)p.A * p.C * (p.v_rs / 8);      // uint4 per piece
   uint4* wk = static_cast<uint4*>(ws);
   uint4* wv = wk + 2 * nk;
-  const int64_t work = nk + nv / 2;
+  float* kinv = reinterpret_cast<float*>(wv + 2 * nv);
+  float* vinv = kinv + x6_kinv_floats(p.A, p.C, R);
+  int mmax = 1;
+  for (int c = 0; c < p.S.n; c++) mmax = p.S.c[c].M > mmax ? p.S.c[c].M : mmax;
+  X6SplitArgs sp{};
+  sp.S = p.S; sp.A = p.A; sp.C = p.C; sp.H = p.H;
+  sp.k = p.k; sp.vt = p.v; sp.k_rs = p.k_rs; sp.v_rs = p.v_rs; sp.k_sa = p.k_sa; sp.v_sa = p.v_sa; sp.k_rows = R;
+  sp.outk = wk; sp.outv = wv; sp.kinv = kinv; sp.vinv = vinv;
+  sp.q_groups = 0; sp.k_groups = (((mmax + 7) / 8) * p.H + 3) / 4;
   // (tag 3: the prologue of the attention launch that follows -- bench.py adds its time to that launch)
-  launch_kernel(3, attn_split_kv_kernel, dim3((unsigned)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256)), dim3(256), st, p.k, p.k_rs, p.k_sa,
-                p.v, p.v_rs, p.v_sa, p.A, R, p.C, wk, wv);
+  launch_kernel(3, x6_split_kernel, dim3((unsigned)(p.A * sp.k_groups + (p.C + 3) / 4), (unsigned)p.S.n), dim3(256), st, sp);
   AttnPieces X;
   for (int pc = 0; pc < 2; pc++) {
     X.k[pc] = wk + pc * nk;
     X.v[pc] = wv + pc * nv;
   }
+  X.kinv = kinv; X.vinv = vinv; X.nblk = (int)((R + 7) / 8);
   const dim3 grid((unsigned)((nmax + 127) / 128), (unsigned)p.H, (unsigned)(p.S.n * p.A));
   if (g_attn_variant == 12 && p.bias != nullptr) {
     p.prof = g_attn_prof;
@@ -2386,7 +2546,8 @@ extern "C" int se3_cross_eq_stack_fwd(const float* q, const float* k, const floa
 // k (A, k_rows, C) and vt (A, C, v_row_stride) are split into f16 hi / lo pieces in `workspace` (se3_cross_eq_x6_workspace_bytes), then the flash
 // loop runs on the bf16 matrix cores at f32 accuracy.  Other shapes take the f32 kernels of se3_cross_eq_stack_fwd.
 extern "C" size_t se3_cross_eq_x6_workspace_bytes(int A, int64_t q_rows, int64_t k_rows, int C, int v_row_stride) {
-  return (size_t)4 * A * ((size_t)q_rows * C + (size_t)k_rows * C + (size_t)C * v_row_stride) + 256;      // two f16 pieces per value
+  return (size_t)4 * A * ((size_t)q_rows * C + (size_t)k_rows * C + (size_t)C * v_row_stride) + 256 +      // two f16 pieces per value
+         (x6_qinv_floats(A, C, q_rows) + x6_kinv_floats(A, C, k_rows) + x6_vinv_floats(C)) * sizeof(float);  // + their scales
 }
 
 extern "C" int se3_cross_eq_stack_x6_fwd(const float* q, const float* k, const float* vt, const int64_t* q_starts,
@@ -2434,16 +2595,28 @@ extern "C" int se3_cross_eq_stack_x6_fwd(const float* q, const float* k, const f
   uint4* wq = static_cast<uint4*>(workspace);
   uint4* wk = wq + 2 * nq;
   uint4* wv = wk + 2 * nk;
-  x6_split_rows_kernel<<<(unsigned)((nq + 255) / 256 > 4096 ? 4096 : (nq + 255) / 256), 256, 0, st>>>(q, A, q_rows, C, q_anchor_stride, wq);
-  x6_split_rows_kernel<<<(unsigned)((nk + 255) / 256 > 4096 ? 4096 : (nk + 255) / 256), 256, 0, st>>>(k, A, k_rows, C, k_anchor_stride, wk);
-  x6_split_vt_kernel<<<(unsigned)((nv / 2 + 255) / 256 > 4096 ? 4096 : (nv / 2 + 255) / 256), 256, 0, st>>>(vt, A, C, v_row_stride,
-                                                                                                         v_anchor_stride, wv);
+  float* qinv = reinterpret_cast<float*>(wv + 2 * nv);
+  float* kinv = qinv + x6_qinv_floats(A, C, q_rows);
+  float* vinv = kinv + x6_kinv_floats(A, C, k_rows);
+  int nmax = 1, mmax = 1;
+  for (int c = 0; c < num_pairs; c++) {
+    nmax = p.S.c[c].N > nmax ? p.S.c[c].N : nmax;
+    mmax = p.S.c[c].M > mmax ? p.S.c[c].M : mmax;
+  }
+  X6SplitArgs sp{};
+  sp.S = p.S; sp.A = A; sp.C = C; sp.H = H;
+  sp.q = q; sp.k = k; sp.vt = vt; sp.q_rs = C; sp.k_rs = C; sp.v_rs = v_row_stride;
+  sp.q_sa = q_anchor_stride; sp.k_sa = k_anchor_stride; sp.v_sa = v_anchor_stride; sp.q_rows = q_rows; sp.k_rows = k_rows;
+  sp.outq = wq; sp.outk = wk; sp.outv = wv; sp.qinv = qinv; sp.kinv = kinv; sp.vinv = vinv;
+  sp.q_groups = (((nmax + 7) / 8) * H + 3) / 4; sp.k_groups = (((mmax + 7) / 8) * H + 3) / 4;
+  x6_split_kernel<<<dim3((unsigned)(A * (sp.q_groups + sp.k_groups) + (C + 3) / 4), (unsigned)num_pairs), 256, 0, st>>>(sp);
   X6Pieces X;
   for (int pc = 0; pc < 2; pc++) {
     X.q[pc] = wq + pc * nq;
     X.k[pc] = wk + pc * nk;
     X.v[pc] = wv + pc * nv;
   }
+  X.qinv = qinv; X.kinv = kinv; X.vinv = vinv; X.q_rows = q_rows; X.nblk = (int)((k_rows + 7) / 8);
   cross_eq_mix_kernel<<<(unsigned)num_pairs, 64, 0, st>>>(partial_workspace, 1, 0.f, A, num_rotations, trace_idx, mode, mix, weights, nullptr,
                                                        p.S, 1);
   cross_eq_apply_stack_x6_kernel<<<dim3((unsigned)((qt + 3) / 4), (unsigned)H, (unsigned)(A * num_pairs * out_groups)), 256, 0, st>>>(

@@ -160,8 +160,8 @@ def dense_saturated_rows(reset=True):
 
 
 def attention_saturated(reset=True):
-    """Values of q / K / V^T that the operand splits of the f16 attention kernels clamped to the f16 range since the last reset (csrc/attention.hip:
-    h2_split8_sat).  One device synchronisation."""
+    """NaN / Inf values of K / V^T (and of the cross attention's q) that the operand splits of the f16 attention kernels clamped since the last
+    reset (csrc/attention.hip: x6_split_kernel; finite values of any size are scaled, not clamped).  One device synchronisation."""
     return int(lib().se3_debug_attention_saturated(1 if reset else 0))
 
 

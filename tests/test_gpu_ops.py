@@ -1365,32 +1365,86 @@ def test_magnitude_word_of_blocked_features_expires_with_its_ring():
     assert ops._amax_live(second) is None
 
 
-def test_attention_operand_splits_clamp_and_count_instead_of_overflowing():
-    """The q / K / V^T operands of the f16 attention kernels are split as they are (the open remainder of the f16-window item): a value beyond
-    the f16 range must not become Inf -- it is clamped and the launch counts it (ops.attention_saturated); normal magnitudes count nothing."""
-    from se3et_amd import functional as SF
-    from se3et_amd import ops
-    g = torch.Generator().manual_seed(9)
-    A, lengths, C, H = 6, (70, 64), 256, 4
-    st = _attn_state(C, True)
-    xs = [torch.randn(A, n, C, generator=g) for n in lengths]
-    embs = [torch.randn(n, n, C, generator=g) for n in lengths]
-    eqs = [torch.randn(A, n, n, 4, generator=g) for n in lengths]
-    w_stack, b_stack, offs = SF.compose_self_attention_weights(st['l.proj_q.weight'], st['l.proj_q.bias'], st['l.proj_k.weight'],
-                                                               st['l.proj_k.bias'], st['l.proj_p.weight'], st['l.proj_eq.weight'], H)
+def _magnitude_stack(g, A, C, lengths, alphas):
+    """Packed q / k / v of a stack of clouds (32-row padded starts): cloud c's queries times alphas[c] and 2^(-3..3) per row, its keys
+    divided by alphas[c] and times 2^(-3..3) per row (rows of very different size inside one 8-row block), its value channels times
+    10^(-8..8) each -- the logits stay of order one, every operand leaves the f16 range.  Returns q, k, v (A, R, C), starts, beta (n, C)."""
+    pad = lambda n: (n + 31) // 32 * 32
+    starts, r = [], 0
+    for n in lengths:
+        starts.append(r); r += pad(n)
+    q = torch.zeros(A, r, C); k = torch.zeros(A, r, C); v = torch.zeros(A, r, C)
+    beta = 10.0 ** (torch.rand(len(lengths), C, generator=g) * 16 - 8)
+    for c, (n, s0) in enumerate(zip(lengths, starts)):
+        row_q = 2.0 ** torch.randint(-3, 4, (n, 1), generator=g).float()
+        row_k = 2.0 ** torch.randint(-3, 4, (n, 1), generator=g).float()
+        q[:, s0:s0 + n] = torch.randn(A, n, C, generator=g) * 0.3 * row_q * alphas[c]
+        k[:, s0:s0 + n] = torch.randn(A, n, C, generator=g) * 0.3 * row_k / alphas[c]
+        v[:, s0:s0 + n] = torch.randn(A, n, C, generator=g) * beta[c]
+    return q, k, v, starts, beta
 
-    def run(bias_k):
-        packed, starts = SF.pack_rows([x.cuda() for x in xs])
-        b = b_stack.clone()
-        b[offs['k'] + 3] += bias_k                          # one key channel of every row far outside the f16 range
-        return SF.rpe_self_attention_packed(packed, starts, list(lengths), [e.cuda() for e in embs], [e.cuda() for e in eqs], w_stack.cuda(),
-                                            b.cuda(), offs, st['l.proj_v.weight'].cuda(), st['l.proj_v.bias'].cuda(), H).cpu()
+
+def test_attention_stack_operand_scales_over_magnitudes():
+    """The f16 attention kernel's operands carry their own powers of two (csrc/attention.hip: x6_split_kernel -- a query row per head, 8 key
+    rows per head, a value channel per cloud): queries at 1e-12 / 3e7 / 1 by cloud against keys at the inverse, rows of one key block 64x
+    apart, value channels 1e-8 ... 1e8 -- against a float64 evaluation at the f32 tolerance, channel by channel; nothing is clamped.  A
+    non-finite key is clamped and counted (ops.attention_saturated): finite output, the other anchors and clouds bit for bit."""
+    from se3et_amd import ops
+    g = torch.Generator().manual_seed(21)
+    A, H, C, lengths, alphas = 6, 4, 256, (70, 64, 33), (1e-12, 3e7, 1.0)
+    q, k, v, starts, beta = _magnitude_stack(g, A, C, lengths, alphas)
+    biases, offsets, off = [], [], 0
+    for n in lengths:
+        mp = (n + 31) // 32 * 32
+        b = torch.randn(A * H, n, mp, generator=g)
+        biases.append(b); offsets.append(off); off += b.numel()
+    bias = torch.cat([b.reshape(-1) for b in biases]).cuda()
+    vt = v.transpose(1, 2).contiguous().cuda()
+
+    def run(kk):
+        out = torch.zeros(A, q.shape[1], C, device='cuda')
+        ops.attention_stack(q.cuda(), kk.cuda(), vt, bias, offsets, starts, list(lengths), starts, list(lengths), H, out)
+        return out.cpu()
     ops.attention_saturated(reset=True)
-    base = run(0.0)
-    assert ops.attention_saturated() == 0 and torch.isfinite(base).all()
-    out = run(1e7)
+    got = run(k)
+    assert ops.attention_saturated() == 0
+    D = C // H
+    for c, (n, s0) in enumerate(zip(lengths, starts)):
+        qd = q[:, s0:s0 + n].double().view(A, n, H, D); kd = k[:, s0:s0 + n].double().view(A, n, H, D)
+        vd = (v[:, s0:s0 + n] / beta[c]).double().view(A, n, H, D)
+        sc = (torch.einsum('anhd,amhd->ahnm', qd, kd) + biases[c].double().view(A, H, n, -1)[..., :n]) / D ** 0.5
+        want = torch.einsum('ahnm,amhd->anhd', sc.softmax(-1), vd).reshape(A, n, C)
+        assert_close((got[:, s0:s0 + n] / beta[c]).double(), want, 1e-4, 'cloud %d (queries x %g)' % (c, alphas[c]))
+    bad = k.clone()
+    bad[2, starts[1] + 5, 7] = float('inf')
+    out = run(bad)
     assert ops.attention_saturated() > 0
     assert torch.isfinite(out).all()
+    other = [a for a in range(A) if a != 2]
+    assert torch.equal(out[other], got[other]) and torch.equal(out[:, :starts[1]], got[:, :starts[1]])
+
+
+def test_cross_attention_eq_stack_operand_scales_over_magnitudes():
+    """The same for the equivariant cross attention's f16 form (queries split ahead of the kernel with a scale per row and head): against its
+    own f32 stack form on the same operands, channel by channel."""
+    from se3et_amd import ops, tables
+    g = torch.Generator().manual_seed(22)
+    A, H, C, lengths, alphas = 6, 4, 256, (70, 45, 33), (1e-9, 2e6, 1.0)
+    trace = torch.from_numpy(tables.trace_indices()[0]).cuda()
+    q, k, v, starts, beta = _magnitude_stack(g, A, C, lengths, alphas)
+    q, k, vt = q.cuda(), k.cuda(), v.transpose(1, 2).contiguous().cuda()
+    outs = {}
+    ops.attention_saturated(reset=True)
+    for name, flag in (('f16', True), ('f32', False)):
+        ops.CROSS_EQ_BF16X6 = flag
+        out = torch.zeros(A, q.shape[1], C, device='cuda')
+        mix, w = ops.cross_attention_eq_stack(q, k, vt, starts, list(lengths), starts, list(lengths), H, 'a_soft', trace, out)
+        outs[name] = (out.cpu(), mix.cpu())
+    ops.CROSS_EQ_BF16X6 = True
+    assert ops.attention_saturated() == 0
+    assert_close(outs['f16'][1], outs['f32'][1], 1e-5, 'mixing weights')
+    for c, (n, s0) in enumerate(zip(lengths, starts)):
+        assert_close(outs['f16'][0][:, s0:s0 + n] / beta[c], outs['f32'][0][:, s0:s0 + n] / beta[c], 2e-5, 'pair %d (queries x %g)' % (c, alphas[c]))
 
 
 def test_neighbor_table_trim_marks_each_pairs_surplus_columns():

@@ -13,7 +13,7 @@ import collections, csv, sys
 agg = collections.OrderedDict()
 for r in csv.DictReader(open(sys.argv[1])):
     n = r['Kernel_Name']
-    if 'rpe_bias_kernel' in n or 'attention_kernel' in n or 'attention_x6_kernel' in n or 'attn_split_kv_kernel' in n:
+    if 'rpe_bias_kernel' in n or 'attention_kernel' in n or 'attention_x6_kernel' in n or 'attn_split_kv_kernel' in n or 'x6_split_kernel' in n:
         k = (n.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0], r['Grid_Size'], r['Counter_Name'])
         v = agg.setdefault(k, [0, 0.0]); v[0] += 1; v[1] += float(r['Counter_Value'])
 for (n, g, c), (cnt, tot) in agg.items():

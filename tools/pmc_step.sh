@@ -17,7 +17,7 @@ import collections, csv, sys
 fam = [('Cijk_', 'library GEMM'), ('dense_norm', 'dense + GroupNorm fused'), ('linear_', 'weight split'), ('gn_chain_apply', 'GroupNorm apply (pending forms)'),
        ('gn_', 'GroupNorm'), ('kpconv_gather', 'KPConv gather (G form)'), ('kpconv_fused', 'KPConv fused'), ('kpconv_neighbor_table', 'KPConv neighbour table'),
        ('kpconv_', 'KPConv other'), ('rpe_bias', 'RPE logits'), ('attention_kernel', 'attention'), ('attention_x6', 'attention'), ('attn_split', 'attention'),
-       ('cross_eq', 'cross_eq'), ('gram_', 'cross_eq'), ('x6_split', 'cross_eq'), ('geo_', 'geo embedding'), ('embedding_table', 'geo embedding'),
+       ('x6_split', 'attention / cross_eq operand split'), ('cross_eq', 'cross_eq'), ('gram_', 'cross_eq'), ('geo_', 'geo embedding'), ('embedding_table', 'geo embedding'),
        ('knn3', 'geo embedding'), ('sinkhorn', 'sinkhorn'), ('radius_', 'radius search'), ('grid_', 'grid subsample'), ('order_kernel', 'grid subsample'),
        ('neighbor_max', 'neighbor max'), ('add_ln', 'layer norm'), ('elementwise', 'torch elementwise'), ('at::native', 'torch other'), ('rocclr', 'copies / fills')]
 # families whose loads are 16-byte-per-lane streams (float4 / buffer_load_b128 of contiguous rows): FETCH_SIZE x 2 (guide, gfx950)

@@ -5,7 +5,7 @@ import csv, sys
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 69
 fam = [('Cijk_', 'library GEMM'), ('linear_', 'dense f16-split GEMM'), ('dense_norm', 'dense + GroupNorm fused'), ('gn_chain_apply', 'GroupNorm apply (pending forms)'),
        ('gn_', 'GroupNorm'), ('kpconv_gather', 'KPConv gather (G form)'),
-       ('kpconv_fused', 'KPConv fused'), ('kpconv_union_kernel', 'KPConv fused'), ('kpconv_union_plan', 'KPConv union plan + order'), ('point_order', 'KPConv union plan + order'), ('kpconv_neighbor_table', 'KPConv neighbour table'), ('kpconv_', 'KPConv other'), ('rpe_bias', 'RPE logits'), ('attention_kernel', 'attention'), ('attention_x6', 'attention'), ('attn_split', 'attention'), ('cross_eq', 'cross_eq'), ('gram_', 'cross_eq'), ('x6_split', 'cross_eq'),
+       ('kpconv_fused', 'KPConv fused'), ('kpconv_union_kernel', 'KPConv fused'), ('kpconv_union_plan', 'KPConv union plan + order'), ('point_order', 'KPConv union plan + order'), ('kpconv_neighbor_table', 'KPConv neighbour table'), ('kpconv_', 'KPConv other'), ('rpe_bias', 'RPE logits'), ('attention_kernel', 'attention'), ('attention_x6', 'attention'), ('attn_split', 'attention'), ('x6_split', 'attention / cross_eq operand split'), ('cross_eq', 'cross_eq'), ('gram_', 'cross_eq'),
        ('geo_', 'geo embedding'), ('embedding_table', 'geo embedding'), ('knn3', 'geo embedding'), ('sinkhorn', 'sinkhorn'),
        ('radius_', 'radius search'), ('grid_', 'grid subsample'), ('order_kernel', 'grid subsample'), ('neighbor_max', 'neighbor max'),
        ('add_ln', 'layer norm'), ('elementwise', 'torch elementwise'), ('at::native', 'torch other'), ('rocclr', 'copies / fills')]
