@@ -77,6 +77,9 @@ class _HipForwardTorchBackward(torch.autograd.Function):
         return tuple(result)
 
 
+PROFILE_RANGES = False
+
+
 class _HipForwardHipBackward(torch.autograd.Function):
     """Forward and backward both hand-written: bwd_fn(grad_out, needs, *tensors) -> one gradient (or None) per tensor."""
 
@@ -98,7 +101,11 @@ class _HipForwardHipBackward(torch.autograd.Function):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         with torch.no_grad():
-            got = ctx.bwd_fn(grad, needs, *ctx.saved_tensors)
+            if PROFILE_RANGES:                          # (tools/r5/train_launches.py: the node's launches under the op's name)
+                with torch.autograd.profiler.record_function('hipbwd:' + ctx.name):
+                    got = ctx.bwd_fn(grad, needs, *ctx.saved_tensors)
+            else:
+                got = ctx.bwd_fn(grad, needs, *ctx.saved_tensors)
         if BACKWARD_TIMINGS is not None:
             e1.record()
             BACKWARD_TIMINGS.setdefault(ctx.name + ' (HIP)', []).append((e0, e1))

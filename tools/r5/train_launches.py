@@ -10,6 +10,8 @@ from se3et_amd.data import registration_collate_fn_stack_mode
 from se3et_amd.model import create_model, load_synthetic_weights, make_cfg
 from se3et_amd.synthetic import make_pair
 from se3et_amd.training import OverallLoss, make_optimizer
+from se3et_amd import autograd as AG
+AG.PROFILE_RANGES = True
 
 top = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 dev = torch.device('cuda')
@@ -62,6 +64,9 @@ for ev in prof.events():
     node = next((n for n in reversed(names) if n.startswith('autograd::engine::evaluate_function')), None)
     if node is not None:
         root = 'bwd:' + node.split(': ', 1)[1]
+        hip = next((n for n in names if n.startswith('hipbwd:')), None)
+        if hip is not None:
+            root = hip
     if root is None:
         root = next((n for n in reversed(names) if n in ('optimizer', 'loss', 'collate')), names[-1])
     op = names[0]
