@@ -77,7 +77,9 @@ def weighted_circle_loss(pos_masks, neg_masks, feat_dists, pos_margin, neg_margi
     ln = log_scale * (neg_margin - feat_dists) * neg_w
     loss_row = F.softplus(torch.logsumexp(lp, -1) + torch.logsumexp(ln, -1)) / log_scale
     loss_col = F.softplus(torch.logsumexp(lp, -2) + torch.logsumexp(ln, -2)) / log_scale
-    return (loss_row[row_masks].mean() + loss_col[col_masks].mean()) / 2
+    # (means over the masked entries as masked sums: a boolean-mask index is a nonzero() + a host synchronisation, forward and backward)
+    zero = torch.zeros((), dtype=loss_row.dtype, device=loss_row.device)
+    return (torch.where(row_masks, loss_row, zero).sum() / row_masks.sum() + torch.where(col_masks, loss_col, zero).sum() / col_masks.sum()) / 2
 
 
 class OverallLoss(torch.nn.Module):
@@ -108,7 +110,7 @@ class OverallLoss(torch.nn.Module):
         labels[:, :-1, :-1] = corr
         labels[:, :-1, -1] = (corr.sum(2) == 0) & rm
         labels[:, -1, :-1] = (corr.sum(1) == 0) & sm
-        return -scores[labels].mean()
+        return -(torch.where(labels, scores, torch.zeros((), dtype=scores.dtype, device=scores.device)).sum() / labels.sum())
 
     def forward(self, out, data_dict):
         c, f = self.coarse(out), self.fine(out, data_dict['transform'])
