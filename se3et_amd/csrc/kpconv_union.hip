@@ -35,8 +35,13 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kHeaderB = 256;                // weight-fragment buffer header (csrc/kpconv_mfma.hip)
-constexpr int kUCap = 128;                   // distinct support rows per (sub-)tile (160 measured: 64 -> 80 registers of A fragments, 27 instead of 10 spilled, 13 KB
-                                             // more LDS -- the narrow layers the policy gives this kernel ran 0.401 / 0.283 / 0.544 ms instead of 0.345 / 0.236 / 0.526)
+#ifndef SE3_UCAP
+#define SE3_UCAP 128
+#endif
+constexpr int kUCap = SE3_UCAP;                   // distinct support rows per (sub-)tile (160 measured: 64 -> 80 registers of A fragments, 27 instead of 10 spilled, 13 KB
+                                             // more LDS -- the narrow layers the policy gives this kernel ran 0.401 / 0.283 / 0.544 ms instead of 0.345 / 0.236 / 0.526;
+                                             // 96 (-DSE3_UCAP=96, tools/r5/build_variant.sh): the 32-wide layers another 3-4 % faster, the 64-wide
+                                             // ones 20 % slower -- 1.27 instead of 1.01 passes per group)
 constexpr int kKSM = kUCap / 32;             // K32-steps of the gather product
 constexpr int kBFragB = 1024;                // one B fragment: 64 lanes x 16 B
 constexpr int kBImgB = 2 * 3 * kKSM * kBFragB;   // [piece][anchor pair][K32-step][lane]: 30 720 B
