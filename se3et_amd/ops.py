@@ -688,6 +688,7 @@ KPCONV_BLOCKED = True          # False: the KPConv input in the plain layout (A/
 _KPCONV_UNION_ENV = os.environ.get('SE3_KPCONV_UNION', '1')
 KPCONV_UNION = _KPCONV_UNION_ENV != '0'
 KPCONV_UNION_ALL = _KPCONV_UNION_ENV == 'all'
+KPCONV_UNION_BIG = os.environ.get('SE3_KPCONV_UNION_BIG', '0') == '1'      # A/B: the policy's layers also for clouds beyond 8192 points (order through torch.sort)
 KPCONV_UNION_MIN_POINTS = 24000           # stage-0 points of a pyramid from which the pyramid builder registers orders (single pairs stay on the gather kernel)
 
 
@@ -1147,8 +1148,9 @@ def register_point_orders(points_list, lengths_list, cells):
                                                              for p, l in zip(points_list, lens))
     if not ok:
         # (clouds beyond 8192 points -- the KITTI configuration -- would take the keys + torch.sort + placement form, whose launches cost more
-        # than the four narrow layers gain there: 142 against 141 pairs/s at C3; only on request)
-        return [register_point_order(p, l, c) for p, l, c in zip(points_list, lengths_list, cells)] if KPCONV_UNION_ALL else [None] * len(points_list)
+        # than the four narrow layers gain there: 142 against 141 pairs/s at C3 with the 160-row cap, 138.6 against 140.4 with the 128-row cap
+        # and NN = 38 -- SE3_KPCONV_UNION_BIG=1; only on request)
+        return [register_point_order(p, l, c) for p, l, c in zip(points_list, lengths_list, cells)] if (KPCONV_UNION_ALL or KPCONV_UNION_BIG) else [None] * len(points_list)
     S = len(points_list)
     las = [_i64_array(l) for l in lens]
     Gs = [int(lib().se3_point_order_groups(la, len(l))) for la, l in zip(las, lens)]
