@@ -1293,12 +1293,22 @@ __global__ __launch_bounds__(256) void x6_split_kernel(X6SplitArgs p) {
         return m;
       };
       auto emit = [&](int aa, int b, const float4 (&x)[4], float s) {
-        const float lo[8] = {x[0].x * s, x[0].y * s, x[0].z * s, x[0].w * s, x[2].x * s, x[2].y * s, x[2].z * s, x[2].w * s};      // keys 0..3, 8..11
-        const float hi[8] = {x[1].x * s, x[1].y * s, x[1].z * s, x[1].w * s, x[3].x * s, x[3].y * s, x[3].z * s, x[3].w * s};      // keys 4..7, 12..15
+        // (the padding keys of the last tile are multiplied by P = 0: they only have to be finite -- whatever the caller's buffer holds
+        //  there, they are stored as zeros and never counted)
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int key = 16 * b + 4 * u;
+          v[4 * u + 0] = key + 0 < cl.M ? x[u].x * s : 0.f;
+          v[4 * u + 1] = key + 1 < cl.M ? x[u].y * s : 0.f;
+          v[4 * u + 2] = key + 2 < cl.M ? x[u].z * s : 0.f;
+          v[4 * u + 3] = key + 3 < cl.M ? x[u].w * s : 0.f;
+        }
+        const float lo[8] = {v[0], v[1], v[2], v[3], v[8], v[9], v[10], v[11]};          // keys 0..3, 8..11
+        const float hi[8] = {v[4], v[5], v[6], v[7], v[12], v[13], v[14], v[15]};        // keys 4..7, 12..15
         uint4 a1, a2, b1, b2;
-        // (the padding keys of the last tile are multiplied by P = 0: they only have to be finite, which the clamp sees to)
         const bool s1 = h2_split8_sat(lo, a1, a2), s2 = h2_split8_sat(hi, b1, b2);
-        sat |= (s1 || s2) && 16 * b < cl.M;
+        sat |= s1 || s2;
         const int64_t j = ((int64_t)aa * p.C + c) * vblocks + (cl.k_start >> 4) + b;
         p.outv[2 * j] = a1; p.outv[2 * j + 1] = b1;
         p.outv[2 * (vtot + j)] = a2; p.outv[2 * (vtot + j) + 1] = b2;
