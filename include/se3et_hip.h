@@ -57,6 +57,9 @@ void se3_debug_set_kpconv_variant(int variant);
 /* Diagnostic bits of se3_kpconv_so3_union (timing only: results are wrong with any bit set): 1 producers skip the gather product, 2 the row loads,
  * 4 the A fragments; 8 consumers skip their MFMAs. */
 void se3_debug_set_kpconv_union_variant(int variant);
+/* se3_log_sinkhorn_fwd: 0 = the iteration in base 2 with the previous iteration's logsumexp as the shift (default), 1 = natural base with the exact
+ * maximum in every pass (the reference's order of operations) -- A/B runs. */
+void se3_debug_set_sinkhorn_variant(int variant);
 /* Rows of dense launches (se3_linear_stream*, se3_dense_norm_fwd, se3_dense_residual_fwd, se3_linear_f16) whose values left the headroom of the
  * row's f16-split scale -- more than 2^8 times the largest magnitude of the row's first 32 values -- or held NaN / Inf, since the last
  * reset: such values are clamped to the f16 range (finite, wrong) and counted here (events: once per row, K-step and column block).  Synchronises the device; reset != 0 zeroes the count. */

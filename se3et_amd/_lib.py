@@ -19,6 +19,7 @@ SIGNATURES = {
     'se3_debug_set_attention_variant': (None, [_i32]),
     'se3_debug_set_kpconv_variant': (None, [_i32]),
     'se3_debug_set_kpconv_union_variant': (None, [_i32]),
+    'se3_debug_set_sinkhorn_variant': (None, [_i32]),
     'se3_debug_dense_saturated_rows': (ctypes.c_uint64, [_i32]),
     'se3_debug_attention_saturated': (ctypes.c_uint64, [_i32]),
     'se3_debug_set_attention_profile': (None, [_vp]),

@@ -30,13 +30,22 @@ __device__ __forceinline__ float group_sum(float s) {
 
 constexpr int kThreads = 576;      // 9 waves: (65 rows) x 8 lanes, or (129 rows) x 4 lanes
 
-template <int LANES, int EPL>      // lanes cooperating on one row/column (4 or 8), entries per lane
+// FAST (the default; late round 5 -- the kernel is bound by its vector instructions: 87 % of the issue slots of 9 waves x 74 instructions per
+// half-iteration): the same iteration in base 2 -- Z, u, v, log mu, log nu times log2(e) once, so that an exponential is ONE v_exp_f32 and the
+// logarithm ONE v_log_f32 (natural-base expf = multiply + v_exp_f32, logf = a ten-instruction sequence), converted back in the epilogue --,
+// entries beyond the matrix hold -inf from the start instead of being selected in every pass, and the shift of a row's / column's
+// logsumexp is the value of the SAME logsumexp one iteration earlier instead of the exact maximum (the sum then sits near 1; a sum outside
+// [2^-60, 2^60] -- the duals moved far, an overflow, the first iteration -- sends the whole wave through the exact form: the result is the
+// logsumexp either way, to rounding).  !FAST: the reference's order of operations, kept for A/B runs (se3_debug_set_sinkhorn_variant).
+template <int LANES, int EPL, bool FAST>      // lanes cooperating on one row/column (4 or 8), entries per lane
 __global__ __launch_bounds__(kThreads) void sinkhorn_kernel(const float* __restrict__ scores,
                                                             const uint8_t* __restrict__ row_masks,
                                                             const uint8_t* __restrict__ col_masks,
                                                             const float* __restrict__ alpha_p, int R, int C, int iters,
                                                             float inf, float* __restrict__ out) {
   __shared__ float u[160], v[160], log_mu[160], log_nu[160];
+  constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+  const float unit = FAST ? kLog2e : 1.f;                 // the dual variables and Z live in units of 1 / unit nats
   const int b = blockIdx.x;
   const int R1 = R + 1, C1 = C + 1;
   const int tid = threadIdx.x;
@@ -50,33 +59,68 @@ __global__ __launch_bounds__(kThreads) void sinkhorn_kernel(const float* __restr
   const float nvr = (float)__syncthreads_count(tid < R && rm[tid < R ? tid : 0] != 0);
   const float nvc = (float)__syncthreads_count(tid < C && cm[tid < C ? tid : 0] != 0);
   const float norm = -logf(nvr + nvc);
-  for (int i = tid; i < R1; i += kThreads) {
+  for (int i = tid; i < 160; i += kThreads) {
     const bool masked = i < R && !rm[i];
-    log_mu[i] = masked ? -inf : (i < R ? norm : logf(nvc) + norm);
-    u[i] = 0.f;
+    log_mu[i] = i < R1 ? (masked ? -inf : (i < R ? norm : logf(nvc) + norm)) * unit : 0.f;
+    u[i] = 0.f;                                           // (also beyond the matrix: FAST reads those entries and adds them to -inf)
   }
-  for (int j = tid; j < C1; j += kThreads) {
+  for (int j = tid; j < 160; j += kThreads) {
     const bool masked = j < C && !cm[j];
-    log_nu[j] = masked ? -inf : (j < C ? norm : logf(nvr) + norm);
+    log_nu[j] = j < C1 ? (masked ? -inf : (j < C ? norm : logf(nvr) + norm)) * unit : 0.f;
     v[j] = 0.f;
   }
 
   auto zval = [&](int i, int j) -> float {
     const bool masked = (i < R && !rm[i]) || (j < C && !cm[j]);
-    if (masked) return -inf;
-    return (i < R && j < C) ? S[(size_t)i * C + j] : alpha;
+    if (masked) return -inf * unit;
+    return ((i < R && j < C) ? S[(size_t)i * C + j] : alpha) * unit;
   };
   // row-owner copy: row `owner`, columns sub, sub+LANES, ... ; column-owner copy: column `owner`, rows sub, sub+LANES, ...
+  const float outside = FAST ? -INFINITY : 0.f;
   float zr[EPL], zc[EPL];
 #pragma unroll
   for (int e = 0; e < EPL; e++) {
     const int j = sub + e * LANES;
-    zr[e] = (owner < R1 && j < C1) ? zval(owner, j) : 0.f;
+    zr[e] = owner < R1 ? (j < C1 ? zval(owner, j) : outside) : 0.f;
     const int i = sub + e * LANES;
-    zc[e] = (owner < C1 && i < R1) ? zval(i, owner) : 0.f;
+    zc[e] = owner < C1 ? (i < R1 ? zval(i, owner) : outside) : 0.f;
   }
   __syncthreads();
 
+  if (FAST) {
+    // one half-iteration: dual[owner] = log_m[owner] - LSE2_e(z[e] + other[sub + e LANES]); lse: this owner's logsumexp of the previous iteration
+    auto half = [&](const float (&z)[EPL], const float* other, const float* log_m, float* dual, int n_own, float& lse, bool first) {
+      float t[EPL];
+#pragma unroll
+      for (int e = 0; e < EPL; e++) t[e] = z[e] + other[sub + e * LANES];
+      float s = 0.f;
+      if (!first) {
+#pragma unroll
+        for (int e = 0; e < EPL; e++) s += __builtin_amdgcn_exp2f(t[e] - lse);
+        s = group_sum<LANES>(s);
+      }
+      if (__any(owner < n_own && !(s > 8.67e-19f && s < 1.15e18f))) {       // (wave-uniform; NaN fails both) the exact form
+        float m = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) m = fmaxf(m, t[e]);
+        m = group_max<LANES>(m);
+        s = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) s += __builtin_amdgcn_exp2f(t[e] - m);
+        s = group_sum<LANES>(s);
+        lse = m;
+      }
+      lse += __builtin_amdgcn_logf(s);
+      if (sub == 0 && owner < n_own) dual[owner] = log_m[owner] - lse;
+    };
+    float lse_r = 0.f, lse_c = 0.f;
+    for (int it = 0; it < iters; it++) {
+      half(zr, v, log_mu, u, R1, lse_r, it == 0);
+      __syncthreads();
+      half(zc, u, log_nu, v, C1, lse_c, it == 0);
+      __syncthreads();
+    }
+  } else {
   for (int it = 0; it < iters; it++) {
     {  // u_i = log_mu_i - LSE_j(Z_ij + v_j)
       float t[EPL], m = -INFINITY;
@@ -111,6 +155,7 @@ __global__ __launch_bounds__(kThreads) void sinkhorn_kernel(const float* __restr
     }
     __syncthreads();
   }
+  }
 
   float* O = out + (size_t)b * R1 * C1;
   if (owner < R1) {
@@ -118,7 +163,7 @@ __global__ __launch_bounds__(kThreads) void sinkhorn_kernel(const float* __restr
 #pragma unroll
     for (int e = 0; e < EPL; e++) {
       const int j = sub + e * LANES;
-      if (j < C1) O[(size_t)owner * C1 + j] = zr[e] + ui + v[j] - norm;
+      if (j < C1) O[(size_t)owner * C1 + j] = FAST ? (zr[e] + ui + v[j]) * kLn2 - norm : zr[e] + ui + v[j] - norm;
     }
   }
 }
@@ -322,6 +367,9 @@ __global__ __launch_bounds__(kThreads) void sinkhorn_bwd_kernel(const float* __r
 
 }  // namespace
 
+static int g_sinkhorn_variant = 0;          // 0: base-2 iteration with carried shifts (default); 1: the reference's order of operations
+extern "C" void se3_debug_set_sinkhorn_variant(int variant) { g_sinkhorn_variant = variant; }
+
 extern "C" int se3_log_sinkhorn_fwd(const float* scores, const uint8_t* row_masks, const uint8_t* col_masks,
                                     const float* alpha, int batch, int rows, int cols, int iterations, float inf,
                                     float* out, void* stream) {
@@ -331,10 +379,13 @@ extern "C" int se3_log_sinkhorn_fwd(const float* scores, const uint8_t* row_mask
   SE3_REQUIRE(dim <= 144, SE3_ERR_UNSUPPORTED, "log_sinkhorn: patches of %d x %d points exceed 143", rows, cols);
   if (batch == 0) return SE3_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (dim <= 72)
-    sinkhorn_kernel<8, 9><<<batch, kThreads, 0, st>>>(scores, row_masks, col_masks, alpha, rows, cols, iterations, inf, out);
-  else
-    sinkhorn_kernel<4, 36><<<batch, kThreads, 0, st>>>(scores, row_masks, col_masks, alpha, rows, cols, iterations, inf, out);
+  if (dim <= 72) {
+    if (g_sinkhorn_variant == 0) sinkhorn_kernel<8, 9, true><<<batch, kThreads, 0, st>>>(scores, row_masks, col_masks, alpha, rows, cols, iterations, inf, out);
+    else sinkhorn_kernel<8, 9, false><<<batch, kThreads, 0, st>>>(scores, row_masks, col_masks, alpha, rows, cols, iterations, inf, out);
+  } else {
+    if (g_sinkhorn_variant == 0) sinkhorn_kernel<4, 36, true><<<batch, kThreads, 0, st>>>(scores, row_masks, col_masks, alpha, rows, cols, iterations, inf, out);
+    else sinkhorn_kernel<4, 36, false><<<batch, kThreads, 0, st>>>(scores, row_masks, col_masks, alpha, rows, cols, iterations, inf, out);
+  }
   SE3_CHECK_LAUNCH("log_sinkhorn");
   return SE3_OK;
 }
