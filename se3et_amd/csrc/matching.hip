@@ -5,6 +5,15 @@
 
 namespace {
 
+// one K4-step of a feature dot product and the score of a finished one, with the roundings spelled out: the per-pair kernel and the stack
+// kernel (eight rows per workgroup) must agree bit for bit, whatever the compiler would contract in either loop
+__device__ __forceinline__ float sp_dot_step(float acc, const float* f, const float4& v) {
+  const float a = __fmaf_rn(f[0], v.x, __fmul_rn(f[1], v.y));
+  const float b = __fmaf_rn(f[2], v.z, __fmul_rn(f[3], v.w));
+  return __fadd_rn(acc, __fadd_rn(a, b));
+}
+__device__ __forceinline__ float sp_score(float dot) { return __expf(-fmaxf(__fmaf_rn(-2.f, dot, 2.f), 0.f)); }
+
 // one workgroup per reference row n; thread t handles columns t, t + 256, ...
 __global__ __launch_bounds__(256) void sp_scores_kernel(const float* __restrict__ ref, const float* __restrict__ src, int N,
                                                         int M, int C, float* __restrict__ S, float* __restrict__ rowsum) {
@@ -19,9 +28,9 @@ __global__ __launch_bounds__(256) void sp_scores_kernel(const float* __restrict_
     float acc = 0.f;
     for (int c4 = 0; c4 < C / 4; c4++) {
       const float4 v = sp[c4];
-      acc += (rf[4 * c4] * v.x + rf[4 * c4 + 1] * v.y) + (rf[4 * c4 + 2] * v.z + rf[4 * c4 + 3] * v.w);
+      acc = sp_dot_step(acc, rf + 4 * c4, v);
     }
-    const float s = __expf(-fmaxf(2.f - 2.f * acc, 0.f));
+    const float s = sp_score(acc);
     S[(size_t)n * M + m] = s;
     rs += s;
   }
@@ -65,39 +74,62 @@ struct MatchPairs {
   int n;
 };
 
-// one workgroup per (pair, reference row); raw scores into the pair's row of the padded (B, stride) output, row sums over the
+// one workgroup per (pair, 8 reference rows); raw scores into the pair's rows of the padded (B, stride) output, row sums over the
 // valid columns into the workspace.  Nodes with mask 0 (no fine point) are absent, as the reference drops them beforehand.
+// (Late round 5: eight rows per workgroup instead of one -- a thread's source row (1 KB, one lane per row: 64 cache lines per load
+// instruction) is fetched once for eight dot products instead of once per dot product; every dot product keeps its order of operations.)
+template <int kSpRows>              // 8; 1 for feature widths whose eight rows would not fit 64 KB of LDS
 __global__ __launch_bounds__(256) void sp_scores_stack_kernel(const float* __restrict__ feats, const unsigned char* __restrict__ masks,
                                                               MatchPairs T, int C, int64_t stride, float* __restrict__ S,
                                                               float* __restrict__ rowsum) {
-  extern __shared__ float rf[];
-  __shared__ float part[4];
-  int p = 0;
-  for (int k = 1; k < T.n; k++)
-    if ((int)blockIdx.x >= T.row0[k]) p = k;
-  const int n = blockIdx.x - T.row0[p], M = T.M[p];
-  if (!masks[T.ref_mask[p] + n]) return;
-  const float* ref = feats + (size_t)(T.ref_row[p] + n) * C;
-  for (int c = threadIdx.x; c < C; c += 256) rf[c] = ref[c];
+  extern __shared__ float rf[];                                 // kSpRows x C
+  __shared__ float part[kSpRows][4];
+  const int p = blockIdx.y, N = T.N[p], M = T.M[p];
+  const int n0 = blockIdx.x * kSpRows;
+  if (n0 >= N) return;
+  const int nr = min(kSpRows, N - n0);
+  for (int e = threadIdx.x; e < kSpRows * C; e += 256) {
+    const int r = e / C, c = e - r * C;
+    rf[e] = r < nr ? feats[(size_t)(T.ref_row[p] + n0 + r) * C + c] : 0.f;
+  }
   __syncthreads();
-  float* Srow = S + (size_t)p * stride + (size_t)n * M;
   const unsigned char* cm = masks + T.src_mask[p];
-  float rs = 0.f;
+  const unsigned char* rmk = masks + T.ref_mask[p] + n0;
+  bool present[kSpRows];
+#pragma unroll
+  for (int r = 0; r < kSpRows; r++) present[r] = r < nr && rmk[r < nr ? r : 0] != 0;
+  float rs[kSpRows];
+#pragma unroll
+  for (int r = 0; r < kSpRows; r++) rs[r] = 0.f;
   for (int m = threadIdx.x; m < M; m += 256) {
     const float4* sp = reinterpret_cast<const float4*>(feats + (size_t)(T.src_row[p] + m) * C);
-    float acc = 0.f;
+    float acc[kSpRows];
+#pragma unroll
+    for (int r = 0; r < kSpRows; r++) acc[r] = 0.f;
     for (int c4 = 0; c4 < C / 4; c4++) {
       const float4 v = sp[c4];
-      acc += (rf[4 * c4] * v.x + rf[4 * c4 + 1] * v.y) + (rf[4 * c4 + 2] * v.z + rf[4 * c4 + 3] * v.w);
+#pragma unroll
+      for (int r = 0; r < kSpRows; r++) {
+        acc[r] = sp_dot_step(acc[r], rf + r * C + 4 * c4, v);
+      }
     }
-    const float s = cm[m] ? __expf(-fmaxf(2.f - 2.f * acc, 0.f)) : 0.f;
-    Srow[m] = s;
-    rs += s;
+    const bool cv = cm[m] != 0;
+#pragma unroll
+    for (int r = 0; r < kSpRows; r++) {
+      if (!present[r]) continue;
+      const float sc = cv ? sp_score(acc[r]) : 0.f;
+      S[(size_t)p * stride + (size_t)(n0 + r) * M + m] = sc;
+      rs[r] += sc;
+    }
   }
-  rs = se3_wave_sum(rs);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = rs;
+#pragma unroll
+  for (int r = 0; r < kSpRows; r++) {
+    const float w = se3_wave_sum(rs[r]);
+    if ((threadIdx.x & 63) == 0) part[r][threadIdx.x >> 6] = w;
+  }
   __syncthreads();
-  if (threadIdx.x == 0) rowsum[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+  if ((int)threadIdx.x < nr && rmk[threadIdx.x])
+    rowsum[T.row0[p] + n0 + threadIdx.x] = (part[threadIdx.x][0] + part[threadIdx.x][1]) + (part[threadIdx.x][2] + part[threadIdx.x][3]);
 }
 
 __global__ __launch_bounds__(256) void sp_colsum_stack_kernel(const float* __restrict__ S, const unsigned char* __restrict__ masks,
@@ -178,7 +210,14 @@ extern "C" int se3_superpoint_scores_stack(const float* feats, const uint8_t* no
   hipStream_t st = (hipStream_t)stream;
   float* rowsum = workspace;               // rows floats
   float* colsum = workspace + rows;        // cols floats
-  sp_scores_stack_kernel<<<(unsigned)rows, 256, C * sizeof(float), st>>>(feats, node_masks, T, C, score_stride, scores, rowsum);
+  int max_n = 0;
+  for (int p = 0; p < num_pairs; p++) max_n = T.N[p] > max_n ? T.N[p] : max_n;
+  if (C <= 1024)
+    sp_scores_stack_kernel<8><<<dim3((unsigned)((max_n + 7) / 8), (unsigned)num_pairs), 256, (size_t)8 * C * sizeof(float), st>>>(
+        feats, node_masks, T, C, score_stride, scores, rowsum);
+  else
+    sp_scores_stack_kernel<1><<<dim3((unsigned)max_n, (unsigned)num_pairs), 256, (size_t)C * sizeof(float), st>>>(feats, node_masks, T, C,
+                                                                                                                score_stride, scores, rowsum);
   if (dual_normalization)
     sp_colsum_stack_kernel<<<dim3((unsigned)((max_m + 63) / 64), (unsigned)num_pairs), 256, 0, st>>>(scores, node_masks, T,
                                                                                                   score_stride, colsum);
