@@ -1,6 +1,6 @@
 """The two forms of the Sinkhorn forward kernel (csrc/sinkhorn.hip: base 2 with carried shifts / the reference's order of operations) on the
 bench shape -- 2048 patch pairs of 64 x 64 points, 100 iterations -- and the KITTI one; time per call and the largest difference on valid
-entries.    python tools/micro/sinkhorn_ab.py"""
+entries.    python tools/micro/sinkhorn_ab.py [one]"""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from se3et_amd import functional as SF
@@ -17,7 +17,9 @@ def timeit(f, n=10):
 
 
 g = torch.Generator().manual_seed(0)
-for B, R, C, frac, scale in ((2048, 64, 64, 0.8, 3.0), (2048, 64, 64, 1.0, 1.0), (1024, 64, 64, 0.6, 12.0), (256, 128, 128, 0.7, 3.0)):
+shapes = ((2048, 64, 64, 0.8, 3.0), (2048, 64, 64, 1.0, 1.0), (1024, 64, 64, 0.6, 12.0), (256, 128, 128, 0.7, 3.0))
+one = len(sys.argv) > 1 and sys.argv[1] == 'one'          # counter passes (tools/pmc_kernel.sh): the bench shape only, three calls per form
+for B, R, C, frac, scale in shapes[:1] if one else shapes:
     scores = (torch.randn(B, R, C, generator=g) * scale).cuda()
     rm, cm = (torch.rand(B, R, generator=g) < frac).cuda(), (torch.rand(B, C, generator=g) < frac).cuda()
     alpha = torch.tensor(1.0).cuda()
@@ -25,7 +27,7 @@ for B, R, C, frac, scale in ((2048, 64, 64, 0.8, 3.0), (2048, 64, 64, 1.0, 1.0),
     for variant in (1, 0):
         lib().se3_debug_set_sinkhorn_variant(variant)
         f = lambda: SF.log_optimal_transport(scores, rm, cm, alpha, 100, 1e12)
-        outs.append(f()); ms.append(timeit(f))
+        outs.append(f()); ms.append(timeit(f, 2 if one else 10))
     lib().se3_debug_set_sinkhorn_variant(0)
     valid = outs[0] > -1e11
     assert torch.equal(outs[1] > -1e11, valid)
