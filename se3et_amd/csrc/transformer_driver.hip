@@ -16,6 +16,7 @@
 
 #include "../../include/se3et_hip.h"
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -87,6 +88,8 @@ int eq_groups(int A, const Half& q, int H, int C, const Half& k, int64_t v_row_s
   int64_t wgs = 0;
   for (int i = 0; i < q.n; i++) wgs += (q.lengths[i] + 127) / 128;
   wgs *= (int64_t)H * A;
+  static const int forced = getenv("SE3_EQ_GROUPS") ? atoi(getenv("SE3_EQ_GROUPS")) : 0;      // A/B runs: 2 or 3
+  if ((forced == 2 || forced == 3) && A % forced == 0) return forced;
   if (A % 3 == 0 && wgs * 3 <= 320) return 3;
   if (A % 2 == 0 && wgs * 2 <= 320) return 2;
   return 1;

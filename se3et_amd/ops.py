@@ -1648,6 +1648,9 @@ def cross_eq_groups(A, q_lengths, num_heads, C, k_starts, vt):
     if not CROSS_EQ_BF16X6 or C // H != 64 or C % H or A > 6 or vt.stride(1) % 16 or vt.stride(2) != 1 or any(int(s) % 16 for s in k_starts):
         return 1
     wgs = sum((int(n) + 127) // 128 for n in q_lengths) * H * A
+    forced = int(os.environ.get('SE3_EQ_GROUPS', '0'))          # A/B runs: 2 or 3
+    if forced in (2, 3) and A % forced == 0:
+        return forced
     for G in (3, 2):
         if A % G == 0 and wgs * G <= 320:
             return G
