@@ -467,6 +467,8 @@ def main():
     sharding.barrier(dev)
     elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
     host_cpu_s = time.process_time() - cpu0           # CPU seconds of this rank's process (all host threads) over the timed region
+    # (grows with the number of timed steps -- 0.013 s per step at 20, 0.036 at 60 -- through the roofline's own per-launch HIP events, which stay
+    #  alive until the run is over: DESIGN section 5)
     timings, se3_ops.KERNEL_TIMINGS = se3_ops.KERNEL_TIMINGS, None
 
     roofline = collect_roofline(se3_lib, timings, args)
