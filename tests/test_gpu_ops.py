@@ -66,6 +66,31 @@ def test_sinkhorn_wide_score_ranges_match_oracle(scale):
     assert float((got[valid] - want[valid]).abs().max()) <= 1e-4 * float(want[valid].abs().max())
 
 
+@pytest.mark.parametrize('B,R,C,frac,scale,iters', [(64, 64, 64, 0.8, 3.0, 100), (16, 64, 64, 0.05, 3.0, 100), (16, 64, 64, 1.0, 40.0, 100),
+                                                    (8, 128, 128, 0.6, 8.0, 100), (8, 17, 40, 0.7, 3.0, 100), (8, 64, 64, 0.8, 3.0, 1),
+                                                    (8, 64, 64, 0.8, 3.0, 0), (4, 1, 1, 1.0, 1.0, 100)])
+def test_sinkhorn_forms_agree(B, R, C, frac, scale, iters):
+    """csrc/sinkhorn.hip: the default loop (base 2, one v_exp_f32 per entry and pass, the previous pass's logsumexp as the shift with the exact
+    form as the per-wave fallback) against the reference-order loop kept in the library (se3_debug_set_sinkhorn_variant(1)): nearly empty
+    masks, scores 40 wide (every pass of some rows falls back), non-square patches, zero / one iteration, a 1 x 1 patch."""
+    from se3et_amd import functional as SF
+    from se3et_amd._lib import lib
+    g = torch.Generator().manual_seed(B + R + iters)
+    scores = (torch.randn(B, R, C, generator=g) * scale).cuda()
+    rm, cm = (torch.rand(B, R, generator=g) < frac).cuda(), (torch.rand(B, C, generator=g) < frac).cuda()
+    rm[:, 0], cm[:, 0] = True, True
+    alpha = torch.tensor(0.9).cuda()
+    try:
+        lib().se3_debug_set_sinkhorn_variant(1)
+        want = SF.log_optimal_transport(scores, rm, cm, alpha, iters, 1e12).cpu()
+    finally:
+        lib().se3_debug_set_sinkhorn_variant(0)
+    got = SF.log_optimal_transport(scores, rm, cm, alpha, iters, 1e12).cpu()
+    valid = want > -1e11
+    assert torch.equal(got > -1e11, valid) and torch.isfinite(got).all()
+    assert float((got[valid] - want[valid]).abs().max()) <= 2e-5 * float(want[valid].abs().max().clamp_min(1.0))
+
+
 def test_sinkhorn_matches_reference_fixture(golden_dir):
     from se3et_amd import functional as SF
     g = _golden(golden_dir)
