@@ -155,12 +155,10 @@ class SE3ET(nn.Module):
             # (experiments/se3eti.kitti/model.py:82-87) although the forward only reaches them with supervise_rotation /
             # anchor_matching (both off in its config).  They are carried as parameter holders so that a reference checkpoint
             # loads with strict=True; nothing here evaluates them.
-            C, na = g.output_dim, cfg.epn.kanchor
-            self.rotation_supervision = nn.ModuleDict({'proj_q': nn.Linear(C, C), 'proj_k': nn.Linear(C, C)})
-            pi = nn.Module()
-            pi.anchors = nn.Parameter(torch.from_numpy(tables.rotations().astype('float32')), requires_grad=False)
-            pi.fc1, pi.batch_norm, pi.fc2 = nn.Linear(na * C, na * C), nn.BatchNorm1d(na * C), nn.Linear(na * C, C)
-            self.permutation_invariant = pi
+            from .modules.transformer.permutation_invariant import PermutationInvariantLayer
+            from .modules.transformer.rotation_supervision import RotationAttentionLayer
+            self.rotation_supervision = RotationAttentionLayer(g.output_dim, g.num_heads)
+            self.permutation_invariant = PermutationInvariantLayer(cfg.epn.kanchor, g.output_dim)
         self._tls = threading.local()       # per-thread pinned scratch (pairs may be processed by several host threads)
         self.packed_inference = True        # inference of one pair through se3et_amd.batched.forward_pairs (False: the per-module path)
         self.stage_hook = None              # optional callable invoked between backbone and transformer (pipelined drivers)

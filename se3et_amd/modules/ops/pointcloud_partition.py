@@ -1,6 +1,18 @@
 import torch
 
 from ... import ops as _ops
+from .pairwise_distance import pairwise_distance
+
+
+@torch.no_grad()
+def get_point_to_node_indices(points, nodes, return_counts=False):
+    """Index of the nearest node of every point (N,), optionally the number of points per node (M,)
+    (geotransformer/modules/ops/pointcloud_partition.py:9-32; used by the reference's ground-truth helpers, not by the forward, which
+    takes the fused `point_to_node_partition` below)."""
+    nearest = pairwise_distance(points, nodes).argmin(dim=1)
+    if return_counts:
+        return nearest, torch.bincount(nearest, minlength=nodes.shape[0])
+    return nearest
 
 
 @torch.no_grad()

@@ -9,7 +9,15 @@ Mirror of the call sites of vgtk.cuda.{gathering, grouping, zpconv} in the refer
     vgtk/spconv/functional.py:314-335  InterZPConvGrouping (autograd)  -> InterZPConvGrouping, inter_zpconv_grouping
     vgtk/spconv/functional.py:211-238  IntraZPConvGrouping (autograd)  -> IntraZPConvGrouping, intra_zpconv_grouping
 Same tensor layouts (channel-first float32, int32 indices), CUDA tensors only (on ROCm 'cuda' is the HIP device).  No SE3ET model
-calls these; they exist because BASELINE.json lists the vgtk CUDA ops as a replaced subsystem."""
+calls these; they exist because BASELINE.json lists the vgtk CUDA ops as a replaced subsystem.
+
+Host-side constants (no kernel), for the reference's experiments/<variant>/loss.py:88-145, which builds its rotation-matching loss from the
+toolkit at construction time even though every SE3ET config leaves it switched off (se3et_amd.dropin aliases this module as `vgtk`,
+`vgtk.functional`, `vgtk.so3conv`):
+    vgtk/so3conv/functional.py:398-399   get_octahedron_vertices        -> get_octahedron_vertices   (se3et_amd.tables)
+    vgtk/functional/rotation.py:566-579  get_relativeV_index            -> get_relativeV_index
+    vgtk/functional/rotation.py:922-934  label_relative_rotation_simple -> label_relative_rotation_simple"""
+import numpy as np
 import torch
 
 from . import ops as _ops
@@ -165,3 +173,33 @@ class IntraZPConvGrouping(torch.autograd.Function):
 
 def intra_zpconv_grouping(intra_idx, intra_w, feats):
     return IntraZPConvGrouping.apply(intra_idx, intra_w, feats)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# constant tables of the octahedral group under the toolkit's names (host side, numpy / torch; values from se3et_amd.tables)
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def get_octahedron_vertices():
+    """-> vs (6, 3) f32, v_adjs (6, 4) int: the four neighbours of every vertex in ascending order, vRs (24, 3, 3) f32: the group
+    rotations, four per vertex, ecs (12, 3) f32: unit edge centres in lexicographic edge order, face_normals (8, 3) f32."""
+    from . import tables
+    vs = tables.VERTICES.copy()
+    d2 = ((vs[:, None] - vs[None]) ** 2).sum(-1)
+    v_adjs = np.stack([np.nonzero(d2[i] == 2)[0] for i in range(len(vs))]).astype(np.int64)
+    edges = [(i, int(j)) for i in range(len(vs)) for j in v_adjs[i] if j > i]
+    ecs = np.stack([vs[i] + vs[j] for i, j in edges]).astype(np.float32)
+    ecs /= np.linalg.norm(ecs, axis=1, keepdims=True)
+    return vs, v_adjs, tables.rotations().copy(), ecs, tables.face_normals()
+
+
+def get_relativeV_index(Rs, vs):
+    """Permutation of the vertices under the rotations: trace_idx_ori[r, a] = e with R_r v_a = v_e, trace_idx_rot[r, e] = a."""
+    moved = np.einsum('rij,aj->rai', np.asarray(Rs, np.float64), np.asarray(vs, np.float64))
+    d = ((moved[:, :, None, :] - np.asarray(vs, np.float64)[None, None]) ** 2).sum(-1)
+    return d.argmin(2), d.argmin(1)
+
+
+def label_relative_rotation_simple(anchors, T):
+    """The anchor rotation closest to T (largest trace of T anchor^T): -> (T anchor[label]^T (3, 3), label (0-d int64 tensor))."""
+    rel = torch.einsum('ij,akj->aik', T, anchors)
+    label = rel.diagonal(dim1=-2, dim2=-1).sum(-1).argmax(dim=0)
+    return rel[int(label)], label
