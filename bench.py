@@ -228,7 +228,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=9)
     ap.add_argument('--variant', default='se3ete')
     ap.add_argument('--pair', default='c2_5k')
-    ap.add_argument('--cpu-baseline-pairs', type=int, default=2)
+    ap.add_argument('--cpu-baseline-pairs', type=int, default=5, help='timed pairs of the CPU baseline (after 3 warm-up pairs; median)')
+    ap.add_argument('--cpu-baseline-threads', type=int, default=0, help='torch threads of the CPU baseline (0: min(cores, 16))')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--batch', type=int, default=8, help='registration pairs per forward / step (se3et_amd.batched), 1..16; '
                     '1 = the single-pair forward of the reference API')
@@ -252,6 +253,9 @@ def main():
                     '`single_pair` (rank 0 at --gpus 1 only; 0 = skip)')
     ap.add_argument('--train-steps', type=int, default=5, help='training steps (fwd + bwd + Adam, one pair each) of the `train_step` object '
                     '(rank 0 at --gpus 1 only; 0 = skip)')
+    ap.add_argument('--repeat-regions', type=int, default=2, help='the timed region (the same K steps between the same barrier + synchronize '
+                    'bracket) is run this many MORE times after the headline region; `dispersion` reports all values with their median, min '
+                    'and max (VERDICT round 5 item 6: a 4 %% move must be resolvable against the run-to-run spread).  0: off')
     ap.add_argument('--roofline-quiet-steps', type=int, default=3, help='extra steps after the timed region with one batch in flight and no '
                     'other stream, for `roofline.quiet` (0 = skip)')
     ap.add_argument('--force-dist', action='store_true', help='initialise torch.distributed (RCCL) also with ONE rank: the device barrier and the '
@@ -266,6 +270,10 @@ def main():
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     if args.fake_device:
         return run_fake(args)
+
+    # blocking host waits on THIS rank's device, as the process's first GPU call (se3et_amd/__init__.py: later it is ineffective or harmful)
+    import se3et_amd
+    se3et_amd.request_blocking_sync(int(os.environ.get('LOCAL_RANK', '0')))
 
     from se3et_amd import ops as se3_ops
     from se3et_amd import _lib as se3_lib
@@ -287,6 +295,8 @@ def main():
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    import se3et_amd
+    host_waits = se3et_amd.blocking_sync_status(local)           # requested at the top of main(), before the first GPU call of this process
 
     cfg = make_cfg(args.variant, attention_dtype=args.attention_dtype)
     model = load_synthetic_weights(create_model(cfg)).to(dev).eval()
@@ -304,7 +314,7 @@ def main():
         cores_here = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         cores_here = host_cores
-    args.inflight = inflight_for_cores(cores_here, args.inflight, PB, blocking_waits=__import__('se3et_amd').BLOCKING_SYNC_STATUS == 'set')
+    args.inflight = inflight_for_cores(cores_here, args.inflight, PB, blocking_waits=host_waits == 'set')
     if args.inflight > 1:
         args.prefetch = 0                 # every in-flight thread builds its own pyramid
     if args.prefetch is None:
@@ -471,6 +481,25 @@ def main():
     #  alive until the run is over: DESIGN section 5)
     timings, se3_ops.KERNEL_TIMINGS = se3_ops.KERNEL_TIMINGS, None
 
+    # Dispersion: the SAME K steps between the same bracket, `--repeat-regions` more times (per-launch event timing off: the headline region
+    # above carries it).  `value` stays the first region -- the contract's "exactly K steps" -- and the repeats say how far a single region moves.
+    region_s = [elapsed]
+    se3_lib.lib().se3_debug_kernel_timing(0)
+    for _ in range(max(0, args.repeat_regions)):
+        torch.cuda.synchronize()
+        sharding.barrier(dev)
+        t_r = time.perf_counter()
+        run_all(list(range(args.warmup, total_steps)))
+        torch.cuda.synchronize()
+        sharding.barrier(dev)
+        region_s.append(sharding.max_over_ranks(time.perf_counter() - t_r, dev))
+    rates = [world * args.steps * PB / t for t in region_s]
+    dispersion = {'regions': len(rates), 'steps_per_region': args.steps, 'values': [round(v, 2) for v in rates],
+                  'median': round(sorted(rates)[len(rates) // 2], 2), 'min': round(min(rates), 2), 'max': round(max(rates), 2),
+                  'spread_rel': round((max(rates) - min(rates)) / sorted(rates)[len(rates) // 2], 4),
+                  'note': 'values[0] is `value` (the timed region of the contract, with the per-launch HIP events of the roofline); the others '
+                          'are the same steps again, same bracket, without those events'}
+
     roofline = collect_roofline(se3_lib, timings, args)
     roofline_kpconv = collect_kpconv_roofline(timings)
     roofline_dense = collect_dense_roofline(timings)
@@ -501,15 +530,24 @@ def main():
                             'time slices of the other streams); `quiet` = the same kernels alone on the GPU'
                             % ('%d batches in flight' % args.inflight if args.inflight > 1 else "the next batch's pyramid kernels"))
 
+    # the auxiliary measurements never take the headline line down with them: a failure is reported in their place (and on stderr)
+    def guarded(what, f, *a):
+        try:
+            return f(*a)
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            return {'error': '%s failed: %s' % (what, repr(e)[:300])}
+
     single_pair = None
     if rank == 0 and args.gpus == 1 and args.single_pair_steps > 0:
-        single_pair = run_single_pair(model, cfg, args, dev, feats)
+        single_pair = guarded('single_pair', run_single_pair, model, cfg, args, dev, feats)
     train = None
     if rank == 0 and args.gpus == 1 and args.train_steps > 0 and args.variant == 'se3ete':
-        train = run_train_step(args.variant, args, dev)
+        train = guarded('train_step', run_train_step, args.variant, args, dev)
     cpu_baseline = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(model, cfg, args)
+        cpu_baseline = guarded('cpu_baseline', run_cpu_baseline, model, cfg, args)
     ranks_seen = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
 
     if rank == 0:
@@ -527,11 +565,11 @@ def main():
                        'variant': args.variant, 'pair_preset': args.pair, 'sharding': 'pairs round-robin over ranks, no collective',
                        'pairs_per_forward': PB, 'batches_in_flight_per_gpu': max(1, args.inflight), 'pyramid_prefetch': bool(args.prefetch),
                        'host_cores': host_cores, 'host_cores_per_rank': cores_here,
-                       'host_waits': 'hipDeviceScheduleBlockingSync ' + __import__('se3et_amd').BLOCKING_SYNC_STATUS,
+                       'host_waits': 'hipDeviceScheduleBlockingSync ' + host_waits + ' (device %d)' % local,
                        'chained_sections': sorted(__import__('se3et_amd.batched', fromlist=['x']).CHAINED_SECTIONS),
                        'priority_sections': sorted(__import__('se3et_amd.batched', fromlist=['x']).PRIORITY_SECTIONS),
                        'attention_dtype': args.attention_dtype},
-            'roofline': roofline, 'roofline_kpconv': roofline_kpconv, 'roofline_dense': roofline_dense, 'roofline_step': roofline_step, 'cpu_baseline': cpu_baseline, 'single_pair': single_pair, 'train_step': train,
+            'roofline': roofline, 'roofline_kpconv': roofline_kpconv, 'roofline_dense': roofline_dense, 'roofline_step': roofline_step, 'dispersion': dispersion, 'cpu_baseline': cpu_baseline, 'single_pair': single_pair, 'train_step': train,
         }
         print(json.dumps(line), flush=True)
     if torch.distributed.is_initialized():
@@ -765,7 +803,24 @@ def run_single_pair(model, cfg, args, dev, feats_unused):
         return model(data)
 
     for i in range(WU):
-        one(i)
+        try:
+            one(i)
+        except Exception:
+            if os.environ.get('SE3_DEBUG_SINGLE_PAIR'):           # where does it break: which warm-up pair, with what in the pipeline
+                from se3et_amd.batched import forward_pairs
+                pts, lens = inputs[i]
+                data = precompute_data_stack_mode(pts, lens, b.num_stages, b.init_voxel_size, b.init_radius, cfg.neighbor_limits)
+                data['features'] = ones
+                out = forward_pairs(model, data, with_registration=False)[0]
+                torch.cuda.synchronize()
+                ms = out['matching_scores']
+                print('single pair %d (of %d warm-up) failed: patches %d, matching_scores %s finite %s max %s, knn masks %d / %d, feats_f finite %s, '
+                      'ref_feats_c finite %s, widths %s' % (
+                          i, WU, out['ref_node_corr_indices'].shape[0], tuple(ms.shape), bool(torch.isfinite(ms).all()),
+                          float(ms[:, :-1, :-1].max()) if ms.numel() else None, int(out['ref_node_corr_knn_masks'].sum()),
+                          int(out['src_node_corr_knn_masks'].sum()), bool(torch.isfinite(out['feats_f']).all()),
+                          bool(torch.isfinite(out['ref_feats_c']).all()), [tuple(t.shape) for t in data['neighbors']]), file=sys.stderr, flush=True)
+            raise
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(WU, n_pairs):
@@ -886,15 +941,28 @@ def run_single_pair(model, cfg, args, dev, feats_unused):
                     'interpreter), which more host threads only contend for -- stack pairs (the headline configuration) instead'}
 
 
+def cpu_model_name():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def run_cpu_baseline(model, cfg, args):
-    """The CPU oracle (a restatement of the reference algorithm, kind 'port') on a bounded sample of the same workload."""
+    """The CPU oracle (a restatement of the reference algorithm, kind 'port') on a bounded sample of the same workload: 3 warm-up pairs, then
+    `--cpu-baseline-pairs` (default 5) timed ONE BY ONE, median.  Threads: `--cpu-baseline-threads`, default
+    min(cores, 16) -- profiles/r06_cpu_baseline_threads.txt (tools/r6/cpu_threads.py, this box's host) is the scaling table behind the cap."""
     from oracle import se3et_oracle as O
     from se3et_amd.synthetic import make_pair
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 16))          # the small CPU ops of this path stop scaling (and thrash) beyond ~16 threads
+    cores = max(1, min(avail, args.cpu_baseline_threads or 16))
     torch.set_num_threads(cores)
     state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     b = cfg.backbone
@@ -903,28 +971,29 @@ def run_cpu_baseline(model, cfg, args):
     def one(i):
         ref, src, _ = make_pair(args.pair, index=i)
         pts = torch.from_numpy(np.concatenate([ref, src], 0))
+        t0 = time.perf_counter()
         data = O.precompute(pts, torch.tensor([len(ref), len(src)]), oc.num_stages, oc.init_voxel_size, oc.init_radius,
                             oc.neighbor_limits)
         data['features'] = torch.ones((pts.shape[0], 1))
         with torch.no_grad():
-            return O.forward(state, oc, data)
+            O.forward(state, oc, data)
+        return time.perf_counter() - t0
 
-    t0 = time.perf_counter()
-    one(0)
-    warm = time.perf_counter() - t0
-    n_timed = args.cpu_baseline_pairs if warm < 15.0 else 0      # keep the default run within minutes on slow hosts
-    if n_timed:
-        t0 = time.perf_counter()
-        for i in range(n_timed):
-            one(i + 1)
-        dt = time.perf_counter() - t0
-    else:
-        n_timed, dt = 1, warm
-    args.cpu_baseline_pairs = n_timed
-    return {'value': round(args.cpu_baseline_pairs / dt, 4), 'unit': 'pairs/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d pair(s) of the same workload (oracle/se3et_oracle.py on PyTorch-CPU fp32, '
-                      '%d threads); the genuine reference measured 0.19 pairs/s on 8 cores (BASELINE.md)' %
-                      (args.cpu_baseline_pairs, cores)}
+    first = one(0)
+    slow = first >= 15.0                                         # keep the default run within minutes on slow hosts
+    warm = 1 if slow else 3
+    for i in range(1, warm):
+        one(i)
+    n_timed = 1 if slow else max(1, args.cpu_baseline_pairs)
+    times = sorted(one(warm + i) for i in range(n_timed)) if not slow else [first]
+    med = times[len(times) // 2]
+    return {'value': round(1.0 / med, 4), 'unit': 'pairs/s', 'cores': cores, 'kind': 'port',
+            'cpu_model': cpu_model_name(), 'host_cores': os.cpu_count(),
+            's_per_pair': {'median': round(med, 3), 'min': round(times[0], 3), 'max': round(times[-1], 3)},
+            'warmup_pairs': warm, 'timed_pairs': len(times),
+            'sample': '%d warm-up + %d timed pair(s) of the same workload, timed one by one, median (oracle/se3et_oracle.py on PyTorch-CPU '
+                      'fp32, %d threads on a %d-core %s); the genuine reference measured 0.19 pairs/s on 8 cores (BASELINE.md)' %
+                      (warm, len(times), cores, os.cpu_count() or 0, cpu_model_name())}
 
 
 if __name__ == '__main__':

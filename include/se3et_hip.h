@@ -111,6 +111,40 @@ int se3_radius_neighbors_grid(const float* q_points, int64_t nq, const int64_t* 
 /* (max_count_is_zero != 0: the caller cleared max_count itself -- e.g. one fill for the counters of all searches of a pyramid -- and the
  * call does not clear it again; the search only ever raises the values.) */
 
+/* ---- A2, exact ties: the reference's order of exactly tied distances (round 6; csrc/radius_ties.hip) ----------------------------------
+ * The reference's row is the head of ALL in-radius matches in the order of its k-d tree walk, std::sort-ed (unstable) on the distance alone
+ * (extensions/extra/nanoflann/nanoflann.hpp:857-1002,1286-1287,1348-1407; cpu/radius_neighbors/radius_neighbors_cpu.cpp:29-90): which
+ * member of a group of EXACTLY equal float32 distances comes first -- and which ones a neighbour limit keeps -- depends on that walk.  The
+ * searches above order such groups by index.  Their `_ties` forms additionally append the number of every row whose kept columns hold an
+ * exact tie (among themselves or with the first column cut) to tie_rows (DEVICE int32, room for nq entries) behind the DEVICE counter
+ * tie_count (int32, cleared by the caller; both NULL: the plain search).  For those rows se3_radius_neighbors_tie_order reproduces the
+ * reference: one lane per row walks the reference's tree -- built on the HOST by se3_kdtree_build_host from a host copy of the support
+ * clouds (se3_kdtree_max_bytes: size of the buffer; *used_bytes: what to upload) -- with the reference's float arithmetic, collects the
+ * matches in walk order and sorts them with a restatement of libstdc++'s std::sort.  max_hits >= the search's largest max_count;
+ * scratch: DEVICE, se3_radius_tie_scratch_bytes(num_tie_rows, max_hits).  Clouds without ties never pay for any of this. */
+int se3_radius_neighbors_ties(const float* q_points, int64_t nq, const float* s_points, int64_t ns, const int64_t* q_lengths_host,
+                              const int64_t* s_lengths_host, int batch, float radius, int limit, int64_t* neighbors, int32_t* max_count,
+                              int32_t* tie_rows, int32_t* tie_count, void* stream);
+int se3_radius_neighbors_grid_ties(const float* q_points, int64_t nq, const int64_t* q_lengths_host, const int64_t* s_lengths_host,
+                                   int64_t ns, int batch, const void* grid_workspace, float radius, int limit, int64_t* neighbors,
+                                   int32_t* max_count, int max_count_is_zero, int32_t* tie_rows, int32_t* tie_count, void* stream);
+size_t se3_kdtree_max_bytes(int64_t ns, int batch);
+int se3_kdtree_build_host(const float* s_points_host, int64_t ns, const int64_t* s_lengths_host, int batch, void* tree_host, size_t capacity,
+                          size_t* used_bytes);
+size_t se3_radius_tie_scratch_bytes(int64_t num_tie_rows, int max_hits);
+int se3_radius_neighbors_tie_order(const float* q_points, int64_t nq, const float* s_points, int64_t ns, const int64_t* q_lengths_host,
+                                   const int64_t* s_lengths_host, int batch, const void* tree_dev, float radius, int limit,
+                                   const int32_t* tie_rows, int64_t num_tie_rows, int max_hits, void* scratch, size_t scratch_bytes,
+                                   int64_t* neighbors, void* stream);
+/* The code of se3_radius_neighbors_tie_order's kernel run on HOST memory (all pointers host, tree_host as built): lets the walk and the
+ * std::sort restatement be checked where there is no GPU.  *overflowed: rows that did not fit max_hits (left untouched). */
+int se3_debug_radius_tie_order_host(const float* q_points, int64_t nq, const float* s_points, int64_t ns, const int64_t* q_lengths,
+                                    const int64_t* s_lengths, int batch, const void* tree_host, float radius, int limit,
+                                    const int32_t* tie_rows, int64_t num_tie_rows, int max_hits, int64_t* neighbors, int* overflowed);
+/* The std::sort restatement of that kernel against libstdc++ on the host: mode 0 the whole sort against std::sort, mode 1 its heap sort against
+ * std::partial_sort(first, last, last); keys compare on their high 32 bits alone.  Returns the number of differing positions (0: identical). */
+int64_t se3_debug_std_sort_host(const unsigned long long* keys, int64_t n, int mode);
+
 /* ---- A1: stack-mode grid subsampling ----------------------------------------------------------------------
  * Replaces geotransformer.ext.grid_subsampling (pybind.cpp:13-17, cpu/grid_subsampling/grid_subsampling.cpp:5-83,
  * grid_subsampling_cpu.cpp:3-109, grid_subsampling_cpu.h:24-74).  Per batch element: voxel hash, per voxel the

@@ -30,6 +30,14 @@ SIGNATURES = {
     'se3_radius_grid_workspace_bytes': (_sz, [_i64, _i32]),
     'se3_radius_grid_build': (_i32, [_vp, _i64, _vp, _i32, _f32, _vp, _sz, _vp]),
     'se3_radius_neighbors_grid': (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _vp, _f32, _i32, _vp, _vp, _i32, _vp]),
+    'se3_radius_neighbors_ties': (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'se3_radius_neighbors_grid_ties': (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _vp, _f32, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
+    'se3_kdtree_max_bytes': (_sz, [_i64, _i32]),
+    'se3_kdtree_build_host': (_i32, [_vp, _i64, _vp, _i32, _vp, _sz, _vp]),
+    'se3_radius_tie_scratch_bytes': (_sz, [_i64, _i32]),
+    'se3_radius_neighbors_tie_order': (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp, _f32, _i32, _vp, _i64, _i32, _vp, _sz, _vp, _vp]),
+    'se3_debug_std_sort_host': (_i64, [_vp, _i64, _i32]),
+    'se3_debug_radius_tie_order_host': (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp, _f32, _i32, _vp, _i64, _i32, _vp, _vp]),
     'se3_grid_subsample_workspace_bytes': (_sz, [_i64, _i32]),
     'se3_grid_subsample': (_i32, [_vp, _vp, _i64, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
     'se3_grid_subsample_dev': (_i32, [_vp, _vp, _i64, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -1173,16 +1173,19 @@ __device__ __forceinline__ void h2_split8(const float (&x)[8], uint4& hi, uint4&
 // The operand splits of the f16 attention kernels carry their own powers of two (round 5: the last part of the f16-window item, DESIGN
 // section 4 "Range of the f16 split"): a query row of one head, a block of 8 key rows of one head and a value channel of one cloud are each
 // brought to [2^6, 2^7) before the split -- exact, and the kernels take the scales out of the f32 logits (per lane: the query; per register
-// group of the S^T tile: the key block) and of the output (per channel).  Nothing finite leaves the f16 range any more; a NaN / Inf still
-// must not become Inf in every key's score: it is clamped and the launch counts it (se3_debug_attention_saturated).
+// group of the S^T tile: the key block) and of the output (per channel).  Nothing finite leaves the f16 range any more; a NaN / Inf in an
+// operand becomes NaN pieces (the output rows it reaches are NaN, as with the reference's matmul + softmax) and the launch counts it
+// (se3_debug_attention_saturated).
 __device__ unsigned long long g_attn_saturated = 0;
 __device__ __forceinline__ bool h2_split8_sat(const float (&x)[8], uint4& hi, uint4& lo) {
   float c[8];
   bool sat = false;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    c[i] = fminf(fmaxf(x[i], -65000.f), 65000.f);              // (NaN -> -65000)
+    const bool nonfinite = (__float_as_uint(x[i]) & 0x7f800000u) == 0x7f800000u;
+    c[i] = fminf(fmaxf(x[i], -65000.f), 65000.f);              // finite overflow: clamped and counted
     sat |= !(c[i] == x[i]);
+    c[i] = nonfinite ? __builtin_bit_cast(float, 0x7fc00000) : c[i];      // NaN / Inf: NaN pieces -> NaN scores -> NaN rows, as the reference's matmul
   }
   h2_split8(c, hi, lo);
   return sat;

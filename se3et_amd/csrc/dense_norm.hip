@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256, MODE == 3 ? 2 : 3) void dense_norm_kernel(cons
   // f16); outside, the row is multiplied by the power of two that puts that magnitude into [2^6, 2^7) (exact), and the epilogue takes the
   // scale out of the accumulators with v_ldexp.  A row whose first 32 values are all zero stays unscaled.  The scale of a row is fixed
   // for the tile: a later value that exceeds the row's headroom (more than 2^8 times its first 32 values -- or NaN / Inf) is clamped to
-  // the f16 range and COUNTED (se3_debug_dense_saturated_rows): loud instead of Inf.  A row's scale is a function of that row's values
+  // the f16 range and COUNTED (se3_debug_dense_saturated_rows): loud instead of Inf; a NaN / Inf input value makes its row's outputs NaN
+  // (both pieces NaN), as the reference's matmul would.  A row's scale is a function of that row's values
   // only: rows -- the padding rows of a packed batch included -- do not influence each other.
   __shared__ __align__(16) int row_exp[2][TR];                           // per image: exponent - 141 of a scaled row, valid for the tile ending in step ...
   __shared__ __align__(16) int row_exp_step[2][TR];                      // ... row_exp_step (any other tile: 0)
@@ -274,7 +275,8 @@ __global__ __launch_bounds__(256, MODE == 3 ? 2 : 3) void dense_norm_kernel(cons
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         float te = __builtin_ldexpf(t[e], 141 - e_row);
-        te = fminf(fmaxf(te, -65000.f), 65000.f);                        // (saturation: finite, and counted below; NaN becomes -65000)
+        te = fminf(fmaxf(te, -65000.f), 65000.f);                        // (finite overflow of the row's headroom: clamped, and counted below)
+        te = (__float_as_uint(t[e]) & 0x7f800000u) == 0x7f800000u ? __builtin_bit_cast(float, 0x7fc00000) : te;   // NaN / Inf: the row's outputs are NaN
         hi[e] = (_Float16)te;
         lo[e] = (_Float16)(te - (float)hi[e]);
       }
@@ -417,15 +419,25 @@ __global__ __launch_bounds__(256, MODE == 3 ? 2 : 3) void dense_norm_kernel(cons
     // the row scales out again: acc 2^(E - 141), exact (v_ldexp: gradual underflow instead of a flushed factor); tiles without a scaled
     // row -- all of them, for activations of ordinary magnitude -- skip this on one flag
     if (__builtin_expect(row_scl[buf] == p.tile * nkt + p.kk, 0)) {
+      // (round 6: the exponents of a lane's four consecutive rows as ONE 16-byte read each of the step tags and of the exponents, selected in
+      //  registers.  The round-4 form -- a conditional 4-byte read per accumulator row between scheduling barriers, spilled through scratch --
+      //  scaled accumulator row 1 of a tile by a stale word whenever ANOTHER row of the tile carried a scale: one row in ~10^5 of the
+      //  backbone came out as Inf, which the f16 split of the next layer clamped to 65000 unnoticed until non-finite values were allowed
+      //  to propagate; tests/test_gpu_ops.py::test_a_scaled_row_leaves_the_other_rows_of_its_tile_alone.)
+      const int step_id = p.tile * nkt + p.kk;
 #pragma unroll
       for (int r = 0; r < RT; r++)
 #pragma unroll
-        for (int v = 0; v < 16; v++) {
-          const int row = (wm * RT + r) * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-          const int ev = row_exp_step[buf][row] == p.tile * nkt + p.kk ? row_exp[buf][row] : 0;
+        for (int g = 0; g < 4; g++) {
+          const int base = (wm * RT + r) * 32 + 8 * g + 4 * h;              // rows base .. base + 3 = accumulator registers 4 g .. 4 g + 3
+          const i32x4 tag = *reinterpret_cast<const i32x4*>(&row_exp_step[buf][base]);
+          const i32x4 ex = *reinterpret_cast<const i32x4*>(&row_exp[buf][base]);
 #pragma unroll
-          for (int c = 0; c < CT; c++) acc[r][c][v] = __builtin_ldexpf(acc[r][c][v], ev);
-          __builtin_amdgcn_sched_barrier(0);
+          for (int j = 0; j < 4; j++) {
+            const int ev = tag[j] == step_id ? ex[j] : 0;
+#pragma unroll
+            for (int c = 0; c < CT; c++) acc[r][c][4 * g + j] = __builtin_ldexpf(acc[r][c][4 * g + j], ev);
+          }
         }
     }
     if constexpr (MODE == 4) {

@@ -292,8 +292,13 @@ extern "C" int se3_kpconv_so3_gather_bwd(const float* q_pts, const float* s_pts,
 namespace {
 __global__ void fixed_to_float_kernel(const long long* __restrict__ f, int64_t n, const float* __restrict__ bound, int64_t P, int growth,
                                       float* __restrict__ out) {
-  const double inv = ldexp(1.0, -se3_fixed_scale_exp(bound, P, growth));
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (float)((double)f[i] * inv);
+  // a NaN / Inf bound = a NaN / Inf among the contributions (the bound is their largest magnitude, or a product of such): the sums mean
+  // nothing -- the result is NaN everywhere, as loud as the float scatter it replaces
+  const bool finite = ((__float_as_uint(*bound) >> 23) & 0xff) != 0xff;
+  const double inv = finite ? ldexp(1.0, -se3_fixed_scale_exp(bound, P, growth)) : 0.0;
+  const float nan = __builtin_bit_cast(float, 0x7fc00000);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = finite ? (float)((double)f[i] * inv) : nan;
 }
 }  // namespace
 

@@ -77,7 +77,8 @@ __device__ __forceinline__ float x_split_scale(const float* amax) {
   const unsigned b = *reinterpret_cast<const unsigned*>(amax);
   const int e = (int)((b >> 23) & 0xff);
   if (e == 0 || e == 0xff || (e >= 123 && e <= 133)) return 1.f;
-  return __builtin_bit_cast(float, (unsigned)(127 + 133 - e) << 23);
+  const int k = 133 - e > 126 ? 126 : 133 - e;                           // (a largest magnitude below 2^-120: 2^126, the scale stays a normal float)
+  return __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
 }
 
 // 16-byte run of (orbit, anchor) inside a point's row: anchor-major, so that the 16 orbits a producer wave holds for one anchor are contiguous

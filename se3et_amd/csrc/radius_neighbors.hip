@@ -71,9 +71,23 @@ __device__ __forceinline__ unsigned long long wave_merge_lower(unsigned long lon
   return v;
 }
 
+// Rows whose result depends on the ORDER of exactly tied distances (the reference leaves it to its k-d tree walk + an unstable sort,
+// csrc/radius_ties.hip): two neighbouring entries of the sorted list with the same d2, the first of them inside the kept `limit` columns --
+// a tie among the kept entries, or between the last kept one and the first one cut.  `best`: the wave's sorted (d2, index) list, one entry per
+// lane; `count`: in-radius points of the query.  With limit = 64 the entry behind the cut is not in the list: a row with more than 64
+// matches is flagged.  The row number is appended to tie_rows behind the device counter tie_count (order of arrival: rows are independent).
+__device__ __forceinline__ void flag_tie_row(unsigned long long best, int count, int limit, int64_t row, int32_t* __restrict__ tie_rows,
+                                             int32_t* __restrict__ tie_count) {
+  const int lane = threadIdx.x & 63;
+  const unsigned d_here = (unsigned)(best >> 32), d_next = (unsigned)__shfl_down((int)d_here, 1);
+  const int kept = count < 64 ? count : 64;
+  const bool tie = (lane + 1 < kept && lane < limit && d_here == d_next) || (limit == 64 && count > 64);
+  if (__ballot(tie) != 0ull && lane == 0) tie_rows[atomicAdd(tie_count, 1)] = (int32_t)row;
+}
+
 __global__ __launch_bounds__(kWaves* SE3_WAVE) void radius_search_kernel(
     const float* __restrict__ q, const float* __restrict__ s, BatchTable bt, int64_t ns_total, float r2, int limit,
-    int64_t* __restrict__ out, int32_t* __restrict__ max_count) {
+    int64_t* __restrict__ out, int32_t* __restrict__ max_count, int32_t* __restrict__ tie_rows, int32_t* __restrict__ tie_count) {
   __shared__ float sx[kTile], sy[kTile], sz[kTile];
   const int b = blockIdx.y;
   const int64_t qn = bt.q_count[b], sn = bt.s_count[b];
@@ -147,14 +161,17 @@ __global__ __launch_bounds__(kWaves* SE3_WAVE) void radius_search_kernel(
     // same-line atomics serialise in the L2 (~7 ns each: 80 000 queries = 0.5 ms); the running maximum is monotonic, so a plain
     // (possibly stale) read filters almost all of them
     if (lane == 0 && count[j] > __atomic_load_n(max_count + b, __ATOMIC_RELAXED)) atomicMax(max_count + b, count[j]);
+    if (tie_rows != nullptr) flag_tie_row(best[j], count[j], limit, q0 + qi, tie_rows, tie_count);
   }
 }
 
 }  // namespace
 
-extern "C" int se3_radius_neighbors(const float* q_points, int64_t nq, const float* s_points, int64_t ns,
-                                    const int64_t* q_lengths_host, const int64_t* s_lengths_host, int batch,
-                                    float radius, int limit, int64_t* neighbors, int32_t* max_count, void* stream) {
+extern "C" int se3_radius_neighbors_ties(const float* q_points, int64_t nq, const float* s_points, int64_t ns,
+                                         const int64_t* q_lengths_host, const int64_t* s_lengths_host, int batch,
+                                         float radius, int limit, int64_t* neighbors, int32_t* max_count, int32_t* tie_rows,
+                                         int32_t* tie_count, void* stream) {
+  SE3_REQUIRE((tie_rows == nullptr) == (tie_count == nullptr), SE3_ERR_INVALID_ARG, "radius_neighbors: tie_rows and tie_count go together");
   SE3_REQUIRE(batch >= 1 && batch <= SE3_MAX_BATCH, SE3_ERR_INVALID_ARG, "radius_neighbors: batch %d not in [1,%d]",
               batch, SE3_MAX_BATCH);
   SE3_REQUIRE(limit >= 1 && limit <= SE3_MAX_NEIGHBOR_LIMIT, SE3_ERR_UNSUPPORTED,
@@ -181,9 +198,16 @@ extern "C" int se3_radius_neighbors(const float* q_points, int64_t nq, const flo
   if (nq == 0) return SE3_OK;
   dim3 grid((unsigned)se3_cdiv(qmax, kQPB), (unsigned)batch);
   radius_search_kernel<<<grid, kWaves * SE3_WAVE, 0, st>>>(q_points, s_points, bt, ns, radius * radius, limit, neighbors,
-                                                         max_count);
+                                                         max_count, tie_rows, tie_count);
   SE3_CHECK_LAUNCH("radius_neighbors");
   return SE3_OK;
+}
+
+extern "C" int se3_radius_neighbors(const float* q_points, int64_t nq, const float* s_points, int64_t ns,
+                                    const int64_t* q_lengths_host, const int64_t* s_lengths_host, int batch,
+                                    float radius, int limit, int64_t* neighbors, int32_t* max_count, void* stream) {
+  return se3_radius_neighbors_ties(q_points, nq, s_points, ns, q_lengths_host, s_lengths_host, batch, radius, limit, neighbors, max_count,
+                                   nullptr, nullptr, stream);
 }
 
 // =====================================================================================================================
@@ -333,7 +357,8 @@ __global__ void grid_scatter_kernel(const float* __restrict__ s, BatchTable bt, 
 // one wavefront per query; the nine (y, z) rows of the 3x3x3 cell block are contiguous runs of `sorted`
 __global__ __launch_bounds__(256) void radius_grid_search_kernel(const float* __restrict__ q, BatchTable bt, GridLayout G,
                                                                  int64_t ns_total, float r2, int limit,
-                                                                 int64_t* __restrict__ out, int32_t* __restrict__ max_count) {
+                                                                 int64_t* __restrict__ out, int32_t* __restrict__ max_count,
+                                                                 int32_t* __restrict__ tie_rows, int32_t* __restrict__ tie_count) {
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -409,6 +434,7 @@ __global__ __launch_bounds__(256) void radius_grid_search_kernel(const float* __
   // same-line atomics serialise in the L2 (~7 ns each: 80 000 queries = 0.5 ms); the running maximum is monotonic, so a plain
   // (possibly stale) read filters almost all of them
   if (lane == 0 && count > __atomic_load_n(max_count + b, __ATOMIC_RELAXED)) atomicMax(max_count + b, count);
+  if (tie_rows != nullptr) flag_tie_row(best, count, limit, gq, tie_rows, tie_count);
 }
 
 int fill_batch_table(BatchTable* bt, const int64_t* q_len, const int64_t* s_len, int batch, int64_t nq, int64_t ns,
@@ -467,10 +493,11 @@ extern "C" int se3_radius_grid_build(const float* s_points, int64_t ns, const in
   return SE3_OK;
 }
 
-extern "C" int se3_radius_neighbors_grid(const float* q_points, int64_t nq, const int64_t* q_lengths_host,
-                                         const int64_t* s_lengths_host, int64_t ns, int batch, const void* grid_workspace,
-                                         float radius, int limit, int64_t* neighbors, int32_t* max_count, int max_count_is_zero,
-                                         void* stream) {
+extern "C" int se3_radius_neighbors_grid_ties(const float* q_points, int64_t nq, const int64_t* q_lengths_host,
+                                              const int64_t* s_lengths_host, int64_t ns, int batch, const void* grid_workspace,
+                                              float radius, int limit, int64_t* neighbors, int32_t* max_count, int max_count_is_zero,
+                                              int32_t* tie_rows, int32_t* tie_count, void* stream) {
+  SE3_REQUIRE((tie_rows == nullptr) == (tie_count == nullptr), SE3_ERR_INVALID_ARG, "radius_neighbors_grid: tie_rows and tie_count go together");
   SE3_REQUIRE(q_points && q_lengths_host && s_lengths_host && grid_workspace && neighbors && max_count, SE3_ERR_INVALID_ARG,
               "radius_neighbors_grid: null pointer");
   SE3_REQUIRE(batch >= 1 && batch <= SE3_MAX_BATCH, SE3_ERR_INVALID_ARG, "radius_neighbors_grid: batch");
@@ -488,9 +515,17 @@ extern "C" int se3_radius_neighbors_grid(const float* q_points, int64_t nq, cons
   }
   if (nq == 0) return SE3_OK;
   dim3 grid((unsigned)se3_cdiv(qmax, 4), (unsigned)batch);
-  radius_grid_search_kernel<<<grid, 256, 0, st>>>(q_points, bt, G, ns, radius * radius, limit, neighbors, max_count);
+  radius_grid_search_kernel<<<grid, 256, 0, st>>>(q_points, bt, G, ns, radius * radius, limit, neighbors, max_count, tie_rows, tie_count);
   SE3_CHECK_LAUNCH("radius_neighbors_grid");
   return SE3_OK;
+}
+
+extern "C" int se3_radius_neighbors_grid(const float* q_points, int64_t nq, const int64_t* q_lengths_host,
+                                         const int64_t* s_lengths_host, int64_t ns, int batch, const void* grid_workspace,
+                                         float radius, int limit, int64_t* neighbors, int32_t* max_count, int max_count_is_zero,
+                                         void* stream) {
+  return se3_radius_neighbors_grid_ties(q_points, nq, q_lengths_host, s_lengths_host, ns, batch, grid_workspace, radius, limit, neighbors,
+                                        max_count, max_count_is_zero, nullptr, nullptr, stream);
 }
 
 // ---- stacked pairs: the neighbour table cut to the width a batch needs, columns past a PAIR's own width marked -1 ----------------------

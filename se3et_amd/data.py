@@ -2,7 +2,9 @@
 
 The reference runs grid subsampling and the 3S-2 radius searches on the CPU inside DataLoader workers; here the
 whole pyramid is built on the GPU in the main process right after the raw pair was uploaded, with two host
-synchronisations (the counts of all subsampling stages, the widths of all neighbour tables).  List structure,
+synchronisations (the counts of all subsampling stages; the widths of all neighbour tables + the number of rows with exact distance
+ties).  Clouds that hold exact ties (real scans) take one more per support stage: a host copy of the stage's points, from which the
+reference's k-d tree is built for the device pass that gives those rows the reference's order (csrc/radius_ties.hip).  List structure,
 voxel/radius doubling, the 2000-point cap of the coarsest stage and the column truncation are reproduced exactly
 (pinned by tests/golden/precompute_c1.npz)."""
 import torch
@@ -63,22 +65,53 @@ def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, 
                           if s_pts.shape[0] >= _ops.GRID_SEARCH_MIN_SUPPORT else None)
         return grids[key]
 
-    counters = torch.zeros((3 * num_stages - 2, len(lengths_list[0])), dtype=torch.int32, device=points.device)   # one fill for all searches
+    n_jobs, n_clouds = 3 * num_stages - 2, len(lengths_list[0])
+    # one fill for the counters of all searches: per job the largest in-radius count of every cloud, then per job the number of rows whose
+    # kept columns hold an EXACT distance tie (the reference orders those by its k-d tree walk: csrc/radius_ties.hip)
+    words = torch.zeros((n_jobs * n_clouds + n_jobs,), dtype=torch.int32, device=points.device)
+    counters, tie_counts = words[:n_jobs * n_clouds].view(n_jobs, n_clouds), words[n_jobs * n_clouds:]
+    want_ties = _ops.RADIUS_REFERENCE_TIES
+    q_rows = [points_list[i].shape[0] for i in range(num_stages)]
+    tie_rows = torch.empty((sum(q_rows) + sum(q_rows[1:]) + sum(q_rows[:-1]),), dtype=torch.int32, device=points.device) if want_ties else None
+    tie_at = [0]
+
+    def ties_for(nq):             # this job's slice of the row list + its counter word
+        if not want_ties:
+            return None
+        j, o = len(jobs), tie_at[0]
+        tie_at[0] += nq
+        return tie_rows[o:o + nq], tie_counts[j:j + 1]
+
+    searches = []                 # per job: (queries, support, q_lengths, s_lengths, radius, support stage, ties)
     for i in range(num_stages):
         cur, cl = points_list[i], lengths_list[i]
+        t = ties_for(cur.shape[0])
+        searches.append((cur, cur, cl, cl, radius, i, t))
         jobs.append(('neighbors', _ops.radius_neighbors(cur, cur, cl, cl, radius, neighbor_limits[i], grid=grid_for(i, radius),
-                                                        zeroed_max_count=counters[len(jobs)])))
+                                                        zeroed_max_count=counters[len(jobs)], ties=t)))
         if i < num_stages - 1:
             sub, sl = points_list[i + 1], lengths_list[i + 1]
+            t = ties_for(sub.shape[0])
+            searches.append((sub, cur, sl, cl, radius, i, t))
             jobs.append(('subsampling', _ops.radius_neighbors(sub, cur, sl, cl, radius, neighbor_limits[i],
-                                                              grid=grid_for(i, radius), zeroed_max_count=counters[len(jobs)])))
+                                                              grid=grid_for(i, radius), zeroed_max_count=counters[len(jobs)], ties=t)))
+            t = ties_for(cur.shape[0])
+            searches.append((cur, sub, cl, sl, radius * 2, i + 1, t))
             jobs.append(('upsampling', _ops.radius_neighbors(cur, sub, cl, sl, radius * 2, neighbor_limits[i + 1],
-                                                             grid=grid_for(i + 1, radius * 2), zeroed_max_count=counters[len(jobs)])))
+                                                             grid=grid_for(i + 1, radius * 2), zeroed_max_count=counters[len(jobs)], ties=t)))
         radius *= 2
     for j, (_, (_, mc)) in enumerate(jobs):       # (a search on a small support takes the exhaustive kernel, which fills a counter of its own)
         if mc.data_ptr() != counters[j].data_ptr():
             counters[j].copy_(mc)
-    counts = counters.cpu()                                                       # (jobs, clouds): the ONE synchronisation of the searches
+    words_host = words.cpu()                                                      # the ONE synchronisation of the searches
+    counts = words_host[:n_jobs * n_clouds].view(n_jobs, n_clouds)                # (jobs, clouds)
+    # rows with exact ties (none on jittered synthetic clouds, most rows of a real scan): the reference's order, support stage by support stage
+    trees = {}
+    for j, (q_pts, s_pts, q_len, s_len, r, s_stage, t) in enumerate(searches):
+        n_tie = int(words_host[n_jobs * n_clouds + j])
+        if n_tie > 0:
+            trees[s_stage] = _ops.radius_tie_order(jobs[j][1][0], q_pts, s_pts, q_len, s_len, r, t[0], n_tie, max(int(counts[j].max()), 1),
+                                                   tree=trees.get(s_stage))
     num_pairs = counts.shape[1] // 2
     pair_counts = counts.view(counts.shape[0], num_pairs, 2).amax(2).tolist() if counts.shape[1] % 2 == 0 else None
     out = {'points': points_list, 'lengths': lengths_list, 'neighbors': [], 'subsampling': [], 'upsampling': []}

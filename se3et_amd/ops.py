@@ -288,8 +288,9 @@ class RadiusGrid:
         check(lib().se3_radius_grid_build(self.s_points.data_ptr(), self.ns, self.lengths, self.batch, self.radius,
                                           self.ws.data_ptr(), nbytes, _stream()), 'se3_radius_grid_build')
 
-    def search(self, q_points, q_lengths, limit, zeroed_max_count=None):
-        """zeroed_max_count: a (batch,) int32 device tensor the caller has already cleared (one fill for all searches of a pyramid)."""
+    def search(self, q_points, q_lengths, limit, zeroed_max_count=None, ties=None):
+        """zeroed_max_count: a (batch,) int32 device tensor the caller has already cleared (one fill for all searches of a pyramid).
+        ties: None, or (tie_rows (>= Nq,) int32, tie_count (1,) int32 cleared by the caller) -- see radius_neighbors."""
         _req(q_points, torch.float32, 'q_points', 2)
         ql, nb = _host_lengths(q_lengths, 'q_lengths')
         if nb != self.batch:
@@ -302,17 +303,30 @@ class RadiusGrid:
                 raise RuntimeError('radius search: zeroed_max_count must be a contiguous (batch,) int32 tensor')
         else:
             max_count = torch.empty((nb,), dtype=torch.int32, device=q_points.device)
-        check(lib().se3_radius_neighbors_grid(q_points.data_ptr(), nq, ql, self.lengths, self.ns, self.batch, self.ws.data_ptr(),
-                                              self.radius, int(limit), out.data_ptr(), max_count.data_ptr(),
-                                              1 if zeroed_max_count is not None else 0, _stream()),
+        tr, tc = _tie_buffers(ties, nq)
+        check(lib().se3_radius_neighbors_grid_ties(q_points.data_ptr(), nq, ql, self.lengths, self.ns, self.batch, self.ws.data_ptr(),
+                                                   self.radius, int(limit), out.data_ptr(), max_count.data_ptr(),
+                                                   1 if zeroed_max_count is not None else 0, tr, tc, _stream()),
               'se3_radius_neighbors_grid')
         return out, max_count
 
 
-def radius_neighbors(q_points, s_points, q_lengths, s_lengths, radius, limit, grid=None, zeroed_max_count=None):
+def _tie_buffers(ties, nq):
+    if ties is None:
+        return None, None
+    rows, count = ties
+    _req(rows, torch.int32, 'tie_rows', 1), _req(count, torch.int32, 'tie_count', 1)
+    if rows.shape[0] < nq or count.shape[0] != 1:
+        raise RuntimeError('radius search: tie_rows needs room for every query row, tie_count is ONE int32 word')
+    return rows.data_ptr(), count.data_ptr()
+
+
+def radius_neighbors(q_points, s_points, q_lengths, s_lengths, radius, limit, grid=None, zeroed_max_count=None, ties=None):
     """Returns (neighbors (Nq, limit) int64 padded with Ns, max_count (batch,) int32 device tensor: per cloud the largest
     in-radius count).  Large supports go through
-    a uniform grid (pass a prebuilt RadiusGrid to share it between searches); results are identical either way."""
+    a uniform grid (pass a prebuilt RadiusGrid to share it between searches); results are identical either way.
+    Exactly tied distances come in index order; `ties` = (tie_rows (>= Nq,) int32, tie_count (1,) int32, CLEARED by the caller) makes the
+    search list the rows whose kept columns hold such a tie (radius_tie_order then gives them the reference's order)."""
     _req(q_points, torch.float32, 'q_points', 2)
     _req(s_points, torch.float32, 's_points', 2)
     if grid is None and s_points.shape[0] >= GRID_SEARCH_MIN_SUPPORT:
@@ -320,7 +334,7 @@ def radius_neighbors(q_points, s_points, q_lengths, s_lengths, radius, limit, gr
     if grid is not None:
         if grid.s_points.data_ptr() != s_points.data_ptr() or grid.radius != float(radius):
             raise RuntimeError('radius_neighbors: the grid was built for another support cloud / radius')
-        return grid.search(q_points, q_lengths, limit, zeroed_max_count)
+        return grid.search(q_points, q_lengths, limit, zeroed_max_count, ties)
     ql, nb = _host_lengths(q_lengths, 'q_lengths')
     sl, nb2 = _host_lengths(s_lengths, 's_lengths')
     if nb != nb2:
@@ -328,10 +342,67 @@ def radius_neighbors(q_points, s_points, q_lengths, s_lengths, radius, limit, gr
     nq, ns = q_points.shape[0], s_points.shape[0]
     out = torch.empty((nq, limit), dtype=torch.int64, device=q_points.device)
     max_count = torch.empty((nb,), dtype=torch.int32, device=q_points.device)
-    check(lib().se3_radius_neighbors(q_points.data_ptr(), nq, s_points.data_ptr(), ns, ql, sl, nb, float(radius),
-                                     int(limit), out.data_ptr(), max_count.data_ptr(), _stream()),
+    tr, tc = _tie_buffers(ties, nq)
+    check(lib().se3_radius_neighbors_ties(q_points.data_ptr(), nq, s_points.data_ptr(), ns, ql, sl, nb, float(radius),
+                                          int(limit), out.data_ptr(), max_count.data_ptr(), tr, tc, _stream()),
           'se3_radius_neighbors')
     return out, max_count
+
+
+# The reference's order of exactly tied distances (csrc/radius_ties.hip).  On by default: clouds without exact ties
+# (every jittered synthetic configuration) pay one ballot per row in the search kernels and nothing else.
+RADIUS_REFERENCE_TIES = True
+
+
+class ReferenceTree:
+    """The reference's k-d tree (nanoflann, leaf size 10) of the support clouds, built on the HOST from a host copy of the points
+    (se3_kdtree_build_host: structural preprocessing, 12 + ~6 bytes per point) and uploaded; walked on the GPU by radius_tie_order."""
+
+    def __init__(self, s_points, s_lengths):
+        self.s_points = _req(s_points, torch.float32, 's_points', 2)
+        self.lengths, self.batch = _host_lengths(s_lengths, 's_lengths')
+        self.ns = s_points.shape[0]
+        host_pts = s_points.cpu()                                              # (a synchronisation: only ever reached when rows were flagged)
+        cap = lib().se3_kdtree_max_bytes(self.ns, self.batch)
+        host = torch.empty((cap,), dtype=torch.uint8).pin_memory()
+        used = ctypes.c_size_t(0)
+        check(lib().se3_kdtree_build_host(host_pts.data_ptr(), self.ns, self.lengths, self.batch, host.data_ptr(), cap, ctypes.byref(used)),
+              'se3_kdtree_build_host')
+        self.tree = host[:int(used.value)].to(s_points.device, non_blocking=True)
+        self._host = host                                                      # (kept until the copy has been consumed)
+
+
+def radius_tie_order(neighbors, q_points, s_points, q_lengths, s_lengths, radius, tie_rows, num_tie_rows, max_hits, tree=None):
+    """Rewrites the `num_tie_rows` rows listed in tie_rows (device int32; what a search with `ties` flagged) of the (Nq, limit) table
+    `neighbors` IN PLACE with the reference's order / choice of exactly tied distances.  max_hits: the search's largest in-radius count
+    (host int).  tree: a ReferenceTree of the same support clouds (built when omitted).  Returns the tree."""
+    if num_tie_rows <= 0:
+        return tree
+    _req(neighbors, torch.int64, 'neighbors', 2)
+    tree = tree if tree is not None else ReferenceTree(s_points, s_lengths)
+    if tree.s_points.data_ptr() != s_points.data_ptr():
+        raise RuntimeError('radius_tie_order: the tree was built for another support cloud')
+    ql, nb = _host_lengths(q_lengths, 'q_lengths')
+    nbytes = lib().se3_radius_tie_scratch_bytes(int(num_tie_rows), int(max_hits))
+    scratch = torch.empty((nbytes,), dtype=torch.uint8, device=q_points.device)
+    check(lib().se3_radius_neighbors_tie_order(q_points.data_ptr(), q_points.shape[0], s_points.data_ptr(), s_points.shape[0], ql, tree.lengths,
+                                               nb, tree.tree.data_ptr(), float(radius), neighbors.shape[1], tie_rows.data_ptr(),
+                                               int(num_tie_rows), int(max_hits), scratch.data_ptr(), nbytes, neighbors.data_ptr(), _stream()),
+          'se3_radius_neighbors_tie_order')
+    return tree
+
+
+def radius_search_reference_order(q_points, s_points, q_lengths, s_lengths, radius, limit):
+    """One search with the reference's tie order: (neighbors (Nq, limit), largest in-radius count (host int)).  Two synchronisations when
+    rows were flagged (the counts; the host copy of the support points for the tree), one otherwise."""
+    nq = q_points.shape[0]
+    flags = torch.zeros((nq + 1,), dtype=torch.int32, device=q_points.device) if RADIUS_REFERENCE_TIES else None
+    ties = (flags[1:], flags[:1]) if flags is not None else None
+    full, max_count = radius_neighbors(q_points, s_points, q_lengths, s_lengths, radius, limit, ties=ties)
+    host = torch.cat((max_count.max().reshape(1), flags[:1])).tolist() if flags is not None else [int(max_count.max()), 0]
+    if host[1] > 0:
+        radius_tie_order(full, q_points, s_points, q_lengths, s_lengths, radius, flags[1:], host[1], max(host[0], 1))
+    return full, host[0]
 
 
 def grid_subsample(points, lengths, normals, voxel_size):
@@ -529,7 +600,7 @@ def neighbor_max_pool_bwd(x, idx, grad_out):
     n = x.shape[0]
     width = x.numel() // max(n, 1)
     if TRAINING_DETERMINISTIC:
-        bound = g.abs().max().reshape(1)
+        bound = g.abs().max().reshape(1) if g.numel() else g.new_zeros(1)
         fixed = torch.zeros(x.shape, dtype=torch.int64, device=x.device)
         dx = torch.empty_like(x)
         check(lib().se3_neighbor_max_pool_bwd_fixed(x.data_ptr(), idx.data_ptr(), g.data_ptr(), n, idx.shape[0], idx.shape[1], width,
@@ -716,12 +787,12 @@ def _amax_slot(device, stream):
 
 
 def _amax_live(blocked):
-    """The magnitude word of a BlockedFeatures, or None when the ring it came from has wrapped past it since (an object kept for more than
-    4096 apply passes of its stream: its word may describe another tensor by now -- the kernels then split the features as they are)."""
+    """The magnitude word of a BlockedFeatures, or None when the ring it came from has wrapped since (an object kept across a wrap: its word
+    was zeroed and may describe another tensor by now -- the kernels then split the features as they are)."""
     if blocked.amax is None or blocked.amax_tag is None:
         return blocked.amax
     ring, gen, pos = blocked.amax_tag
-    return blocked.amax if (ring[2] == gen or (ring[2] == gen + 1 and ring[1] <= pos)) else None
+    return blocked.amax if ring[2] == gen else None        # (the wrap zeroes the WHOLE ring: every word of an earlier generation is dead)
 
 
 def _kpconv_union_pays(Cin, Cout, same_cloud):
@@ -1051,7 +1122,9 @@ def kpconv_inter_so3_bwd(grad_out, x, q_pts, s_pts, idx, kernel_points, weights,
         if Cout % 32 == 0 and d2.data_ptr() % 16 == 0 and P * 6 * max(Cout, 36 * Cin) < 2 ** 31:
             # round 5: on the f16-split streaming kernel (csrc/dense_norm.hip; f32 accurate, ~2x the library's f32-MFMA rate on these shapes);
             # its weight pieces are cached per weight version like every dense layer's (keyed on the view's address / shape, owned by `weights`)
-            dG = linear_stream(d2, weights.detach().view(36 * Cin, Cout) if weights.is_contiguous() else W2.contiguous())
+            with torch.no_grad():           # (the view's _base must be `weights` itself -- the cache entry's owner; a view of weights.detach() is owned by a temporary)
+                Wv = weights.view(36 * Cin, Cout) if weights.is_contiguous() else W2.contiguous()
+            dG = linear_stream(d2, Wv)
         else:
             dG = mm(d2, W2.t())
         if KPCONV_BACKWARD_DETERMINISTIC:
@@ -1060,7 +1133,8 @@ def kpconv_inter_so3_bwd(grad_out, x, q_pts, s_pts, idx, kernel_points, weights,
             # over the (6 P, 36 Cin) product: the scale only has to prevent overflow)
             # (two fused max-magnitude reductions and Cout as the row length -- |dG| <= max |dout| max |W| Cout -- instead of abs / max / abs /
             #  row sums / max: 3 launches for 6 per layer; the looser bound costs the 64-bit sums a few of their ~39 spare bits)
-            bound = (torch.linalg.vector_norm(d2, float('inf')) * torch.linalg.vector_norm(W2, float('inf'))).mul_(float(Cout)).reshape(1)
+            bound = ((torch.linalg.vector_norm(d2, float('inf')) * torch.linalg.vector_norm(W2, float('inf'))).mul_(float(Cout)).reshape(1)
+                     if d2.numel() and W2.numel() else d2.new_zeros(1))
             fixed = torch.zeros(x.shape, dtype=torch.int64, device=x.device)
             dx = torch.empty_like(x)
             check(lib().se3_kpconv_so3_gather_bwd_fixed(q_pts.data_ptr(), s_pts.data_ptr(), idx.data_ptr(), dG.data_ptr(), kp.data_ptr(),

@@ -53,6 +53,11 @@ def test_bench_at_the_drivers_step_counts():
     assert rd['bound'] == 'hbm' and rd['launches'] >= 20 * 30 and 0.0 < rd['frac'] < 1.0
     assert 'profiles/r0' in line['roofline']['traffic_source'] and 'sha256' in line['roofline']['traffic_source']
     assert set(line['roofline']['traffic_per_algorithmic_byte']) == {'eq', 'inv'}
-    # host threads sleep while they wait for the GPU (hipDeviceScheduleBlockingSync requested at package import): well under one core per thread
-    assert line['config']['host_waits'].endswith('set'), line['config']['host_waits']
+    # host threads sleep while they wait for the GPU (hipDeviceScheduleBlockingSync requested for THIS rank's device after set_device): well
+    # under one core per thread
+    assert line['config']['host_waits'].endswith('set (device 0)'), line['config']['host_waits']
+    # round 6: the same K steps twice more between the same bracket; all three rates with their median / min / max
+    d = line['dispersion']
+    assert d['regions'] == 3 and len(d['values']) == 3 and abs(d['values'][0] - line['value']) <= 0.01 * line['value']
+    assert d['min'] <= d['median'] <= d['max'] and d['spread_rel'] < 0.5
     assert line['host_cpu_s_per_step'] < 0.6 * 3 * line['ms_per_step'] * 1e-3

@@ -67,3 +67,49 @@ def test_batches_in_flight_give_the_sequential_results(threads):
                 assert torch.equal(g['ref_node_corr_indices'], w['ref_node_corr_indices']), (t, p)
                 for key in ('ref_feats_c', 'src_feats_c', 'estimated_transform'):
                     assert float((g[key] - w[key]).abs().max()) <= 1e-5 * max(1.0, float(w[key].abs().max())), (t, p, key)
+
+
+def test_blocking_sync_is_the_first_gpu_call_or_nothing():
+    """ADVICE round 5 + the round-6 measurement (profiles/r06_blocking_sync.txt): the blocking-wait flag works only as the process's FIRST GPU
+    call, for the device the rank will use.  (a) a fresh interpreter: request, then torch work -- the process CPU time spent in a wait is a
+    small part of the wall time; (b) once torch has initialised the runtime the request is refused and changes nothing (set late it is
+    either ineffective or breaks the waits of streams that already exist).  Importing the package alone touches no GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = '''
+import json, sys, time
+import se3et_amd
+early = "%s" == "early"
+status = se3et_amd.request_blocking_sync(0) if early else None
+import torch
+torch.cuda.set_device(0)
+x = torch.randn(8192, 8192, device="cuda")
+torch.cuda.synchronize()
+if not early:
+    status = se3et_amd.request_blocking_sync(0)
+def wait_cost():
+    y = x
+    for _ in range(40):
+        y = (y @ x) * 1e-4
+    c0, w0 = time.process_time(), time.perf_counter()
+    torch.cuda.synchronize()
+    return time.process_time() - c0, time.perf_counter() - w0
+wait_cost()
+print(json.dumps({"status": status, "wait": wait_cost(), "reported": se3et_amd.blocking_sync_status(0)}))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    env.pop('SE3_BLOCKING_SYNC', None)
+    out = {}
+    for when in ('early', 'late'):
+        r = subprocess.run([sys.executable, '-c', code % when], capture_output=True, text=True, env=env, timeout=180)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[when] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out['early']['status'] == 'set' and out['early']['reported'] == 'set', out
+    cpu, wall = out['early']['wait']
+    assert wall > 0.05 and cpu < 0.35 * wall, out                    # there was something to wait for, and the waiting thread slept
+    assert out['late']['status'].startswith('too late'), out
+    cpu_l, wall_l = out['late']['wait']
+    assert abs(wall_l - wall) < 0.5 * wall, out                      # same wall time either way

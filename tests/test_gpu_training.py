@@ -504,6 +504,43 @@ def test_kpconv_backward_is_bit_identical_between_runs():
         ops.KPCONV_BACKWARD_DETERMINISTIC = saved
 
 
+def test_fixed_point_scatters_propagate_non_finite_gradients_and_take_empty_inputs():
+    """the order-independent (64-bit fixed-point) scatters of the default training backward quantise through an integer
+    conversion -- a NaN / Inf gradient must not come out as a finite number: the bound word of the call is non-finite then and
+    se3_fixed_to_float writes NaN.  Empty gradients / empty index tables return zeros like the float forms."""
+    from se3et_amd import ops, tables
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(50, 6, 16, generator=g).cuda()
+    idx = torch.randint(0, 51, (30, 9), generator=g).cuda()
+    go = torch.randn(30, 6, 16, generator=g).cuda()
+    clean = ops.neighbor_max_pool_bwd(go, x, idx)
+    assert bool(torch.isfinite(clean).all())
+    for bad in (float('nan'), float('inf'), float('-inf')):
+        gb = go.clone()
+        gb[4, 2, 3] = bad
+        assert bool(torch.isnan(ops.neighbor_max_pool_bwd(gb, x, idx)).all()), bad
+        rows = torch.randn(30, 9, 8, generator=g).cuda()
+        rows[1, 1, 1] = bad
+        assert bool(torch.isnan(ops.scatter_add_rows(rows, idx, 50)).all()), bad
+    assert torch.equal(ops.neighbor_max_pool_bwd(go[:0], x, idx[:0]), torch.zeros_like(x))
+    assert torch.equal(ops.scatter_add_rows(go[:0], idx[:0, 0], 50), torch.zeros(50, 6, 16, device='cuda'))
+    # KPConv: a NaN in grad_out reaches dx as NaN; an empty query set gives zeros
+    Ns, P, NN, Cin, Cout, radius, sigma = 300, 200, 20, 16, 32, 0.0625, 0.05
+    s_pts = (torch.rand(Ns, 3, generator=g) * 0.2).cuda()
+    q_pts = s_pts[:P].contiguous()
+    nb = ((q_pts[:, None] - s_pts[None]) ** 2).sum(-1).topk(NN, dim=1, largest=False)[1]
+    xx = torch.randn(Ns, 6, Cin, generator=g).cuda()
+    w = (torch.randn(6, 6, Cin, Cout, generator=g) / (36 * Cin) ** 0.5).cuda()
+    kp = torch.from_numpy(tables.kernel_points(radius)).cuda()
+    kidx, ridx = torch.from_numpy(tables.kernel_slot_table()).cuda(), torch.from_numpy(tables.anchor_slot_table()).cuda()
+    d = torch.randn(P, 6, Cout, generator=g).cuda()
+    assert bool(torch.isfinite(ops.kpconv_inter_so3_bwd(d, xx, q_pts, s_pts, nb, kp, w, kidx, ridx, sigma, need_x=True, need_w=False)[0]).all())
+    d[7, 0, 0] = float('nan')
+    assert bool(torch.isnan(ops.kpconv_inter_so3_bwd(d, xx, q_pts, s_pts, nb, kp, w, kidx, ridx, sigma, need_x=True, need_w=False)[0]).all())
+    dx0 = ops.kpconv_inter_so3_bwd(d[:0], xx, q_pts[:0], s_pts, nb[:0], kp, w, kidx, ridx, sigma, need_x=True, need_w=False)[0]
+    assert torch.equal(dx0, torch.zeros_like(xx))
+
+
 @pytest.mark.parametrize('variant,preset', [('micro_e', 'micro'), ('se3ete', 'c1_2k')])
 def test_training_step_is_bit_identical_between_runs(variant, preset):
     """VERDICT round 4 (missing 5 / next 7): 'two runs bit-identical'.  Every scatter-add of the step is order-independent -- the KPConv input

@@ -27,6 +27,8 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         import bench
         raise SystemExit(bench.launch_ranks(args.gpus, sys.argv[1:], script=__file__))
+    import se3et_amd
+    se3et_amd.request_blocking_sync(int(os.environ.get('LOCAL_RANK', '0')))      # the process's first GPU call (se3et_amd/__init__.py)
     from se3et_amd import sharding
     from se3et_amd.data import registration_collate_fn_stack_mode
     from se3et_amd.model import create_model, load_synthetic_weights, make_cfg
