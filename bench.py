@@ -937,8 +937,10 @@ def run_single_pair(model, cfg, args, dev, feats_unused):
             'note': 'one pair per forward incl. on-GPU pyramid and LGR, forwards strictly one after the other; host_ms = wall time per pair '
                     'not covered by kernel time.  pyramid_prefetched: the pyramid of the next pair built by a worker thread on its own stream '
                     '(the reference builds it in DataLoader workers); three_in_flight: three one-pair forwards at a time on three streams.  '
-                    'Neither helps: one pair per forward is bound by the host (about 500 launches of 10-20 us each from one Python '
-                    'interpreter), which more host threads only contend for -- stack pairs (the headline configuration) instead'}
+                    'Neither helps.  The measured split is in gpu_kernel_ms / host_ms / launches: one pair per forward is KERNEL-bound -- '
+                    'about 420 launches sized for 8 pairs that one pair under-fills (6.9 of the 7.6 ms per pair are kernel time, 0.7 ms host gaps): '
+                    'the dense + GroupNorm family costs 3.6x its per-pair share of a stacked step.  Stack pairs (the headline configuration), or '
+                    'wait for the small-row dense path (DESIGN section 7 item 6)'}
 
 
 def cpu_model_name():

@@ -136,19 +136,32 @@ __host__ __device__ void insertion_sort(const Strip& s, int first, int last) {
     }
   }
 }
+// A lane's explicit stacks live outside its registers / private memory (the kernel keeps them in LDS: a per-lane array of a few hundred
+// bytes is scratch memory, and a dispatch with that much scratch stalled the HOST for ~10 ms per launch while the runtime resized the scratch
+// pool -- 100 ms per pyramid of the real pair for 5 ms of kernels).  Slot d of the lane at [d * stride].
+struct Stacks {
+  int* i;          // walk: node | stage << 30          sort: first | last << 16
+  float* a;        // walk: the frame's `outside`       sort: depth (integer bits)
+  float* b;        // walk: the saved `side` value
+  int stride;
+};
+constexpr int kMaxDepth = 48;
+
 // std::sort(first, last, comp) of libstdc++ (bits/stl_algo.h: __sort -> __introsort_loop + __final_insertion_sort)
-__host__ __device__ void std_sort(const Strip& s, int n) {
+__host__ __device__ void std_sort(const Strip& s, int n, const Stacks& K) {
   if (n <= 0) return;
   constexpr int kThreshold = 16;
   int depth0 = 0;
   while ((2 << depth0) <= n) depth0++;                                  // floor(log2 n)
   // the loop recurses on the right part and iterates on the left; the two parts are disjoint, so an explicit stack in any order
-  // performs the same exchanges
-  int st_first[64], st_last[64], st_depth[64], sp = 0;
-  st_first[0] = 0; st_last[0] = n; st_depth[0] = 2 * depth0; sp = 1;
+  // performs the same exchanges (n < 65536: first | last << 16; at most 2 floor(log2 n) <= 30 pending parts)
+  int sp = 1;
+  K.i[0] = 0 | (n << 16);
+  K.a[0] = __builtin_bit_cast(float, 2 * depth0);
   while (sp > 0) {
     --sp;
-    int first = st_first[sp], last = st_last[sp], depth = st_depth[sp];
+    const int packed = K.i[sp * K.stride];
+    int first = packed & 0xffff, last = (int)((unsigned)packed >> 16), depth = __builtin_bit_cast(int, K.a[sp * K.stride]);
     while (last - first > kThreshold) {
       if (depth == 0) {
         heap_sort(s, first, last);
@@ -172,7 +185,11 @@ __host__ __device__ void std_sort(const Strip& s, int n) {
         swap_at(s, lo, hi);
         ++lo;
       }
-      if (sp < 64) { st_first[sp] = lo; st_last[sp] = last; st_depth[sp] = depth; sp++; }
+      if (sp < kMaxDepth) {
+        K.i[sp * K.stride] = lo | (last << 16);
+        K.a[sp * K.stride] = __builtin_bit_cast(float, depth);
+        sp++;
+      }
       last = lo;
     }
   }
@@ -184,14 +201,13 @@ __host__ __device__ void std_sort(const Strip& s, int n) {
   }
 }
 
-struct Frame { int node; float outside, kept; int stage; };
-constexpr int kMaxDepth = 64;
 
 // One flagged row: walk, collect, sort, rewrite.  Returns false when the strip (max_hits) or the walk stack overflowed (the row is left as
 // it is).  Host-callable as well: se3_debug_radius_tie_order_host runs exactly this code on the CPU (tests/test_radius_ties_cpu.py checks
 // it against the host twin's std::sort there, where no GPU is needed).
 __host__ __device__ bool tie_row(const float* __restrict__ q, const float* __restrict__ s, const Batch& bt, const unsigned char* __restrict__ tree,
-                                 float r2, int limit, int64_t row, int max_hits, const Strip& strip, int64_t ns_total, int64_t* __restrict__ out) {
+                                 float r2, int limit, int64_t row, int max_hits, const Strip& strip, const Stacks& K, int64_t ns_total,
+                                 int64_t* __restrict__ out) {
   int b = 0;
   while (b + 1 < bt.n && row >= bt.q_start[b] + bt.q_count[b]) b++;
   const KdHeader* H = reinterpret_cast<const KdHeader*>(tree);
@@ -208,12 +224,15 @@ __host__ __device__ bool tie_row(const float* __restrict__ q, const float* __res
       if (qv[d] < cl.lo[d]) { side[d] = (qv[d] - cl.lo[d]) * (qv[d] - cl.lo[d]); outside += side[d]; }
       if (qv[d] > cl.hi[d]) { side[d] = (qv[d] - cl.hi[d]) * (qv[d] - cl.hi[d]); outside += side[d]; }
     }
-    Frame st[kMaxDepth];
+    // frames of the walk: (node, stage) in K.i, the box distance `outside` the node was entered with in K.a, the saved side value in K.b
     int sp_ = 1;
-    st[0] = Frame{0, outside, 0.f, 0};
+    K.i[0] = 0;
+    K.a[0] = outside;
     while (sp_ > 0) {
-      Frame& f = st[sp_ - 1];
-      const KdNode nd = nodes[f.node];
+      const int top = (sp_ - 1) * K.stride;
+      const int word = K.i[top], node = word & 0x3fffffff, stage = (int)((unsigned)word >> 30);
+      const float f_outside = K.a[top];
+      const KdNode nd = nodes[node];
       if (nd.kid0 < 0) {
         for (int k = nd.first; k < nd.last; k++) {
           const int j = perm[k];
@@ -234,28 +253,30 @@ __host__ __device__ bool tie_row(const float* __restrict__ q, const float* __res
       const float to_low = v - nd.low_end, to_high = v - nd.high_start;
       const bool low_first = (to_low + to_high) < 0;
       const float gap = low_first ? to_high * to_high : to_low * to_low;
-      if (f.stage == 0) {
-        f.stage = 1;
-        if (sp_ < kMaxDepth) { st[sp_] = Frame{low_first ? nd.kid0 : nd.kid1, f.outside, 0.f, 0}; sp_++; } else { over = true; sp_--; }
-      } else if (f.stage == 1) {
+      if (stage == 0) {
+        K.i[top] = node | (1 << 30);
+        if (sp_ < kMaxDepth) { K.i[sp_ * K.stride] = low_first ? nd.kid0 : nd.kid1; K.a[sp_ * K.stride] = f_outside; sp_++; } else { over = true; sp_--; }
+      } else if (stage == 1) {
         const float kept = nd.axis == 0 ? side[0] : (nd.axis == 1 ? side[1] : side[2]);
-        const float far_outside = f.outside + gap - kept;
+        const float far_outside = f_outside + gap - kept;
         if (far_outside * 1.0f <= r2) {
-          f.kept = kept;
-          f.stage = 2;
+          K.b[top] = kept;
+          K.i[top] = node | (2 << 30);
           if (nd.axis == 0) side[0] = gap; else if (nd.axis == 1) side[1] = gap; else side[2] = gap;
-          if (sp_ < kMaxDepth) { st[sp_] = Frame{low_first ? nd.kid1 : nd.kid0, far_outside, 0.f, 0}; sp_++; } else { over = true; sp_--; }
+          if (sp_ < kMaxDepth) { K.i[sp_ * K.stride] = low_first ? nd.kid1 : nd.kid0; K.a[sp_ * K.stride] = far_outside; sp_++; } else { over = true; sp_--; }
         } else {
           sp_--;
         }
       } else {
-        if (nd.axis == 0) side[0] = f.kept; else if (nd.axis == 1) side[1] = f.kept; else side[2] = f.kept;
+        const float kept = K.b[top];
+        if (nd.axis == 0) side[0] = kept; else if (nd.axis == 1) side[1] = kept; else side[2] = kept;
         sp_--;
       }
     }
   }
+  if (n >= 65536) over = true;                 // (the sort's stack packs positions into 16 bits)
   if (over) return false;                      // (cannot happen with max_hits = the search's own largest count: the row keeps its index order)
-  std_sort(strip, n);
+  std_sort(strip, n, K);
   for (int k = 0; k < limit; k++) out[row * limit + k] = k < n ? (int64_t)(unsigned)(strip.get(k) & 0xffffffffull) : ns_total;
   return true;
 }
@@ -265,9 +286,12 @@ __global__ __launch_bounds__(64) void radius_tie_rows_kernel(const float* __rest
                                                              const int32_t* __restrict__ rows, int64_t num_rows, int max_hits,
                                                              unsigned long long* __restrict__ scratch, int64_t ns_total,
                                                              int64_t* __restrict__ out, int32_t* __restrict__ overflow) {
+  __shared__ int stk_i[kMaxDepth * 64];
+  __shared__ float stk_a[kMaxDepth * 64], stk_b[kMaxDepth * 64];
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= num_rows) return;
-  if (!tie_row(q, s, bt, tree, r2, limit, rows[r], max_hits, Strip{scratch + r, num_rows}, ns_total, out)) atomicAdd(overflow, 1);
+  const Stacks K{stk_i + threadIdx.x, stk_a + threadIdx.x, stk_b + threadIdx.x, 64};
+  if (!tie_row(q, s, bt, tree, r2, limit, rows[r], max_hits, Strip{scratch + r, num_rows}, K, ns_total, out)) atomicAdd(overflow, 1);
 }
 
 int fill_batch(Batch* bt, const int64_t* q_len, const int64_t* s_len, int batch, int64_t nq, int64_t ns) {
@@ -390,9 +414,12 @@ extern "C" int se3_debug_radius_tie_order_host(const float* q_points, int64_t nq
   Batch bt;
   SE3_REQUIRE(fill_batch(&bt, q_lengths, s_lengths, batch, nq, ns) == 0, SE3_ERR_INVALID_ARG, "debug_radius_tie_order_host: lengths do not sum to the sizes");
   std::vector<unsigned long long> strip((size_t)max_hits);
+  int si[kMaxDepth];
+  float sa[kMaxDepth], sb[kMaxDepth];
+  const Stacks K{si, sa, sb, 1};
   *overflowed = 0;
   for (int64_t r = 0; r < num_tie_rows; r++)
-    if (!tie_row(q_points, s_points, bt, (const unsigned char*)tree_host, radius * radius, limit, tie_rows[r], max_hits, Strip{strip.data(), 1}, ns, neighbors))
+    if (!tie_row(q_points, s_points, bt, (const unsigned char*)tree_host, radius * radius, limit, tie_rows[r], max_hits, Strip{strip.data(), 1}, K, ns, neighbors))
       *overflowed += 1;
   return SE3_OK;
 }
@@ -401,12 +428,14 @@ extern "C" int se3_debug_radius_tie_order_host(const float* q_points, int64_t nq
 // std::partial_sort(first, last, last) (what the introsort loop calls once its depth limit is spent), both on copies of keys[0..n) with the
 // comparison of the search (the high 32 bits alone).  Returns the number of positions where the two results differ (0 = identical), or -1.
 extern "C" int64_t se3_debug_std_sort_host(const unsigned long long* keys, int64_t n, int mode) {
-  if (keys == nullptr || n < 0 || n > (1ll << 28)) return -1;
+  if (keys == nullptr || n < 0 || n >= 65536) return -1;
   std::vector<unsigned long long> a(keys, keys + n), b(keys, keys + n);
   auto cmp = [](unsigned long long x, unsigned long long y) { return (unsigned)(x >> 32) < (unsigned)(y >> 32); };
   const Strip strip{a.data(), 1};
+  int si[kMaxDepth];
+  float sa[kMaxDepth], sb[kMaxDepth];
   if (mode == 0) {
-    std_sort(strip, (int)n);
+    std_sort(strip, (int)n, Stacks{si, sa, sb, 1});
     std::sort(b.begin(), b.end(), cmp);
   } else {
     heap_sort(strip, 0, (int)n);

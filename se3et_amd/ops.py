@@ -364,12 +364,11 @@ class ReferenceTree:
         self.ns = s_points.shape[0]
         host_pts = s_points.cpu()                                              # (a synchronisation: only ever reached when rows were flagged)
         cap = lib().se3_kdtree_max_bytes(self.ns, self.batch)
-        host = torch.empty((cap,), dtype=torch.uint8).pin_memory()
+        host = torch.empty((cap,), dtype=torch.uint8)                          # (pageable: pinning a fresh buffer per tree costs more than the copy)
         used = ctypes.c_size_t(0)
         check(lib().se3_kdtree_build_host(host_pts.data_ptr(), self.ns, self.lengths, self.batch, host.data_ptr(), cap, ctypes.byref(used)),
               'se3_kdtree_build_host')
-        self.tree = host[:int(used.value)].to(s_points.device, non_blocking=True)
-        self._host = host                                                      # (kept until the copy has been consumed)
+        self.tree = host[:int(used.value)].to(s_points.device)
 
 
 def radius_tie_order(neighbors, q_points, s_points, q_lengths, s_lengths, radius, tie_rows, num_tie_rows, max_hits, tree=None):

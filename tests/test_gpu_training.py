@@ -513,16 +513,16 @@ def test_fixed_point_scatters_propagate_non_finite_gradients_and_take_empty_inpu
     x = torch.randn(50, 6, 16, generator=g).cuda()
     idx = torch.randint(0, 51, (30, 9), generator=g).cuda()
     go = torch.randn(30, 6, 16, generator=g).cuda()
-    clean = ops.neighbor_max_pool_bwd(go, x, idx)
+    clean = ops.neighbor_max_pool_bwd(x, idx, go)
     assert bool(torch.isfinite(clean).all())
     for bad in (float('nan'), float('inf'), float('-inf')):
         gb = go.clone()
         gb[4, 2, 3] = bad
-        assert bool(torch.isnan(ops.neighbor_max_pool_bwd(gb, x, idx)).all()), bad
+        assert bool(torch.isnan(ops.neighbor_max_pool_bwd(x, idx, gb)).all()), bad
         rows = torch.randn(30, 9, 8, generator=g).cuda()
         rows[1, 1, 1] = bad
         assert bool(torch.isnan(ops.scatter_add_rows(rows, idx, 50)).all()), bad
-    assert torch.equal(ops.neighbor_max_pool_bwd(go[:0], x, idx[:0]), torch.zeros_like(x))
+    assert torch.equal(ops.neighbor_max_pool_bwd(x, idx[:0], go[:0]), torch.zeros_like(x))
     assert torch.equal(ops.scatter_add_rows(go[:0], idx[:0, 0], 50), torch.zeros(50, 6, 16, device='cuda'))
     # KPConv: a NaN in grad_out reaches dx as NaN; an empty query set gives zeros
     Ns, P, NN, Cin, Cout, radius, sigma = 300, 200, 20, 16, 32, 0.0625, 0.05

@@ -50,3 +50,27 @@ for name, clouds in (('data/demo real pair', [g['ref'], g['src']]), ('synthetic 
     model(dd)
     ms, _ = timed(lambda: model(dd), 5)
     print('%-22s forward %7.2f ms' % (name, ms))
+
+# ---- where the time of the tie pass goes (stage 0 of the real pair: 34 930 points, limit 38)
+import ctypes
+from se3et_amd._lib import lib
+pts = torch.from_numpy(np.concatenate([g['ref'], g['src']], 0)).cuda()
+lens = torch.tensor([len(g['ref']), len(g['src'])])
+ops.RADIUS_REFERENCE_TIES = True
+ms, host = timed(lambda: pts.cpu())
+print('stage 0: device -> host copy of the points      %7.2f ms' % ms)
+cap = lib().se3_kdtree_max_bytes(pts.shape[0], 2)
+buf = torch.empty(cap, dtype=torch.uint8)
+used = ctypes.c_size_t(0)
+l64 = (ctypes.c_int64 * 2)(*lens.tolist())
+ms, _ = timed(lambda: lib().se3_kdtree_build_host(host.data_ptr(), pts.shape[0], l64, 2, buf.data_ptr(), cap, ctypes.byref(used)))
+print('stage 0: reference k-d tree on the host (1 thread) %7.2f ms, %d bytes' % (ms, used.value))
+ms, tree = timed(lambda: ops.ReferenceTree(pts, lens))
+print('stage 0: ops.ReferenceTree (copy + build + upload) %7.2f ms' % ms)
+flags = torch.zeros(pts.shape[0] + 1, dtype=torch.int32, device='cuda')
+full, mc = ops.radius_neighbors(pts, pts, lens, lens, b.init_radius, 38, ties=(flags[1:], flags[:1]))
+n_tie, hits = int(flags[0]), int(mc.max())
+ms, _ = timed(lambda: ops.radius_tie_order(full, pts, pts, lens, lens, b.init_radius, flags[1:], n_tie, hits, tree=tree))
+print('stage 0: tie-order kernel, %d rows, max %d matches  %7.2f ms' % (n_tie, hits, ms))
+ms, _ = timed(lambda: ops.radius_neighbors(pts, pts, lens, lens, b.init_radius, 38))
+print('stage 0: the plain search                          %7.2f ms' % ms)
