@@ -2,7 +2,8 @@
 """Benchmark of the SE3ET hot path on MI355X:  python bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json configs[1]): SE3ET-E forward on synthetic 5k+5k point-cloud pairs (3DMatch-sized), fp32,
-name-keyed synthetic weights.  A step = one batch of `--batch` (default 8) registration pairs per rank through ONE forward
+name-keyed synthetic weights.  A step = one batch of `--batch` (default 16 since round 6: +5 % over 8,
+profiles/r06_batch_inflight_sweep.txt) registration pairs per rank through ONE forward
 (se3et_amd.batched: clouds stacked ref0, src0, ref1, ...; per pair the results of the single-pair forward): on-GPU stage
 pyramid (grid subsampling + 10 radius searches) -> E2PN backbone -> geometric transformer -> superpoint matching ->
 Sinkhorn -> local-to-global registration.  `--batch 1` runs the reference-shaped single-pair forward.  By default three such
@@ -229,9 +230,9 @@ def main():
     ap.add_argument('--variant', default='se3ete')
     ap.add_argument('--pair', default='c2_5k')
     ap.add_argument('--cpu-baseline-pairs', type=int, default=5, help='timed pairs of the CPU baseline (after 3 warm-up pairs; median)')
-    ap.add_argument('--cpu-baseline-threads', type=int, default=0, help='torch threads of the CPU baseline (0: min(cores, 16))')
+    ap.add_argument('--cpu-baseline-threads', type=int, default=0, help='torch threads of the CPU baseline (0: min(cores, 8) -- the fastest setting on the host of the GPU box, profiles/r06_cpu_baseline_threads.txt)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--batch', type=int, default=8, help='registration pairs per forward / step (se3et_amd.batched), 1..16; '
+    ap.add_argument('--batch', type=int, default=16, help='registration pairs per forward / step (se3et_amd.batched), 1..16; '
                     '1 = the single-pair forward of the reference API')
     ap.add_argument('--switch-interval', type=float, default=1e-3)
     ap.add_argument('--prefetch', type=int, default=None, help='build the pyramid of the next batch on a second host thread / HIP '
@@ -560,7 +561,7 @@ def main():
             'data': 'synthetic', 'host_cpu_s_per_step': round(host_cpu_s / max(args.steps, 1), 5),
             'config': {'workload': 'SE3ET-E forward (pyramid + backbone + transformer + matching + Sinkhorn + LGR) on '
                                    'synthetic %d+%d-point pairs, %d pair(s) per rank per step' % (n, n, PB) +
-                                   (' = BASELINE.json configs[3]: 64 independent pairs per step over 8 GPUs' if world == 8 and PB == 8 else ''),
+                                   (' = the workload of BASELINE.json configs[3] (independent 5k+5k pairs sharded over 8 GPUs, no collective): %d pairs per step' % (world * PB) if world == 8 else ''),
                        'ranks_seen': ranks_seen, 'collectives': 'rccl' if torch.distributed.is_initialized() else 'none (one rank)',
                        'variant': args.variant, 'pair_preset': args.pair, 'sharding': 'pairs round-robin over ranks, no collective',
                        'pairs_per_forward': PB, 'batches_in_flight_per_gpu': max(1, args.inflight), 'pyramid_prefetch': bool(args.prefetch),
@@ -601,8 +602,11 @@ def collect_step_roofline(elapsed, steps, args):
     """Whole-step HBM figure: the HBM-side bytes of one 8-pair step by kernel family from the committed whole-step
     PMC passes (tools/pmc_step.sh), over this run's time per step."""
     total, fams, source = load_pmc_step()
-    if total is None or args.batch != 8 or args.variant != 'se3ete' or args.pair != 'c2_5k' or args.attention_dtype != 'float32':
+    if total is None or args.batch < 2 or args.variant != 'se3ete' or args.pair != 'c2_5k' or args.attention_dtype != 'float32':
         return {'bytes_per_step': None, 'source': source if total is None else 'the PMC passes were taken on the default workload (8 x c2_5k pairs, se3ete, f32)'}
+    # (the passes were taken on an 8-pair step; every pair of a stacked step moves the same bytes: scaled to this run's pairs per step)
+    total = total * args.batch / 8.0
+    fams = {k: v * args.batch / 8.0 for k, v in fams.items()}
     s_per_step = elapsed / max(steps, 1)
     achieved = total / s_per_step / 1e9
     return {'bound': 'hbm', 'bytes_per_step': int(total), 'ms_per_step': round(s_per_step * 1e3, 3), 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
@@ -957,14 +961,15 @@ def cpu_model_name():
 def run_cpu_baseline(model, cfg, args):
     """The CPU oracle (a restatement of the reference algorithm, kind 'port') on a bounded sample of the same workload: 3 warm-up pairs, then
     `--cpu-baseline-pairs` (default 5) timed ONE BY ONE, median.  Threads: `--cpu-baseline-threads`, default
-    min(cores, 16) -- profiles/r06_cpu_baseline_threads.txt (tools/r6/cpu_threads.py, this box's host) is the scaling table behind the cap."""
+    min(cores, 8): profiles/r06_cpu_baseline_threads.txt (tools/r6/cpu_threads.py on the GPU box's 256-core EPYC 9575F) -- 7.08 s per pair
+    at 8 threads, 7.27 at 16, 10.1 at 32, 24.5 at 64: the small CPU ops of this path thrash beyond a few cores, 8 is the fastest."""
     from oracle import se3et_oracle as O
     from se3et_amd.synthetic import make_pair
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, args.cpu_baseline_threads or 16))
+    cores = max(1, min(avail, args.cpu_baseline_threads or 8))
     torch.set_num_threads(cores)
     state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     b = cfg.backbone

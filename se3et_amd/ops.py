@@ -598,8 +598,10 @@ def neighbor_max_pool_bwd(x, idx, grad_out):
     g = _req(grad_out.contiguous(), torch.float32, 'grad_out')
     n = x.shape[0]
     width = x.numel() // max(n, 1)
+    if idx.shape[0] == 0 or g.numel() == 0:                  # nothing pooled: no gradient (empty tensors have no address to hand to the C side)
+        return torch.zeros_like(x)
     if TRAINING_DETERMINISTIC:
-        bound = g.abs().max().reshape(1) if g.numel() else g.new_zeros(1)
+        bound = g.abs().max().reshape(1)
         fixed = torch.zeros(x.shape, dtype=torch.int64, device=x.device)
         dx = torch.empty_like(x)
         check(lib().se3_neighbor_max_pool_bwd_fixed(x.data_ptr(), idx.data_ptr(), g.data_ptr(), n, idx.shape[0], idx.shape[1], width,
@@ -620,7 +622,9 @@ def scatter_add_rows(g, idx, n):
     m = idx.numel()
     width = g.numel() // max(m, 1)
     tail = tuple(g.shape[idx.dim():])
-    bound = g.abs().max().reshape(1) if g.numel() else g.new_zeros(1)
+    if m == 0 or g.numel() == 0:
+        return torch.zeros((n,) + tail, dtype=torch.float32, device=g.device)
+    bound = g.abs().max().reshape(1)
     fixed = torch.zeros((n,) + tail, dtype=torch.int64, device=g.device)
     out = torch.empty((n,) + tail, dtype=torch.float32, device=g.device)
     check(lib().se3_scatter_add_rows_fixed(g.data_ptr(), idx.data_ptr(), n, m, width, bound.data_ptr(), fixed.data_ptr(), _stream()),
@@ -1109,6 +1113,8 @@ def kpconv_inter_so3_bwd(grad_out, x, q_pts, s_pts, idx, kernel_points, weights,
     P, NN = idx.shape
     Ns, A, Cin = x.shape
     Cout = weights.shape[-1]
+    if P == 0:                                                   # no query points: zero gradients (empty tensors have no address for the C side)
+        return (torch.zeros_like(x) if need_x else None), (torch.zeros_like(weights) if need_w else None)
     d2 = _req(grad_out.contiguous(), torch.float32, 'grad_out').reshape(P * 6, Cout)
     dx = dw = None
     if need_w:

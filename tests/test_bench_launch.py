@@ -23,10 +23,10 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1, out
     line = json.loads(lines[0])
     assert line['n_gpus'] == 2 and line['config']['ranks_seen'] == 2
-    assert line['config']['pairs_sharded'] == 2 * 4 * 8            # every pair of every step owned by exactly one rank
+    assert line['config']['pairs_sharded'] == 2 * 4 * 16           # every pair of every step owned by exactly one rank
     # the job time is the slowest rank's (rank 1 sleeps 4 ms per step)
     assert line['ms_per_step'] >= 3.9
-    assert abs(line['value'] - 2 * 3 * 8 / (line['ms_per_step'] * 3 / 1e3)) <= 0.01 * line['value']
+    assert abs(line['value'] - 2 * 3 * 16 / (line['ms_per_step'] * 3 / 1e3)) <= 0.01 * line['value']
 
 
 def test_bench_single_rank_and_torchrun_environment():
@@ -105,3 +105,20 @@ def test_launcher_gives_every_rank_a_disjoint_slice_of_the_host_cores():
     cpus = json.loads(out.strip())['config']['rank_cpus']
     assert len(cpus) == 2 and all(len(c) == have // 2 for c in cpus), cpus
     assert not set(cpus[0]) & set(cpus[1]), cpus
+
+
+def test_train_bench_launches_its_own_ranks_and_keeps_the_replicas_in_sync():
+    """tools/train_bench.py's launcher branch at world size 2 over gloo -- the self-launch (bench.launch_ranks), the
+    rendezvous, se3et_amd.training.distributed_model (DistributedDataParallel) and make_optimizer (lr x world size) around a stub model on
+    the CPU, barrier + MAX-over-ranks clock, ONE JSON line from rank 0.  Every rank feeds its own data: the replicas stay identical only if
+    the gradient all-reduce runs."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'train_bench.py'), '--gpus', '2', '--fake-device', '--steps', '3', '--warmup', '1'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd='/tmp')
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.lstrip().startswith('{')]
+    assert len(lines) == 1, r.stdout.decode()
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['ranks_seen'] == 2 and line['steps'] == 3
+    assert line['replicas_in_sync'] is True
+    assert abs(line['lr'] - 2e-2) < 1e-12                      # the reference scales the learning rate by the world size (base_trainer.py:191-196)

@@ -43,7 +43,8 @@ def test_bench_collectives_run_on_rccl_at_world_size_one():
 def test_bench_at_the_drivers_step_counts():
     line = _bench(['--gpus', '1', '--steps', '20', '--warmup', '5'] + LIGHT)
     assert line['steps'] == 20 and line['warmup'] == 5 and line['config']['batches_in_flight_per_gpu'] == 3
-    assert abs(line['value'] - 20 * 8 / (line['ms_per_step'] * 20 / 1e3)) <= 0.01 * line['value']
+    assert line['config']['pairs_per_forward'] == 16            # the default since round 6 (profiles/r06_batch_inflight_sweep.txt)
+    assert abs(line['value'] - 20 * 16 / (line['ms_per_step'] * 20 / 1e3)) <= 0.01 * line['value']
     assert line['roofline']['launches'] == 20 * 5            # five RPE self-attention calls per SE3ET-E forward, all of them timed
     assert line['host_cpu_s_per_step'] > 0
     # round 5: whole-step HBM figure from the committed counter passes, the dense + GroupNorm family's own roofline, traffic parsed at run time

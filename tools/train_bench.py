@@ -15,6 +15,47 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def run_fake(args):
+    """Everything of the multi-process training contract except the GPU and the model: a stub network behind the SAME wrapper, optimizer
+    factory, barrier and clock as the real run; rank r feeds its own data, the gradient all-reduce keeps the replicas identical."""
+    from types import SimpleNamespace
+    from se3et_amd import sharding
+    from se3et_amd.training import distributed_model, make_optimizer
+    rank, world, _ = sharding.init_distributed('gloo')
+    if world != args.gpus:
+        raise SystemExit('train_bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    torch.manual_seed(0)                                      # the same initial replica on every rank
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 1))
+    net = distributed_model(model) if world > 1 else model
+    opt = make_optimizer(net, SimpleNamespace(optim=SimpleNamespace(lr=1e-2, weight_decay=0.0)), world)
+    g = torch.Generator().manual_seed(100 + rank)             # ... and different data per rank
+
+    def step():
+        x = torch.randn(32, 8, generator=g)
+        loss = (net(x) - x.sum(1, keepdim=True)).pow(2).mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(args.warmup):
+        step()
+    sharding.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sharding.barrier()
+    dt = sharding.max_over_ranks(time.perf_counter() - t0)
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    spread = sharding.max_over_ranks(float(flat.double().sum())) + sharding.max_over_ranks(-float(flat.double().sum()))     # max - min over ranks
+    if rank == 0:
+        print(json.dumps({'metric': 'training launcher self-test (no GPU work)', 's_per_step': round(dt / max(args.steps, 1), 5), 'n_gpus': world,
+                          'ranks_seen': torch.distributed.get_world_size() if world > 1 else 1, 'steps': args.steps, 'warmup': args.warmup,
+                          'loss': float(loss.detach()), 'replicas_in_sync': abs(spread) < 1e-9, 'lr': opt.param_groups[0]['lr'],
+                          'data': 'none (fake device)'}), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -23,10 +64,15 @@ def main():
     ap.add_argument('--variant', default='se3ete')
     ap.add_argument('--pair', default='c2_5k')
     ap.add_argument('--profile', action='store_true', help='GPU time of the backward of each HIP op (HIP events), one extra step')
+    ap.add_argument('--fake-device', action='store_true', help='launcher self-test (no GPU): the self-launch, the gloo rendezvous, DistributedDataParallel '
+                    'through se3et_amd.training.distributed_model with a stub model on the CPU, the barrier + MAX-over-ranks clock and the one JSON '
+                    'line run for real (tests/test_bench_launch.py)')
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         import bench
         raise SystemExit(bench.launch_ranks(args.gpus, sys.argv[1:], script=__file__))
+    if args.fake_device:
+        return run_fake(args)
     import se3et_amd
     se3et_amd.request_blocking_sync(int(os.environ.get('LOCAL_RANK', '0')))      # the process's first GPU call (se3et_amd/__init__.py)
     from se3et_amd import sharding
