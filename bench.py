@@ -470,7 +470,11 @@ def main():
     torch.cuda.synchronize()
     sharding.barrier(dev)
     cpu0 = time.process_time()
-    se3_ops.KERNEL_TIMINGS = {}
+    # The headline region carries the event pairs of the ROOFLINE kernel only -- the RPE self-attention launches, taken on the C side with the
+    # dispatch's own begin / end timestamps (hipExtLaunchKernelGGL).  The event pairs of the two additional families (`roofline_kpconv`,
+    # `roofline_dense`: ~50 torch event pairs per step from Python) move to the FIRST REPEAT of the region, the same K steps between the same
+    # bracket: in the headline region they cost ~2 % of the rate (region 1 against regions 2 and 3, profiles/r06_batch_inflight_sweep.txt).
+    se3_ops.KERNEL_TIMINGS = None
     se3_lib.lib().se3_debug_kernel_timing(1)        # every RPE attention launch gets its own HIP event pair
     t0 = time.perf_counter()
     run_all(list(range(args.warmup, total_steps)))
@@ -480,13 +484,15 @@ def main():
     host_cpu_s = time.process_time() - cpu0           # CPU seconds of this rank's process (all host threads) over the timed region
     # (grows with the number of timed steps -- 0.013 s per step at 20, 0.036 at 60 -- through the roofline's own per-launch HIP events, which stay
     #  alive until the run is over: DESIGN section 5)
-    timings, se3_ops.KERNEL_TIMINGS = se3_ops.KERNEL_TIMINGS, None
+    roofline = collect_roofline(se3_lib, {}, args)     # (waits for the recorded launches, releases their events, timing off)
 
     # Dispersion: the SAME K steps between the same bracket, `--repeat-regions` more times (per-launch event timing off: the headline region
     # above carries it).  `value` stays the first region -- the contract's "exactly K steps" -- and the repeats say how far a single region moves.
     region_s = [elapsed]
     se3_lib.lib().se3_debug_kernel_timing(0)
-    for _ in range(max(0, args.repeat_regions)):
+    timings = {}
+    for rep in range(max(1, args.repeat_regions)):     # (at least one: the KPConv / dense families are timed in it)
+        se3_ops.KERNEL_TIMINGS = {} if rep == 0 else None
         torch.cuda.synchronize()
         sharding.barrier(dev)
         t_r = time.perf_counter()
@@ -494,16 +500,21 @@ def main():
         torch.cuda.synchronize()
         sharding.barrier(dev)
         region_s.append(sharding.max_over_ranks(time.perf_counter() - t_r, dev))
+        if rep == 0:
+            timings, se3_ops.KERNEL_TIMINGS = se3_ops.KERNEL_TIMINGS, None
     rates = [world * args.steps * PB / t for t in region_s]
     dispersion = {'regions': len(rates), 'steps_per_region': args.steps, 'values': [round(v, 2) for v in rates],
                   'median': round(sorted(rates)[len(rates) // 2], 2), 'min': round(min(rates), 2), 'max': round(max(rates), 2),
                   'spread_rel': round((max(rates) - min(rates)) / sorted(rates)[len(rates) // 2], 4),
-                  'note': 'values[0] is `value` (the timed region of the contract, with the per-launch HIP events of the roofline); the others '
-                          'are the same steps again, same bracket, without those events'}
+                  'note': 'values[0] is `value` (the timed region of the contract, with the per-launch HIP events of the roofline kernel); values[1] '
+                          'is the same steps again, same bracket, with the event pairs of the KPConv and dense families instead (roofline_kpconv, '
+                          'roofline_dense); the others carry no events'}
 
-    roofline = collect_roofline(se3_lib, timings, args)
     roofline_kpconv = collect_kpconv_roofline(timings)
     roofline_dense = collect_dense_roofline(timings)
+    for extra in (roofline_kpconv, roofline_dense):
+        if extra is not None:
+            extra['measured_in'] = 'the first repeat of the timed region (dispersion.values[1]): the same K steps between the same bracket'
     roofline_step = collect_step_roofline(elapsed, args.steps, args)
     # The same kernels with nothing else on the GPU: by default other batches (--inflight) or the next batch's pyramid (--prefetch 1) run on
     # other streams BESIDE the timed kernels, which lengthens them; a few extra steps with one batch in flight (after the timed region)
@@ -534,6 +545,13 @@ def main():
     # the auxiliary measurements never take the headline line down with them: a failure is reported in their place (and on stderr)
     def guarded(what, f, *a):
         try:
+            # every auxiliary measurement starts from an empty caching allocator, as if it ran in a process of its own: the one-pair forwards
+            # after three 16-pair steps on the same stream otherwise spend 3.4 ms of HOST time per pair re-cutting that stream's blocks
+            # (96 against 128 pairs/s, gpu_kernel_ms unchanged; round 6)
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
             return f(*a)
         except Exception as e:
             import traceback
