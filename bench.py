@@ -273,8 +273,12 @@ def main():
         return run_fake(args)
 
     # blocking host waits on THIS rank's device, as the process's first GPU call (se3et_amd/__init__.py: later it is ineffective or harmful)
+    # Only where it has been measured: ONE rank on the box (tests/test_gpu_concurrency.py, BENCH_r05 / r06).  A multi-rank run has never had a
+    # node to run on (SCALE_r01..r05 skipped): there the runtime's default spinning waits stay -- 3 busy cores per rank of the 32 a rank owns
+    # on the 256-thread host -- unless SE3_BLOCKING_SYNC=force.
     import se3et_amd
-    se3et_amd.request_blocking_sync(int(os.environ.get('LOCAL_RANK', '0')))
+    if int(os.environ.get('WORLD_SIZE', '1')) == 1 or os.environ.get('SE3_BLOCKING_SYNC') == 'force':
+        se3et_amd.request_blocking_sync(int(os.environ.get('LOCAL_RANK', '0')))
 
     from se3et_amd import ops as se3_ops
     from se3et_amd import _lib as se3_lib

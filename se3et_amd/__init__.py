@@ -24,7 +24,7 @@ def request_blocking_sync(device_index=None):
     if device_index is None:
         device_index = int(_os.environ.get('LOCAL_RANK', '0'))
     device_index = int(device_index)
-    if _os.environ.get('SE3_BLOCKING_SYNC', '1') == '0':
+    if _os.environ.get('SE3_BLOCKING_SYNC', '1') == '0':           # ('force': bench.py requests it in multi-rank runs as well)
         status = 'not requested'
     elif not _os.path.exists('/dev/kfd'):            # no GPU in this container: nothing to ask (and no runtime to wake up)
         status = 'no GPU'

@@ -35,6 +35,8 @@ tools/pmc_passes.sh > $O/${tag}_pmc_attention_raw.txt 2>&1
 tools/pmc_step.sh ${tag} > $O/pmc_step.log 2>&1; cp gpurun_out/${tag}_pmc_step.txt $O/${tag}_pmc_step.txt
 for K in rpe_bias_kernel attention_x6_kernel; do echo "== $K (tools/pmc_attention.py: 16 clouds per launch; equivariant and invariant dispatches averaged together)"; tools/pmc_kernel.sh $K tools/pmc_attention.py; done > $O/${tag}_pmc_attention_sq.txt 2>&1
 timeout 600 python tools/train_bench.py --steps 5 --warmup 2 --profile > $O/${tag}_train_bench.txt 2>&1
+timeout 300 python tools/r6/tie_cost.py 2>&1 | grep -v "amdgpu.ids\|Warning" > $O/${tag}_tie_cost.txt
+tools/prof.sh ${tag}demo tools/r6/demo_pyramid.py 8 >> $O/prof.txt 2>&1 < /dev/null; cp gpurun_out/${tag}demo_kernel_stats.csv $O/${tag}_kernel_stats_demo_pyramid.csv; grep pyramid gpurun_out/prof_${tag}demo.log > $O/${tag}_demo_pyramid_times.txt
 timeout 300 python tools/micro/sinkhorn_ab.py 2>&1 | grep -v "amdgpu.ids\|Warning" > $O/${tag}_sinkhorn_ab.txt
 for V in true false; do echo "== sinkhorn_kernel<8, 9, $V> (tools/micro/sinkhorn_ab.py one: 2 048 patch pairs of 64 x 64, 100 iterations; true = base 2 with carried shifts, false = the reference's order of operations), average per dispatch"; tools/pmc_kernel.sh "sinkhorn_kernel<8, 9, $V>" tools/micro/sinkhorn_ab.py one; done > $O/${tag}_pmc_sinkhorn.txt 2>&1
 ls -la $O

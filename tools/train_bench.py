@@ -74,7 +74,8 @@ def main():
     if args.fake_device:
         return run_fake(args)
     import se3et_amd
-    se3et_amd.request_blocking_sync(int(os.environ.get('LOCAL_RANK', '0')))      # the process's first GPU call (se3et_amd/__init__.py)
+    if int(os.environ.get('WORLD_SIZE', '1')) == 1 or os.environ.get('SE3_BLOCKING_SYNC') == 'force':      # (as bench.py: measured with one rank only)
+        se3et_amd.request_blocking_sync(int(os.environ.get('LOCAL_RANK', '0')))  # the process's first GPU call (se3et_amd/__init__.py)
     from se3et_amd import sharding
     from se3et_amd.data import registration_collate_fn_stack_mode
     from se3et_amd.model import create_model, load_synthetic_weights, make_cfg
