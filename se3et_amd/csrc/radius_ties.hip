@@ -23,6 +23,8 @@
 #include "common.h"
 #include "kdtree_ref.h"
 #include <string.h>
+#include <memory>
+#include <thread>
 
 namespace {
 
@@ -333,16 +335,36 @@ extern "C" int se3_kdtree_build_host(const float* s_points_host, int64_t ns, con
   KdCloud* clouds = (KdCloud*)(base + H.off_clouds);
   int32_t* perm = (int32_t*)(base + H.off_perm);
   KdNode* nodes = (KdNode*)(base + H.off_nodes);
+  // the trees of the clouds are independent: built by one host thread each (at most 16 at a time; small batches of small clouds stay on the
+  // caller's thread), flattened in cloud order afterwards
+  std::vector<int64_t> start((size_t)batch + 1, 0);
+  for (int b = 0; b < batch; b++) {
+    SE3_REQUIRE(s_lengths_host[b] >= 0 && start[(size_t)b] + s_lengths_host[b] <= ns, SE3_ERR_INVALID_ARG, "kdtree_build_host: lengths exceed the point count");
+    start[(size_t)b + 1] = start[(size_t)b] + s_lengths_host[b];
+  }
+  std::vector<std::unique_ptr<se3_kd::KdTree>> trees((size_t)batch);
+  auto build_one = [&](int b) {
+    const int64_t n = s_lengths_host[b];
+    if (n > 0) trees[(size_t)b].reset(new se3_kd::KdTree(s_points_host + 3 * start[(size_t)b], n));
+  };
+  if (batch > 1 && ns >= 4096) {
+    for (int b0 = 0; b0 < batch; b0 += 16) {
+      std::vector<std::thread> pool;
+      for (int b = b0; b < batch && b < b0 + 16; b++) pool.emplace_back(build_one, b);
+      for (auto& t : pool) t.join();
+    }
+  } else {
+    for (int b = 0; b < batch; b++) build_one(b);
+  }
   int64_t s0 = 0, n0 = 0;
   for (int b = 0; b < batch; b++) {
     const int64_t n = s_lengths_host[b];
-    SE3_REQUIRE(n >= 0 && s0 + n <= ns, SE3_ERR_INVALID_ARG, "kdtree_build_host: lengths exceed the point count");
     KdCloud c{};
     c.node_base = (int32_t)n0;
     c.perm_base = (int32_t)s0;
     c.n_points = (int32_t)n;
     if (n > 0) {
-      const se3_kd::KdTree tree(s_points_host + 3 * s0, n);
+      const se3_kd::KdTree& tree = *trees[(size_t)b];
       const auto& tn = tree.nodes();
       const auto& tp = tree.perm();
       c.n_nodes = (int32_t)tn.size();
