@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 # '#' lines: the collecting commit and the algorithmic bytes of the two calls).  Counters cannot be read inside this process, so the ratio
 # of that run is applied to the calls of this run.  gfx950 correction (/opt/skills/guides/MI355X_MICROARCH.md, HBM): FETCH_SIZE x2 for the
 # 16-B/lane streaming reads of rpe_bias_kernel and the operand split (x6_split_kernel; attn_split_kv_kernel in files of earlier commits); the attention kernel's counters as reported.
-PMC_TRAFFIC_FILES = ('profiles/r05_pmc_attention_raw.txt', 'profiles/r04_pmc_attention_raw.txt')
+PMC_TRAFFIC_FILES = ('profiles/r06_pmc_attention_raw.txt', 'profiles/r05_pmc_attention_raw.txt', 'profiles/r04_pmc_attention_raw.txt')
 PMC_ALGORITHMIC_MB_R04 = {'eq': 2549.0, 'inv': 2222.9}      # (the round-4 file carries no '# algorithmic' lines: tools/pmc_attention.py at its shape)
 
 
@@ -82,9 +82,9 @@ def load_pmc_traffic():
 
 def load_pmc_step():
     """HBM-side bytes of ONE 8-pair bench step by kernel family from the committed whole-step PMC passes (tools/pmc_step.sh ->
-    profiles/r05_pmc_step.txt) -> (total bytes, {family: bytes}, source) or (None, None, reason)."""
+    profiles/r06_pmc_step.txt) -> (total bytes, {family: bytes}, source) or (None, None, reason)."""
     import hashlib
-    rel = 'profiles/r05_pmc_step.txt'
+    rel = 'profiles/r06_pmc_step.txt' if os.path.exists(os.path.join(ROOT, 'profiles/r06_pmc_step.txt')) else 'profiles/r05_pmc_step.txt'
     path = os.path.join(ROOT, rel)
     if not os.path.exists(path):
         return None, None, rel + ' missing'

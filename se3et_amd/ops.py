@@ -351,7 +351,7 @@ def radius_neighbors(q_points, s_points, q_lengths, s_lengths, radius, limit, gr
 
 # The reference's order of exactly tied distances (csrc/radius_ties.hip).  On by default: clouds without exact ties
 # (every jittered synthetic configuration) pay one ballot per row in the search kernels and nothing else.
-RADIUS_REFERENCE_TIES = True
+RADIUS_REFERENCE_TIES = os.environ.get('SE3_RADIUS_REFERENCE_TIES', '1') != '0'       # (0: the kernels' index order; A/B runs)
 
 
 class ReferenceTree:

@@ -49,7 +49,7 @@ def test_bench_at_the_drivers_step_counts():
     assert line['host_cpu_s_per_step'] > 0
     # round 5: whole-step HBM figure from the committed counter passes, the dense + GroupNorm family's own roofline, traffic parsed at run time
     rs, rd = line['roofline_step'], line['roofline_dense']
-    assert rs['bytes_per_step'] > 20e9 and 0.05 < rs['frac'] < 1.0 and 'profiles/r05_pmc_step.txt' in rs['source']
+    assert rs['bytes_per_step'] > 20e9 and 0.05 < rs['frac'] < 1.0 and 'profiles/r06_pmc_step.txt' in rs['source']
     assert abs(rs['achieved'] - rs['bytes_per_step'] / (line['ms_per_step'] * 1e-3) / 1e9) <= 0.01 * rs['achieved']
     assert rd['bound'] == 'hbm' and rd['launches'] >= 20 * 30 and 0.0 < rd['frac'] < 1.0
     assert 'profiles/r0' in line['roofline']['traffic_source'] and 'sha256' in line['roofline']['traffic_source']

@@ -14,10 +14,10 @@ tools/prof.sh ${tag} bench.py --no-cpu-baseline --single-pair-steps 0 --train-st
 # one batch in flight, pyramid and model back to back: every kernel alone on the GPU (the per-step categories and the kernels' own durations)
 tools/prof.sh ${tag}seq bench.py --inflight 1 --prefetch 0 --no-cpu-baseline --single-pair-steps 0 --train-steps 0 --roofline-quiet-steps 0 >> $O/prof.txt 2>&1; cp gpurun_out/${tag}seq_kernel_stats.csv $O/${tag}_kernel_stats_sequential.csv
 tools/prof.sh ${tag}b1 bench.py --batch 1 --no-cpu-baseline --single-pair-steps 0 --train-steps 0 >> $O/prof.txt 2>&1; cp gpurun_out/${tag}b1_kernel_stats.csv $O/${tag}_kernel_stats_batch1.csv
-python tools/step_breakdown.py $O/${tag}_kernel_stats_sequential.csv 69 > $O/${tag}_step_breakdown.txt 2>&1      # 60 steps + 9 warm-up
+python tools/step_breakdown.py $O/${tag}_kernel_stats_sequential.csv 189 > $O/${tag}_step_breakdown.txt 2>&1      # 9 warm-up + 3 regions of 60 steps (16 pairs each since round 6)
 # BASELINE.json configs[2] (SE3ET-I KITTI configuration, 20k+20k pairs): every kernel alone, per-step categories (10 steps + 3 warm-up)
 tools/prof.sh ${tag}c3 bench.py --variant se3eti_kitti --pair c3_20k --batch 4 --steps 10 --warmup 3 --inflight 1 --prefetch 0 --no-cpu-baseline --single-pair-steps 0 --train-steps 0 --roofline-quiet-steps 0 >> $O/prof.txt 2>&1; cp gpurun_out/${tag}c3_kernel_stats.csv $O/${tag}_kernel_stats_c3.csv
-python tools/step_breakdown.py $O/${tag}_kernel_stats_c3.csv 13 > $O/${tag}_step_breakdown_c3.txt 2>&1
+python tools/step_breakdown.py $O/${tag}_kernel_stats_c3.csv 33 > $O/${tag}_step_breakdown_c3.txt 2>&1      # 3 warm-up + 3 regions of 10 steps
 # the training step, kernel by kernel (5 steps + 2 warm-up)
 tools/prof.sh ${tag}train tools/train_bench.py --steps 5 --warmup 2 >> $O/prof.txt 2>&1; cp gpurun_out/${tag}train_kernel_stats.csv $O/${tag}_kernel_stats_train.csv
 # how busy the GPU is with three batches in flight
