@@ -118,3 +118,20 @@ def test_pyramid_of_lattice_clouds_equals_the_host_collate():
             r *= 2
         for i in range(4):
             offs[i].append(offs[i][-1] + P[i].shape[0])
+
+
+@pytest.mark.parametrize('n1,n2,step,radius,limit', [(6000, 5000, 0.001, 0.0625, 38), (2500, 2000, 0.01, 0.125, 36)])
+def test_radius_search_equals_the_reference_binary(n1, n2, step, radius, limit):
+    """The same against the reference's OWN compiled extension where it travelled with the tree (oracle/_ref/libref_ext.so: the reference's
+    radius_neighbors_cpu.cpp + nanoflann built by oracle/ref_ext/Makefile in the build container; git-ignored, not gpurun-ignored): the device
+    search + tie pass against nanoflann itself, ties included."""
+    import os
+    from oracle import ref_shims
+    if not os.path.exists(ref_shims.REF_EXT_SO):
+        pytest.skip('oracle/_ref/libref_ext.so did not travel with this tree')
+    from se3et_amd.modules.ops import radius_search
+    ext = ref_shims._RefExt(ref_shims.REF_EXT_SO)
+    s, sl = _clouds(n1, n2, step, seed=40)
+    want = ext.radius_neighbors(s, s, sl, sl, radius)[:, :limit]
+    got = radius_search(s.cuda(), s.cuda(), sl, sl, radius, limit)
+    assert torch.equal(got.cpu(), want)
