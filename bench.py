@@ -478,7 +478,7 @@ def main():
     # dispatch's own begin / end timestamps (hipExtLaunchKernelGGL).  The event pairs of the two additional families (`roofline_kpconv`,
     # `roofline_dense`: ~50 torch event pairs per step from Python) move to the FIRST REPEAT of the region, the same K steps between the same
     # bracket: in the headline region they cost ~2 % of the rate (region 1 against regions 2 and 3, profiles/r06_batch_inflight_sweep.txt).
-    se3_ops.KERNEL_TIMINGS = None
+    se3_ops.KERNEL_TIMINGS = {} if os.environ.get('SE3_BENCH_PY_EVENTS') == '1' else None      # (A/B switch: round 5 recorded the families' event pairs here)
     se3_lib.lib().se3_debug_kernel_timing(1)        # every RPE attention launch gets its own HIP event pair
     t0 = time.perf_counter()
     run_all(list(range(args.warmup, total_steps)))

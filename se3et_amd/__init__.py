@@ -35,7 +35,9 @@ def request_blocking_sync(device_index=None):
     else:
         try:
             hip = _ctypes.CDLL('libamdhip64.so')
-            rc = hip.hipSetDevice(_ctypes.c_int(device_index))
+            # device 0 is the process's current device before any HIP call: the flag call alone, as the very first call (round 5's form;
+            # with hipSetDevice(0) in front of it the waits of a bench rank kept 1.4-1.8 cores busy instead of 0.8)
+            rc = hip.hipSetDevice(_ctypes.c_int(device_index)) if device_index != 0 else 0
             if rc == 0:
                 rc = hip.hipSetDeviceFlags(_ctypes.c_uint(4))          # hipDeviceScheduleBlockingSync
             status = 'set' if rc == 0 else 'refused (hipError %d)' % rc
@@ -46,12 +48,13 @@ def request_blocking_sync(device_index=None):
 
 
 def _torch_runtime_is_live():
+    """Has torch initialised CUDA / HIP in this process?  Read from torch.cuda's own Python flag WITHOUT calling into torch:
+    torch.cuda.is_initialized() goes through torch._C (_cuda_isInBadFork), and a request made behind it was only half effective (a bench
+    rank kept 1.7 cores busy instead of 0.8: round 6, same-box A/B against the round-5 tree)."""
     import sys
     torch = sys.modules.get('torch')
-    try:
-        return bool(torch is not None and torch.cuda.is_initialized())
-    except Exception:
-        return False
+    cuda = getattr(torch, 'cuda', None) if torch is not None else None
+    return bool(getattr(cuda, '_initialized', False))
 
 
 def blocking_sync_status(device_index):
