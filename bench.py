@@ -148,6 +148,20 @@ def rank_cpu_set(local_rank, local_world, available=None):
     return set(cores[local_rank * per:(local_rank + 1) * per])
 
 
+def thread_cpu_times():
+    """{tid: (name, user + system CPU seconds)} of every thread of this process (Linux /proc)."""
+    out, tick = {}, os.sysconf('SC_CLK_TCK')
+    for tid in os.listdir('/proc/self/task'):
+        try:
+            stat = open('/proc/self/task/%s/stat' % tid).read()
+            name = stat[stat.index('(') + 1:stat.rindex(')')]
+            f = stat[stat.rindex(')') + 2:].split()
+            out[int(tid)] = (name, (int(f[11]) + int(f[12])) / tick)
+        except (OSError, ValueError):
+            pass
+    return out
+
+
 def inflight_for_cores(cores_per_rank, requested=None, batch=8, blocking_waits=False):
     """Batches in flight per rank that `cores_per_rank` host cores carry.  With SPINNING waits (the runtime's default) every in-flight thread
     is a busy core while it waits for the GPU: one core per thread plus one for the process.  With BLOCKING waits (se3et_amd asks for them at
@@ -473,6 +487,7 @@ def main():
     run_all(list(range(args.warmup)))
     torch.cuda.synchronize()
     sharding.barrier(dev)
+    thread_cpu0 = thread_cpu_times() if os.environ.get('SE3_BENCH_THREAD_CPU') == '1' else None
     cpu0 = time.process_time()
     # The headline region carries the event pairs of the ROOFLINE kernel only -- the RPE self-attention launches, taken on the C side with the
     # dispatch's own begin / end timestamps (hipExtLaunchKernelGGL).  The event pairs of the two additional families (`roofline_kpconv`,
@@ -486,6 +501,18 @@ def main():
     sharding.barrier(dev)
     elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
     host_cpu_s = time.process_time() - cpu0           # CPU seconds of this rank's process (all host threads) over the timed region
+    if thread_cpu0 is not None:                       # which threads burned it (name from /proc/self/task/<tid>/comm)
+        now = thread_cpu_times()
+        used = sorted(((now[t][1] - thread_cpu0.get(t, (now[t][0], 0.0))[1], now[t][0], t) for t in now), reverse=True)
+        def ctx(t):
+            try:
+                st = open('/proc/self/task/%d/status' % t).read()
+                return ' '.join(l.split(':')[1].strip() for l in st.splitlines() if 'ctxt_switches' in l)
+            except OSError:
+                return '?'
+        print('thread CPU over the timed region (%.3f s of wall; pid %d, %d threads): ' % (elapsed, os.getpid(), len(now)) +
+              ', '.join('%s[%d] %.3f s (ctx switches vol/nonvol %s)' % (n, t, c, ctx(t)) for c, n, t in used[:6] if c > 0.001), file=sys.stderr, flush=True)
+        print('all threads: ' + ' '.join('%d:%s:%.2f' % (t, now[t][0], now[t][1]) for t in sorted(now)), file=sys.stderr, flush=True)
     # (grows with the number of timed steps -- 0.013 s per step at 20, 0.036 at 60 -- through the roofline's own per-launch HIP events, which stay
     #  alive until the run is over: DESIGN section 5)
     roofline = collect_roofline(se3_lib, {}, args)     # (waits for the recorded launches, releases their events, timing off)
