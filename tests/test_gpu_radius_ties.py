@@ -135,3 +135,42 @@ def test_radius_search_equals_the_reference_binary(n1, n2, step, radius, limit):
     want = ext.radius_neighbors(s, s, sl, sl, radius)[:, :limit]
     got = radius_search(s.cuda(), s.cuda(), sl, sl, radius, limit)
     assert torch.equal(got.cpu(), want)
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_random_degenerate_clouds_equal_the_host_twin(seed):
+    """Assorted awkward clouds -- duplicates of every point, all points on a line / in a plane / identical, one cloud empty or a single point,
+    queries far outside the support box, limits from 1 to 64 -- through the device search + tie pass against the host twin, every row."""
+    from se3et_amd import ext
+    from se3et_amd.modules.ops import radius_search
+    g = np.random.default_rng(100 + seed)
+    step = float(g.choice([0.001, 0.004, 0.01, 0.05]))
+    kind = seed % 5
+    n = [int(g.integers(1, 2500)), int(g.integers(0 if seed % 3 == 0 else 1, 1800))]
+    clouds = []
+    for k in n:
+        p = g.uniform(0, 1, (k, 3)) * np.array([0.5, 0.4, 0.3])
+        if kind == 1:
+            p[:, 1:] = 0.2                                   # a line
+        elif kind == 2:
+            p[:, 2] = 0.1                                    # a plane
+        elif kind == 3 and k:
+            p[:] = p[0]                                      # one point, k times
+        elif kind == 4:
+            p = np.repeat(p[:max(k // 2, 1)], 2, axis=0)[:k]  # every point twice
+        clouds.append((np.round(p / step) * step).astype(np.float32))
+    s = torch.from_numpy(np.concatenate(clouds, 0))
+    sl = torch.tensor([len(c) for c in clouds])
+    q, ql = s, sl
+    if seed % 2:                                             # odd seeds: other queries (every third point per cloud), some far outside the box
+        n0 = len(clouds[0])
+        parts = [s[:n0][::3], torch.cat([s[n0:][::3], s[n0:][:5] + 10.0])]
+        q, ql = torch.cat(parts).contiguous(), torch.tensor([len(parts[0]), len(parts[1])])
+    radius = float(g.choice([0.03, 0.0625, 0.15]))
+    limit = int(g.choice([1, 5, 36, 38, 64]))
+    if s.shape[0] == 0 or q.shape[0] == 0:
+        pytest.skip('empty stack')
+    want = ext.radius_neighbors(q, s, ql, sl, radius)[:, :limit]
+    got = radius_search(q.cuda(), s.cuda(), ql, sl, radius, limit)
+    assert got.shape == want.shape, (tuple(got.shape), tuple(want.shape))
+    assert torch.equal(got.cpu(), want), 'seed %d kind %d limit %d radius %g step %g sizes %s' % (seed, kind, limit, radius, step, n)
