@@ -112,6 +112,8 @@ def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, 
         if n_tie > 0:
             trees[s_stage] = _ops.radius_tie_order(jobs[j][1][0], q_pts, s_pts, q_len, s_len, r, t[0], n_tie, max(int(counts[j].max()), 1),
                                                    tree=trees.get(s_stage))
+    if trees:
+        _ops.tie_overflow_check()              # (one more small copy on the path that already copied the stage's points: a row left behind raises)
     num_pairs = counts.shape[1] // 2
     pair_counts = counts.view(counts.shape[0], num_pairs, 2).amax(2).tolist() if counts.shape[1] % 2 == 0 else None
     out = {'points': points_list, 'lengths': lengths_list, 'neighbors': [], 'subsampling': [], 'upsampling': []}

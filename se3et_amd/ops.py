@@ -388,7 +388,28 @@ def radius_tie_order(neighbors, q_points, s_points, q_lengths, s_lengths, radius
                                                nb, tree.tree.data_ptr(), float(radius), neighbors.shape[1], tie_rows.data_ptr(),
                                                int(num_tie_rows), int(max_hits), scratch.data_ptr(), nbytes, neighbors.data_ptr(), _stream()),
           'se3_radius_neighbors_tie_order')
+    # the last 256 bytes of the scratch hold the number of rows that did not fit (more matches than max_hits, a tree deeper than the walk's
+    # stack): they keep their index order -- callers read the word with their next synchronisation and fail loudly (tie_overflow_check)
+    if not hasattr(_tie_tls, 'words'):
+        _tie_tls.words = []
+    _tie_tls.words.append(scratch[nbytes - 256:nbytes - 252].view(torch.int32))
     return tree
+
+
+_tie_tls = threading.local()          # per host thread (= per stream): a thread only ever checks the passes it issued itself
+
+
+def tie_overflow_check():
+    """Raises if any row of the tie passes issued since the last check was left in index order (one small device -> host copy; a no-op when
+    no tie pass ran)."""
+    words = getattr(_tie_tls, 'words', None)
+    if not words:
+        return
+    _tie_tls.words = []
+    left = int(torch.cat(words).sum())
+    if left:
+        raise RuntimeError('radius search: %d row(s) with exactly tied distances could not be given the reference order (more matches than the '
+                           'search counted, or a k-d tree deeper than %d levels)' % (left, 48))
 
 
 def radius_search_reference_order(q_points, s_points, q_lengths, s_lengths, radius, limit):
@@ -401,6 +422,7 @@ def radius_search_reference_order(q_points, s_points, q_lengths, s_lengths, radi
     host = torch.cat((max_count.max().reshape(1), flags[:1])).tolist() if flags is not None else [int(max_count.max()), 0]
     if host[1] > 0:
         radius_tie_order(full, q_points, s_points, q_lengths, s_lengths, radius, flags[1:], host[1], max(host[0], 1))
+        tie_overflow_check()
     return full, host[0]
 
 

@@ -174,3 +174,21 @@ def test_random_degenerate_clouds_equal_the_host_twin(seed):
     got = radius_search(q.cuda(), s.cuda(), ql, sl, radius, limit)
     assert got.shape == want.shape, (tuple(got.shape), tuple(want.shape))
     assert torch.equal(got.cpu(), want), 'seed %d kind %d limit %d radius %g step %g sizes %s' % (seed, kind, limit, radius, step, n)
+
+
+def test_a_row_the_pass_cannot_order_raises():
+    """The pass is handed a strip shorter than a flagged row's matches (max_hits below the search's count): the rows it leaves behind are
+    counted on the device and the next check raises instead of keeping the index order silently."""
+    from se3et_amd import ops
+    s, sl = _clouds(3000, 2500, 0.001)
+    sc = s.cuda()
+    flags = torch.zeros(sc.shape[0] + 1, dtype=torch.int32, device='cuda')
+    full, mc = ops.radius_neighbors(sc, sc, sl, sl, 0.0625, 38, ties=(flags[1:], flags[:1]))
+    n_tie = int(flags[0])
+    assert n_tie > 0
+    ops.radius_tie_order(full, sc, sc, sl, sl, 0.0625, flags[1:], n_tie, 3)          # 3 << the ~40 matches of a row
+    with pytest.raises(RuntimeError, match='could not be given the reference order'):
+        ops.tie_overflow_check()
+    ops.tie_overflow_check()                                                            # (the words are consumed: a second check is a no-op)
+    ops.radius_tie_order(full, sc, sc, sl, sl, 0.0625, flags[1:], n_tie, int(mc.max()))
+    ops.tie_overflow_check()
