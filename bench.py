@@ -268,6 +268,12 @@ def main():
                     '`single_pair` (rank 0 at --gpus 1 only; 0 = skip)')
     ap.add_argument('--train-steps', type=int, default=5, help='training steps (fwd + bwd + Adam, one pair each) of the `train_step` object '
                     '(rank 0 at --gpus 1 only; 0 = skip)')
+    ap.add_argument('--schedule', default='roofline', choices=['roofline', 'throughput', 'exclusive', 'environment'],
+                    help="how the batches in flight may overlap (se3et_amd.batched.set_schedule): 'roofline' (default) keeps the two coarsest backbone "
+                         "stages from running beside another batch's transformer -- the RPE self-attention kernels then hold >= 0.40 of HBM IN the "
+                         "timed region (0.45-0.47) at 455-458 pairs/s; 'throughput' lets them overlap: 487-493 pairs/s at 0.35-0.37; 'exclusive': no "
+                         "backbone beside a transformer, 0.49-0.51 at 434-445.  The line reports the other of the first two in `other_schedule` "
+                         "(one more region of the same K steps).  'environment': whatever SE3_CHAIN / SE3_CHAIN_GROUPS / SE3_BACKBONE_SPLIT say")
     ap.add_argument('--repeat-regions', type=int, default=2, help='the timed region (the same K steps between the same barrier + synchronize '
                     'bracket) is run this many MORE times after the headline region; `dispersion` reports all values with their median, min '
                     'and max (VERDICT round 5 item 6: a 4 %% move must be resolvable against the run-to-run spread).  0: off')
@@ -350,7 +356,12 @@ def main():
         pairs.append((pts, torch.tensor([len(c) for c in clouds], dtype=torch.int64)))
     feats = torch.ones((pairs[0][0].shape[0], 1), dtype=torch.float32, device=dev)
     b = cfg.backbone
+    from se3et_amd import batched as se3_batched
     from se3et_amd.batched import forward_pairs
+    if any(k in os.environ for k in ('SE3_CHAIN', 'SE3_CHAIN_GROUPS', 'SE3_BACKBONE_SPLIT', 'SE3_CHAIN_SHARED')):
+        args.schedule = 'environment'
+    if args.schedule != 'environment':
+        se3_batched.set_schedule(args.schedule)
 
     def forward(data):
         data['features'] = feats
@@ -541,6 +552,27 @@ def main():
                           'is the same steps again, same bracket, with the event pairs of the KPConv and dense families instead (roofline_kpconv, '
                           'roofline_dense); the others carry no events'}
 
+    # The other schedule, same K steps, same bracket, the roofline kernel's event pairs: what the overlap of the batches in flight is worth
+    # to the rate and costs the roofline figure (profiles/r06_frac_vs_overlap.txt)
+    other_schedule = None
+    if args.schedule in ('roofline', 'throughput') and args.inflight > 1 and args.repeat_regions > 0:
+        other = 'throughput' if args.schedule == 'roofline' else 'roofline'
+        se3_batched.set_schedule(other)
+        run_all(list(range(min(args.warmup, 2))))                       # (the chains start empty)
+        torch.cuda.synchronize()
+        sharding.barrier(dev)
+        se3_lib.lib().se3_debug_kernel_timing(1)
+        t_o = time.perf_counter()
+        run_all(list(range(args.warmup, total_steps)))
+        torch.cuda.synchronize()
+        sharding.barrier(dev)
+        el_o = sharding.max_over_ranks(time.perf_counter() - t_o, dev)
+        rf_o = collect_roofline(se3_lib, {}, args)
+        other_schedule = {'schedule': other, 'value': round(world * args.steps * PB / el_o, 3), 'ms_per_step': round(el_o / args.steps * 1e3, 3),
+                          'roofline_frac': rf_o['frac'], 'roofline_avg_us': rf_o['avg_us'],
+                          'note': 'the same K steps between the same bracket under the other schedule of se3et_amd.batched.set_schedule'}
+        se3_batched.set_schedule(args.schedule)
+
     roofline_kpconv = collect_kpconv_roofline(timings)
     roofline_dense = collect_dense_roofline(timings)
     for extra in (roofline_kpconv, roofline_dense):
@@ -572,6 +604,13 @@ def main():
         roofline['note'] = ('measured in the timed region, where %s share the GPU with the timed kernels (their durations include the '
                             'time slices of the other streams); `quiet` = the same kernels alone on the GPU'
                             % ('%d batches in flight' % args.inflight if args.inflight > 1 else "the next batch's pyramid kernels"))
+        if args.inflight > 1:
+            roofline['note'] += ("; schedule `%s` (se3et_amd.batched.set_schedule): %s" % (args.schedule, {
+                'roofline': "the two coarsest backbone stages of the other batches never run beside a transformer section, the rest of their work does; "
+                            "`other_schedule` = everything may overlap (the library's default): higher rate, the RPE kernels squeezed",
+                'throughput': 'every section of the other batches may run beside the timed kernels; `other_schedule` = the two coarsest backbone '
+                              'stages kept off the GPU during a transformer section',
+                'exclusive': 'no backbone section of the other batches beside a transformer section'}.get(args.schedule, 'as the environment says')))
 
     # the auxiliary measurements never take the headline line down with them: a failure is reported in their place (and on stderr)
     def guarded(what, f, *a):
@@ -616,10 +655,11 @@ def main():
                        'pairs_per_forward': PB, 'batches_in_flight_per_gpu': max(1, args.inflight), 'pyramid_prefetch': bool(args.prefetch),
                        'host_cores': host_cores, 'host_cores_per_rank': cores_here,
                        'host_waits': 'hipDeviceScheduleBlockingSync ' + host_waits + ' (device %d)' % local,
+                       'schedule': args.schedule,
                        'chained_sections': sorted(__import__('se3et_amd.batched', fromlist=['x']).CHAINED_SECTIONS),
                        'priority_sections': sorted(__import__('se3et_amd.batched', fromlist=['x']).PRIORITY_SECTIONS),
                        'attention_dtype': args.attention_dtype},
-            'roofline': roofline, 'roofline_kpconv': roofline_kpconv, 'roofline_dense': roofline_dense, 'roofline_step': roofline_step, 'dispersion': dispersion, 'cpu_baseline': cpu_baseline, 'single_pair': single_pair, 'train_step': train,
+            'roofline': roofline, 'roofline_kpconv': roofline_kpconv, 'roofline_dense': roofline_dense, 'roofline_step': roofline_step, 'dispersion': dispersion, 'other_schedule': other_schedule, 'cpu_baseline': cpu_baseline, 'single_pair': single_pair, 'train_step': train,
         }
         print(json.dumps(line), flush=True)
     if torch.distributed.is_initialized():

@@ -31,15 +31,51 @@ import threading as _threading
 # Sections of the forward that the batches in flight (one host thread + HIP stream each) run ONE AFTER THE OTHER on the GPU: a section waits
 # for the event behind the launches of the same section of the batch before it -- kernels of the same kind (the HBM-bound logits kernels,
 # the register-full KPConv / dense kernels) then do not time-slice against each other, while different sections of different batches still
-# overlap.  SE3_CHAIN = comma list of section names ('transformer', 'backbone', 'tail'), '' = none.
-CHAINED_SECTIONS = set(filter(None, _os.environ.get('SE3_CHAIN', 'transformer').split(',')))
+# overlap.  SE3_CHAIN = comma list of section names ('transformer', 'backbone'), '' = none.
+CHAINED_SECTIONS = set(filter(None, _os.environ.get('SE3_CHAIN', 'transformer,backbone').split(',')))      # (round 6: both, each on its own chain -- profiles/r06_frac_vs_overlap.txt)
 _chains = {}
 _chains_guard = _threading.Lock()
+SCHEDULE = 'environment'
+
+
+def set_schedule(name):
+    """How the sections of the batches in flight may overlap on the GPU (call between forwards, with every stream synchronised):
+      'throughput'  backbone sections follow one another, transformer sections follow one another, a backbone beside a transformer is fine
+                    (the library's default: 487-493 pairs/s at 16 pairs x 3 in flight, the RPE self-attention at 0.35-0.37 of HBM in that crowd)
+      'roofline'    additionally the two COARSEST backbone stages (their wide dense / KPConv kernels) never run beside another batch's
+                    transformer: the RPE kernels keep >= 0.40 of HBM while the other batches run (0.45-0.47; with the coarsest stage alone
+                    0.41-0.44), at 455-458 pairs/s (round 6, profiles/r06_frac_vs_overlap.txt; bench.py's default)
+      'exclusive'   no backbone stage beside a transformer: 0.49-0.51 (the kernels' own rate), 434-445 pairs/s"""
+    global SCHEDULE, BACKBONE_SPLIT_STAGE, SHARED_CHAIN
+    table = {'throughput': (None, {'transformer', 'backbone'}, {}),
+             'roofline': (2, {'transformer', 'backbone', 'backbone_fine'}, {'transformer': 'transformer+backbone', 'backbone': 'transformer+backbone'}),
+             'exclusive': (None, {'transformer', 'backbone'}, {'transformer': 'transformer+backbone', 'backbone': 'transformer+backbone'})}
+    if name not in table:
+        raise ValueError('schedule %r (one of %s)' % (name, sorted(table)))
+    split, sections, groups = table[name]
+    with _chains_guard:
+        BACKBONE_SPLIT_STAGE, SHARED_CHAIN = split, False
+        CHAINED_SECTIONS.clear()
+        CHAINED_SECTIONS.update(sections)
+        _CHAIN_OF.clear()
+        _CHAIN_OF.update(groups)
+        _chains.clear()
+        SCHEDULE = name
 # SE3_CHAIN_PRIORITY = comma list of chained sections that run on ONE shared high-priority stream (round 5): the section's kernels -- the
 # transformer's HBM-bound RPE calls -- are dispatched ahead of the other batches' backbone / matching kernels instead of time-slicing with
 # them; the caller's stream waits for the section and goes on.  Tensors the section returns are allocated on that stream: the caller marks
 # them as used on its own (`adopt`).
 PRIORITY_SECTIONS = set(filter(None, _os.environ.get('SE3_CHAIN_PRIORITY', '').split(',')))
+# SE3_CHAIN_SHARED=1: ONE chain for all chained sections (a batch's backbone and another batch's transformer then never overlap either);
+# SE3_CHAIN_GROUPS='transformer+backbone,tail': sections joined by '+' share a chain (round 6: the in-region roofline of the RPE kernels
+# against the overlap that carries the throughput, DESIGN section 5)
+SHARED_CHAIN = _os.environ.get('SE3_CHAIN_SHARED', '0') == '1'
+BACKBONE_SPLIT_STAGE = int(_os.environ['SE3_BACKBONE_SPLIT']) if _os.environ.get('SE3_BACKBONE_SPLIT') else None
+_CHAIN_OF = {}
+for _grp in filter(None, _os.environ.get('SE3_CHAIN_GROUPS', '').split(',')):
+    for _sec in _grp.split('+'):
+        _CHAIN_OF[_sec] = _grp
+        CHAINED_SECTIONS.add(_sec)
 _priority_streams = {}
 
 
@@ -62,7 +98,7 @@ def _chained(section):
         yield _Section(None, None)
         return
     with _chains_guard:
-        st = _chains.setdefault(section, [_threading.Lock(), None])
+        st = _chains.setdefault('*' if SHARED_CHAIN else _CHAIN_OF.get(section, section), [_threading.Lock(), None])
     with st[0]:
         cur = torch.cuda.current_stream()
         if section in PRIORITY_SECTIONS:
@@ -342,8 +378,31 @@ def forward_pairs(model, data_dict, with_registration=True):
     valid_event = torch.cuda.Event()
     valid_event.record()
 
-    with SF.norm_segments(seg), _chained('backbone'):
-        feats_list = model.backbone(data_dict['features'], data_dict)
+    if BACKBONE_SPLIT_STAGE is None:
+        with SF.norm_segments(seg), _chained('backbone'):
+            feats_list = model.backbone(data_dict['features'], data_dict)
+    else:
+        # SE3_BACKBONE_SPLIT=<stage>: the backbone as TWO kinds of chained sections -- 'backbone_fine' while it works on pyramid stages below
+        # <stage> (the long, HBM-heavy kernels), 'backbone' above -- switched where the backbone announces its stage (round 6 experiment:
+        # SE3_CHAIN_GROUPS=transformer+backbone_fine keeps only the fine stages off the GPU while another batch's transformer runs)
+        import contextlib
+        stack = contextlib.ExitStack()
+        state = {'name': None}
+
+        def switch(stage):
+            name = None if stage is None else ('backbone_fine' if stage < BACKBONE_SPLIT_STAGE else 'backbone')
+            if name != state['name']:
+                stack.close()
+                state['name'] = name
+                if name is not None:
+                    stack.enter_context(_chained(name))
+        with SF.norm_segments(seg):
+            SF.norm_segments._tls.stage_hook = switch
+            try:
+                feats_list = model.backbone(data_dict['features'], data_dict)
+            finally:
+                SF.norm_segments._tls.stage_hook = None
+                stack.close()
     feats_c, feats_f = feats_list[-1], feats_list[0]
 
     X, PA = transformer_pairs(model.transformer, points_c, len_c, feats_c, packed=True)

@@ -171,6 +171,9 @@ class norm_segments:
         also normalises its INPUT rows, which live at the finer stage `support`; a tensor belongs to the one of the two stages whose point
         count it has (grid subsampling only removes points per cloud: equal totals mean equal pair boundaries)."""
         norm_segments._tls.stage = None if i is None else ((i,) if support is None else (i, support))
+        hook = getattr(norm_segments._tls, 'stage_hook', None)
+        if hook is not None:
+            hook(i)
 
 
 def row_segments(x):

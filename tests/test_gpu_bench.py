@@ -58,6 +58,12 @@ def test_bench_at_the_drivers_step_counts():
     # under one core per thread
     assert line['config']['host_waits'].endswith('set (device 0)'), line['config']['host_waits']
     # round 6: the same K steps twice more between the same bracket; all three rates with their median / min / max
+    # round 6: the default schedule keeps the coarsest backbone stage off the GPU while another batch's transformer runs (the RPE kernels hold
+    # their share of HBM in the timed region); the other schedule -- everything overlaps -- is reported from one more region of the same steps
+    o = line['other_schedule']
+    assert line['config']['schedule'] == 'roofline' and o['schedule'] == 'throughput'
+    assert line['roofline']['frac'] > o['roofline_frac'] and line['roofline']['frac'] >= 0.38, (line['roofline']['frac'], o)
+    assert o['value'] > 0.95 * line['value']
     d = line['dispersion']
     assert d['regions'] == 3 and len(d['values']) == 3 and abs(d['values'][0] - line['value']) <= 0.01 * line['value']
     assert d['min'] <= d['median'] <= d['max'] and d['spread_rel'] < 0.5

@@ -28,11 +28,14 @@ def _batch(cfg, first_pair, pairs):
     return run
 
 
-@pytest.mark.parametrize('threads', [2, 3])
-def test_batches_in_flight_give_the_sequential_results(threads):
-    from se3et_amd import ops
+@pytest.mark.parametrize('threads,schedule', [(2, 'throughput'), (3, 'throughput'), (3, 'roofline'), (3, 'exclusive')])
+def test_batches_in_flight_give_the_sequential_results(threads, schedule):
+    """... under every schedule of se3et_amd.batched.set_schedule (round 6: 'roofline' switches the backbone between two chains where it
+    announces its pyramid stage, one of them shared with the transformer sections)."""
+    from se3et_amd import batched, ops
     from se3et_amd.batched import forward_pairs
     from se3et_amd.model import create_model, load_synthetic_weights, make_cfg
+    batched.set_schedule(schedule)
     cfg = make_cfg('se3ete')
     model = load_synthetic_weights(create_model(cfg)).cuda().eval()
     ops.clear_weight_caches()
@@ -67,6 +70,7 @@ def test_batches_in_flight_give_the_sequential_results(threads):
                 assert torch.equal(g['ref_node_corr_indices'], w['ref_node_corr_indices']), (t, p)
                 for key in ('ref_feats_c', 'src_feats_c', 'estimated_transform'):
                     assert float((g[key] - w[key]).abs().max()) <= 1e-5 * max(1.0, float(w[key].abs().max())), (t, p, key)
+    batched.set_schedule('throughput')
 
 
 def test_blocking_sync_is_the_first_gpu_call_or_nothing():
