@@ -512,6 +512,9 @@ def main():
     sharding.barrier(dev)
     elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
     host_cpu_s = time.process_time() - cpu0           # CPU seconds of this rank's process (all host threads) over the timed region
+    if getattr(se3_batched, '_LOCK_WAIT', None) is not None:
+        print('host time waiting for chain locks since the start (s): %s; timed region %.3f s of wall x %d threads' % (
+            {k: round(v, 3) for k, v in se3_batched._LOCK_WAIT.items()}, elapsed, max(1, args.inflight)), file=sys.stderr, flush=True)
     if thread_cpu0 is not None:                       # which threads burned it (name from /proc/self/task/<tid>/comm)
         now = thread_cpu_times()
         used = sorted(((now[t][1] - thread_cpu0.get(t, (now[t][0], 0.0))[1], now[t][0], t) for t in now), reverse=True)

@@ -70,6 +70,7 @@ PRIORITY_SECTIONS = set(filter(None, _os.environ.get('SE3_CHAIN_PRIORITY', '').s
 # SE3_CHAIN_GROUPS='transformer+backbone,tail': sections joined by '+' share a chain (round 6: the in-region roofline of the RPE kernels
 # against the overlap that carries the throughput)
 SHARED_CHAIN = _os.environ.get('SE3_CHAIN_SHARED', '0') == '1'
+_LOCK_WAIT = {} if _os.environ.get('SE3_CHAIN_LOCK_STATS') == '1' else None
 BACKBONE_SPLIT_STAGE = int(_os.environ['SE3_BACKBONE_SPLIT']) if _os.environ.get('SE3_BACKBONE_SPLIT') else None
 _CHAIN_OF = {}
 for _grp in filter(None, _os.environ.get('SE3_CHAIN_GROUPS', '').split(',')):
@@ -99,6 +100,14 @@ def _chained(section):
         return
     with _chains_guard:
         st = _chains.setdefault('*' if SHARED_CHAIN else _CHAIN_OF.get(section, section), [_threading.Lock(), None])
+    if _LOCK_WAIT is not None:                    # (SE3_CHAIN_LOCK_STATS=1: host time spent waiting for a chain's lock, per chain)
+        import time as _time
+        t0 = _time.perf_counter()
+        st[0].acquire()
+        with _chains_guard:
+            key = _CHAIN_OF.get(section, section)
+            _LOCK_WAIT[key] = _LOCK_WAIT.get(key, 0.0) + _time.perf_counter() - t0
+        st[0].release()
     with st[0]:
         cur = torch.cuda.current_stream()
         if section in PRIORITY_SECTIONS:
